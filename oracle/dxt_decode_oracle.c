@@ -1,0 +1,112 @@
+/*
+ * dxt_decode_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU DXT5-YCoCg and DXT1 block decoders, used (a) as the sanity gate for the
+ * "parity unpinned" DXT encoder oracle (decode what it produced, check PSNR against
+ * the source) and (b) as the oracle of the decompress-side kernels.
+ *
+ * DXT5-YCoCg follows the reference's CPU decoder cuda_dxt/dxt62tga.c:24-106
+ * (fp64; alpha = Y with 8-level interpolation, colour = (Co, Cg, scale) with palette
+ * thirds, scale = 1/(31.875*b + 1), R = Y+Co-Cg, G = Y+Cg, B = Y-Co-Cg,
+ * clamp(x*255 + 0.5)); output here is RGB order rather than the tool's BGR.
+ * DXT1 is standard S3TC 4-colour mode (c0 > c1 is guaranteed by the encoder,
+ * compress_dxt1_fp.glsl:116-123); colour expansion /31, /63 as dxt62tga.c:63-68.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#include "oracle.h"
+
+static uint8_t clamp8(double s)
+{
+        int is = (int) (s + 0.5);
+        return is > 255 ? 255 : (is < 0 ? 0 : is);
+}
+
+static double alpha_decode(double a0, double a1, int idx)
+{
+        if (a0 > a1) {
+                switch (idx) {
+                case 0: return a0;
+                case 1: return a1;
+                default: return ((8 - idx) * a0 + (idx - 1) * a1) / 7.0;
+                }
+        }
+        switch (idx) {
+        case 0: return a0;
+        case 1: return a1;
+        case 6: return 0.0;
+        case 7: return 1.0;
+        default: return ((6 - idx) * a0 + (idx - 1) * a1) / 5.0;
+        }
+}
+
+void oracle_dxt5ycocg_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
+{
+        for (int by = 0; by < h / 4; by++) {
+                for (int bx = 0; bx < w / 4; bx++) {
+                        uint64_t ac, cc;
+                        memcpy(&ac, src, 8);
+                        memcpy(&cc, src + 8, 8);
+                        src += 16;
+                        const double a0 = (ac & 0xFF) / 255.0, a1 = ((ac >> 8) & 0xFF) / 255.0;
+                        double r[4], g[4], b[4];
+                        b[0] = (cc & 0x1F) / 31.0;
+                        g[0] = ((cc >> 5) & 0x3F) / 63.0;
+                        r[0] = ((cc >> 11) & 0x1F) / 31.0;
+                        b[1] = ((cc >> 16) & 0x1F) / 31.0;
+                        g[1] = ((cc >> 21) & 0x3F) / 63.0;
+                        r[1] = ((cc >> 27) & 0x1F) / 31.0;
+                        b[2] = (2.0 * b[0] + b[1]) / 3.0; g[2] = (2.0 * g[0] + g[1]) / 3.0; r[2] = (2.0 * r[0] + r[1]) / 3.0;
+                        b[3] = (b[0] + 2.0 * b[1]) / 3.0; g[3] = (g[0] + 2.0 * g[1]) / 3.0; r[3] = (r[0] + 2.0 * r[1]) / 3.0;
+                        ac >>= 16;
+                        cc >>= 32;
+                        for (int y = 0; y < 4; y++) {
+                                for (int x = 0; x < 4; x++) {
+                                        const double a = alpha_decode(a0, a1, ac & 7);
+                                        const int ci = cc & 3;
+                                        ac >>= 3;
+                                        cc >>= 2;
+                                        const double scale = 1.0 / (31.875 * b[ci] + 1.0);
+                                        const double Co = (r[ci] - 5.01960814E-01) * scale;
+                                        const double Cg = (g[ci] - 5.01960814E-01) * scale;
+                                        uint8_t *o = dst + 3 * ((long) (4 * by + y) * w + 4 * bx + x);
+                                        o[0] = clamp8(((a + Co) - Cg) * 255.0);
+                                        o[1] = clamp8((a + Cg) * 255.0);
+                                        o[2] = clamp8(((a - Co) - Cg) * 255.0);
+                                }
+                        }
+                }
+        }
+}
+
+void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
+{
+        for (int by = 0; by < h / 4; by++) {
+                for (int bx = 0; bx < w / 4; bx++) {
+                        uint16_t c0, c1;
+                        uint32_t idx;
+                        memcpy(&c0, src, 2);
+                        memcpy(&c1, src + 2, 2);
+                        memcpy(&idx, src + 4, 4);
+                        src += 8;
+                        double p[4][3];
+                        p[0][0] = ((c0 >> 11) & 0x1F) / 31.0; p[0][1] = ((c0 >> 5) & 0x3F) / 63.0; p[0][2] = (c0 & 0x1F) / 31.0;
+                        p[1][0] = ((c1 >> 11) & 0x1F) / 31.0; p[1][1] = ((c1 >> 5) & 0x3F) / 63.0; p[1][2] = (c1 & 0x1F) / 31.0;
+                        for (int k = 0; k < 3; k++) {
+                                if (c0 > c1) {
+                                        p[2][k] = (2.0 * p[0][k] + p[1][k]) / 3.0;
+                                        p[3][k] = (p[0][k] + 2.0 * p[1][k]) / 3.0;
+                                } else { /* 3-colour + transparent-black mode */
+                                        p[2][k] = (p[0][k] + p[1][k]) / 2.0;
+                                        p[3][k] = 0.0;
+                                }
+                        }
+                        for (int i = 0; i < 16; i++) {
+                                const int ci = (idx >> (2 * i)) & 3;
+                                uint8_t *o = dst + 3 * ((long) (4 * by + i / 4) * w + 4 * bx + i % 4);
+                                for (int k = 0; k < 3; k++) o[k] = clamp8(p[ci][k] * 255.0);
+                        }
+                }
+        }
+}

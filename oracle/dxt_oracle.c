@@ -1,0 +1,528 @@
+/*
+ * dxt_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product path).
+ *
+ * Strict-IEEE-fp32 CPU restatement of UltraGrid's DXT1 and DXT5-YCoCg 4x4 block
+ * encoders.  The reference has no CPU encoder (dxt_compress/dxt_encoder.c is an
+ * OpenGL driver for GLSL fragment shaders; cuda_dxt/cuda_dxt.cu is CUDA), so this
+ * file is the normative restatement the HIP kernels are checked against.
+ *
+ * PARITY UNPINNED: the reference ships no golden vector / known-answer test for DXT
+ * output (test/misc_test.c:298 only round-trips the codec *name*).  The restatement
+ * is cross-checked by decoding its output with a restatement of the reference's CPU
+ * DXT5-YCoCg decoder (cuda_dxt/dxt62tga.c:24-106, see dxt_decode_oracle.c) and
+ * gating on PSNR, plus structural S3TC checks.  See DESIGN.md "Oracle".
+ *
+ * Normative choices:
+ *   - every source-level operation of the shader is ONE IEEE-754 binary32 operation,
+ *     rounded individually; no fused multiply-add (build: -ffp-contract=off);
+ *   - input normalisation is  byte * 0.00392156862745f  (cuda_dxt/cuda_dxt.cu:666-683),
+ *     the only form written out in the reference;
+ *   - round() is roundf(): half away from zero (cuda_dxt.cu:122-124, 284-285, 352);
+ *   - sub-expressions that cuda_dxt.cu evaluates in double because of un-suffixed
+ *     literals (cuda_dxt.cu:143-145,178,184,364-372) are fp32 here, as in the GLSL
+ *     (compress_dxt5ycocg_fp.glsl:29-31,82,88,266-274);
+ *   - DXT1 follows the GLSL shader (compress_dxt1_fp.glsl), which is what
+ *     dxt_encoder.c runs; the CUDA DXT1 (cuda_dxt.cu:512-617) is a different
+ *     algorithm and is not the oracle.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "oracle.h"
+
+typedef struct { float x, y, z; } v3;
+
+/* cuda_dxt.cu:666 / compress_*_fp.glsl unorm8 fetch (see header: D1) */
+static inline float unorm8(uint8_t p) { return (float) p * 0.00392156862745f; }
+
+static inline float clamp01(float v) { return fminf(1.0f, fmaxf(0.0f, v)); }
+
+/* compress_dxt5ycocg_fp.glsl:12-23 ; compress_dxt1_fp.glsl:12-23 ; cuda_dxt.cu:444-451 */
+static inline v3 yuv_to_rgb(v3 c)
+{
+        float Y = 1.1643f * (c.x - 0.0625f);
+        float U = c.y - 0.5f;
+        float V = c.z - 0.5f;
+        v3 o;
+        o.x = Y + 1.7926f * V;
+        float g = Y - 0.2132f * U;
+        o.y = g - 0.5328f * V;
+        o.z = Y + 2.1124f * U;
+        return o;
+}
+
+/* compress_dxt5ycocg_fp.glsl:25-34 ; cuda_dxt.cu:139-148 */
+#define YCOCG_OFFSET ((float) (128.0 / 255.0))
+static inline v3 rgb_to_ycocg(v3 c)
+{
+        const float offset = YCOCG_OFFSET;
+        v3 o;
+        float t;
+        t   = c.x + 2.0f * c.y;
+        t   = t + c.z;
+        o.x = t * 0.25f;
+        t   = 2.0f * c.x - 2.0f * c.z;
+        t   = t * 0.25f;
+        o.y = t + offset;
+        t   = -c.x + 2.0f * c.y;
+        t   = t - c.z;
+        t   = t * 0.25f;
+        o.z = t + offset;
+        return o;
+}
+
+/* compress_dxt5ycocg_fp.glsl:69-78 */
+static void find_minmax(const v3 b[16], v3 *mn, v3 *mx)
+{
+        *mn = b[0];
+        *mx = b[0];
+        for (int i = 1; i < 16; i++) {
+                mn->x = fminf(mn->x, b[i].x);
+                mn->y = fminf(mn->y, b[i].y);
+                mn->z = fminf(mn->z, b[i].z);
+                mx->x = fmaxf(mx->x, b[i].x);
+                mx->y = fmaxf(mx->y, b[i].y);
+                mx->z = fmaxf(mx->z, b[i].z);
+        }
+}
+
+/* lerp == GLSL mix(a,b,q) = a*(1-q) + b*q ; cuda_dxt.cu:126-128 */
+static inline float lerpf(float a, float b, float q)
+{
+        float w = 1.0f - q;
+        float p0 = a * w;
+        float p1 = b * q;
+        return p0 + p1;
+}
+
+/* 2-bit palette index from the four squared distances;
+ * compress_dxt5ycocg_fp.glsl:237-244 ; compress_dxt1_fp.glsl:148-155 */
+static inline uint32_t palette_index(float d0, float d1, float d2, float d3)
+{
+        uint32_t b0 = d0 > d3;
+        uint32_t b1 = d1 > d2;
+        uint32_t b2 = d0 > d2;
+        uint32_t b3 = d1 > d3;
+        uint32_t b4 = d2 > d3;
+        return (b0 & b4) | (((b1 & b2) | (b0 & b3)) << 1);
+}
+
+/* ------------------------------------------------------------------------- */
+/* DXT5-YCoCg ("DXT6"); compress_dxt5ycocg_fp.glsl:326-377, cuda_dxt.cu:471-509 */
+/* ------------------------------------------------------------------------- */
+void oracle_dxt5ycocg_encode_block(const float rgb[16][3], uint32_t out[4])
+{
+        const float offset = YCOCG_OFFSET;
+        v3 blk[16];
+        for (int i = 0; i < 16; i++) {
+                v3 c = { rgb[i][0], rgb[i][1], rgb[i][2] };
+                blk[i] = rgb_to_ycocg(c);
+        }
+
+        v3 mn, mx;
+        find_minmax(blk, &mn, &mx);
+
+        /* SelectYCoCgDiagonal, glsl:169-183 */
+        {
+                float midx = (mx.y + mn.y) * 0.5f;
+                float midy = (mx.z + mn.z) * 0.5f;
+                float cov = 0.0f;
+                for (int i = 0; i < 16; i++) {
+                        float tx = blk[i].y - midx;
+                        float ty = blk[i].z - midy;
+                        float p = tx * ty;
+                        cov = cov + p;
+                }
+                if (cov < 0.0f) {
+                        float t = mx.z;
+                        mx.z = mn.z;
+                        mn.z = t;
+                }
+        }
+
+        /* ScaleYCoCg, glsl:150-167 */
+        uint32_t scale = 1;
+        {
+                float m0x = fabsf(mn.y - offset), m0y = fabsf(mn.z - offset);
+                float m1x = fabsf(mx.y - offset), m1y = fabsf(mx.z - offset);
+                float m = fmaxf(fmaxf(m0x, m0y), fmaxf(m1x, m1y));
+                const float s0 = (float) (64.0 / 255.0);
+                const float s1 = (float) (32.0 / 255.0);
+                if (m < s0) scale = 2;
+                if (m < s1) scale = 4;
+        }
+
+        /* EmitEndPointsYCoCgDXT5, glsl:185-215 (+ InsetCoCgBBox glsl:92-97) */
+        float mnc[2] = { mn.y, mn.z }, mxc[2] = { mx.y, mx.z };
+        uint32_t w_endpoints;
+        {
+                const float fs = (float) scale;
+                const float inset_c = (float) ((8.0 / 255.0) / 16.0);
+                const float q[2] = { 31.0f, 63.0f };
+                uint32_t imax[2], imin[2];
+                for (int k = 0; k < 2; k++) {
+                        float a = (mxc[k] - offset) * fs;
+                        a = a + offset;
+                        float b = (mnc[k] - offset) * fs;
+                        b = b + offset;
+                        float inset = (a - b) / 16.0f;
+                        inset = inset - inset_c;
+                        b = clamp01(b + inset);
+                        a = clamp01(a - inset);
+                        a = roundf(a * q[k]);
+                        b = roundf(b * q[k]);
+                        imax[k] = (uint32_t) a;
+                        imin[k] = (uint32_t) b;
+                }
+                uint32_t o0 = (imax[0] << 11) | (imax[1] << 5) | (scale - 1);
+                uint32_t o1 = (imin[0] << 11) | (imin[1] << 5) | (scale - 1);
+                w_endpoints = o0 | (o1 << 16);
+
+                imax[0] = (imax[0] << 3) | (imax[0] >> 2);
+                imax[1] = (imax[1] << 2) | (imax[1] >> 4);
+                imin[0] = (imin[0] << 3) | (imin[0] >> 2);
+                imin[1] = (imin[1] << 2) | (imin[1] >> 4);
+                const float inv255 = (float) (1.0 / 255.0);
+                for (int k = 0; k < 2; k++) {
+                        float a = (float) imax[k] * inv255;
+                        float b = (float) imin[k] * inv255;
+                        a = (a - offset) / fs;
+                        mxc[k] = a + offset;
+                        b = (b - offset) / fs;
+                        mnc[k] = b + offset;
+                }
+        }
+
+        /* EmitIndicesYCoCgDXT5, glsl:217-250 */
+        uint32_t w_cidx = 0;
+        {
+                const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
+                float c[4][2];
+                for (int k = 0; k < 2; k++) {
+                        c[0][k] = mxc[k];
+                        c[1][k] = mnc[k];
+                        c[2][k] = lerpf(c[0][k], c[1][k], q1);
+                        c[3][k] = lerpf(c[0][k], c[1][k], q2);
+                }
+                for (int i = 0; i < 16; i++) {
+                        float d[4];
+                        for (int k = 0; k < 4; k++) {
+                                float tx = blk[i].y - c[k][0];
+                                float ty = blk[i].z - c[k][1];
+                                float px = tx * tx;
+                                float py = ty * ty;
+                                d[k] = px + py;
+                        }
+                        w_cidx |= palette_index(d[0], d[1], d[2], d[3]) << (2 * i);
+                }
+        }
+
+        /* InsetYBBox, glsl:86-91 */
+        float mnY = mn.x, mxY = mx.x;
+        {
+                const float inset_c = (float) ((16.0 / 255.0) / 32.0);
+                float inset = (mxY - mnY) / 32.0f;
+                inset = inset - inset_c;
+                mnY = clamp01(mnY + inset);
+                mxY = clamp01(mxY - inset);
+        }
+
+        /* EmitAlphaEndPointsYCoCgDXT5, glsl:252-259 */
+        uint32_t w0 = ((uint32_t) roundf(mnY * 255.0f) << 8) | (uint32_t) roundf(mxY * 255.0f);
+        uint32_t w1 = 0;
+
+        /* EmitAlphaIndicesYCoCgDXT5, glsl:262-312 */
+        {
+                const float inv7 = (float) (1.0 / 7.0);
+                float mid = (mxY - mnY) / 14.0f;
+                float ab[8];
+                ab[1] = mnY + mid;
+                for (int k = 2; k <= 7; k++) {
+                        float a = (float) (8 - k) * mxY;
+                        float b = (float) (k - 1) * mnY;
+                        float s = a + b;
+                        s = s * inv7;
+                        ab[k] = s + mid;
+                }
+                uint32_t index = 1;
+                for (int i = 0; i < 16; i++) {
+                        float a = blk[i].x;
+                        index = 1;
+                        for (int k = 1; k <= 7; k++) {
+                                index += (a <= ab[k]) ? 1u : 0u;
+                        }
+                        index &= 7u;
+                        index ^= (2u > index) ? 1u : 0u;
+                        if (i < 6) {
+                                w0 |= index << (3 * i + 16); /* px5: top 2 bits fall off (uint32) */
+                                if (i == 5) {
+                                        w1 = index >> 1;
+                                }
+                        } else {
+                                w1 |= index << (3 * i - 16);
+                        }
+                }
+        }
+
+        out[0] = w0;
+        out[1] = w1;
+        out[2] = w_endpoints;
+        out[3] = w_cidx;
+}
+
+/* ------------------------------------------------------------------------- */
+/* DXT1 (normative = GLSL); compress_dxt1_fp.glsl:177-229                      */
+/* ------------------------------------------------------------------------- */
+void oracle_dxt1_encode_block(const float rgb[16][3], uint32_t out[2])
+{
+        v3 blk[16];
+        for (int i = 0; i < 16; i++) {
+                blk[i].x = rgb[i][0];
+                blk[i].y = rgb[i][1];
+                blk[i].z = rgb[i][2];
+        }
+        v3 mn, mx;
+        find_minmax(blk, &mn, &mx);
+
+        /* SelectDiagonal, glsl:69-90 */
+        {
+                float cx = (mn.x + mx.x) * 0.5f;
+                float cy = (mn.y + mx.y) * 0.5f;
+                float cz = (mn.z + mx.z) * 0.5f;
+                float cov_x = 0.0f, cov_y = 0.0f;
+                for (int i = 0; i < 16; i++) {
+                        float tx = blk[i].x - cx;
+                        float ty = blk[i].y - cy;
+                        float tz = blk[i].z - cz;
+                        float p = tx * tz;
+                        cov_x = cov_x + p;
+                        p = ty * tz;
+                        cov_y = cov_y + p;
+                }
+                if (cov_x < 0.0f) { float t = mx.x; mx.x = mn.x; mn.x = t; }
+                if (cov_y < 0.0f) { float t = mx.y; mx.y = mn.y; mn.y = t; }
+        }
+
+        /* InsetBBox, glsl:92-97 */
+        float mnc[3] = { mn.x, mn.y, mn.z }, mxc[3] = { mx.x, mx.y, mx.z };
+        {
+                const float inset_c = (float) ((8.0 / 255.0) / 16.0);
+                for (int k = 0; k < 3; k++) {
+                        float inset = (mxc[k] - mnc[k]) / 16.0f;
+                        inset = inset - inset_c;
+                        mnc[k] = clamp01(mnc[k] + inset);
+                        mxc[k] = clamp01(mxc[k] - inset);
+                }
+        }
+
+        /* EmitEndPointsDXT1 + RoundAndExpand, glsl:99-126 */
+        uint32_t code_max, code_min;
+        {
+                const float q[3] = { 31.0f, 63.0f, 31.0f };
+                const float inv255 = (float) (1.0 / 255.0);
+                uint32_t cm[3], cn[3];
+                for (int k = 0; k < 3; k++) {
+                        cm[k] = (uint32_t) roundf(mxc[k] * q[k]);
+                        cn[k] = (uint32_t) roundf(mnc[k] * q[k]);
+                }
+                code_max = (cm[0] << 11) | (cm[1] << 5) | cm[2];
+                code_min = (cn[0] << 11) | (cn[1] << 5) | cn[2];
+                cm[0] = (cm[0] << 3) | (cm[0] >> 2);
+                cm[2] = (cm[2] << 3) | (cm[2] >> 2);
+                cm[1] = (cm[1] << 2) | (cm[1] >> 4);
+                cn[0] = (cn[0] << 3) | (cn[0] >> 2);
+                cn[2] = (cn[2] << 3) | (cn[2] >> 2);
+                cn[1] = (cn[1] << 2) | (cn[1] >> 4);
+                for (int k = 0; k < 3; k++) {
+                        mxc[k] = (float) cm[k] * inv255;
+                        mnc[k] = (float) cn[k] * inv255;
+                }
+        }
+        uint32_t w_endpoints;
+        if (code_max < code_min) {
+                for (int k = 0; k < 3; k++) {
+                        float t = mnc[k]; mnc[k] = mxc[k]; mxc[k] = t;
+                }
+                w_endpoints = code_min | (code_max << 16);
+        } else {
+                w_endpoints = code_max | (code_min << 16);
+        }
+
+        /* EmitIndicesDXT1, glsl:128-161 */
+        uint32_t w_idx = 0;
+        {
+                const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
+                float c[4][3];
+                for (int k = 0; k < 3; k++) {
+                        c[0][k] = mxc[k];
+                        c[1][k] = mnc[k];
+                        c[2][k] = lerpf(c[0][k], c[1][k], q1);
+                        c[3][k] = lerpf(c[0][k], c[1][k], q2);
+                }
+                for (int i = 0; i < 16; i++) {
+                        float d[4];
+                        for (int k = 0; k < 4; k++) {
+                                float tx = blk[i].x - c[k][0];
+                                float ty = blk[i].y - c[k][1];
+                                float tz = blk[i].z - c[k][2];
+                                /* dot(v,v) = v.x*v.x + v.y*v.y + v.z*v.z, left to right
+                                 * (cuda_dxt.cu:106-108) */
+                                float px = tx * tx;
+                                float py = ty * ty;
+                                float pz = tz * tz;
+                                float s = px + py;
+                                d[k] = s + pz;
+                        }
+                        w_idx |= palette_index(d[0], d[1], d[2], d[3]) << (2 * i);
+                }
+        }
+
+        /* pack, glsl:219-228: 4 x uint16 = c0, c1, idx_lo, idx_hi (little endian) */
+        out[0] = w_endpoints;
+        out[1] = w_idx;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Frame drivers                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* Source row for image row `y` (cuda_dxt.cu:652-655: negative height => the image is
+ * read bottom-up). */
+static inline const uint8_t *src_row(const uint8_t *src, long pitch, int y, int h, int mirror)
+{
+        int r = mirror ? h - 1 - y : y;
+        return src + (long) r * pitch;
+}
+
+typedef void (*fetch_px_t)(const uint8_t *row, int x, float out[3]);
+
+static void fetch_rgb(const uint8_t *row, int x, float out[3])
+{
+        out[0] = unorm8(row[3 * x + 0]);
+        out[1] = unorm8(row[3 * x + 1]);
+        out[2] = unorm8(row[3 * x + 2]);
+}
+/* RGBA: alpha ignored (dxt_encoder.c uploads RGBA, shader reads .rgb;
+ * compress_dxt1_fp.glsl:41) */
+static void fetch_rgba(const uint8_t *row, int x, float out[3])
+{
+        out[0] = unorm8(row[4 * x + 0]);
+        out[1] = unorm8(row[4 * x + 1]);
+        out[2] = unorm8(row[4 * x + 2]);
+}
+/* packed 4:4:4 YUV (output of cuda_yuv422_to_yuv444), converted to RGB;
+ * cuda_dxt.cu:686-691 */
+static void fetch_yuv444(const uint8_t *row, int x, float out[3])
+{
+        v3 c = { unorm8(row[3 * x + 0]), unorm8(row[3 * x + 1]), unorm8(row[3 * x + 2]) };
+        c = yuv_to_rgb(c);
+        out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+/* UYVY: chroma replicated to both pixels of a pair (yuv422_to_yuv444.glsl:22-30,
+ * cuda_dxt.cu:697-732), then YUV->RGB */
+static void fetch_uyvy(const uint8_t *row, int x, float out[3])
+{
+        const uint8_t *p = row + 4 * (x >> 1);
+        v3 c = { unorm8(p[1 + 2 * (x & 1)]), unorm8(p[0]), unorm8(p[2]) };
+        c = yuv_to_rgb(c);
+        out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+/* UYVY without colour conversion: the DXT1_YUV variant stores YCbCr in the RGB
+ * channels (dxt_encoder.c:318-323) */
+static void fetch_uyvy_raw(const uint8_t *row, int x, float out[3])
+{
+        const uint8_t *p = row + 4 * (x >> 1);
+        out[0] = unorm8(p[1 + 2 * (x & 1)]);
+        out[1] = unorm8(p[0]);
+        out[2] = unorm8(p[2]);
+}
+
+/* v210 sample extraction: 10-bit sample k (0..2) of little-endian word w */
+static inline unsigned v210_s(const uint8_t *row, int word, int k)
+{
+        uint32_t w;
+        memcpy(&w, row + 4 * word, 4);
+        return (w >> (10 * k)) & 0x3ffu;
+}
+/* v210 -> 8-bit Y,U,V by >>2 (vc_copylinev210, pixfmt_conv.c:86-130, which is the
+ * decoder cuda_dxt.cpp:162 selects for v210 input), then the UYVY path. */
+static void fetch_v210(const uint8_t *row, int x, float out[3])
+{
+        /* 6 px per 16 B: words [U0 Y0 V0][Y1 U2 Y2][V2 Y3 U4][Y4 V4 Y5] */
+        static const uint8_t ypos[6][2] = { {0,1}, {1,0}, {1,2}, {2,1}, {3,0}, {3,2} };
+        static const uint8_t upos[3][2] = { {0,0}, {1,1}, {2,2} };
+        static const uint8_t vpos[3][2] = { {0,2}, {2,0}, {3,1} };
+        const uint8_t *g = row + 16 * (x / 6);
+        int i = x % 6;
+        unsigned Y = v210_s(g, ypos[i][0], ypos[i][1]) >> 2;
+        unsigned U = v210_s(g, upos[i / 2][0], upos[i / 2][1]) >> 2;
+        unsigned V = v210_s(g, vpos[i / 2][0], vpos[i / 2][1]) >> 2;
+        v3 c = { unorm8((uint8_t) Y), unorm8((uint8_t) U), unorm8((uint8_t) V) };
+        c = yuv_to_rgb(c);
+        out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+static fetch_px_t fetch_for(int fmt)
+{
+        switch (fmt) {
+        case ORACLE_IN_RGB:      return fetch_rgb;
+        case ORACLE_IN_RGBA:     return fetch_rgba;
+        case ORACLE_IN_YUV444:   return fetch_yuv444;
+        case ORACLE_IN_UYVY:     return fetch_uyvy;
+        case ORACLE_IN_UYVY_RAW: return fetch_uyvy_raw;
+        case ORACLE_IN_V210:     return fetch_v210;
+        }
+        return 0;
+}
+
+/* Block raster order idx = bx + (w/4)*by (cuda_dxt.cu:633); pixel i = 4*row + col
+ * (compress_dxt5ycocg_fp.glsl:50-54). */
+int oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
+                      int w, int h, long pitch)
+{
+        int mirror = 0;
+        if (h < 0) { mirror = 1; h = -h; }
+        fetch_px_t fetch = fetch_for(in_fmt);
+        if (!fetch || (w & 3) || (h & 3) || w <= 0) {  /* cuda_dxt.cu:745 */
+                return -1;
+        }
+        const int bw = w / 4;
+        for (int by = 0; by < h / 4; by++) {
+                for (int bx = 0; bx < bw; bx++) {
+                        float rgb[16][3];
+                        for (int r = 0; r < 4; r++) {
+                                const uint8_t *row = src_row(src, pitch, 4 * by + r, h, mirror);
+                                for (int c = 0; c < 4; c++) {
+                                        fetch(row, 4 * bx + c, rgb[4 * r + c]);
+                                }
+                        }
+                        long idx = bx + (long) bw * by;
+                        if (out_fmt == ORACLE_OUT_DXT5YCOCG) {
+                                uint32_t o[4];
+                                oracle_dxt5ycocg_encode_block(rgb, o);
+                                memcpy(dst + 16 * idx, o, 16);
+                        } else if (out_fmt == ORACLE_OUT_DXT1) {
+                                uint32_t o[2];
+                                oracle_dxt1_encode_block(rgb, o);
+                                memcpy(dst + 8 * idx, o, 8);
+                        } else {
+                                return -1;
+                        }
+                }
+        }
+        return 0;
+}
+
+/* cuda_dxt.cu:697-732 / yuv422_to_yuv444.glsl:22-30 : UYVY -> packed Y,U,V triplets */
+void oracle_yuv422_to_yuv444(const uint8_t *src, uint8_t *dst, long pix_count)
+{
+        for (long i = 0; i < pix_count / 2; i++) {
+                const uint8_t *p = src + 4 * i;
+                uint8_t *o = dst + 6 * i;
+                o[0] = p[1]; o[1] = p[0]; o[2] = p[2];
+                o[3] = p[3]; o[4] = p[0]; o[5] = p[2];
+        }
+}

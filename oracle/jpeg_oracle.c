@@ -1,0 +1,164 @@
+/*
+ * jpeg_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product path).
+ *
+ * CPU specification of the JPEG 8x8 forward-DCT + quantisation stage.
+ *
+ * PARITY UNPINNED.  UltraGrid does not contain this code: `-c gpujpeg` / `-c jpeg`
+ * call the external library CESNET/GPUJPEG (configure.ac:2631-2675 requires
+ * `libgpujpeg >= 0.14.0`; ext-deps/bootstrap_gpujpeg.sh clones an unpinned HEAD; call
+ * sites src/video_compress/gpujpeg.cpp:279-353,617-631).  The library is neither
+ * vendored under /root/reference nor installed in this image, and the only reference
+ * test at that boundary (test/gpujpeg_test.cpp:68-106: flat 127 frame, |diff| <= 1 after
+ * a full encode/decode round trip) pins no coefficient.  This file therefore *defines*
+ * the stage from the published algorithms:
+ *
+ *   - samples are level-shifted by -128 (ITU-T T.81 A.3.1);
+ *   - 2-D DCT-II by the Arai-Agui-Nakajima (AAN) factorisation in fp32, rows then
+ *     columns, 5 multiplies + 29 adds per 1-D transform (Arai, Agui, Nakajima, Trans.
+ *     IEICE E-71(11), 1988; the same factorisation GPUJPEG and IJG's float DCT use),
+ *     every operation one IEEE binary32 operation, no FMA (-ffp-contract=off);
+ *   - the AAN output is scaled by 8*aan[u]*aan[v]; that factor is folded into the fp32
+ *     reciprocal quantiser  div[i] = (float)(1.0 / (q[i] * aan[row] * aan[col] * 8.0));
+ *   - quantised value = (int16) rintf(coef * div)   (round-half-to-even);
+ *   - quantiser tables: T.81 Annex K.1 (luma) / K.2 (chroma) scaled by the IJG quality
+ *     rule  s = q < 50 ? 5000/q : 200 - 2q ;  t = clamp((base*s + 50)/100, 1, 255);
+ *   - coefficients are emitted in zig-zag order (T.81 Figure A.6).
+ *
+ * Tolerance contract (tests/test_jpeg_*.py):
+ *   (a) HIP kernel vs this file: unquantised fp32 coefficients identical (0 ULP; the
+ *       north-star bound is 1 ULP) and quantised int16 output identical -- same op order,
+ *       no contraction on either side;
+ *   (b) this file vs an fp64 scipy.fft.dctn reference: |quantised - round(DCT64/q)| <= 1
+ *       on every coefficient and == 0 on > 99.99 % of them.
+ */
+#include <math.h>
+#include <stdint.h>
+
+#include "oracle.h"
+
+const uint8_t oracle_jpeg_zigzag[64] = {
+         0,  1,  8, 16,  9,  2,  3, 10,
+        17, 24, 32, 25, 18, 11,  4,  5,
+        12, 19, 26, 33, 40, 48, 41, 34,
+        27, 20, 13,  6,  7, 14, 21, 28,
+        35, 42, 49, 56, 57, 50, 43, 36,
+        29, 22, 15, 23, 30, 37, 44, 51,
+        58, 59, 52, 45, 38, 31, 39, 46,
+        53, 60, 61, 54, 47, 55, 62, 63,
+};
+
+/* T.81 Annex K, Tables K.1 and K.2, natural (row-major) order */
+static const uint8_t k1_luma[64] = {
+        16, 11, 10, 16,  24,  40,  51,  61,
+        12, 12, 14, 19,  26,  58,  60,  55,
+        14, 13, 16, 24,  40,  57,  69,  56,
+        14, 17, 22, 29,  51,  87,  80,  62,
+        18, 22, 37, 56,  68, 109, 103,  77,
+        24, 35, 55, 64,  81, 104, 113,  92,
+        49, 64, 78, 87, 103, 121, 120, 101,
+        72, 92, 95, 98, 112, 100, 103,  99,
+};
+static const uint8_t k2_chroma[64] = {
+        17, 18, 24, 47, 99, 99, 99, 99,
+        18, 21, 26, 66, 99, 99, 99, 99,
+        24, 26, 56, 99, 99, 99, 99, 99,
+        47, 66, 99, 99, 99, 99, 99, 99,
+        99, 99, 99, 99, 99, 99, 99, 99,
+        99, 99, 99, 99, 99, 99, 99, 99,
+        99, 99, 99, 99, 99, 99, 99, 99,
+        99, 99, 99, 99, 99, 99, 99, 99,
+};
+
+void oracle_jpeg_qtable(int quality, int comp, uint8_t table[64])
+{
+        if (quality < 1) quality = 1;
+        if (quality > 100) quality = 100;
+        const int s = quality < 50 ? 5000 / quality : 200 - quality * 2;
+        const uint8_t *base = comp == 0 ? k1_luma : k2_chroma;
+        for (int i = 0; i < 64; i++) {
+                int t = (base[i] * s + 50) / 100;
+                table[i] = t < 1 ? 1 : (t > 255 ? 255 : t);
+        }
+}
+
+/* AAN post-scale: aan[0] = 1, aan[k] = cos(k*pi/16) * sqrt(2) */
+static const double aan_scale[8] = {
+        1.0, 1.387039845, 1.306562965, 1.175875602,
+        1.0, 0.785694958, 0.541196100, 0.275899379,
+};
+
+void oracle_jpeg_divisors(const uint8_t q[64], float div[64])
+{
+        for (int r = 0; r < 8; r++) {
+                for (int c = 0; c < 8; c++) {
+                        div[8 * r + c] =
+                            (float) (1.0 / ((double) q[8 * r + c] * aan_scale[r] * aan_scale[c] * 8.0));
+                }
+        }
+}
+
+/* one 1-D AAN pass over 8 values with stride `st` (in place) */
+static void aan_1d(float *d, int st)
+{
+        const float c4 = 0.707106781f, c6 = 0.382683433f, c2mc6 = 0.541196100f, c2pc6 = 1.306562965f;
+        float t0 = d[0 * st] + d[7 * st], t7 = d[0 * st] - d[7 * st];
+        float t1 = d[1 * st] + d[6 * st], t6 = d[1 * st] - d[6 * st];
+        float t2 = d[2 * st] + d[5 * st], t5 = d[2 * st] - d[5 * st];
+        float t3 = d[3 * st] + d[4 * st], t4 = d[3 * st] - d[4 * st];
+        /* even part */
+        float t10 = t0 + t3, t13 = t0 - t3;
+        float t11 = t1 + t2, t12 = t1 - t2;
+        d[0 * st] = t10 + t11;
+        d[4 * st] = t10 - t11;
+        float z1 = t12 + t13;
+        z1 = z1 * c4;
+        d[2 * st] = t13 + z1;
+        d[6 * st] = t13 - z1;
+        /* odd part */
+        t10 = t4 + t5;
+        t11 = t5 + t6;
+        t12 = t6 + t7;
+        float z5 = t10 - t12;
+        z5 = z5 * c6;
+        float z2 = c2mc6 * t10;
+        z2 = z2 + z5;
+        float z4 = c2pc6 * t12;
+        z4 = z4 + z5;
+        float z3 = t11 * c4;
+        float z11 = t7 + z3, z13 = t7 - z3;
+        d[5 * st] = z13 + z2;
+        d[3 * st] = z13 - z2;
+        d[1 * st] = z11 + z4;
+        d[7 * st] = z11 - z4;
+}
+
+void oracle_jpeg_fdct_quant_plane(const uint8_t *plane, int ls, int width, int height,
+                                  int blocks_w, int blocks_h, const float div[64],
+                                  int16_t *out, float *coef_out)
+{
+        for (int by = 0; by < blocks_h; by++) {
+                for (int bx = 0; bx < blocks_w; bx++) {
+                        float blk[64];
+                        for (int r = 0; r < 8; r++) {
+                                int y = 8 * by + r;
+                                if (y > height - 1) y = height - 1;
+                                for (int c = 0; c < 8; c++) {
+                                        int x = 8 * bx + c;
+                                        if (x > width - 1) x = width - 1;
+                                        blk[8 * r + c] = (float) ((int) plane[(long) y * ls + x] - 128);
+                                }
+                        }
+                        for (int r = 0; r < 8; r++) aan_1d(blk + 8 * r, 1);
+                        for (int c = 0; c < 8; c++) aan_1d(blk + c, 8);
+                        long b = (long) by * blocks_w + bx;
+                        if (coef_out) {
+                                for (int i = 0; i < 64; i++) coef_out[64 * b + i] = blk[i];
+                        }
+                        for (int k = 0; k < 64; k++) {
+                                int i = oracle_jpeg_zigzag[k];
+                                float q = blk[i] * div[i];
+                                out[64 * b + k] = (int16_t) rintf(q);
+                        }
+                }
+        }
+}

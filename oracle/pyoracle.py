@@ -1,0 +1,281 @@
+"""ctypes front-end to the CPU oracles -- TEST INFRASTRUCTURE ONLY.
+
+Two libraries:
+  * ``oracle/liboracle_ug.so``  -- our plain-C restatements (oracle/*.c).
+  * ``oracle/_ref/libugref.so`` -- the reference's OWN pixfmt C compiled from
+    /root/reference by ``make -C oracle ref`` (present in the build container and, as a
+    prebuilt file, on the GPU box).  Used to pin the restatement and as the
+    ``cpu_baseline.kind == "reference"`` timing leg.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() import this module.
+The product package (ultragrid_amd) must never import it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_ug.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "libugref.so")
+# same sources built without -msse4.1 (portable scalar paths; see oracle/Makefile)
+_REF_SCALAR_PATH = os.path.join(_HERE, "_ref", "libugref_scalar.so")
+
+# our format ids (oracle.h)
+IN_RGB, IN_RGBA, IN_YUV444, IN_UYVY, IN_UYVY_RAW, IN_V210 = range(6)
+OUT_DXT1, OUT_DXT5YCOCG = 1, 6
+OPF = dict(RGBA=1, UYVY=2, YUYV=3, RGB=4, BGR=5, v210=6, RG48=7, I420=8)
+# reference codec_t values (src/types.h:62-112)
+REF_CODEC = dict(RGBA=1, UYVY=2, YUYV=3, v210=7, DXT1=9, DXT5=11, RGB=12, BGR=20, RG48=27, I420=29)
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(force: bool = False) -> None:
+    """Compile oracle/*.c (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE) if f.endswith((".c", ".h"))
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if os.path.isdir("/root/reference/src") and (force or not have_ref()):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+_lib = None
+_refs: dict = {}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_dxt_encode.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long]
+        _lib.oracle_dxt_encode.restype = C.c_int
+        _lib.oracle_yuv422_to_yuv444.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        _lib.oracle_yuv422_to_yuv444.restype = None
+        for n in ("oracle_dxt5ycocg_decode_rgb", "oracle_dxt1_decode_rgb"):
+            getattr(_lib, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            getattr(_lib, n).restype = None
+        _lib.oracle_linesize.argtypes = [C.c_int, C.c_int]
+        _lib.oracle_size.argtypes = [C.c_int, C.c_int]
+        _lib.oracle_convert_line.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 3
+        _lib.oracle_convert_frame.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_int] * 3
+        _lib.oracle_uyvy_to_i420.argtypes = [C.c_void_p, C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int]
+        _lib.oracle_uyvy_to_i420.restype = None
+        _lib.oracle_v210_to_p010le.argtypes = [C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_int, C.c_int]
+        _lib.oracle_v210_to_p010le.restype = None
+        _lib.oracle_color_coeffs.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+        _lib.oracle_jpeg_qtable.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        _lib.oracle_jpeg_qtable.restype = None
+        _lib.oracle_jpeg_divisors.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.oracle_jpeg_divisors.restype = None
+        _lib.oracle_jpeg_fdct_quant_plane.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3
+        _lib.oracle_jpeg_fdct_quant_plane.restype = None
+        _lib.oracle_dxt5ycocg_encode_block.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.oracle_dxt1_encode_block.argtypes = [C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def have_ref() -> bool:
+    return os.path.exists(_REF_PATH) and os.path.exists(_REF_SCALAR_PATH)
+
+
+class _ToPlanar(C.Structure):  # src/to_planar.h:53-59
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("out_data", C.c_void_p * 4),
+                ("out_linesize", C.c_uint * 4), ("in_data", C.c_void_p)]
+
+
+def ref(scalar: bool = False) -> C.CDLL:
+    """The compiled reference (raises if it was not built).  scalar=True: the build
+    without -msse4.1 (the reference's portable code paths)."""
+    path = _REF_SCALAR_PATH if scalar else _REF_PATH
+    _ref = _refs.get(path)
+    if _ref is None:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
+        _ref = _refs[path] = C.CDLL(path)
+        _ref.get_decoder_from_to.argtypes = [C.c_int, C.c_int]
+        _ref.get_decoder_from_to.restype = C.c_void_p
+        _ref.vc_get_linesize.argtypes = [C.c_uint, C.c_int]
+        _ref.vc_get_size.argtypes = [C.c_uint, C.c_int]
+        _ref.get_color_coeffs.argtypes = [C.c_int, C.c_int]
+        _ref.get_color_coeffs.restype = C.c_void_p
+        for n in ("uyvy_to_i420", "v210_to_p010le"):
+            getattr(_ref, n).argtypes = [_ToPlanar]
+            getattr(_ref, n).restype = None
+    return _ref
+
+
+_DECODER_T = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+MAX_PADDING = 64  # src/video_codec.h:61
+
+
+def _ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------------
+# DXT
+# ----------------------------------------------------------------------------------
+def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch: int | None = None) -> np.ndarray:
+    """h < 0 => bottom-up source (cuda_dxt.cu:652-655)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    if pitch is None:
+        pitch = {IN_RGB: 3 * w, IN_RGBA: 4 * w, IN_YUV444: 3 * w, IN_UYVY: 2 * w, IN_UYVY_RAW: 2 * w,
+                 IN_V210: (w + 47) // 48 * 128}[in_fmt]
+    n = w * abs(h) // (2 if out_fmt == OUT_DXT1 else 1)
+    out = np.zeros(n, dtype=np.uint8)
+    rc = lib().oracle_dxt_encode(in_fmt, out_fmt, _ptr(src), _ptr(out), w, h, pitch)
+    if rc:
+        raise ValueError(f"oracle_dxt_encode rc={rc}")
+    return out
+
+
+def yuv422_to_yuv444(src: np.ndarray, pix: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    out = np.zeros(pix * 3, np.uint8)
+    lib().oracle_yuv422_to_yuv444(_ptr(src), _ptr(out), pix)
+    return out
+
+
+def dxt_decode_rgb(out_fmt: int, blocks: np.ndarray, w: int, h: int) -> np.ndarray:
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).ravel()
+    out = np.zeros(w * h * 3, np.uint8)
+    fn = lib().oracle_dxt5ycocg_decode_rgb if out_fmt == OUT_DXT5YCOCG else lib().oracle_dxt1_decode_rgb
+    fn(_ptr(blocks), _ptr(out), w, h)
+    return out.reshape(h, w, 3)
+
+
+# ----------------------------------------------------------------------------------
+# pixfmt: restatement and compiled reference behind the same call shape
+# ----------------------------------------------------------------------------------
+def linesize(width: int, fmt: str) -> int:
+    return lib().oracle_linesize(width, OPF[fmt])
+
+
+def convert_frame(in_fmt: str, out_fmt: str, src: np.ndarray, w: int, h: int, shifts=(0, 8, 16)) -> np.ndarray:
+    """Restatement (oracle/pixfmt_oracle.c); line loop of testcard_common.c:121-129."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    sls, dls = linesize(w, in_fmt), linesize(w, out_fmt)
+    assert src.size >= sls * h
+    src = np.concatenate([src, np.zeros(MAX_PADDING, np.uint8)])
+    out = np.zeros(dls * h + MAX_PADDING, np.uint8)
+    rc = lib().oracle_convert_frame(OPF[in_fmt], OPF[out_fmt], _ptr(out), _ptr(src), w, h, *shifts)
+    if rc:
+        raise ValueError(f"no restated decoder {in_fmt}->{out_fmt}")
+    return out[: dls * h]
+
+
+def ref_convert_frame(in_fmt: str, out_fmt: str, src: np.ndarray, w: int, h: int, shifts=(0, 8, 16),
+                      scalar: bool = False) -> np.ndarray:
+    """The compiled reference: get_decoder_from_to() per line (pixfmt_conv.c:3110)."""
+    r = ref(scalar)
+    fn = r.get_decoder_from_to(REF_CODEC[in_fmt], REF_CODEC[out_fmt])
+    if not fn:
+        raise ValueError(f"reference has no decoder {in_fmt}->{out_fmt}")
+    dec = _DECODER_T(fn)
+    sls, dls = r.vc_get_linesize(w, REF_CODEC[in_fmt]), r.vc_get_linesize(w, REF_CODEC[out_fmt])
+    dsz = r.vc_get_size(w, REF_CODEC[out_fmt])
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    assert src.size >= sls * h
+    src = np.concatenate([src, np.zeros(MAX_PADDING, np.uint8)])
+    out = np.zeros(dls * h + MAX_PADDING, np.uint8)
+    sp, dp = src.ctypes.data, out.ctypes.data
+    for y in range(h):
+        dec(dp + y * dls, sp + y * sls, dsz, *shifts)
+    return out[: dls * h]
+
+
+def uyvy_to_i420(src: np.ndarray, w: int, h: int, use_ref: bool = False):
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    y = np.zeros((h, w), np.uint8)
+    u = np.zeros((ch, cw), np.uint8)
+    v = np.zeros((ch, cw), np.uint8)
+    if use_ref:
+        d = _ToPlanar()
+        d.width, d.height = w, h
+        d.out_data[0], d.out_data[1], d.out_data[2] = y.ctypes.data, u.ctypes.data, v.ctypes.data
+        d.out_linesize[0], d.out_linesize[1], d.out_linesize[2] = w, cw, cw
+        d.in_data = src.ctypes.data
+        ref().uyvy_to_i420(d)
+    else:
+        lib().oracle_uyvy_to_i420(_ptr(y), w, _ptr(u), cw, _ptr(v), cw, _ptr(src), w, h)
+    return y, u, v
+
+
+def v210_to_p010le(src: np.ndarray, w: int, h: int, use_ref: bool = False):
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    y = np.zeros((h, w), np.uint16)
+    uv = np.zeros((h // 2, w), np.uint16)
+    if use_ref:
+        d = _ToPlanar()
+        d.width, d.height = w, h
+        d.out_data[0], d.out_data[1] = y.ctypes.data, uv.ctypes.data
+        d.out_linesize[0], d.out_linesize[1] = 2 * w, 2 * w
+        d.in_data = src.ctypes.data
+        ref().v210_to_p010le(d)
+    else:
+        lib().oracle_v210_to_p010le(_ptr(y), 2 * w, _ptr(uv), 2 * w, _ptr(src), w, h)
+    return y, uv
+
+
+def color_coeffs(depth: int, bt601: bool = False) -> list[int]:
+    o = (C.c_int * 14)()
+    if lib().oracle_color_coeffs(int(bt601), depth, o):
+        raise ValueError("bad depth")
+    return list(o)
+
+
+class _RefCoeffs(C.Structure):  # src/color_space.h:135-148
+    _fields_ = [(n, C.c_short) for n in
+                "y_r y_g y_b cb_r cb_g cb_b cr_r cr_g cr_b y_scale r_cr g_cb g_cr".split()] + [("b_cb", C.c_int)]
+
+
+def ref_color_coeffs(depth: int) -> list[int]:
+    p = ref().get_color_coeffs(0, depth)  # CS_DFL
+    s = _RefCoeffs.from_address(p)
+    return [getattr(s, n) for n, _ in _RefCoeffs._fields_]
+
+
+# ----------------------------------------------------------------------------------
+# JPEG FDCT + quant
+# ----------------------------------------------------------------------------------
+def jpeg_qtable(quality: int, comp: int) -> np.ndarray:
+    t = np.zeros(64, np.uint8)
+    lib().oracle_jpeg_qtable(quality, comp, _ptr(t))
+    return t
+
+
+def jpeg_divisors(qtable: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(qtable, np.uint8)
+    d = np.zeros(64, np.float32)
+    lib().oracle_jpeg_divisors(_ptr(q), _ptr(d))
+    return d
+
+
+def jpeg_fdct_quant_plane(plane: np.ndarray, div: np.ndarray, blocks_w: int | None = None,
+                          blocks_h: int | None = None, want_coef: bool = False):
+    plane = np.ascontiguousarray(plane, np.uint8)
+    h, w = plane.shape
+    bw = blocks_w or (w + 7) // 8
+    bh = blocks_h or (h + 7) // 8
+    out = np.zeros((bh * bw, 64), np.int16)
+    coef = np.zeros((bh * bw, 64), np.float32) if want_coef else None
+    div = np.ascontiguousarray(div, np.float32)
+    lib().oracle_jpeg_fdct_quant_plane(_ptr(plane), w, w, h, bw, bh, _ptr(div), _ptr(out),
+                                       _ptr(coef) if want_coef else None)
+    return (out, coef) if want_coef else out
+
+
+ZIGZAG = np.array([
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34,
+    27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63], dtype=np.int64)
