@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpixels/s encode (UYVY -> DXT5-YCoCg, 4K) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path (fused UYVY unpack + YUV->RGB + RGB->YCoCg + DXT5 block
+encode, ug_hip_dxt_encode_batch) over one batch of `--frames` distinct synthetic 3840x2160 UYVY
+frames that are already resident in HBM (BASELINE.json configs[2]).  Frames are independent, so
+ranks shard them with no collective (weak scaling: every rank encodes its own batch).
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  roofline     -- algorithmic bytes (3.0 B/px: 2 read + 1 written) x pixels per
+                  launch / average launch duration measured with HIP events on the launch stream;
+  cpu_baseline -- the CPU oracle (oracle/dxt_oracle.c, "port": the reference has no CPU DXT encoder)
+                  timed on this box's host cores on a bounded sample (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+W, H = 3840, 2160
+ALG_BYTES_PER_PX = 3.0     # UYVY 2 B/px read + DXT5 1 B/px written
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_frames(n: int, rank: int) -> np.ndarray:
+    """n distinct legal-range video-noise frames (S2); 4 generated bases, the rest are row-rotations
+    by multiples of 4 lines (distinct bytes in memory, same statistics)."""
+    from ultragrid_amd import synth
+    bases = [synth.s2_video("UYVY", W, H, salt=100 * rank + i).reshape(H, 2 * W) for i in range(min(n, 4))]
+    out = np.empty((n, H, 2 * W), np.uint8)
+    for i in range(n):
+        out[i] = np.roll(bases[i % len(bases)], 4 * 37 * (i // len(bases)), axis=0)
+    return out.reshape(n, -1)
+
+
+def cpu_baseline(frame: np.ndarray, target_s: float = 12.0) -> dict:
+    """Oracle (C restatement) on all host cores, row-band split like the reference parallelises its CPU
+    conversions (src/utils/parallel_conv.c:64-85)."""
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    img = frame.reshape(H, 2 * W)
+    bands = [(H // 4 * i // cores * 4, H // 4 * (i + 1) // cores * 4) for i in range(cores)]
+
+    def run_band(lo, hi):
+        po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, img[lo:hi], W, hi - lo)
+
+    def one_frame():
+        ts = [threading.Thread(target=run_band, args=b) for b in bands if b[1] > b[0]]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+
+    t0 = time.perf_counter(); one_frame(); t1 = time.perf_counter() - t0   # warm + calibrate
+    n = max(3, min(200, int(target_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_frame()
+    dt = time.perf_counter() - t0
+    return {"value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x 3840x2160 UYVY->DXT5-YCoCg frames through oracle/dxt_oracle.c (gcc -O2, strict fp32), "
+                      f"{cores} threads by row bands, {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=16, help="distinct 4K frames per step (batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL: used ONLY for the timing barrier + max-over-ranks, not on the data path
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ultragrid_amd import codec, lib
+    lib.load()
+
+    F = args.frames
+    host = make_frames(F, rank)
+    src = torch.from_numpy(host).cuda()
+    frame_bytes = 2 * W * H
+    dst = torch.empty(F * W * H, dtype=torch.uint8, device="cuda")
+
+    def step():
+        codec.dxt_encode_batch(lib.PF_UYVY, lib.DXT5_YCOCG, src, W, H, F, frame_bytes, dst=dst)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                      # same stream the kernel is launched on (torch current stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration (back-to-back launches)
+
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    if rank == 0:
+        px_per_step = F * W * H * world
+        value = px_per_step * args.steps / wall / 1e6
+        achieved = ALG_BYTES_PER_PX * F * W * H / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes, see DESIGN.md
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"uyvy_dxt5_4k_x{F}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "3840x2160 UYVY->YCoCg->DXT5 fused encode (BASELINE.json configs[2])",
+                       "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": W * H,
+                       "input": "S2 legal-range video noise, resident in HBM", "fps_4k": round(value * 1e6 / (W * H), 1),
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "dxt_encode_kernel<UYVY,DXT5_YCOCG>", "ms_per_launch": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * F * W * H),
+                         "note": "VALU-bound kernel (SURVEY.md F9); see DESIGN.md for the VALU side-roofline"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host[0])
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

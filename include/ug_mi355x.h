@@ -1,0 +1,165 @@
+/*
+ * ug_mi355x.h -- C ABI of libug_mi355x.so, the MI355X (gfx950 / CDNA4) kernel library for
+ * UltraGrid's per-frame pixel-format-conversion + block-compression hot path.
+ *
+ * This header is the drop-in boundary.  It replaces, for this path,
+ *   - cuda_dxt/cuda_dxt.h:30-89      (cuda_{rgb,yuv}_to_dxt{1,6}, cuda_yuv422_to_yuv444)
+ *   - src/cuda_wrapper.h:50-76       (device select / alloc / memcpy / last-error shim)
+ *   - the per-line CPU decoder_t loop every compress module runs before upload
+ *     (src/pixfmt_conv.h:87-88, src/video_compress/cuda_dxt.cpp:206-220,
+ *      src/video_compress/dxt_glsl.cpp:277-289, src/video_compress/gpujpeg.cpp:592-608)
+ *   - the packed->planar whole-buffer converters src/to_planar.h:53-74
+ *   - the FDCT+quantise stage UltraGrid gets from libgpujpeg
+ *     (src/video_compress/gpujpeg.cpp:617-631)
+ *
+ * Conventions (same as cuda_dxt.h): plain C, no C++ types, no ownership transfer (the
+ * caller owns every buffer), every function returns 0 on success and a negative
+ * UG_HIP_E* code on failure and never throws; distinct streams may be driven from
+ * distinct threads concurrently.  Kernels are ASYNCHRONOUS on `stream` (unlike
+ * cuda_dxt.cu:759, which synchronises after every launch) -- call ug_hip_stream_sync()
+ * or order a D2H copy on the same stream.  `stream` == NULL is the device's null stream.
+ *
+ * Image geometry: `width`/`height` in pixels; a NEGATIVE height means the source image is
+ * read bottom-up (vertical mirror), exactly as cuda_dxt.h:38-39.  `src_pitch` is the
+ * source line stride in bytes; 0 selects the tightly packed UltraGrid line size
+ * (vc_get_linesize, src/video_codec.c:507-521).
+ */
+#ifndef UG_MI355X_H
+#define UG_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UG_HIP_ABI_VERSION 1
+
+/* error codes (cuda_dxt.cu:745-746,759 uses -1 bad size/alignment, -3 runtime failure) */
+#define UG_HIP_SUCCESS      0
+#define UG_HIP_EINVAL     (-1) /* bad size / alignment / NULL pointer */
+#define UG_HIP_EUNSUPP    (-2) /* no kernel for this format pair */
+#define UG_HIP_ERUNTIME   (-3) /* HIP runtime error: see ug_hip_last_error_string() */
+
+typedef void *ug_hip_stream_t; /* == hipStream_t; replaces cuda_wrapper_stream_t */
+
+/* Pixel formats (own numbering; UltraGrid codec_t values are mapped by the module shim,
+ * ultragrid_amd/module/ug_codec_map.h). */
+typedef enum {
+        UG_PF_NONE = 0,
+        UG_PF_RGBA = 1,     /* 8-bit R,G,B,A bytes (shifts configurable on output) */
+        UG_PF_UYVY = 2,     /* 8-bit 4:2:2  U Y0 V Y1 */
+        UG_PF_YUYV = 3,     /* 8-bit 4:2:2  Y0 U Y1 V */
+        UG_PF_RGB  = 4,     /* 8-bit R,G,B */
+        UG_PF_BGR  = 5,     /* 8-bit B,G,R */
+        UG_PF_V210 = 6,     /* 10-bit 4:2:2, 6 px / 16 B, lines padded to 128 B */
+        UG_PF_RG48 = 7,     /* 16-bit little-endian R,G,B */
+        UG_PF_YUV444 = 8,   /* packed 8-bit Y,U,V triplets (output of *_yuv422_to_yuv444) */
+        UG_PF_UYVY_RAW = 9, /* UYVY fed to the encoder WITHOUT colour conversion (DXT1_YUV) */
+} ug_pixfmt_t;
+
+typedef enum {
+        UG_DXT1       = 1, /* 8 B / 4x4 block, output size w*h/2 (dxt_util.h:59-67) */
+        UG_DXT5_YCOCG = 6, /* "DXT6": 16 B / block, output size w*h */
+} ug_dxt_t;
+
+/* ------------------------------------------------------------------------------------
+ * Runtime shim (replaces src/cuda_wrapper.h:50-76)
+ * ---------------------------------------------------------------------------------- */
+int         ug_hip_abi_version(void);
+int         ug_hip_device_count(int *count);
+int         ug_hip_set_device(int index);                              /* cuda_wrapper_set_device */
+int         ug_hip_malloc(void **buffer, size_t size);                 /* cuda_wrapper_malloc */
+int         ug_hip_free(void *buffer);                                 /* cuda_wrapper_free */
+int         ug_hip_malloc_host(void **buffer, size_t size);            /* cuda_wrapper_malloc_host (pinned) */
+int         ug_hip_free_host(void *buffer);                            /* cuda_wrapper_free_host */
+#define UG_HIP_MEMCPY_HOST_TO_DEVICE 0
+#define UG_HIP_MEMCPY_DEVICE_TO_HOST 1
+#define UG_HIP_MEMCPY_DEVICE_TO_DEVICE 2
+int         ug_hip_memcpy(void *dst, const void *src, size_t count, int kind);       /* cuda_wrapper_memcpy */
+int         ug_hip_memcpy_async(void *dst, const void *src, size_t count, int kind, ug_hip_stream_t stream);
+int         ug_hip_stream_create(ug_hip_stream_t *stream);
+int         ug_hip_stream_destroy(ug_hip_stream_t stream);
+int         ug_hip_stream_sync(ug_hip_stream_t stream);
+const char *ug_hip_last_error_string(void);                            /* cuda_wrapper_last_error_string */
+/* Average duration in milliseconds of `iters` back-to-back launches of the DXT encoder on
+ * `stream`, measured with hipEvents on that stream (cuda_dxt/rgb2dxt1.c:87-108 is the
+ * reference's equivalent harness).  Writes ms per launch to *ms_per_launch. */
+int         ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width,
+                                   int height, int src_pitch, int frames, size_t src_frame_stride,
+                                   size_t dst_frame_stride, int iters, ug_hip_stream_t stream,
+                                   float *ms_per_launch);
+
+/* ------------------------------------------------------------------------------------
+ * DXT encoders (replace cuda_dxt/cuda_dxt.h:30-89)
+ * ---------------------------------------------------------------------------------- */
+/* Fused pixel-format unpack + colour conversion + 4x4 block encode, one pass, no
+ * intermediate buffer.  `in` in {RGB, RGBA, UYVY, UYVY_RAW, V210, YUV444}.
+ * Requirements (cuda_dxt.cu:745): width % 4 == 0, |height| % 4 == 0 (V210 additionally
+ * width % 12 == 0 for the 3-block groups), src 16-B aligned, dst 16-B aligned, pitch % 4 == 0. */
+int ug_hip_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev, void *dst_dev,
+                      int width, int height, int src_pitch, ug_hip_stream_t stream);
+/* Same, `frames` images per launch (tiles of one frame or consecutive frames):
+ * image i at src + i*src_frame_stride -> dst + i*dst_frame_stride. */
+int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev, void *dst_dev,
+                            int width, int height, int src_pitch, int frames,
+                            size_t src_frame_stride, size_t dst_frame_stride,
+                            ug_hip_stream_t stream);
+/* bytes produced for one image */
+size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height);
+
+/* Signature-compatible counterparts of cuda_dxt.h (src = tightly packed 3 B/px device
+ * buffer; cuda_yuv_* take packed Y,U,V triplets).  These are asynchronous too. */
+int ug_hip_rgb_to_dxt1(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_rgb_to_dxt1, cuda_dxt.h:41 */
+int ug_hip_yuv_to_dxt1(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_yuv_to_dxt1, cuda_dxt.h:62 */
+int ug_hip_rgb_to_dxt6(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_rgb_to_dxt6, cuda_dxt.h:83 */
+int ug_hip_yuv_to_dxt6(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_yuv_to_dxt6, cuda_dxt.h:86 */
+int ug_hip_yuv422_to_yuv444(const void *src, void *out, int pix_count, ug_hip_stream_t stream);     /* cuda_yuv422_to_yuv444, cuda_dxt.h:88 */
+
+/* ------------------------------------------------------------------------------------
+ * Pixel-format conversion, whole frame on the device (replaces the decoder_t line loop,
+ * pixfmt_conv.h:87-88 / pixfmt_conv.c:3041-3125)
+ * ---------------------------------------------------------------------------------- */
+/* 1 if a kernel exists for in -> out (the subset of decoders[] on the hot path) */
+int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out);
+/* rshift/gshift/bshift have decoder_t meaning (honoured for RGBA / RGB outputs, defaults
+ * 0/8/16, pixfmt_conv.h:62-65).  Pitches 0 = vc_get_linesize(). */
+int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev,
+                          int width, int height, int src_pitch, int dst_pitch,
+                          int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* vc_get_linesize (video_codec.c:507-521) for the formats above */
+int ug_hip_linesize(ug_pixfmt_t fmt, int width);
+
+/* packed -> planar (to_planar.h:53-74) */
+int ug_hip_uyvy_to_i420(const void *src_dev, int src_pitch, void *y, int y_pitch, void *u, int u_pitch,
+                        void *v, int v_pitch, int width, int height, ug_hip_stream_t stream); /* uyvy_to_i420, to_planar.c:343 */
+int ug_hip_v210_to_p010le(const void *src_dev, int src_pitch, void *y, int y_pitch, void *uv, int uv_pitch,
+                          int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
+
+/* ------------------------------------------------------------------------------------
+ * JPEG: 8x8 forward DCT + quantisation (the stage libgpujpeg provides behind
+ * gpujpeg_encoder_encode, src/video_compress/gpujpeg.cpp:624)
+ * ---------------------------------------------------------------------------------- */
+/* Annex-K tables scaled by quality (1..100), natural order; comp 0 luma / 1 chroma */
+void ug_hip_jpeg_qtable(int quality, int comp, uint8_t table[64]);
+/* fp32 reciprocal divisors (AAN scale folded in), natural order */
+void ug_hip_jpeg_divisors(const uint8_t qtable[64], float div[64]);
+/* One 8-bit plane -> int16 coefficients, zig-zag order, 64 per block, blocks raster order.
+ * blocks_w*8 >= width, blocks_h*8 >= height; edge samples replicated.  `div_dev` = 64 floats
+ * in device memory.  coef_dev (may be NULL) receives the unquantised fp32 coefficients. */
+int ug_hip_jpeg_fdct_quant_plane(const void *plane_dev, int pitch, int width, int height,
+                                 int blocks_w, int blocks_h, const float *div_dev,
+                                 int16_t *out_dev, float *coef_dev, ug_hip_stream_t stream);
+/* Fused UYVY -> 4:2:0 (uyvy_to_i420 rounding) -> FDCT+quantise of Y, Cb, Cr without the
+ * I420 round trip through HBM.  Block counts follow 16x16 MCUs: luma (2*mcu_w) x (2*mcu_h)
+ * blocks, chroma mcu_w x mcu_h each, mcu_w = ceil(width/16), mcu_h = ceil(height/16).
+ * out_y / out_cb / out_cr as above. div_dev = 128 floats (luma then chroma). */
+int ug_hip_uyvy_to_jpeg420_coeffs(const void *src_dev, int src_pitch, int width, int height,
+                                  const float *div_dev, int16_t *out_y, int16_t *out_cb,
+                                  int16_t *out_cr, ug_hip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UG_MI355X_H */

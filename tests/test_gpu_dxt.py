@@ -1,0 +1,165 @@
+"""GPU parity: HIP DXT encoders (through the C ABI) vs oracle/dxt_oracle.c -- bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from ultragrid_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dxt_oracle.npz"))
+
+FMTS = ["RGB", "RGBA", "UYVY", "v210", "YUV444", "UYVY_RAW"]
+OUTS = ["dxt1", "dxt5ycocg"]
+
+
+def _ids(po, L):
+    pin = {"RGB": po.IN_RGB, "RGBA": po.IN_RGBA, "UYVY": po.IN_UYVY, "v210": po.IN_V210, "YUV444": po.IN_YUV444,
+           "UYVY_RAW": po.IN_UYVY_RAW}
+    lin = {"RGB": L.PF_RGB, "RGBA": L.PF_RGBA, "UYVY": L.PF_UYVY, "v210": L.PF_V210, "YUV444": L.PF_YUV444,
+           "UYVY_RAW": L.PF_UYVY_RAW}
+    return pin, lin
+
+
+def _src(kind, fmt, w, h, salt=0):
+    base = {"YUV444": "RGB", "UYVY_RAW": "UYVY"}.get(fmt, fmt)
+    return synth.frame(kind, base, w, h, salt) if kind != "S3" or base in ("UYVY", "RGB") else synth.frame("S2", base, w, h, salt)
+
+
+def _run(hip, po, fmt, out, src, w, h):
+    import torch
+    from ultragrid_amd import lib as L
+    pin, lin = _ids(po, L)
+    oid_p, oid_l = (po.OUT_DXT1, L.DXT1) if out == "dxt1" else (po.OUT_DXT5YCOCG, L.DXT5_YCOCG)
+    got = hip.dxt_encode(lin[fmt], oid_l, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
+    want = po.dxt_encode(pin[fmt], oid_p, src, w, h)
+    return got, want
+
+
+@pytest.mark.parametrize("out", OUTS)
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("kind", ["S1", "S2", "S3", "S4"])
+def test_bit_exact_small(hip, po, fmt, out, kind):
+    for (w, h) in [(48, 16), (192, 64), (1920, 36)] if fmt == "v210" else [(4, 4), (8, 8), (48, 16), (200, 64), (1920, 36)]:
+        src = _src(kind, fmt, w, h, salt=w)
+        got, want = _run(hip, po, fmt, out, src, w, h)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"{fmt}->{out} {kind} {w}x{h}: {bad.size} bytes differ, first block {bad[0] // (8 if out == 'dxt1' else 16)}"
+
+
+@pytest.mark.parametrize("out", OUTS)
+@pytest.mark.parametrize("fmt", ["RGB", "UYVY", "v210"])
+def test_vertical_mirror(hip, po, fmt, out):
+    w, h = 96, 32
+    src = _src("S1", fmt, w, h)
+    got, want = _run(hip, po, fmt, out, src, w, -h)
+    assert np.array_equal(got, want)
+
+
+def test_committed_golden(hip, po):
+    import torch
+    from ultragrid_amd import lib as L
+    _, lin = _ids(po, L)
+    for k in GOLD.files:
+        if not k.startswith("out"):
+            continue
+        tag, kind, name, oname = k.split("_")
+        src = GOLD[f"in_{kind}_{name}"]
+        h = -16 if tag == "outm" else 16
+        got = hip.dxt_encode(lin[name], L.DXT1 if oname == "dxt1" else L.DXT5_YCOCG, torch.from_numpy(src).cuda(), 48, h)
+        assert np.array_equal(got.cpu().numpy(), GOLD[k]), k
+
+
+@pytest.mark.parametrize("cfg", [("RGB", "dxt1", 1920, 1080), ("UYVY", "dxt5ycocg", 3840, 2160)],
+                         ids=["cfg1-1080p-RGB-DXT1", "cfg2-4K-UYVY-DXT5"])
+def test_baseline_configs_full_size(hip, po, cfg):
+    """BASELINE.json configs[1] and configs[2] at full size, bit-exact vs the oracle (S2 content)."""
+    fmt, out, w, h = cfg
+    src = _src("S2", fmt, w, h)
+    got, want = _run(hip, po, fmt, out, src, w, h)
+    assert np.array_equal(got, want)
+
+
+def test_8k_v210_properties(hip, po):
+    """configs[4] at 7680x4320: the oracle would take ~1 min on this frame, so check size-independent
+    properties: (1) a random sample of block rows equals the oracle on those rows, (2) v210 == (v210->UYVY
+    on the GPU) -> UYVY encoder, (3) batch == per-frame, (4) mirror == encode of the flipped frame."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 7680, 4320
+    one = synth.s2_video("v210", w, 48)
+    reps = h // 48
+    frame = np.tile(one.reshape(48, -1), (reps, 1))
+    rng = np.random.default_rng(9)
+    frame[:, :64] ^= rng.integers(0, 256, (h, 64), dtype=np.uint8) & 0x3F  # de-periodise a little (keeps pad bits 0: mask <= 0x3f on byte 0..)
+    frame = (frame.view(np.uint32) & 0x3FFFFFFF).view(np.uint8).ravel()
+    dev = torch.from_numpy(frame).cuda()
+    full = hip.dxt_encode(L.PF_V210, L.DXT5_YCOCG, dev, w, h)
+    pitch = 20480
+    for by in rng.integers(0, h // 4, 6):
+        rows = frame.reshape(h, pitch)[4 * by: 4 * by + 4]
+        want = po.dxt_encode(po.IN_V210, po.OUT_DXT5YCOCG, rows, w, 4)
+        assert np.array_equal(full[by * (w // 4) * 16: (by + 1) * (w // 4) * 16].cpu().numpy(), want)
+    uyvy = hip.pixfmt_convert(L.PF_V210, L.PF_UYVY, dev, w, h)
+    assert torch.equal(hip.dxt_encode(L.PF_UYVY, L.DXT5_YCOCG, uyvy, w, h), full)
+    two = torch.cat([dev, dev.flip(0).contiguous()])
+    b = hip.dxt_encode_batch(L.PF_V210, L.DXT5_YCOCG, two, w, h, 2, dev.numel())
+    assert torch.equal(b[: full.numel()], full)
+    flipped = torch.from_numpy(np.ascontiguousarray(frame.reshape(h, pitch)[::-1])).cuda().ravel()
+    assert torch.equal(hip.dxt_encode(L.PF_V210, L.DXT5_YCOCG, dev, w, -h), hip.dxt_encode(L.PF_V210, L.DXT5_YCOCG, flipped, w, h))
+
+
+def test_cuda_dxt_h_shaped_entry_points(hip, po):
+    """ug_hip_{rgb,yuv}_to_dxt{1,6} + ug_hip_yuv422_to_yuv444 == the reference's two-pass CUDA call sequence
+    (cuda_dxt.cpp:223-260)."""
+    import torch
+    from ultragrid_amd import lib as L
+    l = L.load()
+    w, h = 192, 64
+    st = torch.cuda.current_stream().cuda_stream
+    uy = synth.s1_random("UYVY", w, h)
+    d_uy = torch.from_numpy(uy).cuda()
+    d444 = hip.yuv422_to_yuv444(d_uy, w * h)
+    assert np.array_equal(d444.cpu().numpy(), po.yuv422_to_yuv444(uy, w * h))
+    for fn, pf, oid, size in [(l.ug_hip_yuv_to_dxt6, po.IN_YUV444, po.OUT_DXT5YCOCG, w * h), (l.ug_hip_yuv_to_dxt1, po.IN_YUV444, po.OUT_DXT1, w * h // 2)]:
+        out = torch.empty(size, dtype=torch.uint8, device="cuda")
+        assert fn(d444.data_ptr(), out.data_ptr(), w, h, st) == 0
+        assert np.array_equal(out.cpu().numpy(), po.dxt_encode(pf, oid, d444.cpu().numpy(), w, h))
+        assert np.array_equal(out.cpu().numpy(), po.dxt_encode(po.IN_UYVY, oid, uy, w, h))  # fused == two-pass
+    rgb = synth.s1_random("RGB", w, h)
+    d_rgb = torch.from_numpy(rgb).cuda()
+    for fn, oid, size in [(l.ug_hip_rgb_to_dxt6, po.OUT_DXT5YCOCG, w * h), (l.ug_hip_rgb_to_dxt1, po.OUT_DXT1, w * h // 2)]:
+        out = torch.empty(size, dtype=torch.uint8, device="cuda")
+        assert fn(d_rgb.data_ptr(), out.data_ptr(), w, -h, st) == 0   # negative height = bottom-up
+        assert np.array_equal(out.cpu().numpy(), po.dxt_encode(po.IN_RGB, oid, rgb, w, -h))
+
+
+def test_batch_and_pitch(hip, po):
+    import torch
+    from ultragrid_amd import lib as L
+    w, h, n = 96, 32, 5
+    frames = [synth.s1_random("UYVY", w, h, salt=i) for i in range(n)]
+    dev = torch.from_numpy(np.concatenate(frames)).cuda()
+    out = hip.dxt_encode_batch(L.PF_UYVY, L.DXT5_YCOCG, dev, w, h, n, frames[0].size).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i * w * h: (i + 1) * w * h], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frames[i], w, h))
+    # padded pitch
+    pitch = 2 * w + 64
+    padded = np.zeros((h, pitch), np.uint8)
+    padded[:, : 2 * w] = frames[0].reshape(h, 2 * w)
+    got = hip.dxt_encode(L.PF_UYVY, L.DXT1, torch.from_numpy(padded.ravel()).cuda(), w, h, pitch=pitch).cpu().numpy()
+    assert np.array_equal(got, po.dxt_encode(po.IN_UYVY, po.OUT_DXT1, frames[0], w, h))
+
+
+def test_error_codes_on_device(hip):
+    import torch
+    from ultragrid_amd import lib as L
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(L.UgHipError) as e:
+        hip.dxt_encode(L.PF_RGB, L.DXT1, buf, 18, 4)
+    assert e.value.rc == L.EINVAL
+    with pytest.raises(L.UgHipError) as e:
+        hip.dxt_encode(L.PF_RG48, L.DXT1, buf, 16, 4)
+    assert e.value.rc == L.EUNSUPP
+    with pytest.raises(ValueError):
+        hip.dxt_encode(L.PF_RGB, L.DXT1, torch.zeros(64, dtype=torch.uint8), 4, 4)  # host tensor: no CPU fallback

@@ -1,0 +1,103 @@
+"""GPU parity: HIP pixel-format kernels vs the reference's compiled C (oracle/_ref, when it travelled),
+the committed fixtures generated from it, and the restatement -- bit-exact (integer work)."""
+import os
+
+import numpy as np
+import pytest
+
+from ultragrid_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "pixfmt_ref.npz"))
+PAIRS = sorted({tuple(k.split("_")[1:3]) for k in GOLD.files if k.startswith("in_")})
+
+
+def _conv(hip, i, o, src, w, h, sh=(0, 8, 16)):
+    import torch
+    from ultragrid_amd import lib as L
+    # the reference's decoders may over-read the source by up to MAX_PADDING (pixfmt_conv.h:70-74)
+    dev = torch.from_numpy(np.concatenate([src, np.zeros(64, np.uint8)])).cuda()
+    return hip.pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], dev, w, h, sh).cpu().numpy()
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_vs_committed_reference_fixtures(hip, pair):
+    i, o = pair
+    n = 0
+    for k in GOLD.files:
+        if not k.startswith(f"out_{i}_{o}_"):
+            continue
+        _, _, _, dims, rs, gs, bs = k.split("_")
+        w, h = map(int, dims.split("x"))
+        got = _conv(hip, i, o, GOLD[f"in_{i}_{o}_{dims}"], w, h, (int(rs), int(gs), int(bs)))
+        assert np.array_equal(got, GOLD[k]), k
+        n += 1
+    assert n >= 4
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_vs_oracle_ragged_and_aligned(hip, po, pair):
+    i, o = pair
+    for (w, h) in [(2, 2), (6, 1), (50, 3), (127, 5), (96, 4), (1920, 8), (3840, 4)]:
+        for sh in [(0, 8, 16), (16, 8, 0)]:
+            src = synth.s1_random(i, w, h, salt=w)
+            want = po.convert_frame(i, o, src, w, h, sh)
+            if po.have_ref():  # the real thing, when oracle/_ref travelled to this box
+                assert np.array_equal(want, po.ref_convert_frame(i, o, src, w, h, sh, scalar=True))
+            got = _conv(hip, i, o, src, w, h, sh)
+            assert np.array_equal(got, want), (i, o, w, h, sh)
+
+
+def test_identity_copies(hip, po):
+    for f in ("UYVY", "v210", "YUYV"):
+        src = synth.s1_random(f, 96, 4)
+        assert np.array_equal(_conv(hip, f, f, src, 96, 4), src)
+
+
+def test_baseline_config0_1080p_uyvy_to_rgb(hip, po):
+    """BASELINE.json configs[0]: 1920x1080 UYVY->RGB -- GPU vs the reference CPU path, S1/S2/S3 content."""
+    w, h = 1920, 1080
+    for kind in ("S1", "S2", "S3"):
+        src = synth.frame(kind, "UYVY", w, h)
+        want = po.ref_convert_frame("UYVY", "RGB", src, w, h) if po.have_ref() else po.convert_frame("UYVY", "RGB", src, w, h)
+        assert np.array_equal(_conv(hip, "UYVY", "RGB", src, w, h), want), kind
+
+
+def test_full_size_roundtrip_properties(hip):
+    """8K: UYVY -> v210 -> UYVY is the identity (8-bit samples survive <<2 then >>2); YUYV swap is an involution."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 7680, 4320
+    src = torch.from_numpy(synth.s1_random("UYVY", w, 16)).cuda().repeat(h // 16)
+    v = hip.pixfmt_convert(L.PF_UYVY, L.PF_V210, src, w, h)
+    assert v.numel() == 20480 * h
+    assert torch.equal(hip.pixfmt_convert(L.PF_V210, L.PF_UYVY, v, w, h), src)
+    y = hip.pixfmt_convert(L.PF_UYVY, L.PF_YUYV, src, w, h)
+    assert torch.equal(hip.pixfmt_convert(L.PF_YUYV, L.PF_UYVY, y, w, h), src)
+
+
+def test_planar(hip, po):
+    import torch
+    for k in GOLD.files:
+        if k.startswith("i420_in_"):
+            dims = k.split("_")[2]
+            w, h = map(int, dims.split("x"))
+            y, u, v = hip.uyvy_to_i420(torch.from_numpy(GOLD[k]).cuda(), w, h)
+            assert np.array_equal(y.cpu().numpy(), GOLD[f"i420_y_{dims}"]) and np.array_equal(u.cpu().numpy(), GOLD[f"i420_u_{dims}"]) \
+                and np.array_equal(v.cpu().numpy(), GOLD[f"i420_v_{dims}"]), dims
+        if k.startswith("p010_in_"):
+            dims = k.split("_")[2]
+            w, h = map(int, dims.split("x"))
+            y, uv = hip.v210_to_p010le(torch.from_numpy(GOLD[k]).cuda(), w, h)
+            assert np.array_equal(y.cpu().numpy().view(np.uint16), GOLD[f"p010_y_{dims}"]) and \
+                np.array_equal(uv.cpu().numpy().view(np.uint16), GOLD[f"p010_uv_{dims}"]), dims
+    # reference test pattern (test/codec_conversions_test.cpp:28-84) and full-size 4K (config 3 front end)
+    for w, h in [(1, 2), (2, 1), (16, 1), (16, 16), (127, 255), (3840, 2160)]:
+        src = synth.s1_random("UYVY", w, h, salt=1) if w > 16 else np.tile(np.frombuffer(b"uyvY", np.uint8), ((w + 1) // 2) * h)
+        y, u, v = hip.uyvy_to_i420(torch.from_numpy(src).cuda(), w, h)
+        for a, b in zip((y, u, v), po.uyvy_to_i420(src, w, h)):
+            assert np.array_equal(a.cpu().numpy(), b), (w, h)
+    src = synth.s1_random("v210", 1920, 8)
+    y, uv = hip.v210_to_p010le(torch.from_numpy(src).cuda(), 1920, 8)
+    wy, wuv = po.v210_to_p010le(src, 1920, 8)
+    assert np.array_equal(y.cpu().numpy().view(np.uint16), wy) and np.array_equal(uv.cpu().numpy().view(np.uint16), wuv)

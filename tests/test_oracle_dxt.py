@@ -1,0 +1,169 @@
+"""CPU: the strict-fp32 DXT restatement (oracle/dxt_oracle.c).  Parity is UNPINNED against the
+reference (no CPU DXT encoder, no known-answer test there); what can be checked is (a) regression
+against committed oracle outputs, (b) the bitstream decodes -- with the restated reference CPU decoder
+cuda_dxt/dxt62tga.c -- to an image close to the source, (c) structural S3TC invariants, and (d) a
+pure-Python/numpy-float32 re-derivation of one block from SURVEY.md Appendix A."""
+import os
+
+import numpy as np
+import pytest
+
+from ultragrid_amd import synth
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dxt_oracle.npz"))
+F32 = np.float32
+
+
+def psnr(a, b):
+    m = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if m == 0 else 10 * np.log10(255.0 ** 2 / m)
+
+
+def test_regression_vs_committed_oracle_outputs(po):
+    fmts = {"RGB": po.IN_RGB, "RGBA": po.IN_RGBA, "UYVY": po.IN_UYVY, "v210": po.IN_V210}
+    n = 0
+    for k in GOLD.files:
+        if not k.startswith("out"):
+            continue
+        tag, kind, name, oname = k.split("_")
+        src = GOLD[f"in_{kind}_{name}"]
+        h = -16 if tag == "outm" else 16
+        got = po.dxt_encode(fmts[name], po.OUT_DXT1 if oname == "dxt1" else po.OUT_DXT5YCOCG, src, 48, h)
+        assert np.array_equal(got, GOLD[k]), k
+        n += 1
+    assert n == 48
+
+
+@pytest.mark.parametrize("out", ["dxt1", "dxt5ycocg"])
+def test_decode_psnr_gate(po, out):
+    w, h = 288, 128
+    oid = po.OUT_DXT1 if out == "dxt1" else po.OUT_DXT5YCOCG
+    # smooth natural-image-like content (S2's per-pixel chroma noise is a stress input, not a quality gate)
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0),
+                    128 + 80 * np.sin(yy / 9.0)], -1)
+    rgb = (rgb + np.random.default_rng(2).normal(0, 2, rgb.shape)).clip(0, 255).astype(np.uint8)
+    dec = po.dxt_decode_rgb(oid, po.dxt_encode(po.IN_RGB, oid, rgb, w, h), w, h)
+    assert psnr(rgb, dec) > (35.0 if out == "dxt1" else 38.0)
+    # UYVY path: compare with the reference's own UYVY->RGB (Q14) of the same frame
+    uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+    ref_rgb = po.convert_frame("UYVY", "RGB", uyvy, w, h).reshape(h, w, 3)
+    dec = po.dxt_decode_rgb(oid, po.dxt_encode(po.IN_UYVY, oid, uyvy, w, h), w, h)
+    assert psnr(ref_rgb, dec) > (35.0 if out == "dxt1" else 38.0)
+    # v210 path through the same content
+    v210 = po.convert_frame("UYVY", "v210", uyvy, w, h) if w % 48 == 0 else None
+    if v210 is not None:
+        dec = po.dxt_decode_rgb(oid, po.dxt_encode(po.IN_V210, oid, v210, w, h), w, h)
+        assert psnr(ref_rgb, dec) > (35.0 if out == "dxt1" else 38.0)
+
+
+def test_structural_invariants(po):
+    w, h = 128, 64
+    for kind in ("S1", "S2", "S4"):
+        src = synth.frame(kind, "RGB", w, h)
+        d5 = po.dxt_encode(po.IN_RGB, po.OUT_DXT5YCOCG, src, w, h).view(np.uint32).reshape(-1, 4)
+        a0, a1 = d5[:, 0] & 0xFF, (d5[:, 0] >> 8) & 0xFF
+        assert (a0 >= a1).all()          # alpha0 = maxY, alpha1 = minY (glsl:252-259)
+        c0, c1 = d5[:, 2] & 0xFFFF, d5[:, 2] >> 16
+        assert ((c0 & 0x1F) == (c1 & 0x1F)).all() and ((c0 & 0x1F) <= 3).all() and ((c0 & 0x1F) != 2).all()  # scale-1 in {0,1,3}
+        d1 = po.dxt_encode(po.IN_RGB, po.OUT_DXT1, src, w, h).view(np.uint16).reshape(-1, 4)
+        assert (d1[:, 0] >= d1[:, 1]).all()  # 4-colour mode (compress_dxt1_fp.glsl:116-123)
+    assert po.dxt_encode(po.IN_RGB, po.OUT_DXT1, synth.s1_random("RGB", 16, 8), 16, 8).size == 16 * 8 // 2  # dxt_util.h:59-67
+    with pytest.raises(ValueError):
+        po.dxt_encode(po.IN_RGB, po.OUT_DXT1, np.zeros(18 * 4 * 3, np.uint8), 18, 4)  # cuda_dxt.cu:745
+
+
+def test_format_equivalences(po):
+    w, h = 96, 32
+    uy = synth.s1_random("UYVY", w, h)
+    y444 = po.yuv422_to_yuv444(uy, w * h)
+    for oid in (po.OUT_DXT1, po.OUT_DXT5YCOCG):
+        # the reference's two-pass CUDA path (422->444 kernel, then cuda_yuv_to_dxt*) == our fused definition
+        assert np.array_equal(po.dxt_encode(po.IN_YUV444, oid, y444, w, h), po.dxt_encode(po.IN_UYVY, oid, uy, w, h))
+        # v210 == vc_copylinev210 (>>2) then UYVY (cuda_dxt.cpp:162,213-218)
+        v = synth.s1_random("v210", w, h)
+        as_uyvy = po.convert_frame("v210", "UYVY", v, w, h)
+        assert np.array_equal(po.dxt_encode(po.IN_V210, oid, v, w, h), po.dxt_encode(po.IN_UYVY, oid, as_uyvy, w, h))
+        # RGBA ignores alpha
+        rgba = synth.s1_random("RGBA", w, h)
+        rgb = po.convert_frame("RGBA", "RGB", rgba, w, h)
+        assert np.array_equal(po.dxt_encode(po.IN_RGBA, oid, rgba, w, h), po.dxt_encode(po.IN_RGB, oid, rgb, w, h))
+        # negative height = vertical mirror of the source (cuda_dxt.cu:652-655)
+        flipped = np.ascontiguousarray(rgb.reshape(h, w * 3)[::-1])
+        assert np.array_equal(po.dxt_encode(po.IN_RGB, oid, rgb, w, -h), po.dxt_encode(po.IN_RGB, oid, flipped, w, h))
+
+
+def _dxt5_block_numpy(rgb):
+    """One block per SURVEY.md Appendix A in numpy float32 scalar arithmetic (independent re-derivation)."""
+    f = F32
+    off = f(128.0 / 255.0)
+    px = rgb.astype(np.float32) * f(0.00392156862745)
+    Y = ((px[:, 0] + f(2) * px[:, 1]) + px[:, 2]) * f(0.25)
+    Co = ((f(2) * px[:, 0] - f(2) * px[:, 2]) * f(0.25)) + off
+    Cg = (((-px[:, 0] + f(2) * px[:, 1]) - px[:, 2]) * f(0.25)) + off
+    mn = [Y.min(), Co.min(), Cg.min()]; mx = [Y.max(), Co.max(), Cg.max()]
+    midx, midy = (mx[1] + mn[1]) * f(0.5), (mx[2] + mn[2]) * f(0.5)
+    cov = f(0)
+    for i in range(16):
+        cov = f(cov + f((Co[i] - midx) * (Cg[i] - midy)))
+    if cov < 0:
+        mx[2], mn[2] = mn[2], mx[2]
+    m = max(abs(f(mn[1] - off)), abs(f(mn[2] - off)), abs(f(mx[1] - off)), abs(f(mx[2] - off)))
+    scale = 1
+    if m < f(64.0 / 255.0): scale = 2
+    if m < f(32.0 / 255.0): scale = 4
+    fs = f(scale)
+    rnd = lambda x: int(np.floor(np.float64(x) + 0.5))  # x >= 0: half away == floor(x + .5) in fp64 (exact)
+    q = [f(31), f(63)]
+    imax, imin, emx, emn = [], [], [], []
+    for k in range(2):
+        a = f(f(f(mx[1 + k] - off) * fs) + off); b = f(f(f(mn[1 + k] - off) * fs) + off)
+        inset = f(f(f(a - b) / f(16)) - f((8.0 / 255.0) / 16.0))
+        b = min(f(1), max(f(0), f(b + inset))); a = min(f(1), max(f(0), f(a - inset)))
+        imax.append(rnd(f(a * q[k]))); imin.append(rnd(f(b * q[k])))
+    w2 = ((imax[0] << 11) | (imax[1] << 5) | (scale - 1)) | (((imin[0] << 11) | (imin[1] << 5) | (scale - 1)) << 16)
+    ex = lambda v, k: ((v << 3) | (v >> 2)) if k == 0 else ((v << 2) | (v >> 4))
+    inv255 = f(1.0 / 255.0)
+    for k in range(2):
+        emx.append(f(f(f(f(ex(imax[k], k)) * inv255) - off) / fs + off)); emn.append(f(f(f(f(ex(imin[k], k)) * inv255) - off) / fs + off))
+    q1, q2 = f(1.0 / 3.0), f(2.0 / 3.0)
+    lerp = lambda a, b, t: f(f(a * f(f(1) - t)) + f(b * t))
+    c = [emx, emn, [lerp(emx[k], emn[k], q1) for k in range(2)], [lerp(emx[k], emn[k], q2) for k in range(2)]]
+    w3 = 0
+    for i in range(16):
+        d = [f(f(f(Co[i] - c[k][0]) * f(Co[i] - c[k][0])) + f(f(Cg[i] - c[k][1]) * f(Cg[i] - c[k][1]))) for k in range(4)]
+        b0, b1, b2, b3, b4 = d[0] > d[3], d[1] > d[2], d[0] > d[2], d[1] > d[3], d[2] > d[3]
+        w3 |= (int(b0 & b4) | (int((b1 & b2) | (b0 & b3)) << 1)) << (2 * i)
+    inset = f(f(f(mx[0] - mn[0]) / f(32)) - f((16.0 / 255.0) / 32.0))
+    mnY = min(f(1), max(f(0), f(mn[0] + inset))); mxY = min(f(1), max(f(0), f(mx[0] - inset)))
+    w0 = (rnd(f(mnY * f(255))) << 8) | rnd(f(mxY * f(255)))
+    mid = f(f(mxY - mnY) / f(14))
+    ab = [None, f(mnY + mid)] + [f(f(f(f(f(8 - k) * mxY) + f(f(k - 1) * mnY)) * f(1.0 / 7.0)) + mid) for k in range(2, 8)]
+    w1 = 0
+    for i in range(16):
+        idx = 1 + sum(int(Y[i] <= ab[k]) for k in range(1, 8))
+        idx &= 7
+        idx ^= int(2 > idx)
+        if i < 6:
+            w0 |= (idx << (3 * i + 16)) & 0xFFFFFFFF
+            if i == 5:
+                w1 = idx >> 1
+        else:
+            w1 |= idx << (3 * i - 16)
+    return [w0, w1, w2, w3]
+
+
+def test_independent_numpy_float32_rederivation(po):
+    rng = np.random.default_rng(5)
+    with np.errstate(all="ignore"):
+        for trial in range(40):
+            if trial % 4 == 0:
+                blk = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+            elif trial % 4 == 1:  # low-contrast: exercises scale 2 / 4
+                blk = (128 + rng.integers(-6, 7, (16, 3))).astype(np.uint8)
+            elif trial % 4 == 2:  # flat
+                blk = np.full((16, 3), rng.integers(0, 256), np.uint8)
+            else:                 # smooth gradient
+                blk = (np.linspace(40, 200, 16)[:, None] + rng.integers(-3, 4, (16, 3))).clip(0, 255).astype(np.uint8)
+            got = po.dxt_encode(po.IN_RGB, po.OUT_DXT5YCOCG, blk.reshape(4, 12), 4, 4).view(np.uint32).tolist()
+            assert got == _dxt5_block_numpy(blk), trial

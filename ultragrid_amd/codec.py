@@ -1,0 +1,143 @@
+"""Thin torch-tensor front end over the C ABI (test / bench driver).
+
+torch is used only for device memory and streams; every compute call goes through
+libug_mi355x.so (ultragrid_amd/lib.py).  Function names follow the reference interface
+they stand in for (cuda_dxt.h, pixfmt_conv.h decoder_t loop, to_planar.h).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _u8(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError("device tensor required (the product path has no CPU fallback)")
+    if t.dtype != torch.uint8 or not t.is_contiguous():
+        raise ValueError("contiguous uint8 tensor required")
+    return t
+
+
+def dxt_size(out: int, w: int, h: int) -> int:
+    return L.load().ug_hip_dxt_size(out, w, h)
+
+
+def dxt_encode(in_fmt: int, out_fmt: int, src: torch.Tensor, w: int, h: int, pitch: int = 0,
+               dst: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused unpack + colour conversion + block encode of one image (cuda_{rgb,yuv}_to_dxt{1,6},
+    cuda_dxt.h:30-89, plus the decoder_t pre-pass).  h < 0 reads the source bottom-up."""
+    src = _u8(src)
+    if dst is None:
+        dst = torch.empty(dxt_size(out_fmt, w, h), dtype=torch.uint8, device=src.device)
+    rc = L.load().ug_hip_dxt_encode(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, _stream())
+    L.check(rc, "ug_hip_dxt_encode")
+    return dst
+
+
+def dxt_encode_batch(in_fmt: int, out_fmt: int, src: torch.Tensor, w: int, h: int, frames: int,
+                     src_frame_stride: int, dst: torch.Tensor | None = None, pitch: int = 0) -> torch.Tensor:
+    src = _u8(src)
+    per = dxt_size(out_fmt, w, h)
+    if dst is None:
+        dst = torch.empty(per * frames, dtype=torch.uint8, device=src.device)
+    rc = L.load().ug_hip_dxt_encode_batch(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, frames,
+                                          src_frame_stride, per, _stream())
+    L.check(rc, "ug_hip_dxt_encode_batch")
+    return dst
+
+
+def time_dxt_encode(in_fmt: int, out_fmt: int, src: torch.Tensor, dst: torch.Tensor, w: int, h: int, frames: int,
+                    src_frame_stride: int, dst_frame_stride: int, iters: int) -> float:
+    """ms per launch, hipEvents on the current stream (ug_hip_time_dxt_encode)."""
+    import ctypes as C
+    ms = C.c_float(0)
+    rc = L.load().ug_hip_time_dxt_encode(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, 0, frames,
+                                         src_frame_stride, dst_frame_stride, iters, _stream(), C.byref(ms))
+    L.check(rc, "ug_hip_time_dxt_encode")
+    return ms.value
+
+
+def yuv422_to_yuv444(src: torch.Tensor, pix_count: int) -> torch.Tensor:
+    src = _u8(src)
+    dst = torch.empty(pix_count * 3, dtype=torch.uint8, device=src.device)
+    L.check(L.load().ug_hip_yuv422_to_yuv444(src.data_ptr(), dst.data_ptr(), pix_count, _stream()),
+            "ug_hip_yuv422_to_yuv444")
+    return dst
+
+
+def linesize(fmt: int, w: int) -> int:
+    return L.load().ug_hip_linesize(fmt, w)
+
+
+def pixfmt_convert(in_fmt: int, out_fmt: int, src: torch.Tensor, w: int, h: int, shifts=(0, 8, 16)) -> torch.Tensor:
+    """Whole-frame decoder_t conversion on the device (pixfmt_conv.c:3041-3125)."""
+    src = _u8(src)
+    dst = torch.zeros(linesize(out_fmt, w) * h, dtype=torch.uint8, device=src.device)
+    rc = L.load().ug_hip_pixfmt_convert(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, 0, 0, *shifts, _stream())
+    L.check(rc, "ug_hip_pixfmt_convert")
+    return dst
+
+
+def uyvy_to_i420(src: torch.Tensor, w: int, h: int):
+    src = _u8(src)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    y = torch.zeros((h, w), dtype=torch.uint8, device=src.device)
+    u = torch.zeros((ch, cw), dtype=torch.uint8, device=src.device)
+    v = torch.zeros((ch, cw), dtype=torch.uint8, device=src.device)
+    rc = L.load().ug_hip_uyvy_to_i420(src.data_ptr(), 0, y.data_ptr(), w, u.data_ptr(), cw, v.data_ptr(), cw, w, h,
+                                      _stream())
+    L.check(rc, "ug_hip_uyvy_to_i420")
+    return y, u, v
+
+
+def v210_to_p010le(src: torch.Tensor, w: int, h: int):
+    src = _u8(src)
+    y = torch.zeros((h, w), dtype=torch.int16, device=src.device)
+    uv = torch.zeros((h // 2, w), dtype=torch.int16, device=src.device)
+    rc = L.load().ug_hip_v210_to_p010le(src.data_ptr(), 0, y.data_ptr(), 2 * w, uv.data_ptr(), 2 * w, w, h, _stream())
+    L.check(rc, "ug_hip_v210_to_p010le")
+    return y, uv
+
+
+def jpeg_divisors_device(quality: int, device) -> torch.Tensor:
+    """128 fp32 divisors (luma, chroma) in device memory."""
+    import ctypes as C
+    import numpy as np
+    out = np.zeros(128, np.float32)
+    for comp in (0, 1):
+        q = (C.c_uint8 * 64)()
+        d = (C.c_float * 64)()
+        L.load().ug_hip_jpeg_qtable(quality, comp, q)
+        L.load().ug_hip_jpeg_divisors(q, d)
+        out[64 * comp: 64 * comp + 64] = np.frombuffer(d, np.float32)
+    return torch.from_numpy(out).to(device)
+
+
+def jpeg_fdct_quant_plane(plane: torch.Tensor, div: torch.Tensor, blocks_w: int = 0, blocks_h: int = 0,
+                          want_coef: bool = False):
+    h, w = plane.shape
+    bw = blocks_w or (w + 7) // 8
+    bh = blocks_h or (h + 7) // 8
+    out = torch.zeros((bw * bh, 64), dtype=torch.int16, device=plane.device)
+    coef = torch.zeros((bw * bh, 64), dtype=torch.float32, device=plane.device) if want_coef else None
+    rc = L.load().ug_hip_jpeg_fdct_quant_plane(plane.data_ptr(), plane.stride(0), w, h, bw, bh, div.data_ptr(),
+                                               out.data_ptr(), coef.data_ptr() if want_coef else None, _stream())
+    L.check(rc, "ug_hip_jpeg_fdct_quant_plane")
+    return (out, coef) if want_coef else out
+
+
+def uyvy_to_jpeg420_coeffs(src: torch.Tensor, w: int, h: int, div: torch.Tensor):
+    src = _u8(src)
+    mw, mh = (w + 15) // 16, (h + 15) // 16
+    oy = torch.zeros((4 * mw * mh, 64), dtype=torch.int16, device=src.device)
+    ocb = torch.zeros((mw * mh, 64), dtype=torch.int16, device=src.device)
+    ocr = torch.zeros((mw * mh, 64), dtype=torch.int16, device=src.device)
+    rc = L.load().ug_hip_uyvy_to_jpeg420_coeffs(src.data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(),
+                                                ocr.data_ptr(), _stream())
+    L.check(rc, "ug_hip_uyvy_to_jpeg420_coeffs")
+    return oy, ocb, ocr

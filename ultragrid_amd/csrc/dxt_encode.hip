@@ -1,0 +1,621 @@
+// dxt_encode.hip -- fused pixel-format unpack + colour conversion + DXT1 / DXT5-YCoCg 4x4
+// block encode for gfx950 (CDNA4).
+//
+// Replaces, in one pass and with no intermediate buffer:
+//   - the CPU decoder_t line loop of the compress modules (cuda_dxt.cpp:206-220,
+//     dxt_glsl.cpp:277-289): v210 -> UYVY (pixfmt_conv.c:86-130) is folded into the load;
+//   - cuda_yuv422_to_yuv444 / yuv422_to_yuv444.glsl (chroma replication, a full-frame pass
+//     in the reference: cuda_dxt.cu:697-732, dxt_encoder.c:482-542);
+//   - the block encoders dxt_kernel<...> (cuda_dxt.cu:622-695) / fp_compress_dxt5ycocg
+//     (compress_dxt5ycocg_fp.glsl:326-377) / fp_compress_dxt1 (compress_dxt1_fp.glsl:177-229).
+//
+// Numerics contract: bit-identical to oracle/dxt_oracle.c, the strict-fp32 restatement of
+// the shaders.  Every source-level operation is one IEEE binary32 operation; this file is
+// compiled with -ffp-contract=off.  Where an operation is fused or strength-reduced below,
+// the comment states why the result is bit-identical (exact products by powers of two).
+//
+// Mapping: one lane encodes one 4x4 block (v210: three consecutive blocks = one 32-byte
+// group pair per row).  Consecutive lanes take consecutive blocks of a block-row, so a
+// wave's row loads are contiguous (64 x 8 B UYVY, 64 x 12 B RGB, 64 x 32 B v210) and its
+// 64 x 16 B (DXT5) / 64 x 8 B (DXT1) stores form one contiguous 1 KiB / 512 B burst.
+// The work is VALU-bound: no LDS staging is needed because each input
+// byte is read by exactly one lane.
+#include "ug_common.h"
+
+namespace {
+
+constexpr float kInv255  = 0.00392156862745f;           // cuda_dxt.cu:666
+constexpr float kOffset  = (float) (128.0 / 255.0);     // compress_dxt5ycocg_fp.glsl:25
+constexpr float kInsetC  = (float) ((8.0 / 255.0) / 16.0);
+constexpr float kInsetY  = (float) ((16.0 / 255.0) / 32.0);
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(1.0f, fmaxf(0.0f, v)); }
+
+// GLSL mix(a,b,q) = a*(1-q) + b*q, w = 1-q precomputed in fp32 (cuda_dxt.cu:126-128)
+__device__ __forceinline__ float lerp_w(float a, float b, float w, float q)
+{
+        float p0 = a * w;
+        float p1 = b * q;
+        return p0 + p1;
+}
+
+__device__ __forceinline__ uint32_t palette_index(float d0, float d1, float d2, float d3)
+{
+        // compress_dxt5ycocg_fp.glsl:237-244
+        uint32_t b0 = d0 > d3, b1 = d1 > d2, b2 = d0 > d2, b3 = d1 > d3, b4 = d2 > d3;
+        return (b0 & b4) | (((b1 & b2) | (b0 & b3)) << 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// colour front ends: bytes -> normalised (c0,c1,c2) per pixel
+// ---------------------------------------------------------------------------------------
+struct Px16 {
+        float a[16], b[16], c[16];
+};
+
+// ConvertYUVToRGB (compress_dxt5ycocg_fp.glsl:12-23) for a pixel pair sharing chroma.
+__device__ __forceinline__ void yuv_pair_to_rgb(float y0, float y1, float u, float v, Px16 &p, int i)
+{
+        const float U = u - 0.5f, V = v - 0.5f;
+        const float rv = 1.7926f * V, gu = 0.2132f * U, gv = 0.5328f * V, bu = 2.1124f * U;
+        const float Y0 = 1.1643f * (y0 - 0.0625f), Y1 = 1.1643f * (y1 - 0.0625f);
+        p.a[i] = Y0 + rv;
+        p.b[i] = (Y0 - gu) - gv;
+        p.c[i] = Y0 + bu;
+        p.a[i + 1] = Y1 + rv;
+        p.b[i + 1] = (Y1 - gu) - gv;
+        p.c[i + 1] = Y1 + bu;
+}
+
+__device__ __forceinline__ float byte_f(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 0xffu) * kInv255; }
+
+// 4 pixels of one row from three RGB words (12 B)
+__device__ __forceinline__ void row_rgb(const uint32_t *w, Px16 &p, int i)
+{
+        p.a[i + 0] = byte_f(w[0], 0); p.b[i + 0] = byte_f(w[0], 1); p.c[i + 0] = byte_f(w[0], 2);
+        p.a[i + 1] = byte_f(w[0], 3); p.b[i + 1] = byte_f(w[1], 0); p.c[i + 1] = byte_f(w[1], 1);
+        p.a[i + 2] = byte_f(w[1], 2); p.b[i + 2] = byte_f(w[1], 3); p.c[i + 2] = byte_f(w[2], 0);
+        p.a[i + 3] = byte_f(w[2], 1); p.b[i + 3] = byte_f(w[2], 2); p.c[i + 3] = byte_f(w[2], 3);
+}
+
+template <int IN>
+struct Loader;
+
+// ---- RGB / YUV444: 12 B per block row ----
+template <bool YUV>
+struct Loader3 {
+        static constexpr int kBlocks = 1;
+        uint32_t w[4][3];
+        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t *p = (const uint32_t *) (src + (long) rows[r] * pitch) + unit_x * 3;
+                        w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+                }
+        }
+        __device__ __forceinline__ void block(int, Px16 &p) const
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        row_rgb(w[r], p, 4 * r);
+                }
+                if (YUV) { // cuda_dxt.cu:686-691 (per pixel, no chroma sharing in 4:4:4)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                                const float U = p.b[i] - 0.5f, V = p.c[i] - 0.5f;
+                                const float Y = 1.1643f * (p.a[i] - 0.0625f);
+                                p.a[i] = Y + 1.7926f * V;
+                                p.b[i] = (Y - 0.2132f * U) - 0.5328f * V;
+                                p.c[i] = Y + 2.1124f * U;
+                        }
+                }
+        }
+};
+template <> struct Loader<UG_PF_RGB> : Loader3<false> {};
+template <> struct Loader<UG_PF_YUV444> : Loader3<true> {};
+
+// ---- RGBA: 16 B per block row, alpha ignored (compress_dxt1_fp.glsl:41 reads .rgb) ----
+template <>
+struct Loader<UG_PF_RGBA> {
+        static constexpr int kBlocks = 1;
+        uint4 w[4];
+        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        w[r] = ((const uint4 *) (src + (long) rows[r] * pitch))[unit_x];
+                }
+        }
+        __device__ __forceinline__ void block(int, Px16 &p) const
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t q[4] = { w[r].x, w[r].y, w[r].z, w[r].w };
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                                p.a[4 * r + c] = byte_f(q[c], 0);
+                                p.b[4 * r + c] = byte_f(q[c], 1);
+                                p.c[4 * r + c] = byte_f(q[c], 2);
+                        }
+                }
+        }
+};
+
+// ---- UYVY: 8 B per block row; chroma replicated (yuv422_to_yuv444.glsl:22-30) ----
+template <bool CONVERT>
+struct LoaderUYVY {
+        static constexpr int kBlocks = 1;
+        uint2 w[4];
+        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        w[r] = ((const uint2 *) (src + (long) rows[r] * pitch))[unit_x];
+                }
+        }
+        __device__ __forceinline__ void block(int, Px16 &p) const
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t q[2] = { w[r].x, w[r].y };
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                                const float u = byte_f(q[k], 0), y0 = byte_f(q[k], 1);
+                                const float v = byte_f(q[k], 2), y1 = byte_f(q[k], 3);
+                                const int i = 4 * r + 2 * k;
+                                if (CONVERT) {
+                                        yuv_pair_to_rgb(y0, y1, u, v, p, i);
+                                } else { // DXT1_YUV: YCbCr stored in the RGB channels (dxt_encoder.c:318-323)
+                                        p.a[i] = y0; p.b[i] = u; p.c[i] = v;
+                                        p.a[i + 1] = y1; p.b[i + 1] = u; p.c[i + 1] = v;
+                                }
+                        }
+                }
+        }
+};
+template <> struct Loader<UG_PF_UYVY> : LoaderUYVY<true> {};
+template <> struct Loader<UG_PF_UYVY_RAW> : LoaderUYVY<false> {};
+
+// ---- v210: 12 px = 3 blocks = 32 B per row.  The 10-bit samples come in UYVY order, three
+// per little-endian word; the reference converts to 8-bit UYVY by >>2 first
+// (vc_copylinev210, pixfmt_conv.c:86-130, selected by cuda_dxt.cpp:162) ----
+template <>
+struct Loader<UG_PF_V210> {
+        static constexpr int kBlocks = 3;
+        uint32_t w[4][8];
+        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint4 *p = (const uint4 *) (src + (long) rows[r] * pitch) + unit_x * 2;
+                        const uint4 q0 = p[0], q1 = p[1];
+                        w[r][0] = q0.x; w[r][1] = q0.y; w[r][2] = q0.z; w[r][3] = q0.w;
+                        w[r][4] = q1.x; w[r][5] = q1.y; w[r][6] = q1.z; w[r][7] = q1.w;
+                }
+        }
+        // sample s (0..23) of the row, top 8 bits of the 10-bit field
+        __device__ __forceinline__ float samp(int r, int s) const
+        {
+                return (float) ((w[r][s / 3] >> (10 * (s % 3) + 2)) & 0xffu) * kInv255;
+        }
+        __device__ __forceinline__ void block(int k, Px16 &p) const
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) {
+                                const int s = 8 * k + 4 * pr; // U Y0 V Y1
+                                yuv_pair_to_rgb(samp(r, s + 1), samp(r, s + 3), samp(r, s), samp(r, s + 2), p, 4 * r + 2 * pr);
+                        }
+                }
+        }
+};
+
+// ---------------------------------------------------------------------------------------
+// DXT5-YCoCg block encode (compress_dxt5ycocg_fp.glsl:326-377 / cuda_dxt.cu:471-509)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
+{
+        // ConvertRGBToYCoCg (glsl:27-34).  2.0*x and *0.25 are exact (powers of two), so
+        //   (r + 2g + b)*0.25      : fma(g,2,r) == r + 2g bit-for-bit (2g exact)
+        //   (2r - 2b)*0.25 + off   : 2r-2b == 2(r-b) exactly, *0.25 exact -> (r-b)*0.5 + off,
+        //                            and fma(r-b, 0.5, off) == ((r-b)*0.5) + off (product exact)
+        //   (-r + 2g - b)*0.25+off : fma(g,2,-r) == -r + 2g ; fma(t,0.25,off) == t*0.25 + off
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+                const float r = p.a[i], g = p.b[i], b = p.c[i];
+                const float t = __builtin_fmaf(g, 2.0f, r);
+                p.a[i] = (t + b) * 0.25f;
+                p.b[i] = __builtin_fmaf(r - b, 0.5f, kOffset);
+                p.c[i] = __builtin_fmaf(__builtin_fmaf(g, 2.0f, -r) - b, 0.25f, kOffset);
+        }
+        float *Y = p.a, *Co = p.b, *Cg = p.c;
+
+        // FindMinMaxColorsBox (glsl:69-78)
+        float mnY = Y[0], mxY = Y[0], mnCo = Co[0], mxCo = Co[0], mnCg = Cg[0], mxCg = Cg[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) {
+                mnY = fminf(mnY, Y[i]);    mxY = fmaxf(mxY, Y[i]);
+                mnCo = fminf(mnCo, Co[i]); mxCo = fmaxf(mxCo, Co[i]);
+                mnCg = fminf(mnCg, Cg[i]); mxCg = fmaxf(mxCg, Cg[i]);
+        }
+
+        // SelectYCoCgDiagonal (glsl:169-183): sequential sum, i = 0..15
+        {
+                const float midx = (mxCo + mnCo) * 0.5f, midy = (mxCg + mnCg) * 0.5f;
+                float cov = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                        const float tx = Co[i] - midx, ty = Cg[i] - midy;
+                        cov = cov + tx * ty;
+                }
+                if (cov < 0.0f) {
+                        const float t = mxCg; mxCg = mnCg; mnCg = t;
+                }
+        }
+
+        // ScaleYCoCg (glsl:150-167)
+        uint32_t scale = 1;
+        {
+                const float m0 = fmaxf(fabsf(mnCo - kOffset), fabsf(mnCg - kOffset));
+                const float m1 = fmaxf(fabsf(mxCo - kOffset), fabsf(mxCg - kOffset));
+                const float m = fmaxf(m0, m1);
+                if (m < (float) (64.0 / 255.0)) scale = 2;
+                if (m < (float) (32.0 / 255.0)) scale = 4;
+        }
+
+        // EmitEndPointsYCoCgDXT5 (glsl:185-215) with InsetCoCgBBox (glsl:92-97).
+        // "/ 16.0" and "/ float(scale)" are multiplications by exact powers of two.
+        const float fs = (float) scale, rfs = 1.0f / fs;
+        uint32_t w_end;
+        float cmx[2], cmn[2];
+        {
+                const float q[2] = { 31.0f, 63.0f };
+                const float mx_in[2] = { mxCo, mxCg }, mn_in[2] = { mnCo, mnCg };
+                uint32_t imax[2], imin[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                        float a = (mx_in[k] - kOffset) * fs + kOffset;
+                        float b = (mn_in[k] - kOffset) * fs + kOffset;
+                        const float inset = (a - b) * 0.0625f - kInsetC;
+                        b = clamp01(b + inset);
+                        a = clamp01(a - inset);
+                        imax[k] = (uint32_t) roundf(a * q[k]);
+                        imin[k] = (uint32_t) roundf(b * q[k]);
+                }
+                w_end = ((imax[0] << 11) | (imax[1] << 5) | (scale - 1)) |
+                        (((imin[0] << 11) | (imin[1] << 5) | (scale - 1)) << 16);
+                imax[0] = (imax[0] << 3) | (imax[0] >> 2);
+                imax[1] = (imax[1] << 2) | (imax[1] >> 4);
+                imin[0] = (imin[0] << 3) | (imin[0] >> 2);
+                imin[1] = (imin[1] << 2) | (imin[1] >> 4);
+                const float inv255 = (float) (1.0 / 255.0);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                        cmx[k] = ((float) imax[k] * inv255 - kOffset) * rfs + kOffset;
+                        cmn[k] = ((float) imin[k] * inv255 - kOffset) * rfs + kOffset;
+                }
+        }
+
+        // EmitIndicesYCoCgDXT5 (glsl:217-250)
+        uint32_t w_cidx = 0;
+        {
+                const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
+                const float w1 = 1.0f - q1, w2 = 1.0f - q2;
+                float cx[4], cy[4];
+                cx[0] = cmx[0]; cy[0] = cmx[1];
+                cx[1] = cmn[0]; cy[1] = cmn[1];
+                cx[2] = lerp_w(cx[0], cx[1], w1, q1); cy[2] = lerp_w(cy[0], cy[1], w1, q1);
+                cx[3] = lerp_w(cx[0], cx[1], w2, q2); cy[3] = lerp_w(cy[0], cy[1], w2, q2);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                        float d[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                                const float tx = Co[i] - cx[k], ty = Cg[i] - cy[k];
+                                d[k] = tx * tx + ty * ty;
+                        }
+                        w_cidx |= palette_index(d[0], d[1], d[2], d[3]) << (2 * i);
+                }
+        }
+
+        // InsetYBBox (glsl:86-91)
+        {
+                const float inset = (mxY - mnY) * 0.03125f - kInsetY;
+                mnY = clamp01(mnY + inset);
+                mxY = clamp01(mxY - inset);
+        }
+        // EmitAlphaEndPointsYCoCgDXT5 (glsl:252-259)
+        uint32_t w0 = ((uint32_t) roundf(mnY * 255.0f) << 8) | (uint32_t) roundf(mxY * 255.0f);
+        uint32_t w1 = 0;
+        // EmitAlphaIndicesYCoCgDXT5 (glsl:262-312)
+        {
+                const float inv7 = (float) (1.0 / 7.0);
+                const float mid = (mxY - mnY) / 14.0f; // IEEE division (not a power of two)
+                float ab[8];
+                ab[1] = mnY + mid;
+#pragma unroll
+                for (int k = 2; k <= 7; k++) {
+                        ab[k] = ((float) (8 - k) * mxY + (float) (k - 1) * mnY) * inv7 + mid;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                        const float a = Y[i];
+                        uint32_t idx = 1;
+#pragma unroll
+                        for (int k = 1; k <= 7; k++) {
+                                idx += (a <= ab[k]) ? 1u : 0u;
+                        }
+                        idx &= 7u;
+                        idx ^= (2u > idx) ? 1u : 0u;
+                        if (i < 5) {
+                                w0 |= idx << (3 * i + 16);
+                        } else if (i == 5) {
+                                w0 |= idx << 31; // upper two bits fall off
+                                w1 = idx >> 1;
+                        } else {
+                                w1 |= idx << (3 * i - 16);
+                        }
+                }
+        }
+        return make_uint4(w0, w1, w_end, w_cidx);
+}
+
+// ---------------------------------------------------------------------------------------
+// DXT1 block encode, normative = GLSL (compress_dxt1_fp.glsl:177-229)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
+{
+        const float *R = p.a, *G = p.b, *B = p.c;
+        float mn[3] = { R[0], G[0], B[0] }, mx[3] = { R[0], G[0], B[0] };
+#pragma unroll
+        for (int i = 1; i < 16; i++) {
+                mn[0] = fminf(mn[0], R[i]); mx[0] = fmaxf(mx[0], R[i]);
+                mn[1] = fminf(mn[1], G[i]); mx[1] = fmaxf(mx[1], G[i]);
+                mn[2] = fminf(mn[2], B[i]); mx[2] = fmaxf(mx[2], B[i]);
+        }
+        // SelectDiagonal (glsl:69-90)
+        {
+                const float cx = (mn[0] + mx[0]) * 0.5f, cy = (mn[1] + mx[1]) * 0.5f, cz = (mn[2] + mx[2]) * 0.5f;
+                float cov_x = 0.0f, cov_y = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                        const float tx = R[i] - cx, ty = G[i] - cy, tz = B[i] - cz;
+                        cov_x = cov_x + tx * tz;
+                        cov_y = cov_y + ty * tz;
+                }
+                if (cov_x < 0.0f) { const float t = mx[0]; mx[0] = mn[0]; mn[0] = t; }
+                if (cov_y < 0.0f) { const float t = mx[1]; mx[1] = mn[1]; mn[1] = t; }
+        }
+        // InsetBBox (glsl:92-97), RoundAndExpand + EmitEndPointsDXT1 (glsl:99-126)
+        uint32_t cm[3], cn[3];
+        {
+                const float q[3] = { 31.0f, 63.0f, 31.0f };
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                        const float inset = (mx[k] - mn[k]) * 0.0625f - kInsetC;
+                        const float lo = clamp01(mn[k] + inset), hi = clamp01(mx[k] - inset);
+                        cm[k] = (uint32_t) roundf(hi * q[k]);
+                        cn[k] = (uint32_t) roundf(lo * q[k]);
+                }
+        }
+        const uint32_t code_max = (cm[0] << 11) | (cm[1] << 5) | cm[2];
+        const uint32_t code_min = (cn[0] << 11) | (cn[1] << 5) | cn[2];
+        cm[0] = (cm[0] << 3) | (cm[0] >> 2); cm[2] = (cm[2] << 3) | (cm[2] >> 2); cm[1] = (cm[1] << 2) | (cm[1] >> 4);
+        cn[0] = (cn[0] << 3) | (cn[0] >> 2); cn[2] = (cn[2] << 3) | (cn[2] >> 2); cn[1] = (cn[1] << 2) | (cn[1] >> 4);
+        const float inv255 = (float) (1.0 / 255.0);
+        const bool swap = code_max < code_min;
+        float c0[3], c1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+                const float hi = (float) cm[k] * inv255, lo = (float) cn[k] * inv255;
+                c0[k] = swap ? lo : hi;
+                c1[k] = swap ? hi : lo;
+        }
+        const uint32_t w_end = swap ? (code_min | (code_max << 16)) : (code_max | (code_min << 16));
+
+        // EmitIndicesDXT1 (glsl:128-161)
+        uint32_t w_idx = 0;
+        {
+                const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
+                const float w1 = 1.0f - q1, w2 = 1.0f - q2;
+                float c2[3], c3[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                        c2[k] = lerp_w(c0[k], c1[k], w1, q1);
+                        c3[k] = lerp_w(c0[k], c1[k], w2, q2);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                        float d[4];
+                        const float *c[4] = { c0, c1, c2, c3 };
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                                const float tx = R[i] - c[k][0], ty = G[i] - c[k][1], tz = B[i] - c[k][2];
+                                d[k] = (tx * tx + ty * ty) + tz * tz;
+                        }
+                        w_idx |= palette_index(d[0], d[1], d[2], d[3]) << (2 * i);
+                }
+        }
+        return make_uint2(w_end, w_idx);
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel: grid-stride free, 1-D; unit = Loader::kBlocks consecutive blocks of a block row
+// ---------------------------------------------------------------------------------------
+template <int IN, int OUT, bool MIRROR>
+__global__ __launch_bounds__(256) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                         int units_per_row, int block_rows, int height,
+                                                         long pitch, long total_units, size_t src_frame_stride,
+                                                         size_t dst_frame_stride)
+{
+        using L = Loader<IN>;
+        const long u = (long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (u >= total_units) {
+                return;
+        }
+        const int units_per_frame = units_per_row * block_rows;
+        const int frame = (int) (u / units_per_frame);
+        const int uf = (int) (u - (long) frame * units_per_frame);
+        const int by = uf / units_per_row;
+        const int ux = uf - by * units_per_row;
+
+        src += (size_t) frame * src_frame_stride;
+        dst += (size_t) frame * dst_frame_stride;
+
+        int rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+                const int y = 4 * by + r;
+                rows[r] = MIRROR ? height - 1 - y : y; // cuda_dxt.cu:652-655
+        }
+        L ld;
+        ld.load(src, pitch, ux, rows);
+
+        // block raster order idx = bx + (w/4)*by (cuda_dxt.cu:633)
+        const long block0 = (long) by * units_per_row * L::kBlocks + (long) ux * L::kBlocks;
+#pragma unroll
+        for (int k = 0; k < L::kBlocks; k++) {
+                Px16 p;
+                ld.block(k, p);
+                if (OUT == UG_DXT5_YCOCG) {
+                        ((uint4 *) dst)[block0 + k] = encode_dxt5ycocg(p);
+                } else {
+                        ((uint2 *) dst)[block0 + k] = encode_dxt1(p);
+                }
+        }
+}
+
+template <int IN, int OUT>
+int launch(const void *src, void *dst, int w, int h, int pitch, int frames, size_t sfs, size_t dfs, hipStream_t st)
+{
+        using L = Loader<IN>;
+        const bool mirror = h < 0;
+        if (mirror) h = -h;
+        const int upr = (w / 4) / L::kBlocks, brows = h / 4;
+        const long total = (long) upr * brows * frames;
+        if (total == 0) return UG_HIP_SUCCESS;
+        const dim3 block(256), grid((unsigned) ((total + 255) / 256));
+        if (mirror) {
+                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, true>), grid, block, 0, st, (const uint8_t *) src,
+                                   (uint8_t *) dst, upr, brows, h, (long) pitch, total, sfs, dfs);
+        } else {
+                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, false>), grid, block, 0, st, (const uint8_t *) src,
+                                   (uint8_t *) dst, upr, brows, h, (long) pitch, total, sfs, dfs);
+        }
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+template <int IN>
+int launch_out(ug_dxt_t out, const void *src, void *dst, int w, int h, int pitch, int frames, size_t sfs, size_t dfs,
+               hipStream_t st)
+{
+        switch (out) {
+        case UG_DXT1: return launch<IN, UG_DXT1>(src, dst, w, h, pitch, frames, sfs, dfs, st);
+        case UG_DXT5_YCOCG: return launch<IN, UG_DXT5_YCOCG>(src, dst, w, h, pitch, frames, sfs, dfs, st);
+        }
+        return UG_HIP_EUNSUPP;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height)
+{
+        if (height < 0) height = -height;
+        const size_t px = (size_t) width * (size_t) height; // dxt_util.h:59-67
+        return out == UG_DXT1 ? px / 2 : px;
+}
+
+int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
+                            int src_pitch, int frames, size_t src_frame_stride, size_t dst_frame_stride,
+                            ug_hip_stream_t stream)
+{
+        const int ah = height < 0 ? -height : height;
+        if (!src || !dst || width <= 0 || ah == 0 || (width & 3) || (ah & 3) || frames < 0 ||
+            (15 & (uintptr_t) src) || (15 & (uintptr_t) dst)) { // cuda_dxt.cu:745
+                ug::set_last_error_msg("ug_hip_dxt_encode: bad size or alignment");
+                return UG_HIP_EINVAL;
+        }
+        if (src_pitch == 0) {
+                src_pitch = ug::linesize(in, width);
+        }
+        if (src_pitch <= 0 || (src_pitch & 3)) {
+                ug::set_last_error_msg("ug_hip_dxt_encode: bad pitch / unsupported input format");
+                return src_pitch <= 0 ? UG_HIP_EUNSUPP : UG_HIP_EINVAL;
+        }
+        if (frames > 1 && ((src_frame_stride & 15) || (dst_frame_stride & 15))) {
+                ug::set_last_error_msg("ug_hip_dxt_encode: frame strides must be multiples of 16");
+                return UG_HIP_EINVAL;
+        }
+        hipStream_t st = (hipStream_t) stream;
+        switch (in) {
+        case UG_PF_RGB: return launch_out<UG_PF_RGB>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        case UG_PF_RGBA:
+                if (src_pitch & 15) break;
+                return launch_out<UG_PF_RGBA>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        case UG_PF_YUV444: return launch_out<UG_PF_YUV444>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        case UG_PF_UYVY:
+                if (src_pitch & 7) break;
+                return launch_out<UG_PF_UYVY>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        case UG_PF_UYVY_RAW:
+                if (src_pitch & 7) break;
+                return launch_out<UG_PF_UYVY_RAW>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        case UG_PF_V210:
+                if ((src_pitch & 15) || width % 12) break;
+                return launch_out<UG_PF_V210>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        default:
+                ug::set_last_error_msg("ug_hip_dxt_encode: unsupported input format");
+                return UG_HIP_EUNSUPP;
+        }
+        ug::set_last_error_msg("ug_hip_dxt_encode: pitch/width not aligned for this input format");
+        return UG_HIP_EINVAL;
+}
+
+int ug_hip_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height, int src_pitch,
+                      ug_hip_stream_t stream)
+{
+        return ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, 1, 0, 0, stream);
+}
+
+// cuda_dxt.h-shaped entry points
+int ug_hip_rgb_to_dxt1(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_RGB, UG_DXT1, src, out, sx, sy, 0, s); }
+int ug_hip_yuv_to_dxt1(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_YUV444, UG_DXT1, src, out, sx, sy, 0, s); }
+int ug_hip_rgb_to_dxt6(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_RGB, UG_DXT5_YCOCG, src, out, sx, sy, 0, s); }
+int ug_hip_yuv_to_dxt6(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_YUV444, UG_DXT5_YCOCG, src, out, sx, sy, 0, s); }
+
+int ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
+                           int src_pitch, int frames, size_t sfs, size_t dfs, int iters, ug_hip_stream_t stream,
+                           float *ms_per_launch)
+{
+        if (!ms_per_launch || iters <= 0) return UG_HIP_EINVAL;
+        hipStream_t st = (hipStream_t) stream;
+        hipEvent_t e0, e1;
+        UG_HIP_TRY(hipEventCreate(&e0));
+        UG_HIP_TRY(hipEventCreate(&e1));
+        int rc = ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, frames, sfs, dfs, stream); // warm
+        if (rc == UG_HIP_SUCCESS) {
+                (void) hipEventRecord(e0, st);
+                for (int i = 0; i < iters && rc == UG_HIP_SUCCESS; i++) {
+                        rc = ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, frames, sfs, dfs, stream);
+                }
+                (void) hipEventRecord(e1, st);
+                hipError_t e = hipEventSynchronize(e1);
+                if (e != hipSuccess) {
+                        ug::set_last_error(e, "hipEventSynchronize");
+                        rc = UG_HIP_ERUNTIME;
+                } else {
+                        float ms = 0;
+                        (void) hipEventElapsedTime(&ms, e0, e1);
+                        *ms_per_launch = ms / iters;
+                }
+        }
+        (void) hipEventDestroy(e0);
+        (void) hipEventDestroy(e1);
+        return rc;
+}
+
+} // extern "C"

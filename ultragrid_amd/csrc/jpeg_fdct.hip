@@ -1,0 +1,253 @@
+// jpeg_fdct.hip -- JPEG 8x8 forward DCT + quantisation on gfx950.
+//
+// UltraGrid gets this stage from the external libgpujpeg (gpujpeg_encoder_encode,
+// src/video_compress/gpujpeg.cpp:624); it is not in the reference tree.  The stage is
+// specified in oracle/jpeg_oracle.c (level shift, AAN float FDCT rows-then-columns, fp32
+// reciprocal quantiser with the AAN scale folded in, rintf, zig-zag) and this file is
+// bit-identical to that specification: same operation order, no FMA contraction
+// (-ffp-contract=off).
+//
+// Mapping: one lane owns one 8x8 block (64 fp32 registers).  Consecutive lanes own
+// consecutive blocks of a block row, so each of the 8 row loads of a wave is 64 x 8 B of
+// contiguous plane memory.  The stage is HBM-bound (about 12 lane-ops per pixel against
+// 1 B read + 2 B written per sample): see DESIGN.md.
+#include "ug_common.h"
+
+namespace {
+
+__device__ __forceinline__ void aan_1d(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6, float &d7)
+{
+        constexpr float c4 = 0.707106781f, c6 = 0.382683433f, c2mc6 = 0.541196100f, c2pc6 = 1.306562965f;
+        const float t0 = d0 + d7, t7 = d0 - d7;
+        const float t1 = d1 + d6, t6 = d1 - d6;
+        const float t2 = d2 + d5, t5 = d2 - d5;
+        const float t3 = d3 + d4, t4 = d3 - d4;
+        // even part
+        float t10 = t0 + t3;
+        const float t13 = t0 - t3;
+        float t11 = t1 + t2;
+        float t12 = t1 - t2;
+        d0 = t10 + t11;
+        d4 = t10 - t11;
+        const float z1 = (t12 + t13) * c4;
+        d2 = t13 + z1;
+        d6 = t13 - z1;
+        // odd part
+        t10 = t4 + t5;
+        t11 = t5 + t6;
+        t12 = t6 + t7;
+        const float z5 = (t10 - t12) * c6;
+        const float z2 = c2mc6 * t10 + z5;
+        const float z4 = c2pc6 * t12 + z5;
+        const float z3 = t11 * c4;
+        const float z11 = t7 + z3, z13 = t7 - z3;
+        d5 = z13 + z2;
+        d3 = z13 - z2;
+        d1 = z11 + z4;
+        d7 = z11 - z4;
+}
+
+__device__ __forceinline__ void fdct8x8(float (&b)[64])
+{
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+                aan_1d(b[8 * r], b[8 * r + 1], b[8 * r + 2], b[8 * r + 3], b[8 * r + 4], b[8 * r + 5], b[8 * r + 6], b[8 * r + 7]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+                aan_1d(b[c], b[8 + c], b[16 + c], b[24 + c], b[32 + c], b[40 + c], b[48 + c], b[56 + c]);
+        }
+}
+
+// zig-zag scan (T.81 Figure A.6): kZig[k] = natural index of the k-th coefficient
+__device__ constexpr uint8_t kZig[64] = {
+        0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+};
+
+// quantise + zig-zag + store one block (128 B)
+__device__ __forceinline__ void quant_store(const float (&b)[64], const float *__restrict__ div, int16_t *__restrict__ out)
+{
+        uint32_t w[32];
+#pragma unroll
+        for (int k = 0; k < 64; k += 2) {
+                const int i0 = kZig[k], i1 = kZig[k + 1];
+                const int q0 = (int) rintf(b[i0] * div[i0]);
+                const int q1 = (int) rintf(b[i1] * div[i1]);
+                w[k / 2] = ((uint32_t) q0 & 0xffffu) | ((uint32_t) q1 << 16);
+        }
+        uint4 *o = (uint4 *) out;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+        }
+}
+
+__global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__restrict__ plane, int pitch, int width, int height,
+                                                               int blocks_w, long total, const float *__restrict__ div,
+                                                               int16_t *__restrict__ out, float *__restrict__ coef)
+{
+        const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= total) return;
+        const int by = (int) (idx / blocks_w), bx = (int) (idx - (long) by * blocks_w);
+        float b[64];
+        const bool interior = 8 * bx + 8 <= width && 8 * by + 8 <= height && !(pitch & 7) && !(7 & (uintptr_t) plane);
+        if (interior) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                        const uint2 q = *(const uint2 *) (plane + (long) (8 * by + r) * pitch + 8 * bx);
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                                b[8 * r + c] = (float) ((int) ((q.x >> (8 * c)) & 0xff) - 128);
+                                b[8 * r + 4 + c] = (float) ((int) ((q.y >> (8 * c)) & 0xff) - 128);
+                        }
+                }
+        } else { // edge replication
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                        const int y = min(8 * by + r, height - 1);
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                                const int x = min(8 * bx + c, width - 1);
+                                b[8 * r + c] = (float) ((int) plane[(long) y * pitch + x] - 128);
+                        }
+                }
+        }
+        fdct8x8(b);
+        if (coef) {
+#pragma unroll
+                for (int i = 0; i < 64; i++) coef[64 * idx + i] = b[i];
+        }
+        quant_store(b, div, out + 64 * idx);
+}
+
+// Fused UYVY -> 4:2:0 -> FDCT+quant.  Tasks [0, n_luma) are luma blocks (8 rows x 16 B of UYVY),
+// tasks [n_luma, n_luma + 2*n_chroma) are Cb then Cr blocks (16 rows x 32 B, vertical
+// (a+b+1)/2 average as uyvy_to_i420, to_planar.c:343-378).  Edges replicate.
+__global__ __launch_bounds__(256) void uyvy_jpeg420_kernel(const uint8_t *__restrict__ src, int pitch, int width, int height,
+                                                           int mcu_w, int mcu_h, const float *__restrict__ div,
+                                                           int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
+                                                           int16_t *__restrict__ out_cr)
+{
+        const long n_luma = 4L * mcu_w * mcu_h, n_chroma = (long) mcu_w * mcu_h;
+        const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= n_luma + 2 * n_chroma) return;
+        float b[64];
+        const int cw = (width + 1) / 2, ch = (height + 1) / 2; // I420 chroma plane size
+        if (idx < n_luma) {
+                const int bw = 2 * mcu_w;
+                const int by = (int) (idx / bw), bx = (int) (idx - (long) by * bw);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                        const int y = min(8 * by + r, height - 1);
+                        const uint8_t *row = src + (long) y * pitch;
+                        if (8 * bx + 8 <= width && !(pitch & 15) && !(15 & (uintptr_t) src)) {
+                                const uint4 q = *(const uint4 *) (row + 16 * bx);
+                                const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                        b[8 * r + 2 * k] = (float) ((int) ((w[k] >> 8) & 0xff) - 128);
+                                        b[8 * r + 2 * k + 1] = (float) ((int) (w[k] >> 24) - 128);
+                                }
+                        } else {
+#pragma unroll
+                                for (int c = 0; c < 8; c++) {
+                                        const int x = min(8 * bx + c, width - 1);
+                                        b[8 * r + c] = (float) ((int) row[2 * x + 1] - 128);
+                                }
+                        }
+                }
+                fdct8x8(b);
+                quant_store(b, div, out_y + 64 * idx);
+        } else {
+                long t = idx - n_luma;
+                const int comp = t >= n_chroma; // 0 = Cb, 1 = Cr
+                t -= comp ? n_chroma : 0;
+                const int by = (int) (t / mcu_w), bx = (int) (t - (long) by * mcu_w);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                        const int cy = min(8 * by + r, ch - 1);
+                        const int y0 = 2 * cy, y1 = min(2 * cy + 1, height - 1); // odd height: last line doubled
+                        const uint8_t *r0 = src + (long) y0 * pitch, *r1 = src + (long) y1 * pitch;
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                                const int cx = min(8 * bx + c, cw - 1);
+                                const int a = r0[4 * cx + 2 * comp], bb = r1[4 * cx + 2 * comp];
+                                b[8 * r + c] = (float) (((a + bb + 1) >> 1) - 128);
+                        }
+                }
+                fdct8x8(b);
+                quant_store(b, div + 64, (comp ? out_cr : out_cb) + 64 * t);
+        }
+}
+
+// T.81 Annex K tables (natural order) -- same data as oracle/jpeg_oracle.c by construction of the
+// standard; kept separately so the product never links the oracle.
+const uint8_t kLuma[64] = {
+        16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+        18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99,
+};
+const uint8_t kChroma[64] = {
+        17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+        99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+};
+const double kAan[8] = { 1.0, 1.387039845, 1.306562965, 1.175875602, 1.0, 0.785694958, 0.541196100, 0.275899379 };
+
+} // namespace
+
+extern "C" {
+
+void ug_hip_jpeg_qtable(int quality, int comp, uint8_t table[64])
+{
+        if (quality < 1) quality = 1;
+        if (quality > 100) quality = 100;
+        const int s = quality < 50 ? 5000 / quality : 200 - quality * 2; // IJG quality rule
+        const uint8_t *base = comp == 0 ? kLuma : kChroma;
+        for (int i = 0; i < 64; i++) {
+                const int t = (base[i] * s + 50) / 100;
+                table[i] = t < 1 ? 1 : (t > 255 ? 255 : t);
+        }
+}
+
+void ug_hip_jpeg_divisors(const uint8_t q[64], float div[64])
+{
+        for (int r = 0; r < 8; r++) {
+                for (int c = 0; c < 8; c++) {
+                        div[8 * r + c] = (float) (1.0 / ((double) q[8 * r + c] * kAan[r] * kAan[c] * 8.0));
+                }
+        }
+}
+
+int ug_hip_jpeg_fdct_quant_plane(const void *plane, int pitch, int width, int height, int blocks_w, int blocks_h,
+                                 const float *div, int16_t *out, float *coef, ug_hip_stream_t stream)
+{
+        if (!plane || !div || !out || width <= 0 || height <= 0 || blocks_w * 8 < width || blocks_h * 8 < height ||
+            (15 & (uintptr_t) out) || pitch < width) {
+                ug::set_last_error_msg("ug_hip_jpeg_fdct_quant_plane: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        const long total = (long) blocks_w * blocks_h;
+        hipLaunchKernelGGL(fdct_quant_plane_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                           (const uint8_t *) plane, pitch, width, height, blocks_w, total, div, out, coef);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_uyvy_to_jpeg420_coeffs(const void *src, int src_pitch, int width, int height, const float *div,
+                                  int16_t *out_y, int16_t *out_cb, int16_t *out_cr, ug_hip_stream_t stream)
+{
+        if (!src || !div || !out_y || !out_cb || !out_cr || width <= 0 || height <= 0 ||
+            ((uintptr_t) out_y | (uintptr_t) out_cb | (uintptr_t) out_cr) & 15) {
+                ug::set_last_error_msg("ug_hip_uyvy_to_jpeg420_coeffs: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
+        const int mcu_w = (width + 15) / 16, mcu_h = (height + 15) / 16;
+        const long total = 6L * mcu_w * mcu_h;
+        hipLaunchKernelGGL(uyvy_jpeg420_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                           (const uint8_t *) src, src_pitch, width, height, mcu_w, mcu_h, div, out_y, out_cb, out_cr);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+} // extern "C"

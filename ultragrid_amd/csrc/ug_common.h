@@ -1,0 +1,55 @@
+// ug_common.h -- internal helpers shared by the HIP translation units of libug_mi355x.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ug_mi355x.h"
+
+namespace ug {
+
+// thread-local copy of the last HIP error text (cuda_wrapper.cu:115-118 keeps the same state)
+void set_last_error(hipError_t e, const char *what);
+void set_last_error_msg(const char *msg);
+
+#define UG_HIP_TRY(expr)                                                     \
+        do {                                                                 \
+                hipError_t e_ = (expr);                                      \
+                if (e_ != hipSuccess) {                                      \
+                        ug::set_last_error(e_, #expr);                       \
+                        return UG_HIP_ERUNTIME;                              \
+                }                                                            \
+        } while (0)
+
+// check the asynchronous launch error right after a <<<>>> launch
+#define UG_HIP_LAUNCH_CHECK()                                                \
+        do {                                                                 \
+                hipError_t e_ = hipGetLastError();                           \
+                if (e_ != hipSuccess) {                                      \
+                        ug::set_last_error(e_, "kernel launch");             \
+                        return UG_HIP_ERUNTIME;                              \
+                }                                                            \
+        } while (0)
+
+static inline int linesize(ug_pixfmt_t f, int width)
+{
+        // video_codec.c:120-206 (block bytes / pixels, h_align) and :507-521
+        int bb, bp, ha;
+        switch (f) {
+        case UG_PF_RGBA: bb = 4; bp = 1; ha = 1; break;
+        case UG_PF_UYVY:
+        case UG_PF_UYVY_RAW:
+        case UG_PF_YUYV: bb = 4; bp = 2; ha = 2; break;
+        case UG_PF_RGB:
+        case UG_PF_BGR:
+        case UG_PF_YUV444: bb = 3; bp = 1; ha = 1; break;
+        case UG_PF_V210: bb = 16; bp = 6; ha = 48; break;
+        case UG_PF_RG48: bb = 6; bp = 1; ha = 1; break;
+        default: return 0;
+        }
+        width = (width + ha - 1) / ha * ha;
+        return (width + bp - 1) / bp * bb;
+}
+
+} // namespace ug

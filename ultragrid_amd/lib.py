@@ -1,0 +1,95 @@
+"""ctypes binding of libug_mi355x.so (include/ug_mi355x.h).
+
+This is the test / bench driver's view of the C ABI; UltraGrid itself binds the same
+symbols from C++ (ultragrid_amd/module/).  There is NO fallback: if the HIP library is
+missing or a symbol is absent, import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libug_mi355x.so")
+
+# ug_pixfmt_t
+PF_NONE, PF_RGBA, PF_UYVY, PF_YUYV, PF_RGB, PF_BGR, PF_V210, PF_RG48, PF_YUV444, PF_UYVY_RAW = range(10)
+PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "BGR": PF_BGR, "v210": PF_V210,
+            "RG48": PF_RG48, "YUV444": PF_YUV444, "UYVY_RAW": PF_UYVY_RAW}
+# ug_dxt_t
+DXT1, DXT5_YCOCG = 1, 6
+
+SUCCESS, EINVAL, EUNSUPP, ERUNTIME = 0, -1, -2, -3
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# every symbol include/ug_mi355x.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ug_hip_abi_version": (_i, []),
+    "ug_hip_device_count": (_i, [C.POINTER(_i)]),
+    "ug_hip_set_device": (_i, [_i]),
+    "ug_hip_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "ug_hip_free": (_i, [_vp]),
+    "ug_hip_malloc_host": (_i, [C.POINTER(_vp), _sz]),
+    "ug_hip_free_host": (_i, [_vp]),
+    "ug_hip_memcpy": (_i, [_vp, _vp, _sz, _i]),
+    "ug_hip_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ug_hip_stream_create": (_i, [C.POINTER(_vp)]),
+    "ug_hip_stream_destroy": (_i, [_vp]),
+    "ug_hip_stream_sync": (_i, [_vp]),
+    "ug_hip_last_error_string": (C.c_char_p, []),
+    "ug_hip_time_dxt_encode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _i, _vp, C.POINTER(C.c_float)]),
+    "ug_hip_dxt_encode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "ug_hip_dxt_encode_batch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _vp]),
+    "ug_hip_dxt_size": (_sz, [_i, _i, _i]),
+    "ug_hip_rgb_to_dxt1": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ug_hip_yuv_to_dxt1": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ug_hip_rgb_to_dxt6": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ug_hip_yuv_to_dxt6": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ug_hip_yuv422_to_yuv444": (_i, [_vp, _vp, _i, _vp]),
+    "ug_hip_pixfmt_supported": (_i, [_i, _i]),
+    "ug_hip_pixfmt_convert": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ug_hip_linesize": (_i, [_i, _i]),
+    "ug_hip_uyvy_to_i420": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_v210_to_p010le": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_jpeg_qtable": (None, [_i, _i, _vp]),
+    "ug_hip_jpeg_divisors": (None, [_vp, _vp]),
+    "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ug_hip_uyvy_to_jpeg420_coeffs": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class UgHipError(RuntimeError):
+    def __init__(self, rc: int, what: str):
+        self.rc = rc
+        super().__init__(f"{what}: rc={rc}: {last_error()}")
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C ultragrid_amd/csrc` (there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if lib.ug_hip_abi_version() != 1:
+            raise ImportError("libug_mi355x.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().ug_hip_last_error_string().decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != SUCCESS:
+        raise UgHipError(rc, what)
