@@ -76,12 +76,22 @@ struct SwapYUYV { // pixfmt_conv.c:136-198
                 d[0] = b; d[1] = a; d[2] = e; d[3] = c;
         }
 };
+// hipcc (ROCm 7.2) fuses "clamp(x >> 14, 0, 255) | clamp(y >> 14, 0, 255) << 8" into gfx950's
+// v_ashr_pk_u8_i32 and then ORs further bytes into the result assuming its upper 16 bits are zero;
+// on MI355X the instruction leaves the destination's upper half unchanged, so stale bytes leak into
+// the packed word (caught by tests/test_gpu_pixfmt.py).  Making the clamped value opaque keeps the
+// clamp (v_med3_i32) and the byte packing as separate, correct instructions at zero run-time cost.
+__device__ __forceinline__ int opaque(int v)
+{
+        asm volatile("" : "+v"(v));
+        return v;
+}
 __device__ __forceinline__ void yuv_to_rgb8(int y, int u, int v, uint8_t *o)
 {
         // copylineYUVtoRGB, pixfmt_conv.c:1065-1094: clamp [0,255]
-        o[0] = clampi((y + v * kCfs8.r_cr) >> kBase, 0, 255);
-        o[1] = clampi((y + u * kCfs8.g_cb + v * kCfs8.g_cr) >> kBase, 0, 255);
-        o[2] = clampi((y + u * kCfs8.b_cb) >> kBase, 0, 255);
+        o[0] = opaque(clampi((y + v * kCfs8.r_cr) >> kBase, 0, 255));
+        o[1] = opaque(clampi((y + u * kCfs8.g_cb + v * kCfs8.g_cr) >> kBase, 0, 255));
+        o[2] = opaque(clampi((y + u * kCfs8.b_cb) >> kBase, 0, 255));
 }
 struct UYVYtoRGB { // pixfmt_conv.c:1102-1108
         static __device__ __host__ int units(int dl) { return dl / 6; }
