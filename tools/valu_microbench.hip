@@ -1,0 +1,103 @@
+// valu_microbench.hip -- issue-rate microbenchmark for the VALU instruction classes the DXT
+// encoders are made of (gfx950).  Build: hipcc --offload-arch=gfx950 -O3 -o valu_microbench valu_microbench.hip
+// Prints wave-instructions per cycle per CU (assuming 2.4 GHz; the measured ratio between rows is what matters).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#define REP8(x) x x x x x x x x
+#define BODY(ASM)                                                                                         \
+        for (int it = 0; it < iters; it++) {                                                              \
+                REP8(asm volatile(ASM : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                                   : "v"(b0), "v"(b1) : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)  \
+        }
+
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+template <int K>
+__global__ __launch_bounds__(256) void bench(float *out, int iters)
+{
+        float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+        float b0 = 1.0001f, b1 = 0.9999f;
+        if (K == 0) BODY("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %9\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %9\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %9")
+        if (K == 1) BODY("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %9, %8\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %9, %8\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %9, %8\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %9, %8")
+        if (K == 2) BODY("v_min3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %9, %8\n v_min3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %9, %8\n v_min3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %9, %8\n v_min3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %9, %8")
+        if (K == 3) BODY("v_cmp_gt_f32 s[20:21], %0, %8\n v_cmp_gt_f32 s[22:23], %1, %9\n v_cmp_gt_f32 s[24:25], %2, %8\n v_cmp_gt_f32 s[26:27], %3, %9\n v_cmp_gt_f32 s[20:21], %4, %8\n v_cmp_gt_f32 s[22:23], %5, %9\n v_cmp_gt_f32 s[24:25], %6, %8\n v_cmp_gt_f32 s[26:27], %7, %9")
+        if (K == 4) BODY("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %9, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %9, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %9, vcc")
+        if (K == 5) BODY("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte1 %1, %1\n v_cvt_f32_ubyte2 %2, %2\n v_cvt_f32_ubyte3 %3, %3\n v_cvt_f32_ubyte0 %4, %4\n v_cvt_f32_ubyte1 %5, %5\n v_cvt_f32_ubyte2 %6, %6\n v_cvt_f32_ubyte3 %7, %7")
+        if (K == 6) BODY("v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_addc_co_u32 %4, vcc, %4, %4, vcc\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n v_addc_co_u32 %7, vcc, %7, %7, vcc")
+        if (K == 7) BODY("v_lshl_or_b32 %0, %0, 2, %8\n v_lshl_or_b32 %1, %1, 2, %9\n v_lshl_or_b32 %2, %2, 2, %8\n v_lshl_or_b32 %3, %3, 2, %9\n v_lshl_or_b32 %4, %4, 2, %8\n v_lshl_or_b32 %5, %5, 2, %9\n v_lshl_or_b32 %6, %6, 2, %8\n v_lshl_or_b32 %7, %7, 2, %9")
+        if (K == 8) BODY("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %9\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %9")
+        if (K == 9) BODY("v_cmp_gt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_gt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n v_cmp_gt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_gt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc")
+
+        if (K == 10) BODY("v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %9\n v_min_f32 %2, %2, %8\n v_max_f32 %3, %3, %9\n v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %9\n v_min_f32 %6, %6, %8\n v_max_f32 %7, %7, %9")
+        if (K == 11) BODY("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %9\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %9\n v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %9\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %9")
+        if (K == 12) BODY("v_cmp_gt_f32 vcc, %0, %8\n v_cmp_gt_f32 vcc, %1, %9\n v_cmp_gt_f32 vcc, %2, %8\n v_cmp_gt_f32 vcc, %3, %9\n v_cmp_gt_f32 vcc, %4, %8\n v_cmp_gt_f32 vcc, %5, %9\n v_cmp_gt_f32 vcc, %6, %8\n v_cmp_gt_f32 vcc, %7, %9")
+        if (K == 13) BODY("v_cmp_gt_f32 s[20:21], %0, %8\n v_cndmask_b32 %1, %1, %9, s[20:21]\n v_cmp_gt_f32 s[22:23], %2, %8\n v_cndmask_b32 %3, %3, %9, s[22:23]\n v_cmp_gt_f32 s[24:25], %4, %8\n v_cndmask_b32 %5, %5, %9, s[24:25]\n v_cmp_gt_f32 s[26:27], %6, %8\n v_cndmask_b32 %7, %7, %9, s[26:27]")
+        if (K == 14) BODY("v_and_b32 %0, %0, %8\n v_or_b32 %1, %1, %9\n v_and_b32 %2, %2, %8\n v_or_b32 %3, %3, %9\n v_xor_b32 %4, %4, %8\n v_or_b32 %5, %5, %9\n v_and_b32 %6, %6, %8\n v_xor_b32 %7, %7, %9")
+        if (K == 15) BODY("v_mov_b32 %0, %8\n v_mov_b32 %1, %9\n v_mov_b32 %2, %8\n v_mov_b32 %3, %9\n v_mov_b32 %4, %8\n v_mov_b32 %5, %9\n v_mov_b32 %6, %8\n v_mov_b32 %7, %9")
+        if (K == 16) BODY("v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %9, %8\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %9, %8\n v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %9, %8\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %9, %8")
+        if (K == 17) BODY("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %9, %8\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %9, %8\n v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %9, %8\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %9, %8")
+        if (K == 18) BODY("v_bfe_u32 %0, %0, 8, 8\n v_bfe_u32 %1, %1, 8, 8\n v_bfe_u32 %2, %2, 8, 8\n v_bfe_u32 %3, %3, 8, 8\n v_bfe_u32 %4, %4, 8, 8\n v_bfe_u32 %5, %5, 8, 8\n v_bfe_u32 %6, %6, 8, 8\n v_bfe_u32 %7, %7, 8, 8")
+        if (K == 19) BODY("v_cvt_u32_f32 %0, %0\n v_cvt_u32_f32 %1, %1\n v_cvt_u32_f32 %2, %2\n v_cvt_u32_f32 %3, %3\n v_cvt_u32_f32 %4, %4\n v_cvt_u32_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_u32_f32 %7, %7")
+        if (K == 20) BODY("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %9, %8\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %9, %8\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %9, %8\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %9, %8")
+        if (K == 21) BODY("v_fract_f32 %0, %0\n v_rndne_f32 %1, %1\n v_fract_f32 %2, %2\n v_trunc_f32 %3, %3\n v_fract_f32 %4, %4\n v_floor_f32 %5, %5\n v_fract_f32 %6, %6\n v_rndne_f32 %7, %7")
+        if (K == 22) BODY("v_add_f32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %9 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %9 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %9 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %9 row_shr:1 row_mask:0xf bank_mask:0xf")
+        if (K == 23) BODY("v_cmp_gt_f32 s[20:21], %0, %8\n s_and_b64 s[22:23], s[20:21], s[24:25]\n v_cmp_gt_f32 s[24:25], %2, %8\n s_or_b64 s[26:27], s[22:23], s[24:25]\n v_cmp_gt_f32 s[20:21], %4, %8\n s_and_b64 s[22:23], s[20:21], s[26:27]\n v_cmp_gt_f32 s[24:25], %6, %8\n s_or_b64 s[26:27], s[22:23], s[24:25]")
+        if (K == 24) BODY("v_add_f32 %0, %0, %8\n v_cmp_gt_f32 s[20:21], %1, %9\n v_add_f32 %2, %2, %8\n v_cmp_gt_f32 s[22:23], %3, %9\n v_add_f32 %4, %4, %8\n v_cmp_gt_f32 s[24:25], %5, %9\n v_add_f32 %6, %6, %8\n v_cmp_gt_f32 s[26:27], %7, %9")
+        if (K == 25) BODY("v_max3_f32 %0, %0, %8, %9\n v_add_f32 %1, %1, %9\n v_min3_f32 %2, %2, %8, %9\n v_add_f32 %3, %3, %9\n v_max3_f32 %4, %4, %8, %9\n v_add_f32 %5, %5, %9\n v_min3_f32 %6, %6, %8, %9\n v_add_f32 %7, %7, %9")
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// packed: operands are register pairs
+#define BODYP(ASM)                                                                                        \
+        for (int it = 0; it < iters; it++) {                                                              \
+                REP8(asm volatile(ASM : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(q0), "v"(q1));)      \
+        }
+template <int K>
+__global__ __launch_bounds__(256) void benchp(float *out, int iters)
+{
+        float2_ p0 = { (float) threadIdx.x, 1 }, p1 = p0 + 1.0f, p2 = p0 + 2.0f, p3 = p0 + 3.0f;
+        float2_ q0 = { 1.0001f, 0.9999f }, q1 = { 0.9999f, 1.0001f };
+        if (K == 0) BODYP("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n v_pk_add_f32 %0, %0, %5\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %5\n v_pk_add_f32 %3, %3, %4")
+        if (K == 1) BODYP("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %5, %4\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %5, %4\n v_pk_fma_f32 %0, %0, %5, %4\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %5, %4\n v_pk_fma_f32 %3, %3, %4, %5")
+        if (K == 2) BODYP("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %5\n v_pk_mul_f32 %0, %0, %5\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %5\n v_pk_mul_f32 %3, %3, %4")
+
+        if (K == 3) BODYP("v_pk_add_f32 %0, %0, %4 op_sel:[0,0] op_sel_hi:[1,0]\n v_pk_add_f32 %1, %1, %5 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %2, %2, %4 op_sel:[0,0] op_sel_hi:[1,0]\n v_pk_add_f32 %3, %3, %5 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %0, %0, %5 op_sel:[0,0] op_sel_hi:[1,0]\n v_pk_add_f32 %1, %1, %4 op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %2, %2, %5 op_sel:[0,0] op_sel_hi:[1,0]\n v_pk_add_f32 %3, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]")
+        if (K == 4) BODYP("v_pk_mov_b32 %0, %4, %5\n v_pk_mov_b32 %1, %5, %4\n v_pk_mov_b32 %2, %4, %5\n v_pk_mov_b32 %3, %5, %4\n v_pk_mov_b32 %0, %5, %4\n v_pk_mov_b32 %1, %4, %5\n v_pk_mov_b32 %2, %5, %4\n v_pk_mov_b32 %3, %4, %5")
+        out[blockIdx.x * blockDim.x + threadIdx.x] = p0.x + p1.y + p2.x + p3.y;
+}
+
+template <class F>
+static void run(const char *name, F launch)
+{
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        launch(10);
+        hipDeviceSynchronize();
+        const int iters = 20000;
+        hipEventRecord(e0);
+        launch(iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double waves = 256.0 * 8 * 4;               // blocks * waves per block
+        const double instr = waves * iters * 64.0;         // 8 reps x 8 instructions
+        const double per_s = instr / (ms * 1e-3);
+        printf("%-28s %8.3f ms  %7.2f G wave-instr/s  = %5.3f wave-instr/clk/CU @2.4GHz (%.1f T lane-ops/s)\n", name, ms, per_s / 1e9,
+               per_s / 256 / 2.4e9, per_s * 64 / 1e12);
+}
+
+int main()
+{
+        float *out;
+        hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+        const dim3 g(256 * 8), b(256);
+#define R(name, K) run(name, [&](int it) { hipLaunchKernelGGL(bench<K>, g, b, 0, 0, out, it); })
+#define RP(name, K) run(name, [&](int it) { hipLaunchKernelGGL(benchp<K>, g, b, 0, 0, out, it); })
+        R("v_add_f32", 0); R("v_mul_f32", 8); R("v_fma_f32", 1); R("v_min3/max3_f32", 2); R("v_cmp_gt_f32 (sgpr dst)", 3);
+        R("v_cndmask_b32", 4); R("v_cvt_f32_ubyteN", 5); R("v_addc_co_u32", 6); R("v_lshl_or_b32", 7); R("v_cmp+v_cndmask (vcc dep)", 9);
+        R("v_min/max_f32 (2-op)", 10); R("v_sub_f32", 11); R("v_cmp_gt_f32 e32 (vcc)", 12); R("v_cmp(sgpr)+v_cndmask(sgpr)", 13); R("v_and/or/xor_b32", 14); R("v_mov_b32", 15); R("v_perm_b32", 16); R("v_med3_f32", 17); R("v_bfe_u32", 18); R("v_cvt_u32_f32", 19); R("v_fmac_f32 (VOP2)", 20); R("v_fract/rndne/trunc/floor", 21); R("v_add_f32_dpp row_shr", 22); R("v_cmp + s_and/s_or (1:1)", 23); R("v_add + v_cmp (1:1)", 24); R("v_min3/max3 + v_add (1:1)", 25);
+        RP("v_pk_add_f32", 0); RP("v_pk_add_f32 op_sel bcast", 3); RP("v_pk_mov_b32", 4); RP("v_pk_mul_f32", 2); RP("v_pk_fma_f32", 1);
+        return 0;
+}
