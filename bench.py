@@ -108,29 +108,23 @@ def main() -> None:
     def step():
         codec.dxt_encode_batch(lib.PF_UYVY, lib.DXT5_YCOCG, src, W, H, F, frame_bytes, dst=dst)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    from ultragrid_amd import shard
     for _ in range(args.warmup):
         step()
-    barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                      # same stream the kernel is launched on (torch current stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration (back-to-back launches)
+    count = [0]
 
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    def timed_step():
+        if count[0] == 0:
+            ev0.record()              # same stream the kernel is launched on (torch current stream)
+        step()
+        count[0] += 1
+        if count[0] == args.steps:
+            ev1.record()
+
+    # barrier + synchronize on both sides of exactly K steps, MAX over ranks (ultragrid_amd/shard.py)
+    wall = shard.timed_steps(timed_step, args.steps, torch.cuda.synchronize, dist, device="cuda")
+    kern_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration (back-to-back launches on one stream)
 
     if rank == 0:
         px_per_step = F * W * H * world

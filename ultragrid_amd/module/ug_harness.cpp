@@ -1,0 +1,89 @@
+/**
+ * @file ug_harness.cpp
+ * Drop-in proof: links UltraGrid's OWN compress framework + plugin registry
+ * (src/video_compress.cpp, src/lib_common.cpp and their support objects, compiled from
+ * /root/reference by ultragrid_amd/module/Makefile -- recipe of SURVEY.md 8(b) [probe]) with our
+ * module object, then drives the public API exactly as rxtx.cpp does:
+ *
+ *     compress_init(nullptr, "dxt:DXT5", &c); compress_frame(c, frame); compress_pop(c); compress_done(c);
+ *
+ * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles]
+ *        ug_harness list
+ * The compressed tile(s) are written to <out.bin> (tile after tile); a test compares them with the
+ * CPU oracle.  Exit code 0 = OK, 2 = module refused (no GPU / bad cfg), 3 = frame dropped.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "debug.h"
+#include "host.h"
+#include "lib_common.h"
+#include "types.h"
+#include "video_codec.h"
+#include "video_compress.h"
+#include "video_frame.h"
+
+int main(int argc, char **argv)
+{
+        if (argc == 2 && strcmp(argv[1], "list") == 0) {
+                list_modules(LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION, true);
+                return 0;
+        }
+        if (argc < 7) {
+                fprintf(stderr, "usage: %s <cfg> <codec> <w> <h> <in.raw> <out.bin> [tiles]\n       %s list\n", argv[0], argv[0]);
+                return 1;
+        }
+        const char *cfg = argv[1];
+        const codec_t codec = get_codec_from_name(argv[2]);
+        const unsigned w = atoi(argv[3]), h = atoi(argv[4]);
+        const unsigned tiles = argc > 7 ? atoi(argv[7]) : 1;
+        if (codec == VIDEO_CODEC_NONE) {
+                fprintf(stderr, "unknown codec %s\n", argv[2]);
+                return 1;
+        }
+        struct video_desc desc{};
+        desc.width = w; desc.height = h; desc.color_spec = codec; desc.fps = 30; desc.interlacing = PROGRESSIVE;
+        desc.tile_count = tiles;
+        struct video_frame *f = vf_alloc_desc_data(desc);
+        FILE *in = fopen(argv[5], "rb");
+        if (!in) { perror("in"); return 1; }
+        for (unsigned t = 0; t < tiles; t++) {
+                if (fread(f->tiles[t].data, 1, f->tiles[t].data_len, in) != f->tiles[t].data_len) {
+                        fprintf(stderr, "short read (%u bytes per tile expected)\n", f->tiles[t].data_len);
+                        return 1;
+                }
+        }
+        fclose(in);
+
+        struct compress_state *c = nullptr;
+        int rc = compress_init(nullptr, cfg, &c);
+        if (rc != 0) {
+                fprintf(stderr, "compress_init(\"%s\") rc=%d\n", cfg, rc);
+                return 2;
+        }
+        std::shared_ptr<video_frame> frame(f, vf_free);
+        compress_frame(c, frame);
+        std::shared_ptr<video_frame> out = compress_pop(c);
+        if (!out) {
+                fprintf(stderr, "frame dropped\n");
+                compress_done(c);
+                return 3;
+        }
+        FILE *o = fopen(argv[6], "wb");
+        if (!o) { perror("out"); return 1; }
+        for (unsigned t = 0; t < out->tile_count; t++) {
+                fwrite(out->tiles[t].data, 1, out->tiles[t].data_len, o);
+        }
+        fclose(o);
+        printf("OK codec=%s tiles=%u tile0=%ux%u len=%u compress_ms=%.3f\n", get_codec_name(out->color_spec), out->tile_count,
+               out->tiles[0].width, out->tiles[0].height, out->tiles[0].data_len,
+               (double) (out->compress_end - out->compress_start) / 1e6);
+        out.reset();
+        compress_frame(c, {}); // poison pill, as rxtx does on exit
+        compress_pop(c);
+        compress_done(c);
+        return 0;
+}

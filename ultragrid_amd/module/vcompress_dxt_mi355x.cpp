@@ -1,0 +1,255 @@
+/**
+ * @file vcompress_dxt_mi355x.cpp
+ * UltraGrid video_compress module "dxt" (-c dxt[:DXT1|:DXT5][:dev=<n>]) backed by the MI355X
+ * kernel library libug_mi355x.so (include/ug_mi355x.h).
+ *
+ * This is the host-side half of the drop-in boundary.  It is compiled
+ * against UltraGrid's own headers and registers through lib_common.cpp exactly like the
+ * reference's GPU DXT modules do (src/video_compress/cuda_dxt.cpp:278-290,
+ * src/video_compress/dxt_glsl.cpp:319-332): tile API, one state per tile, lazy reconfigure on
+ * format change, empty shared_ptr as poison pill / error.
+ *
+ * What is different from cuda_dxt.cpp by design (MI355X-first):
+ *  - no CPU decoder_t pre-pass (cuda_dxt.cpp:206-220) and no 4:2:2->4:4:4 intermediate
+ *    (cuda_dxt.cpp:223-232): the frame is uploaded in its wire format (RGB / RGBA / UYVY / v210,
+ *    YUYV and BGR via a device-side swizzle) and unpacked + colour-converted + encoded by ONE
+ *    fused kernel;
+ *  - one HIP stream per module instance, asynchronous H2D -> kernel -> D2H, a single stream
+ *    synchronisation per frame (cuda_dxt.cu:759 synchronises after every launch);
+ *  - the device index comes from the module option dev=<n> (default 0); UltraGrid's -D list is capped
+ *    at MAX_CUDA_DEVICES = 4 (host.h:97), too small for an 8-GPU MI355X node.
+ *
+ * There is deliberately no CPU fallback: if the GPU path cannot take a format, the module says
+ * so and drops the frame (video_compress.cpp:394-398 semantics).
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "debug.h"
+#include "host.h"
+#include "lib_common.h"
+#include "types.h"
+#include "utils/video_frame_pool.h"
+#include "video_codec.h"
+#include "video_compress.h"
+#include "video_frame.h"
+
+#include "../../include/ug_mi355x.h"
+#include "ug_codec_map.h"
+
+#define MOD_NAME "[DXT MI355X] "
+
+#define CHECK_HIP(cmd, msg, action) \
+        if ((cmd) != UG_HIP_SUCCESS) { \
+                MSG(ERROR, "%s: %s\n", msg, ug_hip_last_error_string()); \
+                action; \
+        }
+
+namespace {
+
+/// pinned host memory for the compressed output frames (cuda_dxt.cpp:68-83 does the same with CUDA)
+struct hip_pinned_allocator : public video_frame_pool_allocator {
+        void *allocate(size_t size) override {
+                void *ptr = nullptr;
+                if (ug_hip_malloc_host(&ptr, size) != UG_HIP_SUCCESS) {
+                        return nullptr;
+                }
+                return ptr;
+        }
+        void deallocate(void *ptr) override { ug_hip_free_host(ptr); }
+        video_frame_pool_allocator *clone() const override { return new hip_pinned_allocator(*this); }
+};
+
+struct state_video_compress_dxt_mi355x {
+        struct video_desc saved_desc{};
+        int               device = 0;
+        codec_t           out_codec = DXT1;
+        ug_dxt_t          out_fmt = UG_DXT1;
+        ug_pixfmt_t       in_fmt = UG_PF_NONE;      ///< format the encoder kernel reads
+        ug_pixfmt_t       pre_in = UG_PF_NONE;      ///< != NONE: device-side swizzle first (YUYV->UYVY, BGR->RGB)
+        ug_hip_stream_t   stream = nullptr;
+        void             *dev_in = nullptr;         ///< uploaded frame, wire format
+        void             *dev_pre = nullptr;        ///< swizzle result (only if pre_in != NONE)
+        void             *dev_out = nullptr;        ///< DXT blocks
+        size_t            in_len = 0, out_len = 0;
+        video_frame_pool  pool{0, hip_pinned_allocator()};
+};
+
+void cleanup(state_video_compress_dxt_mi355x *s)
+{
+        for (void **p : { &s->dev_in, &s->dev_pre, &s->dev_out }) {
+                if (*p) {
+                        ug_hip_free(*p);
+                        *p = nullptr;
+                }
+        }
+}
+
+void usage()
+{
+        printf("MI355X DXT compression usage:\n"
+               "\t-c dxt[:DXT1|:DXT5][:dev=<index>]\n"
+               "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg\n"
+               "\t\tdev  - HIP device index (default 0)\n");
+}
+
+void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
+{
+        (void) parent;
+        auto *s = new state_video_compress_dxt_mi355x();
+        std::string cfg = fmt ? fmt : "";
+        size_t pos = 0;
+        while (pos <= cfg.size() && !cfg.empty()) {
+                size_t end = cfg.find(':', pos);
+                std::string tok = cfg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+                if (strcasecmp(tok.c_str(), "DXT5") == 0) {
+                        s->out_codec = DXT5;
+                        s->out_fmt = UG_DXT5_YCOCG;
+                } else if (strcasecmp(tok.c_str(), "DXT1") == 0) {
+                        s->out_codec = DXT1;
+                        s->out_fmt = UG_DXT1;
+                } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
+                        s->device = atoi(tok.c_str() + 4);
+                } else if (tok == "help") {
+                        usage();
+                        delete s;
+                        return INIT_NOERR;
+                } else if (!tok.empty()) {
+                        MSG(ERROR, "unknown option: %s\n", tok.c_str());
+                        usage();
+                        delete s;
+                        return nullptr;
+                }
+                if (end == std::string::npos) {
+                        break;
+                }
+                pos = end + 1;
+        }
+        if (ug_hip_set_device(s->device) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "cannot use HIP device %d: %s\n", s->device, ug_hip_last_error_string());
+                delete s;
+                return nullptr;
+        }
+        return s;
+}
+
+bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
+{
+        cleanup(s);
+        s->pre_in = UG_PF_NONE;
+        const ug_pixfmt_t wire = ug_pixfmt_from_codec(desc.color_spec);
+        switch (wire) {
+        case UG_PF_RGB: case UG_PF_RGBA: case UG_PF_UYVY: case UG_PF_V210:
+                s->in_fmt = wire;
+                break;
+        case UG_PF_YUYV: s->pre_in = wire; s->in_fmt = UG_PF_UYVY; break;
+        case UG_PF_BGR:  s->pre_in = wire; s->in_fmt = UG_PF_RGB;  break;
+        default:
+                MSG(ERROR, "Unsupported codec: %s (GPU path takes RGB, RGBA, BGR, UYVY, YUYV, v210)\n",
+                    get_codec_name(desc.color_spec));
+                return false;
+        }
+        if (desc.width % 4 != 0 || desc.height % 4 != 0 || (s->in_fmt == UG_PF_V210 && desc.width % 12 != 0)) {
+                MSG(ERROR, "Frame size %ux%u is not a multiple of the 4x4 block (v210: 12x4)\n", desc.width, desc.height);
+                return false;
+        }
+        if (get_bits_per_component(desc.color_spec) > 8) {
+                MSG(NOTICE, "Converting from %d to 8 bits on the GPU.\n", get_bits_per_component(desc.color_spec));
+        }
+        s->in_len = (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
+        s->out_len = ug_hip_dxt_size(s->out_fmt, (int) desc.width, (int) desc.height);
+        CHECK_HIP(ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING), "Could not allocate device input buffer", return false);
+        if (s->pre_in != UG_PF_NONE) {
+                CHECK_HIP(ug_hip_malloc(&s->dev_pre, s->in_len + MAX_PADDING), "Could not allocate device swizzle buffer", return false);
+        }
+        CHECK_HIP(ug_hip_malloc(&s->dev_out, s->out_len), "Could not allocate device output buffer", return false);
+
+        struct video_desc compressed_desc = desc;
+        compressed_desc.color_spec = s->out_codec;
+        compressed_desc.tile_count = 1;
+        s->pool.reconfigure(compressed_desc, s->out_len);
+        return true;
+}
+
+std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_ptr<video_frame> tx)
+{
+        if (!tx) {
+                return {}; // poison pill (video_compress.cpp:345-347)
+        }
+        auto *s = static_cast<state_video_compress_dxt_mi355x *>(state);
+        CHECK_HIP(ug_hip_set_device(s->device), "set device", return {}); // tile callbacks run on pool threads
+
+        if (!video_desc_eq_excl_param(video_desc_from_frame(tx.get()), s->saved_desc, PARAM_TILE_COUNT)) {
+                if (configure_with(s, video_desc_from_frame(tx.get()))) {
+                        s->saved_desc = video_desc_from_frame(tx.get());
+                } else {
+                        MSG(ERROR, "Reconfiguration failed!\n");
+                        s->saved_desc = {};
+                        return {};
+                }
+        }
+        const int w = (int) tx->tiles[0].width, h = (int) tx->tiles[0].height;
+
+        CHECK_HIP(ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
+                  "H2D copy failed", return {});
+        const void *enc_src = s->dev_in;
+        if (s->pre_in != UG_PF_NONE) {
+                CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->in_fmt, s->dev_in, s->dev_pre, w, h, 0, 0, 0, 8, 16, s->stream),
+                          "device swizzle failed", return {});
+                enc_src = s->dev_pre;
+        }
+        CHECK_HIP(ug_hip_dxt_encode(s->in_fmt, s->out_fmt, enc_src, s->dev_out, w, h, 0, s->stream),
+                  "Encoding failed", return {});
+
+        std::shared_ptr<video_frame> out = s->pool.get_frame();
+        CHECK_HIP(ug_hip_memcpy_async(out->tiles[0].data, s->dev_out, s->out_len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream),
+                  "D2H copy failed", return {});
+        CHECK_HIP(ug_hip_stream_sync(s->stream), "stream sync failed", return {});
+        out->tiles[0].data_len = (unsigned int) s->out_len;
+        return out;
+}
+
+void dxt_mi355x_compress_done(void *state)
+{
+        auto *s = static_cast<state_video_compress_dxt_mi355x *>(state);
+        ug_hip_set_device(s->device);
+        cleanup(s);
+        if (s->stream) {
+                ug_hip_stream_destroy(s->stream);
+        }
+        delete s;
+}
+
+compress_module_info get_dxt_mi355x_module_info()
+{
+        compress_module_info module_info;
+        module_info.name = "dxt";
+        for (const char *c : { "DXT1", "DXT5" }) {
+                codec codec_info;
+                codec_info.name = c;
+                codec_info.priority = 400;
+                codec_info.encoders.emplace_back(encoder{ "default", std::string(":") + c });
+                module_info.codecs.emplace_back(std::move(codec_info));
+        }
+        return module_info;
+}
+
+const struct video_compress_info dxt_mi355x_info = {
+        dxt_mi355x_compress_init,
+        dxt_mi355x_compress_done,
+        NULL,
+        dxt_mi355x_compress_tile,
+        NULL,
+        NULL,
+        NULL,
+        NULL,
+        get_dxt_mi355x_module_info,
+};
+
+// "dxt" is a free name in the reference (it registers rtdxt, cuda_dxt, gpujpeg/jpeg)
+REGISTER_MODULE(dxt, &dxt_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+
+} // end of anonymous namespace

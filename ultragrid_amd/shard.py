@@ -1,0 +1,55 @@
+"""Frame sharding across GPUs: frames are independent, so N ranks encode disjoint frames
+with NO data-path collective.  Assignment and in-order delivery follow the reference's multi-GPU JPEG module
+(sequence numbers handed out at push, round-robin over devices, reorder on pop:
+src/video_compress/gpujpeg.cpp:643-676,688-722).  torch.distributed (RCCL on GPUs, gloo in CPU tests) is used
+only for the timing barrier and the max-over-ranks reduction."""
+from __future__ import annotations
+
+import time
+from typing import Callable, Iterable, List, Sequence, Tuple
+
+
+def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
+    """Sequence numbers handled by `rank`: seq % world == rank (round-robin, gpujpeg.cpp:661-675)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_frames, world))
+
+
+def reorder(parts: Iterable[Sequence[Tuple[int, object]]]) -> List[object]:
+    """Merge per-rank [(seq, payload), ...] lists back into sequence order (gpujpeg.cpp:688-722);
+    raises if a frame is missing or was encoded twice."""
+    merged = {}
+    for part in parts:
+        for seq, payload in part:
+            if seq in merged:
+                raise ValueError(f"frame {seq} encoded twice")
+            merged[seq] = payload
+    n = len(merged)
+    if sorted(merged) != list(range(n)):
+        raise ValueError("missing frames: " + str(sorted(set(range(max(merged, default=-1) + 1)) - set(merged))))
+    return [merged[i] for i in range(n)]
+
+
+def timed_steps(step: Callable[[], None], steps: int, sync: Callable[[], None], dist=None, device=None) -> float:
+    """Bench contract: barrier + device sync on both sides of exactly `steps` steps; returns the MAX wall time
+    over ranks (seconds)."""
+    import torch
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall
