@@ -15,7 +15,7 @@ needs_harness = pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_
 
 
 def _run(args, **kw):
-    return subprocess.run([HARNESS] + [str(a) for a in args], capture_output=True, text=True, timeout=120, **kw)
+    return subprocess.run([HARNESS] + [str(a) for a in args], capture_output=True, text=True, timeout=30, **kw)
 
 
 @needs_harness

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "debug.h"
@@ -65,13 +66,23 @@ int main(int argc, char **argv)
                 return 2;
         }
         std::shared_ptr<video_frame> frame(f, vf_free);
+        // sender-thread stand-in (rxtx.cpp:260-288): pops until the poison pill arrives
+        std::vector<std::shared_ptr<video_frame>> popped;
+        std::thread sender([&] {
+                while (std::shared_ptr<video_frame> f2 = compress_pop(c)) {
+                        popped.push_back(f2);
+                }
+        });
         compress_frame(c, frame);
-        std::shared_ptr<video_frame> out = compress_pop(c);
-        if (!out) {
+        frame.reset();
+        compress_frame(c, {}); // poison pill, as rxtx does on exit
+        sender.join();
+        if (popped.empty()) { // only the pill came back: the module dropped the frame (video_compress.cpp:394-398)
                 fprintf(stderr, "frame dropped\n");
                 compress_done(c);
                 return 3;
         }
+        std::shared_ptr<video_frame> out = popped[0];
         FILE *o = fopen(argv[6], "wb");
         if (!o) { perror("out"); return 1; }
         for (unsigned t = 0; t < out->tile_count; t++) {
@@ -82,8 +93,7 @@ int main(int argc, char **argv)
                out->tiles[0].width, out->tiles[0].height, out->tiles[0].data_len,
                (double) (out->compress_end - out->compress_start) / 1e6);
         out.reset();
-        compress_frame(c, {}); // poison pill, as rxtx does on exit
-        compress_pop(c);
+        popped.clear();
         compress_done(c);
         return 0;
 }
