@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table for every hot-path kernel (SURVEY.md 8(d) algorithmic bytes per pixel).
+Inputs resident in HBM, >= 256 MB working set per launch sequence (rotating distinct frames), HIP events on the
+launch stream.  Usage (GPU box): python tools/bench_kernels.py [--json out.json]"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from ultragrid_amd import codec, lib, synth
+
+L = lib
+PEAK = 8000.0
+
+
+def timeit(fn, iters=30, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def frames(fmt, w, h, n):
+    """n distinct frames of S2-like content derived cheaply from one base (row rotations)."""
+    base_fmt = {"YUV444": "RGB", "UYVY_RAW": "UYVY"}.get(fmt, fmt)
+    try:
+        one = synth.s2_video(base_fmt, w, min(h, 64))
+    except (ValueError, AssertionError):
+        one = synth.s1_random(base_fmt, w, min(h, 64))
+    ls = one.size // min(h, 64)
+    img = np.tile(one.reshape(min(h, 64), ls), ((h + 63) // 64, 1))[:h]
+    out = np.stack([np.roll(img, 4 * i, axis=0) for i in range(n)])
+    return torch.from_numpy(out.reshape(n, -1)).cuda()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json")
+    args = ap.parse_args()
+    lib.load()
+    rows = []
+
+    def add(name, w, h, n, bytes_per_px, ms):
+        px = w * h * n
+        gbs = bytes_per_px * px / (ms * 1e-3) / 1e9
+        rows.append({"kernel": name, "size": f"{w}x{h}x{n}", "ms_per_launch": round(ms, 4), "Mpix_s": round(px / ms / 1e3, 1),
+                     "fps": round(n / (ms * 1e-3), 1), "alg_B_per_px": bytes_per_px, "GB_s": round(gbs, 1), "frac_8TBs": round(gbs / PEAK, 4)})
+        print(f"{name:34s} {w}x{h} x{n:<3d} {ms:8.4f} ms  {px / ms / 1e3:10.1f} Mpx/s  {gbs:7.1f} GB/s  {gbs / PEAK:6.3f}", flush=True)
+
+    # ---- DXT encoders (batched launch over n frames) ----
+    for (fmt, pf, out, oid, w, h, n, bpp) in [
+        ("UYVY", L.PF_UYVY, "DXT5", L.DXT5_YCOCG, 3840, 2160, 16, 3.0),
+        ("UYVY", L.PF_UYVY, "DXT5", L.DXT5_YCOCG, 1920, 1080, 64, 3.0),
+        ("UYVY", L.PF_UYVY, "DXT5", L.DXT5_YCOCG, 7680, 4320, 4, 3.0),
+        ("v210", L.PF_V210, "DXT5", L.DXT5_YCOCG, 7680, 4320, 4, 16 / 6 + 1),
+        ("RGB", L.PF_RGB, "DXT1", L.DXT1, 1920, 1080, 64, 3.5),
+        ("RGB", L.PF_RGB, "DXT5", L.DXT5_YCOCG, 3840, 2160, 12, 4.0),
+        ("UYVY", L.PF_UYVY, "DXT1", L.DXT1, 3840, 2160, 16, 2.5),
+        ("RGBA", L.PF_RGBA, "DXT1", L.DXT1, 3840, 2160, 8, 4.5),
+    ]:
+        src = frames(fmt, w, h, n)
+        dst = torch.empty(codec.dxt_size(oid, w, h) * n, dtype=torch.uint8, device="cuda")
+        ms = timeit(lambda: codec.dxt_encode_batch(pf, oid, src, w, h, n, src.shape[1], dst=dst))
+        add(f"dxt_encode {fmt}->{out}", w, h, n, bpp, ms)
+        del src, dst
+
+    # ---- pixfmt (one frame per launch, rotating over n frames) ----
+    for (i, o, w, h, n, bpp) in [
+        ("v210", "UYVY", 7680, 4320, 6, 16 / 6 + 2), ("v210", "UYVY", 3840, 2160, 16, 16 / 6 + 2),
+        ("UYVY", "RGB", 3840, 2160, 16, 5.0), ("UYVY", "RGB", 1920, 1080, 64, 5.0), ("RGB", "UYVY", 3840, 2160, 12, 5.0),
+        ("v210", "RGB", 3840, 2160, 12, 16 / 6 + 3), ("RGBA", "RGB", 3840, 2160, 8, 7.0), ("UYVY", "YUYV", 3840, 2160, 16, 4.0),
+        ("UYVY", "RGBA", 3840, 2160, 12, 6.0), ("RGB", "RGBA", 3840, 2160, 8, 7.0), ("UYVY", "v210", 3840, 2160, 12, 2 + 16 / 6),
+    ]:
+        src = frames(i, w, h, n)
+        dsts = torch.empty((n, codec.linesize(L.PF_NAMES[o], w) * h), dtype=torch.uint8, device="cuda")
+        k = [0]
+        l = lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            j = k[0] % n
+            k[0] += 1
+            rc = l.ug_hip_pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], src[j].data_ptr(), dsts[j].data_ptr(), w, h, 0, 0, 0, 8, 16, st)
+            assert rc == 0
+        ms = timeit(run, iters=3 * n)
+        add(f"pixfmt {i}->{o}", w, h, 1, bpp, ms)
+        del src, dsts
+
+    # ---- planar + JPEG ----
+    w, h, n = 3840, 2160, 16
+    src = frames("UYVY", w, h, n)
+    y = torch.empty((h, w), dtype=torch.uint8, device="cuda"); u = torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"); v = torch.empty_like(u)
+    l = lib.load(); st = torch.cuda.current_stream().cuda_stream
+    k = [0]
+
+    def run_i420():
+        j = k[0] % n; k[0] += 1
+        assert l.ug_hip_uyvy_to_i420(src[j].data_ptr(), 0, y.data_ptr(), w, u.data_ptr(), w // 2, v.data_ptr(), w // 2, w, h, st) == 0
+    add("uyvy_to_i420", w, h, 1, 3.5, timeit(run_i420, iters=3 * n))
+    div = codec.jpeg_divisors_device(75, "cuda")
+    mw, mh = (w + 15) // 16, (h + 15) // 16
+    oy = torch.empty((4 * mw * mh, 64), dtype=torch.int16, device="cuda"); ocb = torch.empty((mw * mh, 64), dtype=torch.int16, device="cuda"); ocr = torch.empty_like(ocb)
+
+    def run_jpeg():
+        j = k[0] % n; k[0] += 1
+        assert l.ug_hip_uyvy_to_jpeg420_coeffs(src[j].data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), st) == 0
+    add("uyvy->420->FDCT+quant (fused)", w, h, 1, 5.0, timeit(run_jpeg, iters=3 * n))
+    plane = torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda")
+    outp = torch.empty((w // 8 * h // 8, 64), dtype=torch.int16, device="cuda")
+
+    def run_plane():
+        assert l.ug_hip_jpeg_fdct_quant_plane(plane.data_ptr(), w, w, h, w // 8, h // 8, div.data_ptr(), outp.data_ptr(), None, st) == 0
+    add("fdct_quant_plane (8-bit plane)", w, h, 1, 3.0, timeit(run_plane))
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,22 @@ __device__ __forceinline__ uint32_t palette_index(float d0, float d1, float d2, 
         return (b0 & b4) | (((b1 & b2) | (b0 & b3)) << 1);
 }
 
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc = 2*acc + bit in ONE VALU instruction: the boolean lives in an SGPR lane mask (it is the
+// result of v_cmp / SALU mask logic) and is consumed as the carry-in of v_addc_co_u32.
+typedef unsigned long long lanemask_t;
+// lane mask of a comparison: the SGPR pair v_cmp writes; mask logic on these runs on the scalar unit
+#define LANEMASK(cmp) __builtin_amdgcn_ballot_w64(cmp)
+__device__ __forceinline__ uint32_t shift_in(uint32_t acc, lanemask_t mask)
+{
+        lanemask_t carry_out;
+        uint32_t r;
+        asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(acc), "s"(mask));
+        return r;
+}
+
 // ---------------------------------------------------------------------------------------
 // colour front ends: bytes -> normalised (c0,c1,c2) per pixel
 // ---------------------------------------------------------------------------------------
@@ -298,7 +314,9 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 }
         }
 
-        // EmitIndicesYCoCgDXT5 (glsl:217-250)
+        // EmitIndicesYCoCgDXT5 (glsl:217-250).  The four squared distances of TWO horizontally adjacent
+        // pixels are computed with packed fp32 (v_pk_add/v_pk_mul: IEEE per component, so bit-identical to the
+        // scalar form); the kernel is VALU-issue bound and this halves the issue slots of its largest stage.
         uint32_t w_cidx = 0;
         {
                 const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
@@ -308,15 +326,30 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 cx[1] = cmn[0]; cy[1] = cmn[1];
                 cx[2] = lerp_w(cx[0], cx[1], w1, q1); cy[2] = lerp_w(cy[0], cy[1], w1, q1);
                 cx[3] = lerp_w(cx[0], cx[1], w2, q2); cy[3] = lerp_w(cy[0], cy[1], w2, q2);
+                f32x2 cx2[4], cy2[4];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                        float d[4];
+                for (int k = 0; k < 4; k++) {
+                        cx2[k] = (f32x2) { cx[k], cx[k] };
+                        cy2[k] = (f32x2) { cy[k], cy[k] };
+                }
+#pragma unroll
+                for (int i = 14; i >= 0; i -= 2) { // pixel pairs, last first: bits are shifted in MSB first
+                        const f32x2 co = { Co[i], Co[i + 1] }, cg = { Cg[i], Cg[i + 1] };
+                        f32x2 d[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                                const float tx = Co[i] - cx[k], ty = Cg[i] - cy[k];
+                                const f32x2 tx = co - cx2[k], ty = cg - cy2[k];
                                 d[k] = tx * tx + ty * ty;
                         }
-                        w_cidx |= palette_index(d[0], d[1], d[2], d[3]) << (2 * i);
+#pragma unroll
+                        for (int h = 1; h >= 0; h--) { // pixel i+1, then pixel i
+                                const float d0 = d[0][h], d1 = d[1][h], d2 = d[2][h], d3 = d[3][h];
+                                // glsl:237-244
+                                const lanemask_t b0 = LANEMASK(d0 > d3), b1 = LANEMASK(d1 > d2), b2 = LANEMASK(d0 > d2),
+                                                 b3 = LANEMASK(d1 > d3), b4 = LANEMASK(d2 > d3);
+                                w_cidx = shift_in(w_cidx, (b1 & b2) | (b0 & b3)); // bit 2i+1
+                                w_cidx = shift_in(w_cidx, b0 & b4);               // bit 2i
+                        }
                 }
         }
 
@@ -329,7 +362,7 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
         // EmitAlphaEndPointsYCoCgDXT5 (glsl:252-259)
         uint32_t w0 = ((uint32_t) roundf(mnY * 255.0f) << 8) | (uint32_t) roundf(mxY * 255.0f);
         uint32_t w1 = 0;
-        // EmitAlphaIndicesYCoCgDXT5 (glsl:262-312)
+        // EmitAlphaIndicesYCoCgDXT5 (glsl:262-312): count c = #{k : a <= ab_k}, index = f(c).
         {
                 const float inv7 = (float) (1.0 / 7.0);
                 const float mid = (mxY - mnY) / 14.0f; // IEEE division (not a power of two)
@@ -339,25 +372,60 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 for (int k = 2; k <= 7; k++) {
                         ab[k] = ((float) (8 - k) * mxY + (float) (k - 1) * mnY) * inv7 + mid;
                 }
+                // Thresholds in ascending order are T1..T7 = ab1, ab7, ab6, ab5, ab4, ab3, ab2 whenever they are
+                // monotone (always, except degenerate blocks whose clamped min == max).  For a monotone set the
+                // count is a 3-step binary search (3 compares + 4 selects instead of 7 compares + 7 adds); it is
+                // the SAME function of (a, ab[]) as the reference's linear count, so results stay bit-identical.
+                const float T1 = ab[1], T2 = ab[7], T3 = ab[6], T4 = ab[5], T5 = ab[4], T6 = ab[3], T7 = ab[2];
+                const bool mono = (T1 <= T2) & (T2 <= T3) & (T3 <= T4) & (T4 <= T5) & (T5 <= T6) & (T6 <= T7);
+                // raw counts, 3 bits per pixel: lo = px 0..9 (30 bits), hi = px 10..15 (18 bits)
+                uint32_t lo = 0, hi = 0;
+                if (__builtin_expect(__all(mono), 1)) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                        const float a = Y[i];
-                        uint32_t idx = 1;
-#pragma unroll
-                        for (int k = 1; k <= 7; k++) {
-                                idx += (a <= ab[k]) ? 1u : 0u;
+                        for (int i = 15; i >= 0; i--) {
+                                const float a = Y[i];
+                                const bool g4 = a <= T4;
+                                const float t2 = g4 ? T2 : T6, t15 = g4 ? T1 : T5, t37 = g4 ? T3 : T7;
+                                const bool g2 = a <= t2;
+                                const float t1 = g2 ? t15 : t37;
+                                const bool g1 = a <= t1;
+                                uint32_t &acc = i >= 10 ? hi : lo;
+                                acc = shift_in(acc, LANEMASK(g4));
+                                acc = shift_in(acc, LANEMASK(g2));
+                                acc = shift_in(acc, LANEMASK(g1));
                         }
-                        idx &= 7u;
-                        idx ^= (2u > idx) ? 1u : 0u;
-                        if (i < 5) {
-                                w0 |= idx << (3 * i + 16);
-                        } else if (i == 5) {
-                                w0 |= idx << 31; // upper two bits fall off
-                                w1 = idx >> 1;
-                        } else {
-                                w1 |= idx << (3 * i - 16);
+                } else { // reference form, 7 compares per pixel, for every lane of the wave (degenerate blocks only)
+                        // The empty asm keeps this a real branch: without it the compiler if-converts the two
+                        // sides and every block pays for both.
+                        asm volatile("; alpha linear fallback" ::: "memory");
+#pragma unroll
+                        for (int i = 15; i >= 0; i--) {
+                                const float a = Y[i];
+                                uint32_t c = 0;
+#pragma unroll
+                                for (int k = 1; k <= 7; k++) {
+                                        c += (a <= ab[k]) ? 1u : 0u;
+                                }
+                                uint32_t &acc = i >= 10 ? hi : lo;
+                                acc = (acc << 3) | c;
                         }
                 }
+                // index = ((c + 1) & 7) ^ (((c + 1) & 7) < 2)   (glsl:281-290), i.e. 0->0, 1..6 -> c+1, 7->1,
+                // applied to all 3-bit fields of a word at once: with field bits (c2 c1 c0)
+                //   i0 = (~c0 & (c1 | c2)) | (c0 & c1 & c2),  i1 = c1 ^ c0,  i2 = c2 ^ (c1 & c0)
+                auto map_fields = [](uint32_t w) {
+                        const uint32_t M = 0x09249249u; // bit 0 of every 3-bit field
+                        const uint32_t c0 = w & M, c1 = (w >> 1) & M, c2 = (w >> 2) & M;
+                        const uint32_t t = c1 & c0;
+                        const uint32_t i0 = ((c0 ^ M) & (c1 | c2)) | (t & c2);
+                        const uint32_t i1 = c1 ^ c0, i2 = c2 ^ t;
+                        return i0 | (i1 << 1) | (i2 << 2);
+                };
+                lo = map_fields(lo);
+                hi = map_fields(hi);
+                // 48-bit index field F = lo | hi << 30: word0[31:16] = F[15:0], word1 = F[47:16]  (glsl:291-308)
+                w0 |= lo << 16;
+                w1 = (lo >> 16) | (hi << 14);
         }
         return make_uint4(w0, w1, w_end, w_cidx);
 }
@@ -442,27 +510,26 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 }
 
 // ---------------------------------------------------------------------------------------
-// kernel: grid-stride free, 1-D; unit = Loader::kBlocks consecutive blocks of a block row
+// kernel.  Workgroup = 64 x 4 lanes: wave w of the group encodes 64 consecutive units of block row
+// blockIdx.y*4 + w (unit = Loader::kBlocks consecutive blocks), blockIdx.z = image of the batch.
+// No integer division anywhere; lanes idle only at the right/bottom edge of the block grid.
 // ---------------------------------------------------------------------------------------
+#ifndef UG_DXT_MIN_WAVES
+#define UG_DXT_MIN_WAVES 1
+#endif
 template <int IN, int OUT, bool MIRROR>
-__global__ __launch_bounds__(256) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                         int units_per_row, int block_rows, int height,
-                                                         long pitch, long total_units, size_t src_frame_stride,
-                                                         size_t dst_frame_stride)
+__global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                         int units_per_row, int block_rows, int height, long pitch,
+                                                         size_t src_frame_stride, size_t dst_frame_stride)
 {
         using L = Loader<IN>;
-        const long u = (long) blockIdx.x * blockDim.x + threadIdx.x;
-        if (u >= total_units) {
+        const int ux = blockIdx.x * 64 + threadIdx.x;
+        const int by = blockIdx.y * 4 + threadIdx.y;
+        if (ux >= units_per_row || by >= block_rows) {
                 return;
         }
-        const int units_per_frame = units_per_row * block_rows;
-        const int frame = (int) (u / units_per_frame);
-        const int uf = (int) (u - (long) frame * units_per_frame);
-        const int by = uf / units_per_row;
-        const int ux = uf - by * units_per_row;
-
-        src += (size_t) frame * src_frame_stride;
-        dst += (size_t) frame * dst_frame_stride;
+        src += (size_t) blockIdx.z * src_frame_stride;
+        dst += (size_t) blockIdx.z * dst_frame_stride;
 
         int rows[4];
 #pragma unroll
@@ -474,7 +541,7 @@ __global__ __launch_bounds__(256) void dxt_encode_kernel(const uint8_t *__restri
         ld.load(src, pitch, ux, rows);
 
         // block raster order idx = bx + (w/4)*by (cuda_dxt.cu:633)
-        const long block0 = (long) by * units_per_row * L::kBlocks + (long) ux * L::kBlocks;
+        const long block0 = ((long) by * units_per_row + ux) * L::kBlocks;
 #pragma unroll
         for (int k = 0; k < L::kBlocks; k++) {
                 Px16 p;
@@ -494,15 +561,18 @@ int launch(const void *src, void *dst, int w, int h, int pitch, int frames, size
         const bool mirror = h < 0;
         if (mirror) h = -h;
         const int upr = (w / 4) / L::kBlocks, brows = h / 4;
-        const long total = (long) upr * brows * frames;
-        if (total == 0) return UG_HIP_SUCCESS;
-        const dim3 block(256), grid((unsigned) ((total + 255) / 256));
+        if (upr == 0 || brows == 0 || frames == 0) return UG_HIP_SUCCESS;
+        if (frames > 65535 || (brows + 3) / 4 > 65535) {
+                ug::set_last_error_msg("ug_hip_dxt_encode: image too tall / too many frames for one launch");
+                return UG_HIP_EINVAL;
+        }
+        const dim3 block(64, 4), grid((unsigned) ((upr + 63) / 64), (unsigned) ((brows + 3) / 4), (unsigned) frames);
         if (mirror) {
                 hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, true>), grid, block, 0, st, (const uint8_t *) src,
-                                   (uint8_t *) dst, upr, brows, h, (long) pitch, total, sfs, dfs);
+                                   (uint8_t *) dst, upr, brows, h, (long) pitch, sfs, dfs);
         } else {
                 hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, false>), grid, block, 0, st, (const uint8_t *) src,
-                                   (uint8_t *) dst, upr, brows, h, (long) pitch, total, sfs, dfs);
+                                   (uint8_t *) dst, upr, brows, h, (long) pitch, sfs, dfs);
         }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libug_mi355x.so")
+# UG_MI355X_LIB: developer override used for A/B runs of kernel variants (always a HIP build of this library)
+LIB_PATH = os.environ.get("UG_MI355X_LIB") or os.path.join(_HERE, "libug_mi355x.so")
 
 # ug_pixfmt_t
 PF_NONE, PF_RGBA, PF_UYVY, PF_YUYV, PF_RGB, PF_BGR, PF_V210, PF_RG48, PF_YUV444, PF_UYVY_RAW = range(10)
