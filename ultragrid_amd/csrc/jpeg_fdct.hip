@@ -65,17 +65,52 @@ __device__ constexpr uint8_t kZig[64] = {
         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
 };
 
-// quantise + zig-zag + store one block (128 B)
-__device__ __forceinline__ void quant_store(const float (&b)[64], const float *__restrict__ div, int16_t *__restrict__ out)
+// Quantise + zig-zag one block into 32 packed words (int16 pairs).
+// rintf(x) for |x| < 2^22 is computed as the low bits of fl(x + 1.5*2^23): in [2^23, 2^24) the fp32 ulp is 1, so the
+// addition itself performs the round-to-nearest-even, and the low 16 mantissa bits are the two's-complement int16.
+// Two v_add_f32 + one v_perm_b32 per coefficient pair instead of 2x(v_rndne, v_cvt) + pack; bit-identical to
+// (int16_t) rintf(coef * div) of oracle/jpeg_oracle.c.
+__device__ __forceinline__ void quant_pack(const float (&b)[64], const float *__restrict__ div, uint32_t (&w)[32])
 {
-        uint32_t w[32];
+        constexpr float kMagic = 12582912.0f; // 1.5 * 2^23
 #pragma unroll
         for (int k = 0; k < 64; k += 2) {
                 const int i0 = kZig[k], i1 = kZig[k + 1];
-                const int q0 = (int) rintf(b[i0] * div[i0]);
-                const int q1 = (int) rintf(b[i1] * div[i1]);
-                w[k / 2] = ((uint32_t) q0 & 0xffffu) | ((uint32_t) q1 << 16);
+                const float q0 = b[i0] * div[i0] + kMagic;
+                const float q1 = b[i1] * div[i1] + kMagic;
+                // bytes {q1.b1, q1.b0, q0.b1, q0.b0}
+                w[k / 2] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x05040100u);
         }
+}
+
+// A wave holds 64 consecutive blocks (one per lane) = one contiguous 8 KiB stretch of the output.  Stored straight
+// from registers every store instruction would touch 64 different 128-byte lines (16 B each); instead the wave
+// transposes through LDS (row pitch 144 B: conflict-free 128-bit writes) so that each store instruction writes
+// 1 KiB of contiguous memory.  `lds` = this wave's private 64 x 144 B region; `n_valid` lanes hold real blocks.
+constexpr int kLdsPitch = 144;
+__device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint8_t *lds, int16_t *__restrict__ out_wave,
+                                                  int lane, int n_valid)
+{
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+                *(uint4 *) (lds + lane * kLdsPitch + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+        }
+        __builtin_amdgcn_wave_barrier(); // same wave wrote and reads: only ordering inside the wave is needed
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+                const int blk = 8 * j + (lane >> 3), piece = lane & 7;
+                const uint4 v = *(const uint4 *) (lds + blk * kLdsPitch + 16 * piece);
+                if (blk < n_valid) {
+                        ((uint4 *) out_wave)[8 * blk + piece] = v;
+                }
+        }
+}
+
+__device__ __forceinline__ void quant_store(const float (&b)[64], const float *__restrict__ div, int16_t *__restrict__ out)
+{
+        uint32_t w[32];
+        quant_pack(b, div, w);
         uint4 *o = (uint4 *) out;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -87,38 +122,47 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
                                                                int blocks_w, long total, const float *__restrict__ div,
                                                                int16_t *__restrict__ out, float *__restrict__ coef)
 {
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * 64 * kLdsPitch];
         const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
-        if (idx >= total) return;
-        const int by = (int) (idx / blocks_w), bx = (int) (idx - (long) by * blocks_w);
-        float b[64];
-        const bool interior = 8 * bx + 8 <= width && 8 * by + 8 <= height && !(pitch & 7) && !(7 & (uintptr_t) plane);
-        if (interior) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const long wave_first = idx - lane;
+        uint32_t w[32];
+        if (idx < total) {
+                const int by = (int) (idx / blocks_w), bx = (int) (idx - (long) by * blocks_w);
+                float b[64];
+                const bool interior = 8 * bx + 8 <= width && 8 * by + 8 <= height && !(pitch & 7) && !(7 & (uintptr_t) plane);
+                if (interior) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                        const uint2 q = *(const uint2 *) (plane + (long) (8 * by + r) * pitch + 8 * bx);
+                        for (int r = 0; r < 8; r++) {
+                                const uint2 q = *(const uint2 *) (plane + (long) (8 * by + r) * pitch + 8 * bx);
 #pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                                b[8 * r + c] = (float) ((int) ((q.x >> (8 * c)) & 0xff) - 128);
-                                b[8 * r + 4 + c] = (float) ((int) ((q.y >> (8 * c)) & 0xff) - 128);
+                                for (int c = 0; c < 4; c++) {
+                                        b[8 * r + c] = (float) ((int) ((q.x >> (8 * c)) & 0xff) - 128);
+                                        b[8 * r + 4 + c] = (float) ((int) ((q.y >> (8 * c)) & 0xff) - 128);
+                                }
+                        }
+                } else { // edge replication
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                                const int y = min(8 * by + r, height - 1);
+#pragma unroll
+                                for (int c = 0; c < 8; c++) {
+                                        const int x = min(8 * bx + c, width - 1);
+                                        b[8 * r + c] = (float) ((int) plane[(long) y * pitch + x] - 128);
+                                }
                         }
                 }
-        } else { // edge replication
+                fdct8x8(b);
+                if (coef) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                        const int y = min(8 * by + r, height - 1);
-#pragma unroll
-                        for (int c = 0; c < 8; c++) {
-                                const int x = min(8 * bx + c, width - 1);
-                                b[8 * r + c] = (float) ((int) plane[(long) y * pitch + x] - 128);
-                        }
+                        for (int i = 0; i < 64; i++) coef[64 * idx + i] = b[i];
                 }
+                quant_pack(b, div, w);
         }
-        fdct8x8(b);
-        if (coef) {
-#pragma unroll
-                for (int i = 0; i < 64; i++) coef[64 * idx + i] = b[i];
+        if (wave_first < total) {
+                const long left = total - wave_first;
+                wave_store_blocks(w, lds_all + wave * 64 * kLdsPitch, out + 64 * wave_first, lane, left < 64 ? (int) left : 64);
         }
-        quant_store(b, div, out + 64 * idx);
 }
 
 // Fused UYVY -> 4:2:0 -> FDCT+quant.  Tasks [0, n_luma) are luma blocks (8 rows x 16 B of UYVY),
@@ -178,6 +222,87 @@ __global__ __launch_bounds__(256) void uyvy_jpeg420_kernel(const uint8_t *__rest
                 }
                 fdct8x8(b);
                 quant_store(b, div + 64, (comp ? out_cr : out_cb) + 64 * t);
+        }
+}
+
+// MCU-aligned fast path of the fused kernel (width % 16 == 0, 16-byte aligned lines).
+// Workgroup = 3 waves over a strip of 32 MCUs (512 px x 16 rows): wave 0 / 1 = the upper / lower luma block row of
+// the strip (64 blocks each), wave 2 = 32 Cb blocks (lanes 0-31) + 32 Cr blocks (lanes 32-63).  Every wave does 64
+// block DCTs, reads its rows with 128-bit loads that are contiguous across lanes (the chroma wave re-reads the
+// strip from L1/L2, so HBM sees each input byte once) and writes through wave_store_blocks().
+__global__ __launch_bounds__(192) void uyvy_jpeg420_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height, int mcu_w,
+                                                                const float *__restrict__ div, int16_t *__restrict__ out_y,
+                                                                int16_t *__restrict__ out_cb, int16_t *__restrict__ out_cr)
+{
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[3 * 64 * kLdsPitch];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int mcu0 = blockIdx.x * 32, my = blockIdx.y;
+        const int mcus = min(32, mcu_w - mcu0); // MCUs of this strip that exist
+        uint8_t *lds = lds_all + wave * 64 * kLdsPitch;
+        float b[64];
+        uint32_t w[32];
+        if (wave < 2) {
+                const int bx = 2 * mcu0 + lane; // luma block column
+                const bool valid = lane < 2 * mcus;
+                if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                                const int y = min(16 * my + 8 * wave + r, height - 1);
+                                const uint4 q = *(const uint4 *) (src + (long) y * pitch + 16 * bx);
+                                const uint32_t ww[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                        b[8 * r + 2 * k] = (float) ((int) ((ww[k] >> 8) & 0xff) - 128);
+                                        b[8 * r + 2 * k + 1] = (float) ((int) (ww[k] >> 24) - 128);
+                                }
+                        }
+                        fdct8x8(b);
+                        quant_pack(b, div, w);
+                }
+                const long first = (long) (2 * my + wave) * (2 * mcu_w) + 2 * mcu0;
+                wave_store_blocks(w, lds, out_y + 64 * first, lane, 2 * mcus);
+        } else {
+                const int comp = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU within the strip
+                const bool valid = m < mcus;
+                if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                                const int cy = min(8 * my + r, (height + 1) / 2 - 1); // edge replication on the chroma plane
+                                const int y0 = 2 * cy, y1 = min(2 * cy + 1, height - 1);   // odd height: last line doubled
+                                const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * (mcu0 + m));
+                                const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * (mcu0 + m));
+                                const uint4 a0 = p0[0], a1 = p0[1], c0 = p1[0], c1 = p1[1];
+                                const uint32_t wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                                const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+#pragma unroll
+                                for (int c = 0; c < 8; c++) {
+                                        // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367)
+                                        const int sa = comp ? (wa[c] >> 16) & 0xff : wa[c] & 0xff;
+                                        const int sb = comp ? (wc[c] >> 16) & 0xff : wc[c] & 0xff;
+                                        b[8 * r + c] = (float) (((sa + sb + 1) >> 1) - 128);
+                                }
+                        }
+                        fdct8x8(b);
+                        quant_pack(b, div + 64, w);
+                }
+                // lanes 0-31 -> Cb blocks, lanes 32-63 -> Cr blocks of this strip: two contiguous 4 KiB stretches
+                const long first = (long) my * mcu_w + mcu0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                        *(uint4 *) (lds + lane * kLdsPitch + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                        const int blk = 8 * j + (lane >> 3), piece = lane & 7; // blk 0-31 Cb, 32-63 Cr
+                        const uint4 v = *(const uint4 *) (lds + blk * kLdsPitch + 16 * piece);
+                        const int mm = blk & 31;
+                        if (mm < mcus) {
+                                int16_t *o = (blk < 32 ? out_cb : out_cr) + 64 * (first + mm);
+                                ((uint4 *) o)[piece] = v;
+                        }
+                }
         }
 }
 
@@ -243,6 +368,12 @@ int ug_hip_uyvy_to_jpeg420_coeffs(const void *src, int src_pitch, int width, int
         }
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
         const int mcu_w = (width + 15) / 16, mcu_h = (height + 15) / 16;
+        if (width % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src)) {
+                hipLaunchKernelGGL(uyvy_jpeg420_fast_kernel, dim3((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h), dim3(192), 0,
+                                   (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w, div, out_y, out_cb, out_cr);
+                UG_HIP_LAUNCH_CHECK();
+                return UG_HIP_SUCCESS;
+        }
         const long total = 6L * mcu_w * mcu_h;
         hipLaunchKernelGGL(uyvy_jpeg420_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
                            (const uint8_t *) src, src_pitch, width, height, mcu_w, mcu_h, div, out_y, out_cb, out_cr);
