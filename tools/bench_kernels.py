@@ -77,6 +77,7 @@ def main():
     # ---- pixfmt (one frame per launch, rotating over n frames) ----
     for (i, o, w, h, n, bpp) in [
         ("v210", "UYVY", 7680, 4320, 6, 16 / 6 + 2), ("v210", "UYVY", 3840, 2160, 16, 16 / 6 + 2),
+        ("UYVY", "RGB", 7680, 4320, 4, 5.0), ("RGB", "UYVY", 7680, 4320, 4, 5.0), ("v210", "RGB", 7680, 4320, 4, 16 / 6 + 3),
         ("UYVY", "RGB", 3840, 2160, 16, 5.0), ("UYVY", "RGB", 1920, 1080, 64, 5.0), ("RGB", "UYVY", 3840, 2160, 12, 5.0),
         ("v210", "RGB", 3840, 2160, 12, 16 / 6 + 3), ("RGBA", "RGB", 3840, 2160, 8, 7.0), ("UYVY", "YUYV", 3840, 2160, 16, 4.0),
         ("UYVY", "RGBA", 3840, 2160, 12, 6.0), ("RGB", "RGBA", 3840, 2160, 8, 7.0), ("UYVY", "v210", 3840, 2160, 12, 2 + 16 / 6),

@@ -258,7 +258,7 @@ int launch_generic(const Args &a, hipStream_t st)
 // v210 -> UYVY: 16 B (6 px) -> 12 B.  Lane: 2 groups = 32 B in, 24 B out.
 struct FastV210toUYVY {
         static constexpr int PX = 12;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c)
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
         {
                 const uint4 *sp = (const uint4 *) s + 2 * c;
                 uint32_t o[6];
@@ -278,7 +278,7 @@ struct FastV210toUYVY {
 // UYVY -> RGB: lane 16 B (8 px) in, 24 B out
 struct FastUYVYtoRGB {
         static constexpr int PX = 8;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c)
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
         {
                 const uint4 q = ((const uint4 *) s)[c];
                 const uint32_t w[4] = { q.x, q.y, q.z, q.w };
@@ -301,7 +301,7 @@ struct FastUYVYtoRGB {
 template <int RO, int BO>
 struct FastRGBtoUYVY {
         static constexpr int PX = 8;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c)
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
         {
                 const uint2 *sp = (const uint2 *) s + 3 * c;
                 uint8_t b[24];
@@ -333,7 +333,7 @@ struct FastRGBtoUYVY {
 // v210 -> RGB (8-bit): lane 32 B (12 px) in, 36 B out
 struct FastV210toRGB {
         static constexpr int PX = 12;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c)
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
         {
                 const uint4 *sp = (const uint4 *) s + 2 * c;
                 uint8_t o[36];
@@ -363,7 +363,7 @@ struct FastV210toRGB {
 // RGBA -> RGB: lane 16 B (4 px) in, 12 B out ; RGB -> RGBA the inverse
 struct FastRGBAtoRGB {
         static constexpr int PX = 4;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c)
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
         {
                 const uint4 q = ((const uint4 *) s)[c];
                 uint32_t *dp = (uint32_t *) d + 3 * c;
@@ -373,26 +373,108 @@ struct FastRGBAtoRGB {
         }
 };
 
+// UYVY <-> YUYV: lane 16 B, swap the bytes of every 16-bit pair
+struct FastSwapYUYV {
+        static constexpr int PX = 8;
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        {
+                uint4 q = ((const uint4 *) s)[c];
+#define SW(w) ((((w) & 0x00ff00ffu) << 8) | (((w) >> 8) & 0x00ff00ffu))
+                q.x = SW(q.x); q.y = SW(q.y); q.z = SW(q.z); q.w = SW(q.w);
+#undef SW
+                ((uint4 *) d)[c] = q;
+        }
+};
+// RGB -> RGBA with shifts: lane 12 B (4 px) in, 16 B out
+struct FastRGBtoRGBA {
+        static constexpr int PX = 4;
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &a)
+        {
+                const uint32_t *sp = (const uint32_t *) s + 3 * c;
+                const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2];
+                const uint32_t am = alpha_mask(a.rs, a.gs, a.bs);
+                const uint32_t px[4] = { w0 & 0xffffff, (w0 >> 24) | ((w1 & 0xffff) << 8), (w1 >> 16) | ((w2 & 0xff) << 16), w2 >> 8 };
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                        o[i] = am | (px[i] & 0xff) << a.rs | ((px[i] >> 8) & 0xff) << a.gs | (px[i] >> 16) << a.bs;
+                }
+                ((uint4 *) d)[c] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+};
+// UYVY -> v210: lane 24 B (12 px) in, 32 B out; consecutive bytes -> 10-bit fields (<< 2), three per word
+struct FastUYVYtoV210 {
+        static constexpr int PX = 12;
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        {
+                const uint2 *sp = (const uint2 *) s + 3 * c;
+                const uint2 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+                const uint32_t w[6] = { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int f = 0; f < 3; f++) {
+                                const int b = 3 * k + f; // source byte index 0..23
+                                v |= (((w[b / 4] >> (8 * (b % 4))) & 0xffu) << 2) << (10 * f);
+                        }
+                        o[k] = v;
+                }
+                uint4 *dp = (uint4 *) d + 2 * c;
+                dp[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dp[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+};
+// UYVY -> RGBA (fp64 arithmetic of vc_copylineUYVYtoRGBA, pixfmt_conv.c:1137-1163): lane 16 B (8 px) in, 32 B out
+struct FastUYVYtoRGBA {
+        static constexpr int PX = 8;
+        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &a)
+        {
+                const uint4 q = ((const uint4 *) s)[c];
+                const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+                const uint32_t am = alpha_mask(a.rs, a.gs, a.bs);
+                uint32_t o[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                        const int u = w[i] & 0xff, v = (w[i] >> 16) & 0xff;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                                const int y = h ? (int) (w[i] >> 24) : (int) ((w[i] >> 8) & 0xff);
+                                int r = 1.164 * (y - 16) + 1.793 * (v - 128);
+                                int g = 1.164 * (y - 16) - 0.534 * (v - 128) - 0.213 * (u - 128);
+                                int b = 1.164 * (y - 16) + 2.115 * (u - 128);
+                                r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
+                                o[2 * i + h] = am | (uint32_t) r << a.rs | (uint32_t) g << a.gs | (uint32_t) b << a.bs;
+                        }
+                }
+                uint4 *dp = (uint4 *) d + 2 * c;
+                dp[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dp[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+};
+
 template <class F>
-__global__ __launch_bounds__(256) void fast_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int cpl,
-                                                   int spitch, int dpitch, long total)
+__global__ __launch_bounds__(256) void fast_kernel(Args a, int cpl)
 {
-        const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
-        if (idx >= total) return;
-        const int line = (int) (idx / cpl), c = (int) (idx - (long) line * cpl);
-        F::run(src + (long) line * spitch, dst + (long) line * dpitch, c);
+        const int c = blockIdx.x * blockDim.x + threadIdx.x, line = blockIdx.y;
+        if (c >= cpl) return;
+        F::run(a.src + (long) line * a.spitch, a.dst + (long) line * a.dpitch, c, a);
 }
 
 template <class F>
 bool try_fast(const Args &a, hipStream_t st, int &rc)
 {
-        if (a.width % F::PX || (a.spitch & 15) || (a.dpitch & 15) || (15 & (uintptr_t) a.src) || (15 & (uintptr_t) a.dst)) {
+        if (a.width % F::PX || (a.spitch & 15) || (a.dpitch & 15) || (15 & (uintptr_t) a.src) || (15 & (uintptr_t) a.dst) ||
+            a.height > 65535) {
                 return false;
         }
         const int cpl = a.width / F::PX;
-        const long total = (long) cpl * a.height;
-        hipLaunchKernelGGL((fast_kernel<F>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, a.src, a.dst, cpl,
-                           a.spitch, a.dpitch, total);
+        int bx = 64; // workgroup width with the fewest idle lanes at the end of a line (ties: wider)
+        for (int cand : { 128, 256 }) {
+                if ((cpl + cand - 1) / cand * cand <= (cpl + bx - 1) / bx * bx) bx = cand;
+        }
+        hipLaunchKernelGGL((fast_kernel<F>), dim3((unsigned) ((cpl + bx - 1) / bx), (unsigned) a.height), dim3(bx), 0, st, a, cpl);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { ug::set_last_error(e, "kernel launch"); rc = UG_HIP_ERUNTIME; }
         else rc = UG_HIP_SUCCESS;
@@ -554,11 +636,15 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
                 if (try_fast<FastV210toUYVY>(a, st, rc)) return rc;
                 return launch_generic<V210toUYVY>(a, st);
         case PAIR(UG_PF_YUYV, UG_PF_UYVY):
-        case PAIR(UG_PF_UYVY, UG_PF_YUYV): return launch_generic<SwapYUYV>(a, st);
+        case PAIR(UG_PF_UYVY, UG_PF_YUYV):
+                if (try_fast<FastSwapYUYV>(a, st, rc)) return rc;
+                return launch_generic<SwapYUYV>(a, st);
         case PAIR(UG_PF_UYVY, UG_PF_RGB):
                 if (try_fast<FastUYVYtoRGB>(a, st, rc)) return rc;
                 return launch_generic<UYVYtoRGB>(a, st);
-        case PAIR(UG_PF_UYVY, UG_PF_RGBA): return launch_generic<UYVYtoRGBA>(a, st);
+        case PAIR(UG_PF_UYVY, UG_PF_RGBA):
+                if (try_fast<FastUYVYtoRGBA>(a, st, rc)) return rc;
+                return launch_generic<UYVYtoRGBA>(a, st);
         case PAIR(UG_PF_RGB, UG_PF_UYVY):
                 if (try_fast<FastRGBtoUYVY<0, 2>>(a, st, rc)) return rc;
                 return launch_generic<ToUYVY<0, 1, 2, 3>>(a, st);
@@ -574,7 +660,9 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
         case PAIR(UG_PF_RGBA, UG_PF_RGB):
                 if (try_fast<FastRGBAtoRGB>(a, st, rc)) return rc;
                 return launch_generic<RGBAtoRGB>(a, st);
-        case PAIR(UG_PF_RGB, UG_PF_RGBA): return launch_generic<RGBtoRGBA>(a, st);
+        case PAIR(UG_PF_RGB, UG_PF_RGBA):
+                if (try_fast<FastRGBtoRGBA>(a, st, rc)) return rc;
+                return launch_generic<RGBtoRGBA>(a, st);
         case PAIR(UG_PF_RGBA, UG_PF_RGBA):
                 if (rshift == 0 && gshift == 8 && bshift == 16) return launch_generic<Copy>(a, st);
                 return launch_generic<RGBAshift>(a, st);
@@ -584,7 +672,9 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
         case PAIR(UG_PF_BGR, UG_PF_RGB): // vc_copylineBGRtoRGB, pixfmt_conv.c:2520-2527
                 a.rs = 16; a.gs = 8; a.bs = 0;
                 return launch_generic<RGBshift>(a, st);
-        case PAIR(UG_PF_UYVY, UG_PF_V210): return launch_generic<UYVYtoV210>(a, st);
+        case PAIR(UG_PF_UYVY, UG_PF_V210):
+                if (try_fast<FastUYVYtoV210>(a, st, rc)) return rc;
+                return launch_generic<UYVYtoV210>(a, st);
         }
         return UG_HIP_EUNSUPP;
 }
