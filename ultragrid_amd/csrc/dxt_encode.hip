@@ -483,7 +483,7 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
         }
         const uint32_t w_end = swap ? (code_min | (code_max << 16)) : (code_max | (code_min << 16));
 
-        // EmitIndicesDXT1 (glsl:128-161)
+        // EmitIndicesDXT1 (glsl:128-161): packed fp32 over pixel pairs, as in the DXT5-YCoCg encoder
         uint32_t w_idx = 0;
         {
                 const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
@@ -494,16 +494,32 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
                         c2[k] = lerp_w(c0[k], c1[k], w1, q1);
                         c3[k] = lerp_w(c0[k], c1[k], w2, q2);
                 }
+                const float *c[4] = { c0, c1, c2, c3 };
+                f32x2 cc[4][3];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                        float d[4];
-                        const float *c[4] = { c0, c1, c2, c3 };
+                for (int k = 0; k < 4; k++) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                                cc[k][ch] = (f32x2) { c[k][ch], c[k][ch] };
+                        }
+                }
+#pragma unroll
+                for (int i = 14; i >= 0; i -= 2) {
+                        const f32x2 r = { R[i], R[i + 1] }, g = { G[i], G[i + 1] }, bl = { B[i], B[i + 1] };
+                        f32x2 d[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                                const float tx = R[i] - c[k][0], ty = G[i] - c[k][1], tz = B[i] - c[k][2];
-                                d[k] = (tx * tx + ty * ty) + tz * tz;
+                                const f32x2 tx = r - cc[k][0], ty = g - cc[k][1], tz = bl - cc[k][2];
+                                d[k] = (tx * tx + ty * ty) + tz * tz; // dot(v,v): x*x + y*y + z*z, left to right
                         }
-                        w_idx |= palette_index(d[0], d[1], d[2], d[3]) << (2 * i);
+#pragma unroll
+                        for (int h = 1; h >= 0; h--) {
+                                const float d0 = d[0][h], d1 = d[1][h], d2 = d[2][h], d3 = d[3][h];
+                                const lanemask_t b0 = LANEMASK(d0 > d3), b1 = LANEMASK(d1 > d2), b2 = LANEMASK(d0 > d2),
+                                                 b3 = LANEMASK(d1 > d3), b4 = LANEMASK(d2 > d3);
+                                w_idx = shift_in(w_idx, (b1 & b2) | (b0 & b3));
+                                w_idx = shift_in(w_idx, b0 & b4);
+                        }
                 }
         }
         return make_uint2(w_end, w_idx);
