@@ -28,6 +28,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -480,8 +481,25 @@ static fetch_px_t fetch_for(int fmt)
 
 /* Block raster order idx = bx + (w/4)*by (cuda_dxt.cu:633); pixel i = 4*row + col
  * (compress_dxt5ycocg_fp.glsl:50-54). */
+static int encode_rows(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long pitch,
+                       int nthreads);
+
 int oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                       int w, int h, long pitch)
+{
+        return encode_rows(in_fmt, out_fmt, src, dst, w, h, pitch, 1);
+}
+
+/* Same, block rows split over `nthreads` OpenMP threads (0 = all cores) -- the row-band scheme the reference uses
+ * for its CPU conversions (src/utils/parallel_conv.c:64-85).  Only for the cpu_baseline timing leg of bench.py. */
+int oracle_dxt_encode_mt(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
+                         int w, int h, long pitch, int nthreads)
+{
+        return encode_rows(in_fmt, out_fmt, src, dst, w, h, pitch, nthreads <= 0 ? omp_get_max_threads() : nthreads);
+}
+
+static int encode_rows(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long pitch,
+                       int nthreads)
 {
         int mirror = 0;
         if (h < 0) { mirror = 1; h = -h; }
@@ -490,6 +508,10 @@ int oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                 return -1;
         }
         const int bw = w / 4;
+        if (out_fmt != ORACLE_OUT_DXT5YCOCG && out_fmt != ORACLE_OUT_DXT1) {
+                return -1;
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
         for (int by = 0; by < h / 4; by++) {
                 for (int bx = 0; bx < bw; bx++) {
                         float rgb[16][3];
@@ -504,12 +526,10 @@ int oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                                 uint32_t o[4];
                                 oracle_dxt5ycocg_encode_block(rgb, o);
                                 memcpy(dst + 16 * idx, o, 16);
-                        } else if (out_fmt == ORACLE_OUT_DXT1) {
+                        } else {
                                 uint32_t o[2];
                                 oracle_dxt1_encode_block(rgb, o);
                                 memcpy(dst + 8 * idx, o, 8);
-                        } else {
-                                return -1;
                         }
                 }
         }

@@ -34,6 +34,9 @@ void oracle_dxt1_encode_block(const float rgb[16][3], uint32_t out[2]);
 /* h < 0: source read bottom-up. pitch = source line stride in bytes. 0 ok, -1 bad args */
 int  oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                        int w, int h, long pitch);
+/* row bands over nthreads OpenMP threads (0 = all cores); cpu_baseline timing only */
+int  oracle_dxt_encode_mt(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
+                          int w, int h, long pitch, int nthreads);
 void oracle_yuv422_to_yuv444(const uint8_t *src, uint8_t *dst, long pix_count);
 
 /* ---- DXT decode (dxt_decode_oracle.c) ---- */

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_dxt_encode.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long]
         _lib.oracle_dxt_encode.restype = C.c_int
+        _lib.oracle_dxt_encode_mt.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int]
+        _lib.oracle_dxt_encode_mt.restype = C.c_int
         _lib.oracle_yuv422_to_yuv444.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         _lib.oracle_yuv422_to_yuv444.restype = None
         for n in ("oracle_dxt5ycocg_decode_rgb", "oracle_dxt1_decode_rgb"):
@@ -124,15 +126,19 @@ def _ptr(a: np.ndarray):
 # ----------------------------------------------------------------------------------
 # DXT
 # ----------------------------------------------------------------------------------
-def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch: int | None = None) -> np.ndarray:
-    """h < 0 => bottom-up source (cuda_dxt.cu:652-655)."""
+def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch: int | None = None,
+               threads: int = 1) -> np.ndarray:
+    """h < 0 => bottom-up source (cuda_dxt.cu:652-655).  threads != 1: OpenMP row bands (0 = all cores)."""
     src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
     if pitch is None:
         pitch = {IN_RGB: 3 * w, IN_RGBA: 4 * w, IN_YUV444: 3 * w, IN_UYVY: 2 * w, IN_UYVY_RAW: 2 * w,
                  IN_V210: (w + 47) // 48 * 128}[in_fmt]
     n = w * abs(h) // (2 if out_fmt == OUT_DXT1 else 1)
     out = np.zeros(n, dtype=np.uint8)
-    rc = lib().oracle_dxt_encode(in_fmt, out_fmt, _ptr(src), _ptr(out), w, h, pitch)
+    if threads == 1:
+        rc = lib().oracle_dxt_encode(in_fmt, out_fmt, _ptr(src), _ptr(out), w, h, pitch)
+    else:
+        rc = lib().oracle_dxt_encode_mt(in_fmt, out_fmt, _ptr(src), _ptr(out), w, h, pitch, threads)
     if rc:
         raise ValueError(f"oracle_dxt_encode rc={rc}")
     return out
