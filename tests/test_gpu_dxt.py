@@ -163,3 +163,75 @@ def test_error_codes_on_device(hip):
     assert e.value.rc == L.EUNSUPP
     with pytest.raises(ValueError):
         hip.dxt_encode(L.PF_RGB, L.DXT1, torch.zeros(64, dtype=torch.uint8), 4, 4)  # host tensor: no CPU fallback
+
+
+def test_alpha_reference_form_path(po):
+    """The DXT5 kernel counts alpha thresholds by binary search when they are monotone (always, for real
+    content) and falls back to the reference's 7-compare form otherwise.  The fallback is unreachable with
+    byte-quantised input in practice, so a test build that forces it (-DUG_FORCE_ALPHA_LINEAR, built by
+    __graft_entry__.build()) is checked against the oracle in a subprocess."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "ultragrid_amd", "libug_mi355x_alphalinear.so")
+    if not os.path.exists(alt):
+        pytest.skip("alphalinear test build missing (run __graft_entry__.build())")
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import pyoracle as po
+from ultragrid_amd import codec, lib, synth
+assert "alphalinear" in lib.LIB_PATH
+for kind in ("S1", "S2", "S4"):
+    for (fmt, pf, pin) in (("UYVY", lib.PF_UYVY, po.IN_UYVY), ("RGB", lib.PF_RGB, po.IN_RGB)):
+        src = synth.frame(kind, fmt, 192, 64)
+        got = codec.dxt_encode(pf, lib.DXT5_YCOCG, torch.from_numpy(src).cuda(), 192, 64).cpu().numpy()
+        assert np.array_equal(got, po.dxt_encode(pin, po.OUT_DXT5YCOCG, src, 192, 64)), (kind, fmt)
+print("OK")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UG_MI355X_LIB=alt), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_extreme_and_degenerate_content(hip, po):
+    """All-0 / all-255 / super-white / super-black / checkerboard frames: degenerate min == max blocks, clamps on both
+    sides, Y outside [0,1] after the unclamped YUV->RGB (compress_dxt5ycocg_fp.glsl:12-23)."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 96, 32
+    pats = {"zeros": np.zeros(2 * w * h, np.uint8), "ones": np.full(2 * w * h, 255, np.uint8),
+            "superwhite": np.tile(np.array([128, 255, 128, 254], np.uint8), w * h // 2),
+            "superblack": np.tile(np.array([128, 0, 128, 1], np.uint8), w * h // 2),
+            "chroma_extremes": np.tile(np.array([0, 128, 255, 128, 255, 127, 0, 129], np.uint8), w * h // 4),
+            "checker": np.tile(np.array([16, 235, 240, 16, 240, 16, 16, 235], np.uint8), w * h // 4)}
+    for name, src in pats.items():
+        for out_l, out_p in ((L.DXT5_YCOCG, po.OUT_DXT5YCOCG), (L.DXT1, po.OUT_DXT1)):
+            got = hip.dxt_encode(L.PF_UYVY, out_l, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
+            assert np.array_equal(got, po.dxt_encode(po.IN_UYVY, out_p, src, w, h)), name
+            rgb = src[: 3 * w * h] if src.size >= 3 * w * h else np.resize(src, 3 * w * h)
+            got = hip.dxt_encode(L.PF_RGB, out_l, torch.from_numpy(np.ascontiguousarray(rgb)).cuda(), w, h).cpu().numpy()
+            assert np.array_equal(got, po.dxt_encode(po.IN_RGB, out_p, rgb, w, h)), name
+
+
+def test_concurrent_streams_threads(hip, po):
+    """Distinct streams driven from distinct threads (the tile fan-out of video_compress.cpp:441-490)."""
+    import threading
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 384, 128
+    srcs = [synth.s1_random("UYVY", w, h, salt=i) for i in range(4)]
+    outs = [None] * 4
+
+    def work(i):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            d = torch.from_numpy(srcs[i]).cuda()
+            for _ in range(20):
+                o = hip.dxt_encode(L.PF_UYVY, L.DXT5_YCOCG, d, w, h)
+            st.synchronize()
+            outs[i] = o.cpu().numpy()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(4):
+        assert np.array_equal(outs[i], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, srcs[i], w, h)), i

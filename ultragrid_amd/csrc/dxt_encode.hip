@@ -380,7 +380,11 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 const bool mono = (T1 <= T2) & (T2 <= T3) & (T3 <= T4) & (T4 <= T5) & (T5 <= T6) & (T6 <= T7);
                 // raw counts, 3 bits per pixel: lo = px 0..9 (30 bits), hi = px 10..15 (18 bits)
                 uint32_t lo = 0, hi = 0;
+#ifdef UG_FORCE_ALPHA_LINEAR // test build: always take the reference-form path (tests/test_gpu_dxt.py)
+                if (__all(mono) && lo == 0xffffffffu) {
+#else
                 if (__builtin_expect(__all(mono), 1)) {
+#endif
 #pragma unroll
                         for (int i = 15; i >= 0; i--) {
                                 const float a = Y[i];
