@@ -72,3 +72,36 @@ def test_against_fp64_dct(po):
             # breaks exact .5 ties, which are common for DC = sum/8 over integer samples)
             frac = np.abs(np.abs(ref / qt.reshape(8, 8)) % 1.0 - 0.5)
             assert (frac[diff != 0] < 1e-3).all(), kind
+
+
+def test_coefficients_decode_with_an_independent_jpeg_decoder(po):
+    """Wrap the oracle's quantised coefficients in a baseline JFIF stream (tests/jpeg_bitstream.py) and decode it with
+    Pillow/libjpeg: pins level shift, DCT sign/normalisation, quantiser scaling and zig-zag order to real JPEG."""
+    import io
+    from PIL import Image
+    from jpeg_bitstream import write_jpeg420
+    w, h = 160, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    rgb = rgb.clip(0, 255).astype(np.uint8)
+    uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+    y, u, v = po.uyvy_to_i420(uyvy, w, h)
+    for q in (50, 90):
+        ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+        mw, mh = (w + 15) // 16, (h + 15) // 16
+        cy = po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, 2 * mh)
+        cb = po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh)
+        cr = po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh)
+        data = write_jpeg420(w, h, ql, qc, cy, cb, cr)
+        img = Image.open(io.BytesIO(data))
+        img.draft("YCbCr", None)
+        dec = np.asarray(img.convert("YCbCr") if img.mode != "YCbCr" else img)
+        assert dec.shape == (h, w, 3)
+        # Pillow's JFIF YCbCr is full range; our planes are the BT.709 limited-range samples themselves, so compare planes
+        mse = np.mean((dec[..., 0].astype(float) - y.astype(float)) ** 2)
+        psnr = 10 * np.log10(255 ** 2 / mse)
+        assert psnr > (38 if q == 50 else 44), (q, psnr)
+        up = lambda p: np.repeat(np.repeat(p, 2, 0), 2, 1)[:h, :w].astype(float)
+        for plane, ch in ((u, 1), (v, 2)):
+            mse = np.mean((dec[..., ch].astype(float) - up(plane)) ** 2)
+            assert 10 * np.log10(255 ** 2 / mse) > 36, (q, ch)
