@@ -31,18 +31,25 @@ import torch  # noqa: E402
 
 W, H = 3840, 2160
 ALG_BYTES_PER_PX = 3.0     # UYVY 2 B/px read + DXT5 1 B/px written
+# --workload: the default is the configuration BASELINE.json's metric is quoted on (configs[2]); configs[4]
+# (7680x4320 v210 -> DXT5-YCoCg, frames sharded over the GPUs) is available for the scaling study.
+WORKLOADS = {
+    "4k-uyvy": dict(w=3840, h=2160, fmt="UYVY", bpp=3.0, frames=16, name="3840x2160 UYVY->YCoCg->DXT5 fused encode (BASELINE.json configs[2])"),
+    "8k-v210": dict(w=7680, h=4320, fmt="v210", bpp=16 / 6 + 1, frames=4, name="7680x4320 v210 unpack->YCoCg->DXT5 fused encode (BASELINE.json configs[4])"),
+}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_frames(n: int, rank: int) -> np.ndarray:
-    """n distinct legal-range video-noise frames (S2); 4 generated bases, the rest are row-rotations
+def make_frames(n: int, rank: int, fmt: str = "UYVY", w: int = W, h: int = H) -> np.ndarray:
+    """n distinct legal-range video-noise frames (S2); up to 4 generated bases, the rest are row-rotations
     by multiples of 4 lines (distinct bytes in memory, same statistics)."""
     from ultragrid_amd import synth
-    cache = f"/tmp/ug_bench_frames_{n}_{rank}.npy"   # same bytes every time; only saves generation time on repeat runs
+    cache = f"/tmp/ug_bench_frames_{fmt}_{w}x{h}_{n}_{rank}.npy"   # same bytes every time; only saves generation time on repeat runs
     if os.path.exists(cache):
         return np.load(cache)
-    bases = [synth.s2_video("UYVY", W, H, salt=100 * rank + i).reshape(H, 2 * W) for i in range(min(n, 4))]
-    out = np.empty((n, H, 2 * W), np.uint8)
+    ls = synth.linesize(fmt, w)
+    bases = [synth.s2_video(fmt, w, h, salt=100 * rank + i).reshape(h, ls) for i in range(min(n, 4 if w <= 3840 else 2))]
+    out = np.empty((n, h, ls), np.uint8)
     for i in range(n):
         out[i] = np.roll(bases[i % len(bases)], 4 * 37 * (i // len(bases)), axis=0)
     out = out.reshape(n, -1)
@@ -53,21 +60,22 @@ def make_frames(n: int, rank: int) -> np.ndarray:
     return out
 
 
-def cpu_baseline(frame: np.ndarray, target_s: float = 12.0) -> dict:
+def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 12.0) -> dict:
     """The C oracle on all host cores: block rows split statically over OpenMP threads, the row-band scheme the
     reference uses to parallelise its CPU conversions (src/utils/parallel_conv.c:64-85)."""
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
+    pin = {"UYVY": po.IN_UYVY, "v210": po.IN_V210}[fmt]
     t0 = time.perf_counter()
-    po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frame, W, H, threads=cores)   # warm + calibrate
+    po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=cores)   # warm + calibrate
     t1 = time.perf_counter() - t0
     n = max(3, min(2000, int(target_s / max(t1, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(n):
-        po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frame, W, H, threads=cores)
+        po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x 3840x2160 UYVY->DXT5-YCoCg frames through oracle/dxt_oracle.c (gcc -O2, strict fp32, "
+    return {"value": round(n * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x {w}x{h} {fmt}->DXT5-YCoCg frames through oracle/dxt_oracle.c (gcc -O2, strict fp32, "
                       f"OpenMP static row bands on {cores} threads), {dt:.1f} s"}
 
 
@@ -76,7 +84,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=16, help="distinct 4K frames per step (batch)")
+    ap.add_argument("--frames", type=int, default=0, help="distinct frames per step (batch); 0 = workload default")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k-uyvy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,14 +106,18 @@ def main() -> None:
     from ultragrid_amd import codec, lib
     lib.load()
 
-    F = args.frames
-    host = make_frames(F, rank)
+    wl = WORKLOADS[args.workload]
+    W, H = wl["w"], wl["h"]
+    ALG_BYTES_PER_PX = wl["bpp"]
+    F = args.frames or wl["frames"]
+    host = make_frames(F, rank, wl["fmt"], W, H)
     src = torch.from_numpy(host).cuda()
-    frame_bytes = 2 * W * H
+    frame_bytes = host.shape[1]
     dst = torch.empty(F * W * H, dtype=torch.uint8, device="cuda")
+    pf = lib.PF_NAMES[wl["fmt"]]
 
     def step():
-        codec.dxt_encode_batch(lib.PF_UYVY, lib.DXT5_YCOCG, src, W, H, F, frame_bytes, dst=dst)
+        codec.dxt_encode_batch(pf, lib.DXT5_YCOCG, src, W, H, F, frame_bytes, dst=dst)
 
     from ultragrid_amd import shard
     for _ in range(args.warmup):
@@ -132,26 +145,26 @@ def main() -> None:
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes, see DESIGN.md
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"uyvy_dxt5_4k_x{F}")
+                traffic = json.load(open(pmc)).get(f"uyvy_dxt5_4k_x{F}") if args.workload == "4k-uyvy" else None
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)",
+            "metric": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)" if args.workload == "4k-uyvy" else "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "3840x2160 UYVY->YCoCg->DXT5 fused encode (BASELINE.json configs[2])",
+            "config": {"workload": wl["name"],
                        "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": W * H,
-                       "input": "S2 legal-range video noise, resident in HBM", "fps_4k": round(value * 1e6 / (W * H), 1),
+                       "input": "S2 legal-range video noise, resident in HBM", "fps": round(value * 1e6 / (W * H), 1),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "dxt_encode_kernel<UYVY,DXT5_YCOCG>", "ms_per_launch": round(kern_ms, 5),
+                         "kernel": f"dxt_encode_kernel<{wl['fmt']},DXT5_YCOCG>", "ms_per_launch": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * F * W * H),
                          "note": "VALU-bound kernel (SURVEY.md F9); see DESIGN.md for the VALU side-roofline"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host[0])
+            out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
