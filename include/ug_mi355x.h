@@ -118,6 +118,16 @@ int ug_hip_yuv_to_dxt6(const void *src, void *out, int size_x, int size_y, ug_hi
 int ug_hip_yuv422_to_yuv444(const void *src, void *out, int pix_count, ug_hip_stream_t stream);     /* cuda_yuv422_to_yuv444, cuda_dxt.h:88 */
 
 /* ------------------------------------------------------------------------------------
+ * DXT decoders (receiver side; replace dxt_decoder_decompress() behind
+ * src/video_decompress/dxt_glsl.c:142-189 and the CPU tool cuda_dxt/dxt62tga.c:24-106)
+ * ---------------------------------------------------------------------------------- */
+/* `in` in {UG_DXT1, UG_DXT5_YCOCG}; `out` in {UG_PF_RGB, UG_PF_BGR, UG_PF_RGBA, UG_PF_UYVY}.  RGBA output honours
+ * rshift/gshift/bshift exactly like the decompress modules' reconfigure() arguments (video_decompress.h:85-100);
+ * UYVY follows dxt_compress/rgba_to_yuv422.glsl.  width % 4 == 0, height % 4 == 0, dst_pitch 0 = packed. */
+int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
+                      int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Pixel-format conversion, whole frame on the device (replaces the decoder_t line loop,
  * pixfmt_conv.h:87-88 / pixfmt_conv.c:3041-3125)
  * ---------------------------------------------------------------------------------- */

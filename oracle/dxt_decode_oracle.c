@@ -13,6 +13,7 @@
  * compress_dxt1_fp.glsl:116-123); colour expansion /31, /63 as dxt62tga.c:63-68.
  */
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "oracle.h"
@@ -109,4 +110,92 @@ void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
                         }
                 }
         }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic frame decode used as the oracle of the decompress-side kernels.
+ *   in_fmt : ORACLE_OUT_DXT1 / ORACLE_OUT_DXT5YCOCG (same ids as the encoder side)
+ *   out_fmt: OPF_RGB, OPF_BGR, OPF_RGBA (alpha 0xFF, component shifts rs/gs/bs as decoder_t), OPF_UYVY
+ * RGB values are the 8-bit results above (cuda_dxt/dxt62tga.c arithmetic).  UYVY follows the reference's
+ * RGBA->4:2:2 pass (dxt_compress/rgba_to_yuv422.glsl:27-46) applied to those 8-bit texels, every shader
+ * operation one fp32 operation, texel fetch = v / 255.0f, output = floorf(clamp01(x) * 255 + 0.5)
+ * (GL's unorm8 conversions are implementation-defined to that extent: parity unpinned).
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint8_t unorm8_out(float x)
+{
+        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        float t = x * 255.0f;
+        t = t + 0.5f;
+        return (uint8_t) (int) t; /* t >= 0: truncation == floor */
+}
+
+static void rgb_pair_to_uyvy(const uint8_t *p1, const uint8_t *p2, uint8_t *out)
+{
+        float c[2][3], yuv[2][3];
+        for (int k = 0; k < 3; k++) {
+                c[0][k] = (float) p1[k] / 255.0f;
+                c[1][k] = (float) p2[k] / 255.0f;
+        }
+        for (int i = 0; i < 2; i++) {
+                const float r = c[i][0], g = c[i][1], b = c[i][2];
+                float t;
+                t = r * 0.2126f; t = t + g * 0.7152f; t = t + b * 0.0722f; t = t * 0.8588f;
+                yuv[i][0] = (float) (1.0 / 16.0) + t;
+                t = -r * 0.1145f; t = t - g * 0.3854f; t = t + b * 0.5f; t = t * 0.8784f;
+                yuv[i][1] = 0.5f + t;
+                t = r * 0.5f; t = t - g * 0.4541f; t = t - b * 0.0458f; t = t * 0.8784f;
+                yuv[i][2] = 0.5f + t;
+        }
+        /* mix(a, b, 0.5) = a * (1 - 0.5) + b * 0.5 */
+        const float U = yuv[0][1] * 0.5f + yuv[1][1] * 0.5f;
+        const float V = yuv[0][2] * 0.5f + yuv[1][2] * 0.5f;
+        out[0] = unorm8_out(U);
+        out[1] = unorm8_out(yuv[0][0]);
+        out[2] = unorm8_out(V);
+        out[3] = unorm8_out(yuv[1][0]);
+}
+
+int oracle_dxt_decode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long dst_pitch,
+                      int rs, int gs, int bs)
+{
+        if (w <= 0 || h <= 0 || (w & 3) || (h & 3)) {
+                return -1;
+        }
+        uint8_t *rgb = (uint8_t *) malloc((size_t) w * h * 3);
+        if (!rgb) {
+                return -1;
+        }
+        if (in_fmt == ORACLE_OUT_DXT5YCOCG) {
+                oracle_dxt5ycocg_decode_rgb(src, rgb, w, h);
+        } else if (in_fmt == ORACLE_OUT_DXT1) {
+                oracle_dxt1_decode_rgb(src, rgb, w, h);
+        } else {
+                free(rgb);
+                return -1;
+        }
+        int rc = 0;
+        for (int y = 0; y < h && rc == 0; y++) {
+                const uint8_t *s = rgb + (size_t) y * w * 3;
+                uint8_t *d = dst + (long) y * dst_pitch;
+                switch (out_fmt) {
+                case OPF_RGB: memcpy(d, s, (size_t) w * 3); break;
+                case OPF_BGR:
+                        for (int x = 0; x < w; x++) { d[3 * x] = s[3 * x + 2]; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = s[3 * x]; }
+                        break;
+                case OPF_RGBA: {
+                        const uint32_t am = 0xFFFFFFFFU ^ (0xFFU << rs) ^ (0xFFU << gs) ^ (0xFFU << bs);
+                        for (int x = 0; x < w; x++) {
+                                const uint32_t v = am | (uint32_t) s[3 * x] << rs | (uint32_t) s[3 * x + 1] << gs | (uint32_t) s[3 * x + 2] << bs;
+                                memcpy(d + 4 * x, &v, 4);
+                        }
+                        break;
+                }
+                case OPF_UYVY:
+                        for (int x = 0; x < w; x += 2) rgb_pair_to_uyvy(s + 3 * x, s + 3 * x + 3, d + 2 * x);
+                        break;
+                default: rc = -1;
+                }
+        }
+        free(rgb);
+        return rc;
 }

@@ -42,6 +42,9 @@ void oracle_yuv422_to_yuv444(const uint8_t *src, uint8_t *dst, long pix_count);
 /* ---- DXT decode (dxt_decode_oracle.c) ---- */
 void oracle_dxt5ycocg_decode_rgb(const uint8_t *src, uint8_t *dst_rgb, int w, int h);
 void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst_rgb, int w, int h);
+/* in_fmt ORACLE_OUT_*; out_fmt OPF_RGB / OPF_BGR / OPF_RGBA / OPF_UYVY; 0 ok, -1 bad args */
+int  oracle_dxt_decode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long dst_pitch,
+                       int rs, int gs, int bs);
 
 /* ---- pixfmt (pixfmt_oracle.c) ---- */
 enum {

@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
         for n in ("oracle_dxt5ycocg_decode_rgb", "oracle_dxt1_decode_rgb"):
             getattr(_lib, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
             getattr(_lib, n).restype = None
+        _lib.oracle_dxt_decode.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
+        _lib.oracle_dxt_decode.restype = C.c_int
         _lib.oracle_linesize.argtypes = [C.c_int, C.c_int]
         _lib.oracle_size.argtypes = [C.c_int, C.c_int]
         _lib.oracle_convert_line.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 3
@@ -85,7 +87,7 @@ def lib() -> C.CDLL:
 
 
 def have_ref() -> bool:
-    return os.path.exists(_REF_PATH) and os.path.exists(_REF_SCALAR_PATH)
+    return os.path.exists(_REF_PATH) and os.path.exists(_REF_SCALAR_PATH) and os.path.exists(os.path.join(_HERE, "_ref", "dxt62tga"))
 
 
 class _ToPlanar(C.Structure):  # src/to_planar.h:53-59
@@ -157,6 +159,35 @@ def dxt_decode_rgb(out_fmt: int, blocks: np.ndarray, w: int, h: int) -> np.ndarr
     fn = lib().oracle_dxt5ycocg_decode_rgb if out_fmt == OUT_DXT5YCOCG else lib().oracle_dxt1_decode_rgb
     fn(_ptr(blocks), _ptr(out), w, h)
     return out.reshape(h, w, 3)
+
+
+def dxt_decode(in_fmt: int, out_fmt: str, blocks: np.ndarray, w: int, h: int, shifts=(0, 8, 16)) -> np.ndarray:
+    """Frame decode to RGB / BGR / RGBA / UYVY (oracle/dxt_decode_oracle.c)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).ravel()
+    pitch = linesize(w, out_fmt)
+    out = np.zeros(pitch * h, np.uint8)
+    rc = lib().oracle_dxt_decode(in_fmt, OPF[out_fmt], _ptr(blocks), _ptr(out), w, h, pitch, *shifts)
+    if rc:
+        raise ValueError(f"oracle_dxt_decode rc={rc}")
+    return out
+
+
+DXT62TGA = os.path.join(_HERE, "_ref", "dxt62tga")
+
+
+def ref_dxt62tga(blocks: np.ndarray, w: int, h: int) -> np.ndarray:
+    """Run the reference's own stand-alone DXT5-YCoCg decoder (cuda_dxt/dxt62tga.c, compiled to oracle/_ref/dxt62tga)
+    and return its image as RGB rows top-down."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src, out = os.path.join(d, "in.yog"), os.path.join(d, "out.tga")
+        np.ascontiguousarray(blocks, np.uint8).tofile(src)
+        subprocess.check_call([DXT62TGA, str(w), str(h), src, out], stdout=subprocess.DEVNULL)
+        raw = np.fromfile(out, np.uint8)
+    hdr, data = raw[:18], raw[18:18 + w * h * 3].reshape(h, w, 3)
+    if not (hdr[17] & 0x20):      # TGA origin bit: 0 = bottom-left
+        data = data[::-1]
+    return np.ascontiguousarray(data[..., ::-1])  # BGR -> RGB
 
 
 # ----------------------------------------------------------------------------------

@@ -167,3 +167,16 @@ def test_independent_numpy_float32_rederivation(po):
                 blk = (np.linspace(40, 200, 16)[:, None] + rng.integers(-3, 4, (16, 3))).clip(0, 255).astype(np.uint8)
             got = po.dxt_encode(po.IN_RGB, po.OUT_DXT5YCOCG, blk.reshape(4, 12), 4, 4).view(np.uint32).tolist()
             assert got == _dxt5_block_numpy(blk), trial
+
+
+def test_decode_oracle_pinned_to_reference_tool(po):
+    """oracle/dxt_decode_oracle.c == the reference's own CPU decoder cuda_dxt/dxt62tga.c (compiled to
+    oracle/_ref/dxt62tga), on encoder output and on arbitrary bitstreams (both alpha interpolation modes)."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/dxt62tga not built (no /root/reference on this box)")
+    w, h = 96, 32
+    rng = np.random.default_rng(3)
+    cases = [po.dxt_encode(po.IN_RGB, po.OUT_DXT5YCOCG, synth.frame(k, "RGB", w, h), w, h) for k in ("S1", "S2", "S4")]
+    cases += [rng.integers(0, 256, w * h, dtype=np.uint8) for _ in range(3)]
+    for blocks in cases:
+        assert np.array_equal(po.dxt_decode(po.OUT_DXT5YCOCG, "RGB", blocks, w, h).reshape(h, w, 3), po.ref_dxt62tga(blocks, w, h))

@@ -62,6 +62,15 @@ def time_dxt_encode(in_fmt: int, out_fmt: int, src: torch.Tensor, dst: torch.Ten
     return ms.value
 
 
+def dxt_decode(in_fmt: int, out_fmt: int, blocks: torch.Tensor, w: int, h: int, shifts=(0, 8, 16)) -> torch.Tensor:
+    """DXT1 / DXT5-YCoCg -> RGB / BGR / RGBA / UYVY (dxt_decoder_decompress behind video_decompress/dxt_glsl.c:142-189)."""
+    blocks = _u8(blocks)
+    dst = torch.empty(linesize(out_fmt, w) * h, dtype=torch.uint8, device=blocks.device)
+    rc = L.load().ug_hip_dxt_decode(in_fmt, out_fmt, blocks.data_ptr(), dst.data_ptr(), w, h, 0, *shifts, _stream())
+    L.check(rc, "ug_hip_dxt_decode")
+    return dst
+
+
 def yuv422_to_yuv444(src: torch.Tensor, pix_count: int) -> torch.Tensor:
     src = _u8(src)
     dst = torch.empty(pix_count * 3, dtype=torch.uint8, device=src.device)

@@ -1,0 +1,234 @@
+// dxt_decode.hip -- DXT1 / DXT5-YCoCg block decode to RGB / BGR / RGBA / UYVY on gfx950.
+//
+// Receiver-side counterpart of dxt_encode.hip.  The reference decodes with OpenGL
+// (src/video_decompress/dxt_glsl.c:142-189 -> dxt_compress/dxt_decoder.c: fixed-function S3TC fetch +
+// display_dxt5ycocg_fp.glsl [+ rgba_to_yuv422.glsl]); the only CPU statement of the bitstream semantics is
+// the stand-alone tool cuda_dxt/dxt62tga.c:24-106, which this file follows operation for operation in
+// fp64 (-ffp-contract=off): it is bit-identical to oracle/dxt_decode_oracle.c, and that oracle is pinned to
+// the compiled dxt62tga binary (tests/test_oracle_dxt.py).
+//
+// Mapping: one lane = one 4x4 block, a wave = 64 consecutive blocks of a block row: the 16-byte (DXT5) /
+// 8-byte (DXT1) loads and the four row stores (64 x 16 B RGBA, 64 x 12 B RGB, 64 x 8 B UYVY) are contiguous
+// across lanes.  The 8-entry luma table and the 4-entry (Co,Cg) palette of a block live in LDS so that the
+// per-pixel lookups are one ds_read each instead of a chain of 64-bit selects.  HBM-bound:
+// algorithmic bytes per pixel = 1 (DXT5) or 0.5 (DXT1) read + 2 (UYVY) / 3 (RGB) / 4 (RGBA) written.
+#include "ug_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t clamp8(double s)
+{
+        // dxt62tga.c:14-21: (int)(s + 0.5), then clamp to [0, 255]
+        const int is = (int) (s + 0.5);
+        return (uint32_t) (is > 255 ? 255 : (is < 0 ? 0 : is));
+}
+
+__device__ __forceinline__ uint8_t unorm8_out(float x)
+{
+        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        return (uint8_t) (int) (x * 255.0f + 0.5f);
+}
+
+// dxt_compress/rgba_to_yuv422.glsl:27-46 on two 8-bit RGB texels -> one UYVY word
+__device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2)
+{
+        float yuv[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+                const uint32_t p = i ? p2 : p1;
+                const float r = (float) (p & 0xff) / 255.0f, g = (float) ((p >> 8) & 0xff) / 255.0f, b = (float) ((p >> 16) & 0xff) / 255.0f;
+                yuv[i][0] = (float) (1.0 / 16.0) + ((r * 0.2126f + g * 0.7152f) + b * 0.0722f) * 0.8588f;
+                yuv[i][1] = 0.5f + ((-r * 0.1145f - g * 0.3854f) + b * 0.5f) * 0.8784f;
+                yuv[i][2] = 0.5f + ((r * 0.5f - g * 0.4541f) - b * 0.0458f) * 0.8784f;
+        }
+        const float U = yuv[0][1] * 0.5f + yuv[1][1] * 0.5f, V = yuv[0][2] * 0.5f + yuv[1][2] * 0.5f;
+        return (uint32_t) unorm8_out(U) | (uint32_t) unorm8_out(yuv[0][0]) << 8 | (uint32_t) unorm8_out(V) << 16 |
+               (uint32_t) unorm8_out(yuv[1][0]) << 24;
+}
+
+struct OutArgs {
+        uint8_t *dst;
+        long pitch;
+        int rs, gs, bs;
+};
+
+// store one decoded row (4 pixels, packed R | G<<8 | B<<16) of block column bx
+template <int OUT>
+__device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4])
+{
+        uint8_t *row = o.dst + (long) y * o.pitch;
+        if (OUT == UG_PF_RGBA) {
+                const uint32_t am = 0xFFFFFFFFu ^ (0xFFu << o.rs) ^ (0xFFu << o.gs) ^ (0xFFu << o.bs);
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                        v[i] = am | (px[i] & 0xff) << o.rs | ((px[i] >> 8) & 0xff) << o.gs | ((px[i] >> 16) & 0xff) << o.bs;
+                }
+                ((uint4 *) row)[bx] = make_uint4(v[0], v[1], v[2], v[3]);
+        } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
+                uint32_t p[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                        p[i] = OUT == UG_PF_RGB ? px[i] : ((px[i] & 0xff) << 16 | (px[i] & 0xff00) | (px[i] >> 16));
+                }
+                uint32_t *d = (uint32_t *) row + 3 * bx;
+                d[0] = p[0] | p[1] << 24;
+                d[1] = (p[1] >> 8) | p[2] << 16;
+                d[2] = (p[2] >> 16) | p[3] << 8;
+        } else { // UYVY
+                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy(px[0], px[1]), rgb_pair_to_uyvy(px[2], px[3]));
+        }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh)
+{
+        // per-lane tables, entry-major so that a wave's accesses to one entry are contiguous
+        __shared__ double lds_a[8][256];
+        __shared__ double lds_co[4][256], lds_cg[4][256];
+        const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+        const int t = threadIdx.y * 64 + threadIdx.x;
+        if (bx >= bw || by >= bh) return;
+        const uint4 q = src[(long) by * bw + bx];
+        unsigned long long ac = (unsigned long long) q.x | (unsigned long long) q.y << 32;
+        unsigned long long cc = (unsigned long long) q.z | (unsigned long long) q.w << 32;
+
+        // dxt62tga.c:60-62 alpha endpoints, :36-58 the two interpolation modes
+        const double a0 = (double) (ac & 0xFF) / 255.0, a1 = (double) ((ac >> 8) & 0xFF) / 255.0;
+        lds_a[0][t] = a0;
+        lds_a[1][t] = a1;
+        if (a0 > a1) {
+#pragma unroll
+                for (int k = 2; k < 8; k++) lds_a[k][t] = ((double) (8 - k) * a0 + (double) (k - 1) * a1) / 7.0;
+        } else {
+#pragma unroll
+                for (int k = 2; k < 6; k++) lds_a[k][t] = ((double) (6 - k) * a0 + (double) (k - 1) * a1) / 5.0;
+                lds_a[6][t] = 0.0;
+                lds_a[7][t] = 1.0;
+        }
+        // dxt62tga.c:63-74 colour endpoints and the two thirds; :24-27 per-entry scale / Co / Cg
+        double r[4], g[4], b[4];
+        b[0] = (double) (cc & 0x1F) / 31.0;          g[0] = (double) ((cc >> 5) & 0x3F) / 63.0;  r[0] = (double) ((cc >> 11) & 0x1F) / 31.0;
+        b[1] = (double) ((cc >> 16) & 0x1F) / 31.0;  g[1] = (double) ((cc >> 21) & 0x3F) / 63.0; r[1] = (double) ((cc >> 27) & 0x1F) / 31.0;
+        b[2] = (2.0 * b[0] + b[1]) / 3.0; g[2] = (2.0 * g[0] + g[1]) / 3.0; r[2] = (2.0 * r[0] + r[1]) / 3.0;
+        b[3] = (b[0] + 2.0 * b[1]) / 3.0; g[3] = (g[0] + 2.0 * g[1]) / 3.0; r[3] = (r[0] + 2.0 * r[1]) / 3.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+                const double scale = 1.0 / (31.875 * b[k] + 1.0);
+                lds_co[k][t] = (r[k] - 5.01960814E-01) * scale;
+                lds_cg[k][t] = (g[k] - 5.01960814E-01) * scale;
+        }
+        ac >>= 16;
+        cc >>= 32;
+        // (LDS traffic is lane-private: no barrier, a wave's own ds ops are ordered)
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+                uint32_t px[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                        const int ai = (int) (ac & 7), ci = (int) (cc & 3);
+                        ac >>= 3;
+                        cc >>= 2;
+                        const double a = lds_a[ai][t], Co = lds_co[ci][t], Cg = lds_cg[ci][t];
+                        const uint32_t R = clamp8(((a + Co) - Cg) * 255.0);
+                        const uint32_t G = clamp8((a + Cg) * 255.0);
+                        const uint32_t B = clamp8(((a - Co) - Cg) * 255.0);
+                        px[x] = R | G << 8 | B << 16;
+                }
+                store_row<OUT>(o, 4 * by + y, bx, px);
+        }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restrict__ src, OutArgs o, int bw, int bh)
+{
+        const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+        if (bx >= bw || by >= bh) return;
+        const uint2 q = src[(long) by * bw + bx];
+        const uint32_t c0 = q.x & 0xffff, c1 = q.x >> 16;
+        double p[4][3];
+        p[0][0] = (double) ((c0 >> 11) & 0x1F) / 31.0; p[0][1] = (double) ((c0 >> 5) & 0x3F) / 63.0; p[0][2] = (double) (c0 & 0x1F) / 31.0;
+        p[1][0] = (double) ((c1 >> 11) & 0x1F) / 31.0; p[1][1] = (double) ((c1 >> 5) & 0x3F) / 63.0; p[1][2] = (double) (c1 & 0x1F) / 31.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+                if (c0 > c1) {
+                        p[2][k] = (2.0 * p[0][k] + p[1][k]) / 3.0;
+                        p[3][k] = (p[0][k] + 2.0 * p[1][k]) / 3.0;
+                } else { // 3-colour + transparent-black mode (never produced by our encoder)
+                        p[2][k] = (p[0][k] + p[1][k]) / 2.0;
+                        p[3][k] = 0.0;
+                }
+        }
+        uint32_t pal[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+                pal[k] = clamp8(p[k][0] * 255.0) | clamp8(p[k][1] * 255.0) << 8 | clamp8(p[k][2] * 255.0) << 16;
+        }
+        uint32_t idx = q.y;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+                uint32_t px[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                        const uint32_t ci = idx & 3;
+                        idx >>= 2;
+                        const uint32_t lo = (ci & 1) ? pal[1] : pal[0], hi = (ci & 1) ? pal[3] : pal[2];
+                        px[x] = (ci & 2) ? hi : lo;
+                }
+                store_row<OUT>(o, 4 * by + y, bx, px);
+        }
+}
+
+template <int OUT>
+int launch_decode(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
+{
+        const int bw = w / 4, bh = h / 4;
+        const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+        if (in == UG_DXT5_YCOCG) {
+                hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT>), grid, block, 0, st, (const uint4 *) src, o, bw, bh);
+        } else {
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
+        }
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+} // namespace
+
+extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
+                                 int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
+{
+        if (!src_dev || !dst_dev || width <= 0 || height <= 0 || (width & 3) || (height & 3) || (15 & (uintptr_t) dst_dev) ||
+            ((in == UG_DXT5_YCOCG ? 15 : 7) & (uintptr_t) src_dev) || (height / 4 + 3) / 4 > 65535) {
+                ug::set_last_error_msg("ug_hip_dxt_decode: bad size or alignment");
+                return UG_HIP_EINVAL;
+        }
+        if (in != UG_DXT1 && in != UG_DXT5_YCOCG) {
+                ug::set_last_error_msg("ug_hip_dxt_decode: unknown compressed format");
+                return UG_HIP_EUNSUPP;
+        }
+        if (dst_pitch == 0) {
+                dst_pitch = ug::linesize(out, width);
+        }
+        OutArgs o = { (uint8_t *) dst_dev, dst_pitch, rshift, gshift, bshift };
+        hipStream_t st = (hipStream_t) stream;
+        switch (out) {
+        case UG_PF_RGBA:
+                if (dst_pitch & 15) break;
+                return launch_decode<UG_PF_RGBA>(in, src_dev, o, width, height, st);
+        case UG_PF_RGB:
+                if (dst_pitch & 3) break;
+                return launch_decode<UG_PF_RGB>(in, src_dev, o, width, height, st);
+        case UG_PF_BGR:
+                if (dst_pitch & 3) break;
+                return launch_decode<UG_PF_BGR>(in, src_dev, o, width, height, st);
+        case UG_PF_UYVY:
+                if (dst_pitch & 7) break;
+                return launch_decode<UG_PF_UYVY>(in, src_dev, o, width, height, st);
+        default:
+                ug::set_last_error_msg("ug_hip_dxt_decode: unsupported output format");
+                return UG_HIP_EUNSUPP;
+        }
+        ug::set_last_error_msg("ug_hip_dxt_decode: destination pitch not aligned for this output format");
+        return UG_HIP_EINVAL;
+}

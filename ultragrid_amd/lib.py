@@ -48,6 +48,7 @@ SYMBOLS = {
     "ug_hip_rgb_to_dxt6": (_i, [_vp, _vp, _i, _i, _vp]),
     "ug_hip_yuv_to_dxt6": (_i, [_vp, _vp, _i, _i, _vp]),
     "ug_hip_yuv422_to_yuv444": (_i, [_vp, _vp, _i, _vp]),
+    "ug_hip_dxt_decode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ug_hip_pixfmt_supported": (_i, [_i, _i]),
     "ug_hip_pixfmt_convert": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ug_hip_linesize": (_i, [_i, _i]),
