@@ -81,3 +81,38 @@ def test_unsupported_input_is_refused_not_faked(tmp_path):
     np.zeros(64 * 16 * 6, np.uint8).tofile(raw)
     r = _run(["dxt:DXT5", "RG48", 64, 16, raw, tmp_path / "o.bin"])
     assert r.returncode == 3 and "Unsupported codec" in (r.stdout + r.stderr)  # frame dropped, no CPU fallback
+
+
+# ---------------------------------------------------------------------------------------------------------
+# receiver side: the reference's src/video_decompress.c selects our C decompress module by priority
+# ---------------------------------------------------------------------------------------------------------
+DEC_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ug_dec_harness")
+needs_dec_harness = pytest.mark.skipif(not os.path.exists(DEC_HARNESS), reason="oracle/_ref/ug_dec_harness not built")
+
+
+@needs_dec_harness
+def test_decompress_module_registers():
+    r = subprocess.run([DEC_HARNESS, "list"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "dxt_mi355x" in r.stdout.split()
+
+
+@needs_dec_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("out", ["RGBA", "RGB", "UYVY"])
+@pytest.mark.parametrize("comp", ["DXT1", "DXT5"])
+def test_decompress_through_reference_framework(tmp_path, po, comp, out):
+    w, h = 192, 64
+    oid = po.OUT_DXT1 if comp == "DXT1" else po.OUT_DXT5YCOCG
+    blocks = po.dxt_encode(po.IN_UYVY, oid, synth.s2_video("UYVY", w, h), w, h)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.raw"
+    blocks.tofile(src)
+    r = subprocess.run([DEC_HARNESS, comp, out, str(w), str(h), str(src), str(dst)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(dst, np.uint8), po.dxt_decode(oid, out, blocks, w, h))
+    # display pitch larger than the packed line (dxt_glsl.c:163-186 path)
+    ls = po.linesize(w, out)
+    pitch = ls + 64
+    r = subprocess.run([DEC_HARNESS, comp, out, str(w), str(h), str(src), str(dst), str(pitch)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(dst, np.uint8).reshape(h, pitch)[:, :ls]
+    assert np.array_equal(got.ravel(), po.dxt_decode(oid, out, blocks, w, h))

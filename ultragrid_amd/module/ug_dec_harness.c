@@ -1,0 +1,61 @@
+/**
+ * @file ug_dec_harness.c
+ * Receiver-side drop-in proof: the reference's own src/video_decompress.c (module selection by priority through
+ * lib_common.cpp) drives our decompress module:
+ *     decompress_init_multi(DXT5, {}, RGBA, &s, 1); decompress_reconfigure(s, desc, 0, 8, 16, pitch, RGBA);
+ *     decompress_frame(s, dst, src, len, 0, NULL, NULL); decompress_done(s);
+ * usage: ug_dec_harness <DXT1|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]
+ *        ug_dec_harness list
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lib_common.h"
+#include "types.h"
+#include "video_codec.h"
+#include "video_decompress.h"
+
+int main(int argc, char **argv)
+{
+        if (argc == 2 && strcmp(argv[1], "list") == 0) {
+                list_modules(LIBRARY_CLASS_VIDEO_DECOMPRESS, VIDEO_DECOMPRESS_ABI_VERSION, true);
+                return 0;
+        }
+        if (argc < 7) {
+                fprintf(stderr, "usage: %s <DXT1|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]\n", argv[0]);
+                return 1;
+        }
+        const codec_t in = get_codec_from_name(argv[1]), out = get_codec_from_name(argv[2]);
+        const unsigned w = atoi(argv[3]), h = atoi(argv[4]);
+        const int linesize = vc_get_linesize(w, out);
+        const int pitch = argc > 7 ? atoi(argv[7]) : linesize;
+        struct video_desc desc = { .width = w, .height = h, .color_spec = in, .fps = 30, .interlacing = PROGRESSIVE, .tile_count = 1 };
+        const size_t in_len = (size_t) w * h / (in == DXT1 ? 2 : 1);
+        unsigned char *src = malloc(in_len), *dst = calloc((size_t) pitch * h + 64, 1);
+        FILE *f = fopen(argv[5], "rb");
+        if (!f || fread(src, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read input\n"); return 1; }
+        fclose(f);
+
+        struct state_decompress *s = NULL;
+        struct pixfmt_desc internal = { 0 };
+        if (!decompress_init_multi(in, internal, out, &s, 1)) {
+                fprintf(stderr, "no decompressor for %s -> %s\n", argv[1], argv[2]);
+                return 2;
+        }
+        if (!decompress_reconfigure(s, desc, 0, 8, 16, pitch, out)) {
+                fprintf(stderr, "reconfigure failed\n");
+                return 2;
+        }
+        const decompress_status st = decompress_frame(s, dst, src, (unsigned) in_len, 0, NULL, NULL);
+        if (st != DECODER_GOT_FRAME) {
+                fprintf(stderr, "decompress_frame status %d\n", (int) st);
+                return 3;
+        }
+        f = fopen(argv[6], "wb");
+        fwrite(dst, 1, (size_t) pitch * h, f);
+        fclose(f);
+        printf("OK %s -> %s %ux%u pitch=%d\n", argv[1], argv[2], w, h, pitch);
+        decompress_done(s);
+        return 0;
+}
