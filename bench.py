@@ -87,6 +87,8 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=0, help="distinct frames per step (batch); 0 = workload default")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k-uyvy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU smoke test of the N>1 path)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="smoke test only: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,12 +98,17 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL: used ONLY for the timing barrier + max-over-ranks, not on the data path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from ultragrid_amd import codec, lib
     lib.load()
@@ -134,7 +141,8 @@ def main() -> None:
             ev1.record()
 
     # barrier + synchronize on both sides of exactly K steps, MAX over ranks (ultragrid_amd/shard.py)
-    wall = shard.timed_steps(timed_step, args.steps, torch.cuda.synchronize, dist, device="cuda")
+    wall = shard.timed_steps(timed_step, args.steps, torch.cuda.synchronize, dist,
+                             device="cuda" if args.dist_backend == "nccl" else "cpu")
     kern_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration (back-to-back launches on one stream)
 
     if rank == 0:
