@@ -169,6 +169,17 @@ int ug_hip_uyvy_to_jpeg420_coeffs(const void *src_dev, int src_pitch, int width,
                                   const float *div_dev, int16_t *out_y, int16_t *out_cb,
                                   int16_t *out_cr, ug_hip_stream_t stream);
 
+/* Complete baseline JPEG encoder (JFIF, 4:2:0, interleaved scan, restart intervals) = the fused FDCT+quantise
+ * above + Huffman coding (T.81 Annex K.3 tables) + headers.  Object shape of gpujpeg_encoder_create / _encode /
+ * _destroy (src/video_compress/gpujpeg.cpp:353,624,639).  `encode` is synchronous on `stream` (it returns the
+ * stream length); out_capacity must be >= ug_hip_jpeg_encoder_max_size().  Input: UYVY in device memory. */
+typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
+int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out);
+void   ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc);
+size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc);
+int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch,
+                                  void *out_dev, size_t out_capacity, size_t *out_len, ug_hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,9 +94,15 @@ def _block(bw, zz, pred, dc, ac):
     return int(zz[0])
 
 
-def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr):
+def header_bytes(width, height, qt_luma, qt_chroma, restart=0):
+    """SOI .. SOS of the stream write_jpeg420() produces (the product builds the same header on the host)."""
+    return write_jpeg420(width, height, qt_luma, qt_chroma, None, None, None, restart, header_only=True)
+
+
+def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart=0, header_only=False):
     """coef_*: (n_blocks, 64) int16 zig-zag; Y blocks in raster order over a (2*mcu_w) x (2*mcu_h) block grid,
-    chroma over mcu_w x mcu_h.  qt_*: 64 quantiser steps in natural order.  Returns JFIF bytes."""
+    chroma over mcu_w x mcu_h.  qt_*: 64 quantiser steps in natural order.  restart = MCUs per restart interval
+    (0 = none).  Returns JFIF bytes."""
     mw, mh = (width + 15) // 16, (height + 15) // 16
     out = io.BytesIO()
     out.write(b"\xff\xd8")
@@ -106,17 +112,28 @@ def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr):
     out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1]))
     for (tc, th, (bits, vals)) in ((0, 0, DC_L), (1, 0, AC_L), (0, 1, DC_C), (1, 1, AC_C)):
         out.write(b"\xff\xc4" + struct.pack(">HB", 19 + len(vals), (tc << 4) | th) + bytes(bits) + bytes(vals))
+    if restart:
+        out.write(b"\xff\xdd" + struct.pack(">HH", 4, restart))
     out.write(b"\xff\xda" + struct.pack(">HB", 12, 3) + bytes([1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0]))
+    if header_only:
+        return out.getvalue()
     dcl, acl, dcc, acc = _codes(*DC_L), _codes(*AC_L), _codes(*DC_C), _codes(*AC_C)
     bw = _Bits()
     py = pcb = pcr = 0
     bwid = 2 * mw
-    for my in range(mh):
-        for mx in range(mw):
-            for (dy, dx) in ((0, 0), (0, 1), (1, 0), (1, 1)):
-                py = _block(bw, coef_y[(2 * my + dy) * bwid + 2 * mx + dx], py, dcl, acl)
-            pcb = _block(bw, coef_cb[my * mw + mx], pcb, dcc, acc)
-            pcr = _block(bw, coef_cr[my * mw + mx], pcr, dcc, acc)
+    n_mcu = mw * mh
+    for m in range(n_mcu):
+        my, mx = divmod(m, mw)
+        if restart and m and m % restart == 0:
+            bw.flush()
+            out.write(bytes(bw.buf))
+            out.write(bytes([0xFF, 0xD0 + ((m // restart - 1) & 7)]))
+            bw = _Bits()
+            py = pcb = pcr = 0
+        for (dy, dx) in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            py = _block(bw, coef_y[(2 * my + dy) * bwid + 2 * mx + dx], py, dcl, acl)
+        pcb = _block(bw, coef_cb[my * mw + mx], pcb, dcc, acc)
+        pcr = _block(bw, coef_cr[my * mw + mx], pcr, dcc, acc)
     bw.flush()
     out.write(bytes(bw.buf))
     out.write(b"\xff\xd9")

@@ -68,3 +68,57 @@ def test_fused_uyvy_420_pipeline(hip, po, dims):
     div = hip.jpeg_divisors_device(q, "cuda")
     assert torch.equal(hip.jpeg_fdct_quant_plane(gy, div[:64].contiguous(), 2 * mw, 2 * mh), got[0])
     assert torch.equal(hip.jpeg_fdct_quant_plane(gu, div[64:].contiguous(), mw, mh), got[1])
+
+
+@pytest.mark.parametrize("dims", [(16, 16), (160, 96), (200, 120), (1920, 1080)], ids=str)
+@pytest.mark.parametrize("ri", [1, 4, 7])
+def test_full_jpeg_stream(hip, po, dims, ri):
+    """Complete encoder (FDCT+quant + Huffman + JFIF with restart intervals): the byte stream equals the test writer fed with
+    the oracle's coefficients, and an independent decoder (Pillow/libjpeg) reconstructs the picture."""
+    import io
+    import torch
+    from PIL import Image
+    from jpeg_bitstream import write_jpeg420
+    w, h = dims
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    rgb = rgb.clip(0, 255).astype(np.uint8)
+    uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h) if w % 2 == 0 else None
+    q = 75
+    enc = hip.JpegEncoder(w, h, q, ri)
+    data = enc.encode(torch.from_numpy(uyvy).cuda())
+    enc.close()
+    y, u, v = po.uyvy_to_i420(uyvy, w, h)
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    mw, mh = (w + 15) // 16, (h + 15) // 16
+    want = write_jpeg420(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, 2 * mh),
+                         po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh), po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh), restart=ri)
+    assert data == want, (len(data), len(want))
+    img = Image.open(io.BytesIO(data))
+    img.draft("YCbCr", None)
+    dec = np.asarray(img)
+    assert dec.shape == (h, w, 3)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((dec[..., 0].astype(float) - y.astype(float)) ** 2))
+    assert psnr > 40, psnr
+
+
+def test_jpeg_stream_random_content_and_stuffing(hip, po):
+    """Uniform-random frames at q=100 produce long codes and 0xFF bytes: exercises ZRL runs and byte stuffing."""
+    import io
+    import torch
+    from PIL import Image
+    from jpeg_bitstream import write_jpeg420
+    w, h = 128, 64
+    uyvy = synth.s1_random("UYVY", w, h)
+    enc = hip.JpegEncoder(w, h, 100, 2)
+    data = enc.encode(torch.from_numpy(uyvy).cuda())
+    y, u, v = po.uyvy_to_i420(uyvy, w, h)
+    ql, qc = po.jpeg_qtable(100, 0), po.jpeg_qtable(100, 1)
+    want = write_jpeg420(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 16, 8), po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), 8, 4),
+                         po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), 8, 4), restart=2)
+    assert data == want
+    assert b"\xff\x00" in data  # stuffing happened
+    img = Image.open(io.BytesIO(data))
+    img.draft("YCbCr", None)   # raw YCbCr planes, no RGB round trip
+    dec = np.asarray(img)
+    assert np.abs(dec[..., 0].astype(int) - y.astype(int)).mean() < 1.5

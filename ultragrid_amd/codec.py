@@ -150,3 +150,35 @@ def uyvy_to_jpeg420_coeffs(src: torch.Tensor, w: int, h: int, div: torch.Tensor)
                                                 ocr.data_ptr(), _stream())
     L.check(rc, "ug_hip_uyvy_to_jpeg420_coeffs")
     return oy, ocb, ocr
+
+
+class JpegEncoder:
+    """ug_hip_jpeg_encoder_* (gpujpeg_encoder_create / _encode / _destroy shape, gpujpeg.cpp:353,624,639)."""
+
+    def __init__(self, w: int, h: int, quality: int = 75, restart_interval: int = 4):
+        import ctypes as C
+        self._h = C.c_void_p()
+        L.check(L.load().ug_hip_jpeg_encoder_create(w, h, quality, restart_interval, C.byref(self._h)), "ug_hip_jpeg_encoder_create")
+        self.max_size = L.load().ug_hip_jpeg_encoder_max_size(self._h)
+        self._out = None
+
+    def encode(self, src: torch.Tensor) -> bytes:
+        import ctypes as C
+        src = _u8(src)
+        if self._out is None:
+            self._out = torch.empty(self.max_size, dtype=torch.uint8, device=src.device)
+        n = C.c_size_t(0)
+        rc = L.load().ug_hip_jpeg_encoder_encode(self._h, L.PF_UYVY, src.data_ptr(), 0, self._out.data_ptr(), self.max_size, C.byref(n), _stream())
+        L.check(rc, "ug_hip_jpeg_encoder_encode")
+        return bytes(self._out[: n.value].cpu().numpy())
+
+    def close(self):
+        if self._h:
+            L.load().ug_hip_jpeg_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
