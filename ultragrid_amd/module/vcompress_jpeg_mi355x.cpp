@@ -1,0 +1,226 @@
+/**
+ * @file vcompress_jpeg_mi355x.cpp
+ * UltraGrid video_compress module "jpeg" (-c jpeg[:q=<1-100>][:restart=<MCUs>][:dev=<n>]) backed by the MI355X kernel
+ * library (include/ug_mi355x.h: ug_hip_jpeg_encoder_*).  It occupies the name the reference registers as a hidden alias
+ * of its GPUJPEG module (src/video_compress/gpujpeg.cpp:791-792) and follows that module's conventions:
+ * quality / restart-interval options (gpujpeg.cpp:279-285,345-352,479-485), UYVY handed to the encoder as 4:2:x YCbCr in
+ * BT.709 limited range without conversion (gpujpeg.cpp:303-305,329-339), output codec JPEG with restart intervals.
+ *
+ * Differences by design: 4:2:0 baseline stream from a fused UYVY -> 4:2:0 -> FDCT -> quantise kernel; every input
+ * conversion (v210 / YUYV / RGB / RGBA / BGR -> UYVY: the pixfmt_conv.c arithmetic) runs on the device instead of the CPU
+ * line loop of gpujpeg.cpp:592-608; tile API with one stream per module instance; no CPU fallback.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "debug.h"
+#include "host.h"
+#include "lib_common.h"
+#include "types.h"
+#include "utils/video_frame_pool.h"
+#include "video_codec.h"
+#include "video_compress.h"
+#include "video_frame.h"
+
+#include "../../include/ug_mi355x.h"
+#include "ug_codec_map.h"
+
+#define MOD_NAME "[JPEG MI355X] "
+
+namespace {
+
+struct hip_pinned_allocator : public video_frame_pool_allocator {
+        void *allocate(size_t size) override {
+                void *ptr = nullptr;
+                return ug_hip_malloc_host(&ptr, size) == UG_HIP_SUCCESS ? ptr : nullptr;
+        }
+        void deallocate(void *ptr) override { ug_hip_free_host(ptr); }
+        video_frame_pool_allocator *clone() const override { return new hip_pinned_allocator(*this); }
+};
+
+struct state_video_compress_jpeg_mi355x {
+        struct video_desc    saved_desc{};
+        int                  device = 0, quality = 75, restart = 2;
+        ug_pixfmt_t          wire = UG_PF_NONE;     ///< format of the uploaded frame
+        ug_hip_stream_t      stream = nullptr;
+        ug_hip_jpeg_encoder *enc = nullptr;
+        void                *dev_in = nullptr, *dev_uyvy = nullptr, *dev_out = nullptr;
+        size_t               in_len = 0, max_out = 0;
+        video_frame_pool     pool{0, hip_pinned_allocator()};
+};
+
+void cleanup(state_video_compress_jpeg_mi355x *s)
+{
+        if (s->enc) { ug_hip_jpeg_encoder_destroy(s->enc); s->enc = nullptr; }
+        for (void **p : { &s->dev_in, &s->dev_uyvy, &s->dev_out }) {
+                if (*p) { ug_hip_free(*p); *p = nullptr; }
+        }
+}
+
+void usage()
+{
+        printf("MI355X JPEG compression usage:\n"
+               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:dev=<index>]\n");
+}
+
+void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
+{
+        (void) parent;
+        auto *s = new state_video_compress_jpeg_mi355x();
+        std::string cfg = fmt ? fmt : "";
+        size_t pos = 0;
+        while (!cfg.empty() && pos <= cfg.size()) {
+                size_t end = cfg.find(':', pos);
+                std::string tok = cfg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+                if (strncasecmp(tok.c_str(), "q=", 2) == 0) {
+                        s->quality = atoi(tok.c_str() + 2);
+                } else if (strncasecmp(tok.c_str(), "quality=", 8) == 0) {
+                        s->quality = atoi(tok.c_str() + 8);
+                } else if (strncasecmp(tok.c_str(), "restart=", 8) == 0) {
+                        s->restart = atoi(tok.c_str() + 8);
+                } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
+                        s->device = atoi(tok.c_str() + 4);
+                } else if (tok == "help") {
+                        usage();
+                        delete s;
+                        return INIT_NOERR;
+                } else if (!tok.empty()) {
+                        MSG(ERROR, "unknown option: %s\n", tok.c_str());
+                        usage();
+                        delete s;
+                        return nullptr;
+                }
+                if (end == std::string::npos) break;
+                pos = end + 1;
+        }
+        if (s->quality < 1 || s->quality > 100 || s->restart < 1) {
+                MSG(ERROR, "quality must be 1-100 and restart >= 1\n");
+                delete s;
+                return nullptr;
+        }
+        if (ug_hip_set_device(s->device) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "cannot use HIP device %d: %s\n", s->device, ug_hip_last_error_string());
+                delete s;
+                return nullptr;
+        }
+        return s;
+}
+
+bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
+{
+        cleanup(s);
+        s->wire = ug_pixfmt_from_codec(desc.color_spec);
+        if (s->wire != UG_PF_UYVY && !ug_hip_pixfmt_supported(s->wire, UG_PF_UYVY)) {
+                MSG(ERROR, "Unsupported codec: %s (GPU path takes UYVY, YUYV, v210, RGB, RGBA, BGR, RG48)\n", get_codec_name(desc.color_spec));
+                return false;
+        }
+        s->in_len = (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
+        if (ug_hip_jpeg_encoder_create((int) desc.width, (int) desc.height, s->quality, s->restart, &s->enc) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "encoder creation failed: %s\n", ug_hip_last_error_string());
+                return false;
+        }
+        s->max_out = ug_hip_jpeg_encoder_max_size(s->enc);
+        bool ok = ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING) == UG_HIP_SUCCESS &&
+                  ug_hip_malloc(&s->dev_out, s->max_out) == UG_HIP_SUCCESS;
+        if (ok && s->wire != UG_PF_UYVY) {
+                ok = ug_hip_malloc(&s->dev_uyvy, (size_t) vc_get_linesize(desc.width, UYVY) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
+        }
+        if (!ok) {
+                MSG(ERROR, "Could not allocate device buffers: %s\n", ug_hip_last_error_string());
+                return false;
+        }
+        struct video_desc compressed_desc = desc;
+        compressed_desc.color_spec = JPEG;
+        compressed_desc.tile_count = 1;
+        // typical streams are ~10x smaller than the worst case the kernel library sizes for; the pool holds the worst case
+        s->pool.reconfigure(compressed_desc, s->max_out);
+        return true;
+}
+
+std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_ptr<video_frame> tx)
+{
+        if (!tx) {
+                return {};
+        }
+        auto *s = static_cast<state_video_compress_jpeg_mi355x *>(state);
+        if (ug_hip_set_device(s->device) != UG_HIP_SUCCESS) {
+                return {};
+        }
+        if (!video_desc_eq_excl_param(video_desc_from_frame(tx.get()), s->saved_desc, PARAM_TILE_COUNT)) {
+                if (configure_with(s, video_desc_from_frame(tx.get()))) {
+                        s->saved_desc = video_desc_from_frame(tx.get());
+                } else {
+                        MSG(ERROR, "Reconfiguration failed!\n");
+                        s->saved_desc = {};
+                        return {};
+                }
+        }
+        const int w = (int) tx->tiles[0].width, h = (int) tx->tiles[0].height;
+        if (ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "H2D copy failed: %s\n", ug_hip_last_error_string());
+                return {};
+        }
+        const void *uyvy = s->dev_in;
+        if (s->wire != UG_PF_UYVY) {
+                if (ug_hip_pixfmt_convert(s->wire, UG_PF_UYVY, s->dev_in, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
+                        MSG(ERROR, "device conversion to UYVY failed: %s\n", ug_hip_last_error_string());
+                        return {};
+                }
+                uyvy = s->dev_uyvy;
+        }
+        size_t len = 0;
+        if (ug_hip_jpeg_encoder_encode(s->enc, UG_PF_UYVY, uyvy, 0, s->dev_out, s->max_out, &len, s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "Encoding failed: %s\n", ug_hip_last_error_string());
+                return {};
+        }
+        std::shared_ptr<video_frame> out = s->pool.get_frame();
+        if (ug_hip_memcpy_async(out->tiles[0].data, s->dev_out, len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) != UG_HIP_SUCCESS ||
+            ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "D2H copy failed: %s\n", ug_hip_last_error_string());
+                return {};
+        }
+        out->tiles[0].data_len = (unsigned int) len;
+        return out;
+}
+
+void jpeg_mi355x_compress_done(void *state)
+{
+        auto *s = static_cast<state_video_compress_jpeg_mi355x *>(state);
+        ug_hip_set_device(s->device);
+        cleanup(s);
+        if (s->stream) ug_hip_stream_destroy(s->stream);
+        delete s;
+}
+
+compress_module_info get_jpeg_mi355x_module_info()
+{
+        compress_module_info module_info;
+        module_info.name = "jpeg";
+        module_info.opts.emplace_back(module_option{ "Quality", "Quality 1-100", "75", "quality", ":q=", false });
+        module_info.opts.emplace_back(module_option{ "Restart interval", "MCUs per restart interval", "2", "restart_interval", ":restart=", false });
+        codec codec_info;
+        codec_info.name = "JPEG";
+        codec_info.priority = 300;
+        codec_info.encoders.emplace_back(encoder{ "default", "" });
+        module_info.codecs.emplace_back(std::move(codec_info));
+        return module_info;
+}
+
+const struct video_compress_info jpeg_mi355x_info = {
+        jpeg_mi355x_compress_init,
+        jpeg_mi355x_compress_done,
+        NULL,
+        jpeg_mi355x_compress_tile,
+        NULL,
+        NULL,
+        NULL,
+        NULL,
+        get_jpeg_mi355x_module_info,
+};
+
+REGISTER_MODULE(jpeg, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+
+} // end of anonymous namespace
