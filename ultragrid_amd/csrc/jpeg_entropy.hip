@@ -24,111 +24,152 @@ const uint8_t kZigHost[64] = {
         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
 };
 
-struct BitWriter {
-        uint8_t *p;
-        uint64_t acc; // n valid bits, right aligned
-        int n;
-        __device__ __forceinline__ void put(uint32_t code, int len)
-        {
-                acc = (acc << len) | code;
-                n += len;
-                while (n >= 8) {
-                        const uint8_t b = (uint8_t) (acc >> (n - 8));
-                        *p++ = b;
-                        if (b == 0xFF) *p++ = 0; // byte stuffing (T.81 B.1.1.5)
-                        n -= 8;
-                }
-        }
-        __device__ __forceinline__ void flush()
-        {
-                if (n) put((1u << (8 - n)) - 1, 8 - n); // pad with 1-bits
-        }
-};
-
-// one 8x8 block: DC difference + run/size coded AC (T.81 F.1.2)
-__device__ __forceinline__ int encode_block(BitWriter &bw, const int16_t *__restrict__ zz, int pred, int comp)
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-cooperative Huffman coding: one wave per restart segment, one LANE PER COEFFICIENT of the current block.
+//   1. lane k loads zz[k]; lane 0 turns it into the DC difference;
+//   2. zero runs come from the ballot of non-zero AC lanes (distance to the previous set bit), so every emitting lane
+//      builds its own bit string -- up to 3 ZRL codes + run/size code + value bits (+ EOB on the last emitter), <= 63 bits;
+//   3. an exclusive wave scan of the string lengths gives every lane its bit position; lanes OR their strings into a
+//      64-word LDS window (ds_or_b32), and the complete 32-bit words are flushed, byte-swapped, with one coalesced store;
+//   4. the partial word is carried into the next block; the segment ends padded with 1-bits.
+// The scan data written here is NOT yet byte-stuffed: 0xFF bytes are counted per segment and the 0x00 bytes are inserted
+// by the compaction pass, which has to move every byte anyway.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
 {
-        const uint4 *q = (const uint4 *) zz;
-        int16_t c[64];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-                const uint4 v = q[i];
-                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                        c[8 * i + 2 * k] = (int16_t) (w[k] & 0xffff);
-                        c[8 * i + 2 * k + 1] = (int16_t) (w[k] >> 16);
-                }
+        for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(v, d);
+                if (lane >= d) v += t;
         }
-        {
-                const int diff = (int) c[0] - pred;
-                const int a = diff < 0 ? -diff : diff;
-                const int size = a ? 32 - __builtin_clz((unsigned) a) : 0;
-                const uint32_t e = kDcTab[comp][size];
-                bw.put(e & 0xffff, (int) (e >> 16));
-                if (size) bw.put((uint32_t) (diff < 0 ? diff + (1 << size) - 1 : diff), size);
-        }
-        int run = 0;
-        for (int k = 1; k < 64; k++) {
-                const int v = c[k];
-                if (v == 0) {
-                        run++;
-                        continue;
-                }
-                while (run > 15) {
-                        const uint32_t z = kAcTab[comp][0xF0];
-                        bw.put(z & 0xffff, (int) (z >> 16));
-                        run -= 16;
-                }
-                const int a = v < 0 ? -v : v;
-                const int size = 32 - __builtin_clz((unsigned) a);
-                const uint32_t e = kAcTab[comp][(run << 4) | size];
-                bw.put(e & 0xffff, (int) (e >> 16));
-                bw.put((uint32_t) (v < 0 ? v + (1 << size) - 1 : v), size);
-                run = 0;
-        }
-        if (run) {
-                const uint32_t e = kAcTab[comp][0x00];
-                bw.put(e & 0xffff, (int) (e >> 16));
-        }
-        return c[0];
+        return v;
 }
 
-__global__ __launch_bounds__(64) void entropy_segments_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
-                                                              const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int ri,
-                                                              int n_seg, uint8_t *__restrict__ scratch, int cap,
-                                                              uint32_t *__restrict__ seg_len)
+__device__ __forceinline__ int count_ff_bytes(uint32_t w)
 {
-        const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-        if (seg >= n_seg) return;
-        BitWriter bw = { scratch + (size_t) seg * cap, 0, 0 };
-        uint8_t *const start = bw.p;
-        int py = 0, pcb = 0, pcr = 0;
+        return ((w & 0xffu) == 0xffu) + ((w & 0xff00u) == 0xff00u) + ((w & 0xff0000u) == 0xff0000u) + ((w >> 24) == 0xffu);
+}
+
+constexpr int kRawBytesPerBlock = 224; // 56 words >= (31 carried + 64 x 27) bits
+
+__global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
+                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int ri, int n_seg,
+                                                           uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
+                                                           uint32_t *__restrict__ seg_ff)
+{
+        __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
+        __shared__ uint32_t win[4][68];
+        for (int i = threadIdx.x; i < 512; i += 256) ac_tab[i >> 8][i & 255] = kAcTab[i >> 8][i & 255];
+        if (threadIdx.x < 24) dc_tab[threadIdx.x / 12][threadIdx.x % 12] = kDcTab[threadIdx.x / 12][threadIdx.x % 12];
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int seg = blockIdx.x * 4 + wv;
+        if (seg >= n_seg) return; // wave-uniform
+        uint32_t *buf = win[wv];
+        uint32_t *out = raw + (size_t) seg * cap_words;
+        uint32_t carry_word = 0; // partial word, bits left-aligned
+        int carry_bits = 0, wbase = 0, ff = 0;
+        int pred[3] = { 0, 0, 0 };
         const int m_end = min(n_mcu, (seg + 1) * ri);
         for (int m = seg * ri; m < m_end; m++) {
                 const int my = m / mcu_w, mx = m - my * mcu_w;
 #pragma unroll 1
-                for (int b = 0; b < 4; b++) {
-                        const long blk = (long) (2 * my + (b >> 1)) * (2 * mcu_w) + 2 * mx + (b & 1);
-                        py = encode_block(bw, cy + 64 * blk, py, 0);
+                for (int b = 0; b < 6; b++) {
+                        const int comp = b < 4 ? 0 : 1, pi = b < 4 ? 0 : b - 3;
+                        const int16_t *zz = b < 4 ? cy + 64 * ((long) (2 * my + (b >> 1)) * (2 * mcu_w) + 2 * mx + (b & 1))
+                                                  : (b == 4 ? cb : cr) + 64L * m;
+                        int v = zz[lane];
+                        const int dc = __builtin_amdgcn_readfirstlane(v);
+                        if (lane == 0) v = dc - pred[pi];
+                        pred[pi] = dc;
+                        const unsigned long long acmask = __ballot(lane > 0 && v != 0);
+                        const int a = v < 0 ? -v : v;
+                        const int size = a ? 32 - __builtin_clz((unsigned) a) : 0;
+                        const uint32_t vbits = (uint32_t) (v < 0 ? v + (1 << size) - 1 : v) & ((1u << size) - 1);
+                        // zero run before this lane = distance to the previous non-zero AC lane (or to the DC lane)
+                        const unsigned long long below = (acmask | 1ull) & ((1ull << lane) - 1ull);
+                        const int prev = lane ? 63 - __builtin_clzll(below) : 0;
+                        const int run = lane ? lane - prev - 1 : 0;
+                        const uint32_t e = lane == 0 ? dc_tab[comp][size] : ac_tab[comp][((run & 15) << 4) | size];
+                        unsigned long long bits = ((unsigned long long) (e & 0xffff) << size) | vbits;
+                        int nb = (int) (e >> 16) + size;
+                        const bool emits = lane == 0 || ((acmask >> lane) & 1ull);
+                        if (lane > 0 && run > 15) { // 1..3 ZRL symbols in front
+                                const uint32_t z = ac_tab[comp][0xF0];
+                                const unsigned long long zc = z & 0xffff;
+                                const int zl = (int) (z >> 16), nz = run >> 4;
+                                unsigned long long zz3 = zc;
+                                if (nz > 1) zz3 = (zz3 << zl) | zc;
+                                if (nz > 2) zz3 = (zz3 << zl) | zc;
+                                bits |= zz3 << nb;
+                                nb += nz * zl;
+                        }
+                        const int last = 63 - __builtin_clzll(acmask | 1ull);
+                        if (lane == last && last < 63) { // EOB after the last non-zero coefficient
+                                const uint32_t eob = ac_tab[comp][0x00];
+                                bits = (bits << (eob >> 16)) | (eob & 0xffff);
+                                nb += (int) (eob >> 16);
+                        }
+                        if (!emits) nb = 0;
+                        const int incl = wave_inclusive_scan(nb, lane);
+                        const int total = __builtin_amdgcn_readlane(incl, 63);
+                        const int pos = carry_bits + incl - nb;
+                        // window: word 0 starts with the carried partial word
+                        buf[lane] = lane == 0 ? carry_word : 0;
+                        if (lane < 4) buf[64 + lane] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (nb) {
+                                const unsigned long long s = bits << (64 - nb); // left-aligned string
+                                const int j = pos >> 5, o = pos & 31;
+                                atomicOr(&buf[j], (uint32_t) (s >> (32 + o)));
+                                if (o + nb > 32) atomicOr(&buf[j + 1], (uint32_t) (s >> o));
+                                if (o + nb > 64) atomicOr(&buf[j + 2], (uint32_t) (s << (32 - o)));
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int tot = carry_bits + total, nw = tot >> 5;
+                        const uint32_t word = buf[lane];
+                        if (lane < nw) {
+                                out[wbase + lane] = __builtin_bswap32(word); // stream order in memory
+                        }
+                        {
+                                int c = lane < nw ? count_ff_bytes(word) : 0;
+#pragma unroll
+                                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+                                ff += c;
+                        }
+                        carry_word = __builtin_amdgcn_readlane(word, nw & 63);
+                        carry_bits = tot & 31;
+                        wbase += nw;
+                        __builtin_amdgcn_wave_barrier();
                 }
-                pcb = encode_block(bw, cb + 64L * m, pcb, 1);
-                pcr = encode_block(bw, cr + 64L * m, pcr, 1);
         }
-        bw.flush();
-        seg_len[seg] = (uint32_t) (bw.p - start);
+        // pad the last partial byte with 1-bits (T.81 F.1.2.3) and emit the tail bytes
+        int tail = 0;
+        if (carry_bits) {
+                tail = (carry_bits + 7) >> 3;
+                const int pad = 8 * tail - carry_bits;
+                carry_word |= ((1u << pad) - 1u) << (32 - carry_bits - pad);
+                if (lane == 0) out[wbase] = __builtin_bswap32(carry_word);
+                for (int i = 0; i < tail; i++) ff += ((carry_word >> (24 - 8 * i)) & 0xff) == 0xff;
+        }
+        if (lane == 0) {
+                seg_len[seg] = (uint32_t) (4 * wbase + tail);
+                seg_ff[seg] = (uint32_t) ff;
+        }
 }
 
-// exclusive prefix sum of (segment length + 2-byte marker), single workgroup; off[n_seg] = total stream length
-__global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_len, int n_seg, uint32_t header_len,
-                                                               uint32_t *__restrict__ off)
+// exclusive prefix sum of (segment bytes + stuffed zeros + 2-byte marker), single workgroup; off[n_seg] = total length
+__global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ seg_ff,
+                                                               int n_seg, uint32_t header_len, uint32_t *__restrict__ off)
 {
         __shared__ uint32_t part[1024];
         const int t = threadIdx.x;
         const int per = (n_seg + 1023) / 1024;
         const int lo = min(n_seg, t * per), hi = min(n_seg, lo + per);
         uint32_t s = 0;
-        for (int i = lo; i < hi; i++) s += seg_len[i] + 2;
+        for (int i = lo; i < hi; i++) s += seg_len[i] + seg_ff[i] + 2;
         part[t] = s;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
@@ -140,24 +181,37 @@ __global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *_
         uint32_t run = header_len + (t ? part[t - 1] : 0);
         for (int i = lo; i < hi; i++) {
                 off[i] = run;
-                run += seg_len[i] + 2;
+                run += seg_len[i] + seg_ff[i] + 2;
         }
         if (t == 1023) off[n_seg] = header_len + part[1023];
 }
 
-// one wave per segment: copy its bytes to the final position and append RSTm (or EOI after the last one)
-__global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ scratch, int cap, const uint32_t *__restrict__ seg_len,
+// one wave per segment: move its bytes to the final position, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
+// append RSTm (or EOI after the last segment)
+__global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ raw, int cap_bytes, const uint32_t *__restrict__ seg_len,
                                                       const uint32_t *__restrict__ off, int n_seg, uint8_t *__restrict__ out)
 {
         const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (seg >= n_seg) return;
-        const uint8_t *s = scratch + (size_t) seg * cap;
+        const uint8_t *s = raw + (size_t) seg * cap_bytes;
         uint8_t *d = out + off[seg];
         const uint32_t n = seg_len[seg];
-        for (uint32_t i = lane; i < n; i += 64) d[i] = s[i];
+        uint32_t extra = 0; // zeros inserted so far (wave-uniform)
+        for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t i = base + lane;
+                const bool valid = i < n;
+                const uint8_t b = valid ? s[i] : 0;
+                const unsigned long long ffm = __ballot(valid && b == 0xFF);
+                const uint32_t before = (uint32_t) __builtin_popcountll(ffm & ((1ull << lane) - 1ull));
+                if (valid) {
+                        d[i + extra + before] = b;
+                        if (b == 0xFF) d[i + extra + before + 1] = 0;
+                }
+                extra += (uint32_t) __builtin_popcountll(ffm);
+        }
         if (lane == 0) {
-                d[n] = 0xFF;
-                d[n + 1] = seg == n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (seg & 7));
+                d[n + extra] = 0xFF;
+                d[n + extra + 1] = seg == n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (seg & 7));
         }
 }
 
@@ -167,8 +221,8 @@ struct Encoder {
         // device workspace
         float *div;
         int16_t *cy, *cb, *cr;
-        uint8_t *scratch;
-        uint32_t *seg_len, *off;
+        uint32_t *scratch; // per-segment scan data before byte stuffing, cap bytes each
+        uint32_t *seg_len, *seg_ff, *off;
         uint8_t *header_dev;
         uint32_t *total_host; // pinned
 };
@@ -207,7 +261,7 @@ void destroy(Encoder *e)
 {
         if (!e) return;
         for (void *p : { (void *) e->div, (void *) e->cy, (void *) e->cb, (void *) e->cr, (void *) e->scratch, (void *) e->seg_len,
-                         (void *) e->off, (void *) e->header_dev }) {
+                         (void *) e->seg_ff, (void *) e->off, (void *) e->header_dev }) {
                 if (p) (void) hipFree(p);
         }
         if (e->total_host) (void) hipHostFree(e->total_host);
@@ -230,7 +284,7 @@ int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_i
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
         e->mcu_w = (width + 15) / 16; e->mcu_h = (height + 15) / 16; e->n_mcu = e->mcu_w * e->mcu_h;
         e->n_seg = (e->n_mcu + e->ri - 1) / e->ri;
-        e->cap = e->ri * 6 * 448 + 16; // worst case per block: 64 coefficients x (16 + 11) bits = 216 B, doubled if every byte were stuffed
+        e->cap = e->ri * 6 * kRawBytesPerBlock + 8; // unstuffed scan bytes of one segment (worst case 27 bits per coefficient)
         uint8_t ql[64], qc[64];
         float div[128];
         ug_hip_jpeg_qtable(quality, 0, ql);
@@ -246,6 +300,7 @@ int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_i
         alloc((void **) &e->cr, (size_t) e->n_mcu * 128);
         alloc((void **) &e->scratch, (size_t) e->n_seg * e->cap);
         alloc((void **) &e->seg_len, (size_t) e->n_seg * 4);
+        alloc((void **) &e->seg_ff, (size_t) e->n_seg * 4);
         alloc((void **) &e->off, (size_t) (e->n_seg + 1) * 4);
         alloc((void **) &e->header_dev, e->header.size());
         if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocDefault);
@@ -265,7 +320,7 @@ void ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc) { destroy((Encoder *)
 size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc)
 {
         const Encoder *e = (const Encoder *) enc;
-        return e ? e->header.size() + (size_t) e->n_seg * (e->cap + 2) : 0;
+        return e ? e->header.size() + (size_t) e->n_seg * (2 * (size_t) e->cap + 2) : 0; // every byte stuffed = worst case
 }
 
 int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch, void *out_dev,
@@ -287,12 +342,13 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
         hipStream_t st = (hipStream_t) stream;
         int rc = ug_hip_uyvy_to_jpeg420_coeffs(src_dev, src_pitch, e->width, e->height, e->div, e->cy, e->cb, e->cr, stream);
         if (rc != UG_HIP_SUCCESS) return rc;
-        hipLaunchKernelGGL(entropy_segments_kernel, dim3((e->n_seg + 63) / 64), dim3(64), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu,
-                           e->ri, e->n_seg, e->scratch, e->cap, e->seg_len);
-        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_len, e->n_seg, (uint32_t) e->header.size(), e->off);
+        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->ri,
+                           e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
+        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_len, e->seg_ff, e->n_seg, (uint32_t) e->header.size(),
+                           e->off);
         UG_HIP_TRY(hipMemcpyAsync(out_dev, e->header_dev, e->header.size(), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->scratch, e->cap, e->seg_len, e->off, e->n_seg,
-                           (uint8_t *) out_dev);
+        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->off,
+                           e->n_seg, (uint8_t *) out_dev);
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipMemcpyAsync(e->total_host, e->off + e->n_seg, 4, hipMemcpyDeviceToHost, st));
         UG_HIP_TRY(hipStreamSynchronize(st));
