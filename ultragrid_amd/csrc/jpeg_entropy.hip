@@ -35,13 +35,16 @@ const uint8_t kZigHost[64] = {
 // The scan data written here is NOT yet byte-stuffed: 0xFF bytes are counted per segment and the 0x00 bytes are inserted
 // by the compaction pass, which has to move every byte anyway.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+// inclusive prefix sum over the 64 lanes with DPP moves (no LDS traffic): Hillis-Steele inside the 16-lane rows, then the
+// gfx9 row broadcasts carry the row totals across (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_inclusive_scan(int v, int)
 {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(v, d);
-                if (lane >= d) v += t;
-        }
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31
         return v;
 }
 
@@ -55,7 +58,7 @@ constexpr int kRawBytesPerBlock = 224; // 56 words >= (31 carried + 64 x 27) bit
 __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
                                                            const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int ri, int n_seg,
                                                            uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
-                                                           uint32_t *__restrict__ seg_ff)
+                                                           uint32_t *__restrict__ seg_ff /* final size of the segment */)
 {
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
         __shared__ uint32_t win[4][68];
@@ -70,15 +73,29 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         uint32_t carry_word = 0; // partial word, bits left-aligned
         int carry_bits = 0, wbase = 0, ff = 0;
         int pred[3] = { 0, 0, 0 };
-        const int m_end = min(n_mcu, (seg + 1) * ri);
-        for (int m = seg * ri; m < m_end; m++) {
-                const int my = m / mcu_w, mx = m - my * mcu_w;
-#pragma unroll 1
-                for (int b = 0; b < 6; b++) {
+        const int m0 = seg * ri, n_blk = 6 * (min(n_mcu, (seg + 1) * ri) - m0);
+        // Walk the blocks of the segment in scan order (per MCU: Y00 Y01 Y10 Y11 Cb Cr) with incrementally updated
+        // wave-uniform indices (one division per segment), always one block ahead: the load of block t+1 is issued before
+        // block t is coded.
+        int mx = m0 % mcu_w, my = m0 / mcu_w, m = m0, b_next = 0;
+        auto next_ptr = [&]() { // pointer of block (m, b_next), then advance
+                const int16_t *p = b_next < 4 ? cy + 64 * ((long) (2 * my + (b_next >> 1)) * (2 * mcu_w) + 2 * mx + (b_next & 1))
+                                              : (b_next == 4 ? cb : cr) + 64L * m;
+                if (++b_next == 6) {
+                        b_next = 0;
+                        m++;
+                        if (++mx == mcu_w) { mx = 0; my++; }
+                }
+                return p;
+        };
+        int v_next = next_ptr()[lane];
+        int b = -1;
+        for (int t = 0; t < n_blk; t++) {
+                {
+                        b = b == 5 ? 0 : b + 1;
                         const int comp = b < 4 ? 0 : 1, pi = b < 4 ? 0 : b - 3;
-                        const int16_t *zz = b < 4 ? cy + 64 * ((long) (2 * my + (b >> 1)) * (2 * mcu_w) + 2 * mx + (b & 1))
-                                                  : (b == 4 ? cb : cr) + 64L * m;
-                        int v = zz[lane];
+                        int v = v_next;
+                        if (t + 1 < n_blk) v_next = next_ptr()[lane];
                         const int dc = __builtin_amdgcn_readfirstlane(v);
                         if (lane == 0) v = dc - pred[pi];
                         pred[pi] = dc;
@@ -133,12 +150,7 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
                         if (lane < nw) {
                                 out[wbase + lane] = __builtin_bswap32(word); // stream order in memory
                         }
-                        {
-                                int c = lane < nw ? count_ff_bytes(word) : 0;
-#pragma unroll
-                                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-                                ff += c;
-                        }
+                        if (lane < nw) ff += count_ff_bytes(word); // per lane; reduced once at the end of the segment
                         carry_word = __builtin_amdgcn_readlane(word, nw & 63);
                         carry_bits = tot & 31;
                         wbase += nw;
@@ -151,39 +163,51 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
                 tail = (carry_bits + 7) >> 3;
                 const int pad = 8 * tail - carry_bits;
                 carry_word |= ((1u << pad) - 1u) << (32 - carry_bits - pad);
-                if (lane == 0) out[wbase] = __builtin_bswap32(carry_word);
-                for (int i = 0; i < tail; i++) ff += ((carry_word >> (24 - 8 * i)) & 0xff) == 0xff;
+                if (lane == 0) {
+                        out[wbase] = __builtin_bswap32(carry_word);
+                        for (int i = 0; i < tail; i++) ff += ((carry_word >> (24 - 8 * i)) & 0xff) == 0xff;
+                }
         }
+        ff = __builtin_amdgcn_readlane(wave_inclusive_scan(ff, lane), 63);
         if (lane == 0) {
                 seg_len[seg] = (uint32_t) (4 * wbase + tail);
-                seg_ff[seg] = (uint32_t) ff;
+                seg_ff[seg] = (uint32_t) (4 * wbase + tail + ff + 2); // bytes this segment occupies in the final stream (stuffed + marker)
         }
 }
 
-// exclusive prefix sum of (segment bytes + stuffed zeros + 2-byte marker), single workgroup; off[n_seg] = total length
-__global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ seg_ff,
-                                                               int n_seg, uint32_t header_len, uint32_t *__restrict__ off)
+// exclusive prefix sum of the final segment sizes, single workgroup, 4096 elements per pass (one 16-byte load per lane);
+// off[n_seg] = total stream length.  seg_tot is padded to a multiple of 4 entries.
+__global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_tot, int n_seg, uint32_t header_len,
+                                                               uint32_t *__restrict__ off)
 {
-        __shared__ uint32_t part[1024];
-        const int t = threadIdx.x;
-        const int per = (n_seg + 1023) / 1024;
-        const int lo = min(n_seg, t * per), hi = min(n_seg, lo + per);
-        uint32_t s = 0;
-        for (int i = lo; i < hi; i++) s += seg_len[i] + seg_ff[i] + 2;
-        part[t] = s;
+        __shared__ uint32_t wave_sum[16];
+        __shared__ uint32_t carry_s;
+        const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+        if (t == 0) carry_s = header_len;
         __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
-                const uint32_t v = t >= d ? part[t - d] : 0;
+        for (int base = 0; base < n_seg; base += 4096) {
+                const int i = base + 4 * t;
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (i < n_seg) x = *(const uint4 *) (seg_tot + i);
+                if (i + 1 >= n_seg) x.y = 0;
+                if (i + 2 >= n_seg) x.z = 0;
+                if (i + 3 >= n_seg) x.w = 0;
+                const uint32_t mine = x.x + x.y + x.z + x.w;
+                const uint32_t incl = (uint32_t) wave_inclusive_scan((int) mine, lane);
+                if (lane == 63) wave_sum[wv] = incl;
                 __syncthreads();
-                part[t] += v;
+                uint32_t before = carry_s;
+                for (int k = 0; k < wv; k++) before += wave_sum[k];
+                const uint32_t o0 = before + incl - mine;
+                if (i < n_seg) off[i] = o0;
+                if (i + 1 < n_seg) off[i + 1] = o0 + x.x;
+                if (i + 2 < n_seg) off[i + 2] = o0 + x.x + x.y;
+                if (i + 3 < n_seg) off[i + 3] = o0 + x.x + x.y + x.z;
+                __syncthreads();
+                if (t == 1023) carry_s = before + incl;
                 __syncthreads();
         }
-        uint32_t run = header_len + (t ? part[t - 1] : 0);
-        for (int i = lo; i < hi; i++) {
-                off[i] = run;
-                run += seg_len[i] + seg_ff[i] + 2;
-        }
-        if (t == 1023) off[n_seg] = header_len + part[1023];
+        if (t == 0) off[n_seg] = carry_s;
 }
 
 // one wave per segment: move its bytes to the final position, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
@@ -300,7 +324,7 @@ int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_i
         alloc((void **) &e->cr, (size_t) e->n_mcu * 128);
         alloc((void **) &e->scratch, (size_t) e->n_seg * e->cap);
         alloc((void **) &e->seg_len, (size_t) e->n_seg * 4);
-        alloc((void **) &e->seg_ff, (size_t) e->n_seg * 4);
+        alloc((void **) &e->seg_ff, ((size_t) e->n_seg + 4) * 4);
         alloc((void **) &e->off, (size_t) (e->n_seg + 1) * 4);
         alloc((void **) &e->header_dev, e->header.size());
         if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocDefault);
@@ -344,8 +368,7 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
         if (rc != UG_HIP_SUCCESS) return rc;
         hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->ri,
                            e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
-        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_len, e->seg_ff, e->n_seg, (uint32_t) e->header.size(),
-                           e->off);
+        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off);
         UG_HIP_TRY(hipMemcpyAsync(out_dev, e->header_dev, e->header.size(), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->off,
                            e->n_seg, (uint8_t *) out_dev);
