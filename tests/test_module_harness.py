@@ -156,3 +156,21 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec):
     img.draft("YCbCr", None)
     dec = np.asarray(img)
     assert 10 * np.log10(255.0 ** 2 / np.mean((dec[..., 0].astype(float) - y.astype(float)) ** 2)) > 40
+
+
+@needs_harness
+@pytest.mark.gpu
+def test_tiles_dealt_over_device_list(tmp_path, po):
+    """dev=<list>: per-tile module instances are dealt round-robin over the listed devices (one GPU here, listed twice: the
+    code path is the multi-GPU one, the data path has no inter-device traffic)."""
+    w, h, tiles = 384, 128, 4
+    frames = [synth.s1_random("UYVY", w, h, salt=10 + t) for t in range(tiles)]
+    raw, out = tmp_path / "in.raw", tmp_path / "out.bin"
+    np.concatenate(frames).tofile(raw)
+    r = _run(["dxt:DXT5:dev=0,0", "UYVY", w, h, raw, out, tiles])
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, np.uint8).reshape(tiles, -1)
+    for t in range(tiles):
+        assert np.array_equal(got[t], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frames[t], w, h)), t
+    r = _run(["dxt:DXT5:dev=7", "UYVY", w, h, raw, out, tiles])   # no such device on a 1-GPU box: refused at init
+    assert r.returncode == 2 and "cannot use HIP device 7" in (r.stdout + r.stderr)

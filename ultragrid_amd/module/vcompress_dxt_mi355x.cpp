@@ -1,6 +1,6 @@
 /**
  * @file vcompress_dxt_mi355x.cpp
- * UltraGrid video_compress module "dxt" (-c dxt[:DXT1|:DXT5][:dev=<n>]) backed by the MI355X
+ * UltraGrid video_compress module "dxt" (-c dxt[:DXT1|:DXT5][:dev=<n>[,<n>...]]) backed by the MI355X
  * kernel library libug_mi355x.so (include/ug_mi355x.h).
  *
  * This is the host-side half of the drop-in boundary.  It is compiled
@@ -16,17 +16,22 @@
  *    fused kernel;
  *  - one HIP stream per module instance, asynchronous H2D -> kernel -> D2H, a single stream
  *    synchronisation per frame (cuda_dxt.cu:759 synchronises after every launch);
- *  - the device index comes from the module option dev=<n> (default 0); UltraGrid's -D list is capped
- *    at MAX_CUDA_DEVICES = 4 (host.h:97), too small for an 8-GPU MI355X node.
+ *  - devices come from the module option dev=<n>[,<n>...] (default 0); UltraGrid's -D list is capped at
+ *    MAX_CUDA_DEVICES = 4 (host.h:97), too small for an 8-GPU MI355X node.  With several devices the per-tile
+ *    module instances the framework creates (video_compress.cpp:302-319, one init per tile) are dealt out round-robin,
+ *    so the tiles of a tiled 4K/8K frame are encoded on different GPUs concurrently (tile fan-out,
+ *    video_compress.cpp:441-490) -- frames/tiles are independent, there is no inter-GPU traffic.
  *
  * There is deliberately no CPU fallback: if the GPU path cannot take a format, the module says
  * so and drops the frame (video_compress.cpp:394-398 semantics).
  */
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "debug.h"
 #include "host.h"
@@ -91,9 +96,9 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT5][:dev=<index>]\n"
+               "\t-c dxt[:DXT1|:DXT5][:dev=<index>[,<index>...]]\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg\n"
-               "\t\tdev  - HIP device index (default 0)\n");
+               "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n");
 }
 
 void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
@@ -112,7 +117,16 @@ void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
                         s->out_codec = DXT1;
                         s->out_fmt = UG_DXT1;
                 } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
-                        s->device = atoi(tok.c_str() + 4);
+                        std::vector<int> devs;
+                        for (const char *p = tok.c_str() + 4; *p;) {
+                                devs.push_back(atoi(p));
+                                p = strchr(p, ',');
+                                if (!p) break;
+                                p++;
+                        }
+                        if (devs.empty()) devs.push_back(0);
+                        static std::atomic<unsigned> instance_counter{0}; // one init per tile: deal the instances out
+                        s->device = devs[instance_counter++ % devs.size()];
                 } else if (tok == "help") {
                         usage();
                         delete s;
