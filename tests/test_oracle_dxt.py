@@ -180,3 +180,18 @@ def test_decode_oracle_pinned_to_reference_tool(po):
     cases += [rng.integers(0, 256, w * h, dtype=np.uint8) for _ in range(3)]
     for blocks in cases:
         assert np.array_equal(po.dxt_decode(po.OUT_DXT5YCOCG, "RGB", blocks, w, h).reshape(h, w, 3), po.ref_dxt62tga(blocks, w, h))
+
+
+def test_round_u32_identity_used_by_the_hip_encoder():
+    """dxt_encode.hip computes (uint32_t) roundf(x) as `x < 0.5 ? 0 : (uint32_t)(x + 0.5f)`.  Pure IEEE arithmetic, so it is
+    checked here on the CPU: every float within 512 ulps of k and k + 0.5 (k = 0..256) and 4M random floats in [0, 256].
+    (An exhaustive sweep of all floats in [0, 2^22] was run once with the same result: no mismatch.)"""
+    rng = np.random.default_rng(7)
+    centres = np.concatenate([np.arange(0, 257, dtype=np.float32), np.arange(0, 257, dtype=np.float32) + np.float32(0.5)])
+    bits = centres.view(np.uint32).astype(np.int64)[:, None] + np.arange(-512, 513)[None, :]
+    near = bits[bits >= 0].astype(np.uint32).view(np.float32)
+    x = np.concatenate([near, rng.uniform(0, 256, 4_000_000).astype(np.float32), rng.uniform(0, 1, 1_000_000).astype(np.float32)])
+    s = (x + np.float32(0.5)).astype(np.float32)
+    got = np.where(x < np.float32(0.5), 0, s.astype(np.uint32))
+    want = np.floor(x.astype(np.float64) + 0.5).astype(np.uint32)  # roundf for x >= 0: half away from zero
+    assert np.array_equal(got, want)

@@ -31,6 +31,16 @@ constexpr float kInsetY  = (float) ((16.0 / 255.0) / 32.0);
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(1.0f, fmaxf(0.0f, v)); }
 
+// (uint32_t) roundf(x) for 0 <= x < 2^22 (half away from zero, cuda_dxt.cu:122-124).  For x >= 0.5 the fp32 sum x + 0.5f
+// truncates to the right integer: it is exact unless it lands in a higher binade than x, which only happens for
+// x in [2^k - 0.5, 2^k), where both roundf(x) and the (rounded) sum's integer part are 2^k.  Below 0.5 the sum can
+// round up to 1.0 (x = 0.5 - 2^-25), so that range is selected to 0 explicitly.  4 instructions instead of roundf's 7.
+__device__ __forceinline__ uint32_t round_u32(float x)
+{
+        const uint32_t r = (uint32_t) (x + 0.5f);
+        return x < 0.5f ? 0u : r;
+}
+
 // GLSL mix(a,b,q) = a*(1-q) + b*q, w = 1-q precomputed in fp32 (cuda_dxt.cu:126-128)
 __device__ __forceinline__ float lerp_w(float a, float b, float w, float q)
 {
@@ -102,11 +112,11 @@ template <bool YUV>
 struct Loader3 {
         static constexpr int kBlocks = 1;
         uint32_t w[4][3];
-        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        const uint32_t *p = (const uint32_t *) (src + (long) rows[r] * pitch) + unit_x * 3;
+                        const uint32_t *p = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 12u));
                         w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
                 }
         }
@@ -136,11 +146,11 @@ template <>
 struct Loader<UG_PF_RGBA> {
         static constexpr int kBlocks = 1;
         uint4 w[4];
-        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        w[r] = ((const uint4 *) (src + (long) rows[r] * pitch))[unit_x];
+                        w[r] = *(const uint4 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 16u));
                 }
         }
         __device__ __forceinline__ void block(int, Px16 &p) const
@@ -163,11 +173,11 @@ template <bool CONVERT>
 struct LoaderUYVY {
         static constexpr int kBlocks = 1;
         uint2 w[4];
-        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        w[r] = ((const uint2 *) (src + (long) rows[r] * pitch))[unit_x];
+                        w[r] = *(const uint2 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
                 }
         }
         __device__ __forceinline__ void block(int, Px16 &p) const
@@ -200,11 +210,11 @@ template <>
 struct Loader<UG_PF_V210> {
         static constexpr int kBlocks = 3;
         uint32_t w[4][8];
-        __device__ __forceinline__ void load(const uint8_t *src, long pitch, int unit_x, const int (&rows)[4])
+        __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        const uint4 *p = (const uint4 *) (src + (long) rows[r] * pitch) + unit_x * 2;
+                        const uint4 *p = (const uint4 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 32u));
                         const uint4 q0 = p[0], q1 = p[1];
                         w[r][0] = q0.x; w[r][1] = q0.y; w[r][2] = q0.z; w[r][3] = q0.w;
                         w[r][4] = q1.x; w[r][5] = q1.y; w[r][6] = q1.z; w[r][7] = q1.w;
@@ -273,17 +283,17 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
 
         // ScaleYCoCg (glsl:150-167)
         uint32_t scale = 1;
+        float fs = 1.0f, rfs = 1.0f; // float(scale) and its exact reciprocal
         {
                 const float m0 = fmaxf(fabsf(mnCo - kOffset), fabsf(mnCg - kOffset));
                 const float m1 = fmaxf(fabsf(mxCo - kOffset), fabsf(mxCg - kOffset));
                 const float m = fmaxf(m0, m1);
-                if (m < (float) (64.0 / 255.0)) scale = 2;
-                if (m < (float) (32.0 / 255.0)) scale = 4;
+                if (m < (float) (64.0 / 255.0)) { scale = 2; fs = 2.0f; rfs = 0.5f; }
+                if (m < (float) (32.0 / 255.0)) { scale = 4; fs = 4.0f; rfs = 0.25f; }
         }
 
         // EmitEndPointsYCoCgDXT5 (glsl:185-215) with InsetCoCgBBox (glsl:92-97).
         // "/ 16.0" and "/ float(scale)" are multiplications by exact powers of two.
-        const float fs = (float) scale, rfs = 1.0f / fs;
         uint32_t w_end;
         float cmx[2], cmn[2];
         {
@@ -297,8 +307,8 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                         const float inset = (a - b) * 0.0625f - kInsetC;
                         b = clamp01(b + inset);
                         a = clamp01(a - inset);
-                        imax[k] = (uint32_t) roundf(a * q[k]);
-                        imin[k] = (uint32_t) roundf(b * q[k]);
+                        imax[k] = round_u32(a * q[k]);
+                        imin[k] = round_u32(b * q[k]);
                 }
                 w_end = ((imax[0] << 11) | (imax[1] << 5) | (scale - 1)) |
                         (((imin[0] << 11) | (imin[1] << 5) | (scale - 1)) << 16);
@@ -314,45 +324,6 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 }
         }
 
-        // EmitIndicesYCoCgDXT5 (glsl:217-250).  The four squared distances of TWO horizontally adjacent
-        // pixels are computed with packed fp32 (v_pk_add/v_pk_mul: IEEE per component, so bit-identical to the
-        // scalar form); the kernel is VALU-issue bound and this halves the issue slots of its largest stage.
-        uint32_t w_cidx = 0;
-        {
-                const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
-                const float w1 = 1.0f - q1, w2 = 1.0f - q2;
-                float cx[4], cy[4];
-                cx[0] = cmx[0]; cy[0] = cmx[1];
-                cx[1] = cmn[0]; cy[1] = cmn[1];
-                cx[2] = lerp_w(cx[0], cx[1], w1, q1); cy[2] = lerp_w(cy[0], cy[1], w1, q1);
-                cx[3] = lerp_w(cx[0], cx[1], w2, q2); cy[3] = lerp_w(cy[0], cy[1], w2, q2);
-                f32x2 cx2[4], cy2[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                        cx2[k] = (f32x2) { cx[k], cx[k] };
-                        cy2[k] = (f32x2) { cy[k], cy[k] };
-                }
-#pragma unroll
-                for (int i = 14; i >= 0; i -= 2) { // pixel pairs, last first: bits are shifted in MSB first
-                        const f32x2 co = { Co[i], Co[i + 1] }, cg = { Cg[i], Cg[i + 1] };
-                        f32x2 d[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                                const f32x2 tx = co - cx2[k], ty = cg - cy2[k];
-                                d[k] = tx * tx + ty * ty;
-                        }
-#pragma unroll
-                        for (int h = 1; h >= 0; h--) { // pixel i+1, then pixel i
-                                const float d0 = d[0][h], d1 = d[1][h], d2 = d[2][h], d3 = d[3][h];
-                                // glsl:237-244
-                                const lanemask_t b0 = LANEMASK(d0 > d3), b1 = LANEMASK(d1 > d2), b2 = LANEMASK(d0 > d2),
-                                                 b3 = LANEMASK(d1 > d3), b4 = LANEMASK(d2 > d3);
-                                w_cidx = shift_in(w_cidx, (b1 & b2) | (b0 & b3)); // bit 2i+1
-                                w_cidx = shift_in(w_cidx, b0 & b4);               // bit 2i
-                        }
-                }
-        }
-
         // InsetYBBox (glsl:86-91)
         {
                 const float inset = (mxY - mnY) * 0.03125f - kInsetY;
@@ -360,7 +331,7 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 mxY = clamp01(mxY - inset);
         }
         // EmitAlphaEndPointsYCoCgDXT5 (glsl:252-259)
-        uint32_t w0 = ((uint32_t) roundf(mnY * 255.0f) << 8) | (uint32_t) roundf(mxY * 255.0f);
+        uint32_t w0 = (round_u32(mnY * 255.0f) << 8) | round_u32(mxY * 255.0f);
         uint32_t w1 = 0;
         // EmitAlphaIndicesYCoCgDXT5 (glsl:262-312): count c = #{k : a <= ab_k}, index = f(c).
         {
@@ -431,6 +402,45 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 w0 |= lo << 16;
                 w1 = (lo >> 16) | (hi << 14);
         }
+        // EmitIndicesYCoCgDXT5 (glsl:217-250).  The four squared distances of TWO horizontally adjacent
+        // pixels are computed with packed fp32 (v_pk_add/v_pk_mul: IEEE per component, so bit-identical to the
+        // scalar form); the kernel is VALU-issue bound and this halves the issue slots of its largest stage.
+        uint32_t w_cidx = 0;
+        {
+                const float q1 = (float) (1.0 / 3.0), q2 = (float) (2.0 / 3.0);
+                const float w1 = 1.0f - q1, w2 = 1.0f - q2;
+                float cx[4], cy[4];
+                cx[0] = cmx[0]; cy[0] = cmx[1];
+                cx[1] = cmn[0]; cy[1] = cmn[1];
+                cx[2] = lerp_w(cx[0], cx[1], w1, q1); cy[2] = lerp_w(cy[0], cy[1], w1, q1);
+                cx[3] = lerp_w(cx[0], cx[1], w2, q2); cy[3] = lerp_w(cy[0], cy[1], w2, q2);
+                f32x2 cx2[4], cy2[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                        cx2[k] = (f32x2) { cx[k], cx[k] };
+                        cy2[k] = (f32x2) { cy[k], cy[k] };
+                }
+#pragma unroll
+                for (int i = 14; i >= 0; i -= 2) { // pixel pairs, last first: bits are shifted in MSB first
+                        const f32x2 co = { Co[i], Co[i + 1] }, cg = { Cg[i], Cg[i + 1] };
+                        f32x2 d[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                                const f32x2 tx = co - cx2[k], ty = cg - cy2[k];
+                                d[k] = tx * tx + ty * ty;
+                        }
+#pragma unroll
+                        for (int h = 1; h >= 0; h--) { // pixel i+1, then pixel i
+                                const float d0 = d[0][h], d1 = d[1][h], d2 = d[2][h], d3 = d[3][h];
+                                // glsl:237-244
+                                const lanemask_t b0 = LANEMASK(d0 > d3), b1 = LANEMASK(d1 > d2), b2 = LANEMASK(d0 > d2),
+                                                 b3 = LANEMASK(d1 > d3), b4 = LANEMASK(d2 > d3);
+                                w_cidx = shift_in(w_cidx, (b1 & b2) | (b0 & b3)); // bit 2i+1
+                                w_cidx = shift_in(w_cidx, b0 & b4);               // bit 2i
+                        }
+                }
+        }
+
         return make_uint4(w0, w1, w_end, w_cidx);
 }
 
@@ -468,8 +478,8 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
                 for (int k = 0; k < 3; k++) {
                         const float inset = (mx[k] - mn[k]) * 0.0625f - kInsetC;
                         const float lo = clamp01(mn[k] + inset), hi = clamp01(mx[k] - inset);
-                        cm[k] = (uint32_t) roundf(hi * q[k]);
-                        cn[k] = (uint32_t) roundf(lo * q[k]);
+                        cm[k] = round_u32(hi * q[k]);
+                        cn[k] = round_u32(lo * q[k]);
                 }
         }
         const uint32_t code_max = (cm[0] << 11) | (cm[1] << 5) | cm[2];
@@ -548,13 +558,18 @@ constexpr int kRowsPerWave = UG_DXT_ROWS_PER_WAVE;
 
 template <int IN, int OUT, bool MIRROR>
 __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                         int units_per_row, int block_rows, int height, long pitch,
+                                                         int units_per_row, int block_rows, int height, uint32_t pitch,
                                                          size_t src_frame_stride, size_t dst_frame_stride)
 {
         using L = Loader<IN>;
+        // threadIdx.y is wave-uniform (a wave is one 64-lane row of the group): keep the block row, the row base
+        // pointers and the bounds test on the scalar unit -- no per-lane 64-bit multiplies in the prologue.
         const int ux = blockIdx.x * 64 + threadIdx.x;
-        const int by0 = (blockIdx.y * blockDim.y + threadIdx.y) * kRowsPerWave;
-        if (ux >= units_per_row || by0 >= block_rows) {
+        const int by0 = (int) (blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kRowsPerWave;
+        if (by0 >= block_rows) {
+                return;
+        }
+        if (ux >= units_per_row) {
                 return;
         }
         src += (size_t) blockIdx.z * src_frame_stride;
@@ -582,15 +597,17 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
                         load_row(nxt, by + 1);
                 }
                 // block raster order idx = bx + (w/4)*by (cuda_dxt.cu:633)
-                const long block0 = ((long) by * units_per_row + ux) * L::kBlocks;
+                constexpr uint32_t kBlockBytes = OUT == UG_DXT5_YCOCG ? 16 : 8;
+                uint8_t *const dst_row = dst + (size_t) by * units_per_row * (L::kBlocks * kBlockBytes); // scalar
+                const uint32_t dst_off = (uint32_t) ux * (L::kBlocks * kBlockBytes);
 #pragma unroll
                 for (int k = 0; k < L::kBlocks; k++) {
                         Px16 p;
                         cur.block(k, p);
                         if (OUT == UG_DXT5_YCOCG) {
-                                ((uint4 *) dst)[block0 + k] = encode_dxt5ycocg(p);
+                                *(uint4 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt5ycocg(p);
                         } else {
-                                ((uint2 *) dst)[block0 + k] = encode_dxt1(p);
+                                *(uint2 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt1(p);
                         }
                 }
                 if (more) {
@@ -609,6 +626,10 @@ int launch(const void *src, void *dst, int w, int h, int pitch, int frames, size
         if (upr == 0 || brows == 0 || frames == 0) return UG_HIP_SUCCESS;
         constexpr int wg_rows = 4; // waves per workgroup; 1, 2 and 4 measure the same (0.1878-0.1889 ms)
         const int rows_per_group = wg_rows * kRowsPerWave;
+        if ((uint64_t) pitch * (uint64_t) h > 0xffffffffull) { // in-frame byte offsets are 32-bit (scalar base + lane offset)
+                ug::set_last_error_msg("ug_hip_dxt_encode: image larger than 4 GiB");
+                return UG_HIP_EINVAL;
+        }
         if (frames > 65535 || (brows + rows_per_group - 1) / rows_per_group > 65535) {
                 ug::set_last_error_msg("ug_hip_dxt_encode: image too tall / too many frames for one launch");
                 return UG_HIP_EINVAL;
@@ -616,10 +637,10 @@ int launch(const void *src, void *dst, int w, int h, int pitch, int frames, size
         const dim3 block(64, wg_rows), grid((unsigned) ((upr + 63) / 64), (unsigned) ((brows + rows_per_group - 1) / rows_per_group), (unsigned) frames);
         if (mirror) {
                 hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, true>), grid, block, 0, st, (const uint8_t *) src,
-                                   (uint8_t *) dst, upr, brows, h, (long) pitch, sfs, dfs);
+                                   (uint8_t *) dst, upr, brows, h, (uint32_t) pitch, sfs, dfs);
         } else {
                 hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, false>), grid, block, 0, st, (const uint8_t *) src,
-                                   (uint8_t *) dst, upr, brows, h, (long) pitch, sfs, dfs);
+                                   (uint8_t *) dst, upr, brows, h, (uint32_t) pitch, sfs, dfs);
         }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
