@@ -61,22 +61,33 @@ def make_frames(n: int, rank: int, fmt: str = "UYVY", w: int = W, h: int = H) ->
 
 
 def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 12.0) -> dict:
-    """The C oracle on all host cores: block rows split statically over OpenMP threads, the row-band scheme the
-    reference uses to parallelise its CPU conversions (src/utils/parallel_conv.c:64-85)."""
+    """The C oracle on the host cores: block rows dealt to OpenMP threads (row bands, as the reference parallelises its CPU
+    conversions, src/utils/parallel_conv.c:64-85).  The thread count is calibrated (the box may expose more logical CPUs than
+    its cpuset lets run); `cores` reports the count that was used for the timed sample."""
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     pin = {"UYVY": po.IN_UYVY, "v210": po.IN_V210}[fmt]
-    t0 = time.perf_counter()
-    po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=cores)   # warm + calibrate
-    t1 = time.perf_counter() - t0
-    n = max(3, min(2000, int(target_s / max(t1, 1e-4))))
+
+    def one(threads: int) -> float:
+        t0 = time.perf_counter()
+        po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=threads)
+        return time.perf_counter() - t0
+
+    one(1 if ncpu == 1 else min(ncpu, 8))                                  # warm (page in, spawn the team)
+    cands = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, 256, ncpu) if t <= ncpu})
+    best_t, best = 1, float("inf")
+    for t in cands:
+        dt = min(one(t), one(t))
+        if dt < best:
+            best_t, best = t, dt
+    n = max(3, min(4000, int(target_s / max(best, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(n):
-        po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=cores)
+        po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=best_t)
     dt = time.perf_counter() - t0
-    return {"value": round(n * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x {w}x{h} {fmt}->DXT5-YCoCg frames through oracle/dxt_oracle.c (gcc -O2, strict fp32, "
-                      f"OpenMP static row bands on {cores} threads), {dt:.1f} s"}
+    return {"value": round(n * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": best_t, "kind": "port",
+            "sample": f"{n} x {w}x{h} {fmt}->DXT5-YCoCg frames through oracle/dxt_oracle.c (gcc -O2, strict fp32, OpenMP dynamic "
+                      f"row bands; {best_t} threads = best of {cands} on {ncpu} visible CPUs), {dt:.1f} s"}
 
 
 def main() -> None:

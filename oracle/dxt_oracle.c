@@ -490,8 +490,8 @@ int oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
         return encode_rows(in_fmt, out_fmt, src, dst, w, h, pitch, 1);
 }
 
-/* Same, block rows split over `nthreads` OpenMP threads (0 = all cores) -- the row-band scheme the reference uses
- * for its CPU conversions (src/utils/parallel_conv.c:64-85).  Only for the cpu_baseline timing leg of bench.py. */
+/* Same, block rows dealt dynamically to `nthreads` OpenMP threads (0 = all cores) -- row bands as in the reference's
+ * CPU conversions (src/utils/parallel_conv.c:64-85); dynamic so that a cpuset smaller than the thread count does not stall.  Only for the cpu_baseline timing leg of bench.py. */
 int oracle_dxt_encode_mt(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                          int w, int h, long pitch, int nthreads)
 {
@@ -511,7 +511,7 @@ static int encode_rows(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst
         if (out_fmt != ORACLE_OUT_DXT5YCOCG && out_fmt != ORACLE_OUT_DXT1) {
                 return -1;
         }
-#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) if (nthreads > 1)
         for (int by = 0; by < h / 4; by++) {
                 for (int bx = 0; bx < bw; bx++) {
                         float rgb[16][3];
