@@ -168,13 +168,23 @@ int ug_hip_jpeg_fdct_quant_plane(const void *plane_dev, int pitch, int width, in
 int ug_hip_uyvy_to_jpeg420_coeffs(const void *src_dev, int src_pitch, int width, int height,
                                   const float *div_dev, int16_t *out_y, int16_t *out_cb,
                                   int16_t *out_cr, ug_hip_stream_t stream);
+/* Same for 4:2:2, the sampling UltraGrid's GPUJPEG module selects for UYVY input when no `subsampling=` option is
+ * given (gpujpeg.cpp:295-302: autoselect = the input codec's subsampling; UYVY is handed over as GPUJPEG_422_U8_P1020,
+ * :339): chroma samples are taken as they are (uyvy_to_i422, video_codec.c:949-969), MCU = 16x8:
+ * luma (2*mcu_w) x mcu_h blocks, chroma mcu_w x mcu_h each, mcu_w = ceil(width/16), mcu_h = ceil(height/8). */
+int ug_hip_uyvy_to_jpeg422_coeffs(const void *src_dev, int src_pitch, int width, int height,
+                                  const float *div_dev, int16_t *out_y, int16_t *out_cb,
+                                  int16_t *out_cr, ug_hip_stream_t stream);
 
-/* Complete baseline JPEG encoder (JFIF, 4:2:0, interleaved scan, restart intervals) = the fused FDCT+quantise
+/* Complete baseline JPEG encoder (JFIF, 4:2:0 or 4:2:2, interleaved scan, restart intervals) = the fused FDCT+quantise
  * above + Huffman coding (T.81 Annex K.3 tables) + headers.  Object shape of gpujpeg_encoder_create / _encode /
  * _destroy (src/video_compress/gpujpeg.cpp:353,624,639).  `encode` is synchronous on `stream` (it returns the
  * stream length); out_capacity must be >= ug_hip_jpeg_encoder_max_size().  Input: UYVY in device memory. */
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out);
+/* subsampling = 420 or 422 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */
+int    ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int restart_interval, int subsampling,
+                                      ug_hip_jpeg_encoder **out);
 void   ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc);
 size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc);
 int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch,

@@ -248,6 +248,25 @@ def uyvy_to_i420(src: np.ndarray, w: int, h: int, use_ref: bool = False):
     return y, u, v
 
 
+def uyvy_to_i422(src: np.ndarray, w: int, h: int, use_ref: bool = False):
+    """uyvy_to_i422 (video_codec.c:949-969): Y, Cb, Cr planes, chroma (w+1)/2 wide, samples copied as they are.  Lines are
+    vc_get_linesize(UYVY) apart; for odd widths the reference function itself assumes 2*w+1 bytes per line, which contradicts
+    its own linesize, so use_ref is only meaningful for even widths."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    cw = (w + 1) // 2
+    if use_ref:
+        assert w % 2 == 0
+        out = np.zeros(w * h + 2 * cw * h, np.uint8)
+        fn = ref().uyvy_to_i422
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        fn(w, h, src.ctypes.data, out.ctypes.data)
+        return out[: w * h].reshape(h, w), out[w * h: w * h + cw * h].reshape(h, cw), out[w * h + cw * h:].reshape(h, cw)
+    ls = 4 * cw
+    rows = src[: ls * h].reshape(h, ls)
+    return (np.ascontiguousarray(rows[:, 1::2][:, :w]), np.ascontiguousarray(rows[:, 0::4]), np.ascontiguousarray(rows[:, 2::4]))
+
+
 def v210_to_p010le(src: np.ndarray, w: int, h: int, use_ref: bool = False):
     src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
     y = np.zeros((h, w), np.uint16)

@@ -1,4 +1,4 @@
-"""Test-only baseline JPEG writer (T.81 Annex K Huffman tables, 4:2:0, JFIF) that turns quantised zig-zag
+"""Test-only baseline JPEG writer (T.81 Annex K Huffman tables, 4:2:0 or 4:2:2, JFIF) that turns quantised zig-zag
 coefficients -- from the oracle or from the HIP kernels -- into a file an independent decoder (Pillow/libjpeg) can
 read.  Purpose: pin the FDCT / quantiser / zig-zag / level-shift conventions of oracle/jpeg_oracle.c to real JPEG,
 since the reference's own FDCT (external libgpujpeg) is not available.  Not part of the product."""
@@ -94,22 +94,27 @@ def _block(bw, zz, pred, dc, ac):
     return int(zz[0])
 
 
-def header_bytes(width, height, qt_luma, qt_chroma, restart=0):
-    """SOI .. SOS of the stream write_jpeg420() produces (the product builds the same header on the host)."""
-    return write_jpeg420(width, height, qt_luma, qt_chroma, None, None, None, restart, header_only=True)
+def header_bytes(width, height, qt_luma, qt_chroma, restart=0, sub=420):
+    """SOI .. SOS of the stream write_jpeg() produces (the product builds the same header on the host)."""
+    return write_jpeg(width, height, qt_luma, qt_chroma, None, None, None, restart, header_only=True, sub=sub)
 
 
 def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart=0, header_only=False):
-    """coef_*: (n_blocks, 64) int16 zig-zag; Y blocks in raster order over a (2*mcu_w) x (2*mcu_h) block grid,
-    chroma over mcu_w x mcu_h.  qt_*: 64 quantiser steps in natural order.  restart = MCUs per restart interval
-    (0 = none).  Returns JFIF bytes."""
-    mw, mh = (width + 15) // 16, (height + 15) // 16
+    return write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart, header_only, sub=420)
+
+
+def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart=0, header_only=False, sub=420):
+    """coef_*: (n_blocks, 64) int16 zig-zag; Y blocks in raster order over a (2*mcu_w) x (vy*mcu_h) block grid,
+    chroma over mcu_w x mcu_h (sub=420: MCU 16x16, vy=2; sub=422: MCU 16x8, vy=1).  qt_*: 64 quantiser steps in natural
+    order.  restart = MCUs per restart interval (0 = none).  Returns JFIF bytes."""
+    vy = 2 if sub == 420 else 1
+    mw, mh = (width + 15) // 16, (height + 8 * vy - 1) // (8 * vy)
     out = io.BytesIO()
     out.write(b"\xff\xd8")
     out.write(b"\xff\xe0" + struct.pack(">H5sBBBHHBB", 16, b"JFIF\0", 1, 1, 0, 1, 1, 0, 0))
     for tid, qt in ((0, qt_luma), (1, qt_chroma)):
         out.write(b"\xff\xdb" + struct.pack(">HB", 67, tid) + bytes(int(qt[i]) for i in ZIGZAG))
-    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1]))
+    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([1, 0x20 | vy, 0, 2, 0x11, 1, 3, 0x11, 1]))
     for (tc, th, (bits, vals)) in ((0, 0, DC_L), (1, 0, AC_L), (0, 1, DC_C), (1, 1, AC_C)):
         out.write(b"\xff\xc4" + struct.pack(">HB", 19 + len(vals), (tc << 4) | th) + bytes(bits) + bytes(vals))
     if restart:
@@ -130,8 +135,8 @@ def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, r
             out.write(bytes([0xFF, 0xD0 + ((m // restart - 1) & 7)]))
             bw = _Bits()
             py = pcb = pcr = 0
-        for (dy, dx) in ((0, 0), (0, 1), (1, 0), (1, 1)):
-            py = _block(bw, coef_y[(2 * my + dy) * bwid + 2 * mx + dx], py, dcl, acl)
+        for (dy, dx) in ((0, 0), (0, 1), (1, 0), (1, 1))[: 2 * vy]:
+            py = _block(bw, coef_y[(vy * my + dy) * bwid + 2 * mx + dx], py, dcl, acl)
         pcb = _block(bw, coef_cb[my * mw + mx], pcb, dcc, acc)
         pcr = _block(bw, coef_cr[my * mw + mx], pcr, dcc, acc)
     bw.flush()

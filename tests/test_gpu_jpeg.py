@@ -122,3 +122,60 @@ def test_jpeg_stream_random_content_and_stuffing(hip, po):
     img.draft("YCbCr", None)   # raw YCbCr planes, no RGB round trip
     dec = np.asarray(img)
     assert np.abs(dec[..., 0].astype(int) - y.astype(int)).mean() < 1.5
+
+
+def _want_422(po, uyvy, w, h, q):
+    y, u, v = po.uyvy_to_i422(uyvy, w, h, use_ref=po.have_ref() and w % 2 == 0)
+    mw, mh = (w + 15) // 16, (h + 7) // 8
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    dl, dc = po.jpeg_divisors(ql), po.jpeg_divisors(qc)
+    return (y, u, v), (ql, qc), (po.jpeg_fdct_quant_plane(y, dl, 2 * mw, mh), po.jpeg_fdct_quant_plane(u, dc, mw, mh),
+                                 po.jpeg_fdct_quant_plane(v, dc, mw, mh))
+
+
+@pytest.mark.parametrize("dims", [(16, 8), (40, 24), (50, 37), (51, 9), (1920, 1080), (3840, 2160)], ids=str)
+def test_fused_uyvy_422_pipeline(hip, po, dims):
+    """4:2:2 (the sampling the reference module selects for UYVY, gpujpeg.cpp:295-302,339): UYVY -> uyvy_to_i422 planes ->
+    FDCT+quant, fused on the GPU (fast MCU-strip kernel for width % 16 == 0, generic kernel otherwise)."""
+    import torch
+    w, h = dims
+    src = synth.s2_video("UYVY", w, h) if w % 2 == 0 else synth.s1_random("UYVY", w, h)
+    _, _, want = _want_422(po, src, w, h, 75)
+    got = hip.uyvy_to_jpeg_coeffs(torch.from_numpy(src).cuda(), w, h, hip.jpeg_divisors_device(75, "cuda"), 422)
+    for g, wnt, name in zip(got, want, "Y Cb Cr".split()):
+        assert np.array_equal(g.cpu().numpy(), wnt), name
+
+
+@pytest.mark.parametrize("dims", [(16, 8), (160, 96), (200, 120), (1920, 1080)], ids=str)
+@pytest.mark.parametrize("ri", [1, 4, 7])
+def test_full_jpeg_stream_422(hip, po, dims, ri):
+    import io
+    import torch
+    from PIL import Image
+    from jpeg_bitstream import write_jpeg
+    w, h = dims
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    uyvy = po.convert_frame("RGB", "UYVY", rgb.clip(0, 255).astype(np.uint8), w, h)
+    q = 80
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=422)
+    data = enc.encode(torch.from_numpy(uyvy).cuda())
+    enc.close()
+    (y, u, v), (ql, qc), coefs = _want_422(po, uyvy, w, h, q)
+    want = write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=422)
+    assert data == want, (len(data), len(want))
+    img = Image.open(io.BytesIO(data))
+    img.draft("YCbCr", None)
+    dec = np.asarray(img)
+    assert dec.shape == (h, w, 3)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((dec[..., 0].astype(float) - y.astype(float)) ** 2))
+    assert psnr > 40, psnr
+    # chroma really is full vertical resolution: the decoder's (upsampled) Cb at even columns tracks the source rows
+    assert np.abs(dec[:, 0::2, 1].astype(int)[:, : u.shape[1]] - u.astype(int)).mean() < 2.0
+
+
+def test_jpeg_encoder_rejects_unknown_subsampling(hip):
+    import ctypes as C
+    from ultragrid_amd import lib as L
+    h = C.c_void_p()
+    assert L.load().ug_hip_jpeg_encoder_create_sub(64, 64, 75, 4, 444, C.byref(h)) == -2

@@ -126,15 +126,17 @@ def test_jpeg_module_registers():
 
 @needs_harness
 @pytest.mark.gpu
+@pytest.mark.parametrize("sub", [None, 420])
 @pytest.mark.parametrize("codec", ["UYVY", "v210", "RGB", "YUYV"])
-def test_jpeg_through_reference_framework(tmp_path, po, codec):
-    """-c jpeg:q=80:restart=4 through compress_init/compress_frame/compress_pop: the stream is what the test writer produces from
-    the oracle's coefficients (inputs other than UYVY go through the pixfmt_conv.c arithmetic first) and libjpeg decodes it."""
+def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
+    """-c jpeg:q=80:restart=4[:subsampling=420] through compress_init/compress_frame/compress_pop: the stream is what the test
+    writer produces from the oracle's coefficients (inputs other than UYVY go through the pixfmt_conv.c arithmetic first) and
+    libjpeg decodes it.  Without the option the module codes 4:2:2, the reference's autoselection for UYVY (gpujpeg.cpp:295-302)."""
     import io
     import sys
     from PIL import Image
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from jpeg_bitstream import write_jpeg420
+    from jpeg_bitstream import write_jpeg
     w, h = 192, 96
     yy, xx = np.mgrid[0:h, 0:w]
     rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1).clip(0, 255).astype(np.uint8)
@@ -143,19 +145,32 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec):
     uyvy = uyvy0 if codec in ("UYVY", "YUYV", "RGB") else po.convert_frame("v210", "UYVY", src, w, h)
     raw, out = tmp_path / "in.raw", tmp_path / "out.jpg"
     np.ascontiguousarray(src).tofile(raw)
-    r = _run(["jpeg:q=80:restart=4", codec, w, h, raw, out])
+    r = _run(["jpeg:q=80:restart=4" + (f":subsampling={sub}" if sub else ""), codec, w, h, raw, out])
     assert r.returncode == 0 and "JPEG" in r.stdout, r.stdout + r.stderr
-    y, u, v = po.uyvy_to_i420(uyvy, w, h)
     ql, qc = po.jpeg_qtable(80, 0), po.jpeg_qtable(80, 1)
-    mw, mh = (w + 15) // 16, (h + 15) // 16
-    want = write_jpeg420(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, 2 * mh),
-                         po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh), po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh), restart=4)
+    mw = (w + 15) // 16
+    if sub == 420:
+        y, u, v = po.uyvy_to_i420(uyvy, w, h)
+        mh, vy = (h + 15) // 16, 2
+    else:
+        y, u, v = po.uyvy_to_i422(uyvy, w, h)
+        mh, vy = (h + 7) // 8, 1
+    want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, vy * mh),
+                      po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh), po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh),
+                      restart=4, sub=sub or 422)
     data = out.read_bytes()
     assert data == want
     img = Image.open(io.BytesIO(data))
     img.draft("YCbCr", None)
     dec = np.asarray(img)
     assert 10 * np.log10(255.0 ** 2 / np.mean((dec[..., 0].astype(float) - y.astype(float)) ** 2)) > 40
+
+
+@needs_harness
+@pytest.mark.gpu
+def test_jpeg_module_rejects_444():
+    r = _run(["jpeg:subsampling=444", "UYVY", 64, 64, "/dev/null", "/dev/null"])
+    assert r.returncode != 0
 
 
 @needs_harness

@@ -140,25 +140,32 @@ def jpeg_fdct_quant_plane(plane: torch.Tensor, div: torch.Tensor, blocks_w: int 
     return (out, coef) if want_coef else out
 
 
-def uyvy_to_jpeg420_coeffs(src: torch.Tensor, w: int, h: int, div: torch.Tensor):
+def uyvy_to_jpeg_coeffs(src: torch.Tensor, w: int, h: int, div: torch.Tensor, subsampling: int = 420):
+    """Fused UYVY -> planar 4:2:0 / 4:2:2 -> FDCT + quantise (ug_hip_uyvy_to_jpeg42x_coeffs)."""
     src = _u8(src)
-    mw, mh = (w + 15) // 16, (h + 15) // 16
-    oy = torch.zeros((4 * mw * mh, 64), dtype=torch.int16, device=src.device)
+    mw = (w + 15) // 16
+    mh, ybl = ((h + 15) // 16, 4) if subsampling == 420 else ((h + 7) // 8, 2)
+    oy = torch.zeros((ybl * mw * mh, 64), dtype=torch.int16, device=src.device)
     ocb = torch.zeros((mw * mh, 64), dtype=torch.int16, device=src.device)
     ocr = torch.zeros((mw * mh, 64), dtype=torch.int16, device=src.device)
-    rc = L.load().ug_hip_uyvy_to_jpeg420_coeffs(src.data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(),
-                                                ocr.data_ptr(), _stream())
-    L.check(rc, "ug_hip_uyvy_to_jpeg420_coeffs")
+    fn = {420: L.load().ug_hip_uyvy_to_jpeg420_coeffs, 422: L.load().ug_hip_uyvy_to_jpeg422_coeffs}[subsampling]
+    rc = fn(src.data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), _stream())
+    L.check(rc, f"ug_hip_uyvy_to_jpeg{subsampling}_coeffs")
     return oy, ocb, ocr
+
+
+def uyvy_to_jpeg420_coeffs(src: torch.Tensor, w: int, h: int, div: torch.Tensor):
+    return uyvy_to_jpeg_coeffs(src, w, h, div, 420)
 
 
 class JpegEncoder:
     """ug_hip_jpeg_encoder_* (gpujpeg_encoder_create / _encode / _destroy shape, gpujpeg.cpp:353,624,639)."""
 
-    def __init__(self, w: int, h: int, quality: int = 75, restart_interval: int = 4):
+    def __init__(self, w: int, h: int, quality: int = 75, restart_interval: int = 4, subsampling: int = 420):
         import ctypes as C
         self._h = C.c_void_p()
-        L.check(L.load().ug_hip_jpeg_encoder_create(w, h, quality, restart_interval, C.byref(self._h)), "ug_hip_jpeg_encoder_create")
+        L.check(L.load().ug_hip_jpeg_encoder_create_sub(w, h, quality, restart_interval, subsampling, C.byref(self._h)),
+                "ug_hip_jpeg_encoder_create_sub")
         self.max_size = L.load().ug_hip_jpeg_encoder_max_size(self._h)
         self._out = None
 

@@ -3,7 +3,7 @@
 // (src/video_compress/gpujpeg.cpp:624, external libgpujpeg); the object shape below mirrors the call sites
 // gpujpeg_encoder_create / _encode / _destroy (gpujpeg.cpp:353,624,639).
 //
-// Stream: SOI, APP0 (JFIF), DQT x2, SOF0 (8-bit, 3 components, 2x2 / 1x1 / 1x1 = 4:2:0), DHT x4 (T.81 Annex K.3
+// Stream: SOI, APP0 (JFIF), DQT x2, SOF0 (8-bit, 3 components, Y 2x2 (4:2:0) or 2x1 (4:2:2) / 1x1 / 1x1), DHT x4 (T.81 Annex K.3
 // tables), DRI, SOS (interleaved), entropy-coded segments of `restart_interval` MCUs separated by RSTm, EOI.
 // Restart intervals make the scan data-parallel: every segment starts byte-aligned with DC predictors reset, so
 // segments are coded independently (one lane per segment), then compacted by a prefix sum over segment sizes.
@@ -56,7 +56,7 @@ __device__ __forceinline__ int count_ff_bytes(uint32_t w)
 constexpr int kRawBytesPerBlock = 224; // 56 words >= (31 carried + 64 x 27) bits
 
 __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
-                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int ri, int n_seg,
+                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int ybl /* Y blocks per MCU: 4 (4:2:0) or 2 (4:2:2) */, int ri, int n_seg,
                                                            uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
                                                            uint32_t *__restrict__ seg_ff /* final size of the segment */)
 {
@@ -73,15 +73,17 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         uint32_t carry_word = 0; // partial word, bits left-aligned
         int carry_bits = 0, wbase = 0, ff = 0;
         int pred[3] = { 0, 0, 0 };
-        const int m0 = seg * ri, n_blk = 6 * (min(n_mcu, (seg + 1) * ri) - m0);
-        // Walk the blocks of the segment in scan order (per MCU: Y00 Y01 Y10 Y11 Cb Cr) with incrementally updated
+        const int per_mcu = ybl + 2;
+        const int m0 = seg * ri, n_blk = per_mcu * (min(n_mcu, (seg + 1) * ri) - m0);
+        // Walk the blocks of the segment in scan order (per MCU: Y00 Y01 [Y10 Y11] Cb Cr) with incrementally updated
         // wave-uniform indices (one division per segment), always one block ahead: the load of block t+1 is issued before
         // block t is coded.
         int mx = m0 % mcu_w, my = m0 / mcu_w, m = m0, b_next = 0;
         auto next_ptr = [&]() { // pointer of block (m, b_next), then advance
-                const int16_t *p = b_next < 4 ? cy + 64 * ((long) (2 * my + (b_next >> 1)) * (2 * mcu_w) + 2 * mx + (b_next & 1))
-                                              : (b_next == 4 ? cb : cr) + 64L * m;
-                if (++b_next == 6) {
+                const int yrow = ybl == 4 ? 2 * my + (b_next >> 1) : my; // luma block row of this Y block
+                const int16_t *p = b_next < ybl ? cy + 64 * ((long) yrow * (2 * mcu_w) + 2 * mx + (b_next & 1))
+                                                : (b_next == ybl ? cb : cr) + 64L * m;
+                if (++b_next == per_mcu) {
                         b_next = 0;
                         m++;
                         if (++mx == mcu_w) { mx = 0; my++; }
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         int b = -1;
         for (int t = 0; t < n_blk; t++) {
                 {
-                        b = b == 5 ? 0 : b + 1;
-                        const int comp = b < 4 ? 0 : 1, pi = b < 4 ? 0 : b - 3;
+                        b = b == per_mcu - 1 ? 0 : b + 1;
+                        const int comp = b < ybl ? 0 : 1, pi = b < ybl ? 0 : b - ybl + 1;
                         int v = v_next;
                         if (t + 1 < n_blk) v_next = next_ptr()[lane];
                         const int dc = __builtin_amdgcn_readfirstlane(v);
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
 }
 
 struct Encoder {
-        int width, height, quality, ri, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
+        int width, height, quality, ri, sub, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
         std::vector<uint8_t> header;
         // device workspace
         float *div;
@@ -253,7 +255,7 @@ struct Encoder {
 
 void put16(std::vector<uint8_t> &v, int x) { v.push_back((uint8_t) (x >> 8)); v.push_back((uint8_t) x); }
 
-std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t *qc, int ri)
+std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t *qc, int ri, int sub)
 {
         std::vector<uint8_t> v = { 0xFF, 0xD8, 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
         for (int t = 0; t < 2; t++) {
@@ -262,7 +264,7 @@ std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t
         }
         v.insert(v.end(), { 0xFF, 0xC0, 0, 17, 8 });
         put16(v, h); put16(v, w);
-        v.insert(v.end(), { 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1 });
+        v.insert(v.end(), { 3, 1, (uint8_t) (sub == 420 ? 0x22 : 0x21), 0, 2, 0x11, 1, 3, 0x11, 1 }); // H x V sampling of Y
         const struct { int tc, th; const uint8_t *bits, *vals; int n; } dht[4] = {
                 { 0, 0, kDcL_bits, kDcL_vals, (int) sizeof kDcL_vals }, { 1, 0, kAcL_bits, kAcL_vals, (int) sizeof kAcL_vals },
                 { 0, 1, kDcC_bits, kDcC_vals, (int) sizeof kDcC_vals }, { 1, 1, kAcC_bits, kAcC_vals, (int) sizeof kAcC_vals } };
@@ -298,28 +300,33 @@ extern "C" {
 
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 
-int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out)
+int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int restart_interval, int subsampling, ug_hip_jpeg_encoder **out)
 {
         if (!out || width <= 0 || height <= 0 || width > 65535 || height > 65535 || restart_interval < 1 || restart_interval > 65535) {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: bad arguments");
                 return UG_HIP_EINVAL;
         }
+        if (subsampling != 420 && subsampling != 422) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create: subsampling must be 420 or 422");
+                return UG_HIP_EUNSUPP;
+        }
         Encoder *e = new Encoder();
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
-        e->mcu_w = (width + 15) / 16; e->mcu_h = (height + 15) / 16; e->n_mcu = e->mcu_w * e->mcu_h;
+        e->sub = subsampling; e->ybl = subsampling == 420 ? 4 : 2;
+        e->mcu_w = (width + 15) / 16; e->mcu_h = subsampling == 420 ? (height + 15) / 16 : (height + 7) / 8; e->n_mcu = e->mcu_w * e->mcu_h;
         e->n_seg = (e->n_mcu + e->ri - 1) / e->ri;
-        e->cap = e->ri * 6 * kRawBytesPerBlock + 8; // unstuffed scan bytes of one segment (worst case 27 bits per coefficient)
+        e->cap = e->ri * (e->ybl + 2) * kRawBytesPerBlock + 8; // unstuffed scan bytes of one segment (worst case 27 bits per coefficient)
         uint8_t ql[64], qc[64];
         float div[128];
         ug_hip_jpeg_qtable(quality, 0, ql);
         ug_hip_jpeg_qtable(quality, 1, qc);
         ug_hip_jpeg_divisors(ql, div);
         ug_hip_jpeg_divisors(qc, div + 64);
-        e->header = build_header(width, height, ql, qc, e->ri);
+        e->header = build_header(width, height, ql, qc, e->ri, e->sub);
         hipError_t err = hipSuccess;
         auto alloc = [&](void **p, size_t n) { if (err == hipSuccess) err = hipMalloc(p, n); };
         alloc((void **) &e->div, sizeof div);
-        alloc((void **) &e->cy, (size_t) 4 * e->n_mcu * 128);
+        alloc((void **) &e->cy, (size_t) e->ybl * e->n_mcu * 128);
         alloc((void **) &e->cb, (size_t) e->n_mcu * 128);
         alloc((void **) &e->cr, (size_t) e->n_mcu * 128);
         alloc((void **) &e->scratch, (size_t) e->n_seg * e->cap);
@@ -337,6 +344,11 @@ int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_i
         }
         *out = (ug_hip_jpeg_encoder *) e;
         return UG_HIP_SUCCESS;
+}
+
+int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out)
+{
+        return ug_hip_jpeg_encoder_create_sub(width, height, quality, restart_interval, 420, out);
 }
 
 void ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc) { destroy((Encoder *) enc); }
@@ -364,9 +376,10 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                 return UG_HIP_EINVAL;
         }
         hipStream_t st = (hipStream_t) stream;
-        int rc = ug_hip_uyvy_to_jpeg420_coeffs(src_dev, src_pitch, e->width, e->height, e->div, e->cy, e->cb, e->cr, stream);
+        int rc = (e->sub == 420 ? ug_hip_uyvy_to_jpeg420_coeffs : ug_hip_uyvy_to_jpeg422_coeffs)(src_dev, src_pitch, e->width, e->height, e->div,
+                                                                                                 e->cy, e->cb, e->cr, stream);
         if (rc != UG_HIP_SUCCESS) return rc;
-        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->ri,
+        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->ybl, e->ri,
                            e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
         hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off);
         UG_HIP_TRY(hipMemcpyAsync(out_dev, e->header_dev, e->header.size(), hipMemcpyDeviceToDevice, st));

@@ -165,19 +165,21 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
         }
 }
 
-// Fused UYVY -> 4:2:0 -> FDCT+quant.  Tasks [0, n_luma) are luma blocks (8 rows x 16 B of UYVY),
-// tasks [n_luma, n_luma + 2*n_chroma) are Cb then Cr blocks (16 rows x 32 B, vertical
-// (a+b+1)/2 average as uyvy_to_i420, to_planar.c:343-378).  Edges replicate.
-__global__ __launch_bounds__(256) void uyvy_jpeg420_kernel(const uint8_t *__restrict__ src, int pitch, int width, int height,
-                                                           int mcu_w, int mcu_h, const float *__restrict__ div,
-                                                           int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
-                                                           int16_t *__restrict__ out_cr)
+// Fused UYVY -> 4:2:0 / 4:2:2 planar -> FDCT+quant.  Tasks [0, n_luma) are luma blocks (8 rows x 16 B of UYVY),
+// tasks [n_luma, n_luma + 2*n_chroma) are Cb then Cr blocks.  SUB = 420: chroma block = 16 rows x 32 B with the vertical
+// (a+b+1)/2 average of uyvy_to_i420 (to_planar.c:343-378), MCU 16x16.  SUB = 422: chroma block = 8 rows x 32 B, samples
+// taken as they are (uyvy_to_i422, video_codec.c:949-969), MCU 16x8.  Edges replicate.
+template <int SUB>
+__global__ __launch_bounds__(256) void uyvy_jpeg_kernel(const uint8_t *__restrict__ src, int pitch, int width, int height,
+                                                        int mcu_w, int mcu_h, const float *__restrict__ div,
+                                                        int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
+                                                        int16_t *__restrict__ out_cr)
 {
-        const long n_luma = 4L * mcu_w * mcu_h, n_chroma = (long) mcu_w * mcu_h;
+        const long n_chroma = (long) mcu_w * mcu_h, n_luma = (SUB == 420 ? 4L : 2L) * n_chroma;
         const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
         if (idx >= n_luma + 2 * n_chroma) return;
         float b[64];
-        const int cw = (width + 1) / 2, ch = (height + 1) / 2; // I420 chroma plane size
+        const int cw = (width + 1) / 2, ch = (height + 1) / 2; // chroma plane size (ch: 4:2:0 only)
         if (idx < n_luma) {
                 const int bw = 2 * mcu_w;
                 const int by = (int) (idx / bw), bx = (int) (idx - (long) by * bw);
@@ -210,14 +212,19 @@ __global__ __launch_bounds__(256) void uyvy_jpeg420_kernel(const uint8_t *__rest
                 const int by = (int) (t / mcu_w), bx = (int) (t - (long) by * mcu_w);
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                        const int cy = min(8 * by + r, ch - 1);
-                        const int y0 = 2 * cy, y1 = min(2 * cy + 1, height - 1); // odd height: last line doubled
+                        int y0, y1;
+                        if (SUB == 420) {
+                                const int cy = min(8 * by + r, ch - 1);
+                                y0 = 2 * cy; y1 = min(2 * cy + 1, height - 1); // odd height: last line doubled
+                        } else {
+                                y0 = y1 = min(8 * by + r, height - 1);
+                        }
                         const uint8_t *r0 = src + (long) y0 * pitch, *r1 = src + (long) y1 * pitch;
 #pragma unroll
                         for (int c = 0; c < 8; c++) {
                                 const int cx = min(8 * bx + c, cw - 1);
                                 const int a = r0[4 * cx + 2 * comp], bb = r1[4 * cx + 2 * comp];
-                                b[8 * r + c] = (float) (((a + bb + 1) >> 1) - 128);
+                                b[8 * r + c] = (float) ((SUB == 420 ? (a + bb + 1) >> 1 : a) - 128);
                         }
                 }
                 fdct8x8(b);
@@ -226,28 +233,32 @@ __global__ __launch_bounds__(256) void uyvy_jpeg420_kernel(const uint8_t *__rest
 }
 
 // MCU-aligned fast path of the fused kernel (width % 16 == 0, 16-byte aligned lines).
-// Workgroup = 3 waves over a strip of 32 MCUs (512 px x 16 rows): wave 0 / 1 = the upper / lower luma block row of
-// the strip (64 blocks each), wave 2 = 32 Cb blocks (lanes 0-31) + 32 Cr blocks (lanes 32-63).  Every wave does 64
-// block DCTs, reads its rows with 128-bit loads that are contiguous across lanes (the chroma wave re-reads the
-// strip from L1/L2, so HBM sees each input byte once) and writes through wave_store_blocks().
-__global__ __launch_bounds__(192) void uyvy_jpeg420_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height, int mcu_w,
-                                                                const float *__restrict__ div, int16_t *__restrict__ out_y,
-                                                                int16_t *__restrict__ out_cb, int16_t *__restrict__ out_cr)
+// Workgroup = kLumaWaves + 1 waves over a strip of 32 MCUs (512 px x 16 rows for 4:2:0, x 8 rows for 4:2:2): the luma
+// waves take one luma block row of the strip each (64 blocks), the last wave = 32 Cb blocks (lanes 0-31) + 32 Cr blocks
+// (lanes 32-63).  Every wave does 64 block DCTs, reads its rows with 128-bit loads that are contiguous across lanes (the
+// chroma wave re-reads the strip from L1/L2, so HBM sees each input byte once) and writes through wave_store_blocks().
+template <int SUB>
+__global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height,
+                                                                                int mcu_w, const float *__restrict__ div,
+                                                                                int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
+                                                                                int16_t *__restrict__ out_cr)
 {
-        __shared__ __attribute__((aligned(16))) uint8_t lds_all[3 * 64 * kLdsPitch];
+        constexpr int kLumaWaves = SUB == 420 ? 2 : 1;
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[(kLumaWaves + 1) * 64 * kLdsPitch];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int mcu0 = blockIdx.x * 32, my = blockIdx.y;
         const int mcus = min(32, mcu_w - mcu0); // MCUs of this strip that exist
         uint8_t *lds = lds_all + wave * 64 * kLdsPitch;
         float b[64];
         uint32_t w[32];
-        if (wave < 2) {
+        if (wave < kLumaWaves) {
                 const int bx = 2 * mcu0 + lane; // luma block column
                 const bool valid = lane < 2 * mcus;
+                const int brow = kLumaWaves * my + wave; // luma block row
                 if (valid) {
 #pragma unroll
                         for (int r = 0; r < 8; r++) {
-                                const int y = min(16 * my + 8 * wave + r, height - 1);
+                                const int y = min(8 * brow + r, height - 1);
                                 const uint4 q = *(const uint4 *) (src + (long) y * pitch + 16 * bx);
                                 const uint32_t ww[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(192) void uyvy_jpeg420_fast_kernel(const uint8_t *_
                         fdct8x8(b);
                         quant_pack(b, div, w);
                 }
-                const long first = (long) (2 * my + wave) * (2 * mcu_w) + 2 * mcu0;
+                const long first = (long) brow * (2 * mcu_w) + 2 * mcu0;
                 wave_store_blocks(w, lds, out_y + 64 * first, lane, 2 * mcus);
         } else {
                 const int comp = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU within the strip
@@ -267,19 +278,33 @@ __global__ __launch_bounds__(192) void uyvy_jpeg420_fast_kernel(const uint8_t *_
                 if (valid) {
 #pragma unroll
                         for (int r = 0; r < 8; r++) {
-                                const int cy = min(8 * my + r, (height + 1) / 2 - 1); // edge replication on the chroma plane
-                                const int y0 = 2 * cy, y1 = min(2 * cy + 1, height - 1);   // odd height: last line doubled
+                                int y0, y1;
+                                if (SUB == 420) {
+                                        const int cy = min(8 * my + r, (height + 1) / 2 - 1); // edge replication on the chroma plane
+                                        y0 = 2 * cy; y1 = min(2 * cy + 1, height - 1);        // odd height: last line doubled
+                                } else {
+                                        y0 = y1 = min(8 * my + r, height - 1);
+                                }
                                 const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * (mcu0 + m));
-                                const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * (mcu0 + m));
-                                const uint4 a0 = p0[0], a1 = p0[1], c0 = p1[0], c1 = p1[1];
+                                const uint4 a0 = p0[0], a1 = p0[1];
                                 const uint32_t wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-                                const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+                                if (SUB == 420) {
+                                        const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * (mcu0 + m));
+                                        const uint4 c0 = p1[0], c1 = p1[1];
+                                        const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 #pragma unroll
-                                for (int c = 0; c < 8; c++) {
-                                        // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367)
-                                        const int sa = comp ? (wa[c] >> 16) & 0xff : wa[c] & 0xff;
-                                        const int sb = comp ? (wc[c] >> 16) & 0xff : wc[c] & 0xff;
-                                        b[8 * r + c] = (float) (((sa + sb + 1) >> 1) - 128);
+                                        for (int c = 0; c < 8; c++) {
+                                                // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367)
+                                                const int sa = comp ? (wa[c] >> 16) & 0xff : wa[c] & 0xff;
+                                                const int sb = comp ? (wc[c] >> 16) & 0xff : wc[c] & 0xff;
+                                                b[8 * r + c] = (float) (((sa + sb + 1) >> 1) - 128);
+                                        }
+                                } else {
+#pragma unroll
+                                        for (int c = 0; c < 8; c++) { // uyvy_to_i422 (video_codec.c:949-969): samples as they are
+                                                const int sa = comp ? (wa[c] >> 16) & 0xff : wa[c] & 0xff;
+                                                b[8 * r + c] = (float) (sa - 128);
+                                        }
                                 }
                         }
                         fdct8x8(b);
@@ -318,6 +343,33 @@ const uint8_t kChroma[64] = {
 };
 const double kAan[8] = { 1.0, 1.387039845, 1.306562965, 1.175875602, 1.0, 0.785694958, 0.541196100, 0.275899379 };
 
+} // namespace
+
+namespace {
+template <int SUB>
+int launch_uyvy_jpeg(const void *src, int src_pitch, int width, int height, const float *div, int16_t *out_y, int16_t *out_cb,
+                     int16_t *out_cr, ug_hip_stream_t stream, const char *who)
+{
+        if (!src || !div || !out_y || !out_cb || !out_cr || width <= 0 || height <= 0 ||
+            ((uintptr_t) out_y | (uintptr_t) out_cb | (uintptr_t) out_cr) & 15) {
+                ug::set_last_error_msg(who);
+                return UG_HIP_EINVAL;
+        }
+        if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
+        const int mcu_w = (width + 15) / 16, mcu_h = SUB == 420 ? (height + 15) / 16 : (height + 7) / 8;
+        if (width % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src)) {
+                hipLaunchKernelGGL((uyvy_jpeg_fast_kernel<SUB>), dim3((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h),
+                                   dim3(SUB == 420 ? 192 : 128), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w,
+                                   div, out_y, out_cb, out_cr);
+                UG_HIP_LAUNCH_CHECK();
+                return UG_HIP_SUCCESS;
+        }
+        const long total = (SUB == 420 ? 6L : 4L) * mcu_w * mcu_h;
+        hipLaunchKernelGGL((uyvy_jpeg_kernel<SUB>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                           (const uint8_t *) src, src_pitch, width, height, mcu_w, mcu_h, div, out_y, out_cb, out_cr);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
 } // namespace
 
 extern "C" {
@@ -361,24 +413,15 @@ int ug_hip_jpeg_fdct_quant_plane(const void *plane, int pitch, int width, int he
 int ug_hip_uyvy_to_jpeg420_coeffs(const void *src, int src_pitch, int width, int height, const float *div,
                                   int16_t *out_y, int16_t *out_cb, int16_t *out_cr, ug_hip_stream_t stream)
 {
-        if (!src || !div || !out_y || !out_cb || !out_cr || width <= 0 || height <= 0 ||
-            ((uintptr_t) out_y | (uintptr_t) out_cb | (uintptr_t) out_cr) & 15) {
-                ug::set_last_error_msg("ug_hip_uyvy_to_jpeg420_coeffs: bad arguments");
-                return UG_HIP_EINVAL;
-        }
-        if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
-        const int mcu_w = (width + 15) / 16, mcu_h = (height + 15) / 16;
-        if (width % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src)) {
-                hipLaunchKernelGGL(uyvy_jpeg420_fast_kernel, dim3((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h), dim3(192), 0,
-                                   (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w, div, out_y, out_cb, out_cr);
-                UG_HIP_LAUNCH_CHECK();
-                return UG_HIP_SUCCESS;
-        }
-        const long total = 6L * mcu_w * mcu_h;
-        hipLaunchKernelGGL(uyvy_jpeg420_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                           (const uint8_t *) src, src_pitch, width, height, mcu_w, mcu_h, div, out_y, out_cb, out_cr);
-        UG_HIP_LAUNCH_CHECK();
-        return UG_HIP_SUCCESS;
+        return launch_uyvy_jpeg<420>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, stream,
+                                     "ug_hip_uyvy_to_jpeg420_coeffs: bad arguments");
+}
+
+int ug_hip_uyvy_to_jpeg422_coeffs(const void *src, int src_pitch, int width, int height, const float *div,
+                                  int16_t *out_y, int16_t *out_cb, int16_t *out_cr, ug_hip_stream_t stream)
+{
+        return launch_uyvy_jpeg<422>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, stream,
+                                     "ug_hip_uyvy_to_jpeg422_coeffs: bad arguments");
 }
 
 } // extern "C"

@@ -58,7 +58,9 @@ SYMBOLS = {
     "ug_hip_jpeg_divisors": (None, [_vp, _vp]),
     "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ug_hip_uyvy_to_jpeg420_coeffs": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ug_hip_uyvy_to_jpeg422_coeffs": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ug_hip_jpeg_encoder_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    "ug_hip_jpeg_encoder_create_sub": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ug_hip_jpeg_encoder_destroy": (None, [_vp]),
     "ug_hip_jpeg_encoder_max_size": (_sz, [_vp]),
     "ug_hip_jpeg_encoder_encode": (_i, [_vp, _i, _vp, _i, _vp, _sz, C.POINTER(_sz), _vp]),

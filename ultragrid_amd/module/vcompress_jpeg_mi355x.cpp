@@ -1,6 +1,6 @@
 /**
  * @file vcompress_jpeg_mi355x.cpp
- * UltraGrid video_compress module "jpeg" (-c jpeg[:q=<1-100>][:restart=<MCUs>][:dev=<n>]) backed by the MI355X kernel
+ * UltraGrid video_compress module "jpeg" (-c jpeg[:q=<1-100>][:restart=<MCUs>][:subsampling=<422|420>][:dev=<n>]) backed by the MI355X kernel
  * library (include/ug_mi355x.h: ug_hip_jpeg_encoder_*).  It occupies the name the reference registers as a hidden alias
  * of its GPUJPEG module (src/video_compress/gpujpeg.cpp:791-792) and follows that module's conventions:
  * quality / restart-interval options (gpujpeg.cpp:279-285,345-352,479-485), UYVY handed to the encoder as 4:2:x YCbCr in
@@ -44,6 +44,7 @@ struct hip_pinned_allocator : public video_frame_pool_allocator {
 struct state_video_compress_jpeg_mi355x {
         struct video_desc    saved_desc{};
         int                  device = 0, quality = 75, restart = 2;
+        int                  subsampling = 422; // gpujpeg.cpp:295-302: autoselect = subsampling of the (UYVY) encoder input
         ug_pixfmt_t          wire = UG_PF_NONE;     ///< format of the uploaded frame
         ug_hip_stream_t      stream = nullptr;
         ug_hip_jpeg_encoder *enc = nullptr;
@@ -63,7 +64,8 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:dev=<index>]\n");
+               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<422|420>][:dev=<index>]\n"
+               "\t\tsubsampling - JPEG chroma subsampling; default 422 (that of the UYVY encoder input), 420 averages line pairs\n");
 }
 
 void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
@@ -81,6 +83,8 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                         s->quality = atoi(tok.c_str() + 8);
                 } else if (strncasecmp(tok.c_str(), "restart=", 8) == 0) {
                         s->restart = atoi(tok.c_str() + 8);
+                } else if (strncasecmp(tok.c_str(), "subsampling=", 12) == 0 || strncasecmp(tok.c_str(), "sub=", 4) == 0) {
+                        s->subsampling = atoi(strchr(tok.c_str(), '=') + 1); // gpujpeg.cpp:406-408
                 } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
                         s->device = atoi(tok.c_str() + 4);
                 } else if (tok == "help") {
@@ -95,6 +99,11 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                 }
                 if (end == std::string::npos) break;
                 pos = end + 1;
+        }
+        if (s->subsampling != 420 && s->subsampling != 422) {
+                MSG(ERROR, "subsampling must be 422 or 420 (444 is not implemented on this path)\n");
+                delete s;
+                return nullptr;
         }
         if (s->quality < 1 || s->quality > 100 || s->restart < 1) {
                 MSG(ERROR, "quality must be 1-100 and restart >= 1\n");
@@ -118,7 +127,7 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 return false;
         }
         s->in_len = (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
-        if (ug_hip_jpeg_encoder_create((int) desc.width, (int) desc.height, s->quality, s->restart, &s->enc) != UG_HIP_SUCCESS) {
+        if (ug_hip_jpeg_encoder_create_sub((int) desc.width, (int) desc.height, s->quality, s->restart, s->subsampling, &s->enc) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "encoder creation failed: %s\n", ug_hip_last_error_string());
                 return false;
         }
@@ -201,6 +210,7 @@ compress_module_info get_jpeg_mi355x_module_info()
         module_info.name = "jpeg";
         module_info.opts.emplace_back(module_option{ "Quality", "Quality 1-100", "75", "quality", ":q=", false });
         module_info.opts.emplace_back(module_option{ "Restart interval", "MCUs per restart interval", "2", "restart_interval", ":restart=", false });
+        module_info.opts.emplace_back(module_option{ "Subsampling", "JPEG subsampling (422 or 420)", "422", "subsampling", ":subsampling=", false });
         codec codec_info;
         codec_info.name = "JPEG";
         codec_info.priority = 300;
