@@ -57,6 +57,7 @@ typedef enum {
         UG_PF_RG48 = 7,     /* 16-bit little-endian R,G,B */
         UG_PF_YUV444 = 8,   /* packed 8-bit Y,U,V triplets (output of *_yuv422_to_yuv444) */
         UG_PF_UYVY_RAW = 9, /* UYVY fed to the encoder WITHOUT colour conversion (DXT1_YUV) */
+        UG_PF_I420 = 10,    /* planar 4:2:0: Y, U, V planes back to back (JPEG encoder input only) */
 } ug_pixfmt_t;
 
 typedef enum {
@@ -176,13 +177,18 @@ int ug_hip_uyvy_to_jpeg422_coeffs(const void *src_dev, int src_pitch, int width,
                                   const float *div_dev, int16_t *out_y, int16_t *out_cb,
                                   int16_t *out_cr, ug_hip_stream_t stream);
 
-/* Complete baseline JPEG encoder (JFIF, 4:2:0 or 4:2:2, interleaved scan, restart intervals) = the fused FDCT+quantise
- * above + Huffman coding (T.81 Annex K.3 tables) + headers.  Object shape of gpujpeg_encoder_create / _encode /
- * _destroy (src/video_compress/gpujpeg.cpp:353,624,639).  `encode` is synchronous on `stream` (it returns the
- * stream length); out_capacity must be >= ug_hip_jpeg_encoder_max_size().  Input: UYVY in device memory. */
+/* Complete baseline JPEG encoder (interleaved scan, restart intervals) = FDCT+quantise as above + Huffman coding (T.81
+ * Annex K.3 tables) + headers.  Object shape of gpujpeg_encoder_create / _encode / _destroy
+ * (src/video_compress/gpujpeg.cpp:353,624,639).  Sampling / input pairs, as the reference module feeds GPUJPEG
+ * (gpujpeg.cpp:227-236,295-305,333-344):
+ *   420: UG_PF_UYVY (line pairs averaged, uyvy_to_i420) or UG_PF_I420 (planes back to back, passthrough)   JFIF YCbCr
+ *   422: UG_PF_UYVY (samples as they are, uyvy_to_i422)                                                     JFIF YCbCr
+ *   444: UG_PF_RGB, components stay R, G, B (color_space_internal = GPUJPEG_RGB); written the libjpeg way for JCS_RGB:
+ *        Adobe APP14 transform 0, component ids 'R','G','B', quantiser / Huffman table 0 for every component.
+ * `encode` is synchronous on `stream` (it returns the stream length); out_capacity >= ug_hip_jpeg_encoder_max_size(). */
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out);
-/* subsampling = 420 or 422 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */
+/* subsampling = 420, 422 or 444 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */
 int    ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int restart_interval, int subsampling,
                                       ug_hip_jpeg_encoder **out);
 void   ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc);

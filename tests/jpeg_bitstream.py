@@ -104,28 +104,37 @@ def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, r
 
 
 def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart=0, header_only=False, sub=420):
-    """coef_*: (n_blocks, 64) int16 zig-zag; Y blocks in raster order over a (2*mcu_w) x (vy*mcu_h) block grid,
-    chroma over mcu_w x mcu_h (sub=420: MCU 16x16, vy=2; sub=422: MCU 16x8, vy=1).  qt_*: 64 quantiser steps in natural
-    order.  restart = MCUs per restart interval (0 = none).  Returns JFIF bytes."""
-    vy = 2 if sub == 420 else 1
-    mw, mh = (width + 15) // 16, (height + 8 * vy - 1) // (8 * vy)
+    """coef_*: (n_blocks, 64) int16 zig-zag; component-0 blocks in raster order over a (hs*mcu_w) x (vs*mcu_h) block grid,
+    the others over mcu_w x mcu_h.  sub=420: MCU 16x16 (hs=vs=2); 422: MCU 16x8 (hs=2, vs=1), both JFIF YCbCr;
+    444: MCU 8x8 (hs=vs=1), components R, G, B without colour transform, libjpeg conventions for JCS_RGB (Adobe APP14
+    transform 0, ids 'R','G','B', table 0 for every component; pass the table-0 quantiser as qt_chroma too).
+    qt_*: 64 quantiser steps in natural order.  restart = MCUs per restart interval (0 = none).  Returns the stream."""
+    hs, vs = (1, 1) if sub == 444 else ((2, 2) if sub == 420 else (2, 1))
+    rgb = sub == 444
+    mw, mh = (width + 8 * hs - 1) // (8 * hs), (height + 8 * vs - 1) // (8 * vs)
     out = io.BytesIO()
     out.write(b"\xff\xd8")
-    out.write(b"\xff\xe0" + struct.pack(">H5sBBBHHBB", 16, b"JFIF\0", 1, 1, 0, 1, 1, 0, 0))
+    if rgb:
+        out.write(b"\xff\xee" + struct.pack(">H5sHHHB", 14, b"Adobe", 100, 0, 0, 0))
+    else:
+        out.write(b"\xff\xe0" + struct.pack(">H5sBBBHHBB", 16, b"JFIF\0", 1, 1, 0, 1, 1, 0, 0))
     for tid, qt in ((0, qt_luma), (1, qt_chroma)):
         out.write(b"\xff\xdb" + struct.pack(">HB", 67, tid) + bytes(int(qt[i]) for i in ZIGZAG))
-    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([1, 0x20 | vy, 0, 2, 0x11, 1, 3, 0x11, 1]))
+    ids = (0x52, 0x47, 0x42) if rgb else (1, 2, 3)
+    t12 = 0 if rgb else 1
+    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([ids[0], (hs << 4) | vs, 0, ids[1], 0x11, t12, ids[2], 0x11, t12]))
     for (tc, th, (bits, vals)) in ((0, 0, DC_L), (1, 0, AC_L), (0, 1, DC_C), (1, 1, AC_C)):
         out.write(b"\xff\xc4" + struct.pack(">HB", 19 + len(vals), (tc << 4) | th) + bytes(bits) + bytes(vals))
     if restart:
         out.write(b"\xff\xdd" + struct.pack(">HH", 4, restart))
-    out.write(b"\xff\xda" + struct.pack(">HB", 12, 3) + bytes([1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0]))
+    out.write(b"\xff\xda" + struct.pack(">HB", 12, 3) + bytes([ids[0], 0x00, ids[1], t12 * 0x11, ids[2], t12 * 0x11, 0, 63, 0]))
     if header_only:
         return out.getvalue()
-    dcl, acl, dcc, acc = _codes(*DC_L), _codes(*AC_L), _codes(*DC_C), _codes(*AC_C)
+    dcl, acl = _codes(*DC_L), _codes(*AC_L)
+    dcc, acc = (dcl, acl) if rgb else (_codes(*DC_C), _codes(*AC_C))
     bw = _Bits()
     py = pcb = pcr = 0
-    bwid = 2 * mw
+    bwid = hs * mw
     n_mcu = mw * mh
     for m in range(n_mcu):
         my, mx = divmod(m, mw)
@@ -135,8 +144,9 @@ def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, rest
             out.write(bytes([0xFF, 0xD0 + ((m // restart - 1) & 7)]))
             bw = _Bits()
             py = pcb = pcr = 0
-        for (dy, dx) in ((0, 0), (0, 1), (1, 0), (1, 1))[: 2 * vy]:
-            py = _block(bw, coef_y[(vy * my + dy) * bwid + 2 * mx + dx], py, dcl, acl)
+        for dy in range(vs):
+            for dx in range(hs):
+                py = _block(bw, coef_y[(vs * my + dy) * bwid + hs * mx + dx], py, dcl, acl)
         pcb = _block(bw, coef_cb[my * mw + mx], pcb, dcc, acc)
         pcr = _block(bw, coef_cr[my * mw + mx], pcr, dcc, acc)
     bw.flush()

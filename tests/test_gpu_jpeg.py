@@ -178,4 +178,65 @@ def test_jpeg_encoder_rejects_unknown_subsampling(hip):
     import ctypes as C
     from ultragrid_amd import lib as L
     h = C.c_void_p()
-    assert L.load().ug_hip_jpeg_encoder_create_sub(64, 64, 75, 4, 444, C.byref(h)) == -2
+    assert L.load().ug_hip_jpeg_encoder_create_sub(64, 64, 75, 4, 411, C.byref(h)) == -2
+
+
+def _smooth_rgb(w, h):
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    return rgb.clip(0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("dims", [(8, 8), (160, 96), (203, 121), (1920, 1080)], ids=str)
+@pytest.mark.parametrize("ri", [1, 8])
+def test_full_jpeg_stream_444_rgb(hip, po, dims, ri):
+    """RGB input, the reference module's choice for RGB frames (gpujpeg.cpp:303-305,336: 4:4:4, components stay R, G, B): stream equals
+    the test writer fed with the oracle's per-component coefficients; Pillow/libjpeg decodes it as RGB."""
+    import io
+    import torch
+    from PIL import Image
+    from ultragrid_amd import lib as L
+    from jpeg_bitstream import write_jpeg
+    w, h = dims
+    rgb = _smooth_rgb(w, h)
+    q = 85
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=444)
+    data = enc.encode(torch.from_numpy(rgb.ravel()).cuda(), L.PF_RGB)
+    enc.close()
+    ql = po.jpeg_qtable(q, 0)
+    dl = po.jpeg_divisors(ql)
+    bw, bh = (w + 7) // 8, (h + 7) // 8
+    coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(rgb[..., c]), dl, bw, bh) for c in range(3)]
+    want = write_jpeg(w, h, ql, po.jpeg_qtable(q, 1), *coefs, restart=ri, sub=444)
+    assert data == want, (len(data), len(want))
+    img = Image.open(io.BytesIO(data))
+    assert img.mode == "RGB" and img.size == (w, h)
+    dec = np.asarray(img).astype(float)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((dec - rgb.astype(float)) ** 2))
+    assert psnr > 38, psnr
+
+
+@pytest.mark.parametrize("dims", [(16, 16), (50, 38), (1920, 1080)], ids=str)
+def test_i420_input_equals_uyvy_420_path(hip, po, dims):
+    """I420 passthrough (gpujpeg.cpp:227-236,335): feeding the planes uyvy_to_i420 produces gives the very stream the fused UYVY 4:2:0
+    path produces."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = dims
+    uyvy = synth.s2_video("UYVY", w, h)
+    y, u, v = po.uyvy_to_i420(uyvy, w, h)
+    planes = np.concatenate([y.ravel(), u.ravel(), v.ravel()])
+    enc = hip.JpegEncoder(w, h, 75, 3, subsampling=420)
+    a = enc.encode(torch.from_numpy(uyvy).cuda())
+    b = enc.encode(torch.from_numpy(planes).cuda(), L.PF_I420)
+    enc.close()
+    assert a == b
+
+
+def test_jpeg_encoder_input_format_mismatch(hip):
+    import torch
+    from ultragrid_amd import lib as L
+    enc = hip.JpegEncoder(64, 64, 75, 4, subsampling=444)
+    with pytest.raises(RuntimeError):
+        enc.encode(torch.zeros(64 * 64 * 2, dtype=torch.uint8, device="cuda"), L.PF_UYVY)
+    enc.close()

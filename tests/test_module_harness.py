@@ -127,11 +127,12 @@ def test_jpeg_module_registers():
 @needs_harness
 @pytest.mark.gpu
 @pytest.mark.parametrize("sub", [None, 420])
-@pytest.mark.parametrize("codec", ["UYVY", "v210", "RGB", "YUYV"])
+@pytest.mark.parametrize("codec", ["UYVY", "v210", "RGB", "YUYV", "RGBA", "I420"])
 def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
     """-c jpeg:q=80:restart=4[:subsampling=420] through compress_init/compress_frame/compress_pop: the stream is what the test
-    writer produces from the oracle's coefficients (inputs other than UYVY go through the pixfmt_conv.c arithmetic first) and
-    libjpeg decodes it.  Without the option the module codes 4:2:2, the reference's autoselection for UYVY (gpujpeg.cpp:295-302)."""
+    writer produces from the oracle's coefficients and libjpeg decodes it.  Without the option the module codes the input's own
+    sampling like the reference (gpujpeg.cpp:295-305): 4:2:2 for UYVY/YUYV/v210, R,G,B 4:4:4 for RGB/RGBA, 4:2:0 for I420; with
+    subsampling=420 RGB-family input goes through the pixfmt_conv.c RGB->UYVY arithmetic first."""
     import io
     import sys
     from PIL import Image
@@ -141,15 +142,28 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
     yy, xx = np.mgrid[0:h, 0:w]
     rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1).clip(0, 255).astype(np.uint8)
     uyvy0 = po.convert_frame("RGB", "UYVY", rgb, w, h)
-    src = {"UYVY": uyvy0, "RGB": rgb.ravel(), "YUYV": po.convert_frame("UYVY", "YUYV", uyvy0, w, h), "v210": po.convert_frame("UYVY", "v210", uyvy0, w, h)}[codec]
-    uyvy = uyvy0 if codec in ("UYVY", "YUYV", "RGB") else po.convert_frame("v210", "UYVY", src, w, h)
+    rgba = po.convert_frame("RGB", "RGBA", rgb, w, h)
+    i420 = np.concatenate([p.ravel() for p in po.uyvy_to_i420(uyvy0, w, h)])
+    src = {"UYVY": uyvy0, "RGB": rgb.ravel(), "RGBA": rgba, "YUYV": po.convert_frame("UYVY", "YUYV", uyvy0, w, h),
+           "v210": po.convert_frame("UYVY", "v210", uyvy0, w, h), "I420": i420}[codec]
     raw, out = tmp_path / "in.raw", tmp_path / "out.jpg"
     np.ascontiguousarray(src).tofile(raw)
     r = _run(["jpeg:q=80:restart=4" + (f":subsampling={sub}" if sub else ""), codec, w, h, raw, out])
     assert r.returncode == 0 and "JPEG" in r.stdout, r.stdout + r.stderr
+    data = out.read_bytes()
     ql, qc = po.jpeg_qtable(80, 0), po.jpeg_qtable(80, 1)
+    eff = sub or {"RGB": 444, "RGBA": 444, "I420": 420}.get(codec, 422)
+    if eff == 444:
+        comp = rgb if codec == "RGB" else po.convert_frame("RGBA", "RGB", rgba, w, h).reshape(h, w, 3)
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comp[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        assert data == write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444)
+        img = Image.open(io.BytesIO(data))
+        assert img.mode == "RGB"
+        assert 10 * np.log10(255.0 ** 2 / np.mean((np.asarray(img).astype(float) - rgb.astype(float)) ** 2)) > 36
+        return
+    uyvy = {"v210": lambda: po.convert_frame("v210", "UYVY", src, w, h), "RGBA": lambda: po.convert_frame("RGBA", "UYVY", rgba, w, h)}.get(codec, lambda: uyvy0)()
     mw = (w + 15) // 16
-    if sub == 420:
+    if eff == 420:
         y, u, v = po.uyvy_to_i420(uyvy, w, h)
         mh, vy = (h + 15) // 16, 2
     else:
@@ -157,8 +171,7 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
         mh, vy = (h + 7) // 8, 1
     want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, vy * mh),
                       po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh), po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh),
-                      restart=4, sub=sub or 422)
-    data = out.read_bytes()
+                      restart=4, sub=eff)
     assert data == want
     img = Image.open(io.BytesIO(data))
     img.draft("YCbCr", None)
@@ -168,9 +181,11 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
 
 @needs_harness
 @pytest.mark.gpu
-def test_jpeg_module_rejects_444():
-    r = _run(["jpeg:subsampling=444", "UYVY", 64, 64, "/dev/null", "/dev/null"])
-    assert r.returncode != 0
+def test_jpeg_module_rejects_impossible_subsampling(tmp_path):
+    raw = tmp_path / "in.raw"
+    np.zeros(64 * 64 * 2, np.uint8).tofile(raw)
+    assert _run(["jpeg:subsampling=444", "UYVY", 64, 64, raw, tmp_path / "o"]).returncode != 0   # 4:4:4 needs RGB-family input
+    assert _run(["jpeg:subsampling=411", "UYVY", 64, 64, raw, tmp_path / "o"]).returncode != 0
 
 
 @needs_harness

@@ -169,13 +169,14 @@ class JpegEncoder:
         self.max_size = L.load().ug_hip_jpeg_encoder_max_size(self._h)
         self._out = None
 
-    def encode(self, src: torch.Tensor) -> bytes:
+    def encode(self, src: torch.Tensor, in_fmt: int = L.PF_UYVY) -> bytes:
+        """src: UYVY (4:2:0 / 4:2:2 encoder), RGB (4:4:4 encoder) or I420 planes back to back (4:2:0 encoder)."""
         import ctypes as C
         src = _u8(src)
         if self._out is None:
             self._out = torch.empty(self.max_size, dtype=torch.uint8, device=src.device)
         n = C.c_size_t(0)
-        rc = L.load().ug_hip_jpeg_encoder_encode(self._h, L.PF_UYVY, src.data_ptr(), 0, self._out.data_ptr(), self.max_size, C.byref(n), _stream())
+        rc = L.load().ug_hip_jpeg_encoder_encode(self._h, in_fmt, src.data_ptr(), 0, self._out.data_ptr(), self.max_size, C.byref(n), _stream())
         L.check(rc, "ug_hip_jpeg_encoder_encode")
         return bytes(self._out[: n.value].cpu().numpy())
 

@@ -56,7 +56,8 @@ __device__ __forceinline__ int count_ff_bytes(uint32_t w)
 constexpr int kRawBytesPerBlock = 224; // 56 words >= (31 carried + 64 x 27) bits
 
 __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
-                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int ybl /* Y blocks per MCU: 4 (4:2:0) or 2 (4:2:2) */, int ri, int n_seg,
+                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs /* sampling factors of component 0: 2x2 (4:2:0), 2x1 (4:2:2), 1x1 (4:4:4) */,
+                                                           int ctab /* Huffman table set of components 1,2: 1 = chroma (YCbCr), 0 = same as component 0 (RGB) */, int ri, int n_seg,
                                                            uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
                                                            uint32_t *__restrict__ seg_ff /* final size of the segment */)
 {
@@ -73,15 +74,15 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         uint32_t carry_word = 0; // partial word, bits left-aligned
         int carry_bits = 0, wbase = 0, ff = 0;
         int pred[3] = { 0, 0, 0 };
-        const int per_mcu = ybl + 2;
+        const int ybl = hs * vs, per_mcu = ybl + 2;
         const int m0 = seg * ri, n_blk = per_mcu * (min(n_mcu, (seg + 1) * ri) - m0);
         // Walk the blocks of the segment in scan order (per MCU: Y00 Y01 [Y10 Y11] Cb Cr) with incrementally updated
         // wave-uniform indices (one division per segment), always one block ahead: the load of block t+1 is issued before
         // block t is coded.
         int mx = m0 % mcu_w, my = m0 / mcu_w, m = m0, b_next = 0;
         auto next_ptr = [&]() { // pointer of block (m, b_next), then advance
-                const int yrow = ybl == 4 ? 2 * my + (b_next >> 1) : my; // luma block row of this Y block
-                const int16_t *p = b_next < ybl ? cy + 64 * ((long) yrow * (2 * mcu_w) + 2 * mx + (b_next & 1))
+                const int yrow = vs * my + (hs == 2 ? b_next >> 1 : 0), ycol = hs * mx + (hs == 2 ? b_next & 1 : 0); // block of component 0
+                const int16_t *p = b_next < ybl ? cy + 64 * ((long) yrow * (hs * mcu_w) + ycol)
                                                 : (b_next == ybl ? cb : cr) + 64L * m;
                 if (++b_next == per_mcu) {
                         b_next = 0;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         for (int t = 0; t < n_blk; t++) {
                 {
                         b = b == per_mcu - 1 ? 0 : b + 1;
-                        const int comp = b < ybl ? 0 : 1, pi = b < ybl ? 0 : b - ybl + 1;
+                        const int comp = b < ybl ? 0 : ctab, pi = b < ybl ? 0 : b - ybl + 1;
                         int v = v_next;
                         if (t + 1 < n_blk) v_next = next_ptr()[lane];
                         const int dc = __builtin_amdgcn_readfirstlane(v);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
 }
 
 struct Encoder {
-        int width, height, quality, ri, sub, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
+        int width, height, quality, ri, sub, hs, vs, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
         std::vector<uint8_t> header;
         // device workspace
         float *div;
@@ -257,14 +258,26 @@ void put16(std::vector<uint8_t> &v, int x) { v.push_back((uint8_t) (x >> 8)); v.
 
 std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t *qc, int ri, int sub)
 {
-        std::vector<uint8_t> v = { 0xFF, 0xD8, 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
+        // 4:2:0 / 4:2:2: JFIF (YCbCr, BT.709 limited range samples as they come from the UYVY frame).  4:4:4: the components are
+        // R, G, B without colour transform (what the reference's module asks of GPUJPEG for RGB input: color_space_internal =
+        // GPUJPEG_RGB, gpujpeg.cpp:303-305), signalled the libjpeg way: Adobe APP14 with transform 0 and ids 'R','G','B';
+        // every component uses quantiser / Huffman table 0.
+        const bool rgb = sub == 444;
+        std::vector<uint8_t> v = { 0xFF, 0xD8 };
+        if (rgb) {
+                v.insert(v.end(), { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 });
+        } else {
+                v.insert(v.end(), { 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 });
+        }
         for (int t = 0; t < 2; t++) {
                 v.insert(v.end(), { 0xFF, 0xDB, 0, 67, (uint8_t) t });
                 for (int i = 0; i < 64; i++) v.push_back((t ? qc : ql)[kZigHost[i]]);
         }
         v.insert(v.end(), { 0xFF, 0xC0, 0, 17, 8 });
         put16(v, h); put16(v, w);
-        v.insert(v.end(), { 3, 1, (uint8_t) (sub == 420 ? 0x22 : 0x21), 0, 2, 0x11, 1, 3, 0x11, 1 }); // H x V sampling of Y
+        const uint8_t id[3] = { (uint8_t) (rgb ? 'R' : 1), (uint8_t) (rgb ? 'G' : 2), (uint8_t) (rgb ? 'B' : 3) };
+        const uint8_t s0 = sub == 420 ? 0x22 : (sub == 422 ? 0x21 : 0x11), t12 = rgb ? 0 : 1; // H x V sampling of component 0
+        v.insert(v.end(), { 3, id[0], s0, 0, id[1], 0x11, t12, id[2], 0x11, t12 });
         const struct { int tc, th; const uint8_t *bits, *vals; int n; } dht[4] = {
                 { 0, 0, kDcL_bits, kDcL_vals, (int) sizeof kDcL_vals }, { 1, 0, kAcL_bits, kAcL_vals, (int) sizeof kAcL_vals },
                 { 0, 1, kDcC_bits, kDcC_vals, (int) sizeof kDcC_vals }, { 1, 1, kAcC_bits, kAcC_vals, (int) sizeof kAcC_vals } };
@@ -279,7 +292,8 @@ std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t
                 v.insert(v.end(), { 0xFF, 0xDD, 0, 4 });
                 put16(v, ri);
         }
-        v.insert(v.end(), { 0xFF, 0xDA, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0 });
+        const uint8_t h12 = rgb ? 0x00 : 0x11;
+        v.insert(v.end(), { 0xFF, 0xDA, 0, 12, 3, id[0], 0x00, id[1], h12, id[2], h12, 0, 63, 0 });
         return v;
 }
 
@@ -306,14 +320,15 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: bad arguments");
                 return UG_HIP_EINVAL;
         }
-        if (subsampling != 420 && subsampling != 422) {
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_create: subsampling must be 420 or 422");
+        if (subsampling != 420 && subsampling != 422 && subsampling != 444) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create: subsampling must be 420, 422 or 444");
                 return UG_HIP_EUNSUPP;
         }
         Encoder *e = new Encoder();
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
-        e->sub = subsampling; e->ybl = subsampling == 420 ? 4 : 2;
-        e->mcu_w = (width + 15) / 16; e->mcu_h = subsampling == 420 ? (height + 15) / 16 : (height + 7) / 8; e->n_mcu = e->mcu_w * e->mcu_h;
+        e->sub = subsampling;
+        e->hs = subsampling == 444 ? 1 : 2; e->vs = subsampling == 420 ? 2 : 1; e->ybl = e->hs * e->vs;
+        e->mcu_w = (width + 8 * e->hs - 1) / (8 * e->hs); e->mcu_h = (height + 8 * e->vs - 1) / (8 * e->vs); e->n_mcu = e->mcu_w * e->mcu_h;
         e->n_seg = (e->n_mcu + e->ri - 1) / e->ri;
         e->cap = e->ri * (e->ybl + 2) * kRawBytesPerBlock + 8; // unstuffed scan bytes of one segment (worst case 27 bits per coefficient)
         uint8_t ql[64], qc[64];
@@ -321,7 +336,7 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         ug_hip_jpeg_qtable(quality, 0, ql);
         ug_hip_jpeg_qtable(quality, 1, qc);
         ug_hip_jpeg_divisors(ql, div);
-        ug_hip_jpeg_divisors(qc, div + 64);
+        ug_hip_jpeg_divisors(subsampling == 444 ? ql : qc, div + 64); // RGB: every component is quantised with table 0
         e->header = build_header(width, height, ql, qc, e->ri, e->sub);
         hipError_t err = hipSuccess;
         auto alloc = [&](void **p, size_t n) { if (err == hipSuccess) err = hipMalloc(p, n); };
@@ -367,19 +382,41 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: bad arguments");
                 return UG_HIP_EINVAL;
         }
-        if (in != UG_PF_UYVY) {
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: input must be UYVY (convert with ug_hip_pixfmt_convert)");
-                return UG_HIP_EUNSUPP;
-        }
         if (out_capacity < ug_hip_jpeg_encoder_max_size(enc)) {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: output buffer smaller than ug_hip_jpeg_encoder_max_size()");
                 return UG_HIP_EINVAL;
         }
         hipStream_t st = (hipStream_t) stream;
-        int rc = (e->sub == 420 ? ug_hip_uyvy_to_jpeg420_coeffs : ug_hip_uyvy_to_jpeg422_coeffs)(src_dev, src_pitch, e->width, e->height, e->div,
-                                                                                                 e->cy, e->cb, e->cr, stream);
+        int rc;
+        const int w = e->width, h = e->height;
+        if (in == UG_PF_UYVY && e->sub != 444) {
+                rc = (e->sub == 420 ? ug_hip_uyvy_to_jpeg420_coeffs : ug_hip_uyvy_to_jpeg422_coeffs)(src_dev, src_pitch, w, h, e->div, e->cy, e->cb,
+                                                                                                     e->cr, stream);
+        } else if (in == UG_PF_RGB && e->sub == 444) { // GPUJPEG_444_U8_P012, components kept as R, G, B (gpujpeg.cpp:303-305,336)
+                if (!src_pitch) src_pitch = 3 * w;
+                int16_t *const dst[3] = { e->cy, e->cb, e->cr };
+                rc = UG_HIP_SUCCESS;
+                for (int c = 0; c < 3 && rc == UG_HIP_SUCCESS; c++) {
+                        rc = ug::jpeg_fdct_quant_strided((const uint8_t *) src_dev + c, src_pitch, 3, w, h, e->mcu_w, e->mcu_h, e->div, dst[c],
+                                                         nullptr, stream);
+                }
+        } else if (in == UG_PF_I420 && e->sub == 420) { // planar passthrough (GPUJPEG_420_U8_P0P1P2, gpujpeg.cpp:335): Y, U, V planes back to back
+                if (src_pitch && src_pitch != w) {
+                        ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: I420 input must be tightly packed");
+                        return UG_HIP_EINVAL;
+                }
+                const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+                const uint8_t *y = (const uint8_t *) src_dev, *u = y + (size_t) w * h, *v = u + (size_t) cw * ch;
+                rc = ug::jpeg_fdct_quant_strided(y, w, 1, w, h, 2 * e->mcu_w, 2 * e->mcu_h, e->div, e->cy, nullptr, stream);
+                if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(u, cw, 1, cw, ch, e->mcu_w, e->mcu_h, e->div + 64, e->cb, nullptr, stream);
+                if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(v, cw, 1, cw, ch, e->mcu_w, e->mcu_h, e->div + 64, e->cr, nullptr, stream);
+        } else {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: input must be UYVY (4:2:0 / 4:2:2 encoder), I420 (4:2:0) or RGB (4:4:4); "
+                                       "convert other formats with ug_hip_pixfmt_convert");
+                return UG_HIP_EUNSUPP;
+        }
         if (rc != UG_HIP_SUCCESS) return rc;
-        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->ybl, e->ri,
+        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs, e->sub == 444 ? 0 : 1, e->ri,
                            e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
         hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off);
         UG_HIP_TRY(hipMemcpyAsync(out_dev, e->header_dev, e->header.size(), hipMemcpyDeviceToDevice, st));

@@ -118,7 +118,8 @@ __device__ __forceinline__ void quant_store(const float (&b)[64], const float *_
         }
 }
 
-__global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__restrict__ plane, int pitch, int width, int height,
+// xstride = byte step between horizontally adjacent samples: 1 for a plane, 3 for one component of packed RGB.
+__global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__restrict__ plane, int pitch, int xstride, int width, int height,
                                                                int blocks_w, long total, const float *__restrict__ div,
                                                                int16_t *__restrict__ out, float *__restrict__ coef)
 {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
         if (idx < total) {
                 const int by = (int) (idx / blocks_w), bx = (int) (idx - (long) by * blocks_w);
                 float b[64];
-                const bool interior = 8 * bx + 8 <= width && 8 * by + 8 <= height && !(pitch & 7) && !(7 & (uintptr_t) plane);
+                const bool interior = xstride == 1 && 8 * bx + 8 <= width && 8 * by + 8 <= height && !(pitch & 7) && !(7 & (uintptr_t) plane);
                 if (interior) {
 #pragma unroll
                         for (int r = 0; r < 8; r++) {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
 #pragma unroll
                                 for (int c = 0; c < 8; c++) {
                                         const int x = min(8 * bx + c, width - 1);
-                                        b[8 * r + c] = (float) ((int) plane[(long) y * pitch + x] - 128);
+                                        b[8 * r + c] = (float) ((int) plane[(long) y * pitch + (long) x * xstride] - 128);
                                 }
                         }
                 }
@@ -372,6 +373,22 @@ int launch_uyvy_jpeg(const void *src, int src_pitch, int width, int height, cons
 }
 } // namespace
 
+// one component of a planar (xstride 1) or packed (xstride = bytes per pixel) 8-bit image -> quantised blocks
+int ug::jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width, int height, int blocks_w, int blocks_h,
+                                const float *div, int16_t *out, float *coef, ug_hip_stream_t stream)
+{
+        if (!plane || !div || !out || width <= 0 || height <= 0 || xstride < 1 || blocks_w * 8 < width || blocks_h * 8 < height ||
+            (15 & (uintptr_t) out) || pitch < width * xstride) {
+                ug::set_last_error_msg("ug_hip_jpeg_fdct_quant_plane: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        const long total = (long) blocks_w * blocks_h;
+        hipLaunchKernelGGL(fdct_quant_plane_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                           (const uint8_t *) plane, pitch, xstride, width, height, blocks_w, total, div, out, coef);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
 extern "C" {
 
 void ug_hip_jpeg_qtable(int quality, int comp, uint8_t table[64])
@@ -398,16 +415,7 @@ void ug_hip_jpeg_divisors(const uint8_t q[64], float div[64])
 int ug_hip_jpeg_fdct_quant_plane(const void *plane, int pitch, int width, int height, int blocks_w, int blocks_h,
                                  const float *div, int16_t *out, float *coef, ug_hip_stream_t stream)
 {
-        if (!plane || !div || !out || width <= 0 || height <= 0 || blocks_w * 8 < width || blocks_h * 8 < height ||
-            (15 & (uintptr_t) out) || pitch < width) {
-                ug::set_last_error_msg("ug_hip_jpeg_fdct_quant_plane: bad arguments");
-                return UG_HIP_EINVAL;
-        }
-        const long total = (long) blocks_w * blocks_h;
-        hipLaunchKernelGGL(fdct_quant_plane_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                           (const uint8_t *) plane, pitch, width, height, blocks_w, total, div, out, coef);
-        UG_HIP_LAUNCH_CHECK();
-        return UG_HIP_SUCCESS;
+        return ug::jpeg_fdct_quant_strided(plane, pitch, 1, width, height, blocks_w, blocks_h, div, out, coef, stream);
 }
 
 int ug_hip_uyvy_to_jpeg420_coeffs(const void *src, int src_pitch, int width, int height, const float *div,

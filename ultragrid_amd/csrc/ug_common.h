@@ -52,4 +52,8 @@ static inline int linesize(ug_pixfmt_t f, int width)
         return (width + bp - 1) / bp * bb;
 }
 
+// jpeg_fdct.hip: FDCT+quantise of one 8-bit component, planar (xstride 1) or packed (xstride = bytes per pixel)
+int jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width, int height, int blocks_w, int blocks_h,
+                            const float *div, int16_t *out, float *coef, ug_hip_stream_t stream);
+
 } // namespace ug

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UG_MI355X_LIB") or os.path.join(_HERE, "libug_mi355x.so")
 
 # ug_pixfmt_t
-PF_NONE, PF_RGBA, PF_UYVY, PF_YUYV, PF_RGB, PF_BGR, PF_V210, PF_RG48, PF_YUV444, PF_UYVY_RAW = range(10)
+PF_NONE, PF_RGBA, PF_UYVY, PF_YUYV, PF_RGB, PF_BGR, PF_V210, PF_RG48, PF_YUV444, PF_UYVY_RAW, PF_I420 = range(11)
 PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "BGR": PF_BGR, "v210": PF_V210,
             "RG48": PF_RG48, "YUV444": PF_YUV444, "UYVY_RAW": PF_UYVY_RAW}
 # ug_dxt_t

@@ -17,6 +17,7 @@ static inline ug_pixfmt_t ug_pixfmt_from_codec(codec_t c)
         case BGR:  return UG_PF_BGR;
         case v210: return UG_PF_V210;
         case RG48: return UG_PF_RG48;
+        case I420: return UG_PF_I420;
         default:   return UG_PF_NONE;
         }
 }
@@ -31,6 +32,7 @@ static inline codec_t ug_codec_from_pixfmt(ug_pixfmt_t f)
         case UG_PF_BGR:  return BGR;
         case UG_PF_V210: return v210;
         case UG_PF_RG48: return RG48;
+        case UG_PF_I420: return I420;
         default:         return VIDEO_CODEC_NONE;
         }
 }

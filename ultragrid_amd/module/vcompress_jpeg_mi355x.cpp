@@ -1,6 +1,6 @@
 /**
  * @file vcompress_jpeg_mi355x.cpp
- * UltraGrid video_compress module "jpeg" (-c jpeg[:q=<1-100>][:restart=<MCUs>][:subsampling=<422|420>][:dev=<n>]) backed by the MI355X kernel
+ * UltraGrid video_compress module "jpeg" (-c jpeg[:q=<1-100>][:restart=<MCUs>][:subsampling=<444|422|420>][:dev=<n>]) backed by the MI355X kernel
  * library (include/ug_mi355x.h: ug_hip_jpeg_encoder_*).  It occupies the name the reference registers as a hidden alias
  * of its GPUJPEG module (src/video_compress/gpujpeg.cpp:791-792) and follows that module's conventions:
  * quality / restart-interval options (gpujpeg.cpp:279-285,345-352,479-485), UYVY handed to the encoder as 4:2:x YCbCr in
@@ -44,8 +44,9 @@ struct hip_pinned_allocator : public video_frame_pool_allocator {
 struct state_video_compress_jpeg_mi355x {
         struct video_desc    saved_desc{};
         int                  device = 0, quality = 75, restart = 2;
-        int                  subsampling = 422; // gpujpeg.cpp:295-302: autoselect = subsampling of the (UYVY) encoder input
+        int                  subsampling = 0;  ///< 0 = autoselect: that of the input codec (gpujpeg.cpp:168,295-302)
         ug_pixfmt_t          wire = UG_PF_NONE;     ///< format of the uploaded frame
+        ug_pixfmt_t          enc_in = UG_PF_NONE;   ///< what the encoder is fed: UYVY, RGB or I420
         ug_hip_stream_t      stream = nullptr;
         ug_hip_jpeg_encoder *enc = nullptr;
         void                *dev_in = nullptr, *dev_uyvy = nullptr, *dev_out = nullptr;
@@ -64,8 +65,9 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<422|420>][:dev=<index>]\n"
-               "\t\tsubsampling - JPEG chroma subsampling; default 422 (that of the UYVY encoder input), 420 averages line pairs\n");
+               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:dev=<index>]\n"
+               "\t\tsubsampling - JPEG subsampling; default = that of the input: 422 for UYVY/YUYV/v210, 444 (R,G,B components)\n"
+               "\t\t              for RGB/RGBA/BGR, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
 }
 
 void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
@@ -100,8 +102,8 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                 if (end == std::string::npos) break;
                 pos = end + 1;
         }
-        if (s->subsampling != 420 && s->subsampling != 422) {
-                MSG(ERROR, "subsampling must be 422 or 420 (444 is not implemented on this path)\n");
+        if (s->subsampling != 0 && s->subsampling != 420 && s->subsampling != 422 && s->subsampling != 444) {
+                MSG(ERROR, "subsampling must be 444, 422 or 420\n");
                 delete s;
                 return nullptr;
         }
@@ -122,20 +124,41 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
 {
         cleanup(s);
         s->wire = ug_pixfmt_from_codec(desc.color_spec);
-        if (s->wire != UG_PF_UYVY && !ug_hip_pixfmt_supported(s->wire, UG_PF_UYVY)) {
-                MSG(ERROR, "Unsupported codec: %s (GPU path takes UYVY, YUYV, v210, RGB, RGBA, BGR, RG48)\n", get_codec_name(desc.color_spec));
-                return false;
+        // What the encoder is fed and which sampling it codes (gpujpeg.cpp:227-236,295-305,333-344): autoselect = the input
+        // codec's own subsampling; RGB-family input stays R,G,B in 4:4:4, 4:2:2 input is coded as 4:2:2 (or 4:2:0 on request),
+        // I420 passes through.  RGB-family input with subsampling=422/420 goes through the pixfmt_conv.c RGB->UYVY arithmetic.
+        const bool rgb_family = codec_is_a_rgb(desc.color_spec);
+        int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (desc.color_spec == I420 ? 420 : 422));
+        if (s->wire == UG_PF_I420) {
+                s->enc_in = UG_PF_I420;
+                if (sub != 420) {
+                        MSG(ERROR, "I420 input can only be coded as 4:2:0\n");
+                        return false;
+                }
+        } else if (sub == 444) {
+                s->enc_in = UG_PF_RGB;
+                if (!rgb_family || (s->wire != UG_PF_RGB && !ug_hip_pixfmt_supported(s->wire, UG_PF_RGB))) {
+                        MSG(ERROR, "subsampling=444 needs RGB, RGBA or BGR input, not %s\n", get_codec_name(desc.color_spec));
+                        return false;
+                }
+        } else {
+                s->enc_in = UG_PF_UYVY;
+                if (s->wire != UG_PF_UYVY && !ug_hip_pixfmt_supported(s->wire, UG_PF_UYVY)) {
+                        MSG(ERROR, "Unsupported codec: %s (GPU path takes UYVY, YUYV, v210, I420, RGB, RGBA, BGR, RG48)\n", get_codec_name(desc.color_spec));
+                        return false;
+                }
         }
-        s->in_len = (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
-        if (ug_hip_jpeg_encoder_create_sub((int) desc.width, (int) desc.height, s->quality, s->restart, s->subsampling, &s->enc) != UG_HIP_SUCCESS) {
+        s->in_len = s->wire == UG_PF_I420 ? (size_t) desc.width * desc.height + 2 * (size_t) ((desc.width + 1) / 2) * ((desc.height + 1) / 2)
+                                          : (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
+        if (ug_hip_jpeg_encoder_create_sub((int) desc.width, (int) desc.height, s->quality, s->restart, sub, &s->enc) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "encoder creation failed: %s\n", ug_hip_last_error_string());
                 return false;
         }
         s->max_out = ug_hip_jpeg_encoder_max_size(s->enc);
         bool ok = ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING) == UG_HIP_SUCCESS &&
                   ug_hip_malloc(&s->dev_out, s->max_out) == UG_HIP_SUCCESS;
-        if (ok && s->wire != UG_PF_UYVY) {
-                ok = ug_hip_malloc(&s->dev_uyvy, (size_t) vc_get_linesize(desc.width, UYVY) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
+        if (ok && s->wire != s->enc_in) { // staging buffer for the device-side conversion to the encoder's input format
+                ok = ug_hip_malloc(&s->dev_uyvy, (size_t) vc_get_linesize(desc.width, s->enc_in == UG_PF_RGB ? RGB : UYVY) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
         }
         if (!ok) {
                 MSG(ERROR, "Could not allocate device buffers: %s\n", ug_hip_last_error_string());
@@ -172,16 +195,16 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
                 MSG(ERROR, "H2D copy failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
-        const void *uyvy = s->dev_in;
-        if (s->wire != UG_PF_UYVY) {
-                if (ug_hip_pixfmt_convert(s->wire, UG_PF_UYVY, s->dev_in, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
-                        MSG(ERROR, "device conversion to UYVY failed: %s\n", ug_hip_last_error_string());
+        const void *enc_src = s->dev_in;
+        if (s->wire != s->enc_in) {
+                if (ug_hip_pixfmt_convert(s->wire, s->enc_in, s->dev_in, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
+                        MSG(ERROR, "device conversion to the encoder input format failed: %s\n", ug_hip_last_error_string());
                         return {};
                 }
-                uyvy = s->dev_uyvy;
+                enc_src = s->dev_uyvy;
         }
         size_t len = 0;
-        if (ug_hip_jpeg_encoder_encode(s->enc, UG_PF_UYVY, uyvy, 0, s->dev_out, s->max_out, &len, s->stream) != UG_HIP_SUCCESS) {
+        if (ug_hip_jpeg_encoder_encode(s->enc, s->enc_in, enc_src, 0, s->dev_out, s->max_out, &len, s->stream) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "Encoding failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
@@ -210,7 +233,7 @@ compress_module_info get_jpeg_mi355x_module_info()
         module_info.name = "jpeg";
         module_info.opts.emplace_back(module_option{ "Quality", "Quality 1-100", "75", "quality", ":q=", false });
         module_info.opts.emplace_back(module_option{ "Restart interval", "MCUs per restart interval", "2", "restart_interval", ":restart=", false });
-        module_info.opts.emplace_back(module_option{ "Subsampling", "JPEG subsampling (422 or 420)", "422", "subsampling", ":subsampling=", false });
+        module_info.opts.emplace_back(module_option{ "Subsampling", "JPEG subsampling (444, 422 or 420; default: that of the input)", "", "subsampling", ":subsampling=", false });
         codec codec_info;
         codec_info.name = "JPEG";
         codec_info.priority = 300;
