@@ -62,6 +62,8 @@ typedef enum {
 
 typedef enum {
         UG_DXT1       = 1, /* 8 B / 4x4 block, output size w*h/2 (dxt_util.h:59-67) */
+        UG_DXT1_YUV   = 2, /* DXT1 blocks holding Y,Cb,Cr (-c RTDXT:DXT1_YUV, types.h DXT1_YUV): encode takes UG_PF_UYVY only
+                            * (== UG_PF_UYVY_RAW -> UG_DXT1), decode applies display_dxt1_yuv_fp.glsl */
         UG_DXT5_YCOCG = 6, /* "DXT6": 16 B / block, output size w*h */
 } ug_dxt_t;
 

@@ -112,9 +112,58 @@ void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
         }
 }
 
+static inline uint8_t unorm8_out(float x);
+
+/* DXT1_YUV (-c RTDXT:DXT1_YUV): the DXT1 palette holds Y, Cb, Cr; the receiver renders it through
+ * dxt_compress/display_dxt1_yuv_fp.glsl:21-32 (fixed-function S3TC fetch, then the colour matrix).  The palette is the
+ * DXT1 one above (in double, rounded to fp32 where the sampler hands it to the shader), every shader operation is one fp32
+ * operation, the framebuffer write is floorf(clamp01(x) * 255 + 0.5).  GL leaves the S3TC interpolation precision and the
+ * unorm conversion to the implementation: parity unpinned, like the rest of the receiver side. */
+void oracle_dxt1yuv_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
+{
+        for (int by = 0; by < h / 4; by++) {
+                for (int bx = 0; bx < w / 4; bx++) {
+                        uint16_t c0, c1;
+                        uint32_t idx;
+                        memcpy(&c0, src, 2);
+                        memcpy(&c1, src + 2, 2);
+                        memcpy(&idx, src + 4, 4);
+                        src += 8;
+                        double p[4][3];
+                        p[0][0] = ((c0 >> 11) & 0x1F) / 31.0; p[0][1] = ((c0 >> 5) & 0x3F) / 63.0; p[0][2] = (c0 & 0x1F) / 31.0;
+                        p[1][0] = ((c1 >> 11) & 0x1F) / 31.0; p[1][1] = ((c1 >> 5) & 0x3F) / 63.0; p[1][2] = (c1 & 0x1F) / 31.0;
+                        for (int k = 0; k < 3; k++) {
+                                if (c0 > c1) {
+                                        p[2][k] = (2.0 * p[0][k] + p[1][k]) / 3.0;
+                                        p[3][k] = (p[0][k] + 2.0 * p[1][k]) / 3.0;
+                                } else {
+                                        p[2][k] = (p[0][k] + p[1][k]) / 2.0;
+                                        p[3][k] = 0.0;
+                                }
+                        }
+                        uint8_t pal[4][3];
+                        for (int k = 0; k < 4; k++) {
+                                const float col0 = (float) p[k][0], col1 = (float) p[k][1], col2 = (float) p[k][2];
+                                float t;
+                                t = col0 - 0.0625f; const float Y = 1.1643f * t;
+                                t = col1 - 0.5f;    const float U = 1.1384f * t;
+                                t = col2 - 0.5f;    const float V = 1.1384f * t;
+                                float G = 0.39173f * U; G = Y - G; t = 0.81290f * V; G = G - t;
+                                float B = 2.017f * U; B = Y + B;
+                                float R = 1.5958f * V; R = Y + R;
+                                pal[k][0] = unorm8_out(R); pal[k][1] = unorm8_out(G); pal[k][2] = unorm8_out(B);
+                        }
+                        for (int i = 0; i < 16; i++) {
+                                const int ci = (idx >> (2 * i)) & 3;
+                                memcpy(dst + 3 * ((long) (4 * by + i / 4) * w + 4 * bx + i % 4), pal[ci], 3);
+                        }
+                }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Generic frame decode used as the oracle of the decompress-side kernels.
- *   in_fmt : ORACLE_OUT_DXT1 / ORACLE_OUT_DXT5YCOCG (same ids as the encoder side)
+ *   in_fmt : ORACLE_OUT_DXT1 / ORACLE_OUT_DXT1_YUV / ORACLE_OUT_DXT5YCOCG (same ids as the encoder side)
  *   out_fmt: OPF_RGB, OPF_BGR, OPF_RGBA (alpha 0xFF, component shifts rs/gs/bs as decoder_t), OPF_UYVY
  * RGB values are the 8-bit results above (cuda_dxt/dxt62tga.c arithmetic).  UYVY follows the reference's
  * RGBA->4:2:2 pass (dxt_compress/rgba_to_yuv422.glsl:27-46) applied to those 8-bit texels, every shader
@@ -169,6 +218,8 @@ int oracle_dxt_decode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                 oracle_dxt5ycocg_decode_rgb(src, rgb, w, h);
         } else if (in_fmt == ORACLE_OUT_DXT1) {
                 oracle_dxt1_decode_rgb(src, rgb, w, h);
+        } else if (in_fmt == ORACLE_OUT_DXT1_YUV) {
+                oracle_dxt1yuv_decode_rgb(src, rgb, w, h);
         } else {
                 free(rgb);
                 return -1;

@@ -26,6 +26,7 @@ enum {
 };
 enum {
         ORACLE_OUT_DXT1      = 1,
+        ORACLE_OUT_DXT1_YUV  = 2, /* decode side only: DXT1 blocks holding Y,Cb,Cr (encode = ORACLE_IN_UYVY_RAW -> DXT1) */
         ORACLE_OUT_DXT5YCOCG = 6,
 };
 
@@ -42,6 +43,7 @@ void oracle_yuv422_to_yuv444(const uint8_t *src, uint8_t *dst, long pix_count);
 /* ---- DXT decode (dxt_decode_oracle.c) ---- */
 void oracle_dxt5ycocg_decode_rgb(const uint8_t *src, uint8_t *dst_rgb, int w, int h);
 void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst_rgb, int w, int h);
+void oracle_dxt1yuv_decode_rgb(const uint8_t *src, uint8_t *dst_rgb, int w, int h);
 /* in_fmt ORACLE_OUT_*; out_fmt OPF_RGB / OPF_BGR / OPF_RGBA / OPF_UYVY; 0 ok, -1 bad args */
 int  oracle_dxt_decode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long dst_pitch,
                        int rs, int gs, int bs);

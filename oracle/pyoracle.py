@@ -26,7 +26,7 @@ _REF_SCALAR_PATH = os.path.join(_HERE, "_ref", "libugref_scalar.so")
 
 # our format ids (oracle.h)
 IN_RGB, IN_RGBA, IN_YUV444, IN_UYVY, IN_UYVY_RAW, IN_V210 = range(6)
-OUT_DXT1, OUT_DXT5YCOCG = 1, 6
+OUT_DXT1, OUT_DXT1_YUV, OUT_DXT5YCOCG = 1, 2, 6
 OPF = dict(RGBA=1, UYVY=2, YUYV=3, RGB=4, BGR=5, v210=6, RG48=7, I420=8)
 # reference codec_t values (src/types.h:62-112)
 REF_CODEC = dict(RGBA=1, UYVY=2, YUYV=3, v210=7, DXT1=9, DXT5=11, RGB=12, BGR=20, RG48=27, I420=29)

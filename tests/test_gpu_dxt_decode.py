@@ -13,13 +13,16 @@ def _dec(hip, L, in_l, out_name, blocks, w, h, sh=(0, 8, 16)):
 
 
 @pytest.mark.parametrize("out", ["RGB", "BGR", "RGBA", "UYVY"])
-@pytest.mark.parametrize("fmt", ["dxt1", "dxt5ycocg"])
+@pytest.mark.parametrize("fmt", ["dxt1", "dxt1_yuv", "dxt5ycocg"])
 def test_decode_bit_exact(hip, po, fmt, out):
     from ultragrid_amd import lib as L
-    in_p, in_l = (po.OUT_DXT1, L.DXT1) if fmt == "dxt1" else (po.OUT_DXT5YCOCG, L.DXT5_YCOCG)
+    in_p, in_l = {"dxt1": (po.OUT_DXT1, L.DXT1), "dxt1_yuv": (po.OUT_DXT1_YUV, L.DXT1_YUV), "dxt5ycocg": (po.OUT_DXT5YCOCG, L.DXT5_YCOCG)}[fmt]
     rng = np.random.default_rng(17)
     for (w, h) in [(4, 4), (64, 16), (200, 64), (1920, 32)]:
-        cases = [po.dxt_encode(po.IN_RGB, in_p, synth.frame(k, "RGB", w, h), w, h) for k in ("S1", "S2", "S4")]
+        if fmt == "dxt1_yuv":
+            cases = [po.dxt_encode(po.IN_UYVY_RAW, po.OUT_DXT1, synth.frame(k, "UYVY", w, h), w, h) for k in ("S1", "S2", "S4")]
+        else:
+            cases = [po.dxt_encode(po.IN_RGB, in_p, synth.frame(k, "RGB", w, h), w, h) for k in ("S1", "S2", "S4")]
         cases.append(rng.integers(0, 256, cases[0].size, dtype=np.uint8))  # arbitrary bitstream: both alpha modes, 3-colour DXT1
         for blocks in cases:
             for sh in ([(0, 8, 16), (16, 8, 0)] if out == "RGBA" else [(0, 8, 16)]):
@@ -66,3 +69,29 @@ def test_decode_error_codes(hip):
     with pytest.raises(L.UgHipError) as e:
         hip.dxt_decode(L.DXT1, L.PF_V210, b, 48, 4)
     assert e.value.rc == L.EUNSUPP
+
+
+def test_dxt1_yuv_round_trip(hip, po):
+    """UYVY -> DXT1_YUV (ug_hip_dxt_encode with UG_DXT1_YUV == UYVY_RAW -> DXT1) -> RGB through the display matrix: close to
+    the BT.601-style conversion of the source the display shader implements (display_dxt1_yuv_fp.glsl:21-32)."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 512, 128
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 40.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 63.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0 + xx / 300.0)], -1).clip(0, 255).astype(np.uint8)
+    uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+    dev = torch.from_numpy(uyvy).cuda()
+    a = hip.dxt_encode(L.PF_UYVY, L.DXT1_YUV, dev, w, h)
+    b = hip.dxt_encode(L.PF_UYVY_RAW, L.DXT1, dev, w, h)
+    assert torch.equal(a, b) and a.numel() == w * h // 2
+    assert np.array_equal(a.cpu().numpy(), po.dxt_encode(po.IN_UYVY_RAW, po.OUT_DXT1, uyvy, w, h))
+    dec = hip.dxt_decode(L.DXT1_YUV, L.PF_RGB, a, w, h).cpu().numpy().reshape(h, w, 3).astype(float)
+    u = uyvy.reshape(h, w // 2, 4).astype(float) / 255.0
+    Y = 1.1643 * (np.stack([u[..., 1], u[..., 3]], -1).reshape(h, w) - 0.0625)
+    U = 1.1384 * (np.repeat(u[..., 0], 2, axis=1) - 0.5)
+    V = 1.1384 * (np.repeat(u[..., 2], 2, axis=1) - 0.5)
+    ref = np.stack([Y + 1.5958 * V, Y - 0.39173 * U - 0.81290 * V, Y + 2.017 * U], -1).clip(0, 1) * 255
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((dec - ref) ** 2))
+    assert psnr > 30, psnr
+    with pytest.raises(RuntimeError):
+        hip.dxt_encode(L.PF_RGB, L.DXT1_YUV, torch.zeros(64 * 64 * 3, dtype=torch.uint8, device="cuda"), 64, 64)

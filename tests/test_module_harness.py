@@ -60,6 +60,22 @@ def test_compress_frame_through_reference_framework(tmp_path, po, codec, cfg):
 
 @needs_harness
 @pytest.mark.gpu
+@pytest.mark.parametrize("codec", ["UYVY", "YUYV", "v210", "RGB"])
+def test_dxt1_yuv_through_reference_framework(tmp_path, po, codec):
+    """-c dxt:DXT1_YUV (the RTDXT option, dxt_glsl.cpp:104-110,233-234): DXT1 blocks over the Y,Cb,Cr samples of the UYVY form of the
+    frame (everything else is converted to UYVY with the pixfmt_conv.c arithmetic first); output codec DXT1_YUV."""
+    w, h = 192, 64
+    src = synth.s1_random(codec if codec != "YUYV" else "UYVY", w, h, salt=9)
+    raw, out = tmp_path / "in.raw", tmp_path / "out.bin"
+    src.tofile(raw)
+    r = _run(["dxt:DXT1_YUV", codec, w, h, raw, out])
+    assert r.returncode == 0 and "DXT1_YUV" in r.stdout, r.stdout + r.stderr
+    uyvy = src if codec == "UYVY" else po.convert_frame(codec, "UYVY", src, w, h)
+    assert np.array_equal(np.fromfile(out, np.uint8), po.dxt_encode(po.IN_UYVY_RAW, po.OUT_DXT1, uyvy, w, h))
+
+
+@needs_harness
+@pytest.mark.gpu
 def test_tiled_4k_fanout(tmp_path, po):
     """4 tiles ("tiled 4K", types.h:340-343): the framework fans tiles out to worker threads, one module state
     each (video_compress.cpp:441-490); every tile must match the oracle."""
@@ -99,11 +115,11 @@ def test_decompress_module_registers():
 @needs_dec_harness
 @pytest.mark.gpu
 @pytest.mark.parametrize("out", ["RGBA", "RGB", "UYVY"])
-@pytest.mark.parametrize("comp", ["DXT1", "DXT5"])
+@pytest.mark.parametrize("comp", ["DXT1", "DXT1_YUV", "DXT5"])
 def test_decompress_through_reference_framework(tmp_path, po, comp, out):
     w, h = 192, 64
-    oid = po.OUT_DXT1 if comp == "DXT1" else po.OUT_DXT5YCOCG
-    blocks = po.dxt_encode(po.IN_UYVY, oid, synth.s2_video("UYVY", w, h), w, h)
+    oid = {"DXT1": po.OUT_DXT1, "DXT1_YUV": po.OUT_DXT1_YUV, "DXT5": po.OUT_DXT5YCOCG}[comp]
+    blocks = po.dxt_encode(po.IN_UYVY_RAW if comp == "DXT1_YUV" else po.IN_UYVY, po.OUT_DXT1 if comp == "DXT1_YUV" else oid, synth.s2_video("UYVY", w, h), w, h)
     src, dst = tmp_path / "in.bin", tmp_path / "out.raw"
     blocks.tofile(src)
     r = subprocess.run([DEC_HARNESS, comp, out, str(w), str(h), str(src), str(dst)], capture_output=True, text=True, timeout=30)

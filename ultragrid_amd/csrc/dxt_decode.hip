@@ -1,4 +1,4 @@
-// dxt_decode.hip -- DXT1 / DXT5-YCoCg block decode to RGB / BGR / RGBA / UYVY on gfx950.
+// dxt_decode.hip -- DXT1 / DXT1_YUV / DXT5-YCoCg block decode to RGB / BGR / RGBA / UYVY on gfx950.
 //
 // Receiver-side counterpart of dxt_encode.hip.  The reference decodes with OpenGL
 // (src/video_decompress/dxt_glsl.c:142-189 -> dxt_compress/dxt_decoder.c: fixed-function S3TC fetch +
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
         }
 }
 
-template <int OUT>
+// YUV = true: DXT1_YUV -- the palette holds Y, Cb, Cr and goes through the display matrix of
+// dxt_compress/display_dxt1_yuv_fp.glsl:21-32 (fp32, one operation per shader operation) before the 8-bit write.
+template <int OUT, bool YUV>
 __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restrict__ src, OutArgs o, int bw, int bh)
 {
         const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
@@ -162,7 +164,14 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
         uint32_t pal[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-                pal[k] = clamp8(p[k][0] * 255.0) | clamp8(p[k][1] * 255.0) << 8 | clamp8(p[k][2] * 255.0) << 16;
+                if (YUV) {
+                        const float col0 = (float) p[k][0], col1 = (float) p[k][1], col2 = (float) p[k][2];
+                        const float Y = 1.1643f * (col0 - 0.0625f), U = 1.1384f * (col1 - 0.5f), V = 1.1384f * (col2 - 0.5f);
+                        const float G = (Y - 0.39173f * U) - 0.81290f * V, B = Y + 2.017f * U, R = Y + 1.5958f * V;
+                        pal[k] = (uint32_t) unorm8_out(R) | (uint32_t) unorm8_out(G) << 8 | (uint32_t) unorm8_out(B) << 16;
+                } else {
+                        pal[k] = clamp8(p[k][0] * 255.0) | clamp8(p[k][1] * 255.0) << 8 | clamp8(p[k][2] * 255.0) << 16;
+                }
         }
         uint32_t idx = q.y;
 #pragma unroll
@@ -186,8 +195,10 @@ int launch_decode(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, 
         const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
         if (in == UG_DXT5_YCOCG) {
                 hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT>), grid, block, 0, st, (const uint4 *) src, o, bw, bh);
+        } else if (in == UG_DXT1_YUV) {
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         } else {
-                hipLaunchKernelGGL((dxt1_decode_kernel<OUT>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, false>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
@@ -203,7 +214,7 @@ extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_d
                 ug::set_last_error_msg("ug_hip_dxt_decode: bad size or alignment");
                 return UG_HIP_EINVAL;
         }
-        if (in != UG_DXT1 && in != UG_DXT5_YCOCG) {
+        if (in != UG_DXT1 && in != UG_DXT1_YUV && in != UG_DXT5_YCOCG) {
                 ug::set_last_error_msg("ug_hip_dxt_decode: unknown compressed format");
                 return UG_HIP_EUNSUPP;
         }

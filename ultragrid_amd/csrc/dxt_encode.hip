@@ -665,7 +665,7 @@ size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height)
 {
         if (height < 0) height = -height;
         const size_t px = (size_t) width * (size_t) height; // dxt_util.h:59-67
-        return out == UG_DXT1 ? px / 2 : px;
+        return out == UG_DXT1 || out == UG_DXT1_YUV ? px / 2 : px;
 }
 
 int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
@@ -673,6 +673,14 @@ int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void 
                             ug_hip_stream_t stream)
 {
         const int ah = height < 0 ? -height : height;
+        if (out == UG_DXT1_YUV) { // DXT1 over the Y,Cb,Cr samples: UYVY is its only input (dxt_glsl.cpp:104-110)
+                if (in != UG_PF_UYVY && in != UG_PF_UYVY_RAW) {
+                        ug::set_last_error_msg("ug_hip_dxt_encode: DXT1_YUV takes UYVY input only");
+                        return UG_HIP_EUNSUPP;
+                }
+                in = UG_PF_UYVY_RAW;
+                out = UG_DXT1;
+        }
         if (!src || !dst || width <= 0 || ah == 0 || (width & 3) || (ah & 3) || frames < 0 ||
             (15 & (uintptr_t) src) || (15 & (uintptr_t) dst)) { // cuda_dxt.cu:745
                 ug::set_last_error_msg("ug_hip_dxt_encode: bad size or alignment");

@@ -18,7 +18,7 @@ PF_NONE, PF_RGBA, PF_UYVY, PF_YUYV, PF_RGB, PF_BGR, PF_V210, PF_RG48, PF_YUV444,
 PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "BGR": PF_BGR, "v210": PF_V210,
             "RG48": PF_RG48, "YUV444": PF_YUV444, "UYVY_RAW": PF_UYVY_RAW}
 # ug_dxt_t
-DXT1, DXT5_YCOCG = 1, 6
+DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 
 SUCCESS, EINVAL, EUNSUPP, ERUNTIME = 0, -1, -2, -3
 

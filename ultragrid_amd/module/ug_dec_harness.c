@@ -4,7 +4,7 @@
  * lib_common.cpp) drives our decompress module:
  *     decompress_init_multi(DXT5, {}, RGBA, &s, 1); decompress_reconfigure(s, desc, 0, 8, 16, pitch, RGBA);
  *     decompress_frame(s, dst, src, len, 0, NULL, NULL); decompress_done(s);
- * usage: ug_dec_harness <DXT1|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]
+ * usage: ug_dec_harness <DXT1|DXT1_YUV|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]
  *        ug_dec_harness list
  */
 #include <stdio.h>
@@ -23,7 +23,7 @@ int main(int argc, char **argv)
                 return 0;
         }
         if (argc < 7) {
-                fprintf(stderr, "usage: %s <DXT1|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]\n", argv[0]);
+                fprintf(stderr, "usage: %s <DXT1|DXT1_YUV|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]\n", argv[0]);
                 return 1;
         }
         const codec_t in = get_codec_from_name(argv[1]), out = get_codec_from_name(argv[2]);
@@ -31,7 +31,7 @@ int main(int argc, char **argv)
         const int linesize = vc_get_linesize(w, out);
         const int pitch = argc > 7 ? atoi(argv[7]) : linesize;
         struct video_desc desc = { .width = w, .height = h, .color_spec = in, .fps = 30, .interlacing = PROGRESSIVE, .tile_count = 1 };
-        const size_t in_len = (size_t) w * h / (in == DXT1 ? 2 : 1);
+        const size_t in_len = (size_t) w * h / (in == DXT1 || in == DXT1_YUV ? 2 : 1);
         unsigned char *src = malloc(in_len), *dst = calloc((size_t) pitch * h + 64, 1);
         FILE *f = fopen(argv[5], "rb");
         if (!f || fread(src, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read input\n"); return 1; }

@@ -1,6 +1,6 @@
 /**
  * @file vcompress_dxt_mi355x.cpp
- * UltraGrid video_compress module "dxt" (-c dxt[:DXT1|:DXT5][:dev=<n>[,<n>...]]) backed by the MI355X
+ * UltraGrid video_compress module "dxt" (-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<n>[,<n>...]]) backed by the MI355X
  * kernel library libug_mi355x.so (include/ug_mi355x.h).
  *
  * This is the host-side half of the drop-in boundary.  It is compiled
@@ -74,7 +74,8 @@ struct state_video_compress_dxt_mi355x {
         codec_t           out_codec = DXT1;
         ug_dxt_t          out_fmt = UG_DXT1;
         ug_pixfmt_t       in_fmt = UG_PF_NONE;      ///< format the encoder kernel reads
-        ug_pixfmt_t       pre_in = UG_PF_NONE;      ///< != NONE: device-side swizzle first (YUYV->UYVY, BGR->RGB)
+        ug_pixfmt_t       pre_in = UG_PF_NONE;      ///< != NONE: device-side conversion first (YUYV->UYVY, BGR->RGB, DXT1_YUV: anything->UYVY)
+        ug_pixfmt_t       pre_out = UG_PF_NONE;     ///< its target format
         ug_hip_stream_t   stream = nullptr;
         void             *dev_in = nullptr;         ///< uploaded frame, wire format
         void             *dev_pre = nullptr;        ///< swizzle result (only if pre_in != NONE)
@@ -96,8 +97,8 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT5][:dev=<index>[,<index>...]]\n"
-               "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg\n"
+               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]]\n"
+               "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
                "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n");
 }
 
@@ -115,6 +116,9 @@ void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
                         s->out_fmt = UG_DXT5_YCOCG;
                 } else if (strcasecmp(tok.c_str(), "DXT1") == 0) {
                         s->out_codec = DXT1;
+                        s->out_fmt = UG_DXT1;
+                } else if (strcasecmp(tok.c_str(), "DXT1_YUV") == 0) { // dxt_glsl.cpp:233-234
+                        s->out_codec = DXT1_YUV;
                         s->out_fmt = UG_DXT1;
                 } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
                         std::vector<int> devs;
@@ -153,18 +157,33 @@ void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
 bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
 {
         cleanup(s);
-        s->pre_in = UG_PF_NONE;
+        s->pre_in = s->pre_out = UG_PF_NONE;
         const ug_pixfmt_t wire = ug_pixfmt_from_codec(desc.color_spec);
-        switch (wire) {
-        case UG_PF_RGB: case UG_PF_RGBA: case UG_PF_UYVY: case UG_PF_V210:
-                s->in_fmt = wire;
-                break;
-        case UG_PF_YUYV: s->pre_in = wire; s->in_fmt = UG_PF_UYVY; break;
-        case UG_PF_BGR:  s->pre_in = wire; s->in_fmt = UG_PF_RGB;  break;
-        default:
-                MSG(ERROR, "Unsupported codec: %s (GPU path takes RGB, RGBA, BGR, UYVY, YUYV, v210)\n",
-                    get_codec_name(desc.color_spec));
-                return false;
+        if (s->out_codec == DXT1_YUV) {
+                // The DXT1 encoder runs on the 4:2:2 samples themselves (chroma replicated, no colour conversion:
+                // dxt_encoder.c:318-323); its only input is UYVY (dxt_glsl.cpp:104-110), everything else is converted to UYVY
+                // first -- here with the same pixfmt_conv.c arithmetic, on the device.
+                s->in_fmt = UG_PF_UYVY_RAW;
+                if (wire != UG_PF_UYVY) {
+                        if (wire == UG_PF_NONE || !ug_hip_pixfmt_supported(wire, UG_PF_UYVY)) {
+                                MSG(ERROR, "Unsupported codec for DXT1_YUV: %s\n", get_codec_name(desc.color_spec));
+                                return false;
+                        }
+                        s->pre_in = wire;
+                        s->pre_out = UG_PF_UYVY;
+                }
+        } else {
+                switch (wire) {
+                case UG_PF_RGB: case UG_PF_RGBA: case UG_PF_UYVY: case UG_PF_V210:
+                        s->in_fmt = wire;
+                        break;
+                case UG_PF_YUYV: s->pre_in = wire; s->pre_out = s->in_fmt = UG_PF_UYVY; break;
+                case UG_PF_BGR:  s->pre_in = wire; s->pre_out = s->in_fmt = UG_PF_RGB;  break;
+                default:
+                        MSG(ERROR, "Unsupported codec: %s (GPU path takes RGB, RGBA, BGR, UYVY, YUYV, v210)\n",
+                            get_codec_name(desc.color_spec));
+                        return false;
+                }
         }
         if (desc.width % 4 != 0 || desc.height % 4 != 0 || (s->in_fmt == UG_PF_V210 && desc.width % 12 != 0)) {
                 MSG(ERROR, "Frame size %ux%u is not a multiple of the 4x4 block (v210: 12x4)\n", desc.width, desc.height);
@@ -177,7 +196,8 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
         s->out_len = ug_hip_dxt_size(s->out_fmt, (int) desc.width, (int) desc.height);
         CHECK_HIP(ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING), "Could not allocate device input buffer", return false);
         if (s->pre_in != UG_PF_NONE) {
-                CHECK_HIP(ug_hip_malloc(&s->dev_pre, s->in_len + MAX_PADDING), "Could not allocate device swizzle buffer", return false);
+                const size_t pre_len = (size_t) vc_get_linesize(desc.width, ug_codec_from_pixfmt(s->pre_out)) * desc.height;
+                CHECK_HIP(ug_hip_malloc(&s->dev_pre, pre_len + MAX_PADDING), "Could not allocate device conversion buffer", return false);
         }
         CHECK_HIP(ug_hip_malloc(&s->dev_out, s->out_len), "Could not allocate device output buffer", return false);
 
@@ -211,7 +231,7 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
                   "H2D copy failed", return {});
         const void *enc_src = s->dev_in;
         if (s->pre_in != UG_PF_NONE) {
-                CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->in_fmt, s->dev_in, s->dev_pre, w, h, 0, 0, 0, 8, 16, s->stream),
+                CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, s->dev_in, s->dev_pre, w, h, 0, 0, 0, 8, 16, s->stream),
                           "device swizzle failed", return {});
                 enc_src = s->dev_pre;
         }
@@ -241,7 +261,7 @@ compress_module_info get_dxt_mi355x_module_info()
 {
         compress_module_info module_info;
         module_info.name = "dxt";
-        for (const char *c : { "DXT1", "DXT5" }) {
+        for (const char *c : { "DXT1", "DXT1_YUV", "DXT5" }) {
                 codec codec_info;
                 codec_info.name = c;
                 codec_info.priority = 400;

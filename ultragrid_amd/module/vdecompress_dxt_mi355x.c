@@ -1,12 +1,12 @@
 /**
  * @file vdecompress_dxt_mi355x.c
- * UltraGrid video_decompress module "dxt_mi355x": DXT1 / DXT5-YCoCg -> RGBA / RGB / UYVY on an MI355X through
+ * UltraGrid video_decompress module "dxt_mi355x": DXT1 / DXT1_YUV / DXT5-YCoCg -> RGBA / RGB / UYVY on an MI355X through
  * libug_mi355x.so (include/ug_mi355x.h: ug_hip_dxt_decode).  Receiver-side counterpart of
  * vcompress_dxt_mi355x.cpp; plain C like the reference's decompress modules (video_decompress.h:74-171), same
  * callback set and conventions as src/video_decompress/dxt_glsl.c:69-249 (init / reconfigure with shifts+pitch /
  * decompress / get_property / done / priority 500 for DXT1 + DXT5 to RGBA or UYVY).
  *
- * DXT1_YUV is not taken (our encoder side does not emit it; dxt_glsl keeps handling it).
+ * DXT1_YUV (dxt_glsl.c:83-84) goes through the display matrix of display_dxt1_yuv_fp.glsl on the device.
  */
 #include <stdbool.h>
 #include <stdio.h>
@@ -63,6 +63,8 @@ static int dxt_mi355x_decompress_reconfigure(void *state, struct video_desc desc
                 s->in_fmt = UG_DXT5_YCOCG;
         } else if (desc.color_spec == DXT1) {
                 s->in_fmt = UG_DXT1;
+        } else if (desc.color_spec == DXT1_YUV) {
+                s->in_fmt = UG_DXT1_YUV;
         } else {
                 MSG(ERROR, "Wrong compression to decompress: %s\n", get_codec_name(desc.color_spec));
                 return false;
@@ -157,7 +159,7 @@ static void dxt_mi355x_decompress_done(void *state)
 static int dxt_mi355x_decompress_get_priority(codec_t compression, struct pixfmt_desc internal, codec_t ugc)
 {
         (void) internal;
-        if (compression != DXT1 && compression != DXT5) {
+        if (compression != DXT1 && compression != DXT1_YUV && compression != DXT5) { /* dxt_glsl.c:230 */
                 return -1;
         }
         if (ugc != RGBA && ugc != RGB && ugc != UYVY) {
