@@ -148,7 +148,22 @@ int ug_hip_linesize(ug_pixfmt_t fmt, int width);
 int ug_hip_uyvy_to_i420(const void *src_dev, int src_pitch, void *y, int y_pitch, void *u, int u_pitch,
                         void *v, int v_pitch, int width, int height, ug_hip_stream_t stream); /* uyvy_to_i420, to_planar.c:343 */
 int ug_hip_v210_to_p010le(const void *src_dev, int src_pitch, void *y, int y_pitch, void *uv, int uv_pitch,
-                          int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
+                          int width, int height, ug_hip_stream_t stream);
+
+/* Decode-direction shuffles (from_planar.h:58-77 `struct from_planar_data` flattened to scalars; pitch 0 = tightly packed):
+ *   ug_hip_yuv420p_to_uyvy      yuv420p_to_uyvy (from_planar.c:583-683) == i420_8_to_uyvy (video_codec.c:1073-1094) for packed planes
+ *   ug_hip_yuv422p_to_uyvy      yuv422p_to_uyvy (from_planar.c:391-423)
+ *   ug_hip_yuv422p10le_to_v210  yuv422p10le_to_v210 (from_planar.c:296-333): 16-bit little-endian samples holding 10 bits;
+ *                               width / 6 groups per line are written, as in the reference
+ *   ug_hip_uyvy_to_i422         uyvy_to_i422 (video_codec.c:949-969), planes passed separately */
+int ug_hip_yuv420p_to_uyvy(const void *y_dev, int y_pitch, const void *cb_dev, int cb_pitch, const void *cr_dev, int cr_pitch,
+                           void *dst_dev, int dst_pitch, int width, int height, ug_hip_stream_t stream);
+int ug_hip_yuv422p_to_uyvy(const void *y_dev, int y_pitch, const void *cb_dev, int cb_pitch, const void *cr_dev, int cr_pitch,
+                           void *dst_dev, int dst_pitch, int width, int height, ug_hip_stream_t stream);
+int ug_hip_yuv422p10le_to_v210(const void *y_dev, int y_pitch, const void *cb_dev, int cb_pitch, const void *cr_dev, int cr_pitch,
+                               void *dst_dev, int dst_pitch, int width, int height, ug_hip_stream_t stream);
+int ug_hip_uyvy_to_i422(const void *src_dev, int src_pitch, void *y_dev, int y_pitch, void *cb_dev, int cb_pitch, void *cr_dev,
+                        int cr_pitch, int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
 
 /* ------------------------------------------------------------------------------------
  * JPEG: 8x8 forward DCT + quantisation (the stage libgpujpeg provides behind

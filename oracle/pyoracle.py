@@ -267,6 +267,69 @@ def uyvy_to_i422(src: np.ndarray, w: int, h: int, use_ref: bool = False):
     return (np.ascontiguousarray(rows[:, 1::2][:, :w]), np.ascontiguousarray(rows[:, 0::4]), np.ascontiguousarray(rows[:, 2::4]))
 
 
+class _FromPlanar(C.Structure):
+    """struct from_planar_data (from_planar.h:58-70), passed by value"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("out_data", C.c_void_p), ("out_pitch", C.c_uint),
+                ("in_data", C.c_void_p * 4), ("in_linesize", C.c_uint * 4), ("in_depth", C.c_int), ("log2_chroma_h", C.c_int),
+                ("rgb_shift", C.c_int * 3)]
+
+
+def _ref_from_planar(name: str, planes, w: int, h: int, out: np.ndarray, out_pitch: int, depth: int = 8, scalar: bool = False):
+    d = _FromPlanar()
+    d.width, d.height = w, h
+    d.out_data, d.out_pitch = out.ctypes.data, out_pitch
+    for i, pl in enumerate(planes):
+        d.in_data[i] = pl.ctypes.data
+        d.in_linesize[i] = pl.strides[0]
+    d.in_depth = depth
+    fn = getattr(ref(scalar), name)
+    fn.restype = None
+    fn.argtypes = [_FromPlanar]
+    fn(d)
+
+
+def planar_to_uyvy(y: np.ndarray, u: np.ndarray, v: np.ndarray, w: int, h: int, chroma: int = 420, use_ref: bool = False) -> np.ndarray:
+    """yuv420p_to_uyvy (from_planar.c:583-683) / yuv422p_to_uyvy (:391-423).  8-bit planes, chroma planes (w+1)/2 wide."""
+    ls = linesize(w, "UYVY")
+    y, u, v = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v))
+    if use_ref:
+        out = np.zeros(ls * h + MAX_PADDING, np.uint8)
+        # the SSE3 loop of yuv420p_to_uyvy runs `x < width - 15` on an unsigned width: widths below 15 wrap around and crash the
+        # -msse4.1 build, so those go to the build without it (same scalar statements)
+        _ref_from_planar("yuv420p_to_uyvy" if chroma == 420 else "yuv422p_to_uyvy", (y, u, v), w, h, out, ls, scalar=w < 16)
+        return out[: ls * h]
+    out = np.zeros((h, ls), np.uint8)
+    rows = np.arange(h)
+    crow = rows // 2 if chroma == 420 else rows
+    npair = (w + 1) // 2 if chroma == 420 else w // 2
+    out[:, 0:4 * npair:4] = u[crow, :npair]
+    out[:, 2:4 * npair:4] = v[crow, :npair]
+    out[:, 1:4 * (w // 2):4] = y[:, 0:2 * (w // 2):2]
+    out[:, 3:4 * (w // 2):4] = y[:, 1:2 * (w // 2):2]
+    if chroma == 420 and w % 2:          # odd width: Cb Y Cr 0 (from_planar.c:669-680)
+        out[:, 4 * (w // 2) + 1] = y[:, w - 1]
+    return out.ravel()
+
+
+def yuv422p10le_to_v210(y: np.ndarray, u: np.ndarray, v: np.ndarray, w: int, h: int, use_ref: bool = False) -> np.ndarray:
+    """yuv422p10le_to_v210 (from_planar.c:296-333): width / 6 groups per line, samples OR-ed in unmasked."""
+    ls = linesize(w, "v210")
+    y, u, v = (np.ascontiguousarray(a, dtype=np.uint16) for a in (y, u, v))
+    if use_ref:
+        out = np.zeros(ls * h + MAX_PADDING, np.uint8)
+        _ref_from_planar("yuv422p10le_to_v210", (y, u, v), w, h, out, ls, depth=10)
+        return out[: ls * h]
+    g = w // 6
+    out = np.zeros((h, ls // 4), np.uint32)
+    Y = y[:, : 6 * g].astype(np.uint32).reshape(h, g, 6)
+    U = u[:, : 3 * g].astype(np.uint32).reshape(h, g, 3)
+    V = v[:, : 3 * g].astype(np.uint32).reshape(h, g, 3)
+    words = np.stack([U[..., 0] | Y[..., 0] << 10 | V[..., 0] << 20, Y[..., 1] | U[..., 1] << 10 | Y[..., 2] << 20,
+                      V[..., 1] | Y[..., 3] << 10 | U[..., 2] << 20, Y[..., 4] | V[..., 2] << 10 | Y[..., 5] << 20], -1)
+    out[:, : 4 * g] = words.reshape(h, 4 * g)
+    return out.view(np.uint8).ravel()
+
+
 def v210_to_p010le(src: np.ndarray, w: int, h: int, use_ref: bool = False):
     src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
     y = np.zeros((h, w), np.uint16)

@@ -1,0 +1,99 @@
+"""Decode-direction planar <-> packed shuffles: restatement vs compiled reference on the CPU, HIP kernels vs
+the oracle on the GPU."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+common = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+def _planes(rng, w, h, chroma, dtype=np.uint8, hi=256):
+    cw = (w + 1) // 2
+    ch = (h + 1) // 2 if chroma == 420 else h
+    return (rng.integers(0, hi, (h, w)).astype(dtype), rng.integers(0, hi, (ch, cw)).astype(dtype), rng.integers(0, hi, (ch, cw)).astype(dtype))
+
+
+@settings(max_examples=60, **common)
+@given(w=st.integers(1, 140), h=st.integers(1, 21), chroma=st.sampled_from([420, 422]), seed=st.integers(0, 2 ** 16))
+def test_planar_to_uyvy_restatement_vs_reference(po, w, h, chroma, seed):
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    y, u, v = _planes(np.random.default_rng(seed), w, h, chroma)
+    assert np.array_equal(po.planar_to_uyvy(y, u, v, w, h, chroma), po.planar_to_uyvy(y, u, v, w, h, chroma, use_ref=True)), (w, h, chroma)
+
+
+@settings(max_examples=40, **common)
+@given(w=st.integers(1, 140), h=st.integers(1, 12), seed=st.integers(0, 2 ** 16))
+def test_yuv422p10le_to_v210_restatement_vs_reference(po, w, h, seed):
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    y, u, v = _planes(np.random.default_rng(seed), w, h, 422, np.uint16, 1024)
+    assert np.array_equal(po.yuv422p10le_to_v210(y, u, v, w, h), po.yuv422p10le_to_v210(y, u, v, w, h, use_ref=True)), (w, h)
+
+
+def test_i420_8_to_uyvy_is_the_same_shuffle(po):
+    """video_codec.c:1073-1094 for tightly packed planes == yuv420p_to_uyvy (even sizes)."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import ctypes as C
+    w, h = 64, 18
+    y, u, v = _planes(np.random.default_rng(1), w, h, 420)
+    packed = np.concatenate([y.ravel(), u.ravel(), v.ravel()])
+    out = np.zeros(2 * w * h, np.uint8)
+    fn = po.ref().i420_8_to_uyvy
+    fn.restype, fn.argtypes = None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn(w, h, packed.ctypes.data, out.ctypes.data)
+    assert np.array_equal(out, po.planar_to_uyvy(y, u, v, w, h, 420))
+
+
+@pytest.mark.gpu
+@settings(max_examples=60, **common)
+@given(w=st.integers(1, 300), h=st.integers(1, 40), chroma=st.sampled_from([420, 422]), seed=st.integers(0, 2 ** 16))
+def test_gpu_planar_to_uyvy(hip, po, w, h, chroma, seed):
+    import torch
+    y, u, v = _planes(np.random.default_rng(seed), w, h, chroma)
+    got = hip.planar_to_uyvy(torch.from_numpy(y).cuda(), torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda(), w, h, chroma).cpu().numpy()
+    assert np.array_equal(got, po.planar_to_uyvy(y, u, v, w, h, chroma)), (w, h, chroma)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(1920, 1080), (3840, 2160), (1928, 1081)], ids=str)
+def test_gpu_planar_full_size_round_trips(hip, po, dims):
+    """Full frames: UYVY -> I422 planes -> UYVY is the identity; UYVY -> I420 (reference averaging) -> UYVY equals the oracle chain;
+    10-bit planes -> v210 -> UYVY (>>2) equals the 8-bit shuffle of the planes >> 2."""
+    import torch
+    from ultragrid_amd import lib as L, synth
+    w, h = dims
+    src = synth.s1_random("UYVY", w, h, salt=3)
+    dev = torch.from_numpy(src).cuda()
+    y, u, v = hip.uyvy_to_i422(dev, w, h)
+    for g, wnt in zip((y, u, v), po.uyvy_to_i422(src, w, h)):
+        assert np.array_equal(g.cpu().numpy(), wnt)
+    assert torch.equal(hip.planar_to_uyvy(y, u, v, w, h, 422), dev)
+    y0, u0, v0 = hip.uyvy_to_i420(dev, w, h)
+    want = po.planar_to_uyvy(*po.uyvy_to_i420(src, w, h), w, h, 420)
+    assert np.array_equal(hip.planar_to_uyvy(y0, u0, v0, w, h, 420).cpu().numpy(), want)
+    if w % 6 == 0:
+        rng = np.random.default_rng(5)
+        y10, u10, v10 = _planes(rng, w, h, 422, np.uint16, 1024)
+        t = [torch.from_numpy(a.astype(np.int16)).cuda() for a in (y10, u10, v10)]
+        v210 = hip.yuv422p10le_to_v210(*t, w, h)
+        assert np.array_equal(v210.cpu().numpy(), po.yuv422p10le_to_v210(y10, u10, v10, w, h))
+        back = hip.pixfmt_convert(L.PF_V210, L.PF_UYVY, torch.cat([v210, torch.zeros(64, dtype=torch.uint8, device="cuda")]), w, h).cpu().numpy()
+        assert np.array_equal(back, po.planar_to_uyvy((y10 >> 2).astype(np.uint8), (u10 >> 2).astype(np.uint8), (v10 >> 2).astype(np.uint8), w, h, 422))
+
+
+@pytest.mark.gpu
+@settings(max_examples=40, **common)
+@given(w=st.integers(1, 300), h=st.integers(1, 20), seed=st.integers(0, 2 ** 16))
+def test_gpu_yuv422p10le_to_v210_and_i422(hip, po, w, h, seed):
+    import torch
+    from ultragrid_amd import synth
+    rng = np.random.default_rng(seed)
+    y, u, v = _planes(rng, w, h, 422, np.uint16, 1024)
+    t = [torch.from_numpy(a.astype(np.int16)).cuda() for a in (y, u, v)]
+    assert np.array_equal(hip.yuv422p10le_to_v210(*t, w, h).cpu().numpy(), po.yuv422p10le_to_v210(y, u, v, w, h)), (w, h)
+    src = synth.s1_random("UYVY", w, h, salt=seed)
+    got = hip.uyvy_to_i422(torch.from_numpy(src).cuda(), w, h)
+    for g, wnt in zip(got, po.uyvy_to_i422(src, w, h)):
+        assert np.array_equal(g.cpu().numpy(), wnt), (w, h)

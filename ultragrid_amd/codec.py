@@ -113,6 +113,35 @@ def v210_to_p010le(src: torch.Tensor, w: int, h: int):
     return y, uv
 
 
+def planar_to_uyvy(y: torch.Tensor, cb: torch.Tensor, cr: torch.Tensor, w: int, h: int, chroma: int = 420) -> torch.Tensor:
+    """yuv420p_to_uyvy / yuv422p_to_uyvy (from_planar.c:583-683, 391-423): 2-D uint8 plane tensors -> packed UYVY."""
+    out = torch.zeros(linesize(L.PF_UYVY, w) * h, dtype=torch.uint8, device=y.device)
+    fn = L.load().ug_hip_yuv420p_to_uyvy if chroma == 420 else L.load().ug_hip_yuv422p_to_uyvy
+    rc = fn(y.data_ptr(), y.stride(0), cb.data_ptr(), cb.stride(0), cr.data_ptr(), cr.stride(0), out.data_ptr(), 0, w, h, _stream())
+    L.check(rc, "ug_hip_yuv42xp_to_uyvy")
+    return out
+
+
+def yuv422p10le_to_v210(y: torch.Tensor, cb: torch.Tensor, cr: torch.Tensor, w: int, h: int) -> torch.Tensor:
+    """from_planar.c:296-333: int16/uint16 plane tensors (10-bit samples) -> v210."""
+    out = torch.zeros(linesize(L.PF_V210, w) * h, dtype=torch.uint8, device=y.device)
+    rc = L.load().ug_hip_yuv422p10le_to_v210(y.data_ptr(), 2 * y.stride(0), cb.data_ptr(), 2 * cb.stride(0), cr.data_ptr(), 2 * cr.stride(0),
+                                             out.data_ptr(), 0, w, h, _stream())
+    L.check(rc, "ug_hip_yuv422p10le_to_v210")
+    return out
+
+
+def uyvy_to_i422(src: torch.Tensor, w: int, h: int):
+    src = _u8(src)
+    cw = (w + 1) // 2
+    y = torch.zeros((h, w), dtype=torch.uint8, device=src.device)
+    u = torch.zeros((h, cw), dtype=torch.uint8, device=src.device)
+    v = torch.zeros((h, cw), dtype=torch.uint8, device=src.device)
+    rc = L.load().ug_hip_uyvy_to_i422(src.data_ptr(), 0, y.data_ptr(), w, u.data_ptr(), cw, v.data_ptr(), cw, w, h, _stream())
+    L.check(rc, "ug_hip_uyvy_to_i422")
+    return y, u, v
+
+
 def jpeg_divisors_device(quality: int, device) -> torch.Tensor:
     """128 fp32 divisors (luma, chroma) in device memory."""
     import ctypes as C

@@ -54,6 +54,10 @@ SYMBOLS = {
     "ug_hip_linesize": (_i, [_i, _i]),
     "ug_hip_uyvy_to_i420": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_v210_to_p010le": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_yuv420p_to_uyvy": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_yuv422p_to_uyvy": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_yuv422p10le_to_v210": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_uyvy_to_i422": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_jpeg_qtable": (None, [_i, _i, _vp]),
     "ug_hip_jpeg_divisors": (None, [_vp, _vp]),
     "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
