@@ -72,6 +72,9 @@ typedef enum {
  * ---------------------------------------------------------------------------------- */
 int         ug_hip_abi_version(void);
 int         ug_hip_device_count(int *count);
+/* 1 if ptr is device memory of this process (a device-resident video_frame, types.h:295-298 mem_location; the reference's
+ * GPUJPEG module takes such frames without the upload, gpujpeg.cpp:617-622), 0 for host / unknown pointers. Never fails. */
+int         ug_hip_pointer_is_device(const void *ptr);
 int         ug_hip_set_device(int index);                              /* cuda_wrapper_set_device */
 int         ug_hip_malloc(void **buffer, size_t size);                 /* cuda_wrapper_malloc */
 int         ug_hip_free(void *buffer);                                 /* cuda_wrapper_free */

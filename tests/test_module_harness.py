@@ -76,6 +76,30 @@ def test_dxt1_yuv_through_reference_framework(tmp_path, po, codec):
 
 @needs_harness
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,codec", [("dxt:DXT5", "UYVY"), ("dxt:DXT5", "YUYV"), ("dxt:DXT1", "RGB"), ("jpeg:q=80:restart=4", "UYVY"), ("jpeg:q=80:restart=4", "v210")])
+def test_device_resident_frames(tmp_path, po, cfg, codec):
+    """a frame whose tile data already lives in device memory (types.h:295-298 mem_location; the harness also poisons its
+    host copy) is encoded in place, without the upload -- same bytes as the host-frame path."""
+    w, h, tiles = 192, 64, 2
+    frames = [synth.s1_random(codec if codec != "YUYV" else "UYVY", w, h, salt=20 + t) for t in range(tiles)]
+    raw = tmp_path / "in.raw"
+    np.concatenate(frames).tofile(raw)
+    outs = []
+    for mode in ([], ["dev"]):
+        out = tmp_path / f"out{len(mode)}.bin"
+        r = _run([cfg, codec, w, h, raw, out, tiles] + mode)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 0
+    if cfg.startswith("dxt"):
+        oid = po.OUT_DXT5YCOCG if cfg.endswith("DXT5") else po.OUT_DXT1
+        pin = {"UYVY": po.IN_UYVY, "YUYV": po.IN_UYVY, "RGB": po.IN_RGB}[codec]
+        want = [po.dxt_encode(pin, oid, po.convert_frame("YUYV", "UYVY", f, w, h) if codec == "YUYV" else f, w, h) for f in frames]
+        assert outs[1] == b"".join(x.tobytes() for x in want)
+
+
+@needs_harness
+@pytest.mark.gpu
 def test_tiled_4k_fanout(tmp_path, po):
     """4 tiles ("tiled 4K", types.h:340-343): the framework fans tiles out to worker threads, one module state
     each (video_compress.cpp:441-490); every tile must match the oracle."""

@@ -30,6 +30,16 @@ int ug_hip_device_count(int *count)
         return UG_HIP_SUCCESS;
 }
 
+int ug_hip_pointer_is_device(const void *ptr)
+{
+        hipPointerAttribute_t a;
+        if (!ptr || hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+                (void) hipGetLastError(); // plain malloc memory is "invalid value" to the runtime: not an error here
+                return 0;
+        }
+        return a.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
 int ug_hip_set_device(int index)
 {
         UG_HIP_TRY(hipSetDevice(index));

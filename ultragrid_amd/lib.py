@@ -28,6 +28,7 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
     "ug_hip_abi_version": (_i, []),
     "ug_hip_device_count": (_i, [C.POINTER(_i)]),
+    "ug_hip_pointer_is_device": (_i, [_vp]),
     "ug_hip_set_device": (_i, [_i]),
     "ug_hip_malloc": (_i, [C.POINTER(_vp), _sz]),
     "ug_hip_free": (_i, [_vp]),

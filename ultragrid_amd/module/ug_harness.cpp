@@ -7,7 +7,8 @@
  *
  *     compress_init(nullptr, "dxt:DXT5", &c); compress_frame(c, frame); compress_pop(c); compress_done(c);
  *
- * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles]
+ * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles] [dev]
+ *        dev: hand the frame over device-resident (tile data = device pointers, mem_location = CUDA_MEM)
  *        ug_harness list
  * The compressed tile(s) are written to <out.bin> (tile after tile); a test compares them with the
  * CPU oracle.  Exit code 0 = OK, 2 = module refused (no GPU / bad cfg), 3 = frame dropped.
@@ -24,6 +25,7 @@
 #include "lib_common.h"
 #include "types.h"
 #include "video_codec.h"
+#include "../../include/ug_mi355x.h"
 #include "video_compress.h"
 #include "video_frame.h"
 
@@ -58,6 +60,26 @@ int main(int argc, char **argv)
                 }
         }
         fclose(in);
+        const bool devmem = argc > 8 && strcmp(argv[8], "dev") == 0;
+        std::vector<void *> dev_bufs;
+        if (devmem) { // device-resident video_frame (types.h:295-298): the module must not upload it again
+                struct video_frame *fd = vf_alloc_desc(desc);
+                for (unsigned t = 0; t < tiles; t++) {
+                        void *p = nullptr;
+                        if (ug_hip_malloc(&p, f->tiles[t].data_len + 64) != UG_HIP_SUCCESS ||
+                            ug_hip_memcpy(p, f->tiles[t].data, f->tiles[t].data_len, UG_HIP_MEMCPY_HOST_TO_DEVICE) != UG_HIP_SUCCESS) {
+                                fprintf(stderr, "device staging failed: %s\n", ug_hip_last_error_string());
+                                return 1;
+                        }
+                        dev_bufs.push_back(p);
+                        fd->tiles[t].data = (char *) p;
+                        fd->tiles[t].data_len = f->tiles[t].data_len;
+                        memset(f->tiles[t].data, 0xA5, f->tiles[t].data_len); // the host copy must not be what gets encoded
+                }
+                fd->mem_location = CUDA_MEM;
+                vf_free(f);
+                f = fd;
+        }
 
         struct compress_state *c = nullptr;
         int rc = compress_init(nullptr, cfg, &c);
@@ -95,5 +117,6 @@ int main(int argc, char **argv)
         out.reset();
         popped.clear();
         compress_done(c);
+        for (void *p : dev_bufs) ug_hip_free(p);
         return 0;
 }

@@ -227,11 +227,19 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
         }
         const int w = (int) tx->tiles[0].width, h = (int) tx->tiles[0].height;
 
-        CHECK_HIP(ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
-                  "H2D copy failed", return {});
+        // Device-resident frame (mem_location == CUDA_MEM, types.h:295-298; the tile fan-out of video_compress.cpp drops that flag,
+        // so the pointer itself is asked as well): no upload -- the kernels read it in place (gpujpeg.cpp:617-622 does the same).
         const void *enc_src = s->dev_in;
+        if ((tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data)) && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
+                enc_src = tx->tiles[0].data;
+        } else {
+                const bool dev = tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data);
+                CHECK_HIP(ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
+                          "upload failed", return {});
+        }
+        const void *const wire_src = enc_src;
         if (s->pre_in != UG_PF_NONE) {
-                CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, s->dev_in, s->dev_pre, w, h, 0, 0, 0, 8, 16, s->stream),
+                CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, wire_src, s->dev_pre, w, h, 0, 0, 0, 8, 16, s->stream),
                           "device swizzle failed", return {});
                 enc_src = s->dev_pre;
         }

@@ -191,13 +191,18 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
                 }
         }
         const int w = (int) tx->tiles[0].width, h = (int) tx->tiles[0].height;
-        if (ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream) != UG_HIP_SUCCESS) {
-                MSG(ERROR, "H2D copy failed: %s\n", ug_hip_last_error_string());
+        // device-resident frame (types.h:295-298; gpujpeg.cpp:617-622): used in place, no upload
+        const bool on_dev = tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data);
+        const void *enc_src = s->dev_in;
+        if (on_dev && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
+                enc_src = tx->tiles[0].data;
+        } else if (ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, on_dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE,
+                                       s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "upload failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
-        const void *enc_src = s->dev_in;
         if (s->wire != s->enc_in) {
-                if (ug_hip_pixfmt_convert(s->wire, s->enc_in, s->dev_in, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
+                if (ug_hip_pixfmt_convert(s->wire, s->enc_in, enc_src, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
                         MSG(ERROR, "device conversion to the encoder input format failed: %s\n", ug_hip_last_error_string());
                         return {};
                 }
