@@ -166,7 +166,11 @@ int ug_hip_yuv422p_to_uyvy(const void *y_dev, int y_pitch, const void *cb_dev, i
 int ug_hip_yuv422p10le_to_v210(const void *y_dev, int y_pitch, const void *cb_dev, int cb_pitch, const void *cr_dev, int cr_pitch,
                                void *dst_dev, int dst_pitch, int width, int height, ug_hip_stream_t stream);
 int ug_hip_uyvy_to_i422(const void *src_dev, int src_pitch, void *y_dev, int y_pitch, void *cb_dev, int cb_pitch, void *cr_dev,
-                        int cr_pitch, int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
+                        int cr_pitch, int width, int height, ug_hip_stream_t stream);
+/* uyvy_to_nv12 (to_planar.c:207-302) as the reference's default (-msse4.1) build computes it: chroma of a line pair is
+ * (a + b + 1) >> 1 for the first 16 * (width / 16) pixels (_mm_avg_epu8) and (a + b) / 2 for the scalar tail. */
+int ug_hip_uyvy_to_nv12(const void *src_dev, int src_pitch, void *y_dev, int y_pitch, void *cbcr_dev, int cbcr_pitch,
+                        int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
 
 /* ------------------------------------------------------------------------------------
  * JPEG: 8x8 forward DCT + quantisation (the stage libgpujpeg provides behind

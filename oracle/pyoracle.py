@@ -267,6 +267,43 @@ def uyvy_to_i422(src: np.ndarray, w: int, h: int, use_ref: bool = False):
     return (np.ascontiguousarray(rows[:, 1::2][:, :w]), np.ascontiguousarray(rows[:, 0::4]), np.ascontiguousarray(rows[:, 2::4]))
 
 
+def uyvy_to_nv12(src: np.ndarray, w: int, h: int, src_pitch: int = 0, use_ref: bool = False, scalar: bool = False):
+    """uyvy_to_nv12 (to_planar.c:207-302).  Default-build arithmetic: (a+b+1)>>1 for the first 16*(w/16) pixels (SSE avg), (a+b)/2 for
+    the tail; scalar=True: the build without SSE3 (all truncating).  The reference strides its input by 2*width bytes; pass
+    src_pitch=2*w to compare odd widths against it."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    ls = src_pitch or linesize(w, "UYVY")
+    if use_ref:
+        assert ls == 2 * w
+        y = np.zeros((h, w), np.uint8)
+        c = np.zeros((ch, 2 * cw + 16), np.uint8)
+        d = _ToPlanar()
+        d.width, d.height = w, h
+        d.out_data[0], d.out_data[1] = y.ctypes.data, c.ctypes.data
+        d.out_linesize[0], d.out_linesize[1] = w, c.strides[0]
+        pad = np.concatenate([src, np.zeros(MAX_PADDING, np.uint8)])
+        d.in_data = pad.ctypes.data
+        fn = ref(scalar).uyvy_to_nv12
+        fn.restype, fn.argtypes = None, [_ToPlanar]
+        fn(d)
+        return y, np.ascontiguousarray(c[:, : 2 * cw])
+    need = ls * (h - 1) + 4 * cw
+    buf = np.concatenate([src, np.zeros(max(0, ls * h - src.size) + 8, np.uint8)])
+    rows = np.stack([buf[r * ls: r * ls + 4 * cw] for r in range(h)]).astype(np.uint16)
+    top = rows[0::2]
+    bot = rows[1::2] if h % 2 == 0 else np.concatenate([rows[1::2], rows[-1:]])
+    vec = 0 if scalar else 16 * (w // 16)
+    rnd = (np.arange(cw) * 2 < vec).astype(np.uint16)
+    c = np.zeros((ch, 2 * cw), np.uint8)
+    c[:, 0::2] = ((top[:, 0::4] + bot[:, 0::4] + rnd) >> 1).astype(np.uint8)
+    c[:, 1::2] = ((top[:, 2::4] + bot[:, 2::4] + rnd) >> 1).astype(np.uint8)
+    y = np.zeros((h, 2 * cw), np.uint8)
+    y[:, 0::2] = rows[:, 1::4]
+    y[:, 1::2] = rows[:, 3::4]
+    return np.ascontiguousarray(y[:, :w]), c
+
+
 class _FromPlanar(C.Structure):
     """struct from_planar_data (from_planar.h:58-70), passed by value"""
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("out_data", C.c_void_p), ("out_pitch", C.c_uint),

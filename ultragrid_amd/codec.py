@@ -142,6 +142,16 @@ def uyvy_to_i422(src: torch.Tensor, w: int, h: int):
     return y, u, v
 
 
+def uyvy_to_nv12(src: torch.Tensor, w: int, h: int, src_pitch: int = 0):
+    src = _u8(src)
+    cw = (w + 1) // 2
+    y = torch.zeros((h, w), dtype=torch.uint8, device=src.device)
+    c = torch.zeros(((h + 1) // 2, 2 * cw), dtype=torch.uint8, device=src.device)
+    rc = L.load().ug_hip_uyvy_to_nv12(src.data_ptr(), src_pitch, y.data_ptr(), w, c.data_ptr(), 2 * cw, w, h, _stream())
+    L.check(rc, "ug_hip_uyvy_to_nv12")
+    return y, c
+
+
 def jpeg_divisors_device(quality: int, device) -> torch.Tensor:
     """128 fp32 divisors (luma, chroma) in device memory."""
     import ctypes as C

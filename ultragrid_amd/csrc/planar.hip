@@ -7,6 +7,7 @@
 //   yuv422p_to_uyvy     src/from_planar.c:391-423   (8-bit planar 4:2:2 -> UYVY, width/2 pairs per line)
 //   yuv422p10le_to_v210 src/from_planar.c:296-333   (10-bit planar 4:2:2 in 16-bit words -> v210, width/6 groups per line)
 //   uyvy_to_i422        src/video_codec.c:949-969   (UYVY -> planar 4:2:2, chroma (width+1)/2 wide)
+//   uyvy_to_nv12        src/to_planar.c:207-302     (UYVY -> Y plane + interleaved CbCr plane, line pairs averaged)
 //
 // Pure byte movement, HBM-bound: every kernel reads each input byte once and writes each output byte once.  One lane moves
 // 8 pixels (16 B of UYVY, 32 B of v210 per 12 px) with vector accesses when the geometry is aligned; ragged widths and odd
@@ -136,6 +137,32 @@ __global__ __launch_bounds__(256) void uyvy_to_i422_kernel(const uint8_t *__rest
         }
 }
 
+
+// uyvy_to_nv12 (to_planar.c:207-302) with the arithmetic of the reference's default build (-msse4.1, configure.ac:225): the first
+// 16 * (width / 16) pixels of a line pair go through _mm_avg_epu8 = (a + b + 1) >> 1, the rest through the scalar tail
+// (a + b) / 2 -- the result depends on the width, and this kernel reproduces that dependence (vec_px = 16 * (width / 16);
+// vec_px = 0 gives the build without SSE3).  One lane = one pixel pair of a line pair; odd height: the last line pairs with itself.
+__global__ __launch_bounds__(256) void uyvy_to_nv12_kernel(const uint8_t *__restrict__ src, long src_pitch, uint8_t *__restrict__ py, long y_pitch,
+                                                          uint8_t *__restrict__ pc, long c_pitch, int width, int height, int vec_px)
+{
+        const int cy = blockIdx.y * blockDim.y + threadIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+        const int y0 = 2 * cy;
+        if (y0 >= height || i >= (width + 1) / 2) return;
+        const int y1 = y0 + 1 < height ? y0 + 1 : y0;
+        const uint32_t a = *(const uint32_t *) (src + (long) y0 * src_pitch + 4 * i), b = *(const uint32_t *) (src + (long) y1 * src_pitch + 4 * i);
+        const uint32_t rnd = 2 * i < vec_px ? 1 : 0;
+        const uint32_t cb = ((a & 0xff) + (b & 0xff) + rnd) >> 1, cr = (((a >> 16) & 0xff) + ((b >> 16) & 0xff) + rnd) >> 1;
+        *(uint16_t *) (pc + (long) cy * c_pitch + 2 * i) = (uint16_t) (cb | cr << 8);
+        const bool second = 2 * i + 1 < width; // odd width: the last pair has one luma sample (to_planar.c:294-299)
+        uint8_t *d0 = py + (long) y0 * y_pitch + 2 * i, *d1 = py + (long) y1 * y_pitch + 2 * i;
+        d0[0] = (uint8_t) (a >> 8);
+        if (second) d0[1] = (uint8_t) (a >> 24);
+        if (y1 != y0) {
+                d1[0] = (uint8_t) (b >> 8);
+                if (second) d1[1] = (uint8_t) (b >> 24);
+        }
+}
+
 template <int V>
 int launch_planar_to_uyvy(const Planes &p, void *dst, int dst_pitch, int width, int height, hipStream_t st)
 {
@@ -256,6 +283,28 @@ int ug_hip_uyvy_to_i422(const void *src, int src_pitch, void *y, int y_pitch, vo
                 hipLaunchKernelGGL((uyvy_to_i422_kernel<false>), grid, block, 0, (hipStream_t) stream, (const uint8_t *) src, (long) src_pitch,
                                    (uint8_t *) y, (long) y_pitch, (uint8_t *) cb, (long) cb_pitch, (uint8_t *) cr, (long) cr_pitch, width, height);
         }
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_uyvy_to_nv12(const void *src, int src_pitch, void *y, int y_pitch, void *cbcr, int cbcr_pitch, int width, int height,
+                        ug_hip_stream_t stream)
+{
+        if (!src || !y || !cbcr || width <= 0 || height <= 0 || (height + 7) / 8 > 65535 || (3 & (uintptr_t) src) || (1 & (uintptr_t) cbcr)) {
+                ug::set_last_error_msg("ug_hip_uyvy_to_nv12: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        const int cw = (width + 1) / 2;
+        if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
+        if (!y_pitch) y_pitch = width;
+        if (!cbcr_pitch) cbcr_pitch = 2 * cw;
+        if ((src_pitch & 3) || (cbcr_pitch & 1)) {
+                ug::set_last_error_msg("ug_hip_uyvy_to_nv12: source pitch must be a multiple of 4, CbCr pitch of 2");
+                return UG_HIP_EINVAL;
+        }
+        const dim3 block(64, 4), grid((unsigned) ((cw + 63) / 64), (unsigned) (((height + 1) / 2 + 3) / 4));
+        hipLaunchKernelGGL(uyvy_to_nv12_kernel, grid, block, 0, (hipStream_t) stream, (const uint8_t *) src, (long) src_pitch, (uint8_t *) y,
+                           (long) y_pitch, (uint8_t *) cbcr, (long) cbcr_pitch, width, height, 16 * (width / 16));
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
