@@ -122,6 +122,71 @@ def main():
     def run_plane():
         assert l.ug_hip_jpeg_fdct_quant_plane(plane.data_ptr(), w, w, h, w // 8, h // 8, div.data_ptr(), outp.data_ptr(), None, st) == 0
     add("fdct_quant_plane (8-bit plane)", w, h, 1, 3.0, timeit(run_plane))
+    oy2 = torch.empty((2 * mw * ((h + 7) // 8), 64), dtype=torch.int16, device="cuda"); ocb2 = torch.empty((mw * ((h + 7) // 8), 64), dtype=torch.int16, device="cuda"); ocr2 = torch.empty_like(ocb2)
+
+    def run_jpeg422():
+        j = k[0] % n; k[0] += 1
+        assert l.ug_hip_uyvy_to_jpeg422_coeffs(src[j].data_ptr(), 0, w, h, div.data_ptr(), oy2.data_ptr(), ocb2.data_ptr(), ocr2.data_ptr(), st) == 0
+    add("uyvy->422->FDCT+quant (fused)", w, h, 1, 6.0, timeit(run_jpeg422, iters=3 * n))
+
+    # complete encoders (FDCT + entropy + compaction; excludes the 4-byte length read-back sync cost? no: encode() is synchronous)
+    import ctypes as C
+    for sub, fmt_in, pf in ((420, "UYVY", L.PF_UYVY), (422, "UYVY", L.PF_UYVY), (444, "RGB", L.PF_RGB)):
+        srcs = src if fmt_in == "UYVY" else frames("RGB", w, h, 8)
+        nn = srcs.shape[0]
+        enc = C.c_void_p()
+        assert l.ug_hip_jpeg_encoder_create_sub(w, h, 75, 4, sub, C.byref(enc)) == 0
+        cap = l.ug_hip_jpeg_encoder_max_size(enc)
+        outb = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        ln = C.c_size_t(0)
+
+        def run_enc():
+            j = k[0] % nn; k[0] += 1
+            assert l.ug_hip_jpeg_encoder_encode(enc, pf, srcs[j].data_ptr(), 0, outb.data_ptr(), cap, C.byref(ln), st) == 0
+        ms = timeit(run_enc, iters=2 * nn)
+        add(f"jpeg encoder {fmt_in} {sub} q75 ri4 ({ln.value} B)", w, h, 1, {420: 5.0, 422: 6.0, 444: 9.0}[sub], ms)
+        l.ug_hip_jpeg_encoder_destroy(enc)
+
+    # decode-direction shuffles
+    yy, uu, vv = codec.uyvy_to_i422(src[0], w, h)
+    dstu = torch.empty(2 * w * h, dtype=torch.uint8, device="cuda")
+
+    def run_p422():
+        assert l.ug_hip_yuv422p_to_uyvy(yy.data_ptr(), w, uu.data_ptr(), w // 2, vv.data_ptr(), w // 2, dstu.data_ptr(), 0, w, h, st) == 0
+    add("yuv422p_to_uyvy", w, h, 1, 4.0, timeit(run_p422))
+
+    def run_p420():
+        assert l.ug_hip_yuv420p_to_uyvy(y.data_ptr(), w, u.data_ptr(), w // 2, v.data_ptr(), w // 2, dstu.data_ptr(), 0, w, h, st) == 0
+    add("yuv420p_to_uyvy", w, h, 1, 3.5, timeit(run_p420))
+
+    def run_i422():
+        j = k[0] % n; k[0] += 1
+        assert l.ug_hip_uyvy_to_i422(src[j].data_ptr(), 0, yy.data_ptr(), w, uu.data_ptr(), w // 2, vv.data_ptr(), w // 2, w, h, st) == 0
+    add("uyvy_to_i422", w, h, 1, 4.0, timeit(run_i422, iters=3 * n))
+    cplane = torch.empty((h // 2, w), dtype=torch.uint8, device="cuda")
+
+    def run_nv12():
+        j = k[0] % n; k[0] += 1
+        assert l.ug_hip_uyvy_to_nv12(src[j].data_ptr(), 0, yy.data_ptr(), w, cplane.data_ptr(), w, w, h, st) == 0
+    add("uyvy_to_nv12", w, h, 1, 3.5, timeit(run_nv12, iters=3 * n))
+    y10 = torch.randint(0, 1024, (h, w), dtype=torch.int16, device="cuda"); u10 = torch.randint(0, 1024, (h, w // 2), dtype=torch.int16, device="cuda"); v10 = torch.randint(0, 1024, (h, w // 2), dtype=torch.int16, device="cuda")
+    dv = torch.empty(codec.linesize(L.PF_V210, w) * h, dtype=torch.uint8, device="cuda")
+
+    def run_v210():
+        assert l.ug_hip_yuv422p10le_to_v210(y10.data_ptr(), 2 * w, u10.data_ptr(), w, v10.data_ptr(), w, dv.data_ptr(), 0, w, h, st) == 0
+    add("yuv422p10le_to_v210", w, h, 1, 4 + 16 / 6, timeit(run_v210))
+
+    # DXT decoders
+    for (oid, name, outf, bpp) in ((L.DXT5_YCOCG, "DXT5", "RGBA", 5.0), (L.DXT5_YCOCG, "DXT5", "UYVY", 3.0), (L.DXT1, "DXT1", "RGBA", 4.5), (L.DXT1_YUV, "DXT1_YUV", "UYVY", 2.5)):
+        blocks = codec.dxt_encode_batch(L.PF_UYVY, oid, src, w, h, n, src.shape[1])
+        per = codec.dxt_size(oid, w, h)
+        dd = torch.empty(codec.linesize(L.PF_NAMES[outf], w) * h, dtype=torch.uint8, device="cuda")
+
+        def run_dec():
+            j = k[0] % n; k[0] += 1
+            assert l.ug_hip_dxt_decode(oid, L.PF_NAMES[outf], blocks.data_ptr() + j * per, dd.data_ptr(), w, h, 0, 0, 8, 16, st) == 0
+        add(f"dxt_decode {name}->{outf}", w, h, 1, bpp, timeit(run_dec, iters=3 * n))
+        del blocks
     if args.json:
         json.dump(rows, open(args.json, "w"), indent=1)
 

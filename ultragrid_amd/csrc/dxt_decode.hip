@@ -29,14 +29,15 @@ __device__ __forceinline__ uint8_t unorm8_out(float x)
         return (uint8_t) (int) (x * 255.0f + 0.5f);
 }
 
-// dxt_compress/rgba_to_yuv422.glsl:27-46 on two 8-bit RGB texels -> one UYVY word
-__device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2)
+// dxt_compress/rgba_to_yuv422.glsl:27-46 on two 8-bit RGB texels -> one UYVY word.  `unorm` = the 256 values v / 255.0f (the
+// texel fetch), computed once per workgroup with the IEEE division and kept in LDS: a table read instead of six divisions per pair.
+__device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2, const float *unorm)
 {
         float yuv[2][3];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
                 const uint32_t p = i ? p2 : p1;
-                const float r = (float) (p & 0xff) / 255.0f, g = (float) ((p >> 8) & 0xff) / 255.0f, b = (float) ((p >> 16) & 0xff) / 255.0f;
+                const float r = unorm[p & 0xff], g = unorm[(p >> 8) & 0xff], b = unorm[(p >> 16) & 0xff];
                 yuv[i][0] = (float) (1.0 / 16.0) + ((r * 0.2126f + g * 0.7152f) + b * 0.0722f) * 0.8588f;
                 yuv[i][1] = 0.5f + ((-r * 0.1145f - g * 0.3854f) + b * 0.5f) * 0.8784f;
                 yuv[i][2] = 0.5f + ((r * 0.5f - g * 0.4541f) - b * 0.0458f) * 0.8784f;
@@ -44,6 +45,17 @@ __device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2)
         const float U = yuv[0][1] * 0.5f + yuv[1][1] * 0.5f, V = yuv[0][2] * 0.5f + yuv[1][2] * 0.5f;
         return (uint32_t) unorm8_out(U) | (uint32_t) unorm8_out(yuv[0][0]) << 8 | (uint32_t) unorm8_out(V) << 16 |
                (uint32_t) unorm8_out(yuv[1][0]) << 24;
+}
+
+// fill the v / 255.0f table (256 lanes of the 64x4 workgroup, one division each); call before any early return
+template <int OUT>
+__device__ __forceinline__ void fill_unorm(float *unorm)
+{
+        if (OUT == UG_PF_UYVY) {
+                const int t = threadIdx.y * 64 + threadIdx.x;
+                unorm[t] = (float) t / 255.0f;
+                __syncthreads();
+        }
 }
 
 struct OutArgs {
@@ -54,7 +66,7 @@ struct OutArgs {
 
 // store one decoded row (4 pixels, packed R | G<<8 | B<<16) of block column bx
 template <int OUT>
-__device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4])
+__device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4], const float *unorm)
 {
         uint8_t *row = o.dst + (long) y * o.pitch;
         if (OUT == UG_PF_RGBA) {
@@ -76,7 +88,7 @@ __device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const
                 d[1] = (p[1] >> 8) | p[2] << 16;
                 d[2] = (p[2] >> 16) | p[3] << 8;
         } else { // UYVY
-                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy(px[0], px[1]), rgb_pair_to_uyvy(px[2], px[3]));
+                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy(px[0], px[1], unorm), rgb_pair_to_uyvy(px[2], px[3], unorm));
         }
 }
 
@@ -86,6 +98,8 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
         // per-lane tables, entry-major so that a wave's accesses to one entry are contiguous
         __shared__ double lds_a[8][256];
         __shared__ double lds_co[4][256], lds_cg[4][256];
+        __shared__ float unorm[OUT == UG_PF_UYVY ? 256 : 1];
+        fill_unorm<OUT>(unorm);
         const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
         const int t = threadIdx.y * 64 + threadIdx.x;
         if (bx >= bw || by >= bh) return;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
                         const uint32_t B = clamp8(((a - Co) - Cg) * 255.0);
                         px[x] = R | G << 8 | B << 16;
                 }
-                store_row<OUT>(o, 4 * by + y, bx, px);
+                store_row<OUT>(o, 4 * by + y, bx, px, unorm);
         }
 }
 
@@ -144,6 +158,8 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
 template <int OUT, bool YUV>
 __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restrict__ src, OutArgs o, int bw, int bh)
 {
+        __shared__ float unorm[OUT == UG_PF_UYVY ? 256 : 1];
+        fill_unorm<OUT>(unorm);
         const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
         if (bx >= bw || by >= bh) return;
         const uint2 q = src[(long) by * bw + bx];
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                         const uint32_t lo = (ci & 1) ? pal[1] : pal[0], hi = (ci & 1) ? pal[3] : pal[2];
                         px[x] = (ci & 2) ? hi : lo;
                 }
-                store_row<OUT>(o, 4 * by + y, bx, px);
+                store_row<OUT>(o, 4 * by + y, bx, px, unorm);
         }
 }
 
