@@ -111,26 +111,41 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
                         const int prev = lane ? 63 - __builtin_clzll(below) : 0;
                         const int run = lane ? lane - prev - 1 : 0;
                         const uint32_t e = lane == 0 ? dc_tab[comp][size] : ac_tab[comp][((run & 15) << 4) | size];
-                        unsigned long long bits = ((unsigned long long) (e & 0xffff) << size) | vbits;
-                        int nb = (int) (e >> 16) + size;
                         const bool emits = lane == 0 || ((acmask >> lane) & 1ull);
-                        if (lane > 0 && run > 15) { // 1..3 ZRL symbols in front
-                                const uint32_t z = ac_tab[comp][0xF0];
-                                const unsigned long long zc = z & 0xffff;
-                                const int zl = (int) (z >> 16), nz = run >> 4;
-                                unsigned long long zz3 = zc;
-                                if (nz > 1) zz3 = (zz3 << zl) | zc;
-                                if (nz > 2) zz3 = (zz3 << zl) | zc;
-                                bits |= zz3 << nb;
-                                nb += nz * zl;
-                        }
-                        const int last = 63 - __builtin_clzll(acmask | 1ull);
-                        if (lane == last && last < 63) { // EOB after the last non-zero coefficient
+                        const int last = 63 - __builtin_clzll(acmask | 1ull); // wave-uniform
+                        // Common case (no zero run longer than 15 in the block): every string fits 32 bits -- Huffman code (<= 16)
+                        // + value bits (<= 11) -- once the EOB is emitted by the otherwise idle lane last + 1 instead of being
+                        // appended to the last coefficient's string.  Blocks with ZRL symbols take the general 64-bit path.
+                        const bool fast = !__any(emits && run > 15);
+                        unsigned long long bits = 0;
+                        uint32_t bits32 = 0;
+                        int nb;
+                        if (fast) {
+                                const bool eob_lane = lane == last + 1; // exists iff last < 63
                                 const uint32_t eob = ac_tab[comp][0x00];
-                                bits = (bits << (eob >> 16)) | (eob & 0xffff);
-                                nb += (int) (eob >> 16);
+                                bits32 = eob_lane ? (eob & 0xffff) : (((e & 0xffff) << size) | vbits);
+                                nb = eob_lane ? (int) (eob >> 16) : (int) (e >> 16) + size;
+                                if (!(emits || eob_lane)) nb = 0;
+                        } else {
+                                bits = ((unsigned long long) (e & 0xffff) << size) | vbits;
+                                nb = (int) (e >> 16) + size;
+                                if (lane > 0 && run > 15) { // 1..3 ZRL symbols in front
+                                        const uint32_t z = ac_tab[comp][0xF0];
+                                        const unsigned long long zc = z & 0xffff;
+                                        const int zl = (int) (z >> 16), nz = run >> 4;
+                                        unsigned long long zz3 = zc;
+                                        if (nz > 1) zz3 = (zz3 << zl) | zc;
+                                        if (nz > 2) zz3 = (zz3 << zl) | zc;
+                                        bits |= zz3 << nb;
+                                        nb += nz * zl;
+                                }
+                                if (lane == last && last < 63) { // EOB after the last non-zero coefficient
+                                        const uint32_t eob = ac_tab[comp][0x00];
+                                        bits = (bits << (eob >> 16)) | (eob & 0xffff);
+                                        nb += (int) (eob >> 16);
+                                }
+                                if (!emits) nb = 0;
                         }
-                        if (!emits) nb = 0;
                         const int incl = wave_inclusive_scan(nb, lane);
                         const int total = __builtin_amdgcn_readlane(incl, 63);
                         const int pos = carry_bits + incl - nb;
@@ -140,11 +155,17 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         if (nb) {
-                                const unsigned long long s = bits << (64 - nb); // left-aligned string
                                 const int j = pos >> 5, o = pos & 31;
-                                atomicOr(&buf[j], (uint32_t) (s >> (32 + o)));
-                                if (o + nb > 32) atomicOr(&buf[j + 1], (uint32_t) (s >> o));
-                                if (o + nb > 64) atomicOr(&buf[j + 2], (uint32_t) (s << (32 - o)));
+                                if (fast) {
+                                        const uint32_t s32 = bits32 << (32 - nb); // left-aligned string
+                                        atomicOr(&buf[j], s32 >> o);
+                                        if (o + nb > 32) atomicOr(&buf[j + 1], s32 << (32 - o));
+                                } else {
+                                        const unsigned long long s64 = bits << (64 - nb);
+                                        atomicOr(&buf[j], (uint32_t) (s64 >> (32 + o)));
+                                        if (o + nb > 32) atomicOr(&buf[j + 1], (uint32_t) (s64 >> o));
+                                        if (o + nb > 64) atomicOr(&buf[j + 2], (uint32_t) (s64 << (32 - o)));
+                                }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
 // exclusive prefix sum of the final segment sizes, single workgroup, 4096 elements per pass (one 16-byte load per lane);
 // off[n_seg] = total stream length.  seg_tot is padded to a multiple of 4 entries.
 __global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_tot, int n_seg, uint32_t header_len,
-                                                               uint32_t *__restrict__ off)
+                                                               uint32_t *__restrict__ off, uint32_t *__restrict__ total_pinned)
 {
         __shared__ uint32_t wave_sum[16];
         __shared__ uint32_t carry_s;
@@ -210,14 +231,21 @@ __global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *_
                 if (t == 1023) carry_s = before + incl;
                 __syncthreads();
         }
-        if (t == 0) off[n_seg] = carry_s;
+        if (t == 0) {
+                off[n_seg] = carry_s;
+                *total_pinned = carry_s; // pinned host memory mapped into the device: the length needs no copy back
+        }
 }
 
 // one wave per segment: move its bytes to the final position, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
 // append RSTm (or EOI after the last segment)
 __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ raw, int cap_bytes, const uint32_t *__restrict__ seg_len,
-                                                      const uint32_t *__restrict__ off, int n_seg, uint8_t *__restrict__ out)
+                                                      const uint32_t *__restrict__ off, int n_seg, uint8_t *__restrict__ out,
+                                                      const uint8_t *__restrict__ header, int header_len)
 {
+        if (blockIdx.x == 0) { // the first workgroup also lays down SOI .. SOS
+                for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
+        }
         const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (seg >= n_seg) return;
         const uint8_t *s = raw + (size_t) seg * cap_bytes;
@@ -251,7 +279,8 @@ struct Encoder {
         uint32_t *scratch; // per-segment scan data before byte stuffing, cap bytes each
         uint32_t *seg_len, *seg_ff, *off;
         uint8_t *header_dev;
-        uint32_t *total_host; // pinned
+        uint32_t *total_host; // pinned, mapped
+        uint32_t *total_host_dev; // the same word as the device sees it
 };
 
 void put16(std::vector<uint8_t> &v, int x) { v.push_back((uint8_t) (x >> 8)); v.push_back((uint8_t) x); }
@@ -349,7 +378,8 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         alloc((void **) &e->seg_ff, ((size_t) e->n_seg + 4) * 4);
         alloc((void **) &e->off, (size_t) (e->n_seg + 1) * 4);
         alloc((void **) &e->header_dev, e->header.size());
-        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocMapped);
+        if (err == hipSuccess) err = hipHostGetDevicePointer((void **) &e->total_host_dev, e->total_host, 0);
         if (err == hipSuccess) err = hipMemcpy(e->div, div, sizeof div, hipMemcpyHostToDevice);
         if (err == hipSuccess) err = hipMemcpy(e->header_dev, e->header.data(), e->header.size(), hipMemcpyHostToDevice);
         if (err != hipSuccess) {
@@ -418,12 +448,11 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
         if (rc != UG_HIP_SUCCESS) return rc;
         hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs, e->sub == 444 ? 0 : 1, e->ri,
                            e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
-        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off);
-        UG_HIP_TRY(hipMemcpyAsync(out_dev, e->header_dev, e->header.size(), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off,
+                           e->total_host_dev);
         hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->off,
-                           e->n_seg, (uint8_t *) out_dev);
+                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size());
         UG_HIP_LAUNCH_CHECK();
-        UG_HIP_TRY(hipMemcpyAsync(e->total_host, e->off + e->n_seg, 4, hipMemcpyDeviceToHost, st));
         UG_HIP_TRY(hipStreamSynchronize(st));
         *out_len = *e->total_host;
         return UG_HIP_SUCCESS;
