@@ -240,3 +240,42 @@ def test_jpeg_encoder_input_format_mismatch(hip):
     with pytest.raises(RuntimeError):
         enc.encode(torch.zeros(64 * 64 * 2, dtype=torch.uint8, device="cuda"), L.PF_UYVY)
     enc.close()
+
+
+@pytest.mark.parametrize("sub", [420, 422])
+def test_jpeg_zrl_path(hip, po, sub):
+    """Blocks whose only AC energy sits at the highest frequencies: zero runs of 16..62 -> 1..3 ZRL symbols per block (the coder's
+    general 64-bit path), mixed with plain blocks in the same restart segments."""
+    import io
+    import torch
+    from PIL import Image
+    from jpeg_bitstream import write_jpeg, ZIGZAG
+    w, h = 256, 64
+    yy, xx = np.mgrid[0:h, 0:w]
+    k = ((xx // 8) % 4 + 4)                                     # horizontal frequency 4..7 by block column
+    luma = 128 + 60 * np.cos((2 * (xx % 8) + 1) * k * np.pi / 16) * np.cos((2 * (yy % 8) + 1) * 7 * np.pi / 16)
+    luma[:, 128:] = 128 + 50 * np.sin(xx[:, 128:] / 9.0)        # ordinary content in the right half
+    uyvy = np.empty((h, w // 2, 4), np.uint8)
+    uyvy[..., 0] = 128; uyvy[..., 2] = 128
+    uyvy[..., 1] = luma[:, 0::2].clip(0, 255); uyvy[..., 3] = luma[:, 1::2].clip(0, 255)
+    uyvy = uyvy.ravel()
+    q = 90
+    planes = po.uyvy_to_i420(uyvy, w, h) if sub == 420 else po.uyvy_to_i422(uyvy, w, h)
+    vy = 2 if sub == 420 else 1
+    mw, mh = w // 16, h // (8 * vy)
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    cy = po.jpeg_fdct_quant_plane(planes[0], po.jpeg_divisors(ql), 2 * mw, vy * mh)
+    runs = []
+    for blk in cy:
+        nz = np.flatnonzero(blk[1:]) + 1
+        runs.append(int(np.max(np.diff(np.concatenate([[0], nz])) - 1)) if nz.size else 0)
+    assert max(runs) >= 48 and sum(r > 15 for r in runs) > 50 and sum(r <= 15 for r in runs) > 50   # 3-ZRL blocks and plain blocks
+    enc = hip.JpegEncoder(w, h, q, 3, subsampling=sub)
+    data = enc.encode(torch.from_numpy(uyvy).cuda())
+    enc.close()
+    want = write_jpeg(w, h, ql, qc, cy, po.jpeg_fdct_quant_plane(planes[1], po.jpeg_divisors(qc), mw, mh),
+                      po.jpeg_fdct_quant_plane(planes[2], po.jpeg_divisors(qc), mw, mh), restart=3, sub=sub)
+    assert data == want
+    img = Image.open(io.BytesIO(data))
+    img.draft("YCbCr", None)
+    assert np.abs(np.asarray(img)[..., 0].astype(int) - planes[0].astype(int)).mean() < 3
