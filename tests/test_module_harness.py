@@ -100,6 +100,35 @@ def test_device_resident_frames(tmp_path, po, cfg, codec):
 
 @needs_harness
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["dxt:DXT5:dev=0,0,0", "dxt:DXT1:dev=0", "jpeg:q=70:restart=3:dev=0,0"])
+def test_frames_sharded_over_workers_in_order(tmp_path, po, cfg):
+    """frames are dealt to the first idle worker (one per listed device; here one GPU listed several times, so
+    several frames are in flight on it) and come back in push order with their sequence numbers, each identical to the
+    single-frame result -- the reference's GPUJPEG scheme (gpujpeg.cpp:643-722) behind the asynchronous frame API."""
+    w, h, n = 256, 64, 9
+    frames = [synth.s1_random("UYVY", w, h, salt=40 + i) for i in range(n)]
+    raw, out = tmp_path / "in.raw", tmp_path / "out.bin"
+    np.concatenate(frames).tofile(raw)
+    r = _run([cfg, "UYVY", w, h, raw, out, 1, "host", n])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"frames={n}" in r.stdout and "seq=" + ",".join(str(i) for i in range(n)) + "," in r.stdout, r.stdout
+    data = out.read_bytes()
+    if cfg.startswith("dxt"):
+        oid = po.OUT_DXT5YCOCG if "DXT5" in cfg else po.OUT_DXT1
+        want = b"".join(po.dxt_encode(po.IN_UYVY, oid, f, w, h).tobytes() for f in frames)
+        assert data == want
+    else:
+        singles = []
+        for i, f in enumerate(frames):
+            one_in, one_out = tmp_path / f"f{i}.raw", tmp_path / f"f{i}.jpg"
+            f.tofile(one_in)
+            assert _run(["jpeg:q=70:restart=3", "UYVY", w, h, one_in, one_out]).returncode == 0
+            singles.append(one_out.read_bytes())
+        assert data == b"".join(singles)
+
+
+@needs_harness
+@pytest.mark.gpu
 def test_tiled_4k_fanout(tmp_path, po):
     """4 tiles ("tiled 4K", types.h:340-343): the framework fans tiles out to worker threads, one module state
     each (video_compress.cpp:441-490); every tile must match the oracle."""
@@ -156,6 +185,18 @@ def test_decompress_through_reference_framework(tmp_path, po, comp, out):
     assert r.returncode == 0, r.stdout + r.stderr
     got = np.fromfile(dst, np.uint8).reshape(h, pitch)[:, :ls]
     assert np.array_equal(got.ravel(), po.dxt_decode(oid, out, blocks, w, h))
+
+
+SHARDER_TEST = os.path.join(ROOT, "oracle", "_ref", "ug_sharder_test")
+
+
+@pytest.mark.skipif(not os.path.exists(SHARDER_TEST), reason="oracle/_ref/ug_sharder_test not built")
+@pytest.mark.parametrize("workers,frames", [(1, 40), (4, 300), (8, 500)])
+def test_frame_sharder_cpu(workers, frames):
+    """mi355x::frame_sharder with a fake tile encoder (random delays, injected failures, tiled frames): in-order delivery, failed
+    frames skipped, all workers used, metadata kept, the poison pill ends the stream (module/ug_sharder_test.cpp).  No GPU."""
+    r = subprocess.run([SHARDER_TEST, str(workers), str(frames)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
 
 
 @needs_harness
@@ -231,8 +272,8 @@ def test_jpeg_module_rejects_impossible_subsampling(tmp_path):
 @needs_harness
 @pytest.mark.gpu
 def test_tiles_dealt_over_device_list(tmp_path, po):
-    """dev=<list>: per-tile module instances are dealt round-robin over the listed devices (one GPU here, listed twice: the
-    code path is the multi-GPU one, the data path has no inter-device traffic)."""
+    """dev=<list> with a tiled frame: the frame goes to one worker, which encodes its tiles with per-tile encoder states on its
+    device (one GPU here, listed twice: the code path is the multi-GPU one, the data path has no inter-device traffic)."""
     w, h, tiles = 384, 128, 4
     frames = [synth.s1_random("UYVY", w, h, salt=10 + t) for t in range(tiles)]
     raw, out = tmp_path / "in.raw", tmp_path / "out.bin"

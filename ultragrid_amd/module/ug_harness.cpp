@@ -7,7 +7,8 @@
  *
  *     compress_init(nullptr, "dxt:DXT5", &c); compress_frame(c, frame); compress_pop(c); compress_done(c);
  *
- * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles] [dev]
+ * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles] [dev|host] [frames]
+ *        frames: number of frames in in.raw (default 1); all are pushed, the compressed frames are written in pop order
  *        dev: hand the frame over device-resident (tile data = device pointers, mem_location = CUDA_MEM)
  *        ug_harness list
  * The compressed tile(s) are written to <out.bin> (tile after tile); a test compares them with the
@@ -50,36 +51,40 @@ int main(int argc, char **argv)
         struct video_desc desc{};
         desc.width = w; desc.height = h; desc.color_spec = codec; desc.fps = 30; desc.interlacing = PROGRESSIVE;
         desc.tile_count = tiles;
-        struct video_frame *f = vf_alloc_desc_data(desc);
+        const unsigned nframes = argc > 9 ? atoi(argv[9]) : 1;
+        const bool devmem = argc > 8 && strcmp(argv[8], "dev") == 0;
         FILE *in = fopen(argv[5], "rb");
         if (!in) { perror("in"); return 1; }
-        for (unsigned t = 0; t < tiles; t++) {
-                if (fread(f->tiles[t].data, 1, f->tiles[t].data_len, in) != f->tiles[t].data_len) {
-                        fprintf(stderr, "short read (%u bytes per tile expected)\n", f->tiles[t].data_len);
-                        return 1;
-                }
-        }
-        fclose(in);
-        const bool devmem = argc > 8 && strcmp(argv[8], "dev") == 0;
         std::vector<void *> dev_bufs;
-        if (devmem) { // device-resident video_frame (types.h:295-298): the module must not upload it again
-                struct video_frame *fd = vf_alloc_desc(desc);
+        std::vector<std::shared_ptr<video_frame>> inputs;
+        for (unsigned n = 0; n < nframes; n++) {
+                struct video_frame *f = vf_alloc_desc_data(desc);
                 for (unsigned t = 0; t < tiles; t++) {
-                        void *p = nullptr;
-                        if (ug_hip_malloc(&p, f->tiles[t].data_len + 64) != UG_HIP_SUCCESS ||
-                            ug_hip_memcpy(p, f->tiles[t].data, f->tiles[t].data_len, UG_HIP_MEMCPY_HOST_TO_DEVICE) != UG_HIP_SUCCESS) {
-                                fprintf(stderr, "device staging failed: %s\n", ug_hip_last_error_string());
+                        if (fread(f->tiles[t].data, 1, f->tiles[t].data_len, in) != f->tiles[t].data_len) {
+                                fprintf(stderr, "short read (%u bytes per tile expected)\n", f->tiles[t].data_len);
                                 return 1;
                         }
-                        dev_bufs.push_back(p);
-                        fd->tiles[t].data = (char *) p;
-                        fd->tiles[t].data_len = f->tiles[t].data_len;
-                        memset(f->tiles[t].data, 0xA5, f->tiles[t].data_len); // the host copy must not be what gets encoded
                 }
-                fd->mem_location = CUDA_MEM;
-                vf_free(f);
-                f = fd;
+                if (devmem) { // device-resident video_frame (types.h:295-298): the module must not upload it again
+                        struct video_frame *fd = vf_alloc_desc(desc);
+                        for (unsigned t = 0; t < tiles; t++) {
+                                void *p = nullptr;
+                                if (ug_hip_malloc(&p, f->tiles[t].data_len + 64) != UG_HIP_SUCCESS ||
+                                    ug_hip_memcpy(p, f->tiles[t].data, f->tiles[t].data_len, UG_HIP_MEMCPY_HOST_TO_DEVICE) != UG_HIP_SUCCESS) {
+                                        fprintf(stderr, "device staging failed: %s\n", ug_hip_last_error_string());
+                                        return 1;
+                                }
+                                dev_bufs.push_back(p);
+                                fd->tiles[t].data = (char *) p;
+                                fd->tiles[t].data_len = f->tiles[t].data_len;
+                        }
+                        fd->mem_location = CUDA_MEM;
+                        vf_free(f); // the host copy is gone: only the device copy can be what gets encoded
+                        f = fd;
+                }
+                inputs.emplace_back(f, vf_free);
         }
+        fclose(in);
 
         struct compress_state *c = nullptr;
         int rc = compress_init(nullptr, cfg, &c);
@@ -87,7 +92,6 @@ int main(int argc, char **argv)
                 fprintf(stderr, "compress_init(\"%s\") rc=%d\n", cfg, rc);
                 return 2;
         }
-        std::shared_ptr<video_frame> frame(f, vf_free);
         // sender-thread stand-in (rxtx.cpp:260-288): pops until the poison pill arrives
         std::vector<std::shared_ptr<video_frame>> popped;
         std::thread sender([&] {
@@ -95,8 +99,10 @@ int main(int argc, char **argv)
                         popped.push_back(f2);
                 }
         });
-        compress_frame(c, frame);
-        frame.reset();
+        for (auto &frame : inputs) {
+                compress_frame(c, frame);
+                frame.reset();
+        }
         compress_frame(c, {}); // poison pill, as rxtx does on exit
         sender.join();
         if (popped.empty()) { // only the pill came back: the module dropped the frame (video_compress.cpp:394-398)
@@ -104,17 +110,22 @@ int main(int argc, char **argv)
                 compress_done(c);
                 return 3;
         }
-        std::shared_ptr<video_frame> out = popped[0];
         FILE *o = fopen(argv[6], "wb");
         if (!o) { perror("out"); return 1; }
-        for (unsigned t = 0; t < out->tile_count; t++) {
-                fwrite(out->tiles[t].data, 1, out->tiles[t].data_len, o);
+        for (auto &out : popped) {
+                for (unsigned t = 0; t < out->tile_count; t++) {
+                        fwrite(out->tiles[t].data, 1, out->tiles[t].data_len, o);
+                }
         }
         fclose(o);
-        printf("OK codec=%s tiles=%u tile0=%ux%u len=%u compress_ms=%.3f\n", get_codec_name(out->color_spec), out->tile_count,
-               out->tiles[0].width, out->tiles[0].height, out->tiles[0].data_len,
-               (double) (out->compress_end - out->compress_start) / 1e6);
-        out.reset();
+        {
+                std::shared_ptr<video_frame> out = popped[0];
+                printf("OK codec=%s frames=%zu tiles=%u tile0=%ux%u len=%u compress_ms=%.3f seq=", get_codec_name(out->color_spec), popped.size(),
+                       out->tile_count, out->tiles[0].width, out->tiles[0].height, out->tiles[0].data_len,
+                       (double) (out->compress_end - out->compress_start) / 1e6);
+                for (auto &f2 : popped) printf("%u,", f2->seq);
+                printf("\n");
+        }
         popped.clear();
         compress_done(c);
         for (void *p : dev_bufs) ug_hip_free(p);

@@ -1,0 +1,86 @@
+/**
+ * @file ug_sharder_test.cpp
+ * CPU-only test of mi355x::frame_sharder: a fake tile encoder with random delays and injected failures
+ * stands in for the GPU.  Checks: in-order delivery with the sequence numbers of the pushed frames, failed frames skipped,
+ * tiled frames split / merged, every worker used, the poison pill ends pop() after all frames came out, metadata kept.
+ * Links the reference's own video_frame / vf_split objects (no HIP).  usage: ug_sharder_test [workers] [frames]
+ */
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <set>
+#include <thread>
+
+#include "mi355x_frame_sharder.h"
+#include "video_codec.h"
+
+int main(int argc, char **argv)
+{
+        const int workers = argc > 1 ? atoi(argv[1]) : 4;
+        const unsigned frames = argc > 2 ? atoi(argv[2]) : 200;
+        std::vector<int> devices;
+        for (int i = 0; i < workers; i++) devices.push_back(i);
+        std::atomic<unsigned> calls{0};
+        std::mutex used_lock;
+        std::set<int> used;
+        mi355x::frame_sharder sh(devices, [&](int device) -> mi355x::tile_encoder_t {
+                auto rng = std::make_shared<std::mt19937>(1234 + device);
+                return [&, rng, device](int dev, unsigned tile, std::shared_ptr<video_frame> in) -> std::shared_ptr<video_frame> {
+                        if (dev != device) abort();
+                        calls++;
+                        { std::lock_guard<std::mutex> lk(used_lock); used.insert(dev); }
+                        std::this_thread::sleep_for(std::chrono::microseconds((*rng)() % 3000));
+                        uint32_t tag;
+                        memcpy(&tag, in->tiles[0].data, 4);
+                        if (tag % 17 == 5) return {}; // injected encoder failure: this frame must be skipped
+                        struct video_desc d = video_desc_from_frame(in.get());
+                        d.color_spec = DXT5;
+                        std::shared_ptr<video_frame> out(vf_alloc_desc_data(d), vf_free);
+                        memcpy(out->tiles[0].data, &tag, 4);
+                        out->tiles[0].data[4] = (char) tile;
+                        out->tiles[0].data[5] = (char) dev;
+                        return out;
+                };
+        });
+        std::vector<std::shared_ptr<video_frame>> got;
+        std::thread consumer([&] {
+                while (auto f = sh.pop()) got.push_back(f);
+        });
+        unsigned expected = 0;
+        for (unsigned i = 0; i < frames; i++) {
+                struct video_desc d{};
+                d.width = 64; d.height = 16; d.color_spec = UYVY; d.fps = 25; d.interlacing = PROGRESSIVE;
+                d.tile_count = i % 5 == 0 ? 4 : 1;
+                std::shared_ptr<video_frame> f(vf_alloc_desc_data(d), vf_free);
+                for (unsigned t = 0; t < d.tile_count; t++) memcpy(f->tiles[t].data, &i, 4);
+                f->compress_start = 1000 + i;
+                if (i % 17 != 5) expected++;
+                sh.push(f);
+        }
+        sh.push({});
+        consumer.join();
+        int rc = 0;
+        if (got.size() != expected) { fprintf(stderr, "got %zu frames, expected %u\n", got.size(), expected); rc = 1; }
+        uint32_t last = 0;
+        bool first = true;
+        for (auto &f : got) {
+                uint32_t tag;
+                memcpy(&tag, f->tiles[0].data, 4);
+                if (tag != f->seq) { fprintf(stderr, "payload %u under seq %u\n", tag, f->seq); rc = 1; }
+                if (!first && f->seq <= last) { fprintf(stderr, "out of order: %u after %u\n", f->seq, last); rc = 1; }
+                if (f->seq % 17 == 5) { fprintf(stderr, "failed frame %u was delivered\n", f->seq); rc = 1; }
+                if (f->tile_count != (f->seq % 5 == 0 ? 4u : 1u)) { fprintf(stderr, "tile count of %u\n", f->seq); rc = 1; }
+                for (unsigned t = 0; t < f->tile_count; t++) {
+                        if ((unsigned char) f->tiles[t].data[4] != t) { fprintf(stderr, "tile order in %u\n", f->seq); rc = 1; }
+                }
+                if (f->compress_start != (time_ns_t) (1000 + f->seq)) { fprintf(stderr, "metadata of %u lost\n", f->seq); rc = 1; }
+                last = f->seq;
+                first = false;
+        }
+        if ((int) used.size() != workers && frames >= 50) { fprintf(stderr, "only %zu of %d workers used\n", used.size(), workers); rc = 1; }
+        printf("%s frames=%zu tile_encodes=%u workers_used=%zu\n", rc ? "FAIL" : "OK", got.size(), calls.load(), used.size());
+        return rc;
+}

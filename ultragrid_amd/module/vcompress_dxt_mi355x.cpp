@@ -44,6 +44,7 @@
 
 #include "../../include/ug_mi355x.h"
 #include "ug_codec_map.h"
+#include "mi355x_frame_sharder.h"
 
 #define MOD_NAME "[DXT MI355X] "
 
@@ -279,13 +280,19 @@ compress_module_info get_dxt_mi355x_module_info()
         return module_info;
 }
 
+/// module-level init: consumes dev=<list>, creates one worker (thread + per-tile encoder states) per listed device
+void *dxt_mi355x_module_init(struct module *parent, const char *cfg)
+{
+        return mi355x::sharded_init(parent, cfg, dxt_mi355x_compress_init, dxt_mi355x_compress_tile, dxt_mi355x_compress_done, ug_hip_set_device);
+}
+
 const struct video_compress_info dxt_mi355x_info = {
-        dxt_mi355x_compress_init,
-        dxt_mi355x_compress_done,
-        NULL,
-        dxt_mi355x_compress_tile,
+        dxt_mi355x_module_init,
+        mi355x::sharded_done,
         NULL,
         NULL,
+        mi355x::sharded_push, // asynchronous frame API: frames are dealt to one worker per listed GPU and popped in order
+        mi355x::sharded_pop,
         NULL,
         NULL,
         get_dxt_mi355x_module_info,
