@@ -3,24 +3,21 @@
  * UltraGrid video_compress module "dxt" (-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<n>[,<n>...]]) backed by the MI355X
  * kernel library libug_mi355x.so (include/ug_mi355x.h).
  *
- * This is the host-side half of the drop-in boundary.  It is compiled
- * against UltraGrid's own headers and registers through lib_common.cpp exactly like the
- * reference's GPU DXT modules do (src/video_compress/cuda_dxt.cpp:278-290,
- * src/video_compress/dxt_glsl.cpp:319-332): tile API, one state per tile, lazy reconfigure on
- * format change, empty shared_ptr as poison pill / error.
+ * This is the host-side half of the drop-in boundary.  It is compiled against UltraGrid's own headers and
+ * registers through lib_common.cpp exactly like the reference's GPU modules do (src/video_compress/cuda_dxt.cpp:278-290,
+ * src/video_compress/gpujpeg.cpp:761-771).  API shape: the asynchronous frame API (push / pop), as gpujpeg.cpp uses it, on
+ * top of mi355x_frame_sharder.h; the per-tile encoder below (init / compress_tile / done: lazy reconfigure on format change,
+ * empty shared_ptr on error) is what every worker of the sharder runs.
  *
  * What is different from cuda_dxt.cpp by design (MI355X-first):
- *  - no CPU decoder_t pre-pass (cuda_dxt.cpp:206-220) and no 4:2:2->4:4:4 intermediate
- *    (cuda_dxt.cpp:223-232): the frame is uploaded in its wire format (RGB / RGBA / UYVY / v210,
- *    YUYV and BGR via a device-side swizzle) and unpacked + colour-converted + encoded by ONE
- *    fused kernel;
- *  - one HIP stream per module instance, asynchronous H2D -> kernel -> D2H, a single stream
- *    synchronisation per frame (cuda_dxt.cu:759 synchronises after every launch);
- *  - devices come from the module option dev=<n>[,<n>...] (default 0); UltraGrid's -D list is capped at
- *    MAX_CUDA_DEVICES = 4 (host.h:97), too small for an 8-GPU MI355X node.  With several devices the per-tile
- *    module instances the framework creates (video_compress.cpp:302-319, one init per tile) are dealt out round-robin,
- *    so the tiles of a tiled 4K/8K frame are encoded on different GPUs concurrently (tile fan-out,
- *    video_compress.cpp:441-490) -- frames/tiles are independent, there is no inter-GPU traffic.
+ *  - no CPU decoder_t pre-pass (cuda_dxt.cpp:206-220) and no 4:2:2->4:4:4 intermediate (cuda_dxt.cpp:223-232): the frame is
+ *    uploaded in its wire format (RGB / RGBA / UYVY / v210, YUYV and BGR via a device-side swizzle) and unpacked +
+ *    colour-converted + encoded by ONE fused kernel; device-resident frames are encoded in place;
+ *  - one HIP stream per encoder state, asynchronous H2D -> kernel -> D2H, a single stream synchronisation per tile
+ *    (cuda_dxt.cu:759 synchronises after every launch);
+ *  - devices come from the module option dev=<n>[,<n>...] (default 0); UltraGrid's -D list is capped at MAX_CUDA_DEVICES = 4
+ *    (host.h:97), too small for an 8-GPU MI355X node.  Frames are dealt to one worker thread per listed device and delivered
+ *    in order -- frames are independent, there is no inter-GPU traffic.
  *
  * There is deliberately no CPU fallback: if the GPU path cannot take a format, the module says
  * so and drops the frame (video_compress.cpp:394-398 semantics).
