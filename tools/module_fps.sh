@@ -1,0 +1,19 @@
+#!/bin/bash
+# Module-level throughput through the reference's compress framework (host frames in, host frames out, PCIe included):
+#   tools/module_fps.sh   (GPU box; needs oracle/_ref/ug_harness)
+cd ${GRAFT_REPO_ROOT:-.}
+python - <<'PY'
+import numpy as np
+from ultragrid_amd import synth
+for name, fmt, w, h, n in (("4k_uyvy", "UYVY", 3840, 2160, 8), ("8k_v210", "v210", 7680, 4320, 4), ("1080_rgb", "RGB", 1920, 1080, 16)):
+    fr = [synth.s2_video(fmt, w, h, salt=i) if fmt != "RGB" else synth.s1_random(fmt, w, h, salt=i) for i in range(min(n, 2))]
+    np.concatenate([fr[i % len(fr)] for i in range(n)]).tofile(f"/tmp/{name}.raw")
+PY
+H=oracle/_ref/ug_harness
+for cfg in "dxt:DXT5:dev=0" "dxt:DXT5:dev=0,0" "dxt:DXT5:dev=0,0,0,0" "jpeg:q=75:restart=4:dev=0" "jpeg:q=75:restart=4:dev=0,0,0"; do
+  echo "== $cfg  4K UYVY"; $H $cfg UYVY 3840 2160 /tmp/4k_uyvy.raw /tmp/o.bin 1 host 8 40 | grep THROUGHPUT
+done
+for cfg in "dxt:DXT5:dev=0" "dxt:DXT5:dev=0,0,0"; do
+  echo "== $cfg  8K v210"; $H $cfg v210 7680 4320 /tmp/8k_v210.raw /tmp/o.bin 1 host 4 25 | grep THROUGHPUT
+  echo "== $cfg  1080p RGB -> DXT5"; $H $cfg RGB 1920 1080 /tmp/1080_rgb.raw /tmp/o.bin 1 host 16 60 | grep THROUGHPUT
+done

@@ -9,6 +9,7 @@
  *
  * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles] [dev|host] [frames]
  *        frames: number of frames in in.raw (default 1); all are pushed, the compressed frames are written in pop order
+ *        [repeat]: push the frame set that many times (throughput measurement; only the last pass is kept)
  *        dev: hand the frame over device-resident (tile data = device pointers, mem_location = CUDA_MEM)
  *        ug_harness list
  * The compressed tile(s) are written to <out.bin> (tile after tile); a test compares them with the
@@ -25,6 +26,7 @@
 #include "host.h"
 #include "lib_common.h"
 #include "types.h"
+#include "tv.h"
 #include "video_codec.h"
 #include "../../include/ug_mi355x.h"
 #include "video_compress.h"
@@ -52,6 +54,7 @@ int main(int argc, char **argv)
         desc.width = w; desc.height = h; desc.color_spec = codec; desc.fps = 30; desc.interlacing = PROGRESSIVE;
         desc.tile_count = tiles;
         const unsigned nframes = argc > 9 ? atoi(argv[9]) : 1;
+        const unsigned repeat = argc > 10 ? atoi(argv[10]) : 1;
         const bool devmem = argc > 8 && strcmp(argv[8], "dev") == 0;
         FILE *in = fopen(argv[5], "rb");
         if (!in) { perror("in"); return 1; }
@@ -97,14 +100,22 @@ int main(int argc, char **argv)
         std::thread sender([&] {
                 while (std::shared_ptr<video_frame> f2 = compress_pop(c)) {
                         popped.push_back(f2);
+                        if (repeat > 1 && popped.size() > nframes) { // like the real sender: frames go back to the module's pool
+                                popped.erase(popped.begin());
+                        }
                 }
         });
-        for (auto &frame : inputs) {
-                compress_frame(c, frame);
-                frame.reset();
+        const time_ns_t t_start = get_time_in_ns();
+        for (unsigned r = 0; r < repeat; r++) {
+                for (auto &frame : inputs) {
+                        compress_frame(c, frame);
+                }
         }
+        inputs.clear();
         compress_frame(c, {}); // poison pill, as rxtx does on exit
         sender.join();
+        const double wall_s = (double) (get_time_in_ns() - t_start) / 1e9;
+        printf("THROUGHPUT frames=%u wall_s=%.4f fps=%.1f\n", nframes * repeat, wall_s, nframes * repeat / wall_s);
         if (popped.empty()) { // only the pill came back: the module dropped the frame (video_compress.cpp:394-398)
                 fprintf(stderr, "frame dropped\n");
                 compress_done(c);
