@@ -209,7 +209,9 @@ int ug_hip_uyvy_to_jpeg422_coeffs(const void *src_dev, int src_pitch, int width,
  *   422: UG_PF_UYVY (samples as they are, uyvy_to_i422)                                                     JFIF YCbCr
  *   444: UG_PF_RGB, components stay R, G, B (color_space_internal = GPUJPEG_RGB); written the libjpeg way for JCS_RGB:
  *        Adobe APP14 transform 0, component ids 'R','G','B', quantiser / Huffman table 0 for every component.
- * `encode` is synchronous on `stream` (it returns the stream length); out_capacity >= ug_hip_jpeg_encoder_max_size(). */
+ * `encode` is synchronous on `stream` (it returns the stream length).  ug_hip_jpeg_encoder_max_size() is the capacity that can
+ * never overflow (every coefficient at its longest code, every byte stuffed: ~10 B per pixel); a smaller out_capacity is allowed:
+ * if the stream does not fit, UG_HIP_EINVAL is returned with *out_len = the size it needs and the buffer contents undefined. */
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out);
 /* subsampling = 420, 422 or 444 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */

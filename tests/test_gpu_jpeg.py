@@ -279,3 +279,29 @@ def test_jpeg_zrl_path(hip, po, sub):
     img = Image.open(io.BytesIO(data))
     img.draft("YCbCr", None)
     assert np.abs(np.asarray(img)[..., 0].astype(int) - planes[0].astype(int)).mean() < 3
+
+
+def test_jpeg_small_output_buffer_reports_needed_size(hip, po):
+    """out_capacity below the stream size: UG_HIP_EINVAL and *out_len = the size it takes; with exactly that size it succeeds."""
+    import ctypes as C
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 256, 128
+    uyvy = torch.from_numpy(synth.s1_random("UYVY", w, h)).cuda()
+    l = L.load()
+    enc = C.c_void_p()
+    assert l.ug_hip_jpeg_encoder_create_sub(w, h, 95, 4, 422, C.byref(enc)) == 0
+    full = torch.empty(l.ug_hip_jpeg_encoder_max_size(enc), dtype=torch.uint8, device="cuda")
+    n = C.c_size_t(0)
+    st = torch.cuda.current_stream().cuda_stream
+    assert l.ug_hip_jpeg_encoder_encode(enc, L.PF_UYVY, uyvy.data_ptr(), 0, full.data_ptr(), full.numel(), C.byref(n), st) == 0
+    need = n.value
+    ref = bytes(full[:need].cpu().numpy())
+    small = torch.empty(need - 1000, dtype=torch.uint8, device="cuda")
+    n2 = C.c_size_t(0)
+    assert l.ug_hip_jpeg_encoder_encode(enc, L.PF_UYVY, uyvy.data_ptr(), 0, small.data_ptr(), small.numel(), C.byref(n2), st) == -1
+    assert n2.value == need
+    exact = torch.empty(need + 16, dtype=torch.uint8, device="cuda")[:need]
+    assert l.ug_hip_jpeg_encoder_encode(enc, L.PF_UYVY, uyvy.data_ptr(), 0, exact.data_ptr(), need, C.byref(n2), st) == 0
+    assert bytes(exact.cpu().numpy()) == ref
+    l.ug_hip_jpeg_encoder_destroy(enc)

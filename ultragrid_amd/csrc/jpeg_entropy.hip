@@ -241,13 +241,14 @@ __global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *_
 // append RSTm (or EOI after the last segment)
 __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ raw, int cap_bytes, const uint32_t *__restrict__ seg_len,
                                                       const uint32_t *__restrict__ off, int n_seg, uint8_t *__restrict__ out,
-                                                      const uint8_t *__restrict__ header, int header_len)
+                                                      const uint8_t *__restrict__ header, int header_len, size_t capacity)
 {
         if (blockIdx.x == 0) { // the first workgroup also lays down SOI .. SOS
                 for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
         }
         const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (seg >= n_seg) return;
+        if ((size_t) off[seg + 1] > capacity) return; // would not fit: the host reports the needed size from off[n_seg]
         const uint8_t *s = raw + (size_t) seg * cap_bytes;
         uint8_t *d = out + off[seg];
         const uint32_t n = seg_len[seg];
@@ -412,8 +413,8 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: bad arguments");
                 return UG_HIP_EINVAL;
         }
-        if (out_capacity < ug_hip_jpeg_encoder_max_size(enc)) {
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: output buffer smaller than ug_hip_jpeg_encoder_max_size()");
+        if (out_capacity < e->header.size() + 2) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: output buffer smaller than the JPEG header");
                 return UG_HIP_EINVAL;
         }
         hipStream_t st = (hipStream_t) stream;
@@ -451,10 +452,14 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
         hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off,
                            e->total_host_dev);
         hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->off,
-                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size());
+                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity);
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipStreamSynchronize(st));
         *out_len = *e->total_host;
+        if (*out_len > out_capacity) { // segments past the end were not written; *out_len tells the caller what it takes
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: stream does not fit the output buffer (out_len = needed size)");
+                return UG_HIP_EINVAL;
+        }
         return UG_HIP_SUCCESS;
 }
 

@@ -10,6 +10,7 @@
  * conversion (v210 / YUYV / RGB / RGBA / BGR -> UYVY: the pixfmt_conv.c arithmetic) runs on the device instead of the CPU
  * line loop of gpujpeg.cpp:592-608; tile API with one stream per module instance; no CPU fallback.
  */
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -155,7 +156,9 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 MSG(ERROR, "encoder creation failed: %s\n", ug_hip_last_error_string());
                 return false;
         }
-        s->max_out = ug_hip_jpeg_encoder_max_size(s->enc);
+        // Output capacity: the never-overflowing bound of the kernel library is ~10 B per pixel; a JPEG bigger than the raw RGB
+        // frame only comes from noise at q=100, so the pooled (pinned) frames are sized for that and an overflow drops the frame.
+        s->max_out = std::min(ug_hip_jpeg_encoder_max_size(s->enc), (size_t) desc.width * desc.height * 3 + 4096);
         bool ok = ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING) == UG_HIP_SUCCESS &&
                   ug_hip_malloc(&s->dev_out, s->max_out) == UG_HIP_SUCCESS;
         if (ok && s->wire != s->enc_in) { // staging buffer for the device-side conversion to the encoder's input format
@@ -168,7 +171,6 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         struct video_desc compressed_desc = desc;
         compressed_desc.color_spec = JPEG;
         compressed_desc.tile_count = 1;
-        // typical streams are ~10x smaller than the worst case the kernel library sizes for; the pool holds the worst case
         s->pool.reconfigure(compressed_desc, s->max_out);
         return true;
 }
