@@ -425,12 +425,7 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                                                                                                      e->cr, stream);
         } else if (in == UG_PF_RGB && e->sub == 444) { // GPUJPEG_444_U8_P012, components kept as R, G, B (gpujpeg.cpp:303-305,336)
                 if (!src_pitch) src_pitch = 3 * w;
-                int16_t *const dst[3] = { e->cy, e->cb, e->cr };
-                rc = UG_HIP_SUCCESS;
-                for (int c = 0; c < 3 && rc == UG_HIP_SUCCESS; c++) {
-                        rc = ug::jpeg_fdct_quant_strided((const uint8_t *) src_dev + c, src_pitch, 3, w, h, e->mcu_w, e->mcu_h, e->div, dst[c],
-                                                         nullptr, stream);
-                }
+                rc = ug::jpeg_fdct_quant_rgb444(src_dev, src_pitch, w, h, e->mcu_w, e->mcu_h, e->div, e->cy, e->cb, e->cr, stream);
         } else if (in == UG_PF_I420 && e->sub == 420) { // planar passthrough (GPUJPEG_420_U8_P0P1P2, gpujpeg.cpp:335): Y, U, V planes back to back
                 if (src_pitch && src_pitch != w) {
                         ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: I420 input must be tightly packed");

@@ -166,6 +166,72 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
         }
 }
 
+// Packed RGB -> three component planes' worth of blocks (4:4:4, components stay R, G, B) in one pass: a lane holds one 8x8
+// pixel block = 8 rows x 24 B in 48 registers and runs the three DCTs one after another; a wave's 64 blocks are consecutive,
+// so its row loads cover one contiguous 1.5 KiB stretch per row and its stores go through wave_store_blocks().
+// 3 B/px read + 6 B/px written.
+__global__ __launch_bounds__(256) void rgb_jpeg444_kernel(const uint8_t *__restrict__ src, int pitch, int width, int height, int blocks_w,
+                                                          long total, const float *__restrict__ div, int16_t *__restrict__ out0,
+                                                          int16_t *__restrict__ out1, int16_t *__restrict__ out2)
+{
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * 64 * kLdsPitch];
+        const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const long wave_first = idx - lane;
+        if (wave_first >= total) return; // wave-uniform
+        uint8_t *lds = lds_all + wave * 64 * kLdsPitch;
+        const long left = total - wave_first;
+        const int n_valid = left < 64 ? (int) left : 64;
+        uint32_t raw[8][6];
+        if (idx < total) {
+                const int by = (int) (idx / blocks_w), bx = (int) (idx - (long) by * blocks_w);
+                const bool interior = 8 * bx + 8 <= width && 8 * by + 8 <= height && !(pitch & 3) && !(3 & (uintptr_t) src);
+                if (interior) {
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                                const uint32_t *p = (const uint32_t *) (src + (long) (8 * by + r) * pitch + 24 * bx);
+#pragma unroll
+                                for (int k = 0; k < 6; k++) raw[r][k] = p[k];
+                        }
+                } else { // edge replication, byte by byte into the same register layout
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                                const uint8_t *row = src + (long) min(8 * by + r, height - 1) * pitch;
+#pragma unroll
+                                for (int k = 0; k < 6; k++) raw[r][k] = 0;
+#pragma unroll
+                                for (int c = 0; c < 8; c++) {
+                                        const uint8_t *px = row + 3L * min(8 * bx + c, width - 1);
+#pragma unroll
+                                        for (int comp = 0; comp < 3; comp++) {
+                                                const int bi = 3 * c + comp;
+                                                raw[r][bi >> 2] |= (uint32_t) px[comp] << (8 * (bi & 3));
+                                        }
+                                }
+                        }
+                }
+        }
+#pragma unroll
+        for (int comp = 0; comp < 3; comp++) {
+                uint32_t w[32];
+                if (idx < total) {
+                        float b[64];
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+#pragma unroll
+                                for (int c = 0; c < 8; c++) {
+                                        const int bi = 3 * c + comp;
+                                        b[8 * r + c] = (float) ((int) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff) - 128);
+                                }
+                        }
+                        fdct8x8(b);
+                        quant_pack(b, div, w);
+                }
+                wave_store_blocks(w, lds, (comp == 0 ? out0 : (comp == 1 ? out1 : out2)) + 64 * wave_first, lane, n_valid);
+                __builtin_amdgcn_wave_barrier(); // the LDS region is reused by the next component
+        }
+}
+
 // Fused UYVY -> 4:2:0 / 4:2:2 planar -> FDCT+quant.  Tasks [0, n_luma) are luma blocks (8 rows x 16 B of UYVY),
 // tasks [n_luma, n_luma + 2*n_chroma) are Cb then Cr blocks.  SUB = 420: chroma block = 16 rows x 32 B with the vertical
 // (a+b+1)/2 average of uyvy_to_i420 (to_planar.c:343-378), MCU 16x16.  SUB = 422: chroma block = 8 rows x 32 B, samples
@@ -385,6 +451,22 @@ int ug::jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int w
         const long total = (long) blocks_w * blocks_h;
         hipLaunchKernelGGL(fdct_quant_plane_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
                            (const uint8_t *) plane, pitch, xstride, width, height, blocks_w, total, div, out, coef);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+// packed RGB (3 B/px) -> quantised blocks of the R, G and B components, all with the divisors `div` (64 floats)
+int ug::jpeg_fdct_quant_rgb444(const void *src, int pitch, int width, int height, int blocks_w, int blocks_h, const float *div,
+                               int16_t *out_r, int16_t *out_g, int16_t *out_b, ug_hip_stream_t stream)
+{
+        if (!src || !div || !out_r || !out_g || !out_b || width <= 0 || height <= 0 || blocks_w * 8 < width || blocks_h * 8 < height ||
+            (15 & ((uintptr_t) out_r | (uintptr_t) out_g | (uintptr_t) out_b)) || pitch < 3 * width) {
+                ug::set_last_error_msg("jpeg_fdct_quant_rgb444: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        const long total = (long) blocks_w * blocks_h;
+        hipLaunchKernelGGL(rgb_jpeg444_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                           (const uint8_t *) src, pitch, width, height, blocks_w, total, div, out_r, out_g, out_b);
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }

@@ -56,4 +56,7 @@ static inline int linesize(ug_pixfmt_t f, int width)
 int jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width, int height, int blocks_w, int blocks_h,
                             const float *div, int16_t *out, float *coef, ug_hip_stream_t stream);
 
+int jpeg_fdct_quant_rgb444(const void *src, int pitch, int width, int height, int blocks_w, int blocks_h, const float *div,
+                           int16_t *out_r, int16_t *out_g, int16_t *out_b, ug_hip_stream_t stream);
+
 } // namespace ug
