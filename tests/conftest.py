@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Randomised-geometry tests draw the same examples on every run (no example database, no deadline): a failure found here is
+    # reproducible as-is on the GPU box.  UG_HYPOTHESIS_RANDOM=1 explores new examples.
+    try:
+        from hypothesis import settings
+        settings.register_profile("repro", derandomize=True, deadline=None, database=None, print_blob=True)
+        settings.register_profile("explore", deadline=None, database=None, print_blob=True)
+        settings.load_profile("explore" if os.environ.get("UG_HYPOTHESIS_RANDOM") else "repro")
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")
