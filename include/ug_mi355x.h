@@ -132,6 +132,9 @@ int ug_hip_yuv422_to_yuv444(const void *src, void *out, int pix_count, ug_hip_st
  * UYVY follows dxt_compress/rgba_to_yuv422.glsl.  width % 4 == 0, height % 4 == 0, dst_pitch 0 = packed. */
 int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
                       int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* Device self-test: the decoders divide by the constants 255, 31, 63, 7, 5, 3 with a multiply + two fma (correctly rounded for
+ * the numerators a DXT block can produce); this compares every such quotient with the IEEE division. *mismatches must be 0. */
+int ug_hip_selftest_dxt_decode(unsigned *mismatches, ug_hip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Pixel-format conversion, whole frame on the device (replaces the decoder_t line loop,

@@ -95,3 +95,15 @@ def test_dxt1_yuv_round_trip(hip, po):
     assert psnr > 30, psnr
     with pytest.raises(RuntimeError):
         hip.dxt_encode(L.PF_RGB, L.DXT1_YUV, torch.zeros(64 * 64 * 3, dtype=torch.uint8, device="cuda"), 64, 64)
+
+
+def test_constant_divisor_quotients_are_ieee_exact(hip):
+    """The decoders' x / {255, 31, 63, 7, 5, 3} are computed as multiply + residual fma + correction fma; the device self-test compares
+    them with the IEEE division for every numerator a DXT block can produce (all 256 x 256 alpha endpoint pairs x all table entries of
+    both interpolation modes, all 5- / 6-bit endpoint pairs and their thirds)."""
+    import ctypes as C
+    import torch
+    from ultragrid_amd import lib as L
+    n = C.c_uint(12345)
+    assert L.load().ug_hip_selftest_dxt_decode(C.byref(n), torch.cuda.current_stream().cuda_stream) == 0
+    assert n.value == 0

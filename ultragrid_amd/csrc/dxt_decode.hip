@@ -58,6 +58,21 @@ __device__ __forceinline__ void fill_unorm(float *unorm)
         }
 }
 
+
+// x / C for the constant divisors of the decoder (255, 31, 63, 7, 5, 3), correctly rounded without the generic IEEE division
+// sequence (v_div_scale x2, v_rcp, 4-5 fma, v_div_fmas, v_div_fixup): q = RN(x * RN(1/C)), one exact residual r = fma(-q, C, x),
+// one correction RN(q + r * RN(1/C)).  For these divisors and the (finite, small) sets of numerators the decoder produces the
+// result is bit-identical to x / C; that is verified exhaustively on the device by ug_hip_selftest_dxt_decode()
+// (tests/test_gpu_dxt_decode.py), not assumed.
+template <int C>
+__device__ __forceinline__ double div_const(double x)
+{
+        constexpr double rc = 1.0 / (double) C;
+        const double q = x * rc;
+        const double r = __builtin_fma(-q, (double) C, x);
+        return __builtin_fma(r, rc, q);
+}
+
 struct OutArgs {
         uint8_t *dst;
         long pitch;
@@ -108,24 +123,24 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
         unsigned long long cc = (unsigned long long) q.z | (unsigned long long) q.w << 32;
 
         // dxt62tga.c:60-62 alpha endpoints, :36-58 the two interpolation modes
-        const double a0 = (double) (ac & 0xFF) / 255.0, a1 = (double) ((ac >> 8) & 0xFF) / 255.0;
+        const double a0 = div_const<255>((double) (ac & 0xFF)), a1 = div_const<255>((double) ((ac >> 8) & 0xFF));
         lds_a[0][t] = a0;
         lds_a[1][t] = a1;
         if (a0 > a1) {
 #pragma unroll
-                for (int k = 2; k < 8; k++) lds_a[k][t] = ((double) (8 - k) * a0 + (double) (k - 1) * a1) / 7.0;
+                for (int k = 2; k < 8; k++) lds_a[k][t] = div_const<7>((double) (8 - k) * a0 + (double) (k - 1) * a1);
         } else {
 #pragma unroll
-                for (int k = 2; k < 6; k++) lds_a[k][t] = ((double) (6 - k) * a0 + (double) (k - 1) * a1) / 5.0;
+                for (int k = 2; k < 6; k++) lds_a[k][t] = div_const<5>((double) (6 - k) * a0 + (double) (k - 1) * a1);
                 lds_a[6][t] = 0.0;
                 lds_a[7][t] = 1.0;
         }
         // dxt62tga.c:63-74 colour endpoints and the two thirds; :24-27 per-entry scale / Co / Cg
         double r[4], g[4], b[4];
-        b[0] = (double) (cc & 0x1F) / 31.0;          g[0] = (double) ((cc >> 5) & 0x3F) / 63.0;  r[0] = (double) ((cc >> 11) & 0x1F) / 31.0;
-        b[1] = (double) ((cc >> 16) & 0x1F) / 31.0;  g[1] = (double) ((cc >> 21) & 0x3F) / 63.0; r[1] = (double) ((cc >> 27) & 0x1F) / 31.0;
-        b[2] = (2.0 * b[0] + b[1]) / 3.0; g[2] = (2.0 * g[0] + g[1]) / 3.0; r[2] = (2.0 * r[0] + r[1]) / 3.0;
-        b[3] = (b[0] + 2.0 * b[1]) / 3.0; g[3] = (g[0] + 2.0 * g[1]) / 3.0; r[3] = (r[0] + 2.0 * r[1]) / 3.0;
+        b[0] = div_const<31>((double) (cc & 0x1F));         g[0] = div_const<63>((double) ((cc >> 5) & 0x3F));  r[0] = div_const<31>((double) ((cc >> 11) & 0x1F));
+        b[1] = div_const<31>((double) ((cc >> 16) & 0x1F)); g[1] = div_const<63>((double) ((cc >> 21) & 0x3F)); r[1] = div_const<31>((double) ((cc >> 27) & 0x1F));
+        b[2] = div_const<3>(2.0 * b[0] + b[1]); g[2] = div_const<3>(2.0 * g[0] + g[1]); r[2] = div_const<3>(2.0 * r[0] + r[1]);
+        b[3] = div_const<3>(b[0] + 2.0 * b[1]); g[3] = div_const<3>(g[0] + 2.0 * g[1]); r[3] = div_const<3>(r[0] + 2.0 * r[1]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
                 const double scale = 1.0 / (31.875 * b[k] + 1.0);
@@ -165,13 +180,13 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
         const uint2 q = src[(long) by * bw + bx];
         const uint32_t c0 = q.x & 0xffff, c1 = q.x >> 16;
         double p[4][3];
-        p[0][0] = (double) ((c0 >> 11) & 0x1F) / 31.0; p[0][1] = (double) ((c0 >> 5) & 0x3F) / 63.0; p[0][2] = (double) (c0 & 0x1F) / 31.0;
-        p[1][0] = (double) ((c1 >> 11) & 0x1F) / 31.0; p[1][1] = (double) ((c1 >> 5) & 0x3F) / 63.0; p[1][2] = (double) (c1 & 0x1F) / 31.0;
+        p[0][0] = div_const<31>((double) ((c0 >> 11) & 0x1F)); p[0][1] = div_const<63>((double) ((c0 >> 5) & 0x3F)); p[0][2] = div_const<31>((double) (c0 & 0x1F));
+        p[1][0] = div_const<31>((double) ((c1 >> 11) & 0x1F)); p[1][1] = div_const<63>((double) ((c1 >> 5) & 0x3F)); p[1][2] = div_const<31>((double) (c1 & 0x1F));
 #pragma unroll
         for (int k = 0; k < 3; k++) {
                 if (c0 > c1) {
-                        p[2][k] = (2.0 * p[0][k] + p[1][k]) / 3.0;
-                        p[3][k] = (p[0][k] + 2.0 * p[1][k]) / 3.0;
+                        p[2][k] = div_const<3>(2.0 * p[0][k] + p[1][k]);
+                        p[3][k] = div_const<3>(p[0][k] + 2.0 * p[1][k]);
                 } else { // 3-colour + transparent-black mode (never produced by our encoder)
                         p[2][k] = (p[0][k] + p[1][k]) / 2.0;
                         p[3][k] = 0.0;
@@ -202,6 +217,41 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                 }
                 store_row<OUT>(o, 4 * by + y, bx, px, unorm);
         }
+}
+
+
+// ---- exhaustive check of div_const<> against the IEEE division on every numerator the decoders can produce ----
+__device__ __forceinline__ unsigned differs(double a, double b) { return __double_as_longlong(a) != __double_as_longlong(b) ? 1u : 0u; }
+
+__global__ void selftest_div_kernel(unsigned *mismatches)
+{
+        // one thread per (i, j) in 256 x 256
+        const int i = blockIdx.x, j = threadIdx.x;
+        unsigned bad = 0;
+        volatile double d255 = 255.0, d31 = 31.0, d63 = 63.0, d7 = 7.0, d5 = 5.0, d3 = 3.0; // keep the reference divisions real divisions
+        const double a0 = (double) i / d255, a1 = (double) j / d255;
+        bad += differs(div_const<255>((double) i), a0);
+        for (int k = 2; k < 8; k++) {
+                const double n = (double) (8 - k) * a0 + (double) (k - 1) * a1;
+                bad += differs(div_const<7>(n), n / d7);
+        }
+        for (int k = 2; k < 6; k++) {
+                const double n = (double) (6 - k) * a0 + (double) (k - 1) * a1;
+                bad += differs(div_const<5>(n), n / d5);
+        }
+        if (i < 64 && j < 64) { // 6-bit (green) endpoints and their thirds
+                const double g0 = (double) i / d63, g1 = (double) j / d63;
+                bad += differs(div_const<63>((double) i), g0);
+                bad += differs(div_const<3>(2.0 * g0 + g1), (2.0 * g0 + g1) / d3);
+                bad += differs(div_const<3>(g0 + 2.0 * g1), (g0 + 2.0 * g1) / d3);
+        }
+        if (i < 32 && j < 32) { // 5-bit (red / blue) endpoints and their thirds
+                const double b0 = (double) i / d31, b1 = (double) j / d31;
+                bad += differs(div_const<31>((double) i), b0);
+                bad += differs(div_const<3>(2.0 * b0 + b1), (2.0 * b0 + b1) / d3);
+                bad += differs(div_const<3>(b0 + 2.0 * b1), (b0 + 2.0 * b1) / d3);
+        }
+        if (bad) atomicAdd(mismatches, bad);
 }
 
 template <int OUT>
@@ -258,4 +308,26 @@ extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_d
         }
         ug::set_last_error_msg("ug_hip_dxt_decode: destination pitch not aligned for this output format");
         return UG_HIP_EINVAL;
+}
+
+// Runs the exhaustive comparison of the decoders' constant-divisor quotients with the IEEE division; *mismatches must come back 0.
+extern "C" int ug_hip_selftest_dxt_decode(unsigned *mismatches, ug_hip_stream_t stream)
+{
+        if (!mismatches) return UG_HIP_EINVAL;
+        unsigned *dev = nullptr;
+        UG_HIP_TRY(hipMalloc((void **) &dev, sizeof *dev));
+        hipStream_t st = (hipStream_t) stream;
+        hipError_t err = hipMemsetAsync(dev, 0, sizeof *dev, st);
+        if (err == hipSuccess) {
+                hipLaunchKernelGGL(selftest_div_kernel, dim3(256), dim3(256), 0, st, dev);
+                err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipMemcpyAsync(mismatches, dev, sizeof *dev, hipMemcpyDeviceToHost, st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        (void) hipFree(dev);
+        if (err != hipSuccess) {
+                ug::set_last_error(err, "ug_hip_selftest_dxt_decode");
+                return UG_HIP_ERUNTIME;
+        }
+        return UG_HIP_SUCCESS;
 }
