@@ -33,6 +33,9 @@ enum {
 void oracle_dxt5ycocg_encode_block(const float rgb[16][3], uint32_t out[4]);
 void oracle_dxt1_encode_block(const float rgb[16][3], uint32_t out[2]);
 /* h < 0: source read bottom-up. pitch = source line stride in bytes. 0 ok, -1 bad args */
+/* 0 (default): round() = roundf (CUDA port); 1: ties to even (Mesa llvmpipe's GLSL round) -- pinning aid only */
+void oracle_set_round_half_even(int on);
+void oracle_set_dot3_reverse(int on);
 int  oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                        int w, int h, long pitch);
 /* row bands over nthreads OpenMP threads (0 = all cores); cpu_baseline timing only */

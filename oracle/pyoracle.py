@@ -172,6 +172,38 @@ def dxt_decode(in_fmt: int, out_fmt: str, blocks: np.ndarray, w: int, h: int, sh
     return out
 
 
+def set_round_half_even(on: bool) -> None:
+    """GLSL round() tie direction of the encoder restatement: False = roundf (default, the CUDA port), True = ties to even (llvmpipe)."""
+    lib().oracle_set_round_half_even(1 if on else 0)
+
+
+def set_mesa_variant(on: bool) -> None:
+    """Both implementation-defined choices as Mesa llvmpipe makes them: round() ties to even, dot(vec3) summed from the last component.
+    Only for pinning the restatement against the reference's shaders executed there; off = the documented oracle."""
+    lib().oracle_set_round_half_even(1 if on else 0)
+    lib().oracle_set_dot3_reverse(1 if on else 0)
+
+
+GLSL_REF = os.path.join(_HERE, "_ref", "glsl_ref")
+
+
+def have_glsl_ref() -> bool:
+    return os.path.exists(GLSL_REF) and os.path.isdir("/root/reference/dxt_compress")
+
+
+def ref_glsl_dxt_encode(mode: str, fmt: str, src: np.ndarray, w: int, h: int) -> np.ndarray:
+    """The reference's own GLSL encoder (dxt_compress/compress_*_fp.glsl) executed by Mesa llvmpipe through oracle/_ref/glsl_ref.
+    mode: dxt5 | dxt1 | dxt1yuv ; fmt: rgb | rgba | yuv444 | uyvy."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "in.raw"), os.path.join(d, "out.bin")
+        np.ascontiguousarray(src, np.uint8).tofile(a)
+        r = subprocess.run([GLSL_REF, "/root/reference", mode, fmt, str(w), str(h), a, b], capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr)
+        return np.fromfile(b, np.uint8)
+
+
 DXT62TGA = os.path.join(_HERE, "_ref", "dxt62tga")
 
 

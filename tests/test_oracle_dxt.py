@@ -195,3 +195,78 @@ def test_round_u32_identity_used_by_the_hip_encoder():
     got = np.where(x < np.float32(0.5), 0, s.astype(np.uint32))
     want = np.floor(x.astype(np.float64) + 0.5).astype(np.uint32)  # roundf for x >= 0: half away from zero
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The pin: the reference's OWN GLSL encoders, executed by Mesa llvmpipe (oracle/glsl_ref.c), committed as
+# tests/golden/dxt_glsl_ref.npz by tests/golden/make_glsl_golden.py.
+# ---------------------------------------------------------------------------------------------------------------------
+GLSL_GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dxt_glsl_ref.npz"))
+_PIN = {"RGB": "IN_RGB", "RGBA": "IN_RGBA", "UYVY": "IN_UYVY"}
+
+
+def _glsl_cases():
+    for key in GLSL_GOLD.files:
+        if key.startswith("out_"):
+            _, kind, fmt, mode = key.split("_")
+            yield kind, fmt, mode
+
+
+def _oracle_for(po, fmt, mode, src, w, h):
+    pin = po.IN_UYVY_RAW if mode == "dxt1yuv" else getattr(po, _PIN[fmt])
+    return po.dxt_encode(pin, po.OUT_DXT5YCOCG if mode == "dxt5" else po.OUT_DXT1, src, w, h)
+
+
+@pytest.mark.parametrize("kind,fmt,mode", sorted(set(_glsl_cases())))
+def test_restatement_reproduces_the_reference_glsl_shaders(po, kind, fmt, mode):
+    """Bit-for-bit, every block: oracle/dxt_oracle.c == compress_dxt5ycocg_fp.glsl / compress_dxt1_fp.glsl (+ yuv422_to_yuv444.glsl)
+    run on llvmpipe, with the two implementation-defined GLSL choices set as Mesa makes them."""
+    w, h = (int(x) for x in GLSL_GOLD["size"])
+    src = GLSL_GOLD[f"in_{kind}_{fmt}"]
+    po.set_mesa_variant(True)
+    try:
+        got = _oracle_for(po, fmt, mode, src, w, h)
+    finally:
+        po.set_mesa_variant(False)
+    assert np.array_equal(got, GLSL_GOLD[f"out_{kind}_{fmt}_{mode}"])
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "UYVY"])
+def test_restatement_vs_reference_glsl_big_frames_and_the_tie_rule(po, fmt):
+    """4096-block uniform-random frames: identical to the shaders under Mesa's choices; under the documented oracle (roundf as in the
+    reference's CUDA port, dot() left to right) only a few blocks differ, each by one endpoint LSB (an exact .5 tie of round()) or one
+    palette index (a distance near-tie)."""
+    w, h = 512, 128
+    src = synth.s1_random(fmt, w, h, salt=77)
+    crc = int(np.sum(src.astype(np.uint64) * (np.arange(src.size, dtype=np.uint64) % 251 + 1)))
+    assert crc == int(GLSL_GOLD[f"big_{fmt}_crc"][0]), "synthetic frame generator changed: regenerate tests/golden/dxt_glsl_ref.npz"
+    for mode in ("dxt5", "dxt1"):
+        gold = GLSL_GOLD[f"big_{fmt}_{mode}"]
+        po.set_mesa_variant(True)
+        try:
+            mesa = _oracle_for(po, fmt, mode, src, w, h)
+        finally:
+            po.set_mesa_variant(False)
+        assert np.array_equal(mesa, gold), mode
+        dflt = _oracle_for(po, fmt, mode, src, w, h)
+        bs = 16 if mode == "dxt5" else 8
+        differ = np.flatnonzero((dflt.reshape(-1, bs) != gold.reshape(-1, bs)).any(axis=1))
+        assert differ.size <= 0.01 * gold.size // bs, (mode, differ.size)        # ties are rare
+        for i in differ:
+            a, b = dflt.reshape(-1, bs)[i].astype(int), gold.reshape(-1, bs)[i].astype(int)
+            changed = np.flatnonzero(a != b)
+            assert changed.size == 1 and (abs(a[changed[0]] - b[changed[0]]) == 1 or bin(a[changed[0]] ^ b[changed[0]]).count("1") <= 2), (mode, i, a, b)
+
+
+def test_live_reference_glsl_when_available(po):
+    """In the build container the shaders are run live on other geometries than the committed vectors."""
+    if not po.have_glsl_ref():
+        pytest.skip("oracle/_ref/glsl_ref or /root/reference not available")
+    po.set_mesa_variant(True)
+    try:
+        for (w, h, fmt, mode, kind) in [(4, 4, "RGB", "dxt5", "S1"), (8, 4, "UYVY", "dxt5", "S1"), (200, 36, "RGBA", "dxt1", "S2"), (132, 60, "UYVY", "dxt1yuv", "S2"),
+                                        (1920, 64, "UYVY", "dxt5", "S2"), (256, 256, "RGB", "dxt1", "S1")]:
+            src = synth.frame(kind, fmt, w, h, 9)
+            assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), po.ref_glsl_dxt_encode(mode, fmt.lower(), src, w, h)), (w, h, fmt, mode)
+    finally:
+        po.set_mesa_variant(False)
