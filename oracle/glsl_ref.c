@@ -13,6 +13,7 @@
  * no X server, no EGL, no GLEW.
  *
  * usage: glsl_ref <refdir> <dxt5|dxt1|dxt1yuv> <rgb|rgba|yuv444|uyvy> <width> <height> <in.raw> <out.bin>
+ *        glsl_ref <refdir> <dec5|dec1|dec1yuv> rgba <width> <height> <in.dxt> <out.rgba>   (the GL decoder + display shaders)
  *        (dxt1yuv = DXT_TYPE_DXT1_YUV: the DXT1 shader WITHOUT the YUV->RGB step on Y,U,V samples, dxt_encoder.c:320-323)
  *        (yuv444 = DXT_FORMAT_YUV: 4 bytes per pixel Y U V x, as the reference's RGBA upload path takes it)
  */
@@ -77,6 +78,7 @@ GLF(void, p_glClearColor, GLfloat, GLfloat, GLfloat, GLfloat);
 GLF(void, p_glClear, GLbitfield);
 GLF(void, p_glFinish, void);
 GLF(GLenum, p_glGetError, void);
+GLF(void, p_glCompressedTexImage2D, GLenum, GLint, GLenum, GLsizei, GLsizei, GLint, GLsizei, const void *);
 #define LOAD(n) do { *(void **) &p_##n = gpa(#n); if (!p_##n) { fprintf(stderr, "missing %s\n", #n); return 2; } } while (0)
 
 static int make_context(void)
@@ -112,7 +114,7 @@ static int make_context(void)
         LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus); LOAD(glViewport); LOAD(glDisable); LOAD(glGenVertexArrays);
         LOAD(glBindVertexArray); LOAD(glGenBuffers); LOAD(glBindBuffer); LOAD(glBufferData); LOAD(glGetAttribLocation);
         LOAD(glVertexAttribPointer); LOAD(glEnableVertexAttribArray); LOAD(glDrawArrays); LOAD(glDrawBuffer); LOAD(glReadBuffer);
-        LOAD(glReadPixels); LOAD(glClearColor); LOAD(glClear); LOAD(glFinish); LOAD(glGetError);
+        LOAD(glReadPixels); LOAD(glClearColor); LOAD(glClear); LOAD(glFinish); LOAD(glGetError); LOAD(glCompressedTexImage2D);
         return 0;
 }
 
@@ -196,6 +198,53 @@ static void tex_params(void)
         p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
 }
 
+/* dxt_decoder_create / dxt_decoder_decompress (dxt_compress/dxt_decoder.c:126-330,368-470): S3TC texture fetched by the fixed-function
+ * sampler, display shader, RGBA8 framebuffer, read back as bytes R,G,B,A */
+static int run_decode(const char *dir, const char *mode, int w, int h, const char *in_path, const char *out_path)
+{
+        const int dxt5 = !strcmp(mode, "dec5"), yuv = !strcmp(mode, "dec1yuv");
+        const size_t in_len = (size_t) ((w + 3) / 4 * 4) * ((h + 3) / 4 * 4) / (dxt5 ? 1 : 2);
+        uint8_t *in = (uint8_t *) malloc(in_len);
+        FILE *f = fopen(in_path, "rb");
+        if (!f || fread(in, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read %zu bytes from %s\n", in_len, in_path); return 1; }
+        fclose(f);
+        if (make_context()) return 2;
+        GLuint ctex, fbo, otex;
+        p_glGenTextures(1, &ctex);
+        p_glBindTexture(GL_TEXTURE_2D, ctex);
+        tex_params();
+        p_glCompressedTexImage2D(GL_TEXTURE_2D, 0, dxt5 ? GL_COMPRESSED_RGBA_S3TC_DXT5_EXT : GL_COMPRESSED_RGB_S3TC_DXT1_EXT, w, h, 0, (GLsizei) in_len, in);
+        p_glGenFramebuffers(1, &fbo);
+        p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+        p_glGenTextures(1, &otex);
+        p_glBindTexture(GL_TEXTURE_2D, otex);
+        tex_params();
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, w, h, 0, GL_RGBA, GL_UNSIGNED_INT_8_8_8_8_REV, 0);
+        p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, otex, 0);
+        if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) { fprintf(stderr, "framebuffer incomplete\n"); return 2; }
+        const GLuint prog = link_program(compile(GL_VERTEX_SHADER, dir, "compress_vp.glsl", 0, 0),
+                                         compile(GL_FRAGMENT_SHADER, dir, dxt5 ? "display_dxt5ycocg_fp.glsl" : (yuv ? "display_dxt1_yuv_fp.glsl" : "display_fp.glsl"), 0, 0));
+        const GLuint vao = make_vao(prog);
+        p_glViewport(0, 0, w, h);
+        p_glDisable(GL_DEPTH_TEST);
+        p_glUseProgram(prog);
+        p_glUniform1i(p_glGetUniformLocation(prog, yuv ? "yuvtex" : "_image"), 0);
+        p_glBindTexture(GL_TEXTURE_2D, ctex);
+        p_glBindVertexArray(vao);
+        p_glDrawArrays(GL_TRIANGLES, 0, 6);
+        p_glBindVertexArray(0);
+        p_glReadBuffer(GL_COLOR_ATTACHMENT0);
+        uint8_t *out = (uint8_t *) calloc(4, (size_t) w * h);
+        p_glReadPixels(0, 0, w, h, GL_RGBA, GL_UNSIGNED_INT_8_8_8_8_REV, out);
+        p_glFinish();
+        const GLenum e = p_glGetError();
+        if (e != GL_NO_ERROR) { fprintf(stderr, "GL error 0x%x\n", e); return 2; }
+        f = fopen(out_path, "wb");
+        if (!f || fwrite(out, 4, (size_t) w * h, f) != (size_t) w * h) { perror(out_path); return 1; }
+        fclose(f);
+        return 0;
+}
+
 int main(int argc, char **argv)
 {
         if (argc == 2 && !strcmp(argv[1], "probe")) {
@@ -208,6 +257,9 @@ int main(int argc, char **argv)
                 return 1;
         }
         const char *dir = argv[1];
+        if (!strncmp(argv[2], "dec", 3)) { /* <refdir> <dec5|dec1|dec1yuv> rgba <w> <h> <in.dxt> <out.rgba> */
+                return run_decode(dir, argv[2], atoi(argv[4]), atoi(argv[5]), argv[6], argv[7]);
+        }
         const int dxt5 = !strcmp(argv[2], "dxt5"), dxt1yuv = !strcmp(argv[2], "dxt1yuv");
         const char *fmt = argv[3];
         const int w = atoi(argv[4]), h = atoi(argv[5]);

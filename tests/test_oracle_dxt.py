@@ -270,3 +270,26 @@ def test_live_reference_glsl_when_available(po):
             assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), po.ref_glsl_dxt_encode(mode, fmt.lower(), src, w, h)), (w, h, fmt, mode)
     finally:
         po.set_mesa_variant(False)
+
+
+def test_decode_oracle_vs_the_reference_gl_decoder_when_available(po):
+    """Receiver side, informational bound: the reference's GL decoder (fixed-function S3TC fetch + display_*_fp.glsl, dxt_decoder.c) run
+    on Mesa llvmpipe vs the decode oracle (which is bit-equal to the reference's CPU tool cuda_dxt/dxt62tga.c).  GL leaves the S3TC
+    interpolation precision and the unorm conversions to the implementation, so this is a tolerance, not an identity."""
+    if not po.have_glsl_ref():
+        pytest.skip("oracle/_ref/glsl_ref or /root/reference not available")
+    import subprocess
+    import tempfile
+    w, h = 256, 64
+    src = synth.s2_video("UYVY", w, h)
+    for mode, enc_in, enc_out, dec_in, tol in (("dec5", po.IN_UYVY, po.OUT_DXT5YCOCG, po.OUT_DXT5YCOCG, 3), ("dec1", po.IN_UYVY, po.OUT_DXT1, po.OUT_DXT1, 2),
+                                               ("dec1yuv", po.IN_UYVY_RAW, po.OUT_DXT1, po.OUT_DXT1_YUV, 5)):
+        blocks = po.dxt_encode(enc_in, enc_out, src, w, h)
+        with tempfile.TemporaryDirectory() as d:
+            a, b = os.path.join(d, "b.dxt"), os.path.join(d, "o.rgba")
+            blocks.tofile(a)
+            subprocess.check_call([po.GLSL_REF, "/root/reference", mode, "rgba", str(w), str(h), a, b])
+            gl = np.fromfile(b, np.uint8).reshape(h, w, 4)[..., :3].astype(int)
+        ours = po.dxt_decode(dec_in, "RGB", blocks, w, h).reshape(h, w, 3).astype(int)
+        diff = np.abs(gl - ours)
+        assert diff.max() <= tol and diff.mean() < 1.0, (mode, diff.max(), diff.mean())
