@@ -12,6 +12,7 @@
  * DXT1 is standard S3TC 4-colour mode (c0 > c1 is guaranteed by the encoder,
  * compress_dxt1_fp.glsl:116-123); colour expansion /31, /63 as dxt62tga.c:63-68.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -170,10 +171,17 @@ void oracle_dxt1yuv_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
  * operation one fp32 operation, texel fetch = v / 255.0f, output = floorf(clamp01(x) * 255 + 0.5)
  * (GL's unorm8 conversions are implementation-defined to that extent: parity unpinned).
  * ---------------------------------------------------------------------------------------------- */
+/* float -> unorm8 framebuffer write.  GL rounds to nearest and leaves exact .5 ties to the implementation: default here = half up;
+ * oracle_set_unorm_ties_even(1) = ties to even, what Mesa llvmpipe does (pinning aid for tests/test_oracle_dxt.py) */
+static int g_unorm_ties_even = 0;
+void oracle_set_unorm_ties_even(int on) { g_unorm_ties_even = on; }
 static inline uint8_t unorm8_out(float x)
 {
         x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
         float t = x * 255.0f;
+        if (g_unorm_ties_even) {
+                return (uint8_t) (int) rintf(t);
+        }
         t = t + 0.5f;
         return (uint8_t) (int) t; /* t >= 0: truncation == floor */
 }

@@ -14,6 +14,7 @@
  *
  * usage: glsl_ref <refdir> <dxt5|dxt1|dxt1yuv> <rgb|rgba|yuv444|uyvy> <width> <height> <in.raw> <out.bin>
  *        glsl_ref <refdir> <dec5|dec1|dec1yuv> rgba <width> <height> <in.dxt> <out.rgba>   (the GL decoder + display shaders)
+ *        glsl_ref <refdir> rgba2uyvy rgba <width> <height> <in.rgba> <out.uyvy>            (rgba_to_yuv422.glsl alone)
  *        (dxt1yuv = DXT_TYPE_DXT1_YUV: the DXT1 shader WITHOUT the YUV->RGB step on Y,U,V samples, dxt_encoder.c:320-323)
  *        (yuv444 = DXT_FORMAT_YUV: 4 bytes per pixel Y U V x, as the reference's RGBA upload path takes it)
  */
@@ -245,6 +246,50 @@ static int run_decode(const char *dir, const char *mode, int w, int h, const cha
         return 0;
 }
 
+/* the RGBA -> 4:2:2 pass of the GL decoder alone (dxt_decoder.c:211-240,466-515, rgba_to_yuv422.glsl): in = w x h RGBA8, out = UYVY */
+static int run_rgba2uyvy(const char *dir, int w, int h, const char *in_path, const char *out_path)
+{
+        const size_t in_len = (size_t) w * h * 4;
+        uint8_t *in = (uint8_t *) malloc(in_len);
+        FILE *f = fopen(in_path, "rb");
+        if (!f || fread(in, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read %zu bytes from %s\n", in_len, in_path); return 1; }
+        fclose(f);
+        if (make_context()) return 2;
+        GLuint itex, otex, fbo;
+        p_glGenTextures(1, &itex);
+        p_glBindTexture(GL_TEXTURE_2D, itex);
+        tex_params();
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, w, h, 0, GL_RGBA, GL_UNSIGNED_INT_8_8_8_8_REV, in);
+        p_glGenTextures(1, &otex);
+        p_glBindTexture(GL_TEXTURE_2D, otex);
+        tex_params();
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, w / 2, h, 0, GL_RGBA, GL_UNSIGNED_INT_8_8_8_8_REV, 0);
+        p_glGenFramebuffers(1, &fbo);
+        p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+        p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, otex, 0);
+        if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) { fprintf(stderr, "framebuffer incomplete\n"); return 2; }
+        const GLuint prog = link_program(compile(GL_VERTEX_SHADER, dir, "compress_vp.glsl", 0, 0), compile(GL_FRAGMENT_SHADER, dir, "rgba_to_yuv422.glsl", 0, 0));
+        const GLuint vao = make_vao(prog);
+        p_glUseProgram(prog);
+        p_glUniform1i(p_glGetUniformLocation(prog, "image"), 0);
+        p_glUniform1f(p_glGetUniformLocation(prog, "imageWidth"), (GLfloat) w); /* dxt_decoder.c:243-244 */
+        p_glBindTexture(GL_TEXTURE_2D, itex);
+        p_glViewport(0, 0, w / 2, h);
+        p_glDisable(GL_DEPTH_TEST);
+        p_glBindVertexArray(vao);
+        p_glDrawArrays(GL_TRIANGLES, 0, 6);
+        p_glBindVertexArray(0);
+        p_glReadBuffer(GL_COLOR_ATTACHMENT0);
+        uint8_t *out = (uint8_t *) calloc(2, (size_t) w * h);
+        p_glReadPixels(0, 0, w / 2, h, GL_RGBA, GL_UNSIGNED_INT_8_8_8_8_REV, out);
+        p_glFinish();
+        if (p_glGetError() != GL_NO_ERROR) { fprintf(stderr, "GL error\n"); return 2; }
+        f = fopen(out_path, "wb");
+        if (!f || fwrite(out, 2, (size_t) w * h, f) != (size_t) w * h) { perror(out_path); return 1; }
+        fclose(f);
+        return 0;
+}
+
 int main(int argc, char **argv)
 {
         if (argc == 2 && !strcmp(argv[1], "probe")) {
@@ -257,6 +302,9 @@ int main(int argc, char **argv)
                 return 1;
         }
         const char *dir = argv[1];
+        if (!strcmp(argv[2], "rgba2uyvy")) { /* <refdir> rgba2uyvy rgba <w> <h> <in.rgba> <out.uyvy> */
+                return run_rgba2uyvy(dir, atoi(argv[4]), atoi(argv[5]), argv[6], argv[7]);
+        }
         if (!strncmp(argv[2], "dec", 3)) { /* <refdir> <dec5|dec1|dec1yuv> rgba <w> <h> <in.dxt> <out.rgba> */
                 return run_decode(dir, argv[2], atoi(argv[4]), atoi(argv[5]), argv[6], argv[7]);
         }

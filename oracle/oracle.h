@@ -36,6 +36,7 @@ void oracle_dxt1_encode_block(const float rgb[16][3], uint32_t out[2]);
 /* 0 (default): round() = roundf (CUDA port); 1: ties to even (Mesa llvmpipe's GLSL round) -- pinning aid only */
 void oracle_set_round_half_even(int on);
 void oracle_set_dot3_reverse(int on);
+void oracle_set_unorm_ties_even(int on); /* decode side: float -> unorm8 ties (dxt_decode_oracle.c) */
 int  oracle_dxt_encode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst,
                        int w, int h, long pitch);
 /* row bands over nthreads OpenMP threads (0 = all cores); cpu_baseline timing only */

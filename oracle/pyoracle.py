@@ -182,6 +182,7 @@ def set_mesa_variant(on: bool) -> None:
     Only for pinning the restatement against the reference's shaders executed there; off = the documented oracle."""
     lib().oracle_set_round_half_even(1 if on else 0)
     lib().oracle_set_dot3_reverse(1 if on else 0)
+    lib().oracle_set_unorm_ties_even(1 if on else 0)
 
 
 GLSL_REF = os.path.join(_HERE, "_ref", "glsl_ref")

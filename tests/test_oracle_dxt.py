@@ -293,3 +293,32 @@ def test_decode_oracle_vs_the_reference_gl_decoder_when_available(po):
         ours = po.dxt_decode(dec_in, "RGB", blocks, w, h).reshape(h, w, 3).astype(int)
         diff = np.abs(gl - ours)
         assert diff.max() <= tol and diff.mean() < 1.0, (mode, diff.max(), diff.mean())
+
+
+def test_rgba_to_yuv422_restatement_vs_the_reference_shader_when_available(po):
+    """The 4:2:2 output pass of the receiver (rgba_to_yuv422.glsl) alone, run on llvmpipe on the texels our decode oracle produces:
+    the oracle's restatement is byte-identical once the one implementation-defined choice (exact .5 ties of the float -> unorm8
+    framebuffer write: Mesa rounds to even, the oracle half up) is set Mesa's way; with the default it differs in a few bytes per
+    million, by one."""
+    if not po.have_glsl_ref():
+        pytest.skip("oracle/_ref/glsl_ref or /root/reference not available")
+    import subprocess
+    import tempfile
+    w, h = 512, 128
+    for kind, salt in (("S2", 0), ("S1", 0)):
+        blocks = po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, synth.frame(kind, "UYVY", w, h, salt), w, h)
+        rgba = po.dxt_decode(po.OUT_DXT5YCOCG, "RGBA", blocks, w, h)
+        with tempfile.TemporaryDirectory() as d:
+            a, b = os.path.join(d, "i.rgba"), os.path.join(d, "o.uyvy")
+            rgba.tofile(a)
+            subprocess.check_call([po.GLSL_REF, "/root/reference", "rgba2uyvy", "rgba", str(w), str(h), a, b])
+            gl = np.fromfile(b, np.uint8)
+        po.set_mesa_variant(True)
+        try:
+            mesa = po.dxt_decode(po.OUT_DXT5YCOCG, "UYVY", blocks, w, h)
+        finally:
+            po.set_mesa_variant(False)
+        assert np.array_equal(mesa, gl), kind
+        dflt = po.dxt_decode(po.OUT_DXT5YCOCG, "UYVY", blocks, w, h).astype(int)
+        diff = np.abs(dflt - gl.astype(int))
+        assert diff.max() <= 1 and np.count_nonzero(diff) < 1e-4 * diff.size
