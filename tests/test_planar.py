@@ -124,3 +124,17 @@ def test_gpu_uyvy_to_nv12(hip, po, w, h, seed):
     y, c = hip.uyvy_to_nv12(torch.from_numpy(np.concatenate([src, np.zeros(16, np.uint8)])).cuda(), w, h)
     wy, wc = po.uyvy_to_nv12(src, w, h)
     assert np.array_equal(y.cpu().numpy(), wy) and np.array_equal(c.cpu().numpy(), wc), (w, h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(1920, 1080), (3840, 2160), (1928, 1081), (24, 6)], ids=str)
+def test_gpu_uyvy_to_nv12_aligned_sizes(hip, po, dims):
+    """The 8-pixel fast path (width % 8 == 0), incl. a width that is not a multiple of 16 (SSE body / scalar tail boundary inside the
+    line) and an odd height."""
+    import torch
+    from ultragrid_amd import synth
+    w, h = dims
+    src = synth.s1_random("UYVY", w, h, salt=5)
+    y, c = hip.uyvy_to_nv12(torch.from_numpy(src).cuda(), w, h)
+    wy, wc = po.uyvy_to_nv12(src, w, h)
+    assert np.array_equal(y.cpu().numpy(), wy) and np.array_equal(c.cpu().numpy(), wc)

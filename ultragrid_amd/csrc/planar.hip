@@ -163,6 +163,34 @@ __global__ __launch_bounds__(256) void uyvy_to_nv12_kernel(const uint8_t *__rest
         }
 }
 
+// aligned fast path of the same: one lane = 8 pixels of a line pair (two 16 B loads, two 8 B luma stores, one 8 B CbCr store);
+// the (a + b + rnd) >> 1 of four byte lanes at once: per-byte sums cannot carry into the neighbour because the even / odd bytes are
+// averaged in separate 16-bit fields
+__global__ __launch_bounds__(256) void uyvy_to_nv12_fast_kernel(const uint8_t *__restrict__ src, long src_pitch, uint8_t *__restrict__ py, long y_pitch,
+                                                               uint8_t *__restrict__ pc, long c_pitch, int width, int height, int vec_px)
+{
+        const int cy = blockIdx.y * blockDim.y + threadIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+        const int y0 = 2 * cy;
+        if (y0 >= height || 8 * i >= width) return;
+        const int y1 = y0 + 1 < height ? y0 + 1 : y0;
+        const uint4 a = *(const uint4 *) (src + (long) y0 * src_pitch + 16 * i), b = *(const uint4 *) (src + (long) y1 * src_pitch + 16 * i);
+        const uint32_t wa[4] = { a.x, a.y, a.z, a.w }, wb[4] = { b.x, b.y, b.z, b.w };
+        const uint32_t rnd = 8 * i < vec_px ? 0x00010001u : 0u; // vec_px is a multiple of 16: the 8 pixels are on one side of it
+        uint32_t ya[2] = { 0, 0 }, yb[2] = { 0, 0 }, c[2] = { 0, 0 };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+                const uint32_t ca = wa[k] & 0x00ff00ffu, cb = wb[k] & 0x00ff00ffu;        // Cb | Cr << 16
+                const uint32_t avg = ((ca + cb + rnd) >> 1) & 0x00ff00ffu;
+                c[k >> 1] |= ((avg & 0xff) | (avg >> 8)) << (16 * (k & 1));               // Cb, Cr bytes of this pair
+                const uint32_t la = ((wa[k] >> 8) & 0xff) | ((wa[k] >> 24) << 8), lb = ((wb[k] >> 8) & 0xff) | ((wb[k] >> 24) << 8);
+                ya[k >> 1] |= la << (16 * (k & 1));
+                yb[k >> 1] |= lb << (16 * (k & 1));
+        }
+        *(uint2 *) (pc + (long) cy * c_pitch + 8 * i) = make_uint2(c[0], c[1]);
+        *(uint2 *) (py + (long) y0 * y_pitch + 8 * i) = make_uint2(ya[0], ya[1]);
+        if (y1 != y0) *(uint2 *) (py + (long) y1 * y_pitch + 8 * i) = make_uint2(yb[0], yb[1]);
+}
+
 template <int V>
 int launch_planar_to_uyvy(const Planes &p, void *dst, int dst_pitch, int width, int height, hipStream_t st)
 {
@@ -302,7 +330,15 @@ int ug_hip_uyvy_to_nv12(const void *src, int src_pitch, void *y, int y_pitch, vo
                 ug::set_last_error_msg("ug_hip_uyvy_to_nv12: source pitch must be a multiple of 4, CbCr pitch of 2");
                 return UG_HIP_EINVAL;
         }
-        const dim3 block(64, 4), grid((unsigned) ((cw + 63) / 64), (unsigned) (((height + 1) / 2 + 3) / 4));
+        const dim3 block(64, 4);
+        if (width % 8 == 0 && !(src_pitch & 15) && !(y_pitch & 7) && !(cbcr_pitch & 7) && !(15 & (uintptr_t) src) && !(7 & ((uintptr_t) y | (uintptr_t) cbcr))) {
+                const dim3 grid((unsigned) ((width / 8 + 63) / 64), (unsigned) (((height + 1) / 2 + 3) / 4));
+                hipLaunchKernelGGL(uyvy_to_nv12_fast_kernel, grid, block, 0, (hipStream_t) stream, (const uint8_t *) src, (long) src_pitch, (uint8_t *) y,
+                                   (long) y_pitch, (uint8_t *) cbcr, (long) cbcr_pitch, width, height, 16 * (width / 16));
+                UG_HIP_LAUNCH_CHECK();
+                return UG_HIP_SUCCESS;
+        }
+        const dim3 grid((unsigned) ((cw + 63) / 64), (unsigned) (((height + 1) / 2 + 3) / 4));
         hipLaunchKernelGGL(uyvy_to_nv12_kernel, grid, block, 0, (hipStream_t) stream, (const uint8_t *) src, (long) src_pitch, (uint8_t *) y,
                            (long) y_pitch, (uint8_t *) cbcr, (long) cbcr_pitch, width, height, 16 * (width / 16));
         UG_HIP_LAUNCH_CHECK();
