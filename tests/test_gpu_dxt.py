@@ -262,3 +262,42 @@ def test_hip_encoders_vs_the_reference_glsl_shaders(hip, po):
         total += eq.size
         same += int(eq.sum())
     assert total > 7000 and same / total > 0.97, (same, total)   # S3 (flat colour bars) sits on round() ties in every white block
+
+
+def test_mesa_ties_build_equals_the_reference_glsl_shaders():
+    """The same kernels built with GLSL's two implementation-defined choices taken the way Mesa makes them
+    (-DUG_DXT_GLSL_MESA_TIES: round() ties to even, dot(vec3) summed from the last component) reproduce the reference's own
+    shaders -- executed by llvmpipe, tests/golden/dxt_glsl_ref.npz -- on EVERY block, big uniform-random frames included."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "ultragrid_amd", "libug_mi355x_mesaties.so")
+    if not os.path.exists(alt):
+        pytest.skip("mesaties test build missing (run __graft_entry__.build())")
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from ultragrid_amd import codec, lib, synth
+assert "mesaties" in lib.LIB_PATH
+gold = np.load(os.path.join(%r, "tests", "golden", "dxt_glsl_ref.npz"))
+w, h = (int(x) for x in gold["size"])
+n = 0
+for key in gold.files:
+    if key.startswith("out_"):
+        _, kind, fmt, mode = key.split("_")
+        src = gold["in_%%s_%%s" %% (kind, fmt)]
+        in_l = lib.PF_UYVY_RAW if mode == "dxt1yuv" else lib.PF_NAMES[fmt]
+        got = codec.dxt_encode(in_l, lib.DXT5_YCOCG if mode == "dxt5" else lib.DXT1, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
+        assert np.array_equal(got, gold[key]), key
+        n += got.size
+for fmt in ("RGB", "UYVY"):
+    src = synth.s1_random(fmt, 512, 128, salt=77)
+    for mode in ("dxt5", "dxt1"):
+        got = codec.dxt_encode(lib.PF_NAMES[fmt], lib.DXT5_YCOCG if mode == "dxt5" else lib.DXT1, torch.from_numpy(src).cuda(), 512, 128).cpu().numpy()
+        assert np.array_equal(got, gold["big_%%s_%%s" %% (fmt, mode)]), (fmt, mode)
+        n += got.size
+print("OK", n)
+''' % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UG_MI355X_LIB=alt), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

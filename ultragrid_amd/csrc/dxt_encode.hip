@@ -37,8 +37,12 @@ __device__ __forceinline__ float clamp01(float v) { return fminf(1.0f, fmaxf(0.0
 // round up to 1.0 (x = 0.5 - 2^-25), so that range is selected to 0 explicitly.  4 instructions instead of roundf's 7.
 __device__ __forceinline__ uint32_t round_u32(float x)
 {
+#ifdef UG_DXT_GLSL_MESA_TIES // test build: GLSL round() as Mesa llvmpipe implements it (ties to even), tests/test_gpu_dxt.py
+        return (uint32_t) rintf(x);
+#else
         const uint32_t r = (uint32_t) (x + 0.5f);
         return x < 0.5f ? 0u : r;
+#endif
 }
 
 // GLSL mix(a,b,q) = a*(1-q) + b*q, w = 1-q precomputed in fp32 (cuda_dxt.cu:126-128)
@@ -524,7 +528,11 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                                 const f32x2 tx = r - cc[k][0], ty = g - cc[k][1], tz = bl - cc[k][2];
+#ifdef UG_DXT_GLSL_MESA_TIES // Mesa sums dot(vec3) from the last component
+                                d[k] = (tz * tz + ty * ty) + tx * tx;
+#else
                                 d[k] = (tx * tx + ty * ty) + tz * tz; // dot(v,v): x*x + y*y + z*z, left to right
+#endif
                         }
 #pragma unroll
                         for (int h = 1; h >= 0; h--) {
