@@ -29,6 +29,7 @@
 
 #include "debug.h"
 #include "host.h"
+#include "tv.h"
 #include "types.h"
 #include "utils/vf_split.h"
 #include "video_frame.h"
@@ -197,6 +198,7 @@ private:
                         if (r.frame) {
                                 vf_restore_metadata(r.frame.get(), metadata); // gpujpeg.cpp:188-193
                                 r.frame->seq = r.seq;
+                                r.frame->compress_end = get_time_in_ns(); // the async frame API leaves this to the module (gpujpeg.cpp:188-195)
                         }
                         deliver(std::move(r));
                         {

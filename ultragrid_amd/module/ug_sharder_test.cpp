@@ -77,6 +77,7 @@ int main(int argc, char **argv)
                         if ((unsigned char) f->tiles[t].data[4] != t) { fprintf(stderr, "tile order in %u\n", f->seq); rc = 1; }
                 }
                 if (f->compress_start != (time_ns_t) (1000 + f->seq)) { fprintf(stderr, "metadata of %u lost\n", f->seq); rc = 1; }
+                if (f->compress_end <= f->compress_start) { fprintf(stderr, "compress_end of %u not set\n", f->seq); rc = 1; }
                 last = f->seq;
                 first = false;
         }
