@@ -100,7 +100,7 @@ def test_device_resident_frames(tmp_path, po, cfg, codec):
 
 @needs_harness
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["dxt:DXT5:dev=0,0,0", "dxt:DXT1:dev=0", "jpeg:q=70:restart=3:dev=0,0"])
+@pytest.mark.parametrize("cfg", ["dxt:DXT5:dev=0,0,0", "dxt:DXT1:dev=0:workers=1", "dxt:DXT5", "jpeg:q=70:restart=3:dev=0,0:workers=2"])
 def test_frames_sharded_over_workers_in_order(tmp_path, po, cfg):
     """frames are dealt to the first idle worker (one per listed device; here one GPU listed several times, so
     several frames are in flight on it) and come back in push order with their sequence numbers, each identical to the

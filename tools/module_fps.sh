@@ -10,10 +10,10 @@ for name, fmt, w, h, n in (("4k_uyvy", "UYVY", 3840, 2160, 8), ("8k_v210", "v210
     np.concatenate([fr[i % len(fr)] for i in range(n)]).tofile(f"/tmp/{name}.raw")
 PY
 H=oracle/_ref/ug_harness
-for cfg in "dxt:DXT5:dev=0" "dxt:DXT5:dev=0,0" "dxt:DXT5:dev=0,0,0,0" "jpeg:q=75:restart=4:dev=0" "jpeg:q=75:restart=4:dev=0,0,0"; do
+for cfg in "dxt:DXT5:workers=1" "dxt:DXT5" "dxt:DXT5:workers=4" "jpeg:q=75:restart=4:workers=1" "jpeg:q=75:restart=4" "jpeg:q=75:restart=4:workers=3"; do
   echo "== $cfg  4K UYVY"; $H $cfg UYVY 3840 2160 /tmp/4k_uyvy.raw /tmp/o.bin 1 host 8 40 | grep THROUGHPUT
 done
-for cfg in "dxt:DXT5:dev=0" "dxt:DXT5:dev=0,0,0"; do
+for cfg in "dxt:DXT5:workers=1" "dxt:DXT5"; do
   echo "== $cfg  8K v210"; $H $cfg v210 7680 4320 /tmp/8k_v210.raw /tmp/o.bin 1 host 4 25 | grep THROUGHPUT
   echo "== $cfg  1080p RGB -> DXT5"; $H $cfg RGB 1920 1080 /tmp/1080_rgb.raw /tmp/o.bin 1 host 16 60 | grep THROUGHPUT
 done

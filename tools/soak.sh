@@ -7,7 +7,7 @@ from ultragrid_amd import synth
 fr = [synth.s2_video("UYVY", 3840, 2160, salt=i) for i in range(2)]
 np.concatenate([fr[i % 2] for i in range(8)]).tofile("/tmp/4k.raw")
 PY
-for cfg in "dxt:DXT5:dev=0,0" "jpeg:q=75:restart=4:dev=0,0"; do
+for cfg in ${CFGS:-"dxt:DXT5:workers=1" "dxt:DXT5" "jpeg:q=75:restart=4:workers=1" "jpeg:q=75:restart=4"}; do
   oracle/_ref/ug_harness $cfg UYVY 3840 2160 /tmp/4k.raw /tmp/o.bin 1 host 8 ${REPEAT:-400} > /tmp/h.log 2>&1 &
   pid=$!
   peak=0

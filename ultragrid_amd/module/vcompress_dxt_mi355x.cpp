@@ -95,7 +95,7 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]]\n"
+               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>]\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
                "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n");
 }

@@ -67,7 +67,7 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:dev=<index>]\n"
+               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:dev=<index>[,<index>...]][:workers=<per device>]\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the input: 422 for UYVY/YUYV/v210, 444 (R,G,B components)\n"
                "\t\t              for RGB/RGBA/BGR, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
 }
