@@ -135,6 +135,9 @@ int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *d
 /* Device self-test: the decoders divide by the constants 255, 31, 63, 7, 5, 3 with a multiply + two fma (correctly rounded for
  * the numerators a DXT block can produce); this compares every such quotient with the IEEE division. *mismatches must be 0. */
 int ug_hip_selftest_dxt_decode(unsigned *mismatches, ug_hip_stream_t stream);
+/* Same for the encoder: x / 14.0f as multiply + two fma, compared with the IEEE division for x = 0 and every fp32 x in [2^-100, 1] (smaller
+ * values take the division itself). */
+int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Pixel-format conversion, whole frame on the device (replaces the decoder_t line loop,

@@ -301,3 +301,14 @@ print("OK", n)
 ''' % (root, root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UG_MI355X_LIB=alt), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_encoder_strength_reductions_are_ieee_exact(hip):
+    """div14(): x / 14.0f as multiply + two fma, compared on the device with the IEEE division for x = 0 and EVERY fp32 bit pattern in
+    [2^-100, 1]: zero mismatches (the kernel routes the sliver (0, 2^-100), where the quotient goes denormal, to the division itself)."""
+    import ctypes as C
+    import torch
+    from ultragrid_amd import lib as L
+    n = C.c_uint(777)
+    assert L.load().ug_hip_selftest_dxt_encode(C.byref(n), torch.cuda.current_stream().cuda_stream) == 0
+    assert n.value == 0

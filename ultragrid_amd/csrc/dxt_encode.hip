@@ -45,6 +45,19 @@ __device__ __forceinline__ uint32_t round_u32(float x)
 #endif
 }
 
+// x / 14.0f without the IEEE division sequence (v_div_scale x2, v_rcp, v_div_fmas, v_div_fixup + 4 fma: five of them on the slow
+// pipe, the reciprocal at quarter rate): q = RN(x * RN(1/14)), exact residual, one correction.  Bit-identical to the division for
+// x = 0 and EVERY fp32 x in [2^-100, 1], checked exhaustively on the device (ug_hip_selftest_dxt_encode); below 2^-125 the
+// quotient is denormal and the residual no longer exact, so callers route (0, 2^-100) to the real division.
+constexpr uint32_t kDiv14Exact = 0x0d800000u; // bits of 2^-100
+__device__ __forceinline__ float div14(float x)
+{
+        constexpr float rc = 1.0f / 14.0f;
+        const float q = x * rc;
+        const float r = __builtin_fmaf(-q, 14.0f, x);
+        return __builtin_fmaf(r, rc, q);
+}
+
 // GLSL mix(a,b,q) = a*(1-q) + b*q, w = 1-q precomputed in fp32 (cuda_dxt.cu:126-128)
 __device__ __forceinline__ float lerp_w(float a, float b, float w, float q)
 {
@@ -340,7 +353,18 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
         // EmitAlphaIndicesYCoCgDXT5 (glsl:262-312): count c = #{k : a <= ab_k}, index = f(c).
         {
                 const float inv7 = (float) (1.0 / 7.0);
-                const float mid = (mxY - mnY) / 14.0f; // IEEE division (not a power of two)
+                // (mxY - mnY) / 14.0f.  div14() is bit-identical to the division for x = 0 and for every x >= 2^-100 (exhaustive
+                // device self-test); differences of byte-derived luma never fall in between, but the contract does not rest
+                // on that: a wave that sees such a value takes the IEEE division.
+                const float range = mxY - mnY;
+#ifdef UG_DXT_IEEE_DIV14 // A/B switch: the plain division
+                const float mid = range / 14.0f;
+#else
+                float mid = div14(range);
+                if (__builtin_expect(__any((__float_as_uint(range) - 1u) < (kDiv14Exact - 1u)), 0)) {
+                        mid = range / 14.0f;
+                }
+#endif
                 float ab[8];
                 ab[1] = mnY + mid;
 #pragma unroll
@@ -624,6 +648,17 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
         }
 }
 
+// exhaustive check of div14() against the IEEE division over x = 0 and every fp32 bit pattern in [2^-100, 1]
+__global__ void selftest_div14_kernel(unsigned *mismatches)
+{
+        const unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (i > 0x3f800000ull || (i != 0 && i < kDiv14Exact)) return;
+        const float x = __uint_as_float((unsigned) i);
+        volatile float d = 14.0f;
+        const float want = x / d;
+        if (__float_as_uint(div14(x)) != __float_as_uint(want)) atomicAdd(mismatches, 1u);
+}
+
 template <int IN, int OUT>
 int launch(const void *src, void *dst, int w, int h, int pitch, int frames, size_t sfs, size_t dfs, hipStream_t st)
 {
@@ -773,3 +808,25 @@ int ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *
 }
 
 } // extern "C"
+
+// Device self-test of the encoder's exact strength reductions (div14): *mismatches must come back 0.
+extern "C" int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream)
+{
+        if (!mismatches) return UG_HIP_EINVAL;
+        unsigned *dev = nullptr;
+        UG_HIP_TRY(hipMalloc((void **) &dev, sizeof *dev));
+        hipStream_t st = (hipStream_t) stream;
+        hipError_t err = hipMemsetAsync(dev, 0, sizeof *dev, st);
+        if (err == hipSuccess) {
+                hipLaunchKernelGGL(selftest_div14_kernel, dim3((0x3f800000u >> 8) + 1), dim3(256), 0, st, dev);
+                err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipMemcpyAsync(mismatches, dev, sizeof *dev, hipMemcpyDeviceToHost, st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        (void) hipFree(dev);
+        if (err != hipSuccess) {
+                ug::set_last_error(err, "ug_hip_selftest_dxt_encode");
+                return UG_HIP_ERUNTIME;
+        }
+        return UG_HIP_SUCCESS;
+}
