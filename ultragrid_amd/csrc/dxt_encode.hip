@@ -376,13 +376,24 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 // count is a 3-step binary search (3 compares + 4 selects instead of 7 compares + 7 adds); it is
                 // the SAME function of (a, ab[]) as the reference's linear count, so results stay bit-identical.
                 const float T1 = ab[1], T2 = ab[7], T3 = ab[6], T4 = ab[5], T5 = ab[4], T6 = ab[3], T7 = ab[2];
-                const bool mono = (T1 <= T2) & (T2 <= T3) & (T3 <= T4) & (T4 <= T5) & (T5 <= T6) & (T6 <= T7);
+                // Monotone for sure when the clamped range exceeds 2^-10: consecutive thresholds are range/7 apart in exact
+                // arithmetic and each carries < 2^-22 of rounding error (operands <= 7, results <= 1), so 2^-10/7 of spacing
+                // cannot be overturned.  After the inset the range is >= 16/255/16 unless both ends clamp to the same bound,
+                // so one compare decides for practically every block; only a wave that sees a narrower range evaluates the six
+                // explicit comparisons.
+                bool all_mono;
+                if (__builtin_expect(__all(range > 0.0009765625f), 1)) {
+                        all_mono = true;
+                } else {
+                        asm volatile("; explicit monotonicity check" ::: "memory");
+                        all_mono = __all((T1 <= T2) & (T2 <= T3) & (T3 <= T4) & (T4 <= T5) & (T5 <= T6) & (T6 <= T7));
+                }
                 // raw counts, 3 bits per pixel: lo = px 0..9 (30 bits), hi = px 10..15 (18 bits)
                 uint32_t lo = 0, hi = 0;
 #ifdef UG_FORCE_ALPHA_LINEAR // test build: always take the reference-form path (tests/test_gpu_dxt.py)
-                if (__all(mono) && lo == 0xffffffffu) {
+                if (all_mono && lo == 0xffffffffu) {
 #else
-                if (__builtin_expect(__all(mono), 1)) {
+                if (__builtin_expect(all_mono, 1)) {
 #endif
 #pragma unroll
                         for (int i = 15; i >= 0; i--) {
