@@ -22,6 +22,10 @@
 // byte is read by exactly one lane.
 #include "ug_common.h"
 
+#ifndef UG_DXT_TBUF
+#define UG_DXT_TBUF 1 // typed buffer loads do the byte -> float conversion (0: v_cvt_f32_ubyte in the shader; A/B switch)
+#endif
+
 namespace {
 
 constexpr float kInv255  = 0.00392156862745f;           // cuda_dxt.cu:666
@@ -155,12 +159,9 @@ struct Loader3 {
                 }
         }
 };
-template <> struct Loader<UG_PF_RGB> : Loader3<false> {};
-template <> struct Loader<UG_PF_YUV444> : Loader3<true> {};
 
 // ---- RGBA: 16 B per block row, alpha ignored (compress_dxt1_fp.glsl:41 reads .rgb) ----
-template <>
-struct Loader<UG_PF_RGBA> {
+struct LoaderRGBAWords {
         static constexpr int kBlocks = 1;
         uint4 w[4];
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
@@ -217,8 +218,68 @@ struct LoaderUYVY {
                 }
         }
 };
+#if UG_DXT_TBUF
+// Same, but the texture-address unit does the byte -> float conversion: typed buffer loads with format 8_8_8_8 USCALED return
+// float(byte) for the four bytes of a word (exact), so the 32 v_cvt_f32_ubyte of a block -- slow-pipe VALU work -- disappear; the
+// multiplication by kInv255 stays in the shader arithmetic.  Costs 24 more VGPRs (the raw block is held as 32 floats).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <bool CONVERT>
+struct LoaderUYVYTyped {
+        static constexpr int kBlocks = 1;
+        f32x4 f[4][2];
+        __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
+        {
+                const uint64_t base = (uint64_t) src;
+                // V#: base, stride 0, num_records = max, dst_sel xyzw = R G B A, data format 8_8_8_8, type buffer
+                const i32x4 desc = { (int) (uint32_t) base, (int) ((uint32_t) (base >> 32) & 0xffffu), -1, 0x52FAC };
+                uint32_t off[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) off[r] = (uint32_t) rows[r] * pitch + unit_x * 8u;
+                asm volatile("tbuffer_load_format_xyzw %0, %8, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen\n"
+                             "tbuffer_load_format_xyzw %1, %8, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen offset:4\n"
+                             "tbuffer_load_format_xyzw %2, %9, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen\n"
+                             "tbuffer_load_format_xyzw %3, %9, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen offset:4\n"
+                             "tbuffer_load_format_xyzw %4, %10, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen\n"
+                             "tbuffer_load_format_xyzw %5, %10, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen offset:4\n"
+                             "tbuffer_load_format_xyzw %6, %11, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen\n"
+                             "tbuffer_load_format_xyzw %7, %11, %12, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_USCALED] offen offset:4\n"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(f[0][0]), "=&v"(f[0][1]), "=&v"(f[1][0]), "=&v"(f[1][1]), "=&v"(f[2][0]), "=&v"(f[2][1]), "=&v"(f[3][0]), "=&v"(f[3][1])
+                             : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(desc)
+                             : "memory");
+        }
+        __device__ __forceinline__ void block(int, Px16 &p) const
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                                const float u = f[r][k].x * kInv255, y0 = f[r][k].y * kInv255;
+                                const float v = f[r][k].z * kInv255, y1 = f[r][k].w * kInv255;
+                                const int i = 4 * r + 2 * k;
+                                if (CONVERT) {
+                                        yuv_pair_to_rgb(y0, y1, u, v, p, i);
+                                } else {
+                                        p.a[i] = y0; p.b[i] = u; p.c[i] = v;
+                                        p.a[i + 1] = y1; p.b[i + 1] = u; p.c[i + 1] = v;
+                                }
+                        }
+                }
+        }
+};
+template <> struct Loader<UG_PF_UYVY> : LoaderUYVYTyped<true> {};
+template <> struct Loader<UG_PF_UYVY_RAW> : LoaderUYVYTyped<false> {};
+
+#else
 template <> struct Loader<UG_PF_UYVY> : LoaderUYVY<true> {};
 template <> struct Loader<UG_PF_UYVY_RAW> : LoaderUYVY<false> {};
+#endif
+// RGB / YUV444 / RGBA keep word loads: measured with typed loads RGBA is equal and RGB (three 4-byte typed loads per 12-byte row) twice
+// as slow -- the address unit, not the VALU, becomes the limit.
+template <> struct Loader<UG_PF_RGB> : Loader3<false> {};
+template <> struct Loader<UG_PF_YUV444> : Loader3<true> {};
+template <> struct Loader<UG_PF_RGBA> : LoaderRGBAWords {};
 
 // ---- v210: 12 px = 3 blocks = 32 B per row.  The 10-bit samples come in UYVY order, three
 // per little-endian word; the reference converts to 8-bit UYVY by >>2 first
