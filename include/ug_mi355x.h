@@ -178,6 +178,44 @@ int ug_hip_uyvy_to_i422(const void *src_dev, int src_pitch, void *y_dev, int y_p
 int ug_hip_uyvy_to_nv12(const void *src_dev, int src_pitch, void *y_dev, int y_pitch, void *cbcr_dev, int cbcr_pitch,
                         int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
 
+/* The whole of src/from_planar.h and src/to_planar.h by the reference's own function names (these are the
+ * building blocks of libavcodec/{from,to}_lavc_vid_conv.c).  The structs repeat the reference's field for field, all pointers
+ * are device pointers:
+ *   struct ug_from_planar_data == struct from_planar_data (from_planar.h:58-70); `func` = a decode_planar_func_t name (:86-113):
+ *     gbrap_to_rgb gbrap_to_rgba gbrp{10,12,16}le_to_{rgb,rgba,rg48,r10k} gbrp{12,16}le_to_r12l rgbpXX_to_rgb
+ *     rgbpXXle_to_{rg48,r10k,r12l} yuv444p_to_vuya yuv420p_to_uyvy yuv420_to_i420 yuv422p_to_uyvy yuv422p_to_yuyv
+ *     yuv422pXX_to_uyvy yuv422p10le_to_uyvy yuv422p10le_to_v210
+ *   struct ug_to_planar_data == struct to_planar_data (to_planar.h:53-59); `func` = a decode_buffer_func_t name (:65-74):
+ *     v210_to_p010le y216_to_p010le uyvy_to_nv12 rgba_to_bgra vuya_to_i444 uyvy_to_i420 r12l_to_gbrp12le r12l_to_gbrp16le
+ *     r12l_to_rgbp12le            (the packed source is vc_get_linesize(width, codec) per line, as the reference assumes)
+ * Same results as the reference byte for byte, including its habits: no masking of bits above the nominal depth,
+ * gbrap_to_rgb[a] striding every plane by in_linesize[0], R12L groups written whole.  Differences, both on the safe side:
+ * samples past `width` in the last R12L group are taken as 0 (the reference packs uninitialised stack there), and
+ * r12l_to_* writes only the samples inside the picture (the reference writes the whole last group of 8).
+ * Unknown name or unusable geometry -> UG_HIP_EINVAL. */
+struct ug_from_planar_data {
+        int width;
+        int height;
+        void *out_data;
+        unsigned out_pitch;
+        const void *in_data[4];
+        unsigned in_linesize[4];
+        int in_depth;      /* for the XX conversions */
+        int log2_chroma_h; /* unused here (the reference needs it for its row-band threading only) */
+        int rgb_shift[3];  /* *_to_rgba only */
+};
+struct ug_to_planar_data {
+        int width;
+        int height;
+        void *out_data[4];
+        unsigned out_linesize[4];
+        const void *in_data;
+};
+int ug_hip_from_planar(const char *func, const struct ug_from_planar_data *d, ug_hip_stream_t stream);
+int ug_hip_to_planar(const char *func, const struct ug_to_planar_data *d, ug_hip_stream_t stream);
+int ug_hip_from_planar_supported(const char *func); /* 1 / 0 */
+int ug_hip_to_planar_supported(const char *func);
+
 /* ------------------------------------------------------------------------------------
  * JPEG: 8x8 forward DCT + quantisation (the stage libgpujpeg provides behind
  * gpujpeg_encoder_encode, src/video_compress/gpujpeg.cpp:624)

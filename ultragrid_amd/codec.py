@@ -6,6 +6,8 @@ they stand in for (cuda_dxt.h, pixfmt_conv.h decoder_t loop, to_planar.h).
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import lib as L
@@ -150,6 +152,48 @@ def uyvy_to_nv12(src: torch.Tensor, w: int, h: int, src_pitch: int = 0):
     rc = L.load().ug_hip_uyvy_to_nv12(src.data_ptr(), src_pitch, y.data_ptr(), w, c.data_ptr(), 2 * cw, w, h, _stream())
     L.check(rc, "ug_hip_uyvy_to_nv12")
     return y, c
+
+
+class FromPlanarData(C.Structure):
+    """struct ug_from_planar_data (include/ug_mi355x.h) == struct from_planar_data (from_planar.h:58-70)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("out_data", C.c_void_p), ("out_pitch", C.c_uint),
+                ("in_data", C.c_void_p * 4), ("in_linesize", C.c_uint * 4), ("in_depth", C.c_int), ("log2_chroma_h", C.c_int),
+                ("rgb_shift", C.c_int * 3)]
+
+
+class ToPlanarData(C.Structure):
+    """struct ug_to_planar_data == struct to_planar_data (to_planar.h:53-59)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("out_data", C.c_void_p * 4), ("out_linesize", C.c_uint * 4),
+                ("in_data", C.c_void_p)]
+
+
+def from_planar(func: str, planes, w: int, h: int, out: torch.Tensor, out_pitch: int, in_depth: int = 0, rgb_shift=(0, 8, 16)) -> torch.Tensor:
+    """`func` = a decode_planar_func_t name of from_planar.h; planes = 2-D device tensors (uint8, or int16/uint16 holding the samples);
+    `out` = preallocated uint8 device tensor.  The line sizes are the tensors' row strides."""
+    d = FromPlanarData()
+    d.width, d.height = w, h
+    d.out_data, d.out_pitch = out.data_ptr(), out_pitch
+    for i, p in enumerate(planes):
+        d.in_data[i] = p.data_ptr()
+        d.in_linesize[i] = p.stride(0) * p.element_size()
+    d.in_depth = in_depth
+    d.rgb_shift[0], d.rgb_shift[1], d.rgb_shift[2] = rgb_shift
+    rc = L.load().ug_hip_from_planar(func.encode(), C.byref(d), _stream())
+    L.check(rc, f"ug_hip_from_planar({func})")
+    return out
+
+
+def to_planar(func: str, src: torch.Tensor, w: int, h: int, planes) -> list:
+    """`func` = a decode_buffer_func_t name of to_planar.h; planes = preallocated 2-D device tensors"""
+    d = ToPlanarData()
+    d.width, d.height = w, h
+    for i, p in enumerate(planes):
+        d.out_data[i] = p.data_ptr()
+        d.out_linesize[i] = p.stride(0) * p.element_size()
+    d.in_data = src.data_ptr()
+    rc = L.load().ug_hip_to_planar(func.encode(), C.byref(d), _stream())
+    L.check(rc, f"ug_hip_to_planar({func})")
+    return list(planes)
 
 
 def jpeg_divisors_device(quality: int, device) -> torch.Tensor:

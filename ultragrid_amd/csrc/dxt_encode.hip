@@ -768,6 +768,7 @@ int launch_out(ug_dxt_t out, const void *src, void *dst, int w, int h, int pitch
         switch (out) {
         case UG_DXT1: return launch<IN, UG_DXT1>(src, dst, w, h, pitch, frames, sfs, dfs, st);
         case UG_DXT5_YCOCG: return launch<IN, UG_DXT5_YCOCG>(src, dst, w, h, pitch, frames, sfs, dfs, st);
+        default: break; // UG_DXT1_YUV is rewritten to UG_DXT1 over raw UYVY by the caller
         }
         return UG_HIP_EUNSUPP;
 }

@@ -62,6 +62,10 @@ SYMBOLS = {
     "ug_hip_selftest_dxt_decode": (_i, [C.POINTER(C.c_uint), _vp]),
     "ug_hip_selftest_dxt_encode": (_i, [C.POINTER(C.c_uint), _vp]),
     "ug_hip_uyvy_to_nv12": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_from_planar": (_i, [C.c_char_p, _vp, _vp]),
+    "ug_hip_to_planar": (_i, [C.c_char_p, _vp, _vp]),
+    "ug_hip_from_planar_supported": (_i, [C.c_char_p]),
+    "ug_hip_to_planar_supported": (_i, [C.c_char_p]),
     "ug_hip_jpeg_qtable": (None, [_i, _i, _vp]),
     "ug_hip_jpeg_divisors": (None, [_vp, _vp]),
     "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
