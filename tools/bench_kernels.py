@@ -187,6 +187,36 @@ def main():
             assert l.ug_hip_dxt_decode(oid, L.PF_NAMES[outf], blocks.data_ptr() + j * per, dd.data_ptr(), w, h, 0, 0, 8, 16, st) == 0
         add(f"dxt_decode {name}->{outf}", w, h, 1, bpp, timeit(run_dec, iters=3 * n))
         del blocks
+    # from_planar.h / to_planar.h by name (planar_api.hip): 4K, rotating 4 plane sets so L2 does not hold the input
+    NP = 4
+    g16 = [[torch.randint(0, 4096, (h, w), dtype=torch.int16, device="cuda") for _ in range(3)] for _ in range(NP)]
+    g8 = [[torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda") for _ in range(4)] for _ in range(NP)]
+    c16 = [[torch.randint(0, 1024, (h, w), dtype=torch.int16, device="cuda")] + [torch.randint(0, 1024, (h, w // 2), dtype=torch.int16, device="cuda") for _ in range(2)] for _ in range(NP)]
+    for func, planes, depth, out_bpp, in_bpp in (
+            ("gbrp12le_to_rgb", g16, 0, 3, 6), ("gbrp12le_to_rgba", g16, 0, 4, 6), ("gbrp12le_to_rg48", g16, 0, 6, 6),
+            ("gbrp12le_to_r10k", g16, 0, 4, 6), ("gbrp12le_to_r12l", g16, 0, 4.5, 6), ("gbrap_to_rgba", g8, 0, 4, 4),
+            ("gbrap_to_rgb", g8, 0, 3, 3), ("yuv444p_to_vuya", g8, 0, 4, 3), ("yuv422p10le_to_uyvy", c16, 0, 2, 4), ("yuv422p_to_yuyv", None, 0, 2, 2)):
+        if planes is None:
+            planes = [[yy, uu, vv]] * NP
+        pitch = int(out_bpp * w)
+        outb = torch.empty((h, pitch), dtype=torch.uint8, device="cuda")
+
+        def run_fp():
+            j = k[0] % NP; k[0] += 1
+            codec.from_planar(func, planes[j], w, h, outb, pitch, depth)
+        add(f"from_planar {func}", w, h, 1, in_bpp + out_bpp, timeit(run_fp, iters=40))
+    r12 = [torch.randint(0, 256, (h, w // 8 * 36), dtype=torch.uint8, device="cuda") for _ in range(NP)]
+    p16 = [torch.empty((h, w), dtype=torch.int16, device="cuda") for _ in range(3)]
+    rg = [torch.randint(0, 256, (h, 4 * w), dtype=torch.uint8, device="cuda") for _ in range(NP)]
+    p8 = [torch.empty((h, w), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    y2 = [torch.randint(0, 256, (h, 4 * w), dtype=torch.uint8, device="cuda") for _ in range(NP)]  # Y216: 4 B / px
+    for func, srcs, outs, in_bpp, out_bpp in (
+            ("r12l_to_gbrp12le", r12, p16, 4.5, 6), ("r12l_to_gbrp16le", r12, p16, 4.5, 6), ("rgba_to_bgra", rg, [torch.empty((h, 4 * w), dtype=torch.uint8, device="cuda")], 4, 4),
+            ("vuya_to_i444", rg, p8, 4, 3), ("y216_to_p010le", y2, [p16[0], torch.empty((h // 2, w), dtype=torch.int16, device="cuda")], 4, 3)):
+        def run_tp():
+            j = k[0] % NP; k[0] += 1
+            codec.to_planar(func, srcs[j], w, h, outs)
+        add(f"to_planar {func}", w, h, 1, in_bpp + out_bpp, timeit(run_tp, iters=40))
     if args.json:
         json.dump(rows, open(args.json, "w"), indent=1)
 
