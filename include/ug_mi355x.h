@@ -216,6 +216,36 @@ int ug_hip_to_planar(const char *func, const struct ug_to_planar_data *d, ug_hip
 int ug_hip_from_planar_supported(const char *func); /* 1 / 0 */
 int ug_hip_to_planar_supported(const char *func);
 
+/* The pixel-format converters of src/libavcodec/to_lavc_vid_conv.c and from_lavc_vid_conv.c -- the work the
+ * reference reserves a GPU hook for (to_lavc_vid_conv_cuda.h:55-66 `to_lavc_vid_conv_cuda`, from_lavc_vid_conv_cuda.h:55-66
+ * `av_to_uv_convert_cuda`; both return NULL there).  Formats are named as the reference names them: UltraGrid codecs by
+ * get_codec_name() ("UYVY", "v210", "RGB", "RGBA", "R10k", ...), frame formats by av_get_pix_fmt_name() ("yuv420p", "yuv422p10le",
+ * "nv12", "p010le", "gbrp", "xv30le", ...; FFmpeg's enum values are not used, so nothing here needs its headers).
+ * struct ug_av_frame carries the AVFrame fields the reference converters read: data, linesize, width, height, colorspace,
+ * color_range (numeric values as in libavutil/pixfmt.h: AVCOL_SPC_BT709 1, BT470BG 5, SMPTE170M 6, SMPTE240M 7; AVCOL_RANGE_JPEG 2).
+ *   ug_hip_uv_to_av   to_lavc_vid_conv(): rows of get_uv_to_av_conversion's table (to_lavc_vid_conv.c:1458-1529) for UYVY, v210, RGB, RGBA;
+ *                     `in_data` is vc_get_linesize(width, codec) per line, `out` holds the (device) planes to fill
+ *   ug_hip_av_to_uv   av_to_uv_convert(): rows of av_to_uv_conversions (from_lavc_vid_conv.c:2049-2172) whose output is UYVY, v210, RGB,
+ *                     RGBA, R10k (+ the from_planar rows); YCbCr -> RGB picks BT.601 / BT.709 and limited / full range from the
+ *                     frame as get_cs_for_conv does (:2614-2658)
+ * Results equal the reference functions' byte for byte, slips included (listed in csrc/lavc_conv.hip).  No row: UG_HIP_EUNSUPP. */
+struct ug_av_frame {
+        void *data[4];
+        int linesize[4];
+        int width;
+        int height;
+        int colorspace;
+        int color_range;
+};
+int ug_hip_uv_to_av(const char *uv_codec, const char *av_pixfmt, const void *in_data_dev, const struct ug_av_frame *out, ug_hip_stream_t stream);
+int ug_hip_av_to_uv(const char *av_pixfmt, const char *uv_codec, void *dst_dev, int pitch, const struct ug_av_frame *in, const int rgb_shift[3],
+                    ug_hip_stream_t stream);
+int ug_hip_uv_to_av_supported(const char *uv_codec, const char *av_pixfmt); /* 1 / 0 */
+int ug_hip_av_to_uv_supported(const char *av_pixfmt, const char *uv_codec);
+/* get_color_coeffs(cs, depth) (color_space.c:149-184): cs 1 = BT.601, 2 = BT.709; depth 0 (full range), 8, 10, 12, 16; out = the 14 fields
+ * of struct color_coeffs in declaration order */
+int ug_hip_color_coeffs(int cs, int depth, int out[14]);
+
 /* ------------------------------------------------------------------------------------
  * JPEG: 8x8 forward DCT + quantisation (the stage libgpujpeg provides behind
  * gpujpeg_encoder_encode, src/video_compress/gpujpeg.cpp:624)

@@ -1,0 +1,1 @@
+#include "ug_lavc_stub.h"

@@ -41,7 +41,8 @@ def build(force: bool = False) -> None:
         for f in os.listdir(_HERE) if f.endswith((".c", ".h"))
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
-    if os.path.isdir("/root/reference/src") and (force or not have_ref() or not os.path.exists(os.path.join(_HERE, "_ref", "glsl_ref"))):
+    if os.path.isdir("/root/reference/src") and (force or not have_ref() or not os.path.exists(os.path.join(_HERE, "_ref", "glsl_ref"))
+                                                 or not os.path.exists(os.path.join(_HERE, "_ref", "libugref_lavc.so"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 

@@ -196,6 +196,39 @@ def to_planar(func: str, src: torch.Tensor, w: int, h: int, planes) -> list:
     return list(planes)
 
 
+class AvFrame(C.Structure):
+    """struct ug_av_frame (include/ug_mi355x.h): the AVFrame fields the lavc converters read"""
+    _fields_ = [("data", C.c_void_p * 4), ("linesize", C.c_int * 4), ("width", C.c_int), ("height", C.c_int),
+                ("colorspace", C.c_int), ("color_range", C.c_int)]
+
+
+def _av_frame(planes, w: int, h: int, colorspace: int = 2, color_range: int = 1) -> AvFrame:
+    f = AvFrame()
+    for i, p in enumerate(planes):
+        f.data[i] = p.data_ptr()
+        f.linesize[i] = p.stride(0) * p.element_size()
+    f.width, f.height, f.colorspace, f.color_range = w, h, colorspace, color_range
+    return f
+
+
+def uv_to_av(uv_codec: str, av_pixfmt: str, src: torch.Tensor, w: int, h: int, planes) -> list:
+    """to_lavc_vid_conv(): `planes` = preallocated 2-D device tensors (rows x bytes-or-samples) of the output frame"""
+    f = _av_frame(planes, w, h)
+    rc = L.load().ug_hip_uv_to_av(uv_codec.encode(), av_pixfmt.encode(), src.data_ptr(), C.byref(f), _stream())
+    L.check(rc, f"ug_hip_uv_to_av({uv_codec}, {av_pixfmt})")
+    return list(planes)
+
+
+def av_to_uv(av_pixfmt: str, uv_codec: str, planes, w: int, h: int, dst: torch.Tensor, pitch: int, rgb_shift=(0, 8, 16),
+             colorspace: int = 2, color_range: int = 1) -> torch.Tensor:
+    """av_to_uv_convert(): decoder frame (2-D device tensors) -> packed UltraGrid buffer `dst`"""
+    f = _av_frame(planes, w, h, colorspace, color_range)
+    sh = (C.c_int * 3)(*rgb_shift)
+    rc = L.load().ug_hip_av_to_uv(av_pixfmt.encode(), uv_codec.encode(), dst.data_ptr(), pitch, C.byref(f), sh, _stream())
+    L.check(rc, f"ug_hip_av_to_uv({av_pixfmt}, {uv_codec})")
+    return dst
+
+
 def jpeg_divisors_device(quality: int, device) -> torch.Tensor:
     """128 fp32 divisors (luma, chroma) in device memory."""
     import ctypes as C

@@ -1,0 +1,702 @@
+// lavc_conv.hip -- SURVEY.md 8(f) N3: the pixel-format converters of src/libavcodec/to_lavc_vid_conv.c (UltraGrid codec -> the
+// AVFrame an encoder takes) and src/libavcodec/from_lavc_vid_conv.c (a decoder's AVFrame -> UltraGrid codec), for the codecs of the
+// hot path (UYVY, v210, RGB, RGBA) against the frame formats encoders and decoders really use (planar YUV 4:2:0 / 4:2:2 / 4:4:4 at 8
+// and 10 bit, NV12, P010, P210, GBRP, XV30, Y210, VUYA ...).  This is what the reference's reserved GPU hook is for
+// (to_lavc_vid_conv_cuda.h:55-66, from_lavc_vid_conv_cuda.h:55-66: both stubs that return NULL).
+//
+// Every kernel restates ONE reference function statement for statement, one lane per iteration of its inner loop (and per row or
+// row pair), including the reference's slips where it has them -- the results must be identical, and the tests compare against
+// the reference's own functions compiled from /root/reference (oracle/_ref/libugref_lavc.so).  Known slips kept: yuv420p_to_v210
+// and yuv444p1Xle_to_v210 leave some luma samples unshifted (from_lavc_vid_conv.c:599,1099,1107), nv12_to_rgb gives both pixels
+// of a pair the first one's colour (:797-811), yuv444p_to_rgb does not subtract the luma offset (:976), p210le_to_uyvy overwrites
+// Cb and emits three bytes per pair (:1622-1625).
+//
+// Pure sample shuffles and Q14 integer colour arithmetic (color_space.h:100-110), HBM-bound.
+#include <string.h>
+
+#include "ug_common.h"
+
+namespace {
+
+struct Args {
+        uint8_t *d[4]; // AVFrame::data
+        int ls[4];     // AVFrame::linesize
+        uint8_t *buf;  // packed UltraGrid buffer
+        long pitch;    // its line size
+        int w, h;
+        int c[14];     // struct color_coeffs: y_r y_g y_b cb_r cb_g cb_b cr_r cr_g cr_b y_scale r_cr g_cb g_cr b_cb
+        int rs, gs, bs;
+        uint32_t am;   // alpha mask
+};
+enum { Y_R, Y_G, Y_B, CB_R, CB_G, CB_B, CR_R, CR_G, CR_B, Y_SCALE, R_CR, G_CB, G_CR, B_CB };
+constexpr int kBase = 14; // COMP_BASE, color_space.h:71
+
+// get_color_coeffs(cs, depth) (color_space.c:149-184): [cs - 1][0 = full range, 8, 10, 12, 16].  Values = the reference's compile-time
+// tables (tests/test_lavc_conv.py::test_color_coefficient_tables compares them with the compiled reference through ug_hip_color_coeffs).
+const int kCoeffs[2][5][14] = {
+        { { 4899, 9617, 1868, -2765, -5427, 8192, 8191, -6860, -1331, 16384, 22970, -5638, -11700, 29032 },
+          { 4207, 8260, 1604, -2428, -4768, 7196, 7195, -6026, -1169, 19077, 26149, -6419, -13320, 33050 },
+          { 4195, 8235, 1599, -2421, -4754, 7175, 7174, -6008, -1166, 19133, 26226, -6438, -13359, 33148 },
+          { 4192, 8229, 1598, -2420, -4750, 7170, 7169, -6004, -1165, 19147, 26245, -6442, -13369, 33172 },
+          { 4191, 8228, 1598, -2419, -4749, 7168, 7167, -6002, -1165, 19152, 26251, -6444, -13372, 33179 } },
+        { { 3484, 11717, 1183, -1877, -6315, 8192, 8191, -7441, -750, 16384, 25800, -3069, -7671, 30402 },
+          { 2992, 10063, 1016, -1649, -5547, 7196, 7195, -6536, -659, 19077, 29371, -3494, -8733, 34610 },
+          { 2983, 10034, 1013, -1644, -5531, 7175, 7174, -6517, -657, 19133, 29457, -3504, -8758, 34712 },
+          { 2981, 10026, 1012, -1643, -5527, 7170, 7169, -6512, -656, 19147, 29479, -3507, -8765, 34737 },
+          { 2980, 10024, 1012, -1643, -5525, 7168, 7167, -6511, -656, 19152, 29486, -3507, -8767, 34745 } },
+};
+
+int depth_slot(int depth)
+{
+        switch (depth) {
+        case 0: return 0;
+        case 8: return 1;
+        case 10: return 2;
+        case 12: return 3;
+        case 16: return 4;
+        default: return -1;
+        }
+}
+
+#define UG_XY()                                                   \
+        const int x = blockIdx.x * blockDim.x + threadIdx.x;      \
+        const int y = blockIdx.y * blockDim.y + threadIdx.y
+#define ROW(T, plane, row) ((T *) (a.d[plane] + (long) (row) * a.ls[plane]))
+#define BUF(T, row) ((T *) (a.buf + (long) (row) * a.pitch))
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clamp_full(int v, int depth) { return clampi(v, 1 << (depth - 8), (255 << (depth - 8)) - 1); } // CLAMP_FULL
+__device__ __forceinline__ uint32_t mk_rgba(const Args &a, int r, int g, int b)                                                  // MK_RGBA(.., 8)
+{
+        return a.am | (uint32_t) clamp_full(r, 8) << a.rs | (uint32_t) clamp_full(g, 8) << a.gs | (uint32_t) clamp_full(b, 8) << a.bs;
+}
+__device__ __forceinline__ uint32_t v210w(uint32_t lo, uint32_t mid, uint32_t hi) { return lo | mid << 10 | hi << 20; }
+__device__ __forceinline__ void st4(uint32_t *dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+        if (((uintptr_t) dst & 15) == 0) {
+                *(uint4 *) dst = make_uint4(w0, w1, w2, w3);
+        } else {
+                dst[0] = w0, dst[1] = w1, dst[2] = w2, dst[3] = w3;
+        }
+}
+
+// ================================ UltraGrid codec -> AVFrame (to_lavc_vid_conv.c) ==================================================
+// a.buf / a.pitch = the packed input (pitch = vc_get_linesize(width, codec), as the reference strides it), a.d / a.ls = output planes
+
+__global__ void k_uyvy_to_yuv444p(const Args a) // to_lavc_vid_conv.c:174-190
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint32_t s = BUF(const uint32_t, y)[x];
+        const uint8_t cb = s & 0xff, y0 = (s >> 8) & 0xff, cr = (s >> 16) & 0xff, y1 = s >> 24;
+        uint8_t *py = ROW(uint8_t, 0, y) + 2 * x, *pcb = ROW(uint8_t, 1, y) + 2 * x, *pcr = ROW(uint8_t, 2, y) + 2 * x;
+        py[0] = y0, py[1] = y1;
+        pcb[0] = cb, pcb[1] = cb;
+        pcr[0] = cr, pcr[1] = cr;
+}
+
+__global__ void k_uyvy_to_vuya(const Args a) // :155-172
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint32_t s = BUF(const uint32_t, y)[x];
+        const uint32_t cb = s & 0xff, y0 = (s >> 8) & 0xff, cr = (s >> 16) & 0xff, y1 = s >> 24;
+        uint32_t *dst = ROW(uint32_t, 0, y) + 2 * x;
+        dst[0] = cr | cb << 8 | y0 << 16 | 0xff000000u;
+        dst[1] = cr | cb << 8 | y1 << 16 | 0xff000000u;
+}
+
+struct V210Group {
+        uint32_t y[6], cb[3], cr[3];
+};
+__device__ __forceinline__ V210Group v210_unpack(const uint32_t *src)
+{
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        V210Group g;
+        g.y[0] = (w0 >> 10) & 0x3ff, g.y[1] = w1 & 0x3ff, g.y[2] = (w1 >> 20) & 0x3ff;
+        g.y[3] = (w2 >> 10) & 0x3ff, g.y[4] = w3 & 0x3ff, g.y[5] = (w3 >> 20) & 0x3ff;
+        g.cb[0] = w0 & 0x3ff, g.cb[1] = (w1 >> 10) & 0x3ff, g.cb[2] = (w2 >> 20) & 0x3ff;
+        g.cr[0] = (w0 >> 20) & 0x3ff, g.cr[1] = w2 & 0x3ff, g.cr[2] = (w3 >> 10) & 0x3ff;
+        return g;
+}
+template <int N>
+__device__ __forceinline__ void st16(uint16_t *p, const uint32_t (&v)[N], int shift)
+{
+        if (((uintptr_t) p & 3) == 0 && N % 2 == 0) {
+#pragma unroll
+                for (int i = 0; i < N / 2; i++) ((uint32_t *) p)[i] = (v[2 * i] << shift) | (v[2 * i + 1] << shift) << 16;
+        } else {
+#pragma unroll
+                for (int i = 0; i < N; i++) p[i] = (uint16_t) (v[i] << shift);
+        }
+}
+
+enum { V_420P10, V_422P10, V_444P10, V_444P16, V_P210 };
+// v210_to_yuv420p10le :197-262, v210_to_yuv422p10le :264-301, v210_to_yuv444p10le :303-346, v210_to_yuv444p16le :348-389,
+// v210_to_p210le :577-609: width / 6 groups per line.  4:2:0 walks line pairs; with an odd height the reference reads and writes one
+// line past the picture -- here the last line stands alone (its chroma is its own).
+template <int MODE>
+__global__ void k_v210_to_planar(const Args a)
+{
+        UG_XY();
+        const int rows = MODE == V_420P10 ? (a.h + 1) / 2 : a.h;
+        if (x >= a.w / 6 || y >= rows) return;
+        if (MODE == V_420P10) {
+                const int y0 = 2 * y, y1 = 2 * y + 1 < a.h ? 2 * y + 1 : 2 * y;
+                const V210Group g0 = v210_unpack(BUF(const uint32_t, y0) + 4 * x), g1 = v210_unpack(BUF(const uint32_t, y1) + 4 * x);
+                st16<6>(ROW(uint16_t, 0, y0) + 6 * x, g0.y, 0);
+                if (y1 != y0) st16<6>(ROW(uint16_t, 0, y1) + 6 * x, g1.y, 0);
+                uint16_t *cb = (uint16_t *) (a.d[1] + (long) a.ls[1] * y0 / 2) + 3 * x, *cr = (uint16_t *) (a.d[2] + (long) a.ls[2] * y0 / 2) + 3 * x;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                        cb[i] = (uint16_t) ((g0.cb[i] + g1.cb[i]) / 2);
+                        cr[i] = (uint16_t) ((g0.cr[i] + g1.cr[i]) / 2);
+                }
+                return;
+        }
+        const V210Group g = v210_unpack(BUF(const uint32_t, y) + 4 * x);
+        if (MODE == V_422P10) {
+                st16<6>(ROW(uint16_t, 0, y) + 6 * x, g.y, 0);
+                uint16_t *cb = ROW(uint16_t, 1, y) + 3 * x, *cr = ROW(uint16_t, 2, y) + 3 * x;
+#pragma unroll
+                for (int i = 0; i < 3; i++) cb[i] = (uint16_t) g.cb[i], cr[i] = (uint16_t) g.cr[i];
+        } else if (MODE == V_444P10 || MODE == V_444P16) {
+                const int sh = MODE == V_444P16 ? 6 : 0;
+                const uint32_t cb[6] = { g.cb[0], g.cb[0], g.cb[1], g.cb[1], g.cb[2], g.cb[2] }, cr[6] = { g.cr[0], g.cr[0], g.cr[1], g.cr[1], g.cr[2], g.cr[2] };
+                st16<6>(ROW(uint16_t, 0, y) + 6 * x, g.y, sh);
+                st16<6>(ROW(uint16_t, 1, y) + 6 * x, cb, sh);
+                st16<6>(ROW(uint16_t, 2, y) + 6 * x, cr, sh);
+        } else { // V_P210
+                const uint32_t c[6] = { g.cb[0], g.cr[0], g.cb[1], g.cr[1], g.cb[2], g.cr[2] };
+                st16<6>(ROW(uint16_t, 0, y) + 6 * x, g.y, 6);
+                st16<6>(ROW(uint16_t, 1, y) + 6 * x, c, 6);
+        }
+}
+
+__global__ void k_v210_to_xv30(const Args a) // :393-417, (width + 5) / 6 groups, six whole pixels each
+{
+        UG_XY();
+        if (x >= (a.w + 5) / 6 || y >= a.h) return;
+        const uint32_t *src = BUF(const uint32_t, y) + 4 * x;
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        uint32_t *dst = ROW(uint32_t, 0, y) + 6 * x;
+        dst[0] = w0;
+        dst[1] = (w0 & 0xFFF003FFU) | (w1 & 0x3FFU) << 10U;
+        dst[2] = (w2 & 0x3FFU) << 20U | (w1 & 0x3FF00000U) >> 10U | (w1 & 0xFFC00U) >> 10U;
+        dst[3] = (w2 & 0x3FFU) << 20U | (w2 & 0xFFC00U) | (w1 & 0xFFC00U) >> 10U;
+        dst[4] = (w3 & 0xFFC00U) << 10U | (w3 & 0x3FFU) << 10U | (w2 & 0x3FF00000U) >> 20;
+        dst[5] = (w3 & 0xFFC00U) << 10U | (w3 & 0x3FF00000U) >> 10 | (w2 & 0x3FF00000U) >> 20;
+}
+
+__global__ void k_v210_to_y210(const Args a) // :421-450
+{
+        UG_XY();
+        if (x >= (a.w + 5) / 6 || y >= a.h) return;
+        const V210Group g = v210_unpack(BUF(const uint32_t, y) + 4 * x);
+        const uint32_t o[12] = { g.y[0], g.cb[0], g.y[1], g.cr[0], g.y[2], g.cb[1], g.y[3], g.cr[1], g.y[4], g.cb[2], g.y[5], g.cr[2] };
+        st16<12>(ROW(uint16_t, 0, y) + 12 * x, o, 6);
+}
+
+template <int BPP>
+__global__ void k_rgb_to_gbrp(const Args a) // rgb_rgba_to_gbrp :1318-1334 (source lines are bpp * width apart)
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint8_t *src = a.buf + (long) y * (BPP * a.w) + (long) BPP * x;
+        ROW(uint8_t, 2, y)[x] = src[0];
+        ROW(uint8_t, 0, y)[x] = src[1];
+        ROW(uint8_t, 1, y)[x] = src[2];
+}
+
+__global__ void k_rgb_to_yuv444p(const Args a) // :1187-1227
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint8_t *src = BUF(const uint8_t, y) + 3 * x;
+        const int r = src[0], g = src[1], b = src[2];
+        ROW(uint8_t, 0, y)[x] = (uint8_t) (((r * a.c[Y_R] + g * a.c[Y_G] + b * a.c[Y_B]) >> kBase) + 16);
+        ROW(uint8_t, 1, y)[x] = (uint8_t) (((r * a.c[CB_R] + g * a.c[CB_G] + b * a.c[CB_B]) >> kBase) + 128);
+        ROW(uint8_t, 2, y)[x] = (uint8_t) (((r * a.c[CR_R] + g * a.c[CR_G] + b * a.c[CR_B]) >> kBase) + 128);
+}
+
+// ================================ AVFrame -> UltraGrid codec (from_lavc_vid_conv.c) ================================================
+// a.d / a.ls = the decoder's planes, a.buf / a.pitch = output
+
+// yuv420p_to_v210 :554-620, yuv422p_to_v210 :622-661, yuv420p10le_to_v210 :1007-1074, p010le_to_v210 :1498-1566, p210le_to_v210 :1450-1496
+enum { S_420P8, S_422P8, S_420P10, S_P010, S_P210 };
+template <int SRC>
+__global__ void k_planar_to_v210(const Args a)
+{
+        UG_XY();
+        constexpr bool k420 = SRC == S_420P8 || SRC == S_420P10 || SRC == S_P010;
+        if (x >= a.w / 6 || y >= (k420 ? a.h / 2 : a.h)) return;
+#pragma unroll
+        for (int l = 0; l < (k420 ? 2 : 1); l++) {
+                const int row = k420 ? 2 * y + l : y;
+                uint32_t Y[6], cb[3], cr[3];
+                if (SRC == S_420P8 || SRC == S_422P8) {
+                        const uint8_t *sy = ROW(const uint8_t, 0, row) + 6 * x, *scb = ROW(const uint8_t, 1, y) + 3 * x, *scr = ROW(const uint8_t, 2, y) + 3 * x;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) Y[i] = (uint32_t) sy[i] << 2;
+                        if (SRC == S_420P8) Y[4] = sy[4]; // `w0_3 = *src_y1++;` -- not shifted in the reference (:599-600)
+#pragma unroll
+                        for (int i = 0; i < 3; i++) cb[i] = (uint32_t) scb[i] << 2, cr[i] = (uint32_t) scr[i] << 2;
+                } else if (SRC == S_420P10) {
+                        const uint16_t *sy = ROW(const uint16_t, 0, row) + 6 * x, *scb = ROW(const uint16_t, 1, y) + 3 * x, *scr = ROW(const uint16_t, 2, y) + 3 * x;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) Y[i] = sy[i];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) cb[i] = scb[i], cr[i] = scr[i];
+                } else { // P010 / P210: samples in the high bits, Cb Cr interleaved
+                        const uint16_t *sy = ROW(const uint16_t, 0, row) + 6 * x, *sc = ROW(const uint16_t, 1, y) + 6 * x;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) Y[i] = sy[i] >> 6;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) cb[i] = sc[2 * i] >> 6, cr[i] = sc[2 * i + 1] >> 6;
+                }
+                st4(BUF(uint32_t, row) + 4 * x, v210w(cb[0], Y[0], cr[0]), v210w(Y[1], cb[1], Y[2]), v210w(cr[1], Y[3], cb[2]), v210w(Y[4], cr[2], Y[5]));
+        }
+}
+
+// yuv444p_to_v210 :714-762 (8 bit), yuv444p1Xle_to_v210 :1079-1123 (10 / 12 / 16 bit)
+template <int DEPTH>
+__global__ void k_yuv444_to_v210(const Args a)
+{
+        UG_XY();
+        if (x >= a.w / 6 || y >= a.h) return;
+        uint32_t Y[6], cb[3], cr[3];
+        if (DEPTH == 8) {
+                const uint8_t *sy = ROW(const uint8_t, 0, y) + 6 * x, *scb = ROW(const uint8_t, 1, y) + 6 * x, *scr = ROW(const uint8_t, 2, y) + 6 * x;
+#pragma unroll
+                for (int i = 0; i < 6; i++) Y[i] = (uint32_t) sy[i] << 2;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                        cb[i] = (((uint32_t) scb[2 * i] << 2) + ((uint32_t) scb[2 * i + 1] << 2)) / 2;
+                        cr[i] = (((uint32_t) scr[2 * i] << 2) + ((uint32_t) scr[2 * i + 1] << 2)) / 2;
+                }
+        } else {
+                constexpr int sh = DEPTH - 10;
+                const uint16_t *sy = ROW(const uint16_t, 0, y) + 6 * x, *scb = ROW(const uint16_t, 1, y) + 6 * x, *scr = ROW(const uint16_t, 2, y) + 6 * x;
+#pragma unroll
+                for (int i = 0; i < 6; i++) Y[i] = (uint32_t) sy[i] >> sh;
+                Y[1] = sy[1], Y[4] = sy[4]; // `w0_1 = *src_y++;`, `w0_3 = *src_y++;` -- not shifted in the reference (:1099,1107)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                        cb[i] = (((uint32_t) scb[2 * i] >> sh) + ((uint32_t) scb[2 * i + 1] >> sh)) / 2;
+                        cr[i] = (((uint32_t) scr[2 * i] >> sh) + ((uint32_t) scr[2 * i + 1] >> sh)) / 2;
+                }
+        }
+        st4(BUF(uint32_t, y) + 4 * x, v210w(cb[0], Y[0], cr[0]), v210w(Y[1], cb[1], Y[2]), v210w(cr[1], Y[3], cb[2]), v210w(Y[4], cr[2], Y[5]));
+}
+
+// -> UYVY, one lane per pixel pair.  yuv444p_to_uyvy :663-685, yuv444p16le_to_uyvy :687-712 (high bytes), yuv444p1Xle_to_uyvy :1183-1206,
+// yuv420p10le_to_uyvy :1143-1178, p010le_to_uyvy :1568-1603, nv12_to_uyvy :150-169
+enum { U_444P8, U_444P16, U_444P10, U_444P12, U_420P10, U_P010, U_NV12 };
+template <int SRC>
+__global__ void k_to_uyvy(const Args a)
+{
+        UG_XY();
+        constexpr bool kPairRows = SRC == U_420P10 || SRC == U_P010;
+        if (x >= a.w / 2 || y >= (kPairRows ? a.h / 2 : a.h)) return;
+        if (SRC == U_444P8) {
+                const uint8_t *sy = ROW(const uint8_t, 0, y) + 2 * x, *scb = ROW(const uint8_t, 1, y) + 2 * x, *scr = ROW(const uint8_t, 2, y) + 2 * x;
+                BUF(uint32_t, y)[x] = (uint32_t) ((scb[0] + scb[1]) / 2) | (uint32_t) sy[0] << 8 | (uint32_t) ((scr[0] + scr[1]) / 2) << 16 | (uint32_t) sy[1] << 24;
+        } else if (SRC == U_444P16) {
+                const uint16_t *sy = ROW(const uint16_t, 0, y) + 2 * x, *scb = ROW(const uint16_t, 1, y) + 2 * x, *scr = ROW(const uint16_t, 2, y) + 2 * x;
+                BUF(uint32_t, y)[x] = (uint32_t) (((scb[0] >> 8) + (scb[1] >> 8)) / 2) | (uint32_t) (sy[0] >> 8) << 8 |
+                                      (uint32_t) (((scr[0] >> 8) + (scr[1] >> 8)) / 2) << 16 | (uint32_t) (sy[1] >> 8) << 24;
+        } else if (SRC == U_444P10 || SRC == U_444P12) {
+                constexpr int sh = SRC == U_444P10 ? 2 : 4;
+                const uint16_t *sy = ROW(const uint16_t, 0, y) + 2 * x, *scb = ROW(const uint16_t, 1, y) + 2 * x, *scr = ROW(const uint16_t, 2, y) + 2 * x;
+                BUF(uint32_t, y)[x] = (uint32_t) (((scb[0] + scb[1] + 1) / 2 >> sh) & 0xff) | (uint32_t) ((sy[0] >> sh) & 0xff) << 8 |
+                                      (uint32_t) (((scr[0] + scr[1] + 1) / 2 >> sh) & 0xff) << 16 | (uint32_t) ((sy[1] >> sh) & 0xff) << 24;
+        } else if (SRC == U_420P10) {
+                const uint32_t u = (ROW(const uint16_t, 1, y)[x] >> 2) & 0xff, v = (ROW(const uint16_t, 2, y)[x] >> 2) & 0xff;
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                        const uint16_t *sy = ROW(const uint16_t, 0, 2 * y + l) + 2 * x;
+                        BUF(uint32_t, 2 * y + l)[x] = u | (uint32_t) ((sy[0] >> 2) & 0xff) << 8 | v << 16 | (uint32_t) ((sy[1] >> 2) & 0xff) << 24;
+                }
+        } else if (SRC == U_P010) {
+                const uint16_t *sc = ROW(const uint16_t, 1, y) + 2 * x;
+                const uint32_t u = sc[0] >> 8, v = sc[1] >> 8;
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                        const uint16_t *sy = ROW(const uint16_t, 0, 2 * y + l) + 2 * x;
+                        BUF(uint32_t, 2 * y + l)[x] = u | (uint32_t) (sy[0] >> 8) << 8 | v << 16 | (uint32_t) (sy[1] >> 8) << 24;
+                }
+        } else { // U_NV12
+                const uint8_t *sy = ROW(const uint8_t, 0, y) + 2 * x, *sc = ROW(const uint8_t, 1, y / 2) + 2 * x;
+                BUF(uint32_t, y)[x] = (uint32_t) sc[0] | (uint32_t) sy[0] << 8 | (uint32_t) sc[1] << 16 | (uint32_t) sy[1] << 24;
+        }
+}
+
+__global__ void k_p210le_to_uyvy(const Args a) // :1605-1628: `*dst = Cb; *dst++ = Y0; *dst++ = Cr; *dst++ = Y1` -- three bytes per pair
+{
+        UG_XY();
+        if (x >= a.w / 2 || y >= a.h) return;
+        const uint16_t *sy = ROW(const uint16_t, 0, y) + 2 * x, *sc = ROW(const uint16_t, 1, y) + 2 * x;
+        uint8_t *dst = BUF(uint8_t, y) + 3 * x;
+        dst[0] = (uint8_t) (sy[0] >> 8);
+        dst[1] = (uint8_t) (sc[1] >> 8);
+        dst[2] = (uint8_t) (sy[1] >> 8);
+}
+
+__device__ __forceinline__ void put_rgb8(const Args &a, uint8_t *row, int px, bool rgba, int r, int g, int b)
+{
+        if (rgba) {
+                ((uint32_t *) row)[px] = mk_rgba(a, r, g, b);
+        } else {
+                row[3 * px] = (uint8_t) clamp_full(r, 8), row[3 * px + 1] = (uint8_t) clamp_full(g, 8), row[3 * px + 2] = (uint8_t) clamp_full(b, 8);
+        }
+}
+
+// yuv8p_to_rgb :837-919 (4:2:0 / 4:2:2 planar 8 bit -> RGB / RGBA): one lane per pixel pair of a line pair, height / 2 line pairs
+template <int SUB, bool RGBA>
+__global__ void k_yuv8p_to_rgb(const Args a)
+{
+        UG_XY();
+        if (x >= a.w / 2 || y >= a.h / 2) return;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+                const int row = 2 * y + l, crow = SUB == 420 ? y : row;
+                const int cb = ROW(const uint8_t, 1, crow)[x] - 128, cr = ROW(const uint8_t, 2, crow)[x] - 128;
+                const uint8_t *sy = ROW(const uint8_t, 0, row) + 2 * x;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                        const int ys = (sy[i] - 16) * a.c[Y_SCALE];
+                        put_rgb8(a, BUF(uint8_t, row), 2 * x + i, RGBA, (ys + cr * a.c[R_CR]) >> kBase, (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> kBase, (ys + cb * a.c[B_CB]) >> kBase);
+                }
+        }
+}
+
+template <bool RGBA>
+__global__ void k_yuv444p_to_rgb(const Args a) // :953-993 (no luma offset, RGB clamped to 1..254)
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const int cb = ROW(const uint8_t, 1, y)[x] - 128, cr = ROW(const uint8_t, 2, y)[x] - 128, ys = ROW(const uint8_t, 0, y)[x] * a.c[Y_SCALE];
+        put_rgb8(a, BUF(uint8_t, y), x, RGBA, (ys + cr * a.c[R_CR]) >> kBase, (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> kBase, (ys + cb * a.c[B_CB]) >> kBase);
+}
+
+template <bool RGBA>
+__global__ void k_nv12_to_rgb(const Args a) // :770-819: the second pixel of a pair repeats the first one's r, g, b
+{
+        UG_XY();
+        if (x >= a.w / 2 || y >= a.h) return;
+        const uint8_t *sc = ROW(const uint8_t, 1, y / 2) + 2 * x;
+        const int cb = sc[0] - 128, cr = sc[1] - 128, ys = (ROW(const uint8_t, 0, y)[2 * x] - 16) * a.c[Y_SCALE];
+        const int r = (ys + cr * a.c[R_CR]) >> kBase, g = (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> kBase, b = (ys + cb * a.c[B_CB]) >> kBase;
+        put_rgb8(a, BUF(uint8_t, y), 2 * x, RGBA, r, g, b);
+        put_rgb8(a, BUF(uint8_t, y), 2 * x + 1, RGBA, r, g, b);
+}
+
+template <bool RGBA>
+__global__ void k_gbrp_to_rgb(const Args a) // gbrp_to_rgb :221-237, gbrp_to_rgba :239-262: every plane indexed with linesize[0]
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const long idx = (long) y * a.ls[0] + x;
+        const uint32_t r = a.d[2][idx], g = a.d[0][idx], b = a.d[1][idx];
+        if (RGBA) {
+                BUF(uint32_t, y)[x] = a.am | r << a.rs | g << a.gs | b << a.bs;
+        } else {
+                uint8_t *o = BUF(uint8_t, y) + 3 * x;
+                o[0] = (uint8_t) r, o[1] = (uint8_t) g, o[2] = (uint8_t) b;
+        }
+}
+
+// yuvp10le_to_rgb :1273-1374 (4:2:0 / 4:2:2 planar 10 bit -> RGB 24 / R10k 30 / RGBA 32)
+template <int SUB, int OUT_BITS>
+__global__ void k_yuvp10le_to_rgb(const Args a)
+{
+        UG_XY();
+        if (x >= a.w / 2 || y >= a.h / 2) return;
+        constexpr int bpp = OUT_BITS == 30 ? 10 : 8;
+        constexpr int sh = kBase + (10 - bpp);
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+                const int row = 2 * y + l, crow = SUB == 420 ? y : row;
+                const int cr = ROW(const uint16_t, 2, crow)[x] - (1 << 9), cb = ROW(const uint16_t, 1, crow)[x] - (1 << 9);
+                const int rr = (cr * a.c[R_CR]) >> sh, gg = (cb * a.c[G_CB] + cr * a.c[G_CR]) >> sh, bb = (cb * a.c[B_CB]) >> sh;
+                const uint16_t *sy = ROW(const uint16_t, 0, row) + 2 * x;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                        const int ys = (a.c[Y_SCALE] * (sy[i] - (1 << 6))) >> sh;
+                        const uint32_t r = clamp_full(ys + rr, bpp), g = clamp_full(ys + gg, bpp), b = clamp_full(ys + bb, bpp);
+                        const int px = 2 * x + i;
+                        if (OUT_BITS == 32) {
+                                BUF(uint32_t, row)[px] = a.am | (r << a.rs | g << a.gs | b << a.bs);
+                        } else if (OUT_BITS == 24) {
+                                uint8_t *o = BUF(uint8_t, row) + 3 * px;
+                                o[0] = (uint8_t) r, o[1] = (uint8_t) g, o[2] = (uint8_t) b;
+                        } else {
+                                BUF(uint32_t, row)[px] = r >> 2U | (r & 0x3U) << 14 | g >> 4U << 8U | (g & 0xFU) << 20U | b >> 6U << 16U | (b & 0x3FU) << 26U | 0x3U << 24U;
+                        }
+                }
+        }
+}
+
+template <bool RGBA>
+__global__ void k_yuv444p10le_to_rgb(const Args a) // :1393-1435
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const int cb = ROW(const uint16_t, 1, y)[x] - (1 << 9), cr = ROW(const uint16_t, 2, y)[x] - (1 << 9);
+        const int ys = (ROW(const uint16_t, 0, y)[x] - (1 << 6)) * a.c[Y_SCALE];
+        put_rgb8(a, BUF(uint8_t, y), x, RGBA, (ys + cr * a.c[R_CR]) >> (kBase + 2), (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> (kBase + 2), (ys + cb * a.c[B_CB]) >> (kBase + 2));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+enum Nx { NX_W, NX_W2, NX_W2UP, NX_W6, NX_W6UP };
+enum Ny { NY_H, NY_H2, NY_H2UP };
+enum Fwd { F_NONE, F_PIXFMT_RGB_BGR0, F_TO_PLANAR, F_I420, F_I422, F_FROM_PLANAR, F_PIXFMT_RGB_UYVY, F_PIXFMT_RGB_RGBA };
+
+struct Conv {
+        const char *uv, *av;
+        void (*kernel)(const Args);
+        Nx nx;
+        Ny ny;
+        int coeff_depth; // bit depth of the colour coefficients (0 = no colour arithmetic)
+        Fwd fwd;
+        const char *fwd_name;
+        int min_planes;
+};
+
+// get_uv_to_av_conversion table, to_lavc_vid_conv.c:1458-1529 (rows for UYVY, v210, RGB, RGBA)
+const Conv kToAv[] = {
+        { "UYVY", "yuv420p", nullptr, NX_W, NY_H, 0, F_I420, nullptr, 3 },
+        { "UYVY", "yuvj420p", nullptr, NX_W, NY_H, 0, F_I420, nullptr, 3 },
+        { "UYVY", "yuv422p", nullptr, NX_W, NY_H, 0, F_I422, nullptr, 3 },
+        { "UYVY", "yuvj422p", nullptr, NX_W, NY_H, 0, F_I422, nullptr, 3 },
+        { "UYVY", "yuv444p", k_uyvy_to_yuv444p, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuvj444p", k_uyvy_to_yuv444p, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "nv12", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "uyvy_to_nv12", 2 },
+        { "UYVY", "vuya", k_uyvy_to_vuya, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "UYVY", "vuyx", k_uyvy_to_vuya, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "yuv420p10le", k_v210_to_planar<V_420P10>, NX_W6, NY_H2UP, 0, F_NONE, nullptr, 3 },
+        { "v210", "yuv422p10le", k_v210_to_planar<V_422P10>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "v210", "yuv444p10le", k_v210_to_planar<V_444P10>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "v210", "yuv444p16le", k_v210_to_planar<V_444P16>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "v210", "p010le", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "v210_to_p010le", 2 },
+        { "v210", "p210le", k_v210_to_planar<V_P210>, NX_W6, NY_H, 0, F_NONE, nullptr, 2 },
+        { "v210", "xv30le", k_v210_to_xv30, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "y210le", k_v210_to_y210, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "y212le", k_v210_to_y210, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "RGB", "bgr0", nullptr, NX_W, NY_H, 0, F_PIXFMT_RGB_BGR0, nullptr, 1 },
+        { "RGB", "gbrp", k_rgb_to_gbrp<3>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGB", "yuv444p", k_rgb_to_yuv444p, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
+        { "RGBA", "gbrp", k_rgb_to_gbrp<4>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGBA", "bgra", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "rgba_to_bgra", 1 },
+};
+
+// av_to_uv_conversions table, from_lavc_vid_conv.c:2049-2172 (rows whose output is UYVY, v210, RGB, RGBA or R10k)
+#define UG_FP(av, uv, name) { uv, av, nullptr, NX_W, NY_H, 0, F_FROM_PLANAR, name, 3 }
+const Conv kFromAv[] = {
+        { "v210", "yuv420p10le", k_planar_to_v210<S_420P10>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuv420p10le", k_to_uyvy<U_420P10>, NX_W2, NY_H2, 0, F_NONE, nullptr, 3 },
+        { "RGB", "yuv420p10le", k_yuvp10le_to_rgb<420, 24>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
+        { "RGBA", "yuv420p10le", k_yuvp10le_to_rgb<420, 32>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
+        { "R10k", "yuv420p10le", k_yuvp10le_to_rgb<420, 30>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
+        UG_FP("yuv422p10le", "v210", "yuv422p10le_to_v210"),
+        UG_FP("yuv422p10le", "UYVY", "yuv422p10le_to_uyvy"),
+        { "RGB", "yuv422p10le", k_yuvp10le_to_rgb<422, 24>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
+        { "RGBA", "yuv422p10le", k_yuvp10le_to_rgb<422, 32>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
+        { "R10k", "yuv422p10le", k_yuvp10le_to_rgb<422, 30>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
+        { "v210", "yuv444p10le", k_yuv444_to_v210<10>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuv444p10le", k_to_uyvy<U_444P10>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGB", "yuv444p10le", k_yuv444p10le_to_rgb<false>, NX_W, NY_H, 10, F_NONE, nullptr, 3 },
+        { "RGBA", "yuv444p10le", k_yuv444p10le_to_rgb<true>, NX_W, NY_H, 10, F_NONE, nullptr, 3 },
+        { "v210", "yuv444p12le", k_yuv444_to_v210<12>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuv444p12le", k_to_uyvy<U_444P12>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
+        { "v210", "yuv444p16le", k_yuv444_to_v210<16>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuv444p16le", k_to_uyvy<U_444P16>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
+        { "v210", "p210le", k_planar_to_v210<S_P210>, NX_W6, NY_H, 0, F_NONE, nullptr, 2 },
+        { "UYVY", "p210le", k_p210le_to_uyvy, NX_W2, NY_H, 0, F_NONE, nullptr, 2 },
+        { "v210", "p010le", k_planar_to_v210<S_P010>, NX_W6, NY_H2, 0, F_NONE, nullptr, 2 },
+        { "UYVY", "p010le", k_to_uyvy<U_P010>, NX_W2, NY_H2, 0, F_NONE, nullptr, 2 },
+        { "v210", "yuv420p", k_planar_to_v210<S_420P8>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 },
+        UG_FP("yuv420p", "UYVY", "yuv420p_to_uyvy"),
+        { "RGB", "yuv420p", k_yuv8p_to_rgb<420, false>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
+        { "RGBA", "yuv420p", k_yuv8p_to_rgb<420, true>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
+        { "v210", "yuv422p", k_planar_to_v210<S_422P8>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        UG_FP("yuv422p", "UYVY", "yuv422p_to_uyvy"),
+        { "RGB", "yuv422p", k_yuv8p_to_rgb<422, false>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
+        { "RGBA", "yuv422p", k_yuv8p_to_rgb<422, true>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
+        { "v210", "yuv444p", k_yuv444_to_v210<8>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuv444p", k_to_uyvy<U_444P8>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGB", "yuv444p", k_yuv444p_to_rgb<false>, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
+        { "RGBA", "yuv444p", k_yuv444p_to_rgb<true>, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
+        UG_FP("yuv444p", "VUYA", "yuv444p_to_vuya"),
+        { "UYVY", "nv12", k_to_uyvy<U_NV12>, NX_W2, NY_H, 0, F_NONE, nullptr, 2 },
+        { "RGB", "nv12", k_nv12_to_rgb<false>, NX_W2, NY_H, 8, F_NONE, nullptr, 2 },
+        { "RGBA", "nv12", k_nv12_to_rgb<true>, NX_W2, NY_H, 8, F_NONE, nullptr, 2 },
+        { "RGB", "gbrap", nullptr, NX_W, NY_H, 0, F_FROM_PLANAR, "gbrap_to_rgb", 4 },
+        { "RGBA", "gbrap", nullptr, NX_W, NY_H, 0, F_FROM_PLANAR, "gbrap_to_rgba", 4 },
+        { "RGB", "gbrp", k_gbrp_to_rgb<false>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGBA", "gbrp", k_gbrp_to_rgb<true>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "rgb24", nullptr, NX_W, NY_H, 0, F_PIXFMT_RGB_UYVY, nullptr, 1 },
+        { "RGBA", "rgb24", nullptr, NX_W, NY_H, 0, F_PIXFMT_RGB_RGBA, nullptr, 1 },
+        UG_FP("gbrp10le", "R10k", "gbrp10le_to_r10k"), UG_FP("gbrp10le", "RGB", "gbrp10le_to_rgb"), UG_FP("gbrp10le", "RGBA", "gbrp10le_to_rgba"),
+        UG_FP("gbrp10le", "RG48", "gbrp10le_to_rg48"), UG_FP("gbrp12le", "R12L", "gbrp12le_to_r12l"), UG_FP("gbrp12le", "R10k", "gbrp12le_to_r10k"),
+        UG_FP("gbrp12le", "RGB", "gbrp12le_to_rgb"), UG_FP("gbrp12le", "RGBA", "gbrp12le_to_rgba"), UG_FP("gbrp12le", "RG48", "gbrp12le_to_rg48"),
+        UG_FP("gbrp16le", "R12L", "gbrp16le_to_r12l"), UG_FP("gbrp16le", "R10k", "gbrp16le_to_r10k"), UG_FP("gbrp16le", "RG48", "gbrp16le_to_rg48"),
+};
+
+// yuvj* frames take the rows of their yuv* twins (from_lavc_vid_conv.c:2108-2119, to_lavc_vid_conv.c:1496-1505)
+const char *canonical_av(const char *av, char (&tmp)[32])
+{
+        if (av && !strncmp(av, "yuvj", 4) && strlen(av) < sizeof tmp - 1) {
+                snprintf(tmp, sizeof tmp, "yuv%s", av + 4);
+                return tmp;
+        }
+        return av;
+}
+
+template <size_t N>
+const Conv *find(const Conv (&tab)[N], const char *uv, const char *av)
+{
+        char tmp[32];
+        if (!uv || !av) return nullptr;
+        for (const Conv &c : tab) {
+                if (!strcmp(c.uv, uv) && !strcmp(c.av, av)) return &c;
+        }
+        const char *canon = canonical_av(av, tmp);
+        for (const Conv &c : tab) {
+                if (!strcmp(c.uv, uv) && !strcmp(c.av, canon)) return &c;
+        }
+        return nullptr;
+}
+
+int launch(const Conv &c, const Args &a, hipStream_t st)
+{
+        const int w = a.w, h = a.h;
+        const int nx = c.nx == NX_W ? w : c.nx == NX_W2 ? w / 2 : c.nx == NX_W2UP ? (w + 1) / 2 : c.nx == NX_W6 ? w / 6 : (w + 5) / 6;
+        const int ny = c.ny == NY_H ? h : c.ny == NY_H2 ? h / 2 : (h + 1) / 2;
+        if (nx <= 0 || ny <= 0) return UG_HIP_SUCCESS;
+        const dim3 block(64, 4, 1), grid((unsigned) ((nx + 63) / 64), (unsigned) ((ny + 3) / 4), 1);
+        hipLaunchKernelGGL(c.kernel, grid, block, 0, st, a);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+// bytes per sample of a frame format's planes as the kernels address them: 16-bit planes must sit at even addresses, the packed
+// 32-bit formats at multiples of four (the reference asserts the same, e.g. to_lavc_vid_conv.c:199-202,396-397)
+int frame_align(const char *av)
+{
+        if (strstr(av, "xv30") || strstr(av, "vuy")) return 4;
+        if (strstr(av, "10le") || strstr(av, "12le") || strstr(av, "16le") || strstr(av, "y21")) return 2;
+        return 1;
+}
+
+bool fill_frame(Args &a, const ug_av_frame *f, int planes, int align)
+{
+        for (int i = 0; i < planes; i++) {
+                if (!f->data[i] || f->linesize[i] <= 0) return false;
+                if (((uintptr_t) f->data[i] | (uintptr_t) f->linesize[i]) & (uintptr_t) (align - 1)) return false;
+                a.d[i] = (uint8_t *) f->data[i];
+                a.ls[i] = f->linesize[i];
+        }
+        a.w = f->width;
+        a.h = f->height;
+        return a.w > 0 && a.h > 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int ug_hip_color_coeffs(int cs, int depth, int out[14])
+{
+        const int slot = depth_slot(depth);
+        if ((cs != 1 && cs != 2) || slot < 0 || !out) return UG_HIP_EINVAL;
+        memcpy(out, kCoeffs[cs - 1][slot], sizeof kCoeffs[0][0]);
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_uv_to_av_supported(const char *uv_codec, const char *av_pixfmt) { return find(kToAv, uv_codec, av_pixfmt) != nullptr; }
+int ug_hip_av_to_uv_supported(const char *av_pixfmt, const char *uv_codec) { return find(kFromAv, uv_codec, av_pixfmt) != nullptr; }
+
+int ug_hip_uv_to_av(const char *uv_codec, const char *av_pixfmt, const void *in_data, const struct ug_av_frame *out, ug_hip_stream_t stream)
+{
+        const Conv *c = find(kToAv, uv_codec, av_pixfmt);
+        if (!c) {
+                ug::set_last_error_msg("ug_hip_uv_to_av: no such conversion");
+                return UG_HIP_EUNSUPP;
+        }
+        Args a = {};
+        if (!in_data || !out || !fill_frame(a, out, c->min_planes, frame_align(c->av)) || ((uintptr_t) in_data & 3)) {
+                ug::set_last_error_msg("ug_hip_uv_to_av: null pointer, bad geometry or misaligned plane");
+                return UG_HIP_EINVAL;
+        }
+        const int w = a.w, h = a.h;
+        switch (c->fwd) {
+        case F_I420:
+                return ug_hip_uyvy_to_i420(in_data, 0, out->data[0], out->linesize[0], out->data[1], out->linesize[1], out->data[2], out->linesize[2], w, h, stream);
+        case F_I422:
+                return ug_hip_uyvy_to_i422(in_data, 0, out->data[0], out->linesize[0], out->data[1], out->linesize[1], out->data[2], out->linesize[2], w, h, stream);
+        case F_TO_PLANAR: {
+                ug_to_planar_data d = {};
+                d.width = w, d.height = h, d.in_data = in_data;
+                for (int i = 0; i < c->min_planes; i++) d.out_data[i] = out->data[i], d.out_linesize[i] = (unsigned) out->linesize[i];
+                return ug_hip_to_planar(c->fwd_name, &d, stream);
+        }
+        case F_PIXFMT_RGB_BGR0: // rgb_to_bgr0, to_lavc_vid_conv.c:1291-1300: vc_copylineRGBtoRGBA(dst, src, linesize(RGBA), 16, 8, 0)
+                return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_RGBA, in_data, out->data[0], w, h, 0, out->linesize[0], 16, 8, 0, stream);
+        default: break;
+        }
+        a.buf = (uint8_t *) in_data;
+        a.pitch = !strcmp(c->uv, "UYVY") ? ug::linesize(UG_PF_UYVY, w) : !strcmp(c->uv, "v210") ? ug::linesize(UG_PF_V210, w) : !strcmp(c->uv, "RGB") ? 3 * w : 4 * w;
+        if (c->coeff_depth) memcpy(a.c, kCoeffs[1][depth_slot(c->coeff_depth)], sizeof a.c); // get_color_coeffs(CS_DFL, depth): BT.709
+        return launch(*c, a, (hipStream_t) stream);
+}
+
+int ug_hip_av_to_uv(const char *av_pixfmt, const char *uv_codec, void *dst, int pitch, const struct ug_av_frame *in, const int rgb_shift[3],
+                    ug_hip_stream_t stream)
+{
+        const Conv *c = find(kFromAv, uv_codec, av_pixfmt);
+        if (!c) {
+                ug::set_last_error_msg("ug_hip_av_to_uv: no such conversion");
+                return UG_HIP_EUNSUPP;
+        }
+        Args a = {};
+        if (!dst || !in || pitch <= 0 || !fill_frame(a, in, c->min_planes, frame_align(c->av)) || (strcmp(c->uv, "RGB") && (((uintptr_t) dst | (uintptr_t) pitch) & 3))) {
+                ug::set_last_error_msg("ug_hip_av_to_uv: null pointer, bad geometry or misaligned buffer");
+                return UG_HIP_EINVAL;
+        }
+        static const int kDefaultShift[3] = { 0, 8, 16 };
+        const int *sh = rgb_shift ? rgb_shift : kDefaultShift;
+        const int w = a.w, h = a.h;
+        switch (c->fwd) {
+        case F_FROM_PLANAR: {
+                ug_from_planar_data d = {};
+                d.width = w, d.height = h, d.out_data = dst, d.out_pitch = (unsigned) pitch;
+                for (int i = 0; i < c->min_planes; i++) d.in_data[i] = in->data[i], d.in_linesize[i] = (unsigned) in->linesize[i];
+                d.rgb_shift[0] = sh[0], d.rgb_shift[1] = sh[1], d.rgb_shift[2] = sh[2];
+                return ug_hip_from_planar(c->fwd_name, &d, stream);
+        }
+        case F_PIXFMT_RGB_UYVY: // rgb24_to_uyvy :171-184: vc_copylineRGBtoUYVY per line, dst_len = vc_get_linesize(width, UYVY)
+                return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_UYVY, in->data[0], dst, w, h, in->linesize[0], pitch, 0, 8, 16, stream);
+        case F_PIXFMT_RGB_RGBA: // rgb24_to_rgb32 :205-219
+                return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_RGBA, in->data[0], dst, w, h, in->linesize[0], pitch, sh[0], sh[1], sh[2], stream);
+        default: break;
+        }
+        if ((unsigned) sh[0] > 24 || (unsigned) sh[1] > 24 || (unsigned) sh[2] > 24) {
+                ug::set_last_error_msg("ug_hip_av_to_uv: rgb_shift out of range");
+                return UG_HIP_EINVAL;
+        }
+        a.buf = (uint8_t *) dst;
+        a.pitch = pitch;
+        a.rs = sh[0], a.gs = sh[1], a.bs = sh[2];
+        a.am = 0xFFFFFFFFu ^ (0xFFu << a.rs) ^ (0xFFu << a.gs) ^ (0xFFu << a.bs);
+        if (c->coeff_depth) {
+                // get_cs_for_conv, from_lavc_vid_conv.c:2614-2658: BT.601 for BT470BG / SMPTE170M / SMPTE240M frames, else BT.709 (the default);
+                // full-range (AVCOL_RANGE_JPEG) frames take the depth-0 table
+                const bool src_601 = in->colorspace == 5 || in->colorspace == 6 || in->colorspace == 7;
+                const bool full = in->color_range == 2;
+                memcpy(a.c, kCoeffs[src_601 ? 0 : 1][full ? 0 : depth_slot(c->coeff_depth)], sizeof a.c);
+        }
+        return launch(*c, a, (hipStream_t) stream);
+}
+
+} // extern "C"

@@ -66,6 +66,11 @@ SYMBOLS = {
     "ug_hip_to_planar": (_i, [C.c_char_p, _vp, _vp]),
     "ug_hip_from_planar_supported": (_i, [C.c_char_p]),
     "ug_hip_to_planar_supported": (_i, [C.c_char_p]),
+    "ug_hip_uv_to_av": (_i, [C.c_char_p, C.c_char_p, _vp, _vp, _vp]),
+    "ug_hip_av_to_uv": (_i, [C.c_char_p, C.c_char_p, _vp, _i, _vp, C.POINTER(_i), _vp]),
+    "ug_hip_uv_to_av_supported": (_i, [C.c_char_p, C.c_char_p]),
+    "ug_hip_av_to_uv_supported": (_i, [C.c_char_p, C.c_char_p]),
+    "ug_hip_color_coeffs": (_i, [_i, _i, C.POINTER(_i)]),
     "ug_hip_jpeg_qtable": (None, [_i, _i, _vp]),
     "ug_hip_jpeg_divisors": (None, [_vp, _vp]),
     "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
