@@ -217,6 +217,47 @@ def main():
             j = k[0] % NP; k[0] += 1
             codec.to_planar(func, srcs[j], w, h, outs)
         add(f"to_planar {func}", w, h, 1, in_bpp + out_bpp, timeit(run_tp, iters=40))
+    # lavc converters (lavc_conv.hip), 4K: algorithmic bytes = input samples + output bytes
+    def planes_for(av):
+        d16 = any(t in av for t in ("10le", "12le", "16le", "p010", "p210"))
+        bps = 2 if d16 else 1
+        cw, ch = {"420": (w // 2, h // 2), "422": (w // 2, h), "444": (w, h)}.get(av[3:6], (w, h))
+        if av in ("nv12", "p010le"):
+            shp = [(h, w * bps), (h // 2, w * bps)]
+        elif av == "p210le":
+            shp = [(h, w * bps), (h, w * bps)]
+        elif av.startswith("yuv"):
+            shp = [(h, w * bps), (ch, cw * bps), (ch, cw * bps)]
+        else:
+            shp = [(h, w * bps)] * 3
+        hi = 4 if d16 and "p0" not in av and "p2" not in av else 256  # keep 10-bit samples in range (high byte < 4)
+        out = []
+        for (r_, c_) in shp:
+            t = torch.randint(0, 256, (r_, c_), dtype=torch.uint8, device="cuda")
+            if d16 and hi == 4:
+                t[:, 1::2] &= 3
+            out.append(t)
+        return out, sum(r_ * c_ for r_, c_ in shp) / (w * h)
+    v210src = frames("v210", w, h, NP)
+    for uvc, av, srcs, in_bpp in (("v210", "yuv422p10le", v210src, 16 / 6), ("v210", "yuv420p10le", v210src, 16 / 6), ("v210", "p210le", v210src, 16 / 6),
+                                  ("UYVY", "yuv444p", src, 2), ("RGB", "gbrp", frames("RGB", w, h, NP), 3)):
+        outs, out_bpp = planes_for(av)
+
+        def run_to():
+            j = k[0] % NP; k[0] += 1
+            codec.uv_to_av(uvc, av, srcs[j], w, h, outs)
+        add(f"uv_to_av {uvc}->{av}", w, h, 1, in_bpp + out_bpp, timeit(run_to, iters=40))
+    for av, uvc, out_bpp in (("yuv420p", "RGB", 3), ("yuv420p", "RGBA", 4), ("yuv420p", "v210", 16 / 6), ("yuv422p", "RGBA", 4), ("yuv444p", "UYVY", 2), ("nv12", "UYVY", 2),
+                             ("nv12", "RGBA", 4), ("p010le", "v210", 16 / 6), ("yuv420p10le", "v210", 16 / 6), ("yuv420p10le", "UYVY", 2), ("yuv422p10le", "RGBA", 4),
+                             ("yuv444p10le", "v210", 16 / 6)):
+        sets = [planes_for(av) for _ in range(NP)]
+        pitch = int(round(out_bpp * w)) if uvc != "v210" else codec.linesize(L.PF_V210, w)
+        dstb = torch.empty((h, pitch), dtype=torch.uint8, device="cuda")
+
+        def run_from():
+            j = k[0] % NP; k[0] += 1
+            codec.av_to_uv(av, uvc, sets[j][0], w, h, dstb, pitch)
+        add(f"av_to_uv {av}->{uvc}", w, h, 1, sets[0][1] + out_bpp, timeit(run_from, iters=40))
     if args.json:
         json.dump(rows, open(args.json, "w"), indent=1)
 
