@@ -223,10 +223,11 @@ int ug_hip_to_planar_supported(const char *func);
  * "nv12", "p010le", "gbrp", "xv30le", ...; FFmpeg's enum values are not used, so nothing here needs its headers).
  * struct ug_av_frame carries the AVFrame fields the reference converters read: data, linesize, width, height, colorspace,
  * color_range (numeric values as in libavutil/pixfmt.h: AVCOL_SPC_BT709 1, BT470BG 5, SMPTE170M 6, SMPTE240M 7; AVCOL_RANGE_JPEG 2).
- *   ug_hip_uv_to_av   to_lavc_vid_conv(): rows of get_uv_to_av_conversion's table (to_lavc_vid_conv.c:1458-1529) for UYVY, v210, RGB, RGBA;
+ *   ug_hip_uv_to_av   to_lavc_vid_conv(): the rows of get_uv_to_av_conversion's table (to_lavc_vid_conv.c:1458-1529) -- sources UYVY, v210, RGB,
+ *                     RGBA, Y216, Y416, R10k, R12L, RG48 (all but R10k -> bgr0);
  *                     `in_data` is vc_get_linesize(width, codec) per line, `out` holds the (device) planes to fill
- *   ug_hip_av_to_uv   av_to_uv_convert(): rows of av_to_uv_conversions (from_lavc_vid_conv.c:2049-2172) whose output is UYVY, v210, RGB,
- *                     RGBA, R10k (+ the from_planar rows); YCbCr -> RGB picks BT.601 / BT.709 and limited / full range from the
+ *   ug_hip_av_to_uv   av_to_uv_convert(): the rows of av_to_uv_conversions (from_lavc_vid_conv.c:2049-2172) for software frames (not: rgb48le,
+ *                     ayuv64le -> UYVY, y210 -> Y216, hardware frames); YCbCr -> RGB picks BT.601 / BT.709 and limited / full range from the
  *                     frame as get_cs_for_conv does (:2614-2658)
  * Results equal the reference functions' byte for byte, slips included (listed in csrc/lavc_conv.hip).  No row: UG_HIP_EUNSUPP. */
 struct ug_av_frame {

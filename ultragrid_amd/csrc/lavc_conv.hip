@@ -219,6 +219,227 @@ __global__ void k_rgb_to_yuv444p(const Args a) // :1187-1227
         ROW(uint8_t, 2, y)[x] = (uint8_t) (((r * a.c[CR_R] + g * a.c[CR_G] + b * a.c[CR_B]) >> kBase) + 128);
 }
 
+// ---- sources beyond the hot-path four: Y216, Y416, R10k, R12L, RG48 -----------------------------------------------------------------
+
+template <int DEPTH>
+__global__ void k_y216_to_yuv422p(const Args a) // y216_to_yuv422pXXle :1236-1254, (width + 1) / 2 pairs
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint16_t *src = BUF(const uint16_t, y) + 4 * x;
+        ROW(uint16_t, 0, y)[2 * x] = src[0] >> (16 - DEPTH);
+        ROW(uint16_t, 1, y)[x] = src[1] >> (16 - DEPTH);
+        ROW(uint16_t, 0, y)[2 * x + 1] = src[2] >> (16 - DEPTH);
+        ROW(uint16_t, 2, y)[x] = src[3] >> (16 - DEPTH);
+}
+
+__global__ void k_y216_to_yuv444p16le(const Args a) // :1266-1289
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint16_t *src = BUF(const uint16_t, y) + 4 * x;
+        uint16_t *py = ROW(uint16_t, 0, y) + 2 * x, *pcb = ROW(uint16_t, 1, y) + 2 * x, *pcr = ROW(uint16_t, 2, y) + 2 * x;
+        py[0] = src[0], py[1] = src[2];
+        pcb[0] = pcb[1] = src[1];
+        pcr[0] = pcr[1] = src[3];
+}
+
+__global__ void k_y416_to_xv30(const Args a) // :454-470
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint16_t *src = BUF(const uint16_t, y) + 4 * x;
+        const uint32_t u = src[0], Y = src[1], v = src[2], al = src[3];
+        ROW(uint32_t, 0, y)[x] = (al >> 14U) << 30U | (v >> 6U) << 20U | (Y >> 6U) << 10U | (u >> 6U);
+}
+
+__global__ void k_y416_to_yuv444p(const Args a) // :476-498: the odd bytes (most significant of each little-endian sample)
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint8_t *src = BUF(const uint8_t, y) + 8 * x;
+        ROW(uint8_t, 1, y)[x] = src[1];
+        ROW(uint8_t, 0, y)[x] = src[3];
+        ROW(uint8_t, 2, y)[x] = src[5];
+}
+
+template <int DEPTH>
+__global__ void k_y416_to_yuv444pXX(const Args a) // y416_to_yuv444pXXle :500-527
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint16_t *src = BUF(const uint16_t, y) + 4 * x;
+        ROW(uint16_t, 1, y)[x] = src[0] >> (16 - DEPTH);
+        ROW(uint16_t, 0, y)[x] = src[1] >> (16 - DEPTH);
+        ROW(uint16_t, 2, y)[x] = src[2] >> (16 - DEPTH);
+}
+
+__device__ __forceinline__ void r10k_px(const uint8_t *src, int &r, int &g, int &b)
+{
+        r = src[0] << 2 | src[1] >> 6;
+        g = (src[1] & 0x3f) << 4 | src[2] >> 4;
+        b = (src[2] & 0x0f) << 6 | src[3] >> 2;
+}
+#define UG_RGB_TO_Y(r, g, b) ((r) * a.c[Y_R] + (g) * a.c[Y_G] + (b) * a.c[Y_B])
+#define UG_RGB_TO_CB(r, g, b) ((r) * a.c[CB_R] + (g) * a.c[CB_G] + (b) * a.c[CB_B])
+#define UG_RGB_TO_CR(r, g, b) ((r) * a.c[CR_R] + (g) * a.c[CR_G] + (b) * a.c[CR_B])
+
+// r10k_to_yuv42Xp10le :616-687.  4:2:2 (VSUB 1): one lane per pixel pair.  4:2:0 (VSUB 2): one lane per pixel pair of a line pair, the two
+// lines in the reference's order, because odd pairs average with what the chroma plane already holds (:670-677) -- first its previous
+// content, then what the even line left there.
+template <int VSUB>
+__global__ void k_r10k_to_yuv42Xp10le(const Args a)
+{
+        UG_XY();
+        if (x >= a.w / 2 || y >= (VSUB == 2 ? (a.h + 1) / 2 : a.h)) return;
+#pragma unroll
+        for (int l = 0; l < VSUB; l++) {
+                const int row = VSUB * y + l;
+                if (row >= a.h) break;
+                const uint8_t *src = BUF(const uint8_t, row) + 8 * x;
+                int r, g, b;
+                r10k_px(src, r, g, b);
+                ROW(uint16_t, 0, row)[2 * x] = (uint16_t) ((UG_RGB_TO_Y(r, g, b) >> kBase) + (1 << 6));
+                int cb = (UG_RGB_TO_CB(r, g, b) >> kBase) + (1 << 9), cr = (UG_RGB_TO_CR(r, g, b) >> kBase) + (1 << 9);
+                r10k_px(src + 4, r, g, b);
+                ROW(uint16_t, 0, row)[2 * x + 1] = (uint16_t) ((UG_RGB_TO_Y(r, g, b) >> kBase) + (1 << 6));
+                cb += (UG_RGB_TO_CB(r, g, b) >> kBase) + (1 << 9);
+                cr += (UG_RGB_TO_CR(r, g, b) >> kBase) + (1 << 9);
+                cb /= 2, cr /= 2;
+                uint16_t *pcb = ROW(uint16_t, 1, row / VSUB) + x, *pcr = ROW(uint16_t, 2, row / VSUB) + x;
+                if (VSUB == 1 || x % 2 == 0) {
+                        *pcb = (uint16_t) cb, *pcr = (uint16_t) cr;
+                } else {
+                        *pcb = (uint16_t) ((*pcb + cb) / 2), *pcr = (uint16_t) ((*pcr + cr) / 2);
+                }
+        }
+}
+
+// r10k_to_yuv444pXXle :706-740 (IN_DEPTH 10), rg48_to_yuv444pXXle :1136-1170 (IN_DEPTH 16): one lane per pixel
+template <int IN_DEPTH, int OUT_DEPTH>
+__global__ void k_rgb_to_yuv444pXX(const Args a)
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        int r, g, b;
+        if (IN_DEPTH == 10) {
+                r10k_px(BUF(const uint8_t, y) + 4 * x, r, g, b);
+        } else {
+                const uint16_t *src = BUF(const uint16_t, y) + 3 * x;
+                r = src[0], g = src[1], b = src[2];
+        }
+        constexpr int sh = kBase + IN_DEPTH - OUT_DEPTH;
+        ROW(uint16_t, 0, y)[x] = (uint16_t) ((UG_RGB_TO_Y(r, g, b) >> sh) + (1 << (OUT_DEPTH - 4)));
+        ROW(uint16_t, 1, y)[x] = (uint16_t) ((UG_RGB_TO_CB(r, g, b) >> sh) + (1 << (OUT_DEPTH - 1)));
+        ROW(uint16_t, 2, y)[x] = (uint16_t) ((UG_RGB_TO_CR(r, g, b) >> sh) + (1 << (OUT_DEPTH - 1)));
+}
+
+template <int DEPTH>
+__global__ void k_r10k_to_gbrpXX(const Args a) // r10k_to_gbrpXXle :1373-1393
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        int r, g, b;
+        r10k_px(BUF(const uint8_t, y) + 4 * x, r, g, b);
+        ROW(uint16_t, 2, y)[x] = (uint16_t) (r << (DEPTH - 10));
+        ROW(uint16_t, 0, y)[x] = (uint16_t) (g << (DEPTH - 10));
+        ROW(uint16_t, 1, y)[x] = (uint16_t) (b << (DEPTH - 10));
+}
+
+__global__ void k_r10k_to_x2rgb10le(const Args a) // :1338-1348: htonl(word) >> 2
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        ROW(uint32_t, 0, y)[x] = __builtin_bswap32(BUF(const uint32_t, y)[x]) >> 2;
+}
+
+__global__ void k_rg48_to_gbrp12le(const Args a) // :1424-1438
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint16_t *src = BUF(const uint16_t, y) + 3 * x;
+        ROW(uint16_t, 2, y)[x] = src[0] >> 4;
+        ROW(uint16_t, 0, y)[x] = src[1] >> 4;
+        ROW(uint16_t, 1, y)[x] = src[2] >> 4;
+}
+
+// 36 bytes of R12L = 8 pixels of 12-bit r, g, b in a little-endian bit stream (to_lavc_vid_conv.c:796-860 spells the bytes out)
+__device__ __forceinline__ void r12l_unpack(const uint8_t *src, int (&c)[8][3])
+{
+        uint32_t w[9];
+        if (((uintptr_t) src & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) w[i] = ((const uint32_t *) src)[i];
+        } else {
+#pragma unroll
+                for (int i = 0; i < 9; i++) w[i] = src[4 * i] | src[4 * i + 1] << 8 | src[4 * i + 2] << 16 | (uint32_t) src[4 * i + 3] << 24;
+        }
+#pragma unroll
+        for (int k = 0; k < 24; k++) {
+                const int bit = 12 * k, wi = bit / 32, sh = bit % 32;
+                uint32_t v = w[wi] >> sh;
+                if (sh > 20) v |= w[(wi + 1) % 9] << (32 - sh);
+                c[k / 3][k % 3] = (int) (v & 0xfffu);
+        }
+}
+
+// r12l_to_yuv4XXpYYle :761-866: one lane per 8-pixel group (whole groups, also past `width`); 4:2:2 takes the chroma of even pixels
+template <int DEPTH, bool OUT_422>
+__global__ void k_r12l_to_yuv(const Args a)
+{
+        UG_XY();
+        if (x >= (a.w + 7) / 8 || y >= a.h) return;
+        int c[8][3];
+        r12l_unpack(BUF(const uint8_t, y) + 36 * x, c);
+        constexpr int sh = kBase + 12 - DEPTH;
+        uint32_t Y[8], cb[8], cr[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                const int r = c[i][0], g = c[i][1], b = c[i][2];
+                Y[i] = (uint16_t) ((UG_RGB_TO_Y(r, g, b) >> sh) + (1 << (DEPTH - 4)));
+                cb[i] = (uint16_t) ((UG_RGB_TO_CB(r, g, b) >> sh) + (1 << (DEPTH - 1)));
+                cr[i] = (uint16_t) ((UG_RGB_TO_CR(r, g, b) >> sh) + (1 << (DEPTH - 1)));
+        }
+        st16<8>(ROW(uint16_t, 0, y) + 8 * x, Y, 0);
+        if (OUT_422) {
+                const uint32_t cb4[4] = { cb[0], cb[2], cb[4], cb[6] }, cr4[4] = { cr[0], cr[2], cr[4], cr[6] };
+                st16<4>(ROW(uint16_t, 1, y) + 4 * x, cb4, 0);
+                st16<4>(ROW(uint16_t, 2, y) + 4 * x, cr4, 0);
+        } else {
+                st16<8>(ROW(uint16_t, 1, y) + 8 * x, cb, 0);
+                st16<8>(ROW(uint16_t, 2, y) + 8 * x, cr, 0);
+        }
+}
+
+// r12l_to_p210le :899-1015 (the 10-bit coefficient set with 16-bit shifts and offsets, as written there), r12l_to_ayuv64le :1019-1130
+template <bool AYUV>
+__global__ void k_r12l_to_p210_ayuv64(const Args a)
+{
+        UG_XY();
+        if (x >= (a.w + 7) / 8 || y >= a.h) return;
+        int c[8][3];
+        r12l_unpack(BUF(const uint8_t, y) + 36 * x, c);
+        constexpr int sh = kBase + 12 - 16;
+        uint32_t Y[8], cb[8], cr[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                const int r = c[i][0], g = c[i][1], b = c[i][2];
+                Y[i] = (uint16_t) ((UG_RGB_TO_Y(r, g, b) >> sh) + (1 << 12));
+                cb[i] = (uint16_t) ((UG_RGB_TO_CB(r, g, b) >> sh) + (1 << 15));
+                cr[i] = (uint16_t) ((UG_RGB_TO_CR(r, g, b) >> sh) + (1 << 15));
+        }
+        if (AYUV) {
+                uint32_t o[32];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[4 * i] = 0xffff, o[4 * i + 1] = Y[i], o[4 * i + 2] = cb[i], o[4 * i + 3] = cr[i];
+                st16<32>(ROW(uint16_t, 0, y) + 32 * x, o, 0);
+        } else {
+                const uint32_t cc[8] = { cb[0], cr[0], cb[2], cr[2], cb[4], cr[4], cb[6], cr[6] };
+                st16<8>(ROW(uint16_t, 0, y) + 8 * x, Y, 0);
+                st16<8>(ROW(uint16_t, 1, y) + 8 * x, cc, 0);
+        }
+}
+
 // ================================ AVFrame -> UltraGrid codec (from_lavc_vid_conv.c) ================================================
 // a.d / a.ls = the decoder's planes, a.buf / a.pitch = output
 
@@ -447,10 +668,205 @@ __global__ void k_yuv444p10le_to_rgb(const Args a) // :1393-1435
         put_rgb8(a, BUF(uint8_t, y), x, RGBA, (ys + cr * a.c[R_CR]) >> (kBase + 2), (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> (kBase + 2), (ys + cb * a.c[B_CB]) >> (kBase + 2));
 }
 
+// yuv444pXXle_to_r10k :295-334, _to_r12l :363-437, _to_rg48 :464-499: planar 4:4:4 at 10 / 12 / 16 bit -> packed RGB at 10 / 12 / 16 bit.
+// The sums are 32-bit and wrap for extreme 16-bit samples exactly as the reference's comp_type_t arithmetic does on this compiler.
+template <int DEPTH, int OUT_BITS>
+__device__ __forceinline__ void yuv444_px_to_rgb(const Args &a, int row, int col, int &r, int &g, int &b)
+{
+        const int ys = a.c[Y_SCALE] * (ROW(const uint16_t, 0, row)[col] - (1 << (DEPTH - 4)));
+        const int cr = ROW(const uint16_t, 2, row)[col] - (1 << (DEPTH - 1)), cb = ROW(const uint16_t, 1, row)[col] - (1 << (DEPTH - 1));
+        constexpr int sh = kBase - OUT_BITS + DEPTH;
+        r = clamp_full((ys + cr * a.c[R_CR]) >> sh, OUT_BITS);
+        g = clamp_full((ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> sh, OUT_BITS);
+        b = clamp_full((ys + cb * a.c[B_CB]) >> sh, OUT_BITS);
+}
+
+template <int DEPTH>
+__global__ void k_yuv444pXX_to_r10k(const Args a)
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        int r, g, b;
+        yuv444_px_to_rgb<DEPTH, 10>(a, y, x, r, g, b);
+        BUF(uint32_t, y)[x] = (uint32_t) (r >> 2) | (uint32_t) (((r & 0x3) << 6 | g >> 4) & 0xff) << 8 | (uint32_t) (((g & 0xF) << 4 | b >> 6) & 0xff) << 16 |
+                              (uint32_t) (((b & 0x3F) << 2 | 0x3) & 0xff) << 24;
+}
+
+template <int DEPTH>
+__global__ void k_yuv444pXX_to_rg48(const Args a)
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        int r, g, b;
+        yuv444_px_to_rgb<DEPTH, 16>(a, y, x, r, g, b);
+        uint16_t *dst = BUF(uint16_t, y) + 3 * x;
+        dst[0] = (uint16_t) r, dst[1] = (uint16_t) g, dst[2] = (uint16_t) b;
+}
+
+template <int DEPTH>
+__global__ void k_yuv444pXX_to_r12l(const Args a) // whole groups of 8, also past `width` (the reference reads and writes them too)
+{
+        UG_XY();
+        if (x >= (a.w + 7) / 8 || y >= a.h) return;
+        uint32_t v[24], bytes[36];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+                int r, g, b;
+                yuv444_px_to_rgb<DEPTH, 12>(a, y, 8 * x + j, r, g, b);
+                v[3 * j] = r, v[3 * j + 1] = g, v[3 * j + 2] = b;
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) { // :391-433 byte by byte = a little-endian stream of 12-bit values
+                const uint32_t e = v[2 * k], o = v[2 * k + 1];
+                bytes[3 * k] = e & 0xff, bytes[3 * k + 1] = ((o & 0xf) << 4 | e >> 8) & 0xff, bytes[3 * k + 2] = (o >> 4) & 0xff;
+        }
+        uint8_t *dst = BUF(uint8_t, y) + 36 * x;
+        if (((uintptr_t) dst & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) ((uint32_t *) dst)[i] = bytes[4 * i] | bytes[4 * i + 1] << 8 | bytes[4 * i + 2] << 16 | bytes[4 * i + 3] << 24;
+        } else {
+#pragma unroll
+                for (int i = 0; i < 36; i++) dst[i] = (uint8_t) bytes[i];
+        }
+}
+
+template <int DEPTH>
+__global__ void k_yuv444pXX_to_y416(const Args a) // yuv444p1Xle_to_y416 :1223-1248
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        uint16_t *dst = BUF(uint16_t, y) + 4 * x;
+        dst[0] = (uint16_t) (ROW(const uint16_t, 1, y)[x] << (16 - DEPTH));
+        dst[1] = (uint16_t) (ROW(const uint16_t, 0, y)[x] << (16 - DEPTH));
+        dst[2] = (uint16_t) (ROW(const uint16_t, 2, y)[x] << (16 - DEPTH));
+        dst[3] = 0xFFFF;
+}
+
+__global__ void k_xv30_to_uyvy(const Args a) // :1631-1658: pairs, then a lone last pixel as U Y V 0
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint32_t *src = ROW(const uint32_t, 0, y) + 2 * x;
+        const uint32_t in1 = src[0];
+        if (2 * x + 1 < a.w) {
+                const uint32_t in2 = src[1];
+                BUF(uint32_t, y)[x] = ((((in1 >> 2U) & 0xFFU) + (((in2 >> 2U) & 0xFFU) + 1)) >> 1) & 0xff | ((in1 >> 12U) & 0xFFU) << 8 |
+                                      (((((in1 >> 22U) & 0xFFU) + (((in2 >> 22U) & 0xFFU) + 1)) >> 1) & 0xff) << 16 | ((in2 >> 12U) & 0xFFU) << 24;
+        } else {
+                BUF(uint32_t, y)[x] = ((in1 >> 2U) & 0xFFU) | ((in1 >> 12U) & 0xFFU) << 8 | ((in1 >> 22U) & 0xFFU) << 16;
+        }
+}
+
+// xv30_to_v210 :1660-1698 (width / 6 groups), y210_to_v210 :1724-1760 ((width + 5) / 6 groups)
+template <bool XV30>
+__global__ void k_packed_to_v210(const Args a)
+{
+        UG_XY();
+        if (x >= (XV30 ? a.w / 6 : (a.w + 5) / 6) || y >= a.h) return;
+        uint32_t u[3], y0[3], v[3], y1[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+                if (XV30) {
+                        const uint32_t *src = ROW(const uint32_t, 0, y) + 6 * x + 2 * i;
+                        const uint32_t in0 = src[0], in1 = src[1];
+                        u[i] = ((in0 & 0x3FFU) + (in1 & 0x3FFU) + 1) >> 1;
+                        y0[i] = (in0 >> 10U) & 0x3FFU;
+                        v[i] = ((in0 >> 20U & 0x3FFU) + ((in1 >> 20U & 0x3FFU) + 1)) >> 1;
+                        y1[i] = (in1 >> 10U) & 0x3FFU;
+                } else {
+                        const uint16_t *src = ROW(const uint16_t, 0, y) + 12 * x + 4 * i;
+                        y0[i] = src[0] >> 6, u[i] = src[1] >> 6, y1[i] = src[2] >> 6, v[i] = src[3] >> 6;
+                }
+        }
+        st4(BUF(uint32_t, y) + 4 * x, v[0] << 20U | y0[0] << 10U | u[0], y0[1] << 20U | u[1] << 10U | y1[0], u[2] << 20U | (y1[1] << 10U | v[1]),
+            y1[2] << 20U | v[2] << 10U | y0[2]);
+}
+
+__global__ void k_xv30_to_y416(const Args a) // :1700-1720
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint32_t in = ROW(const uint32_t, 0, y)[x];
+        uint16_t *dst = BUF(uint16_t, y) + 4 * x;
+        dst[0] = (in & 0x3FFU) << 6U, dst[1] = ((in >> 10U) & 0x3FFU) << 6U, dst[2] = ((in >> 20U) & 0x3FFU) << 6U, dst[3] = 0xFFFFU;
+}
+
+__global__ void k_y210_to_y416(const Args a) // :1762-1792, (width + 1) / 2 pairs, two whole pixels each
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint16_t *src = ROW(const uint16_t, 0, y) + 4 * x;
+        uint16_t *dst = BUF(uint16_t, y) + 8 * x;
+        dst[0] = src[1], dst[1] = src[0], dst[2] = src[3], dst[3] = 0xFFFFU;
+        dst[4] = src[1], dst[5] = src[2], dst[6] = src[3], dst[7] = 0xFFFFU;
+}
+
+__global__ void k_y210_to_uyvy(const Args a) // :1794-1818: the high bytes
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint8_t *src = ROW(const uint8_t, 0, y) + 8 * x;
+        BUF(uint32_t, y)[x] = (uint32_t) src[3] | (uint32_t) src[1] << 8 | (uint32_t) src[7] << 16 | (uint32_t) src[5] << 24;
+}
+
+__global__ void k_ayuv64_to_y416(const Args a) // :1904-1925
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint16_t *src = ROW(const uint16_t, 0, y) + 4 * x;
+        uint16_t *dst = BUF(uint16_t, y) + 4 * x;
+        dst[0] = src[2], dst[1] = src[1], dst[2] = src[3], dst[3] = src[0];
+}
+
+__global__ void k_ayuv64_to_v210(const Args a) // :1927-1967; `w = src[5]` and `w = src[1]` keep all 16 bits, as written there
+{
+        UG_XY();
+        if (x >= (a.w + 5) / 6 || y >= a.h) return;
+        const uint16_t *src = ROW(const uint16_t, 0, y) + 24 * x;
+        uint32_t w0, w1, w2, w3;
+        w0 = ((src[2] >> 6U) + (src[6] >> 6U)) / 2;
+        w0 = w0 | (src[1] >> 6U) << 10U;
+        w0 = w0 | ((src[3] >> 6U) + (src[7] >> 6U)) / 2 << 20U;
+        w1 = src[5];
+        src += 8;
+        w1 = w1 | ((src[2] >> 6U) + (src[6] >> 6U)) / 2 << 10U;
+        w1 = w1 | (src[1] >> 6U) << 20U;
+        w2 = ((src[3] >> 6U) + (src[7] >> 6U)) / 2;
+        w2 = w2 | (src[5] >> 6U) << 10U;
+        src += 8;
+        w2 = w2 | ((src[2] >> 6U) + (src[6] >> 6U)) / 2 << 20U;
+        w3 = src[1];
+        w3 = w3 | ((src[3] >> 6U) + (src[7] >> 6U)) / 2 << 10U;
+        w3 = w3 | ((src[5] >> 6U)) << 20U;
+        st4(BUF(uint32_t, y) + 4 * x, w0, w1, w2, w3);
+}
+
+__global__ void k_vuya_to_uyvy(const Args a) // :1971-1996
+{
+        UG_XY();
+        if (x >= (a.w + 1) / 2 || y >= a.h) return;
+        const uint8_t *src = ROW(const uint8_t, 0, y) + 8 * x;
+        if (2 * x + 1 < a.w) {
+                BUF(uint32_t, y)[x] = ((src[1] + src[5] + 1U) >> 1U) | (uint32_t) src[2] << 8 | ((src[0] + src[4] + 1U) >> 1U) << 16 | (uint32_t) src[6] << 24;
+        } else {
+                BUF(uint32_t, y)[x] = (uint32_t) src[1] | (uint32_t) src[2] << 8 | (uint32_t) src[0] << 16;
+        }
+}
+
+template <bool ALPHA>
+__global__ void k_vuyax_to_y416(const Args a) // :2001-2015
+{
+        UG_XY();
+        if (x >= a.w || y >= a.h) return;
+        const uint8_t *src = ROW(const uint8_t, 0, y) + 4 * x;
+        uint16_t *dst = BUF(uint16_t, y) + 4 * x;
+        dst[0] = src[1] << 8U, dst[1] = src[2] << 8U, dst[2] = src[0] << 8U, dst[3] = ALPHA ? src[3] << 8U : 0xFFFF;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
-enum Nx { NX_W, NX_W2, NX_W2UP, NX_W6, NX_W6UP };
+enum Nx { NX_W, NX_W2, NX_W2UP, NX_W6, NX_W6UP, NX_W8UP };
 enum Ny { NY_H, NY_H2, NY_H2UP };
-enum Fwd { F_NONE, F_PIXFMT_RGB_BGR0, F_TO_PLANAR, F_I420, F_I422, F_FROM_PLANAR, F_PIXFMT_RGB_UYVY, F_PIXFMT_RGB_RGBA };
+enum Fwd { F_NONE, F_MEMCPY, F_PIXFMT_RGB_BGR0, F_TO_PLANAR, F_I420, F_I422, F_FROM_PLANAR, F_PIXFMT_RGB_UYVY, F_PIXFMT_RGB_RGBA };
 
 struct Conv {
         const char *uv, *av;
@@ -488,6 +904,39 @@ const Conv kToAv[] = {
         { "RGB", "yuv444p", k_rgb_to_yuv444p, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
         { "RGBA", "gbrp", k_rgb_to_gbrp<4>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
         { "RGBA", "bgra", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "rgba_to_bgra", 1 },
+        { "Y216", "y210le", nullptr, NX_W, NY_H, 0, F_MEMCPY, nullptr, 1 },
+        { "Y216", "y212le", nullptr, NX_W, NY_H, 0, F_MEMCPY, nullptr, 1 },
+        { "Y216", "p010le", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "y216_to_p010le", 2 },
+        { "Y216", "yuv422p10le", k_y216_to_yuv422p<10>, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
+        { "Y216", "yuv422p16le", k_y216_to_yuv422p<16>, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
+        { "Y216", "yuv444p16le", k_y216_to_yuv444p16le, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
+        { "Y416", "xv30le", k_y416_to_xv30, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "yuv444p", k_y416_to_yuv444p, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "Y416", "yuv444p10le", k_y416_to_yuv444pXX<10>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "Y416", "yuv444p12le", k_y416_to_yuv444pXX<12>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "Y416", "yuv444p16le", k_y416_to_yuv444pXX<16>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "R10k", "yuv444p10le", k_rgb_to_yuv444pXX<10, 10>, NX_W, NY_H, 10, F_NONE, nullptr, 3 },
+        { "R10k", "yuv444p12le", k_rgb_to_yuv444pXX<10, 12>, NX_W, NY_H, 12, F_NONE, nullptr, 3 },
+        { "R10k", "yuv444p16le", k_rgb_to_yuv444pXX<10, 16>, NX_W, NY_H, 16, F_NONE, nullptr, 3 },
+        { "R10k", "yuv422p10le", k_r10k_to_yuv42Xp10le<1>, NX_W2, NY_H, 10, F_NONE, nullptr, 3 },
+        { "R10k", "yuv420p10le", k_r10k_to_yuv42Xp10le<2>, NX_W2, NY_H2UP, 10, F_NONE, nullptr, 3 },
+        { "R10k", "gbrp10le", k_r10k_to_gbrpXX<10>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "R10k", "gbrp16le", k_r10k_to_gbrpXX<16>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "R10k", "x2rgb10le", k_r10k_to_x2rgb10le, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
+        { "R12L", "yuv444p10le", k_r12l_to_yuv<10, false>, NX_W8UP, NY_H, 10, F_NONE, nullptr, 3 },
+        { "R12L", "yuv444p12le", k_r12l_to_yuv<12, false>, NX_W8UP, NY_H, 12, F_NONE, nullptr, 3 },
+        { "R12L", "yuv444p16le", k_r12l_to_yuv<16, false>, NX_W8UP, NY_H, 16, F_NONE, nullptr, 3 },
+        { "R12L", "yuv422p10le", k_r12l_to_yuv<10, true>, NX_W8UP, NY_H, 10, F_NONE, nullptr, 3 },
+        { "R12L", "yuv422p12le", k_r12l_to_yuv<12, true>, NX_W8UP, NY_H, 12, F_NONE, nullptr, 3 },
+        { "R12L", "yuv422p16le", k_r12l_to_yuv<16, true>, NX_W8UP, NY_H, 16, F_NONE, nullptr, 3 },
+        { "R12L", "p210le", k_r12l_to_p210_ayuv64<false>, NX_W8UP, NY_H, 10, F_NONE, nullptr, 2 },
+        { "R12L", "ayuv64le", k_r12l_to_p210_ayuv64<true>, NX_W8UP, NY_H, 16, F_NONE, nullptr, 1 },
+        { "R12L", "gbrp12le", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "r12l_to_gbrp12le", 3 },
+        { "R12L", "gbrp16le", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "r12l_to_gbrp16le", 3 },
+        { "RG48", "yuv444p10le", k_rgb_to_yuv444pXX<16, 10>, NX_W, NY_H, 10, F_NONE, nullptr, 3 },
+        { "RG48", "yuv444p12le", k_rgb_to_yuv444pXX<16, 12>, NX_W, NY_H, 12, F_NONE, nullptr, 3 },
+        { "RG48", "yuv444p16le", k_rgb_to_yuv444pXX<16, 16>, NX_W, NY_H, 16, F_NONE, nullptr, 3 },
+        { "RG48", "gbrp12le", k_rg48_to_gbrp12le, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
 };
 
 // av_to_uv_conversions table, from_lavc_vid_conv.c:2049-2172 (rows whose output is UYVY, v210, RGB, RGBA or R10k)
@@ -541,6 +990,33 @@ const Conv kFromAv[] = {
         UG_FP("gbrp10le", "RG48", "gbrp10le_to_rg48"), UG_FP("gbrp12le", "R12L", "gbrp12le_to_r12l"), UG_FP("gbrp12le", "R10k", "gbrp12le_to_r10k"),
         UG_FP("gbrp12le", "RGB", "gbrp12le_to_rgb"), UG_FP("gbrp12le", "RGBA", "gbrp12le_to_rgba"), UG_FP("gbrp12le", "RG48", "gbrp12le_to_rg48"),
         UG_FP("gbrp16le", "R12L", "gbrp16le_to_r12l"), UG_FP("gbrp16le", "R10k", "gbrp16le_to_r10k"), UG_FP("gbrp16le", "RG48", "gbrp16le_to_rg48"),
+        { "R10k", "yuv444p10le", k_yuv444pXX_to_r10k<10>, NX_W, NY_H, 10, F_NONE, nullptr, 3 },
+        { "R12L", "yuv444p10le", k_yuv444pXX_to_r12l<10>, NX_W8UP, NY_H, 10, F_NONE, nullptr, 3 },
+        { "RG48", "yuv444p10le", k_yuv444pXX_to_rg48<10>, NX_W, NY_H, 10, F_NONE, nullptr, 3 },
+        { "Y416", "yuv444p10le", k_yuv444pXX_to_y416<10>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "R10k", "yuv444p12le", k_yuv444pXX_to_r10k<12>, NX_W, NY_H, 12, F_NONE, nullptr, 3 },
+        { "R12L", "yuv444p12le", k_yuv444pXX_to_r12l<12>, NX_W8UP, NY_H, 12, F_NONE, nullptr, 3 },
+        { "RG48", "yuv444p12le", k_yuv444pXX_to_rg48<12>, NX_W, NY_H, 12, F_NONE, nullptr, 3 },
+        { "Y416", "yuv444p12le", k_yuv444pXX_to_y416<12>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "R10k", "yuv444p16le", k_yuv444pXX_to_r10k<16>, NX_W, NY_H, 16, F_NONE, nullptr, 3 },
+        { "R12L", "yuv444p16le", k_yuv444pXX_to_r12l<16>, NX_W8UP, NY_H, 16, F_NONE, nullptr, 3 },
+        { "RG48", "yuv444p16le", k_yuv444pXX_to_rg48<16>, NX_W, NY_H, 16, F_NONE, nullptr, 3 },
+        { "Y416", "yuv444p16le", k_yuv444pXX_to_y416<16>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "xv30le", k_xv30_to_uyvy, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "xv30le", k_packed_to_v210<true>, NX_W6, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "xv30le", k_xv30_to_y416, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
+        { "UYVY", "y210le", k_y210_to_uyvy, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "y210le", k_packed_to_v210<false>, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "y210le", k_y210_to_y416, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "UYVY", "y212le", k_y210_to_uyvy, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "y212le", k_packed_to_v210<false>, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "y212le", k_y210_to_y416, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "v210", "ayuv64le", k_ayuv64_to_v210, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "ayuv64le", k_ayuv64_to_y416, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
+        { "UYVY", "vuya", k_vuya_to_uyvy, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "UYVY", "vuyx", k_vuya_to_uyvy, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "vuya", k_vuyax_to_y416<true>, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
+        { "Y416", "vuyx", k_vuyax_to_y416<false>, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
 };
 
 // yuvj* frames take the rows of their yuv* twins (from_lavc_vid_conv.c:2108-2119, to_lavc_vid_conv.c:1496-1505)
@@ -571,7 +1047,7 @@ const Conv *find(const Conv (&tab)[N], const char *uv, const char *av)
 int launch(const Conv &c, const Args &a, hipStream_t st)
 {
         const int w = a.w, h = a.h;
-        const int nx = c.nx == NX_W ? w : c.nx == NX_W2 ? w / 2 : c.nx == NX_W2UP ? (w + 1) / 2 : c.nx == NX_W6 ? w / 6 : (w + 5) / 6;
+        const int nx = c.nx == NX_W ? w : c.nx == NX_W2 ? w / 2 : c.nx == NX_W2UP ? (w + 1) / 2 : c.nx == NX_W6 ? w / 6 : c.nx == NX_W6UP ? (w + 5) / 6 : (w + 7) / 8;
         const int ny = c.ny == NY_H ? h : c.ny == NY_H2 ? h / 2 : (h + 1) / 2;
         if (nx <= 0 || ny <= 0) return UG_HIP_SUCCESS;
         const dim3 block(64, 4, 1), grid((unsigned) ((nx + 63) / 64), (unsigned) ((ny + 3) / 4), 1);
@@ -584,9 +1060,24 @@ int launch(const Conv &c, const Args &a, hipStream_t st)
 // 32-bit formats at multiples of four (the reference asserts the same, e.g. to_lavc_vid_conv.c:199-202,396-397)
 int frame_align(const char *av)
 {
-        if (strstr(av, "xv30") || strstr(av, "vuy")) return 4;
-        if (strstr(av, "10le") || strstr(av, "12le") || strstr(av, "16le") || strstr(av, "y21")) return 2;
+        if (strstr(av, "xv30") || strstr(av, "vuy") || strstr(av, "x2rgb")) return 4;
+        if (strstr(av, "10le") || strstr(av, "12le") || strstr(av, "16le") || strstr(av, "y21") || strstr(av, "ayuv64")) return 2;
         return 1;
+}
+
+// vc_get_linesize (video_codec.c:507-521) for the codecs of the to_lavc table
+long uv_linesize(const char *uv, int w)
+{
+        if (!strcmp(uv, "UYVY")) return ug::linesize(UG_PF_UYVY, w);
+        if (!strcmp(uv, "v210")) return ug::linesize(UG_PF_V210, w);
+        if (!strcmp(uv, "RGB")) return 3L * w;
+        if (!strcmp(uv, "RGBA")) return 4L * w;
+        if (!strcmp(uv, "Y216")) return (w + 1) / 2 * 8L;
+        if (!strcmp(uv, "Y416")) return 8L * w;
+        if (!strcmp(uv, "R10k")) return (w + 63) / 64 * 64 * 4L;
+        if (!strcmp(uv, "R12L")) return (w + 7) / 8 * 36L;
+        if (!strcmp(uv, "RG48")) return 6L * w;
+        return 0;
 }
 
 bool fill_frame(Args &a, const ug_av_frame *f, int planes, int align)
@@ -641,12 +1132,17 @@ int ug_hip_uv_to_av(const char *uv_codec, const char *av_pixfmt, const void *in_
                 for (int i = 0; i < c->min_planes; i++) d.out_data[i] = out->data[i], d.out_linesize[i] = (unsigned) out->linesize[i];
                 return ug_hip_to_planar(c->fwd_name, &d, stream);
         }
+        case F_MEMCPY: { // to_lavc_memcpy_data :1847-1860: vc_get_size(width) bytes of every line
+                const size_t ls = (size_t) uv_linesize(c->uv, w);
+                UG_HIP_TRY(hipMemcpy2DAsync(out->data[0], (size_t) out->linesize[0], in_data, ls, ls, (size_t) h, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+                return UG_HIP_SUCCESS;
+        }
         case F_PIXFMT_RGB_BGR0: // rgb_to_bgr0, to_lavc_vid_conv.c:1291-1300: vc_copylineRGBtoRGBA(dst, src, linesize(RGBA), 16, 8, 0)
                 return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_RGBA, in_data, out->data[0], w, h, 0, out->linesize[0], 16, 8, 0, stream);
         default: break;
         }
         a.buf = (uint8_t *) in_data;
-        a.pitch = !strcmp(c->uv, "UYVY") ? ug::linesize(UG_PF_UYVY, w) : !strcmp(c->uv, "v210") ? ug::linesize(UG_PF_V210, w) : !strcmp(c->uv, "RGB") ? 3 * w : 4 * w;
+        a.pitch = uv_linesize(c->uv, w);
         if (c->coeff_depth) memcpy(a.c, kCoeffs[1][depth_slot(c->coeff_depth)], sizeof a.c); // get_color_coeffs(CS_DFL, depth): BT.709
         return launch(*c, a, (hipStream_t) stream);
 }
