@@ -171,6 +171,29 @@ def test_reference_has_every_row_we_claim():
         r.av_to_uv_conversion_destroy(C.byref(cp))
 
 
+def test_conversion_tables_are_covered():
+    """every row of the reference's two conversion tables (read from its source here, where /root/reference exists) is either
+    supported by the library or on the short list of rows deliberately left out"""
+    import re
+    from ultragrid_amd import lib
+    base = "/root/reference/src/libavcodec/"
+    if not os.path.exists(base):
+        pytest.skip("no /root/reference here")
+    L = lib.load()
+
+    def name(f):
+        return {"XV30": "xv30le", "Y210": "y210le", "Y212": "y212le", "AYUV64": "ayuv64le", "AYUV64LE": "ayuv64le"}.get(f, f.lower())
+    rows = re.findall(r"\{ *(\w+), *AV_PIX_FMT_(\w+), *(\w+) *\}", open(base + "to_lavc_vid_conv.c").read())
+    rows = [r for r in rows if r[0] != "VIDEO_CODEC_NONE"]
+    missing = {(c, f) for c, f, _ in rows if not L.ug_hip_uv_to_av_supported(c.encode(), name(f).encode())}
+    assert len(rows) == 57 and missing == {("R10k", "BGR0")}, missing
+    rows = re.findall(r"\{ *AV_PIX_FMT_(\w+), *(\w+),\s*(\w+),\s*(\w+) *\}", open(base + "from_lavc_vid_conv.c").read())
+    missing = {(f, c) for f, c, _, _ in rows if not L.ug_hip_av_to_uv_supported(name(f).encode(), c.encode())}
+    assert len(rows) == 105, len(rows)
+    assert missing == {("Y212", "Y216"), ("Y210", "Y216"), ("AYUV64", "UYVY"), ("RGB48LE", "R12L"), ("RGB48LE", "RGBA"), ("VDPAU", "HW_VDPAU"),
+                       ("DRM_PRIME", "DRM_PRIME")}, missing
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("uv,av", TO_AV)
 def test_gpu_uv_to_av(hip, uv, av):
