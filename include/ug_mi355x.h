@@ -58,6 +58,13 @@ typedef enum {
         UG_PF_YUV444 = 8,   /* packed 8-bit Y,U,V triplets (output of *_yuv422_to_yuv444) */
         UG_PF_UYVY_RAW = 9, /* UYVY fed to the encoder WITHOUT colour conversion (DXT1_YUV) */
         UG_PF_I420 = 10,    /* planar 4:2:0: Y, U, V planes back to back (JPEG encoder input only) */
+        /* the other codecs of decoders[] (pixfmt_conv.c:3041-3103), ug_hip_pixfmt_convert only: */
+        UG_PF_R10K = 11,    /* 10-bit RGB, 4 B / px big-endian, lines padded to 64 px (types.h R10k) */
+        UG_PF_R12L = 12,    /* 12-bit RGB, 8 px / 36 B little-endian bit stream (R12L) */
+        UG_PF_Y216 = 13,    /* 16-bit 4:2:2  Y0 Cb Y1 Cr */
+        UG_PF_Y416 = 14,    /* 16-bit 4:4:4:4  U Y V A */
+        UG_PF_VUYA = 15,    /* 8-bit 4:4:4:4  V U Y A */
+        UG_PF_DVS10 = 16,   /* 10-bit 4:2:2 of DVS cards, 6 px / 16 B like v210 */
 } ug_pixfmt_t;
 
 typedef enum {
@@ -143,7 +150,7 @@ int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream);
  * Pixel-format conversion, whole frame on the device (replaces the decoder_t line loop,
  * pixfmt_conv.h:87-88 / pixfmt_conv.c:3041-3125)
  * ---------------------------------------------------------------------------------- */
-/* 1 if a kernel exists for in -> out (the subset of decoders[] on the hot path) */
+/* 1 if a kernel exists for in -> out: every pair of decoders[] (== get_decoder_from_to(in, out) != NULL, pixfmt_conv.c:3110-3125) and in == out */
 int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out);
 /* rshift/gshift/bshift have decoder_t meaning (honoured for RGBA / RGB outputs, defaults
  * 0/8/16, pixfmt_conv.h:62-65).  Pitches 0 = vc_get_linesize(). */
@@ -224,9 +231,9 @@ int ug_hip_to_planar_supported(const char *func);
  * struct ug_av_frame carries the AVFrame fields the reference converters read: data, linesize, width, height, colorspace,
  * color_range (numeric values as in libavutil/pixfmt.h: AVCOL_SPC_BT709 1, BT470BG 5, SMPTE170M 6, SMPTE240M 7; AVCOL_RANGE_JPEG 2).
  *   ug_hip_uv_to_av   to_lavc_vid_conv(): the rows of get_uv_to_av_conversion's table (to_lavc_vid_conv.c:1458-1529) -- sources UYVY, v210, RGB,
- *                     RGBA, Y216, Y416, R10k, R12L, RG48 (all but R10k -> bgr0);
+ *                     RGBA, Y216, Y416, R10k, R12L, RG48;
  *                     `in_data` is vc_get_linesize(width, codec) per line, `out` holds the (device) planes to fill
- *   ug_hip_av_to_uv   av_to_uv_convert(): the rows of av_to_uv_conversions (from_lavc_vid_conv.c:2049-2172) for software frames (not: rgb48le,
+ *   ug_hip_av_to_uv   av_to_uv_convert(): the rows of av_to_uv_conversions (from_lavc_vid_conv.c:2049-2172) for software frames (not:
  *                     ayuv64le -> UYVY, y210 -> Y216, hardware frames); YCbCr -> RGB picks BT.601 / BT.709 and limited / full range from the
  *                     frame as get_cs_for_conv does (:2614-2658)
  * Results equal the reference functions' byte for byte, slips included (listed in csrc/lavc_conv.hip).  No row: UG_HIP_EUNSUPP. */

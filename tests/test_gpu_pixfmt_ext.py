@@ -1,0 +1,96 @@
+"""The pairs of decoders[] (src/pixfmt_conv.c:3041-3103) outside the v210 / UYVY / RGB / RGBA core (csrc/pixfmt_ext.hip): every one
+against the reference's own line converter, obtained from get_decoder_from_to() of the compiled reference (oracle/_ref/libugref.so,
+which travels to the GPU box) and run line by line on the box's CPU exactly as tools/convert.cpp:43-48 does.  Whole output buffers
+are compared, padding included."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+PAIRS = [("DVS10", "v210"), ("R10k", "RGBA"), ("R10k", "RG48"), ("R10k", "Y416"), ("R10k", "RGB"), ("R10k", "UYVY"),
+         ("R12L", "RGBA"), ("R12L", "RGB"), ("R12L", "RG48"), ("R12L", "R10k"), ("R12L", "Y416"), ("R12L", "UYVY"),
+         ("RGBA", "R12L"), ("RGB", "R12L"), ("RGBA", "RG48"), ("RGB", "RG48"), ("UYVY", "RG48"),
+         ("RG48", "R12L"), ("RG48", "R10k"), ("RG48", "RGB"), ("RG48", "RGBA"), ("RG48", "v210"), ("RG48", "Y216"), ("RG48", "Y416"),
+         ("Y416", "RG48"), ("RGBA", "VUYA"), ("YUYV", "RGB"), ("RGBA", "R10k"), ("UYVY", "Y216"), ("UYVY", "Y416"),
+         ("VUYA", "Y416"), ("VUYA", "UYVY"), ("VUYA", "RGB"), ("Y216", "UYVY"), ("Y216", "v210"), ("Y416", "UYVY"), ("Y416", "v210"),
+         ("Y416", "R12L"), ("Y416", "R10k"), ("Y416", "RGB"), ("Y416", "RGBA"), ("v210", "Y216"), ("v210", "Y416")]
+SIZES = [(48, 4), (50, 3), (127, 5), (96, 2), (1920, 2), (7, 3), (2, 1)]
+DEC = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+
+
+def aligned(n, fill=None, rng=None):
+    buf = np.zeros(n + 128, np.uint8)
+    off = (-buf.ctypes.data) % 64
+    v = buf[off: off + n]
+    if rng is not None:
+        v[:] = rng.integers(0, 256, n)
+    return v
+
+
+def ref_frame(po, i, o, src, w, h, sh):
+    r = po.ref()
+    r.get_codec_from_name.argtypes = [C.c_char_p]
+    ci, co = r.get_codec_from_name(i.encode()), r.get_codec_from_name(o.encode())
+    fn = r.get_decoder_from_to(ci, co)
+    assert fn, (i, o)
+    sls, dls, dsz = r.vc_get_linesize(w, ci), r.vc_get_linesize(w, co), r.vc_get_size(w, co)
+    out = aligned(dls * h + 64)
+    for y in range(h):
+        DEC(fn)(out.ctypes.data + y * dls, src.ctypes.data + y * sls, dsz, *sh)
+    return out[: dls * h], sls, dls
+
+
+def run_pair(hip, po, i, o, sizes=SIZES):
+    import torch
+    L = hip.L
+    assert L.load().ug_hip_pixfmt_supported(L.PF_NAMES[i], L.PF_NAMES[o]) == 1
+    for k, (w, h) in enumerate(sizes):
+        for sh in [(0, 8, 16), (16, 8, 0)]:
+            r = po.ref()
+            r.get_codec_from_name.argtypes = [C.c_char_p]
+            sls = r.vc_get_linesize(w, r.get_codec_from_name(i.encode()))
+            src = aligned(sls * h + 64, rng=np.random.default_rng(100 * k + sh[0]))
+            want, sls, dls = ref_frame(po, i, o, src, w, h, sh)
+            dsrc = torch.from_numpy(src.copy()).cuda()
+            ddst = torch.zeros(dls * h, dtype=torch.uint8, device="cuda")
+            rc = L.load().ug_hip_pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], dsrc.data_ptr(), ddst.data_ptr(), w, h, 0, 0, *sh, None)
+            assert rc == 0, (i, o, L.last_error() if hasattr(L, "last_error") else rc)
+            torch.cuda.synchronize()
+            got = ddst.cpu().numpy()
+            if not np.array_equal(got, want):
+                bad = np.flatnonzero(got != want)
+                raise AssertionError((i, o, w, h, sh, "first mismatching byte offsets in line:", sorted(set((bad % dls).tolist()))[:24]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_ext_pair_vs_compiled_reference(hip, po, pair):
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    run_pair(hip, po, *pair)
+
+
+@pytest.mark.gpu
+def test_dvs10_to_uyvy(hip, po):
+    """vc_copylineDVS10 (pixfmt_conv.c:690-721) reads and writes 64-bit words: line sizes that keep them aligned"""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    run_pair(hip, po, "DVS10", "UYVY", sizes=[(48, 4), (96, 2), (1920, 2)])
+
+
+def test_every_decoder_pair_is_supported(po):
+    """decoders[] read from the reference source (CPU container): every pair is answered by ug_hip_pixfmt_supported"""
+    import os
+    import re
+    from ultragrid_amd import lib
+    path = "/root/reference/src/pixfmt_conv.c"
+    if not os.path.exists(path):
+        pytest.skip("no /root/reference here")
+    txt = open(path).read()
+    tab = txt[txt.index("static const struct decoder_item decoders[]"):]
+    tab = tab[: tab.index("};")]
+    rows = re.findall(r"\{ *(\w+), *(\w+), *(\w+) *\}", tab)
+    assert len(rows) == 61
+    L = lib.load()
+    missing = [(i, o) for _, i, o in rows if not L.ug_hip_pixfmt_supported(lib.PF_NAMES[i], lib.PF_NAMES[o])]
+    assert not missing, missing

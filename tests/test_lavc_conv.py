@@ -18,7 +18,7 @@ TO_AV = [("UYVY", "yuv420p"), ("UYVY", "yuv422p"), ("UYVY", "yuv444p"), ("UYVY",
          ("Y216", "y210le"), ("Y216", "y212le"), ("Y216", "p010le"), ("Y216", "yuv422p10le"), ("Y216", "yuv422p16le"), ("Y216", "yuv444p16le"),
          ("Y416", "xv30le"), ("Y416", "yuv444p"), ("Y416", "yuv444p10le"), ("Y416", "yuv444p12le"), ("Y416", "yuv444p16le"),
          ("R10k", "yuv444p10le"), ("R10k", "yuv444p12le"), ("R10k", "yuv444p16le"), ("R10k", "yuv422p10le"), ("R10k", "yuv420p10le"),
-         ("R10k", "gbrp10le"), ("R10k", "gbrp16le"), ("R10k", "x2rgb10le"),
+         ("R10k", "gbrp10le"), ("R10k", "gbrp16le"), ("R10k", "x2rgb10le"), ("R10k", "bgr0"),
          ("R12L", "yuv444p10le"), ("R12L", "yuv444p12le"), ("R12L", "yuv444p16le"), ("R12L", "yuv422p10le"), ("R12L", "yuv422p12le"),
          ("R12L", "yuv422p16le"), ("R12L", "p210le"), ("R12L", "ayuv64le"), ("R12L", "gbrp12le"), ("R12L", "gbrp16le"),
          ("RG48", "yuv444p10le"), ("RG48", "yuv444p12le"), ("RG48", "yuv444p16le"), ("RG48", "gbrp12le")]
@@ -43,7 +43,7 @@ FROM_AV = [("yuv420p10le", "v210"), ("yuv420p10le", "UYVY"), ("yuv420p10le", "RG
            ("yuv444p16le", "R10k"), ("yuv444p16le", "R12L"), ("yuv444p16le", "RG48"), ("yuv444p16le", "Y416"),
            ("xv30le", "UYVY"), ("xv30le", "v210"), ("xv30le", "Y416"), ("y210le", "UYVY"), ("y210le", "v210"), ("y210le", "Y416"),
            ("y212le", "UYVY"), ("y212le", "v210"), ("y212le", "Y416"), ("ayuv64le", "v210"), ("ayuv64le", "Y416"),
-           ("vuya", "UYVY"), ("vuyx", "UYVY"), ("vuya", "Y416"), ("vuyx", "Y416")]
+           ("vuya", "UYVY"), ("vuyx", "UYVY"), ("vuya", "Y416"), ("vuyx", "Y416"), ("rgb48le", "RGBA"), ("rgb48le", "R12L")]
 
 
 class StubAVFrame(C.Structure):  # oracle/lavc_stub/ug_lavc_stub.h
@@ -121,7 +121,7 @@ def make_frame(r, av, w, h, seed, colorspace, color_range):
     rng = np.random.default_rng(seed)
     d = depth_of(av)
     for p in plane_arrays(r, fr, h):
-        if d == 8 or av in ("xv30le", "y210le", "y212le", "ayuv64le"):
+        if d == 8 or av in ("xv30le", "y210le", "y212le", "ayuv64le", "rgb48le"):
             p[:] = rng.integers(0, 256, p.shape)
         else:
             v = rng.integers(0, 1 << d, (p.shape[0], p.shape[1] // 2)).astype("<u2")
@@ -186,12 +186,11 @@ def test_conversion_tables_are_covered():
     rows = re.findall(r"\{ *(\w+), *AV_PIX_FMT_(\w+), *(\w+) *\}", open(base + "to_lavc_vid_conv.c").read())
     rows = [r for r in rows if r[0] != "VIDEO_CODEC_NONE"]
     missing = {(c, f) for c, f, _ in rows if not L.ug_hip_uv_to_av_supported(c.encode(), name(f).encode())}
-    assert len(rows) == 57 and missing == {("R10k", "BGR0")}, missing
+    assert len(rows) == 57 and not missing, missing
     rows = re.findall(r"\{ *AV_PIX_FMT_(\w+), *(\w+),\s*(\w+),\s*(\w+) *\}", open(base + "from_lavc_vid_conv.c").read())
     missing = {(f, c) for f, c, _, _ in rows if not L.ug_hip_av_to_uv_supported(name(f).encode(), c.encode())}
     assert len(rows) == 105, len(rows)
-    assert missing == {("Y212", "Y216"), ("Y210", "Y216"), ("AYUV64", "UYVY"), ("RGB48LE", "R12L"), ("RGB48LE", "RGBA"), ("VDPAU", "HW_VDPAU"),
-                       ("DRM_PRIME", "DRM_PRIME")}, missing
+    assert missing == {("Y212", "Y216"), ("Y210", "Y216"), ("AYUV64", "UYVY"), ("VDPAU", "HW_VDPAU"), ("DRM_PRIME", "DRM_PRIME")}, missing
 
 
 @pytest.mark.gpu

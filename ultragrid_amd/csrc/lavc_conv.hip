@@ -866,7 +866,7 @@ __global__ void k_vuyax_to_y416(const Args a) // :2001-2015
 // ---------------------------------------------------------------------------------------------------------------------------------
 enum Nx { NX_W, NX_W2, NX_W2UP, NX_W6, NX_W6UP, NX_W8UP };
 enum Ny { NY_H, NY_H2, NY_H2UP };
-enum Fwd { F_NONE, F_MEMCPY, F_PIXFMT_RGB_BGR0, F_TO_PLANAR, F_I420, F_I422, F_FROM_PLANAR, F_PIXFMT_RGB_UYVY, F_PIXFMT_RGB_RGBA };
+enum Fwd { F_NONE, F_MEMCPY, F_PIXFMT_R10K_BGR0, F_PIXFMT_RG48_RGBA, F_PIXFMT_RG48_R12L, F_PIXFMT_RGB_BGR0, F_TO_PLANAR, F_I420, F_I422, F_FROM_PLANAR, F_PIXFMT_RGB_UYVY, F_PIXFMT_RGB_RGBA };
 
 struct Conv {
         const char *uv, *av;
@@ -923,6 +923,7 @@ const Conv kToAv[] = {
         { "R10k", "gbrp10le", k_r10k_to_gbrpXX<10>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
         { "R10k", "gbrp16le", k_r10k_to_gbrpXX<16>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
         { "R10k", "x2rgb10le", k_r10k_to_x2rgb10le, NX_W, NY_H, 0, F_NONE, nullptr, 1 },
+        { "R10k", "bgr0", nullptr, NX_W, NY_H, 0, F_PIXFMT_R10K_BGR0, nullptr, 1 },
         { "R12L", "yuv444p10le", k_r12l_to_yuv<10, false>, NX_W8UP, NY_H, 10, F_NONE, nullptr, 3 },
         { "R12L", "yuv444p12le", k_r12l_to_yuv<12, false>, NX_W8UP, NY_H, 12, F_NONE, nullptr, 3 },
         { "R12L", "yuv444p16le", k_r12l_to_yuv<16, false>, NX_W8UP, NY_H, 16, F_NONE, nullptr, 3 },
@@ -986,6 +987,8 @@ const Conv kFromAv[] = {
         { "RGBA", "gbrp", k_gbrp_to_rgb<true>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
         { "UYVY", "rgb24", nullptr, NX_W, NY_H, 0, F_PIXFMT_RGB_UYVY, nullptr, 1 },
         { "RGBA", "rgb24", nullptr, NX_W, NY_H, 0, F_PIXFMT_RGB_RGBA, nullptr, 1 },
+        { "RGBA", "rgb48le", nullptr, NX_W, NY_H, 0, F_PIXFMT_RG48_RGBA, nullptr, 1 },
+        { "R12L", "rgb48le", nullptr, NX_W, NY_H, 0, F_PIXFMT_RG48_R12L, nullptr, 1 },
         UG_FP("gbrp10le", "R10k", "gbrp10le_to_r10k"), UG_FP("gbrp10le", "RGB", "gbrp10le_to_rgb"), UG_FP("gbrp10le", "RGBA", "gbrp10le_to_rgba"),
         UG_FP("gbrp10le", "RG48", "gbrp10le_to_rg48"), UG_FP("gbrp12le", "R12L", "gbrp12le_to_r12l"), UG_FP("gbrp12le", "R10k", "gbrp12le_to_r10k"),
         UG_FP("gbrp12le", "RGB", "gbrp12le_to_rgb"), UG_FP("gbrp12le", "RGBA", "gbrp12le_to_rgba"), UG_FP("gbrp12le", "RG48", "gbrp12le_to_rg48"),
@@ -1137,6 +1140,8 @@ int ug_hip_uv_to_av(const char *uv_codec, const char *av_pixfmt, const void *in_
                 UG_HIP_TRY(hipMemcpy2DAsync(out->data[0], (size_t) out->linesize[0], in_data, ls, ls, (size_t) h, hipMemcpyDeviceToDevice, (hipStream_t) stream));
                 return UG_HIP_SUCCESS;
         }
+        case F_PIXFMT_R10K_BGR0: // r10k_to_bgr0 :1302-1312: vc_copyliner10k(dst, src, linesize(RGBA), 16, 8, 0)
+                return ug_hip_pixfmt_convert(UG_PF_R10K, UG_PF_RGBA, in_data, out->data[0], w, h, 0, out->linesize[0], 16, 8, 0, stream);
         case F_PIXFMT_RGB_BGR0: // rgb_to_bgr0, to_lavc_vid_conv.c:1291-1300: vc_copylineRGBtoRGBA(dst, src, linesize(RGBA), 16, 8, 0)
                 return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_RGBA, in_data, out->data[0], w, h, 0, out->linesize[0], 16, 8, 0, stream);
         default: break;
@@ -1173,6 +1178,10 @@ int ug_hip_av_to_uv(const char *av_pixfmt, const char *uv_codec, void *dst, int 
         }
         case F_PIXFMT_RGB_UYVY: // rgb24_to_uyvy :171-184: vc_copylineRGBtoUYVY per line, dst_len = vc_get_linesize(width, UYVY)
                 return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_UYVY, in->data[0], dst, w, h, in->linesize[0], pitch, 0, 8, 16, stream);
+        case F_PIXFMT_RG48_RGBA: // rgb48le_to_rgba :519-534
+                return ug_hip_pixfmt_convert(UG_PF_RG48, UG_PF_RGBA, in->data[0], dst, w, h, in->linesize[0], pitch, sh[0], sh[1], sh[2], stream);
+        case F_PIXFMT_RG48_R12L: // rgb48le_to_r12l :536-552
+                return ug_hip_pixfmt_convert(UG_PF_RG48, UG_PF_R12L, in->data[0], dst, w, h, in->linesize[0], pitch, sh[0], sh[1], sh[2], stream);
         case F_PIXFMT_RGB_RGBA: // rgb24_to_rgb32 :205-219
                 return ug_hip_pixfmt_convert(UG_PF_RGB, UG_PF_RGBA, in->data[0], dst, w, h, in->linesize[0], pitch, sh[0], sh[1], sh[2], stream);
         default: break;

@@ -489,13 +489,19 @@ int size_of(ug_pixfmt_t f, int width) // vc_get_size, video_codec.c:530-538
         case UG_PF_YUYV: return (width + 1) / 2 * 4;
         case UG_PF_RGB:
         case UG_PF_BGR: return width * 3;
+        case UG_PF_DVS10:
         case UG_PF_V210: return (width + 5) / 6 * 16;
         case UG_PF_RG48: return width * 6;
+        case UG_PF_R10K:
+        case UG_PF_VUYA: return width * 4;
+        case UG_PF_R12L: return (width + 7) / 8 * 36;
+        case UG_PF_Y216: return (width + 1) / 2 * 8;
+        case UG_PF_Y416: return width * 8;
         default: return 0;
         }
 }
 
-#define PAIR(a, b) ((a) * 16 + (b))
+#define PAIR(a, b) ((a) * 32 + (b))
 
 // ------------------------------ packed -> planar ------------------------------
 // uyvy_to_i420, to_planar.c:343-378: one lane per (row pair, pixel pair)
@@ -597,6 +603,7 @@ extern "C" {
 int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out)
 {
         if (in == out && in != UG_PF_NONE && size_of(in, 2) != 0) return 1;
+        if (ug::pixfmt_ext_supported(in, out)) return 1;
         switch (PAIR(in, out)) {
         case PAIR(UG_PF_V210, UG_PF_UYVY): case PAIR(UG_PF_YUYV, UG_PF_UYVY): case PAIR(UG_PF_UYVY, UG_PF_YUYV):
         case PAIR(UG_PF_UYVY, UG_PF_RGB): case PAIR(UG_PF_UYVY, UG_PF_RGBA): case PAIR(UG_PF_RGB, UG_PF_UYVY):
@@ -630,6 +637,9 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
 
         if (in == out && out != UG_PF_RGBA && out != UG_PF_RGB) { // get_decoder_from_to, pixfmt_conv.c:3111-3114
                 return launch_generic<Copy>(a, st);
+        }
+        if (ug::pixfmt_ext_supported(in, out)) {
+                return ug::pixfmt_ext_convert(in, out, src, dst, width, height, a.spitch, a.dpitch, a.dst_len, rshift, gshift, bshift, st);
         }
         switch (PAIR(in, out)) {
         case PAIR(UG_PF_V210, UG_PF_UYVY):

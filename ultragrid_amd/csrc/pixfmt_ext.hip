@@ -1,0 +1,667 @@
+// pixfmt_ext.hip -- the rest of decoders[] (src/pixfmt_conv.c:3041-3103): the line converters between the codecs
+// outside the v210 / UYVY / RGB / RGBA core -- R10k, R12L, RG48, Y216, Y416, VUYA, DVS10 -- so that every pair get_decoder_from_to()
+// answers is answered here too.  pixfmt.hip keeps the 17 pairs of P1-P6 with their vectorised fast paths; this file adds the other 44.
+//
+// Each kernel restates one reference function, one lane per iteration of its loop (a pixel, a pixel pair, a 6-pixel v210 group, an
+// 8-pixel R12L group) and per line, with the reference's own iteration count for the `dst_len` of a line (vc_get_size(width, out)),
+// so ragged line ends come out as they do there.  The hand-unrolled R12L functions are written here as what they compute -- a
+// little-endian stream of 12-bit r, g, b -- and checked byte for byte against the compiled reference (tests/test_gpu_pixfmt_ext.py).
+// Integer / byte work, HBM-bound.
+#include <string.h>
+
+#include "ug_common.h"
+
+namespace {
+
+struct XArgs {
+        const uint8_t *src;
+        uint8_t *dst;
+        long spitch, dpitch;
+        int width, height;
+        int L; // dst_len of a line
+        int rs, gs, bs;
+        uint32_t am;
+        int c[14];
+};
+enum { Y_R, Y_G, Y_B, CB_R, CB_G, CB_B, CR_R, CR_G, CR_B, Y_SCALE, R_CR, G_CB, G_CR, B_CB };
+constexpr int kBase = 14;
+
+#define XK(name) __global__ void name(const XArgs a)
+#define XPRO()                                                      \
+        const int x = blockIdx.x * blockDim.x + threadIdx.x;        \
+        const int y = blockIdx.y * blockDim.y + threadIdx.y;        \
+        if (y >= a.height) return;                                  \
+        const uint8_t *const srow = a.src + (long) y * a.spitch;    \
+        uint8_t *const drow = a.dst + (long) y * a.dpitch;          \
+        (void) srow, (void) drow
+#define TO_Y(r, g, b) ((r) * a.c[Y_R] + (g) * a.c[Y_G] + (b) * a.c[Y_B])
+#define TO_CB(r, g, b) ((r) * a.c[CB_R] + (g) * a.c[CB_G] + (b) * a.c[CB_B])
+#define TO_CR(r, g, b) ((r) * a.c[CR_R] + (g) * a.c[CR_G] + (b) * a.c[CR_B])
+#define TO_R(ys, u, v) ((ys) + (v) * a.c[R_CR])
+#define TO_G(ys, u, v) ((ys) + (u) * a.c[G_CB] + (v) * a.c[G_CR])
+#define TO_B(ys, u, v) ((ys) + (u) * a.c[B_CB])
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clamp_full(int v, int depth) { return clampi(v, 1 << (depth - 8), (255 << (depth - 8)) - 1); }
+
+// R10k pixel: 10-bit big-endian R G B in 4 bytes (the bit-field struct of pixfmt_conv.c:214-224)
+__device__ __forceinline__ void r10k_get(const uint8_t *s, uint32_t &r, uint32_t &g, uint32_t &b)
+{
+        r = s[0] << 2 | s[1] >> 6;
+        g = (s[1] & 0x3fu) << 4 | s[2] >> 4;
+        b = (s[2] & 0x0fu) << 6 | s[3] >> 2;
+}
+
+// 36 bytes of R12L <-> 8 x (r, g, b) of 12 bits, little-endian bit stream
+__device__ __forceinline__ void r12l_get(const uint8_t *s, uint32_t (&v)[24])
+{
+#pragma unroll
+        for (int k = 0; k < 12; k++) { // two values per three bytes
+                const uint32_t b0 = s[3 * k], b1 = s[3 * k + 1], b2 = s[3 * k + 2];
+                v[2 * k] = b0 | (b1 & 0xfu) << 8;
+                v[2 * k + 1] = b1 >> 4 | b2 << 4;
+        }
+}
+__device__ __forceinline__ void r12l_put(uint8_t *d, const uint32_t (&v)[24], int nbytes)
+{
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+                const uint32_t e = v[2 * k], o = v[2 * k + 1];
+                if (3 * k < nbytes) d[3 * k] = (uint8_t) e;
+                if (3 * k + 1 < nbytes) d[3 * k + 1] = (uint8_t) ((o & 0xfu) << 4 | e >> 8);
+                if (3 * k + 2 < nbytes) d[3 * k + 2] = (uint8_t) (o >> 4);
+        }
+}
+
+// ---- R10k sources ------------------------------------------------------------------------------------------------------------------
+XK(k_r10k_to_rgba) // vc_copyliner10k :211-276: len / 4 pixels, top 8 bits of each component
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        uint32_t r, g, b;
+        r10k_get(srow + 4 * x, r, g, b);
+        ((uint32_t *) drow)[x] = a.am | (r >> 2) << a.rs | (g >> 2) << a.gs | (b >> 2) << a.bs;
+}
+XK(k_r10k_to_rg48) // :279-295: while (dstlen > 0) -> ceil(L / 6) pixels
+{
+        XPRO();
+        if (x >= (a.L + 5) / 6) return;
+        const uint8_t *s = srow + 4 * x;
+        uint8_t *d = drow + 6 * x;
+        const uint32_t b2 = s[1], b3 = s[2], b4 = s[3];
+        d[1] = s[0], d[0] = b2 & 0xC0u;
+        d[3] = (uint8_t) (b2 << 2 | b3 >> 6), d[2] = (uint8_t) ((b3 & 0x30u) << 2);
+        d[5] = (uint8_t) ((b3 & 0xFu) << 4 | b4 >> 4), d[4] = (uint8_t) ((b4 & 0xCu) << 4);
+}
+XK(k_r10k_to_y416) // :297-329, 16-bit coefficients on components scaled to 16 bits
+{
+        XPRO();
+        if (x >= (a.L + 7) / 8) return;
+        const uint8_t *s = srow + 4 * x;
+        const int r = s[0] << 8 | (s[1] & 0xC0), g = (s[1] & 0x3F) << 10 | (s[2] & 0xF0) << 2, b = (s[2] & 0xF) << 12 | (s[3] & 0xFC) << 4;
+        uint16_t *d = (uint16_t *) drow + 4 * x;
+        d[0] = (uint16_t) ((TO_CB(r, g, b) >> kBase) + (1 << 15));
+        d[1] = (uint16_t) ((TO_Y(r, g, b) >> kBase) + (1 << 12));
+        d[2] = (uint16_t) ((TO_CR(r, g, b) >> kBase) + (1 << 15));
+        d[3] = 0xFFFF;
+}
+XK(k_r10k_to_rgb) // :331-341
+{
+        XPRO();
+        if (x >= (a.L + 2) / 3) return;
+        const uint8_t *s = srow + 4 * x;
+        uint8_t *d = drow + 3 * x;
+        d[0] = s[0], d[1] = (uint8_t) (s[1] << 2 | s[2] >> 6), d[2] = (uint8_t) (s[2] << 4 | s[3] >> 4);
+}
+
+// vc_copylineToUYVY on two 8-bit RGB pixels (:1008-1053): y = (Y >> 14) + 16, u = ((cb1 + cb2) / 2 >> 14) + 128
+__device__ __forceinline__ uint32_t rgb_pair_to_uyvy(const XArgs &a, int r1, int g1, int b1, int r2, int g2, int b2)
+{
+        const int y1 = (TO_Y(r1, g1, b1) >> kBase) + 16, y2 = (TO_Y(r2, g2, b2) >> kBase) + 16;
+        const int u = (((TO_CB(r1, g1, b1) + TO_CB(r2, g2, b2)) / 2) >> kBase) + 128, v = (((TO_CR(r1, g1, b1) + TO_CR(r2, g2, b2)) / 2) >> kBase) + 128;
+        return (uint32_t) (u & 0xff) | (uint32_t) (y1 & 0xff) << 8 | (uint32_t) (v & 0xff) << 16 | (uint32_t) (y2 & 0xff) << 24;
+}
+XK(k_r10k_to_uyvy) // vc_copylineR10ktoUYVY :2320-2340: top 8 bits, then vc_copylineRGBtoUYVY on the pair
+{
+        XPRO();
+        if (x >= (a.L + 3) / 4) return;
+        const uint8_t *s = srow + 8 * x;
+        const int r1 = s[0], g1 = (uint8_t) (s[1] << 2 | s[2] >> 6), b1 = (uint8_t) (s[2] << 4 | s[3] >> 4);
+        const int r2 = s[4], g2 = (uint8_t) (s[5] << 2 | s[6] >> 6), b2 = (uint8_t) (s[6] << 4 | s[7] >> 4);
+        ((uint32_t *) drow)[x] = rgb_pair_to_uyvy(a, r1, g1, b1, r2, g2, b2);
+}
+
+// ---- R12L sources (one lane per group of 8 pixels = 36 source bytes) ---------------------------------------------------------------
+XK(k_r12l_to_rgb) // vc_copylineR12LtoRGB :353-423: whole groups only (x <= dstlen - 24)
+{
+        XPRO();
+        if (x >= a.L / 24) return;
+        uint32_t v[24];
+        r12l_get(srow + 36 * x, v);
+        uint8_t *d = drow + 24 * x;
+#pragma unroll
+        for (int i = 0; i < 24; i++) d[i] = (uint8_t) (v[i] >> 4);
+}
+XK(k_r12l_to_rgba) // vc_copylineR12L :438-517: every started group, the last one cut at dstlen
+{
+        XPRO();
+        if (x >= (a.L + 31) / 32) return;
+        uint32_t v[24];
+        r12l_get(srow + 36 * x, v);
+        uint32_t *d = (uint32_t *) drow + 8 * x;
+        const int n = min(8, (a.L - 32 * x) / 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                if (i < n) d[i] = a.am | (v[3 * i] >> 4) << a.rs | (v[3 * i + 1] >> 4) << a.gs | (v[3 * i + 2] >> 4) << a.bs;
+        }
+        const int rem = a.L - 32 * x - 4 * n; // memcpy(orig_d, tmpbuf, dstlen - x) may end inside a pixel
+        if (n < 8 && rem > 0) {
+                const uint32_t w = a.am | (v[3 * n] >> 4) << a.rs | (v[3 * n + 1] >> 4) << a.gs | (v[3 * n + 2] >> 4) << a.bs;
+                for (int k = 0; k < rem; k++) ((uint8_t *) (d + n))[k] = (uint8_t) (w >> (8 * k));
+        }
+}
+XK(k_r12l_to_rg48) // :1371-1476: whole groups, then the head of one more
+{
+        XPRO();
+        if (x >= (a.L + 47) / 48) return;
+        uint32_t v[24];
+        r12l_get(srow + 36 * x, v);
+        uint8_t *d = drow + 48 * x;
+        const int nb = min(48, a.L - 48 * x);
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+                const uint32_t s16 = v[i] << 4;
+                if (2 * i < nb) d[2 * i] = (uint8_t) s16;
+                if (2 * i + 1 < nb) d[2 * i + 1] = (uint8_t) (s16 >> 8);
+        }
+}
+XK(k_r12l_to_r10k) // :1640-1699: whole groups only
+{
+        XPRO();
+        if (x >= a.L / 32) return;
+        uint32_t v[24];
+        r12l_get(srow + 36 * x, v);
+        uint8_t *d = drow + 32 * x;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                const uint32_t r = v[3 * i], g = v[3 * i + 1], b = v[3 * i + 2]; // 12 bit; the low two bits of b fall into the padding
+                d[4 * i] = (uint8_t) (r >> 4);
+                d[4 * i + 1] = (uint8_t) ((r & 0xC) << 4 | g >> 6);
+                d[4 * i + 2] = (uint8_t) ((g & 0x3C) << 2 | b >> 8);
+                d[4 * i + 3] = (uint8_t) b;
+        }
+        d[7] = (uint8_t) ((v[5] & 0xf0) | (v[3] & 0xf)); // pixel 1: `src[8 + 0] << 4 | (src[4 + 0] & 0xF0) >> 4` takes r1's low nibble (:1657)
+}
+XK(k_r12l_to_y416) // :1478-1542: every started group whole
+{
+        XPRO();
+        if (x >= (a.L + 63) / 64) return;
+        uint32_t v[24];
+        r12l_get(srow + 36 * x, v);
+        uint16_t *d = (uint16_t *) drow + 32 * x;
+        // the reference writes the last group whole, into the head of the next line, whose own conversion then overwrites it: inside
+        // the frame the result is the same as stopping at dst_len (lines are converted concurrently here)
+        const int n = min(8, (a.L - 64 * x) / 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                if (i >= n) break;
+                const int r = v[3 * i] << 4, g = v[3 * i + 1] << 4, b = v[3 * i + 2] << 4;
+                d[4 * i] = (uint16_t) ((TO_CB(r, g, b) >> kBase) + (1 << 15));
+                d[4 * i + 1] = (uint16_t) ((TO_Y(r, g, b) >> kBase) + (1 << 12));
+                d[4 * i + 2] = (uint16_t) ((TO_CR(r, g, b) >> kBase) + (1 << 15));
+                d[4 * i + 3] = 0xFFFF;
+        }
+}
+XK(k_r12l_to_uyvy) // :1544-1638: 16-bit-scaled components, 8-bit coefficients, >> (14 + 8)
+{
+        XPRO();
+        if (x >= (a.L + 15) / 16) return;
+        uint32_t v[24];
+        r12l_get(srow + 36 * x, v);
+        uint32_t *d = (uint32_t *) drow + 4 * x;
+        const int n = min(4, (a.L - 16 * x) / 4); // see k_r12l_to_y416
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+                if (i >= n) break;
+                const int r1 = v[6 * i] << 4, g1 = v[6 * i + 1] << 4, b1 = v[6 * i + 2] << 4, r2 = v[6 * i + 3] << 4, g2 = v[6 * i + 4] << 4, b2 = v[6 * i + 5] << 4;
+                const int u = ((TO_CB(r1, g1, b1) + TO_CB(r2, g2, b2)) >> (kBase + 9)) + 128, vv = ((TO_CR(r1, g1, b1) + TO_CR(r2, g2, b2)) >> (kBase + 9)) + 128;
+                const int y1 = (TO_Y(r1, g1, b1) >> (kBase + 8)) + 16, y2 = (TO_Y(r2, g2, b2) >> (kBase + 8)) + 16;
+                d[i] = (uint32_t) (u & 0xff) | (uint32_t) (y1 & 0xff) << 8 | (uint32_t) (vv & 0xff) << 16 | (uint32_t) (y2 & 0xff) << 24;
+        }
+}
+
+// ---- -> R12L -------------------------------------------------------------------------------------------------------------------------
+template <int BPP>
+XK(k_rgb_to_r12l) // vc_copylineRGB_AtoR12L :1263-1322: whole groups only, component << 4
+{
+        XPRO();
+        if (x >= a.L / 36) return;
+        uint32_t v[24];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                const uint8_t *s = srow + (long) BPP * (8 * x + i);
+                v[3 * i] = s[0] << 4, v[3 * i + 1] = s[1] << 4, v[3 * i + 2] = s[2] << 4;
+        }
+        r12l_put(drow + 36 * x, v, 36);
+}
+XK(k_rg48_to_r12l) // :1701-1826: whole groups only, component >> 4
+{
+        XPRO();
+        if (x >= a.L / 36) return;
+        const uint16_t *s = (const uint16_t *) srow + 24 * x;
+        uint32_t v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = s[i] >> 4;
+        r12l_put(drow + 36 * x, v, 36);
+}
+XK(k_y416_to_r12l) // :1828-1915: every started group whole
+{
+        XPRO();
+        if (x >= (a.L + 35) / 36) return;
+        const uint16_t *s = (const uint16_t *) srow + 32 * x;
+        uint32_t v[24];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+                const int u = s[4 * i] - (1 << 15), ys = a.c[Y_SCALE] * (s[4 * i + 1] - (1 << 12)), vv = s[4 * i + 2] - (1 << 15);
+                v[3 * i] = clamp_full(TO_R(ys, u, vv) >> (kBase + 4), 12);
+                v[3 * i + 1] = clamp_full(TO_G(ys, u, vv) >> (kBase + 4), 12);
+                v[3 * i + 2] = clamp_full(TO_B(ys, u, vv) >> (kBase + 4), 12);
+        }
+        r12l_put(drow + 36 * x, v, 36);
+}
+
+// ---- RGB / RGBA / UYVY -> 16-bit --------------------------------------------------------------------------------------------------
+XK(k_rgba_to_rg48) // :1336-1351
+{
+        XPRO();
+        if (x >= a.L / 6) return;
+        const uint8_t *s = srow + 4 * x;
+        uint16_t *d = (uint16_t *) drow + 3 * x;
+        d[0] = s[0] << 8, d[1] = s[1] << 8, d[2] = s[2] << 8;
+}
+XK(k_rgb_to_rg48) // :1353-1363: one lane per component
+{
+        XPRO();
+        if (x >= a.L / 2) return;
+        ((uint16_t *) drow)[x] = srow[x] << 8;
+}
+template <bool YUYV, bool RGB16>
+XK(k_yuv422_to_rgb) // copylineYUVtoRGB :1065-1094: vc_copylineUYVYtoRG48 (rgb16), vc_copylineYUYVtoRGB; clamp 0..255
+{
+        XPRO();
+        constexpr int kOut = RGB16 ? 12 : 6;
+        if (x >= a.L / kOut) return;
+        const uint8_t *s = srow + 4 * x;
+        const int y1 = a.c[Y_SCALE] * (s[YUYV ? 0 : 1] - 16), y2 = a.c[Y_SCALE] * (s[YUYV ? 2 : 3] - 16), u = s[YUYV ? 1 : 0] - 128, v = s[YUYV ? 3 : 2] - 128;
+        const int o[6] = { clampi(TO_R(y1, u, v) >> kBase, 0, 255), clampi(TO_G(y1, u, v) >> kBase, 0, 255), clampi(TO_B(y1, u, v) >> kBase, 0, 255),
+                           clampi(TO_R(y2, u, v) >> kBase, 0, 255), clampi(TO_G(y2, u, v) >> kBase, 0, 255), clampi(TO_B(y2, u, v) >> kBase, 0, 255) };
+        if (RGB16) {
+                uint16_t *d = (uint16_t *) drow + 6 * x;
+#pragma unroll
+                for (int i = 0; i < 6; i++) d[i] = (uint16_t) (o[i] << 8);
+        } else {
+                uint8_t *d = drow + 6 * x;
+#pragma unroll
+                for (int i = 0; i < 6; i++) d[i] = (uint8_t) o[i];
+        }
+}
+
+// ---- RG48 sources ---------------------------------------------------------------------------------------------------------------------
+XK(k_rg48_to_r10k) // :2008-2029
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint16_t *s = (const uint16_t *) srow + 3 * x;
+        const uint32_t r = s[0] >> 6, g = s[1] >> 6, b = s[2] >> 6;
+        ((uint32_t *) drow)[x] = (b & 0x3FU) << 26U | 0x3000000U | (g & 0xFU) << 20U | (b >> 6U) << 16U | (r & 0x3U) << 14U | (g >> 4U) << 8U | r >> 2U;
+}
+XK(k_rg48_to_rgb) // :2031-2043
+{
+        XPRO();
+        if (x >= a.L / 3) return;
+        const uint8_t *s = srow + 6 * x;
+        uint8_t *d = drow + 3 * x;
+        d[0] = s[1], d[1] = s[3], d[2] = s[5];
+}
+XK(k_rg48_to_rgba) // :2045-2059
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint8_t *s = srow + 6 * x;
+        ((uint32_t *) drow)[x] = a.am | (uint32_t) s[1] << a.rs | (uint32_t) s[3] << a.gs | (uint32_t) s[5] << a.bs;
+}
+XK(k_rg48_to_v210) // :2354-2408: whole 16-byte groups of 6 pixels
+{
+        XPRO();
+        if (x >= a.L / 16) return;
+        const uint16_t *s = (const uint16_t *) srow + 18 * x;
+        constexpr int off = kBase + 6;
+        int Y[6], U[3], V[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+                const int r1 = s[6 * i], g1 = s[6 * i + 1], b1 = s[6 * i + 2], r2 = s[6 * i + 3], g2 = s[6 * i + 4], b2 = s[6 * i + 5];
+                Y[2 * i] = (TO_Y(r1, g1, b1) >> off) + (1 << 6);
+                Y[2 * i + 1] = (TO_Y(r2, g2, b2) >> off) + (1 << 6);
+                U[i] = ((TO_CB(r1, g1, b1) >> off) + (TO_CB(r2, g2, b2) >> off)) / 2 + (1 << 9);
+                V[i] = ((TO_CR(r1, g1, b1) >> off) + (TO_CR(r2, g2, b2) >> off)) / 2 + (1 << 9);
+        }
+        uint32_t *d = (uint32_t *) drow + 4 * x; // unmasked ORs, as in the reference
+        d[0] = (uint32_t) (U[0] | Y[0] << 10 | V[0] << 20);
+        d[1] = (uint32_t) (Y[1] | U[1] << 10 | Y[2] << 20);
+        d[2] = (uint32_t) (V[1] | Y[3] << 10 | U[2] << 20);
+        d[3] = (uint32_t) (Y[4] | V[2] << 10 | Y[5] << 20);
+}
+XK(k_rg48_to_y216) // :2410-2449
+{
+        XPRO();
+        if (x >= (a.L + 7) / 8) return;
+        const uint16_t *s = (const uint16_t *) srow + 6 * x;
+        uint16_t *d = (uint16_t *) drow + 4 * x;
+        const int r1 = s[0], g1 = s[1], b1 = s[2], r2 = s[3], g2 = s[4], b2 = s[5];
+        d[0] = (uint16_t) ((TO_Y(r1, g1, b1) >> kBase) + (1 << 12));
+        d[1] = (uint16_t) ((((TO_CB(r1, g1, b1) >> kBase) + (TO_CB(r2, g2, b2) >> kBase)) / 2) + (1 << 15));
+        d[2] = (uint16_t) ((TO_Y(r2, g2, b2) >> kBase) + (1 << 12));
+        d[3] = (uint16_t) ((((TO_CR(r1, g1, b1) >> kBase) + (TO_CR(r2, g2, b2) >> kBase)) / 2) + (1 << 15));
+}
+XK(k_rg48_to_y416) // :2451-2483
+{
+        XPRO();
+        if (x >= (a.L + 7) / 8) return;
+        const uint16_t *s = (const uint16_t *) srow + 3 * x;
+        uint16_t *d = (uint16_t *) drow + 4 * x;
+        const int r = s[0], g = s[1], b = s[2];
+        d[0] = (uint16_t) ((TO_CB(r, g, b) >> kBase) + (1 << 15));
+        d[1] = (uint16_t) ((TO_Y(r, g, b) >> kBase) + (1 << 12));
+        d[2] = (uint16_t) ((TO_CR(r, g, b) >> kBase) + (1 << 15));
+        d[3] = 0xFFFF;
+}
+
+// ---- Y416 sources (U Y V A, 16 bit) ------------------------------------------------------------------------------------------------
+template <int OUT> // 0 RG48 (:2485-2518), 1 R10k (:1917-1946), 2 RGB (:1948-1976), 3 RGBA (:1978-2006)
+XK(k_y416_to_rgb)
+{
+        XPRO();
+        constexpr int kBytes = OUT == 0 ? 6 : (OUT == 2 ? 3 : 4);
+        if (x >= (a.L + kBytes - 1) / kBytes) return;
+        const uint16_t *s = (const uint16_t *) srow + 4 * x;
+        const int u = s[0] - (1 << 15), ys = a.c[Y_SCALE] * (s[1] - (1 << 12)), v = s[2] - (1 << 15);
+        constexpr int sh = kBase + (OUT == 0 ? 0 : (OUT == 1 ? 6 : 8)), depth = OUT == 0 ? 16 : (OUT == 1 ? 10 : 8);
+        const uint32_t r = clamp_full(TO_R(ys, u, v) >> sh, depth), g = clamp_full(TO_G(ys, u, v) >> sh, depth), b = clamp_full(TO_B(ys, u, v) >> sh, depth);
+        if (OUT == 0) {
+                uint16_t *d = (uint16_t *) drow + 3 * x;
+                d[0] = (uint16_t) r, d[1] = (uint16_t) g, d[2] = (uint16_t) b;
+        } else if (OUT == 1) {
+                uint8_t *d = drow + 4 * x;
+                d[0] = (uint8_t) (r >> 2), d[1] = (uint8_t) ((r & 0x3U) << 6U | g >> 4U), d[2] = (uint8_t) ((g & 0xFU) << 4U | b >> 6U), d[3] = (uint8_t) ((b & 0x3FU) << 2U);
+        } else if (OUT == 2) {
+                uint8_t *d = drow + 3 * x;
+                d[0] = (uint8_t) r, d[1] = (uint8_t) g, d[2] = (uint8_t) b;
+        } else {
+                ((uint32_t *) drow)[x] = a.am | r << a.rs | g << a.gs | b << a.bs;
+        }
+}
+XK(k_y416_to_uyvy) // :2745-2759: high bytes, (a + b) / 2 chroma
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint8_t *s = srow + 16 * x;
+        ((uint32_t *) drow)[x] = (uint32_t) ((s[1] + s[9]) / 2) | (uint32_t) s[3] << 8 | (uint32_t) ((s[5] + s[13]) / 2) << 16 | (uint32_t) s[11] << 24;
+}
+XK(k_y416_to_v210) // :3004-3029
+{
+        XPRO();
+        if (x >= a.L / 16) return;
+        const uint16_t *s = (const uint16_t *) srow + 24 * x;
+        uint32_t *d = (uint32_t *) drow + 4 * x;
+        uint32_t u[3], v[3], Y[6];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+                u[i] = (uint16_t) ((s[8 * i] + s[8 * i + 4]) / 2), v[i] = (uint16_t) ((s[8 * i + 2] + s[8 * i + 6]) / 2);
+                Y[2 * i] = s[8 * i + 1], Y[2 * i + 1] = s[8 * i + 5];
+        }
+        d[0] = u[0] >> 6U | Y[0] >> 6U << 10U | v[0] >> 6U << 20U;
+        d[1] = Y[1] >> 6U | u[1] >> 6U << 10U | Y[2] >> 6U << 20U;
+        d[2] = v[1] >> 6U | Y[3] >> 6U << 10U | u[2] >> 6U << 20U;
+        d[3] = Y[4] >> 6U | v[2] >> 6U << 10U | Y[5] >> 6U << 20U;
+}
+
+// ---- 8-bit packed YUV <-> 16-bit packed YUV, VUYA -------------------------------------------------------------------------------------
+XK(k_rgba_to_vuya) // :2281-2309
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint8_t *s = srow + 4 * x;
+        const int r = s[0], g = s[1], b = s[2];
+        ((uint32_t *) drow)[x] = (uint32_t) (((TO_CR(r, g, b) >> kBase) + 128) & 0xff) | (uint32_t) (((TO_CB(r, g, b) >> kBase) + 128) & 0xff) << 8 |
+                                 (uint32_t) (((TO_Y(r, g, b) >> kBase) + 16) & 0xff) << 16 | (uint32_t) s[3] << 24;
+}
+XK(k_rgba_to_r10k) // :2538-2579 (bit-field struct: p3 = 3, the other padding bits 0)
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint8_t *s = srow + 4 * x;
+        const uint32_t r = s[0], g = s[1], b = s[2];
+        ((uint32_t *) drow)[x] = r | (g >> 2) << 8 | (b >> 4) << 16 | (g & 3u) << 22 | 3u << 24 | (b & 0xfu) << 28;
+}
+XK(k_uyvy_to_y216) // :2609-2627
+{
+        XPRO();
+        if (x >= a.L / 8) return;
+        const uint8_t *s = srow + 4 * x;
+        uint16_t *d = (uint16_t *) drow + 4 * x;
+        d[0] = s[1] << 8, d[1] = s[0] << 8, d[2] = s[3] << 8, d[3] = s[2] << 8;
+}
+XK(k_uyvy_to_y416) // :2629-2664: pairs while dst_len >= 12 (the second pixel is written whole even when only 12 bytes remain), then one more pixel
+{
+        XPRO();
+        int pairs = 0, len = a.L;
+        while (len >= 12) pairs++, len -= 16;
+        const bool tail = len >= 8;
+        if (x >= pairs + (tail ? 1 : 0)) return;
+        const uint8_t *s = srow + 4 * x;
+        uint16_t *d = (uint16_t *) drow + 8 * x;
+        d[0] = s[0] << 8, d[1] = s[1] << 8, d[2] = s[2] << 8, d[3] = 0xFFFF;
+        if (x < pairs) d[4] = s[0] << 8, d[5] = s[3] << 8, d[6] = s[2] << 8, d[7] = 0xFFFF;
+}
+XK(k_vuya_to_y416) // :2668-2687
+{
+        XPRO();
+        if (x >= a.L / 8) return;
+        const uint8_t *s = srow + 4 * x;
+        uint16_t *d = (uint16_t *) drow + 4 * x;
+        d[0] = s[1] << 8, d[1] = s[2] << 8, d[2] = s[0] << 8, d[3] = s[3] << 8;
+}
+XK(k_vuya_to_uyvy) // :2689-2704 (Y1 is taken from the second pixel's alpha byte, src[7], as written there)
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint8_t *s = srow + 8 * x;
+        ((uint32_t *) drow)[x] = (uint32_t) ((s[1] + s[5]) / 2) | (uint32_t) s[2] << 8 | (uint32_t) ((s[0] + s[4]) / 2) << 16 | (uint32_t) s[7] << 24;
+}
+XK(k_vuya_to_rgb) // :2706-2727
+{
+        XPRO();
+        if (x >= (a.L + 2) / 3) return;
+        const uint8_t *s = srow + 4 * x;
+        const int v = s[0] - 128, u = s[1] - 128, ys = a.c[Y_SCALE] * (s[2] - 16);
+        uint8_t *d = drow + 3 * x;
+        d[0] = (uint8_t) clamp_full(TO_R(ys, u, v) >> kBase, 8), d[1] = (uint8_t) clamp_full(TO_G(ys, u, v) >> kBase, 8), d[2] = (uint8_t) clamp_full(TO_B(ys, u, v) >> kBase, 8);
+}
+XK(k_y216_to_uyvy) // :2729-2743
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint8_t *s = srow + 8 * x;
+        ((uint32_t *) drow)[x] = (uint32_t) s[3] | (uint32_t) s[1] << 8 | (uint32_t) s[7] << 16 | (uint32_t) s[5] << 24;
+}
+XK(k_y216_to_v210) // :2761-2790: (dst_len + 15) / 16 groups
+{
+        XPRO();
+        if (x >= (a.L + 15) / 16) return;
+        const uint16_t *s = (const uint16_t *) srow + 12 * x;
+        uint32_t *d = (uint32_t *) drow + 4 * x;
+        d[0] = s[1] >> 6U | s[0] >> 6U << 10U | s[3] >> 6U << 20U;
+        d[1] = s[2] >> 6U | s[5] >> 6U << 10U | s[4] >> 6U << 20U;
+        d[2] = s[7] >> 6U | s[6] >> 6U << 10U | s[9] >> 6U << 20U;
+        d[3] = s[8] >> 6U | s[11] >> 6U << 10U | s[10] >> 6U << 20U;
+}
+template <bool Y416>
+XK(k_v210_to_y2xx) // vc_copylineV210toY216 :2792-2832 (dst_len / 24 groups), vc_copylineV210toY416 :2834-2882 (dst_len / 48)
+{
+        XPRO();
+        if (x >= a.L / (Y416 ? 48 : 24)) return;
+        const uint32_t *s = (const uint32_t *) srow + 4 * x;
+        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2], w3 = s[3];
+        const uint32_t Y[6] = { (w0 >> 10) & 0x3ff, w1 & 0x3ff, (w1 >> 20) & 0x3ff, (w2 >> 10) & 0x3ff, w3 & 0x3ff, (w3 >> 20) & 0x3ff };
+        const uint32_t U[3] = { w0 & 0x3ff, (w1 >> 10) & 0x3ff, (w2 >> 20) & 0x3ff }, V[3] = { (w0 >> 20) & 0x3ff, w2 & 0x3ff, (w3 >> 10) & 0x3ff };
+        if (Y416) {
+                uint16_t *d = (uint16_t *) drow + 24 * x;
+#pragma unroll
+                for (int i = 0; i < 6; i++) d[4 * i] = U[i / 2] << 6, d[4 * i + 1] = Y[i] << 6, d[4 * i + 2] = V[i / 2] << 6, d[4 * i + 3] = 0xFFFF;
+        } else {
+                uint16_t *d = (uint16_t *) drow + 12 * x;
+#pragma unroll
+                for (int i = 0; i < 3; i++) d[4 * i] = Y[2 * i] << 6, d[4 * i + 1] = U[i] << 6, d[4 * i + 2] = Y[2 * i + 1] << 6, d[4 * i + 3] = V[i] << 6;
+        }
+}
+
+// ---- DVS10 ------------------------------------------------------------------------------------------------------------------------------
+XK(k_dvs10_to_v210) // :595-617
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        uint32_t av = ((const uint32_t *) srow)[x], b = av;
+        b = ((b >> 24) * 0x00010101) & 0x00300c03;
+        av <<= 2;
+        b |= av & (0xff << 2);
+        av <<= 2;
+        b |= av & (0xff00 << 4);
+        av <<= 2;
+        b |= av & (0xff0000 << 6);
+        ((uint32_t *) drow)[x] = b;
+}
+XK(k_dvs10_to_uyvy) // vc_copylineDVS10 :690-721: src_len = dst_len / 1.5, one iteration per 16 of it, each moving 32 source bytes to 24
+{                   // (three of every four bytes)
+        XPRO();
+        if (x >= (int) (a.L / 1.5) / 16 * 8) return;
+        const uint8_t *s = srow + 4 * x;
+        uint8_t *d = drow + 3 * x;
+        d[0] = s[0], d[1] = s[1], d[2] = s[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+enum Iter { I_PX, I_PAIR, I_G6, I_G8, I_COMP, I_DVS };
+struct Entry {
+        int in, out;
+        void (*kernel)(const XArgs);
+        Iter iter;
+        int coeff_depth;
+};
+const Entry kTable[] = {
+        { UG_PF_DVS10, UG_PF_UYVY, k_dvs10_to_uyvy, I_DVS, 0 },
+        { UG_PF_DVS10, UG_PF_V210, k_dvs10_to_v210, I_COMP, 0 },
+        { UG_PF_R10K, UG_PF_RGBA, k_r10k_to_rgba, I_PX, 0 },
+        { UG_PF_R10K, UG_PF_RG48, k_r10k_to_rg48, I_PX, 0 },
+        { UG_PF_R10K, UG_PF_Y416, k_r10k_to_y416, I_PX, 16 },
+        { UG_PF_R10K, UG_PF_RGB, k_r10k_to_rgb, I_PX, 0 },
+        { UG_PF_R10K, UG_PF_UYVY, k_r10k_to_uyvy, I_PAIR, 8 },
+        { UG_PF_R12L, UG_PF_RGBA, k_r12l_to_rgba, I_G8, 0 },
+        { UG_PF_R12L, UG_PF_RGB, k_r12l_to_rgb, I_G8, 0 },
+        { UG_PF_R12L, UG_PF_RG48, k_r12l_to_rg48, I_G8, 0 },
+        { UG_PF_R12L, UG_PF_R10K, k_r12l_to_r10k, I_G8, 0 },
+        { UG_PF_R12L, UG_PF_Y416, k_r12l_to_y416, I_G8, 16 },
+        { UG_PF_R12L, UG_PF_UYVY, k_r12l_to_uyvy, I_G8, 8 },
+        { UG_PF_RGBA, UG_PF_R12L, k_rgb_to_r12l<4>, I_G8, 0 },
+        { UG_PF_RGB, UG_PF_R12L, k_rgb_to_r12l<3>, I_G8, 0 },
+        { UG_PF_RGBA, UG_PF_RG48, k_rgba_to_rg48, I_PX, 0 },
+        { UG_PF_RGB, UG_PF_RG48, k_rgb_to_rg48, I_COMP, 0 },
+        { UG_PF_UYVY, UG_PF_RG48, k_yuv422_to_rgb<false, true>, I_PAIR, 8 },
+        { UG_PF_RG48, UG_PF_R12L, k_rg48_to_r12l, I_G8, 0 },
+        { UG_PF_RG48, UG_PF_R10K, k_rg48_to_r10k, I_PX, 0 },
+        { UG_PF_RG48, UG_PF_RGB, k_rg48_to_rgb, I_PX, 0 },
+        { UG_PF_RG48, UG_PF_RGBA, k_rg48_to_rgba, I_PX, 0 },
+        { UG_PF_RG48, UG_PF_V210, k_rg48_to_v210, I_G6, 10 },
+        { UG_PF_RG48, UG_PF_Y216, k_rg48_to_y216, I_PAIR, 16 },
+        { UG_PF_RG48, UG_PF_Y416, k_rg48_to_y416, I_PX, 16 },
+        { UG_PF_Y416, UG_PF_RG48, k_y416_to_rgb<0>, I_PX, 16 },
+        { UG_PF_RGBA, UG_PF_VUYA, k_rgba_to_vuya, I_PX, 8 },
+        { UG_PF_YUYV, UG_PF_RGB, k_yuv422_to_rgb<true, false>, I_PAIR, 8 },
+        { UG_PF_RGBA, UG_PF_R10K, k_rgba_to_r10k, I_PX, 0 },
+        { UG_PF_UYVY, UG_PF_Y216, k_uyvy_to_y216, I_PAIR, 0 },
+        { UG_PF_UYVY, UG_PF_Y416, k_uyvy_to_y416, I_PAIR, 0 },
+        { UG_PF_VUYA, UG_PF_Y416, k_vuya_to_y416, I_PX, 0 },
+        { UG_PF_VUYA, UG_PF_UYVY, k_vuya_to_uyvy, I_PAIR, 0 },
+        { UG_PF_VUYA, UG_PF_RGB, k_vuya_to_rgb, I_PX, 8 },
+        { UG_PF_Y216, UG_PF_UYVY, k_y216_to_uyvy, I_PAIR, 0 },
+        { UG_PF_Y216, UG_PF_V210, k_y216_to_v210, I_G6, 0 },
+        { UG_PF_Y416, UG_PF_UYVY, k_y416_to_uyvy, I_PAIR, 0 },
+        { UG_PF_Y416, UG_PF_V210, k_y416_to_v210, I_G6, 0 },
+        { UG_PF_Y416, UG_PF_R12L, k_y416_to_r12l, I_G8, 16 },
+        { UG_PF_Y416, UG_PF_R10K, k_y416_to_rgb<1>, I_PX, 16 },
+        { UG_PF_Y416, UG_PF_RGB, k_y416_to_rgb<2>, I_PX, 16 },
+        { UG_PF_Y416, UG_PF_RGBA, k_y416_to_rgb<3>, I_PX, 16 },
+        { UG_PF_V210, UG_PF_Y216, k_v210_to_y2xx<false>, I_G6, 0 },
+        { UG_PF_V210, UG_PF_Y416, k_v210_to_y2xx<true>, I_G6, 0 },
+};
+
+// BT.709 limited-range coefficient sets of get_color_coeffs(CS_DFL, depth) (color_space.c:149-184) for depth 8, 10, 16 -- the same
+// constants as lavc_conv.hip, checked against the compiled reference through ug_hip_color_coeffs
+const int kC8[14] = { 2992, 10063, 1016, -1649, -5547, 7196, 7195, -6536, -659, 19077, 29371, -3494, -8733, 34610 };
+const int kC10[14] = { 2983, 10034, 1013, -1644, -5531, 7175, 7174, -6517, -657, 19133, 29457, -3504, -8758, 34712 };
+const int kC16[14] = { 2980, 10024, 1012, -1643, -5525, 7168, 7167, -6511, -656, 19152, 29486, -3507, -8767, 34745 };
+
+const Entry *find(int in, int out)
+{
+        for (const Entry &e : kTable) {
+                if (e.in == in && e.out == out) return &e;
+        }
+        return nullptr;
+}
+
+} // namespace
+
+namespace ug {
+
+int pixfmt_ext_supported(ug_pixfmt_t in, ug_pixfmt_t out) { return find(in, out) != nullptr; }
+
+int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height, int src_pitch, int dst_pitch, int dst_len,
+                       int rshift, int gshift, int bshift, hipStream_t st)
+{
+        const Entry *e = find(in, out);
+        if (!e) return UG_HIP_EUNSUPP;
+        if ((unsigned) rshift > 24 || (unsigned) gshift > 24 || (unsigned) bshift > 24) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert: rgb shift out of range");
+                return UG_HIP_EINVAL;
+        }
+        // the 16- and 32-bit formats are addressed as such (the reference asserts the same alignments)
+        const bool wide_src = in == UG_PF_RG48 || in == UG_PF_Y216 || in == UG_PF_Y416 || in == UG_PF_V210 || in == UG_PF_DVS10;
+        const bool wide_dst = out != UG_PF_RGB && out != UG_PF_R12L && out != UG_PF_R10K;
+        if ((wide_src && (((uintptr_t) src | (uintptr_t) src_pitch) & (in == UG_PF_V210 || in == UG_PF_DVS10 ? 3 : 1))) ||
+            (wide_dst && (((uintptr_t) dst | (uintptr_t) dst_pitch) & (out == UG_PF_RG48 || out == UG_PF_Y216 || out == UG_PF_Y416 ? 1 : 3))) ||
+            (out == UG_PF_R10K && in != UG_PF_R12L && in != UG_PF_Y416 && (((uintptr_t) dst | (uintptr_t) dst_pitch) & 3))) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert: buffer or pitch not aligned for this pair");
+                return UG_HIP_EINVAL;
+        }
+        XArgs a = {};
+        a.src = (const uint8_t *) src, a.dst = (uint8_t *) dst;
+        a.spitch = src_pitch, a.dpitch = dst_pitch;
+        a.width = width, a.height = height, a.L = dst_len;
+        a.rs = rshift, a.gs = gshift, a.bs = bshift;
+        a.am = 0xFFFFFFFFu ^ (0xFFu << rshift) ^ (0xFFu << gshift) ^ (0xFFu << bshift);
+        if (e->coeff_depth) memcpy(a.c, e->coeff_depth == 8 ? kC8 : (e->coeff_depth == 10 ? kC10 : kC16), sizeof a.c);
+        int nx = 0; // an upper bound of the lanes a line needs; every kernel re-derives its exact count from dst_len
+        switch (e->iter) {
+        case I_PX: nx = width + 1; break;
+        case I_PAIR: nx = (width + 1) / 2 + 1; break;
+        case I_G6: nx = (width + 5) / 6 + 1; break;
+        case I_G8: nx = (width + 7) / 8 + 1; break;
+        case I_COMP: nx = dst_len; break;
+        case I_DVS: nx = (int) (dst_len / 1.5) / 16 * 8; break;
+        }
+        const dim3 block(64, 4, 1), grid((unsigned) ((nx + 63) / 64), (unsigned) ((height + 3) / 4), 1);
+        hipLaunchKernelGGL(e->kernel, grid, block, 0, st, a);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
+} // namespace ug

@@ -44,7 +44,13 @@ static inline int linesize(ug_pixfmt_t f, int width)
         case UG_PF_RGB:
         case UG_PF_BGR:
         case UG_PF_YUV444: bb = 3; bp = 1; ha = 1; break;
+        case UG_PF_DVS10:
         case UG_PF_V210: bb = 16; bp = 6; ha = 48; break;
+        case UG_PF_R10K: bb = 4; bp = 1; ha = 64; break;
+        case UG_PF_R12L: bb = 36; bp = 8; ha = 8; break;
+        case UG_PF_Y216: bb = 8; bp = 2; ha = 2; break;
+        case UG_PF_Y416: bb = 8; bp = 1; ha = 1; break;
+        case UG_PF_VUYA: bb = 4; bp = 1; ha = 1; break;
         case UG_PF_RG48: bb = 6; bp = 1; ha = 1; break;
         default: return 0;
         }
@@ -58,5 +64,10 @@ int jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width
 
 int jpeg_fdct_quant_rgb444(const void *src, int pitch, int width, int height, int blocks_w, int blocks_h, const float *div,
                            int16_t *out_r, int16_t *out_g, int16_t *out_b, ug_hip_stream_t stream);
+
+// pixfmt_ext.hip: the pairs of decoders[] outside pixfmt.hip's core
+int pixfmt_ext_supported(ug_pixfmt_t in, ug_pixfmt_t out);
+int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height, int src_pitch, int dst_pitch, int dst_len,
+                       int rshift, int gshift, int bshift, hipStream_t st);
 
 } // namespace ug

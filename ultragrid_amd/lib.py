@@ -15,8 +15,10 @@ LIB_PATH = os.environ.get("UG_MI355X_LIB") or os.path.join(_HERE, "libug_mi355x.
 
 # ug_pixfmt_t
 PF_NONE, PF_RGBA, PF_UYVY, PF_YUYV, PF_RGB, PF_BGR, PF_V210, PF_RG48, PF_YUV444, PF_UYVY_RAW, PF_I420 = range(11)
+PF_R10K, PF_R12L, PF_Y216, PF_Y416, PF_VUYA, PF_DVS10 = range(11, 17)
 PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "BGR": PF_BGR, "v210": PF_V210,
-            "RG48": PF_RG48, "YUV444": PF_YUV444, "UYVY_RAW": PF_UYVY_RAW}
+            "RG48": PF_RG48, "YUV444": PF_YUV444, "UYVY_RAW": PF_UYVY_RAW, "R10k": PF_R10K, "R12L": PF_R12L, "Y216": PF_Y216,
+            "Y416": PF_Y416, "VUYA": PF_VUYA, "DVS10": PF_DVS10}
 # ug_dxt_t
 DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 
