@@ -180,7 +180,7 @@ def main() -> None:
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": f"dxt_encode_kernel<{wl['fmt']},DXT5_YCOCG>", "ms_per_launch": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * F * W * H),
-                         "note": "VALU-issue-bound kernel (SURVEY.md F9): 746 issue slots per wave against a floor of 610 (DESIGN.md 4.1)"},
+                         "note": "VALU-issue-bound kernel (SURVEY.md F9): about 660 VALU issue slots per wave against a floor of about 600 for this formulation (DESIGN.md 4.1)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H)
