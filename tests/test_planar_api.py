@@ -208,6 +208,8 @@ def test_gpu_planar_api_rejects_unknown_names_and_bad_depths(hip):
     out = torch.zeros((4, 64), dtype=torch.uint8, device="cuda")
     with pytest.raises(Exception):
         hip.from_planar("rgbpXXle_to_r12l", [p, p, p], 8, 4, out, 64, in_depth=10)  # the reference would shift by a negative count
+    with pytest.raises(Exception):
+        hip.from_planar("gbrp12le_to_rgb", [p, p, p], 8, 4, out, 0)  # a pitch of 0 would fold every line onto the first
 
 
 @pytest.mark.gpu

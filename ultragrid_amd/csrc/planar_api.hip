@@ -499,6 +499,11 @@ int from_rgbp(const FromConv &c, const ug_from_planar_data *d, hipStream_t st)
         }
         a.in_align = common_align(16, bytes8 ? 8 : 16, ptrs, ls, nplanes);
         static const int kGroupBytes[] = { 24, 32, 32, 48, 32, 36 };
+        const long need = c.out == O_R12L ? (d->width + 7) / 8 * 36L : (long) d->width * kGroupBytes[c.out] / 8;
+        if ((long) d->out_pitch < need) {
+                ug::set_last_error_msg("ug_hip_from_planar: out_pitch is smaller than a line of the output format");
+                return UG_HIP_EINVAL;
+        }
         const void *optr[1] = { a.out };
         const unsigned ols[1] = { a.pitch };
         a.out_align = common_align(16, kGroupBytes[c.out], optr, ols, 1);
@@ -533,6 +538,10 @@ int from_yuv(const FromConv &c, const ug_from_planar_data *d, hipStream_t st)
         const void *optr[1] = { a.out };
         const unsigned ols[1] = { a.pitch };
         const dim3 block(64, 4, 1);
+        if ((long) a.pitch < (c.family == FromConv::VUYA ? 4L * a.width : 4L * (a.width / 2))) {
+                ug::set_last_error_msg("ug_hip_from_planar: out_pitch is smaller than a line of the output format");
+                return UG_HIP_EINVAL;
+        }
         if (c.family == FromConv::VUYA) {
                 a.in_align = common_align(8, 8, ptrs, ls, 3);
                 a.out_align = common_align(16, 32, optr, ols, 1);
