@@ -863,6 +863,141 @@ __global__ void k_vuyax_to_y416(const Args a) // :2001-2015
         dst[0] = src[1] << 8U, dst[1] = src[2] << 8U, dst[2] = src[0] << 8U, dst[3] = ALPHA ? src[3] << 8U : 0xFFFF;
 }
 
+// ---- 8-pixel-per-lane variants of the most used 8-bit conversions (same arithmetic, 64-128 bit accesses) ----------------------------------
+// Taken when every pointer and line size is a multiple of 16 and the lane count divides the line (launch()); otherwise the kernels above.
+
+__device__ __forceinline__ uint32_t byte_of(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
+
+template <bool RGBA>
+__device__ __forceinline__ void store_px8(const Args &a, uint8_t *row, int lane, const int (&r)[8], const int (&g)[8], const int (&b)[8])
+{
+        if (RGBA) {
+                uint32_t w[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) w[i] = mk_rgba(a, r[i], g[i], b[i]);
+                uint4 *d = (uint4 *) (row + 32L * lane);
+                d[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        } else {
+                uint32_t by[24];
+#pragma unroll
+                for (int i = 0; i < 8; i++) by[3 * i] = clamp_full(r[i], 8), by[3 * i + 1] = clamp_full(g[i], 8), by[3 * i + 2] = clamp_full(b[i], 8);
+                uint2 *d = (uint2 *) (row + 24L * lane);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                        d[i] = make_uint2(by[8 * i] | by[8 * i + 1] << 8 | by[8 * i + 2] << 16 | by[8 * i + 3] << 24,
+                                          by[8 * i + 4] | by[8 * i + 5] << 8 | by[8 * i + 6] << 16 | by[8 * i + 7] << 24);
+                }
+        }
+}
+
+template <int SUB, bool RGBA>
+__global__ void k_yuv8p_to_rgb_x8(const Args a) // yuv8p_to_rgb, 4 pixel pairs of a line pair per lane
+{
+        UG_XY();
+        if (x >= a.w / 8 || y >= a.h / 2) return;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+                const int row = 2 * y + l, crow = SUB == 420 ? y : row;
+                const uint2 yy = *(const uint2 *) (ROW(const uint8_t, 0, row) + 8 * x);
+                const uint32_t cb4 = *(const uint32_t *) (ROW(const uint8_t, 1, crow) + 4 * x), cr4 = *(const uint32_t *) (ROW(const uint8_t, 2, crow) + 4 * x);
+                int r[8], g[8], b[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                        const int cb = (int) byte_of(cb4, i / 2) - 128, cr = (int) byte_of(cr4, i / 2) - 128;
+                        const int ys = ((int) byte_of(i < 4 ? yy.x : yy.y, i % 4) - 16) * a.c[Y_SCALE];
+                        r[i] = (ys + cr * a.c[R_CR]) >> kBase, g[i] = (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> kBase, b[i] = (ys + cb * a.c[B_CB]) >> kBase;
+                }
+                store_px8<RGBA>(a, BUF(uint8_t, row), x, r, g, b);
+        }
+}
+
+template <int OUT> // 0 UYVY, 1 RGB, 2 RGBA
+__global__ void k_nv12_x8(const Args a) // nv12_to_uyvy / nv12_to_rgb, 4 pixel pairs per lane
+{
+        UG_XY();
+        if (x >= a.w / 8 || y >= a.h) return;
+        const uint2 yy = *(const uint2 *) (ROW(const uint8_t, 0, y) + 8 * x), cc = *(const uint2 *) (ROW(const uint8_t, 1, y / 2) + 8 * x);
+        if (OUT == 0) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                        const uint32_t c2 = i < 2 ? cc.x : cc.y, y2 = i < 2 ? yy.x : yy.y;
+                        w[i] = byte_of(c2, 2 * (i % 2)) | byte_of(y2, 2 * (i % 2)) << 8 | byte_of(c2, 2 * (i % 2) + 1) << 16 | byte_of(y2, 2 * (i % 2) + 1) << 24;
+                }
+                *(uint4 *) (BUF(uint8_t, y) + 16L * x) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+                int r[8], g[8], b[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { // both pixels of a pair take the first one's colour (:797-811)
+                        const uint32_t c2 = i < 2 ? cc.x : cc.y, y2 = i < 2 ? yy.x : yy.y;
+                        const int cb = (int) byte_of(c2, 2 * (i % 2)) - 128, cr = (int) byte_of(c2, 2 * (i % 2) + 1) - 128;
+                        const int ys = ((int) byte_of(y2, 2 * (i % 2)) - 16) * a.c[Y_SCALE];
+                        r[2 * i] = r[2 * i + 1] = (ys + cr * a.c[R_CR]) >> kBase;
+                        g[2 * i] = g[2 * i + 1] = (ys + cb * a.c[G_CB] + cr * a.c[G_CR]) >> kBase;
+                        b[2 * i] = b[2 * i + 1] = (ys + cb * a.c[B_CB]) >> kBase;
+                }
+                store_px8<OUT == 2>(a, BUF(uint8_t, y), x, r, g, b);
+        }
+}
+
+template <int BPP>
+__global__ void k_rgb_to_gbrp_x8(const Args a) // rgb_rgba_to_gbrp, 8 pixels per lane
+{
+        UG_XY();
+        if (x >= a.w / 8 || y >= a.h) return;
+        const uint32_t *src = (const uint32_t *) (a.buf + (long) y * (BPP * a.w)) + 2 * BPP * x;
+        uint32_t w[2 * BPP];
+#pragma unroll
+        for (int i = 0; i < 2 * BPP; i++) w[i] = src[i];
+        uint32_t c[3][2] = {};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                        const int bi = BPP * i + k;
+                        c[k][i / 4] |= byte_of(w[bi / 4], bi % 4) << (8 * (i % 4));
+                }
+        }
+        *(uint2 *) (ROW(uint8_t, 2, y) + 8 * x) = make_uint2(c[0][0], c[0][1]);
+        *(uint2 *) (ROW(uint8_t, 0, y) + 8 * x) = make_uint2(c[1][0], c[1][1]);
+        *(uint2 *) (ROW(uint8_t, 1, y) + 8 * x) = make_uint2(c[2][0], c[2][1]);
+}
+
+template <int SRC> // S_420P8 / S_422P8: four 6-pixel groups per lane
+__global__ void k_planar8_to_v210_x4(const Args a)
+{
+        UG_XY();
+        constexpr bool k420 = SRC == S_420P8;
+        if (x >= a.w / 24 || y >= (k420 ? a.h / 2 : a.h)) return;
+        const uint8_t *pcb = ROW(const uint8_t, 1, y) + 12 * x, *pcr = ROW(const uint8_t, 2, y) + 12 * x;
+        uint32_t cbw[3], crw[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) cbw[i] = ((const uint32_t *) pcb)[i], crw[i] = ((const uint32_t *) pcr)[i];
+#pragma unroll
+        for (int l = 0; l < (k420 ? 2 : 1); l++) {
+                const int row = k420 ? 2 * y + l : y;
+                const uint2 *py = (const uint2 *) (ROW(const uint8_t, 0, row) + 24 * x);
+                uint32_t yw[6];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                        const uint2 v = py[i];
+                        yw[2 * i] = v.x, yw[2 * i + 1] = v.y;
+                }
+                uint4 *dst = (uint4 *) (BUF(uint8_t, row) + 64L * x);
+#pragma unroll
+                for (int gidx = 0; gidx < 4; gidx++) {
+                        uint32_t Y[6], cb[3], cr[3];
+#pragma unroll
+                        for (int i = 0; i < 6; i++) Y[i] = byte_of(yw[(6 * gidx + i) / 4], (6 * gidx + i) % 4) << 2;
+                        if (k420) Y[4] >>= 2; // unshifted in the reference (:599-600)
+#pragma unroll
+                        for (int i = 0; i < 3; i++) cb[i] = byte_of(cbw[(3 * gidx + i) / 4], (3 * gidx + i) % 4) << 2, cr[i] = byte_of(crw[(3 * gidx + i) / 4], (3 * gidx + i) % 4) << 2;
+                        dst[gidx] = make_uint4(v210w(cb[0], Y[0], cr[0]), v210w(Y[1], cb[1], Y[2]), v210w(cr[1], Y[3], cb[2]), v210w(Y[4], cr[2], Y[5]));
+                }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 enum Nx { NX_W, NX_W2, NX_W2UP, NX_W6, NX_W6UP, NX_W8UP };
 enum Ny { NY_H, NY_H2, NY_H2UP };
@@ -877,6 +1012,8 @@ struct Conv {
         Fwd fwd;
         const char *fwd_name;
         int min_planes;
+        void (*fast)(const Args); // optional wide variant: fast_div iterations of `kernel` per lane
+        int fast_div;
 };
 
 // get_uv_to_av_conversion table, to_lavc_vid_conv.c:1458-1529 (rows for UYVY, v210, RGB, RGBA)
@@ -900,9 +1037,9 @@ const Conv kToAv[] = {
         { "v210", "y210le", k_v210_to_y210, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
         { "v210", "y212le", k_v210_to_y210, NX_W6UP, NY_H, 0, F_NONE, nullptr, 1 },
         { "RGB", "bgr0", nullptr, NX_W, NY_H, 0, F_PIXFMT_RGB_BGR0, nullptr, 1 },
-        { "RGB", "gbrp", k_rgb_to_gbrp<3>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGB", "gbrp", k_rgb_to_gbrp<3>, NX_W, NY_H, 0, F_NONE, nullptr, 3 , k_rgb_to_gbrp_x8<3>, 8 },
         { "RGB", "yuv444p", k_rgb_to_yuv444p, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
-        { "RGBA", "gbrp", k_rgb_to_gbrp<4>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGBA", "gbrp", k_rgb_to_gbrp<4>, NX_W, NY_H, 0, F_NONE, nullptr, 3 , k_rgb_to_gbrp_x8<4>, 8 },
         { "RGBA", "bgra", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "rgba_to_bgra", 1 },
         { "Y216", "y210le", nullptr, NX_W, NY_H, 0, F_MEMCPY, nullptr, 1 },
         { "Y216", "y212le", nullptr, NX_W, NY_H, 0, F_MEMCPY, nullptr, 1 },
@@ -965,22 +1102,22 @@ const Conv kFromAv[] = {
         { "UYVY", "p210le", k_p210le_to_uyvy, NX_W2, NY_H, 0, F_NONE, nullptr, 2 },
         { "v210", "p010le", k_planar_to_v210<S_P010>, NX_W6, NY_H2, 0, F_NONE, nullptr, 2 },
         { "UYVY", "p010le", k_to_uyvy<U_P010>, NX_W2, NY_H2, 0, F_NONE, nullptr, 2 },
-        { "v210", "yuv420p", k_planar_to_v210<S_420P8>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 },
+        { "v210", "yuv420p", k_planar_to_v210<S_420P8>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 , k_planar8_to_v210_x4<S_420P8>, 4 },
         UG_FP("yuv420p", "UYVY", "yuv420p_to_uyvy"),
-        { "RGB", "yuv420p", k_yuv8p_to_rgb<420, false>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
-        { "RGBA", "yuv420p", k_yuv8p_to_rgb<420, true>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
-        { "v210", "yuv422p", k_planar_to_v210<S_422P8>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
+        { "RGB", "yuv420p", k_yuv8p_to_rgb<420, false>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 , k_yuv8p_to_rgb_x8<420, false>, 4 },
+        { "RGBA", "yuv420p", k_yuv8p_to_rgb<420, true>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 , k_yuv8p_to_rgb_x8<420, true>, 4 },
+        { "v210", "yuv422p", k_planar_to_v210<S_422P8>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 , k_planar8_to_v210_x4<S_422P8>, 4 },
         UG_FP("yuv422p", "UYVY", "yuv422p_to_uyvy"),
-        { "RGB", "yuv422p", k_yuv8p_to_rgb<422, false>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
-        { "RGBA", "yuv422p", k_yuv8p_to_rgb<422, true>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 },
+        { "RGB", "yuv422p", k_yuv8p_to_rgb<422, false>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 , k_yuv8p_to_rgb_x8<422, false>, 4 },
+        { "RGBA", "yuv422p", k_yuv8p_to_rgb<422, true>, NX_W2, NY_H2, 8, F_NONE, nullptr, 3 , k_yuv8p_to_rgb_x8<422, true>, 4 },
         { "v210", "yuv444p", k_yuv444_to_v210<8>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
         { "UYVY", "yuv444p", k_to_uyvy<U_444P8>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
         { "RGB", "yuv444p", k_yuv444p_to_rgb<false>, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
         { "RGBA", "yuv444p", k_yuv444p_to_rgb<true>, NX_W, NY_H, 8, F_NONE, nullptr, 3 },
         UG_FP("yuv444p", "VUYA", "yuv444p_to_vuya"),
-        { "UYVY", "nv12", k_to_uyvy<U_NV12>, NX_W2, NY_H, 0, F_NONE, nullptr, 2 },
-        { "RGB", "nv12", k_nv12_to_rgb<false>, NX_W2, NY_H, 8, F_NONE, nullptr, 2 },
-        { "RGBA", "nv12", k_nv12_to_rgb<true>, NX_W2, NY_H, 8, F_NONE, nullptr, 2 },
+        { "UYVY", "nv12", k_to_uyvy<U_NV12>, NX_W2, NY_H, 0, F_NONE, nullptr, 2 , k_nv12_x8<0>, 4 },
+        { "RGB", "nv12", k_nv12_to_rgb<false>, NX_W2, NY_H, 8, F_NONE, nullptr, 2 , k_nv12_x8<1>, 4 },
+        { "RGBA", "nv12", k_nv12_to_rgb<true>, NX_W2, NY_H, 8, F_NONE, nullptr, 2 , k_nv12_x8<2>, 4 },
         { "RGB", "gbrap", nullptr, NX_W, NY_H, 0, F_FROM_PLANAR, "gbrap_to_rgb", 4 },
         { "RGBA", "gbrap", nullptr, NX_W, NY_H, 0, F_FROM_PLANAR, "gbrap_to_rgba", 4 },
         { "RGB", "gbrp", k_gbrp_to_rgb<false>, NX_W, NY_H, 0, F_NONE, nullptr, 3 },
@@ -1053,7 +1190,19 @@ int launch(const Conv &c, const Args &a, hipStream_t st)
         const int nx = c.nx == NX_W ? w : c.nx == NX_W2 ? w / 2 : c.nx == NX_W2UP ? (w + 1) / 2 : c.nx == NX_W6 ? w / 6 : c.nx == NX_W6UP ? (w + 5) / 6 : (w + 7) / 8;
         const int ny = c.ny == NY_H ? h : c.ny == NY_H2 ? h / 2 : (h + 1) / 2;
         if (nx <= 0 || ny <= 0) return UG_HIP_SUCCESS;
-        const dim3 block(64, 4, 1), grid((unsigned) ((nx + 63) / 64), (unsigned) ((ny + 3) / 4), 1);
+        const dim3 block(64, 4, 1);
+        if (c.fast && nx % c.fast_div == 0) {
+                uintptr_t bits = (uintptr_t) a.buf | (uintptr_t) a.pitch;
+                for (int i = 0; i < c.min_planes; i++) bits |= (uintptr_t) a.d[i] | (uintptr_t) a.ls[i];
+                if (!strcmp(c.av, "gbrp") && !strcmp(c.uv, "RGB") && (a.w % 16)) bits |= 1; // 3 * width source lines must stay 16-aligned
+                if ((bits & 15) == 0) {
+                        const int fx = nx / c.fast_div;
+                        hipLaunchKernelGGL(c.fast, dim3((unsigned) ((fx + 63) / 64), (unsigned) ((ny + 3) / 4), 1), block, 0, st, a);
+                        UG_HIP_LAUNCH_CHECK();
+                        return UG_HIP_SUCCESS;
+                }
+        }
+        const dim3 grid((unsigned) ((nx + 63) / 64), (unsigned) ((ny + 3) / 4), 1);
         hipLaunchKernelGGL(c.kernel, grid, block, 0, st, a);
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
