@@ -94,3 +94,23 @@ def test_every_decoder_pair_is_supported(po):
     L = lib.load()
     missing = [(i, o) for _, i, o in rows if not L.ug_hip_pixfmt_supported(lib.PF_NAMES[i], lib.PF_NAMES[o])]
     assert not missing, missing
+
+
+@pytest.mark.gpu
+def test_ext_pairs_vs_committed_vectors(hip):
+    """tests/golden/pixfmt_ext_ref.npz (tests/golden/make_lavc_golden.py, from the compiled reference): needs no oracle/_ref"""
+    import os
+    import torch
+    L = hip.L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pixfmt_ext_ref.npz"))
+    keys = sorted({k.rsplit("|", 1)[0] for k in g.files})
+    assert len(keys) >= 85
+    for key in keys:
+        i, o, dims = key.split("|")
+        w, h = map(int, dims.split("x"))
+        want = g[key + "|out"]
+        dsrc = torch.from_numpy(g[key + "|in"]).cuda()
+        ddst = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+        assert L.load().ug_hip_pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], dsrc.data_ptr(), ddst.data_ptr(), w, h, 0, 0, 0, 8, 16, None) == 0, key
+        torch.cuda.synchronize()
+        assert np.array_equal(ddst.cpu().numpy(), want), key

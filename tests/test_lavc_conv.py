@@ -280,3 +280,51 @@ def test_gpu_v210_planar_round_trip_4k(hip):
     hip.av_to_uv("yuv422p10le", "v210", planes, w, h, back, ls)
     torch.cuda.synchronize()
     assert torch.equal(back.view(torch.int32), src)
+
+
+# ---- the same comparisons against committed vectors (tests/golden/lavc_ref.npz, made by tests/golden/make_lavc_golden.py from the compiled
+# ---- reference): these run on a box that has no oracle/_ref
+def _golden():
+    return np.load(os.path.join(HERE, "golden", "lavc_ref.npz"))
+
+
+@pytest.mark.gpu
+def test_gpu_uv_to_av_vs_committed_vectors(hip):
+    import torch
+    g = _golden()
+    keys = sorted({k.rsplit("|", 1)[0] for k in g.files if k.startswith("to|")})
+    assert len(keys) >= 90
+    for key in keys:
+        _, uv, av, dims = key.split("|")
+        if (uv, av) == ("Y216", "p010le"):
+            continue  # the reference's own output is wrong for padded line sizes (see test_gpu_uv_to_av)
+        w, h = map(int, dims.split("x"))
+        want = [g[f"{key}|p{k}"] for k in range(4) if f"{key}|p{k}" in g.files]
+        planes = [torch.zeros(p.shape, dtype=torch.uint8, device="cuda") for p in want]
+        hip.uv_to_av(uv, av, torch.from_numpy(g[key + "|in"]).cuda(), w, h, planes)
+        torch.cuda.synchronize()
+        for k, (p, wnt) in enumerate(zip(planes, want)):
+            assert np.array_equal(p.cpu().numpy(), wnt), (key, k)
+
+
+@pytest.mark.gpu
+def test_gpu_av_to_uv_vs_committed_vectors(hip):
+    import torch
+    g = _golden()
+    keys = sorted({k.rsplit("|", 1)[0] for k in g.files if k.startswith("from|")})
+    assert len(keys) >= 170
+    for key in keys:
+        _, av, uv, dims, cs, rng_ = key.split("|")
+        w, h = map(int, dims.split("x"))
+        want = g[key + "|out"]
+        planes = [torch.from_numpy(g[f"{key}|p{k}"]).cuda() for k in range(4) if f"{key}|p{k}" in g.files]
+        pitch = want.shape[1]
+        dst = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda")
+        hip.av_to_uv(av, uv, planes, w, h, dst, pitch, (0, 8, 16), colorspace=int(cs), color_range=int(rng_))
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        if uv == "R12L" and w % 8:
+            full = 36 * w // 8
+            assert np.array_equal(got[:, :full], want[:, :full]), key
+            continue
+        assert np.array_equal(got, want), key
