@@ -1,0 +1,72 @@
+"""The drop-in proof for SURVEY.md 8(f) N3: the reference's own libavcodec/to_lavc_vid_conv.c and from_lavc_vid_conv.c, compiled with their
+GPU hook enabled (-DHAVE_LAVC_CUDA_CONV) and linked against ultragrid_amd/module/lavc_conv_mi355x.cpp instead of the reference's stubs
+(oracle/_ref/libugref_lavc_hook.so, `make -C oracle ref_lavc_hook`).  Driving the reference's public API -- to_lavc_vid_conv_init() /
+to_lavc_vid_conv(), get_av_to_uv_conversion() / av_to_uv_convert() -- then runs the conversion on the GPU; the result must equal what the
+same API gives in the plain CPU build (oracle/_ref/libugref_lavc.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import test_lavc_conv as T
+
+HOOK = os.path.join(T.HERE, "..", "oracle", "_ref", "libugref_lavc_hook.so")
+
+
+def hook_lib():
+    if not os.path.exists(HOOK):
+        pytest.skip("oracle/_ref/libugref_lavc_hook.so not built")
+    h = C.CDLL(HOOK)
+    for name in ("ug_stub_frame_new", "ug_stub_pixfmt_by_name", "ug_stub_plane_rows", "av_frame_free", "get_codec_from_name", "vc_get_linesize",
+                 "to_lavc_vid_conv_init", "to_lavc_vid_conv", "to_lavc_vid_conv_destroy", "get_av_to_uv_conversion", "av_to_uv_convert",
+                 "av_to_uv_conversion_destroy"):
+        src = getattr(T.ref(), name)
+        dst = getattr(h, name)
+        dst.restype, dst.argtypes = src.restype, src.argtypes
+    C.c_bool.in_dll(h, "cuda_devices_explicit").value = True  # what `--cuda-device` sets (host.cpp); enables the hook (to_lavc_vid_conv.c:1771-1783)
+    return h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("uv,av", [("UYVY", "yuv444p"), ("UYVY", "yuv422p"), ("v210", "yuv422p10le"), ("v210", "yuv420p10le"), ("RGB", "yuv444p"),
+                                   ("R10k", "yuv420p10le"), ("R12L", "yuv444p12le")])
+def test_reference_to_lavc_runs_on_the_gpu(hip, capfd, monkeypatch, uv, av):
+    monkeypatch.setenv("UG_MI355X_VERBOSE", "1")
+    h, r = hook_lib(), T.ref()
+    for (w, h_) in [(48, 8), (96, 6)]:
+        ls = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
+        src = np.random.default_rng(w).integers(0, 256, ls * h_ + 64).astype(np.uint8)
+        want = T.ref_uv_to_av(uv, av, src, w, h_)
+        st = h.to_lavc_vid_conv_init(h.get_codec_from_name(uv.encode()), w, h_, h.ug_stub_pixfmt_by_name(av.encode()), 1)
+        assert st
+        fr = h.to_lavc_vid_conv(st, src.ctypes.data)
+        assert fr, "the hook returned no frame"
+        got = [p.copy() for p in T.plane_arrays(h, fr.contents, h_)]
+        stp = C.c_void_p(st)
+        h.to_lavc_vid_conv_destroy(C.byref(stp))
+        for k, (g, wnt) in enumerate(zip(got, want)):
+            assert np.array_equal(g, wnt), (uv, av, w, h_, k)
+    assert f"to_lavc {uv} -> {av} on the device" in capfd.readouterr().err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("uv", ["UYVY", "v210", "RGB", "RGBA"])
+def test_reference_from_lavc_runs_on_the_gpu(hip, capfd, monkeypatch, uv):
+    """from_lavc_cuda_supp_formats lists yuv422p (from_lavc_vid_conv_cuda.h:50-52): those frames take the hook"""
+    monkeypatch.setenv("UG_MI355X_VERBOSE", "1")
+    h, r = hook_lib(), T.ref()
+    av = "yuv422p"
+    for (w, h_), cs, rng_ in [((48, 8), 1, 1), ((96, 6), 5, 2)]:
+        frp = T.make_frame(r, av, w, h_, 7, cs, rng_)
+        pitch = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
+        want = T.ref_av_to_uv(frp, av, uv, w, h_, pitch, (0, 8, 16))
+        conv = h.get_av_to_uv_conversion(h.ug_stub_pixfmt_by_name(av.encode()), h.get_codec_from_name(uv.encode()))
+        assert conv
+        dst = np.zeros(pitch * h_ + 64, np.uint8)
+        h.av_to_uv_convert(conv, dst.ctypes.data, frp, pitch, (C.c_int * 3)(0, 8, 16))
+        cp = C.c_void_p(conv)
+        h.av_to_uv_conversion_destroy(C.byref(cp))
+        r.av_frame_free(C.byref(frp))
+        assert np.array_equal(dst[: pitch * h_].reshape(h_, pitch), want), (uv, w, h_, cs, rng_)
+    assert f"from_lavc {av} -> {uv} on the device" in capfd.readouterr().err
