@@ -157,6 +157,12 @@ int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out);
 int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev,
                           int width, int height, int src_pitch, int dst_pitch,
                           int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* The line converters pixfmt_conv.h:93-101 exports outside decoders[] (their callers reach them by name, e.g. video_capture/screen_x11.c:463,
+ * decklink.cpp:1750), whole frame, line by line with the given dst_len (bytes to write per line) and pitches:
+ *   "vc_copylineUYVYtoGrayscale" (:927-938), "vc_copylineABGRtoRGB" (:809-843), "vc_copylineBGRAtoRGB" (:845-857),
+ *   "vc_copylineToRGBA_inplace" (:907-921; rshift/gshift/bshift are the SOURCE shifts, alpha byte 0; dst may equal src). */
+int ug_hip_pixfmt_line_func(const char *func, const void *src_dev, void *dst_dev, int width, int height, int src_pitch, int dst_pitch, int dst_len,
+                            int rshift, int gshift, int bshift, ug_hip_stream_t stream);
 /* vc_get_linesize (video_codec.c:507-521) for the formats above */
 int ug_hip_linesize(ug_pixfmt_t fmt, int width);
 

@@ -114,3 +114,30 @@ def test_ext_pairs_vs_committed_vectors(hip):
         assert L.load().ug_hip_pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], dsrc.data_ptr(), ddst.data_ptr(), w, h, 0, 0, 0, 8, 16, None) == 0, key
         torch.cuda.synchronize()
         assert np.array_equal(ddst.cpu().numpy(), want), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("func,bpp_in,bpp_out", [("vc_copylineUYVYtoGrayscale", 2, 1), ("vc_copylineABGRtoRGB", 4, 3), ("vc_copylineBGRAtoRGB", 4, 3),
+                                                 ("vc_copylineToRGBA_inplace", 4, 4)])
+def test_exported_line_functions(hip, po, func, bpp_in, bpp_out):
+    """the converters pixfmt_conv.h exports outside decoders[], against the same symbols of the compiled reference -- its portable build
+    (no -msse4.1): the SSSE3 branch of vc_copylineABGRtoRGB never advances `src` in its tail loop (pixfmt_conv.c:828-834) and repeats one
+    pixel over the last 4-7 of a line, the same slip as vc_copylineRGBAtoRGB's (oracle/Makefile)"""
+    import torch
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    fn = DEC((func, po.ref(scalar=True)))
+    for (w, h) in [(48, 4), (50, 3), (7, 2), (1920, 2)]:
+        sp = (w * bpp_in + 3) // 4 * 4 + (64 if bpp_in == 2 and w % 2 else 0)
+        dp, L_ = w * bpp_out + 8, w * bpp_out
+        src = aligned(sp * h + 64, rng=np.random.default_rng(w))
+        want = aligned(dp * h + 64)
+        want[:] = 0x5A
+        for y in range(h):
+            fn(want.ctypes.data + y * dp, src.ctypes.data + y * sp, L_, 16, 0, 8)
+        dsrc = torch.from_numpy(src.copy()).cuda()
+        ddst = torch.full((dp * h + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        rc = hip.L.load().ug_hip_pixfmt_line_func(func.encode(), dsrc.data_ptr(), ddst.data_ptr(), w, h, sp, dp, L_, 16, 0, 8, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ddst.cpu().numpy(), want), (func, w, h)

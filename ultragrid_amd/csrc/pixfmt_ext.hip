@@ -549,6 +549,30 @@ XK(k_dvs10_to_uyvy) // vc_copylineDVS10 :690-721: src_len = dst_len / 1.5, one i
         d[0] = s[0], d[1] = s[1], d[2] = s[2];
 }
 
+// ---- exported line converters that are not in decoders[] (pixfmt_conv.h:93-101) ----------------------------------------------------------
+XK(k_uyvy_to_grayscale) // vc_copylineUYVYtoGrayscale :927-938: the two luma bytes of every UYVY word
+{
+        XPRO();
+        if (x >= a.L / 2) return;
+        const uint32_t s = ((const uint32_t *) srow)[x];
+        drow[2 * x] = (uint8_t) (s >> 8), drow[2 * x + 1] = (uint8_t) (s >> 24);
+}
+XK(k_rgba_to_rgb_shift) // vc_copylineRGBAtoRGBwithShift :769-807 (a.rs/gs/bs = SOURCE shifts): vc_copylineABGRtoRGB (24,16,8), vc_copylineBGRAtoRGB (16,8,0)
+{
+        XPRO();
+        if (x >= a.L / 3) return;
+        const uint32_t in = ((const uint32_t *) srow)[x];
+        uint8_t *d = drow + 3 * x;
+        d[0] = (uint8_t) (in >> a.rs), d[1] = (uint8_t) (in >> a.gs), d[2] = (uint8_t) (in >> a.bs);
+}
+XK(k_to_rgba_inplace) // vc_copylineToRGBA_inplace :907-921 (source shifts; alpha byte 0)
+{
+        XPRO();
+        if (x >= a.L / 4) return;
+        const uint32_t in = ((const uint32_t *) srow)[x];
+        ((uint32_t *) drow)[x] = ((in >> a.rs) & 0xff) | ((in >> a.gs) & 0xff) << 8 | ((in >> a.bs) & 0xff) << 16;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------
 enum Iter { I_PX, I_PAIR, I_G6, I_G8, I_COMP, I_DVS };
 struct Entry {
@@ -665,3 +689,33 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
 }
 
 } // namespace ug
+
+extern "C" int ug_hip_pixfmt_line_func(const char *func, const void *src, void *dst, int width, int height, int src_pitch, int dst_pitch, int dst_len,
+                                       int rshift, int gshift, int bshift, ug_hip_stream_t stream)
+{
+        if (!func || !src || !dst || width <= 0 || height <= 0 || dst_len < 0 || (((uintptr_t) src | (uintptr_t) src_pitch) & 3)) {
+                ug::set_last_error_msg("ug_hip_pixfmt_line_func: bad arguments (the sources are read as 32-bit words)");
+                return UG_HIP_EINVAL;
+        }
+        XArgs a = {};
+        a.src = (const uint8_t *) src, a.dst = (uint8_t *) dst, a.spitch = src_pitch, a.dpitch = dst_pitch, a.width = width, a.height = height, a.L = dst_len;
+        void (*k)(const XArgs) = nullptr;
+        int nx = 0;
+        if (!strcmp(func, "vc_copylineUYVYtoGrayscale")) {
+                k = k_uyvy_to_grayscale, nx = dst_len / 2;
+        } else if (!strcmp(func, "vc_copylineABGRtoRGB")) {
+                k = k_rgba_to_rgb_shift, nx = dst_len / 3, a.rs = 24, a.gs = 16, a.bs = 8;
+        } else if (!strcmp(func, "vc_copylineBGRAtoRGB")) {
+                k = k_rgba_to_rgb_shift, nx = dst_len / 3, a.rs = 16, a.gs = 8, a.bs = 0;
+        } else if (!strcmp(func, "vc_copylineToRGBA_inplace")) {
+                if ((unsigned) rshift > 24 || (unsigned) gshift > 24 || (unsigned) bshift > 24 || (((uintptr_t) dst | (uintptr_t) dst_pitch) & 3)) return UG_HIP_EINVAL;
+                k = k_to_rgba_inplace, nx = dst_len / 4, a.rs = rshift, a.gs = gshift, a.bs = bshift;
+        } else {
+                ug::set_last_error_msg("ug_hip_pixfmt_line_func: unknown function name");
+                return UG_HIP_EUNSUPP;
+        }
+        if (nx <= 0) return UG_HIP_SUCCESS;
+        hipLaunchKernelGGL(k, dim3((unsigned) ((nx + 63) / 64), (unsigned) ((height + 3) / 4), 1), dim3(64, 4, 1), 0, (hipStream_t) stream, a);
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
