@@ -157,6 +157,22 @@ def test_color_coefficient_tables():
             assert list(got) == want, (cs, depth)
 
 
+def test_compute_color_coeffs():
+    """ug_hip_compute_color_coeffs == compute_color_coeffs of the compiled reference (color_space.c:193-197), incl. the BT.601 / 709 / 2020 weights"""
+    from oracle import pyoracle as O
+    from ultragrid_amd import lib
+    r = O.ref()
+    r.compute_color_coeffs.restype = O._RefCoeffs
+    r.compute_color_coeffs.argtypes = [C.c_double, C.c_double, C.c_int]
+    for kr, kb in [(0.299, 0.114), (0.2126, 0.0722), (0.2627, 0.0593), (0.212, 0.087), (0.3, 0.11)]:
+        for depth in (0, 8, 10, 12, 16):
+            want = r.compute_color_coeffs(kr, kb, depth)
+            want = [getattr(want, n) for n, _ in O._RefCoeffs._fields_]
+            got = (C.c_int * 14)()
+            assert lib.load().ug_hip_compute_color_coeffs(kr, kb, depth, got) == 0
+            assert list(got) == want, (kr, kb, depth)
+
+
 def test_reference_has_every_row_we_claim():
     r = ref()
     for uv, av in TO_AV:

@@ -1257,6 +1257,28 @@ int ug_hip_color_coeffs(int cs, int depth, int out[14])
         return UG_HIP_SUCCESS;
 }
 
+// compute_color_coeffs(kr, kb, depth) (color_space.c:193-197 over the COEFFS macro, :60-131): Q14 coefficients for arbitrary luma weights;
+// depth 0 = full range.  Doubles, as there; the 13 narrow fields of struct color_coeffs are `short` (color_space.h:135-148).
+int ug_hip_compute_color_coeffs(double kr, double kb, int depth, int out[14])
+{
+        if (!out || depth < 0 || depth > 16 || (depth > 0 && depth < 8)) return UG_HIP_EINVAL;
+        const double kg = 1. - kr - kb, D = 2. * (kr + kg), E = 2. * (1. - kr);
+        const double ylim = depth == 0 ? 1.0 : 219. * (1 << (depth - 8)) / ((1 << depth) - 1);
+        const double clim = depth == 0 ? 1.0 : 224. * (1 << (depth - 8)) / ((1 << depth) - 1);
+        const double base = 1 << kBase, eps = 0.5;
+        auto scaled = [&](double x) { return (int) ((x * base) + (x > 0 ? 1. : -1.) * eps); };
+        const int v[14] = {
+                (int) (((kr * ylim) * base) + eps), (int) (((kg * ylim) * base) + eps), (int) (((kb * ylim) * base) + eps),
+                (int) (((-kr / D * clim) * base) - eps), (int) (((-kg / D * clim) * base) - eps), (int) ((((1 - kb) / D * clim) * base) + eps),
+                (int) ((((1 - kr) / E * clim) * base) - eps), (int) (((-kg / E * clim) * base) - eps), (int) (((-kb / E * clim) * base) + eps),
+                scaled(1. / ylim), scaled((2. * (1. - kr)) / clim), scaled((-kb * (2. * (kr + kg)) / kg) / clim), scaled((-kr * (2. * (1. - kr)) / kg) / clim),
+                scaled((2. * (kr + kg)) / clim),
+        };
+        for (int i = 0; i < 13; i++) out[i] = (short) v[i];
+        out[13] = v[13];
+        return UG_HIP_SUCCESS;
+}
+
 int ug_hip_uv_to_av_supported(const char *uv_codec, const char *av_pixfmt) { return find(kToAv, uv_codec, av_pixfmt) != nullptr; }
 int ug_hip_av_to_uv_supported(const char *av_pixfmt, const char *uv_codec) { return find(kFromAv, uv_codec, av_pixfmt) != nullptr; }
 

@@ -74,6 +74,7 @@ SYMBOLS = {
     "ug_hip_uv_to_av_supported": (_i, [C.c_char_p, C.c_char_p]),
     "ug_hip_av_to_uv_supported": (_i, [C.c_char_p, C.c_char_p]),
     "ug_hip_color_coeffs": (_i, [_i, _i, C.POINTER(_i)]),
+    "ug_hip_compute_color_coeffs": (_i, [C.c_double, C.c_double, _i, C.POINTER(_i)]),
     "ug_hip_jpeg_qtable": (None, [_i, _i, _vp]),
     "ug_hip_jpeg_divisors": (None, [_vp, _vp]),
     "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
