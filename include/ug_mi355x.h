@@ -152,6 +152,10 @@ int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream);
  * ---------------------------------------------------------------------------------- */
 /* 1 if a kernel exists for in -> out: every pair of decoders[] (== get_decoder_from_to(in, out) != NULL, pixfmt_conv.c:3110-3125) and in == out */
 int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out);
+/* get_best_decoder_from (pixfmt_conv.c:3126-3172): `candidates` ends with UG_PF_NONE; *out = the candidate the reference's ranking
+ * (compare_pixdesc, video_codec.c:1148-1192: keep depth, then subsampling, then colour space; ties to the lower codec_t) puts first among
+ * those reachable from `in`.  UG_HIP_EUNSUPP if none is reachable. */
+int ug_hip_pixfmt_best(ug_pixfmt_t in, const ug_pixfmt_t *candidates, ug_pixfmt_t *out);
 /* rshift/gshift/bshift have decoder_t meaning (honoured for RGBA / RGB outputs, defaults
  * 0/8/16, pixfmt_conv.h:62-65).  Pitches 0 = vc_get_linesize(). */
 int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev,

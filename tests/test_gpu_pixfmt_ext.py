@@ -141,3 +141,32 @@ def test_exported_line_functions(hip, po, func, bpp_in, bpp_out):
         assert rc == 0
         torch.cuda.synchronize()
         assert np.array_equal(ddst.cpu().numpy(), want), (func, w, h)
+
+
+def test_best_decoder_choice_equals_the_reference(po):
+    """ug_hip_pixfmt_best == get_best_decoder_from (pixfmt_conv.c:3126-3172) for every source codec and 400 random candidate sets"""
+    from ultragrid_amd import lib
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    r = po.ref()
+    r.get_codec_from_name.argtypes = [C.c_char_p]
+    r.get_best_decoder_from.restype = C.c_void_p
+    r.get_best_decoder_from.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    names = ["RGBA", "UYVY", "YUYV", "VUYA", "R10k", "R12L", "v210", "DVS10", "RGB", "BGR", "RG48", "Y216", "Y416"]
+    ref_id = {n: r.get_codec_from_name(n.encode()) for n in names}
+    back = {v: k for k, v in ref_id.items()}
+    rng = np.random.default_rng(1)
+    L = lib.load()
+    for src in names:
+        for _ in range(400 // len(names) + 1):
+            cand = list(rng.choice(names, size=rng.integers(1, 6), replace=False))
+            rc = (C.c_int * (len(cand) + 1))(*[ref_id[c] for c in cand], 0)
+            rout = C.c_int(0)
+            fn = r.get_best_decoder_from(ref_id[src], rc, C.byref(rout))
+            mc = (C.c_int * (len(cand) + 1))(*[lib.PF_NAMES[c] for c in cand], 0)
+            mout = C.c_int(0)
+            rv = L.ug_hip_pixfmt_best(lib.PF_NAMES[src], mc, C.byref(mout))
+            if not fn:
+                assert rv == lib.EUNSUPP, (src, cand)
+            else:
+                assert rv == 0 and mout.value == lib.PF_NAMES[back[rout.value]], (src, cand, back[rout.value])

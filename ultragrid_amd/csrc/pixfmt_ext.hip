@@ -690,6 +690,62 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
 
 } // namespace ug
 
+// get_best_decoder_from (pixfmt_conv.c:3126-3172): of the candidates reachable from `in`, the one compare_pixdesc (video_codec.c:1148-1192,
+// default preference "dsc": depth, subsampling, colour space) ranks first; ties go to the lower codec_t (types.h:62-112).
+namespace {
+struct PixDesc {
+        int depth, subsampling, rgb, codec_t_value;
+};
+bool pix_desc(ug_pixfmt_t f, PixDesc &d) // get_pixfmt_desc (video_codec.c) for the codecs of this library
+{
+        switch (f) {
+        case UG_PF_RGBA: d = { 8, 4444, 1, 1 }; return true;
+        case UG_PF_UYVY: d = { 8, 4220, 0, 2 }; return true;
+        case UG_PF_YUYV: d = { 8, 4220, 0, 3 }; return true;
+        case UG_PF_VUYA: d = { 8, 4444, 0, 4 }; return true;
+        case UG_PF_R10K: d = { 10, 4440, 1, 5 }; return true;
+        case UG_PF_R12L: d = { 12, 4440, 1, 6 }; return true;
+        case UG_PF_V210: d = { 10, 4220, 0, 7 }; return true;
+        case UG_PF_DVS10: d = { 10, 4220, 0, 8 }; return true;
+        case UG_PF_RGB: d = { 8, 4440, 1, 12 }; return true;
+        case UG_PF_BGR: d = { 8, 4440, 1, 20 }; return true;
+        case UG_PF_RG48: d = { 16, 4440, 1, 27 }; return true;
+        case UG_PF_Y216: d = { 16, 4220, 0, 30 }; return true;
+        case UG_PF_Y416: d = { 16, 4444, 0, 31 }; return true;
+        default: return false;
+        }
+}
+int compare_pixdesc(const PixDesc &a, const PixDesc &b, const PixDesc &src)
+{
+        if (a.depth != b.depth && (a.depth < src.depth || b.depth < src.depth)) return b.depth - a.depth;
+        if (a.subsampling != b.subsampling && (a.subsampling < src.subsampling || b.subsampling < src.subsampling)) return b.subsampling - a.subsampling;
+        if (a.rgb != b.rgb) return a.rgb == src.rgb ? -1 : 1;
+        if (a.depth != b.depth) return a.depth - b.depth;
+        if (a.subsampling != b.subsampling) return a.subsampling - b.subsampling;
+        return 0;
+}
+} // namespace
+
+extern "C" int ug_hip_pixfmt_best(ug_pixfmt_t in, const ug_pixfmt_t *candidates, ug_pixfmt_t *out)
+{
+        PixDesc src, best = {}, d;
+        if (!candidates || !out || !pix_desc(in, src)) return UG_HIP_EINVAL;
+        for (const ug_pixfmt_t *it = candidates; *it != UG_PF_NONE; ++it) { // `in` itself, unless RGB / RGBA (their copy may change the shifts)
+                if (*it == in && in != UG_PF_RGBA && in != UG_PF_RGB) {
+                        *out = in;
+                        return UG_HIP_SUCCESS;
+                }
+        }
+        bool have = false;
+        for (const ug_pixfmt_t *it = candidates; *it != UG_PF_NONE; ++it) {
+                if (!ug_hip_pixfmt_supported(in, *it) || !pix_desc(*it, d)) continue;
+                int c = have ? compare_pixdesc(d, best, src) : -1;
+                if (c == 0) c = d.codec_t_value - best.codec_t_value;
+                if (c < 0) best = d, *out = *it, have = true;
+        }
+        return have ? UG_HIP_SUCCESS : UG_HIP_EUNSUPP;
+}
+
 extern "C" int ug_hip_pixfmt_line_func(const char *func, const void *src, void *dst, int width, int height, int src_pitch, int dst_pitch, int dst_len,
                                        int rshift, int gshift, int bshift, ug_hip_stream_t stream)
 {

@@ -64,6 +64,7 @@ SYMBOLS = {
     "ug_hip_selftest_dxt_decode": (_i, [C.POINTER(C.c_uint), _vp]),
     "ug_hip_selftest_dxt_encode": (_i, [C.POINTER(C.c_uint), _vp]),
     "ug_hip_uyvy_to_nv12": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ug_hip_pixfmt_best": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "ug_hip_pixfmt_line_func": (_i, [C.c_char_p, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ug_hip_from_planar": (_i, [C.c_char_p, _vp, _vp]),
     "ug_hip_to_planar": (_i, [C.c_char_p, _vp, _vp]),
