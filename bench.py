@@ -36,6 +36,7 @@ ALG_BYTES_PER_PX = 3.0     # UYVY 2 B/px read + DXT5 1 B/px written (SURVEY.md 8
 WORKLOADS = {
     "4k-uyvy": dict(w=3840, h=2160, fmt="UYVY", bpp=3.0, frames=16, name="3840x2160 UYVY->YCoCg->DXT5 fused encode (BASELINE.json configs[2])"),
     "8k-v210": dict(w=7680, h=4320, fmt="v210", bpp=16 / 6 + 1, frames=4, name="7680x4320 v210 unpack->YCoCg->DXT5 fused encode (BASELINE.json configs[4])"),
+    "1080p-rgb-dxt1": dict(w=1920, h=1080, fmt="RGB", out="DXT1", bpp=3.5, frames=64, name="1920x1080 RGB->DXT1 encode (BASELINE.json configs[1])"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -48,7 +49,8 @@ def make_frames(n: int, rank: int, fmt: str = "UYVY", w: int = W, h: int = H) ->
     if os.path.exists(cache):
         return np.load(cache)
     ls = synth.linesize(fmt, w)
-    bases = [synth.s2_video(fmt, w, h, salt=100 * rank + i).reshape(h, ls) for i in range(min(n, 4 if w <= 3840 else 2))]
+    gen = synth.s1_random if fmt == "RGB" else synth.s2_video   # RGB: uniform random bytes (S1), every block at full range
+    bases = [gen(fmt, w, h, salt=100 * rank + i).reshape(h, ls) for i in range(min(n, 4 if w <= 3840 else 2))]
     out = np.empty((n, h, ls), np.uint8)
     for i in range(n):
         out[i] = np.roll(bases[i % len(bases)], 4 * 37 * (i // len(bases)), axis=0)
@@ -60,17 +62,18 @@ def make_frames(n: int, rank: int, fmt: str = "UYVY", w: int = W, h: int = H) ->
     return out
 
 
-def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 12.0) -> dict:
+def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 12.0, out: str = "DXT5") -> dict:
     """The C oracle on the host cores: block rows dealt to OpenMP threads (row bands, as the reference parallelises its CPU
     conversions, src/utils/parallel_conv.c:64-85).  The thread count is calibrated (the box may expose more logical CPUs than
     its cpuset lets run); `cores` reports the count that was used for the timed sample."""
     from oracle import pyoracle as po
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    pin = {"UYVY": po.IN_UYVY, "v210": po.IN_V210}[fmt]
+    pin = {"UYVY": po.IN_UYVY, "v210": po.IN_V210, "RGB": po.IN_RGB}[fmt]
+    pout = po.OUT_DXT5YCOCG if out == "DXT5" else po.OUT_DXT1
 
     def one(threads: int) -> float:
         t0 = time.perf_counter()
-        po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=threads)
+        po.dxt_encode(pin, pout, frame, w, h, threads=threads)
         return time.perf_counter() - t0
 
     one(1 if ncpu == 1 else min(ncpu, 8))                                  # warm (page in, spawn the team)
@@ -82,11 +85,11 @@ def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 
             best_t, best = t, dt
     n, t0 = 0, time.perf_counter()
     while n < 3 or time.perf_counter() - t0 < target_s:      # bounded by time, not by a frame count guessed from one call
-        po.dxt_encode(pin, po.OUT_DXT5YCOCG, frame, w, h, threads=best_t)
+        po.dxt_encode(pin, pout, frame, w, h, threads=best_t)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": round(n * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": best_t, "kind": "port",
-            "sample": f"{n} x {w}x{h} {fmt}->DXT5-YCoCg frames through oracle/dxt_oracle.c (gcc -O2, strict fp32, OpenMP dynamic "
+            "sample": f"{n} x {w}x{h} {fmt}->{'DXT5-YCoCg' if out == 'DXT5' else 'DXT1'} frames through oracle/dxt_oracle.c (gcc -O2, strict fp32, OpenMP dynamic "
                       f"row bands; {best_t} threads = best of {cands} on {ncpu} visible CPUs), {dt:.1f} s"}
 
 
@@ -133,9 +136,11 @@ def main() -> None:
     frame_bytes = host.shape[1]
     dst = torch.empty(F * W * H, dtype=torch.uint8, device="cuda")
     pf = lib.PF_NAMES[wl["fmt"]]
+    out_name = wl.get("out", "DXT5")
+    oid = lib.DXT5_YCOCG if out_name == "DXT5" else lib.DXT1
 
     def step():
-        codec.dxt_encode_batch(pf, lib.DXT5_YCOCG, src, W, H, F, frame_bytes, dst=dst)
+        codec.dxt_encode_batch(pf, oid, src, W, H, F, frame_bytes, dst=dst)
 
     from ultragrid_amd import shard
     for _ in range(args.warmup):
@@ -168,22 +173,24 @@ def main() -> None:
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)" if args.workload == "4k-uyvy" else "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
+            "metric": {"4k-uyvy": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)", "8k-v210": "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
+                       "1080p-rgb-dxt1": "Mpixels/s encode (RGB->DXT1, 1080p)"}[args.workload],
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"],
-                       "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": W * H,
-                       "input": "S2 legal-range video noise, resident in HBM", "fps": round(value * 1e6 / (W * H), 1),
+                       "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": W * H if out_name == "DXT5" else W * H // 2,
+                       "input": ("S1 uniform random bytes" if wl["fmt"] == "RGB" else "S2 legal-range video noise") + ", resident in HBM", "fps": round(value * 1e6 / (W * H), 1),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": f"dxt_encode_kernel<{wl['fmt']},DXT5_YCOCG>", "ms_per_launch": round(kern_ms, 5),
+                         "kernel": f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>", "ms_per_launch": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * F * W * H),
-                         "note": "VALU-issue-bound kernel (SURVEY.md F9): about 660 VALU issue slots per wave against a floor of about 600 for this formulation (DESIGN.md 4.1)"},
+                         "note": ("VALU-issue-bound kernel (SURVEY.md F9): about 660 VALU issue slots per wave against a floor of about 600 for this formulation (DESIGN.md 4.1)"
+                                  if args.workload == "4k-uyvy" else "VALU-issue-bound kernel (SURVEY.md F9, DESIGN.md 4.1)")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H)
+            out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H, out=out_name)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
