@@ -36,6 +36,8 @@ ALG_BYTES_PER_PX = 3.0     # UYVY 2 B/px read + DXT5 1 B/px written (SURVEY.md 8
 WORKLOADS = {
     "4k-uyvy": dict(w=3840, h=2160, fmt="UYVY", bpp=3.0, frames=16, name="3840x2160 UYVY->YCoCg->DXT5 fused encode (BASELINE.json configs[2])"),
     "8k-v210": dict(w=7680, h=4320, fmt="v210", bpp=16 / 6 + 1, frames=4, name="7680x4320 v210 unpack->YCoCg->DXT5 fused encode (BASELINE.json configs[4])"),
+    "4k-uyvy-jpeg420": dict(w=3840, h=2160, fmt="UYVY", out="JPEG420", bpp=5.0, frames=8,
+                            name="3840x2160 UYVY->planar 4:2:0 + 8x8 FDCT + quantise, fused (BASELINE.json configs[3]); one launch per frame"),
     "1080p-rgb-dxt1": dict(w=1920, h=1080, fmt="RGB", out="DXT1", bpp=3.5, frames=64, name="1920x1080 RGB->DXT1 encode (BASELINE.json configs[1])"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
@@ -142,6 +144,17 @@ def main() -> None:
     def step():
         codec.dxt_encode_batch(pf, oid, src, W, H, F, frame_bytes, dst=dst)
 
+    if out_name == "JPEG420":   # the JPEG front end: UYVY -> 4:2:0 (uyvy_to_i420 rounding) -> FDCT -> quantise, int16 coefficients out
+        div = codec.jpeg_divisors_device(75, "cuda")
+        mw, mh = (W + 15) // 16, (H + 15) // 16
+        oy = torch.empty((4 * mw * mh, 64), dtype=torch.int16, device="cuda")
+        ocb, ocr = torch.empty((mw * mh, 64), dtype=torch.int16, device="cuda"), torch.empty((mw * mh, 64), dtype=torch.int16, device="cuda")
+        fn = lib.load().ug_hip_uyvy_to_jpeg420_coeffs
+
+        def step():  # noqa: F811
+            for i in range(F):
+                assert fn(src[i].data_ptr(), 0, W, H, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), None) == 0
+
     from ultragrid_amd import shard
     for _ in range(args.warmup):
         step()
@@ -174,22 +187,24 @@ def main() -> None:
                 traffic = None
         out = {
             "metric": {"4k-uyvy": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)", "8k-v210": "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
-                       "1080p-rgb-dxt1": "Mpixels/s encode (RGB->DXT1, 1080p)"}[args.workload],
+                       "1080p-rgb-dxt1": "Mpixels/s encode (RGB->DXT1, 1080p)",
+                       "4k-uyvy-jpeg420": "Mpixels/s (UYVY->4:2:0->FDCT+quantise, 4K)"}[args.workload],
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"],
-                       "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": W * H if out_name == "DXT5" else W * H // 2,
+                       "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3}[out_name],
                        "input": ("S1 uniform random bytes" if wl["fmt"] == "RGB" else "S2 legal-range video noise") + ", resident in HBM", "fps": round(value * 1e6 / (W * H), 1),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>", "ms_per_launch": round(kern_ms, 5),
-                         "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * F * W * H),
+                         "kernel": "uyvy_jpeg_fast_kernel<420>" if out_name == "JPEG420" else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>",
+                         "ms_per_launch": round(kern_ms / (F if out_name == "JPEG420" else 1), 5),
+                         "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * W * H * (1 if out_name == "JPEG420" else F)),
                          "note": ("VALU-issue-bound kernel (SURVEY.md F9): about 660 VALU issue slots per wave against a floor of about 600 for this formulation (DESIGN.md 4.1)"
-                                  if args.workload == "4k-uyvy" else "VALU-issue-bound kernel (SURVEY.md F9, DESIGN.md 4.1)")},
+                                          if args.workload == "4k-uyvy" else ("HBM-bound kernel (DESIGN.md 4.3)" if out_name == "JPEG420" else "VALU-issue-bound kernel (SURVEY.md F9, DESIGN.md 4.1)"))},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and out_name != "JPEG420":
             out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H, out=out_name)
         print(json.dumps(out), flush=True)
     if dist is not None:
