@@ -258,6 +258,19 @@ def main():
             j = k[0] % NP; k[0] += 1
             codec.av_to_uv(av, uvc, sets[j][0], w, h, dstb, pitch)
         add(f"av_to_uv {av}->{uvc}", w, h, 1, sets[0][1] + out_bpp, timeit(run_from, iters=40))
+    # the decoders[] pairs outside the core (pixfmt_ext.hip), 4K
+    BPP = {"UYVY": 2, "v210": 16 / 6, "RGB": 3, "RGBA": 4, "RG48": 6, "R10k": 4, "R12L": 4.5, "Y216": 4, "Y416": 8, "VUYA": 4}
+    for i_, o_ in (("v210", "Y216"), ("UYVY", "Y216"), ("UYVY", "RG48"), ("R10k", "RGBA"), ("R10k", "UYVY"), ("R12L", "RGB"), ("R12L", "UYVY"), ("RG48", "R12L"),
+                   ("RG48", "v210"), ("Y416", "UYVY"), ("Y416", "RGBA"), ("RGBA", "R10k"), ("VUYA", "RGB")):
+        ls_in = l.ug_hip_linesize(L.PF_NAMES[i_], w)
+        ls_out = l.ug_hip_linesize(L.PF_NAMES[o_], w)
+        srcs = [torch.randint(0, 256, (h * ls_in + 64,), dtype=torch.uint8, device="cuda") for _ in range(NP)]
+        dd = torch.empty(h * ls_out + 64, dtype=torch.uint8, device="cuda")
+
+        def run_ext():
+            j = k[0] % NP; k[0] += 1
+            assert l.ug_hip_pixfmt_convert(L.PF_NAMES[i_], L.PF_NAMES[o_], srcs[j].data_ptr(), dd.data_ptr(), w, h, 0, 0, 0, 8, 16, st) == 0
+        add(f"pixfmt {i_}->{o_}", w, h, 1, BPP[i_] + BPP[o_], timeit(run_ext, iters=40))
     if args.json:
         json.dump(rows, open(args.json, "w"), indent=1)
 
