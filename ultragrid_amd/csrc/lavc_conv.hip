@@ -178,14 +178,13 @@ __global__ void k_v210_to_xv30(const Args a) // :393-417, (width + 5) / 6 groups
         UG_XY();
         if (x >= (a.w + 5) / 6 || y >= a.h) return;
         const uint32_t *src = BUF(const uint32_t, y) + 4 * x;
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        const V210Group g = v210_unpack(src);
+        // XV30 pixel = U | Y << 10 | V << 20; chroma of a pair goes to both of its pixels.  The first two pixels are built there on top of
+        // the first v210 word and so inherit its two padding bits
+        const uint32_t pad = src[0] & 0xC0000000u;
         uint32_t *dst = ROW(uint32_t, 0, y) + 6 * x;
-        dst[0] = w0;
-        dst[1] = (w0 & 0xFFF003FFU) | (w1 & 0x3FFU) << 10U;
-        dst[2] = (w2 & 0x3FFU) << 20U | (w1 & 0x3FF00000U) >> 10U | (w1 & 0xFFC00U) >> 10U;
-        dst[3] = (w2 & 0x3FFU) << 20U | (w2 & 0xFFC00U) | (w1 & 0xFFC00U) >> 10U;
-        dst[4] = (w3 & 0xFFC00U) << 10U | (w3 & 0x3FFU) << 10U | (w2 & 0x3FF00000U) >> 20;
-        dst[5] = (w3 & 0xFFC00U) << 10U | (w3 & 0x3FF00000U) >> 10 | (w2 & 0x3FF00000U) >> 20;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dst[i] = g.cb[i / 2] | g.y[i] << 10 | g.cr[i / 2] << 20 | (i < 2 ? pad : 0u);
 }
 
 __global__ void k_v210_to_y210(const Args a) // :421-450
@@ -652,7 +651,9 @@ __global__ void k_yuvp10le_to_rgb(const Args a)
                                 uint8_t *o = BUF(uint8_t, row) + 3 * px;
                                 o[0] = (uint8_t) r, o[1] = (uint8_t) g, o[2] = (uint8_t) b;
                         } else {
-                                BUF(uint32_t, row)[px] = r >> 2U | (r & 0x3U) << 14 | g >> 4U << 8U | (g & 0xFU) << 20U | b >> 6U << 16U | (b & 0x3FU) << 26U | 0x3U << 24U;
+                                // R10k: big-endian 10-bit r, g, b, then two padding bits set
+                                const uint32_t b0 = r >> 2, b1 = (r & 3u) << 6 | g >> 4, b2 = (g & 0xfu) << 4 | b >> 6, b3 = (b & 0x3fu) << 2 | 3u;
+                                BUF(uint32_t, row)[px] = b0 | b1 << 8 | b2 << 16 | b3 << 24;
                         }
                 }
         }
@@ -818,27 +819,22 @@ __global__ void k_ayuv64_to_y416(const Args a) // :1904-1925
         dst[0] = src[2], dst[1] = src[1], dst[2] = src[3], dst[3] = src[0];
 }
 
-__global__ void k_ayuv64_to_v210(const Args a) // :1927-1967; `w = src[5]` and `w = src[1]` keep all 16 bits, as written there
+__global__ void k_ayuv64_to_v210(const Args a) // :1927-1967: six A Y U V pixels -> one v210 group
 {
         UG_XY();
         if (x >= (a.w + 5) / 6 || y >= a.h) return;
-        const uint16_t *src = ROW(const uint16_t, 0, y) + 24 * x;
-        uint32_t w0, w1, w2, w3;
-        w0 = ((src[2] >> 6U) + (src[6] >> 6U)) / 2;
-        w0 = w0 | (src[1] >> 6U) << 10U;
-        w0 = w0 | ((src[3] >> 6U) + (src[7] >> 6U)) / 2 << 20U;
-        w1 = src[5];
-        src += 8;
-        w1 = w1 | ((src[2] >> 6U) + (src[6] >> 6U)) / 2 << 10U;
-        w1 = w1 | (src[1] >> 6U) << 20U;
-        w2 = ((src[3] >> 6U) + (src[7] >> 6U)) / 2;
-        w2 = w2 | (src[5] >> 6U) << 10U;
-        src += 8;
-        w2 = w2 | ((src[2] >> 6U) + (src[6] >> 6U)) / 2 << 20U;
-        w3 = src[1];
-        w3 = w3 | ((src[3] >> 6U) + (src[7] >> 6U)) / 2 << 10U;
-        w3 = w3 | ((src[5] >> 6U)) << 20U;
-        st4(BUF(uint32_t, y) + 4 * x, w0, w1, w2, w3);
+        const uint16_t *px = ROW(const uint16_t, 0, y) + 24 * x; // pixel i: A = px[4i], Y = px[4i + 1], U = px[4i + 2], V = px[4i + 3]
+        uint32_t Y[6], U[3], V[3];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Y[i] = px[4 * i + 1] >> 6;
+        // the luma of the 2nd and 5th pixel enters its word with all 16 bits (`w = src[5]`, `w = src[1]` there), spilling into the fields above
+        Y[1] = px[4 * 1 + 1], Y[4] = px[4 * 4 + 1];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+                U[k] = ((px[8 * k + 2] >> 6) + (px[8 * k + 6] >> 6)) / 2;
+                V[k] = ((px[8 * k + 3] >> 6) + (px[8 * k + 7] >> 6)) / 2;
+        }
+        st4(BUF(uint32_t, y) + 4 * x, v210w(U[0], Y[0], V[0]), v210w(Y[1], U[1], Y[2]), v210w(V[1], Y[3], U[2]), v210w(Y[4], V[2], Y[5]));
 }
 
 __global__ void k_vuya_to_uyvy(const Args a) // :1971-1996

@@ -82,36 +82,38 @@ XK(k_r10k_to_rgba) // vc_copyliner10k :211-276: len / 4 pixels, top 8 bits of ea
         r10k_get(srow + 4 * x, r, g, b);
         ((uint32_t *) drow)[x] = a.am | (r >> 2) << a.rs | (g >> 2) << a.gs | (b >> 2) << a.bs;
 }
-XK(k_r10k_to_rg48) // :279-295: while (dstlen > 0) -> ceil(L / 6) pixels
+XK(k_r10k_to_rg48) // :279-295: while (dstlen > 0) -> ceil(L / 6) pixels; each 10-bit component moves to the top of a 16-bit one
 {
         XPRO();
         if (x >= (a.L + 5) / 6) return;
-        const uint8_t *s = srow + 4 * x;
-        uint8_t *d = drow + 6 * x;
-        const uint32_t b2 = s[1], b3 = s[2], b4 = s[3];
-        d[1] = s[0], d[0] = b2 & 0xC0u;
-        d[3] = (uint8_t) (b2 << 2 | b3 >> 6), d[2] = (uint8_t) ((b3 & 0x30u) << 2);
-        d[5] = (uint8_t) ((b3 & 0xFu) << 4 | b4 >> 4), d[4] = (uint8_t) ((b4 & 0xCu) << 4);
+        uint32_t r, g, b;
+        r10k_get(srow + 4 * x, r, g, b);
+        uint8_t *d = drow + 6 * x; // byte stores: RG48 lines of an odd pixel count need not be 2-aligned
+        const uint32_t c[3] = { r << 6, g << 6, b << 6 };
+#pragma unroll
+        for (int k = 0; k < 3; k++) d[2 * k] = (uint8_t) c[k], d[2 * k + 1] = (uint8_t) (c[k] >> 8);
 }
 XK(k_r10k_to_y416) // :297-329, 16-bit coefficients on components scaled to 16 bits
 {
         XPRO();
         if (x >= (a.L + 7) / 8) return;
-        const uint8_t *s = srow + 4 * x;
-        const int r = s[0] << 8 | (s[1] & 0xC0), g = (s[1] & 0x3F) << 10 | (s[2] & 0xF0) << 2, b = (s[2] & 0xF) << 12 | (s[3] & 0xFC) << 4;
+        uint32_t r10, g10, b10;
+        r10k_get(srow + 4 * x, r10, g10, b10);
+        const int r = r10 << 6, g = g10 << 6, b = b10 << 6;
         uint16_t *d = (uint16_t *) drow + 4 * x;
         d[0] = (uint16_t) ((TO_CB(r, g, b) >> kBase) + (1 << 15));
         d[1] = (uint16_t) ((TO_Y(r, g, b) >> kBase) + (1 << 12));
         d[2] = (uint16_t) ((TO_CR(r, g, b) >> kBase) + (1 << 15));
         d[3] = 0xFFFF;
 }
-XK(k_r10k_to_rgb) // :331-341
+XK(k_r10k_to_rgb) // :331-341: the top 8 bits of each component
 {
         XPRO();
         if (x >= (a.L + 2) / 3) return;
-        const uint8_t *s = srow + 4 * x;
+        uint32_t r, g, b;
+        r10k_get(srow + 4 * x, r, g, b);
         uint8_t *d = drow + 3 * x;
-        d[0] = s[0], d[1] = (uint8_t) (s[1] << 2 | s[2] >> 6), d[2] = (uint8_t) (s[2] << 4 | s[3] >> 4);
+        d[0] = (uint8_t) (r >> 2), d[1] = (uint8_t) (g >> 2), d[2] = (uint8_t) (b >> 2);
 }
 
 // vc_copylineToUYVY on two 8-bit RGB pixels (:1008-1053): y = (Y >> 14) + 16, u = ((cb1 + cb2) / 2 >> 14) + 128
@@ -125,10 +127,10 @@ XK(k_r10k_to_uyvy) // vc_copylineR10ktoUYVY :2320-2340: top 8 bits, then vc_copy
 {
         XPRO();
         if (x >= (a.L + 3) / 4) return;
-        const uint8_t *s = srow + 8 * x;
-        const int r1 = s[0], g1 = (uint8_t) (s[1] << 2 | s[2] >> 6), b1 = (uint8_t) (s[2] << 4 | s[3] >> 4);
-        const int r2 = s[4], g2 = (uint8_t) (s[5] << 2 | s[6] >> 6), b2 = (uint8_t) (s[6] << 4 | s[7] >> 4);
-        ((uint32_t *) drow)[x] = rgb_pair_to_uyvy(a, r1, g1, b1, r2, g2, b2);
+        uint32_t r1, g1, b1, r2, g2, b2;
+        r10k_get(srow + 8 * x, r1, g1, b1);
+        r10k_get(srow + 8 * x + 4, r2, g2, b2);
+        ((uint32_t *) drow)[x] = rgb_pair_to_uyvy(a, r1 >> 2, g1 >> 2, b1 >> 2, r2 >> 2, g2 >> 2, b2 >> 2);
 }
 
 // ---- R12L sources (one lane per group of 8 pixels = 36 source bytes) ---------------------------------------------------------------
@@ -307,13 +309,14 @@ XK(k_yuv422_to_rgb) // copylineYUVtoRGB :1065-1094: vc_copylineUYVYtoRG48 (rgb16
 }
 
 // ---- RG48 sources ---------------------------------------------------------------------------------------------------------------------
-XK(k_rg48_to_r10k) // :2008-2029
+XK(k_rg48_to_r10k) // :2008-2029: top 10 bits of each component, R10k byte order, padding bits 11
 {
         XPRO();
         if (x >= a.L / 4) return;
         const uint16_t *s = (const uint16_t *) srow + 3 * x;
         const uint32_t r = s[0] >> 6, g = s[1] >> 6, b = s[2] >> 6;
-        ((uint32_t *) drow)[x] = (b & 0x3FU) << 26U | 0x3000000U | (g & 0xFU) << 20U | (b >> 6U) << 16U | (r & 0x3U) << 14U | (g >> 4U) << 8U | r >> 2U;
+        const uint32_t b0 = r >> 2, b1 = (r & 3u) << 6 | g >> 4, b2 = (g & 0xfu) << 4 | b >> 6, b3 = (b & 0x3fu) << 2 | 3u;
+        ((uint32_t *) drow)[x] = b0 | b1 << 8 | b2 << 16 | b3 << 24;
 }
 XK(k_rg48_to_rgb) // :2031-2043
 {
@@ -494,16 +497,16 @@ XK(k_y216_to_uyvy) // :2729-2743
         const uint8_t *s = srow + 8 * x;
         ((uint32_t *) drow)[x] = (uint32_t) s[3] | (uint32_t) s[1] << 8 | (uint32_t) s[7] << 16 | (uint32_t) s[5] << 24;
 }
-XK(k_y216_to_v210) // :2761-2790: (dst_len + 15) / 16 groups
+XK(k_y216_to_v210) // :2761-2790: (dst_len + 15) / 16 groups; Y216 = Y0 Cb Y1 Cr per pixel pair
 {
         XPRO();
         if (x >= (a.L + 15) / 16) return;
         const uint16_t *s = (const uint16_t *) srow + 12 * x;
+        uint32_t Y[6], U[3], V[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) Y[2 * k] = s[4 * k] >> 6, U[k] = s[4 * k + 1] >> 6, Y[2 * k + 1] = s[4 * k + 2] >> 6, V[k] = s[4 * k + 3] >> 6;
         uint32_t *d = (uint32_t *) drow + 4 * x;
-        d[0] = s[1] >> 6U | s[0] >> 6U << 10U | s[3] >> 6U << 20U;
-        d[1] = s[2] >> 6U | s[5] >> 6U << 10U | s[4] >> 6U << 20U;
-        d[2] = s[7] >> 6U | s[6] >> 6U << 10U | s[9] >> 6U << 20U;
-        d[3] = s[8] >> 6U | s[11] >> 6U << 10U | s[10] >> 6U << 20U;
+        d[0] = U[0] | Y[0] << 10 | V[0] << 20, d[1] = Y[1] | U[1] << 10 | Y[2] << 20, d[2] = V[1] | Y[3] << 10 | U[2] << 20, d[3] = Y[4] | V[2] << 10 | Y[5] << 20;
 }
 template <bool Y416>
 XK(k_v210_to_y2xx) // vc_copylineV210toY216 :2792-2832 (dst_len / 24 groups), vc_copylineV210toY416 :2834-2882 (dst_len / 48)
@@ -526,19 +529,15 @@ XK(k_v210_to_y2xx) // vc_copylineV210toY216 :2792-2832 (dst_len / 24 groups), vc
 }
 
 // ---- DVS10 ------------------------------------------------------------------------------------------------------------------------------
-XK(k_dvs10_to_v210) // :595-617
+XK(k_dvs10_to_v210) // :595-617: a DVS10 word carries the top 8 bits of three components in bytes 0-2 and their low 2 bits in byte 3
 {
         XPRO();
         if (x >= a.L / 4) return;
-        uint32_t av = ((const uint32_t *) srow)[x], b = av;
-        b = ((b >> 24) * 0x00010101) & 0x00300c03;
-        av <<= 2;
-        b |= av & (0xff << 2);
-        av <<= 2;
-        b |= av & (0xff00 << 4);
-        av <<= 2;
-        b |= av & (0xff0000 << 6);
-        ((uint32_t *) drow)[x] = b;
+        const uint32_t in = ((const uint32_t *) srow)[x], low = in >> 24;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) out |= ((((in >> (8 * k)) & 0xffu) << 2) | ((low >> (2 * k)) & 3u)) << (10 * k);
+        ((uint32_t *) drow)[x] = out;
 }
 XK(k_dvs10_to_uyvy) // vc_copylineDVS10 :690-721: src_len = dst_len / 1.5, one iteration per 16 of it, each moving 32 source bytes to 24
 {                   // (three of every four bytes)
