@@ -246,7 +246,10 @@ int ug_hip_to_planar_supported(const char *func);
  *   ug_hip_av_to_uv   av_to_uv_convert(): the rows of av_to_uv_conversions (from_lavc_vid_conv.c:2049-2172) for software frames (not:
  *                     ayuv64le -> UYVY, y210 -> Y216, hardware frames); YCbCr -> RGB picks BT.601 / BT.709 and limited / full range from the
  *                     frame as get_cs_for_conv does (:2614-2658)
- * Results equal the reference functions' byte for byte, slips included (listed in csrc/lavc_conv.hip).  No row: UG_HIP_EUNSUPP. */
+ * Results equal the reference functions' byte for byte, slips included (listed in csrc/lavc_conv.hip).  No row: UG_HIP_EUNSUPP.
+ * Like the reference functions, some converters work in whole pixel groups (6 for v210, 8 for R12L, 2 for 4:2:2): they may READ up to one
+ * group past the end of the last line of a plane (keep the allocation padded, as FFmpeg does) and they WRITE the whole last group of a line
+ * when the line size has room for it -- never past the line size. */
 struct ug_av_frame {
         void *data[4];
         int linesize[4];

@@ -83,13 +83,14 @@ def ref():
     return _ref
 
 
-def plane_arrays(r, fr, h):
-    """numpy views (rows, linesize) of a stub frame's planes"""
+def plane_arrays(r, fr, h, extra_row=False):
+    """numpy views (rows, linesize) of a stub frame's planes; extra_row: with the spare line the stub allocates behind each plane (some
+    reference converters read whole groups past the end of the last line)"""
     out = []
     for i in range(4):
         if not fr.data[i]:
             break
-        rows = r.ug_stub_plane_rows(fr.format, i, h)
+        rows = r.ug_stub_plane_rows(fr.format, i, h) + (1 if extra_row else 0)
         out.append(np.ctypeslib.as_array(C.cast(fr.data[i], C.POINTER(C.c_uint8)), shape=(rows, fr.linesize[i])))
     return out
 
@@ -252,7 +253,7 @@ def test_gpu_av_to_uv(hip, av, uv):
         fr = frp.contents
         pitch = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
         want = ref_av_to_uv(frp, av, uv, w, h, pitch, shifts)
-        planes = [torch.from_numpy(p.copy()).cuda() for p in plane_arrays(r, fr, h)]
+        planes = [torch.from_numpy(p.copy()).cuda() for p in plane_arrays(r, fr, h, extra_row=True)]
         dst = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda")
         hip.av_to_uv(av, uv, planes, w, h, dst, pitch, shifts, colorspace=cs, color_range=rng_)
         torch.cuda.synchronize()
@@ -344,3 +345,51 @@ def test_gpu_av_to_uv_vs_committed_vectors(hip):
             assert np.array_equal(got[:, :full], want[:, :full]), key
             continue
         assert np.array_equal(got, want), key
+
+
+def _random_sizes(tag: str, n: int = 5):
+    rng = np.random.default_rng(abs(hash(tag)) % (1 << 31) if False else sum(map(ord, tag)))
+    # widths from 16: the SSE loop of the reference's yuv420p_to_uyvy runs `x < width - 15` on an unsigned width and crashes below that
+    return [(int(rng.integers(16, 131)), int(rng.integers(1, 10))) for _ in range(n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("uv,av", [p for p in TO_AV if p not in FORWARDED_TO])
+def test_gpu_uv_to_av_random_sizes(hip, uv, av):
+    """ragged frames: five pseudo-random sizes per conversion (16..130 x 1..9), whole planes against the compiled reference"""
+    import torch
+    r = ref()
+    for (w, h) in _random_sizes(uv + av):
+        if (uv, av) == ("v210", "yuv420p10le") and h % 2:
+            h += 1  # the reference reads and writes one line past an odd-height picture (to_lavc_vid_conv.c:204-208)
+        ls = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
+        src = np.random.default_rng(w * 31 + h).integers(0, 256, ls * (h + 1) + 64).astype(np.uint8)
+        want = ref_uv_to_av(uv, av, src, w, h)
+        planes = [torch.zeros(p.shape, dtype=torch.uint8, device="cuda") for p in want]
+        hip.uv_to_av(uv, av, torch.from_numpy(src).cuda(), w, h, planes)
+        torch.cuda.synchronize()
+        for k, (p, wnt) in enumerate(zip(planes, want)):
+            assert np.array_equal(p.cpu().numpy(), wnt), (uv, av, w, h, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("av,uv", FROM_AV)
+def test_gpu_av_to_uv_random_sizes(hip, av, uv):
+    import torch
+    r = ref()
+    for i, (w, h) in enumerate(_random_sizes(av + uv)):
+        cs, rng_ = (1, 1) if i % 2 else (6, 2)
+        frp = make_frame(r, av, w, h, 90 + i, cs, rng_)
+        pitch = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
+        want = ref_av_to_uv(frp, av, uv, w, h, pitch, (0, 8, 16))
+        planes = [torch.from_numpy(p.copy()).cuda() for p in plane_arrays(r, frp.contents, h, extra_row=True)]
+        dst = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda")
+        hip.av_to_uv(av, uv, planes, w, h, dst, pitch, (0, 8, 16), colorspace=cs, color_range=rng_)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        r.av_frame_free(C.byref(frp))
+        if uv == "R12L" and w % 8:
+            full = 36 * w // 8
+            assert np.array_equal(got[:, :full], want[:, :full]), (av, uv, w, h)
+            continue
+        assert np.array_equal(got, want), (av, uv, w, h, np.argwhere(got != want)[:4])

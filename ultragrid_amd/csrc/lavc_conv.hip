@@ -90,9 +90,10 @@ __global__ void k_uyvy_to_yuv444p(const Args a) // to_lavc_vid_conv.c:174-190
         const uint32_t s = BUF(const uint32_t, y)[x];
         const uint8_t cb = s & 0xff, y0 = (s >> 8) & 0xff, cr = (s >> 16) & 0xff, y1 = s >> 24;
         uint8_t *py = ROW(uint8_t, 0, y) + 2 * x, *pcb = ROW(uint8_t, 1, y) + 2 * x, *pcr = ROW(uint8_t, 2, y) + 2 * x;
-        py[0] = y0, py[1] = y1;
-        pcb[0] = cb, pcb[1] = cb;
-        pcr[0] = cr, pcr[1] = cr;
+        py[0] = y0, pcb[0] = cb, pcr[0] = cr;
+        if (2 * x + 1 < a.ls[0]) py[1] = y1; // the second pixel of a lone last pair may not fit a tightly packed line
+        if (2 * x + 1 < a.ls[1]) pcb[1] = cb;
+        if (2 * x + 1 < a.ls[2]) pcr[1] = cr;
 }
 
 __global__ void k_uyvy_to_vuya(const Args a) // :155-172
@@ -103,7 +104,7 @@ __global__ void k_uyvy_to_vuya(const Args a) // :155-172
         const uint32_t cb = s & 0xff, y0 = (s >> 8) & 0xff, cr = (s >> 16) & 0xff, y1 = s >> 24;
         uint32_t *dst = ROW(uint32_t, 0, y) + 2 * x;
         dst[0] = cr | cb << 8 | y0 << 16 | 0xff000000u;
-        dst[1] = cr | cb << 8 | y1 << 16 | 0xff000000u;
+        if (8 * x + 8 <= a.ls[0]) dst[1] = cr | cb << 8 | y1 << 16 | 0xff000000u;
 }
 
 struct V210Group {
@@ -119,9 +120,24 @@ __device__ __forceinline__ V210Group v210_unpack(const uint32_t *src)
         g.cr[0] = (w0 >> 20) & 0x3ff, g.cr[1] = w2 & 0x3ff, g.cr[2] = (w3 >> 10) & 0x3ff;
         return g;
 }
-template <int N>
-__device__ __forceinline__ void st16(uint16_t *p, const uint32_t (&v)[N], int shift)
+// Several reference converters write whole groups past `width`; past the end of the LINE that lands in the next line, whose own
+// conversion then overwrites it.  Lines are converted concurrently here, so such stores stop at the line size (`room` = samples that
+// still fit): inside the frame the result is the same.
+__device__ __forceinline__ int room16(long line_bytes, long first_sample, int want)
 {
+        const long fit = line_bytes / 2 - first_sample;
+        return (int) (fit < want ? (fit < 0 ? 0 : fit) : want);
+}
+template <int N>
+__device__ __forceinline__ void st16(uint16_t *p, const uint32_t (&v)[N], int shift, int n = N)
+{
+        if (n < N) {
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                        if (i < n) p[i] = (uint16_t) (v[i] << shift);
+                }
+                return;
+        }
         if (((uintptr_t) p & 3) == 0 && N % 2 == 0) {
 #pragma unroll
                 for (int i = 0; i < N / 2; i++) ((uint32_t *) p)[i] = (v[2 * i] << shift) | (v[2 * i + 1] << shift) << 16;
@@ -184,7 +200,9 @@ __global__ void k_v210_to_xv30(const Args a) // :393-417, (width + 5) / 6 groups
         const uint32_t pad = src[0] & 0xC0000000u;
         uint32_t *dst = ROW(uint32_t, 0, y) + 6 * x;
 #pragma unroll
-        for (int i = 0; i < 6; i++) dst[i] = g.cb[i / 2] | g.y[i] << 10 | g.cr[i / 2] << 20 | (i < 2 ? pad : 0u);
+        for (int i = 0; i < 6; i++) {
+                if (4 * (6 * x + i) + 4 <= a.ls[0]) dst[i] = g.cb[i / 2] | g.y[i] << 10 | g.cr[i / 2] << 20 | (i < 2 ? pad : 0u);
+        }
 }
 
 __global__ void k_v210_to_y210(const Args a) // :421-450
@@ -193,7 +211,7 @@ __global__ void k_v210_to_y210(const Args a) // :421-450
         if (x >= (a.w + 5) / 6 || y >= a.h) return;
         const V210Group g = v210_unpack(BUF(const uint32_t, y) + 4 * x);
         const uint32_t o[12] = { g.y[0], g.cb[0], g.y[1], g.cr[0], g.y[2], g.cb[1], g.y[3], g.cr[1], g.y[4], g.cb[2], g.y[5], g.cr[2] };
-        st16<12>(ROW(uint16_t, 0, y) + 12 * x, o, 6);
+        st16<12>(ROW(uint16_t, 0, y) + 12 * x, o, 6, room16(a.ls[0], 12L * x, 12));
 }
 
 template <int BPP>
@@ -228,7 +246,7 @@ __global__ void k_y216_to_yuv422p(const Args a) // y216_to_yuv422pXXle :1236-125
         const uint16_t *src = BUF(const uint16_t, y) + 4 * x;
         ROW(uint16_t, 0, y)[2 * x] = src[0] >> (16 - DEPTH);
         ROW(uint16_t, 1, y)[x] = src[1] >> (16 - DEPTH);
-        ROW(uint16_t, 0, y)[2 * x + 1] = src[2] >> (16 - DEPTH);
+        if (room16(a.ls[0], 2L * x, 2) == 2) ROW(uint16_t, 0, y)[2 * x + 1] = src[2] >> (16 - DEPTH);
         ROW(uint16_t, 2, y)[x] = src[3] >> (16 - DEPTH);
 }
 
@@ -238,9 +256,10 @@ __global__ void k_y216_to_yuv444p16le(const Args a) // :1266-1289
         if (x >= (a.w + 1) / 2 || y >= a.h) return;
         const uint16_t *src = BUF(const uint16_t, y) + 4 * x;
         uint16_t *py = ROW(uint16_t, 0, y) + 2 * x, *pcb = ROW(uint16_t, 1, y) + 2 * x, *pcr = ROW(uint16_t, 2, y) + 2 * x;
-        py[0] = src[0], py[1] = src[2];
-        pcb[0] = pcb[1] = src[1];
-        pcr[0] = pcr[1] = src[3];
+        py[0] = src[0], pcb[0] = src[1], pcr[0] = src[3];
+        if (room16(a.ls[0], 2L * x, 2) == 2) py[1] = src[2];
+        if (room16(a.ls[1], 2L * x, 2) == 2) pcb[1] = src[1];
+        if (room16(a.ls[2], 2L * x, 2) == 2) pcr[1] = src[3];
 }
 
 __global__ void k_y416_to_xv30(const Args a) // :454-470
@@ -399,14 +418,14 @@ __global__ void k_r12l_to_yuv(const Args a)
                 cb[i] = (uint16_t) ((UG_RGB_TO_CB(r, g, b) >> sh) + (1 << (DEPTH - 1)));
                 cr[i] = (uint16_t) ((UG_RGB_TO_CR(r, g, b) >> sh) + (1 << (DEPTH - 1)));
         }
-        st16<8>(ROW(uint16_t, 0, y) + 8 * x, Y, 0);
+        st16<8>(ROW(uint16_t, 0, y) + 8 * x, Y, 0, room16(a.ls[0], 8L * x, 8));
         if (OUT_422) {
                 const uint32_t cb4[4] = { cb[0], cb[2], cb[4], cb[6] }, cr4[4] = { cr[0], cr[2], cr[4], cr[6] };
-                st16<4>(ROW(uint16_t, 1, y) + 4 * x, cb4, 0);
-                st16<4>(ROW(uint16_t, 2, y) + 4 * x, cr4, 0);
+                st16<4>(ROW(uint16_t, 1, y) + 4 * x, cb4, 0, room16(a.ls[1], 4L * x, 4));
+                st16<4>(ROW(uint16_t, 2, y) + 4 * x, cr4, 0, room16(a.ls[2], 4L * x, 4));
         } else {
-                st16<8>(ROW(uint16_t, 1, y) + 8 * x, cb, 0);
-                st16<8>(ROW(uint16_t, 2, y) + 8 * x, cr, 0);
+                st16<8>(ROW(uint16_t, 1, y) + 8 * x, cb, 0, room16(a.ls[1], 8L * x, 8));
+                st16<8>(ROW(uint16_t, 2, y) + 8 * x, cr, 0, room16(a.ls[2], 8L * x, 8));
         }
 }
 
@@ -431,11 +450,11 @@ __global__ void k_r12l_to_p210_ayuv64(const Args a)
                 uint32_t o[32];
 #pragma unroll
                 for (int i = 0; i < 8; i++) o[4 * i] = 0xffff, o[4 * i + 1] = Y[i], o[4 * i + 2] = cb[i], o[4 * i + 3] = cr[i];
-                st16<32>(ROW(uint16_t, 0, y) + 32 * x, o, 0);
+                st16<32>(ROW(uint16_t, 0, y) + 32 * x, o, 0, room16(a.ls[0], 32L * x, 32));
         } else {
                 const uint32_t cc[8] = { cb[0], cr[0], cb[2], cr[2], cb[4], cr[4], cb[6], cr[6] };
-                st16<8>(ROW(uint16_t, 0, y) + 8 * x, Y, 0);
-                st16<8>(ROW(uint16_t, 1, y) + 8 * x, cc, 0);
+                st16<8>(ROW(uint16_t, 0, y) + 8 * x, Y, 0, room16(a.ls[0], 8L * x, 8));
+                st16<8>(ROW(uint16_t, 1, y) + 8 * x, cc, 0, room16(a.ls[1], 8L * x, 8));
         }
 }
 
@@ -799,7 +818,8 @@ __global__ void k_y210_to_y416(const Args a) // :1762-1792, (width + 1) / 2 pair
         const uint16_t *src = ROW(const uint16_t, 0, y) + 4 * x;
         uint16_t *dst = BUF(uint16_t, y) + 8 * x;
         dst[0] = src[1], dst[1] = src[0], dst[2] = src[3], dst[3] = 0xFFFFU;
-        dst[4] = src[1], dst[5] = src[2], dst[6] = src[3], dst[7] = 0xFFFFU;
+        if (room16(a.pitch, 8L * x, 8) == 8) dst[4] = src[1], dst[5] = src[2], dst[6] = src[3], dst[7] = 0xFFFFU; // second pixel of a lone last pair
+
 }
 
 __global__ void k_y210_to_uyvy(const Args a) // :1794-1818: the high bytes
@@ -1228,6 +1248,14 @@ long uv_linesize(const char *uv, int w)
         return 0;
 }
 
+// how the kernels address a packed UltraGrid buffer: 32-bit words (UYVY, v210, RGBA, R10k, VUYA), 16-bit samples (RG48, Y216, Y416), bytes
+int uv_align(const char *uv)
+{
+        if (!strcmp(uv, "RGB") || !strcmp(uv, "R12L")) return 1;
+        if (!strcmp(uv, "RG48") || !strcmp(uv, "Y216") || !strcmp(uv, "Y416")) return 2;
+        return 4;
+}
+
 bool fill_frame(Args &a, const ug_av_frame *f, int planes, int align)
 {
         for (int i = 0; i < planes; i++) {
@@ -1328,7 +1356,7 @@ int ug_hip_av_to_uv(const char *av_pixfmt, const char *uv_codec, void *dst, int 
                 return UG_HIP_EUNSUPP;
         }
         Args a = {};
-        if (!dst || !in || pitch <= 0 || !fill_frame(a, in, c->min_planes, frame_align(c->av)) || (strcmp(c->uv, "RGB") && (((uintptr_t) dst | (uintptr_t) pitch) & 3))) {
+        if (!dst || !in || pitch <= 0 || !fill_frame(a, in, c->min_planes, frame_align(c->av)) || (((uintptr_t) dst | (uintptr_t) pitch) & (uintptr_t) (uv_align(c->uv) - 1))) {
                 ug::set_last_error_msg("ug_hip_av_to_uv: null pointer, bad geometry or misaligned buffer");
                 return UG_HIP_EINVAL;
         }

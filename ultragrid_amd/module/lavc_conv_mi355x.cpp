@@ -47,7 +47,8 @@ struct device_frame {
                         if (size[i] < need) {
                                 ug_hip_free(data[i]);
                                 data[i] = nullptr;
-                                if (ug_hip_malloc(&data[i], need) != UG_HIP_SUCCESS) {
+                                // one spare line: some converters read whole pixel groups past the end of the last line (FFmpeg pads its buffers too)
+                                if (ug_hip_malloc(&data[i], need + (size_t) f->linesize[i]) != UG_HIP_SUCCESS) {
                                         return false;
                                 }
                                 size[i] = need;
