@@ -665,6 +665,10 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
                 ug::set_last_error_msg("ug_hip_pixfmt_convert: buffer or pitch not aligned for this pair");
                 return UG_HIP_EINVAL;
         }
+        if (dst_pitch < dst_len) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert: dst_pitch is smaller than a line of the output format");
+                return UG_HIP_EINVAL;
+        }
         XArgs a = {};
         a.src = (const uint8_t *) src, a.dst = (uint8_t *) dst;
         a.spitch = src_pitch, a.dpitch = dst_pitch;
