@@ -170,3 +170,13 @@ def test_best_decoder_choice_equals_the_reference(po):
                 assert rv == lib.EUNSUPP, (src, cand)
             else:
                 assert rv == 0 and mout.value == lib.PF_NAMES[back[rout.value]], (src, cand, back[rout.value])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_ext_pair_random_sizes(hip, po, pair):
+    """six pseudo-random frame sizes per pair (1..130 x 1..6)"""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(sum(map(ord, pair[0] + pair[1])))
+    run_pair(hip, po, *pair, sizes=[(int(rng.integers(1, 131)), int(rng.integers(1, 7))) for _ in range(6)])
