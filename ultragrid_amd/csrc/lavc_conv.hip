@@ -770,8 +770,8 @@ __global__ void k_xv30_to_uyvy(const Args a) // :1631-1658: pairs, then a lone l
         const uint32_t in1 = src[0];
         if (2 * x + 1 < a.w) {
                 const uint32_t in2 = src[1];
-                BUF(uint32_t, y)[x] = ((((in1 >> 2U) & 0xFFU) + (((in2 >> 2U) & 0xFFU) + 1)) >> 1) & 0xff | ((in1 >> 12U) & 0xFFU) << 8 |
-                                      (((((in1 >> 22U) & 0xFFU) + (((in2 >> 22U) & 0xFFU) + 1)) >> 1) & 0xff) << 16 | ((in2 >> 12U) & 0xFFU) << 24;
+                const uint32_t u = ((((in1 >> 2) & 0xFFu) + (((in2 >> 2) & 0xFFu) + 1)) >> 1) & 0xFFu, v = ((((in1 >> 22) & 0xFFu) + (((in2 >> 22) & 0xFFu) + 1)) >> 1) & 0xFFu;
+                BUF(uint32_t, y)[x] = u | ((in1 >> 12) & 0xFFu) << 8 | v << 16 | ((in2 >> 12) & 0xFFu) << 24;
         } else {
                 BUF(uint32_t, y)[x] = ((in1 >> 2U) & 0xFFU) | ((in1 >> 12U) & 0xFFU) << 8 | ((in1 >> 22U) & 0xFFU) << 16;
         }
