@@ -16,7 +16,25 @@
 
 #include "ug_common.h"
 
+namespace ug {
+const int kColorCoeffs[2][5][14] = {
+        { { 4899, 9617, 1868, -2765, -5427, 8192, 8191, -6860, -1331, 16384, 22970, -5638, -11700, 29032 },
+          { 4207, 8260, 1604, -2428, -4768, 7196, 7195, -6026, -1169, 19077, 26149, -6419, -13320, 33050 },
+          { 4195, 8235, 1599, -2421, -4754, 7175, 7174, -6008, -1166, 19133, 26226, -6438, -13359, 33148 },
+          { 4192, 8229, 1598, -2420, -4750, 7170, 7169, -6004, -1165, 19147, 26245, -6442, -13369, 33172 },
+          { 4191, 8228, 1598, -2419, -4749, 7168, 7167, -6002, -1165, 19152, 26251, -6444, -13372, 33179 } },
+        { { 3484, 11717, 1183, -1877, -6315, 8192, 8191, -7441, -750, 16384, 25800, -3069, -7671, 30402 },
+          { 2992, 10063, 1016, -1649, -5547, 7196, 7195, -6536, -659, 19077, 29371, -3494, -8733, 34610 },
+          { 2983, 10034, 1013, -1644, -5531, 7175, 7174, -6517, -657, 19133, 29457, -3504, -8758, 34712 },
+          { 2981, 10026, 1012, -1643, -5527, 7170, 7169, -6512, -656, 19147, 29479, -3507, -8765, 34737 },
+          { 2980, 10024, 1012, -1643, -5525, 7168, 7167, -6511, -656, 19152, 29486, -3507, -8767, 34745 } },
+};
+} // namespace ug
+
 namespace {
+
+constexpr auto &kCoeffs = ug::kColorCoeffs;
+int depth_slot(int depth) { return ug::color_depth_slot(depth); }
 
 struct Args {
         uint8_t *d[4]; // AVFrame::data
@@ -30,33 +48,6 @@ struct Args {
 };
 enum { Y_R, Y_G, Y_B, CB_R, CB_G, CB_B, CR_R, CR_G, CR_B, Y_SCALE, R_CR, G_CB, G_CR, B_CB };
 constexpr int kBase = 14; // COMP_BASE, color_space.h:71
-
-// get_color_coeffs(cs, depth) (color_space.c:149-184): [cs - 1][0 = full range, 8, 10, 12, 16].  Values = the reference's compile-time
-// tables (tests/test_lavc_conv.py::test_color_coefficient_tables compares them with the compiled reference through ug_hip_color_coeffs).
-const int kCoeffs[2][5][14] = {
-        { { 4899, 9617, 1868, -2765, -5427, 8192, 8191, -6860, -1331, 16384, 22970, -5638, -11700, 29032 },
-          { 4207, 8260, 1604, -2428, -4768, 7196, 7195, -6026, -1169, 19077, 26149, -6419, -13320, 33050 },
-          { 4195, 8235, 1599, -2421, -4754, 7175, 7174, -6008, -1166, 19133, 26226, -6438, -13359, 33148 },
-          { 4192, 8229, 1598, -2420, -4750, 7170, 7169, -6004, -1165, 19147, 26245, -6442, -13369, 33172 },
-          { 4191, 8228, 1598, -2419, -4749, 7168, 7167, -6002, -1165, 19152, 26251, -6444, -13372, 33179 } },
-        { { 3484, 11717, 1183, -1877, -6315, 8192, 8191, -7441, -750, 16384, 25800, -3069, -7671, 30402 },
-          { 2992, 10063, 1016, -1649, -5547, 7196, 7195, -6536, -659, 19077, 29371, -3494, -8733, 34610 },
-          { 2983, 10034, 1013, -1644, -5531, 7175, 7174, -6517, -657, 19133, 29457, -3504, -8758, 34712 },
-          { 2981, 10026, 1012, -1643, -5527, 7170, 7169, -6512, -656, 19147, 29479, -3507, -8765, 34737 },
-          { 2980, 10024, 1012, -1643, -5525, 7168, 7167, -6511, -656, 19152, 29486, -3507, -8767, 34745 } },
-};
-
-int depth_slot(int depth)
-{
-        switch (depth) {
-        case 0: return 0;
-        case 8: return 1;
-        case 10: return 2;
-        case 12: return 3;
-        case 16: return 4;
-        default: return -1;
-        }
-}
 
 #define UG_XY()                                                   \
         const int x = blockIdx.x * blockDim.x + threadIdx.x;      \

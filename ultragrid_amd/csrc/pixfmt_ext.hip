@@ -627,12 +627,6 @@ const Entry kTable[] = {
         { UG_PF_V210, UG_PF_Y416, k_v210_to_y2xx<true>, I_G6, 0 },
 };
 
-// BT.709 limited-range coefficient sets of get_color_coeffs(CS_DFL, depth) (color_space.c:149-184) for depth 8, 10, 16 -- the same
-// constants as lavc_conv.hip, checked against the compiled reference through ug_hip_color_coeffs
-const int kC8[14] = { 2992, 10063, 1016, -1649, -5547, 7196, 7195, -6536, -659, 19077, 29371, -3494, -8733, 34610 };
-const int kC10[14] = { 2983, 10034, 1013, -1644, -5531, 7175, 7174, -6517, -657, 19133, 29457, -3504, -8758, 34712 };
-const int kC16[14] = { 2980, 10024, 1012, -1643, -5525, 7168, 7167, -6511, -656, 19152, 29486, -3507, -8767, 34745 };
-
 const Entry *find(int in, int out)
 {
         for (const Entry &e : kTable) {
@@ -675,7 +669,7 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
         a.width = width, a.height = height, a.L = dst_len;
         a.rs = rshift, a.gs = gshift, a.bs = bshift;
         a.am = 0xFFFFFFFFu ^ (0xFFu << rshift) ^ (0xFFu << gshift) ^ (0xFFu << bshift);
-        if (e->coeff_depth) memcpy(a.c, e->coeff_depth == 8 ? kC8 : (e->coeff_depth == 10 ? kC10 : kC16), sizeof a.c);
+        if (e->coeff_depth) memcpy(a.c, ug::kColorCoeffs[1][ug::color_depth_slot(e->coeff_depth)], sizeof a.c); // get_color_coeffs(CS_DFL, depth): BT.709
         int nx = 0; // an upper bound of the lanes a line needs; every kernel re-derives its exact count from dst_len
         switch (e->iter) {
         case I_PX: nx = width + 1; break;

@@ -65,6 +65,12 @@ int jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width
 int jpeg_fdct_quant_rgb444(const void *src, int pitch, int width, int height, int blocks_w, int blocks_h, const float *div,
                            int16_t *out_r, int16_t *out_g, int16_t *out_b, ug_hip_stream_t stream);
 
+// get_color_coeffs(cs, depth) (color_space.c:149-184) as constants: [cs - 1][slot], cs 1 = BT.601, 2 = BT.709; slot 0 = full range, then
+// 8, 10, 12, 16 bit limited range; 14 ints in the field order of struct color_coeffs.  Defined in lavc_conv.hip, checked against the compiled
+// reference through ug_hip_color_coeffs (tests/test_lavc_conv.py).
+extern const int kColorCoeffs[2][5][14];
+static inline int color_depth_slot(int depth) { return depth == 0 ? 0 : depth == 8 ? 1 : depth == 10 ? 2 : depth == 12 ? 3 : depth == 16 ? 4 : -1; }
+
 // pixfmt_ext.hip: the pairs of decoders[] outside pixfmt.hip's core
 int pixfmt_ext_supported(ug_pixfmt_t in, ug_pixfmt_t out);
 int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height, int src_pitch, int dst_pitch, int dst_len,
