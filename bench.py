@@ -201,7 +201,7 @@ def main() -> None:
                          "kernel": "uyvy_jpeg_fast_kernel<420>" if out_name == "JPEG420" else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>",
                          "ms_per_launch": round(kern_ms / (F if out_name == "JPEG420" else 1), 5),
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * W * H * (1 if out_name == "JPEG420" else F)),
-                         "note": ("VALU-issue-bound kernel (SURVEY.md F9): about 660 VALU issue slots per wave against a floor of about 600 for this formulation (DESIGN.md 4.1)"
+                         "note": ("VALU-issue-bound kernel (SURVEY.md F9): 1049 VALU instructions per wave issue in about 660 slots = 80 % of the two-pipe VALU issue peak (PMC: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU2; DESIGN.md 4.1, 8); HBM traffic = 1.0004 x the algorithmic bytes"
                                           if args.workload == "4k-uyvy" else ("HBM-bound kernel (DESIGN.md 4.3)" if out_name == "JPEG420" else "VALU-issue-bound kernel (SURVEY.md F9, DESIGN.md 4.1)"))},
         }
         if world == 1 and not args.no_cpu_baseline and out_name != "JPEG420":
