@@ -4,14 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path (fused UYVY unpack + YUV->RGB + RGB->YCoCg + DXT5 block
-encode, ug_hip_dxt_encode_batch) over one batch of `--frames` distinct synthetic 3840x2160 UYVY
-frames that are already resident in HBM (BASELINE.json configs[2]).  Frames are independent, so
-ranks shard them with no collective (weak scaling: every rank encodes its own batch).
+One "step" = passes of the hot path (fused UYVY unpack + YUV->RGB + RGB->YCoCg + DXT5 block encode,
+ug_hip_dxt_encode_batch: one launch = `--frames` = 16 distinct synthetic 3840x2160 UYVY frames, BASELINE.json
+configs[2]) over `--batches` = 4 resident batches in turn, as many launches as make >= 50 ms of GPU work
+(`config.launches_per_step`), all input already resident in HBM.  Frames are independent, so ranks shard them
+with no collective (weak scaling: every rank encodes its own batches).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline     -- algorithmic bytes (3.0 B/px: 2 read + 1 written) x pixels per
                   launch / average launch duration measured with HIP events on the launch stream;
+  e2e          -- the PCIe-inclusive rate (pinned host -> H2D -> kernel -> D2H, 3 frames in flight per GPU, all ranks at once) for
+                  8K v210 and 4K UYVY: fps per GPU and in total, PCIe GB/s -- reported beside `value`, never as `value`;
   cpu_baseline -- the CPU oracle (oracle/dxt_oracle.c, "port": the reference has no CPU DXT encoder)
                   timed on this box's host cores on a bounded sample (N=1 only).
 """
@@ -41,6 +44,7 @@ WORKLOADS = {
     "1080p-rgb-dxt1": dict(w=1920, h=1080, fmt="RGB", out="DXT1", bpp=3.5, frames=64, name="1920x1080 RGB->DXT1 encode (BASELINE.json configs[1])"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK = 256 * 2 * 2.4e9  # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32 x one wave64 op per 2 cycles x 2.4 GHz
 
 
 def make_frames(n: int, rank: int, fmt: str = "UYVY", w: int = W, h: int = H) -> np.ndarray:
@@ -95,14 +99,50 @@ def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 
                       f"row bands; {best_t} threads = best of {cands} on {ncpu} visible CPUs), {dt:.1f} s"}
 
 
+def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) -> dict:
+    """PCIe-inclusive leg (never `value`): every rank drives ITS GPU from pinned host frames -- allocated after the
+    process is bound to the GPU's NUMA node -- with 3 frames in flight (H2D -> fused kernel -> D2H), all ranks at the same time,
+    so that at N > 1 the host-side limit (PCIe root complexes, DRAM bandwidth, NUMA) shows up instead of a trivially linear kernel
+    curve (scheme: gpujpeg.cpp:446-466,643-722)."""
+    from ultragrid_amd import pipeline
+    node = pipeline.gpu_numa_node(torch.cuda.current_device())
+    bound = pipeline.bind_to_numa_node(node)
+    res = {}
+    for wl in workloads:
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank)
+        per = [r["fps"]]
+        pcie = [r["pcie_gbs"]]
+        if dist is not None:
+            t = torch.tensor([r["fps"], r["pcie_gbs"]], dtype=torch.float64, device=device_for_gather)
+            parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, t)
+            per = [round(float(p[0]), 1) for p in parts]
+            pcie = [round(float(p[1]), 2) for p in parts]
+        w, h = pipeline.WORKLOADS[wl][3], pipeline.WORKLOADS[wl][4]
+        res[wl] = {"fps_total": round(sum(per), 1), "fps_per_gpu": per, "mpixels_per_s_total": round(sum(per) * w * h / 1e6, 1),
+                   "pcie_gbs_total": round(sum(pcie), 2), "pcie_gbs_per_gpu": pcie, "in_flight": r["in_flight"],
+                   "bytes_in_per_frame": r["bytes_in_per_frame"], "bytes_out_per_frame": r["bytes_out_per_frame"], "seconds": r["seconds"]}
+    res["path"] = "pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU on 3 streams, all ranks concurrently"
+    res["numa_node_rank0"] = node
+    res["cpus_bound_rank0"] = bound
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=0, help="distinct frames per step (batch); 0 = workload default")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=0, help="distinct frames per launch (batch); 0 = workload default")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the launches of a step cycle through")
+    ap.add_argument("--launches-per-step", type=int, default=0, help="kernel launches per step; 0 = as many as make a step >= 50 ms of GPU work")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k-uyvy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--e2e-seconds", type=float, default=2.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU smoke test of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="smoke test only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -125,6 +165,7 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     from ultragrid_amd import codec, lib
     lib.load()
@@ -133,27 +174,63 @@ def main() -> None:
     W, H = wl["w"], wl["h"]
     ALG_BYTES_PER_PX = wl["bpp"]
     F = args.frames or wl["frames"]
-    host = make_frames(F, rank, wl["fmt"], W, H)
-    src = torch.from_numpy(host).cuda()
-    frame_bytes = host.shape[1]
-    dst = torch.empty(F * W * H, dtype=torch.uint8, device="cuda")
-    pf = lib.PF_NAMES[wl["fmt"]]
+    B = max(1, args.batches)
     out_name = wl.get("out", "DXT5")
+    # B resident batches of F distinct frames: a few generated bases, the rest row-rotations made on the device
+    host = make_frames(min(F, 4 if W <= 3840 else 2), rank, wl["fmt"], W, H)
+    frame_bytes = host.shape[1]
+    ls = frame_bytes // H
+    bases = torch.from_numpy(host).cuda().view(host.shape[0], H, ls)
+    src = torch.empty((B, F, H, ls), dtype=torch.uint8, device="cuda")
+    for b in range(B):
+        for i in range(F):
+            k = b * F + i
+            src[b, i] = torch.roll(bases[k % bases.shape[0]], 4 * 37 * (k // bases.shape[0]), dims=0)
+    del bases
+    src = src.view(B, F * frame_bytes)
+    out_bytes = {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3}[out_name]
+    dst = torch.empty((B, F * out_bytes), dtype=torch.uint8, device="cuda")
+    pf = lib.PF_NAMES[wl["fmt"]]
     oid = lib.DXT5_YCOCG if out_name == "DXT5" else lib.DXT1
 
-    def step():
-        codec.dxt_encode_batch(pf, oid, src, W, H, F, frame_bytes, dst=dst)
+    def launch(b: int):
+        codec.dxt_encode_batch(pf, oid, src[b], W, H, F, frame_bytes, dst=dst[b])
 
     if out_name == "JPEG420":   # the JPEG front end: UYVY -> 4:2:0 (uyvy_to_i420 rounding) -> FDCT -> quantise, int16 coefficients out
         div = codec.jpeg_divisors_device(75, "cuda")
         mw, mh = (W + 15) // 16, (H + 15) // 16
-        oy = torch.empty((4 * mw * mh, 64), dtype=torch.int16, device="cuda")
-        ocb, ocr = torch.empty((mw * mh, 64), dtype=torch.int16, device="cuda"), torch.empty((mw * mh, 64), dtype=torch.int16, device="cuda")
-        fn = lib.load().ug_hip_uyvy_to_jpeg420_coeffs
+        nblk = mw * mh
+        oy = torch.empty((F, 4 * nblk, 64), dtype=torch.int16, device="cuda")
+        ocb, ocr = torch.empty((F, nblk, 64), dtype=torch.int16, device="cuda"), torch.empty((F, nblk, 64), dtype=torch.int16, device="cuda")
+        fn = lib.load().ug_hip_uyvy_to_jpeg42x_coeffs_batch
 
-        def step():  # noqa: F811
-            for i in range(F):
-                assert fn(src[i].data_ptr(), 0, W, H, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), None) == 0
+        def launch(b: int):  # noqa: F811  (one launch over the F frames of the batch, grid.z = frame)
+            rc = fn(420, src[b].data_ptr(), 0, W, H, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), F, frame_bytes,
+                    4 * nblk * 128, nblk * 128, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.last_error()
+
+    # calibrate the launches of a step: >= 50 ms of GPU work per step, so that box noise averages out and gpu_busy registers
+    for b in range(B):
+        launch(b)
+    torch.cuda.synchronize()
+    L = args.launches_per_step
+    if L <= 0:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for i in range(4 * B):
+            launch(i % B)
+        c1.record()
+        torch.cuda.synchronize()
+        est = c0.elapsed_time(c1) / (4 * B)
+        L = max(B, int(np.ceil(50.0 / max(est, 1e-3) / B)) * B)
+    if dist is not None:   # same step on every rank
+        t = torch.tensor([L], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        L = int(t.item())
+
+    def step():
+        for i in range(L):
+            launch(i % B)
 
     from ultragrid_amd import shard
     for _ in range(args.warmup):
@@ -170,21 +247,56 @@ def main() -> None:
             ev1.record()
 
     # barrier + synchronize on both sides of exactly K steps, MAX over ranks (ultragrid_amd/shard.py)
-    wall = shard.timed_steps(timed_step, args.steps, torch.cuda.synchronize, dist,
-                             device="cuda" if args.dist_backend == "nccl" else "cpu")
-    kern_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration (back-to-back launches on one stream)
+    wall = shard.timed_steps(timed_step, args.steps, torch.cuda.synchronize, dist, device=coll_dev)
+    kern_ms = ev0.elapsed_time(ev1) / (args.steps * L)   # average launch duration (back-to-back launches on one stream)
+
+    e2e = None
+    if not args.no_e2e and out_name in ("DXT5", "DXT1"):
+        del src, dst
+        torch.cuda.empty_cache()
+        e2e = e2e_leg(["8k-v210", "4k-uyvy"], rank, dist, coll_dev, args.e2e_seconds)
 
     if rank == 0:
-        px_per_step = F * W * H * world
+        px_per_launch = F * W * H
+        px_per_step = px_per_launch * L * world
         value = px_per_step * args.steps / wall / 1e6
-        achieved = ALG_BYTES_PER_PX * F * W * H / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes, see DESIGN.md
-        if os.path.exists(pmc):
+        achieved = ALG_BYTES_PER_PX * px_per_launch / (kern_ms * 1e-3) / 1e9
+        read_bpp = {"UYVY": 2.0, "v210": 16 / 6, "RGB": 3.0}[wl["fmt"]]
+        pmc_key = {"4k-uyvy": f"uyvy_dxt5_4k_x{F}"}.get(args.workload)
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes (tools/pmc_collect.sh)
+        if pmc_key and os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc)).get(f"uyvy_dxt5_4k_x{F}") if args.workload == "4k-uyvy" else None
+                pmc = json.load(open(pmc_path)).get(pmc_key) or {}
+                if not isinstance(pmc, dict):
+                    pmc = {"traffic": pmc}
             except Exception:
-                traffic = None
+                pmc = {}
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
+                "kernel": "uyvy_jpeg_kernel<420> (batched)" if out_name == "JPEG420" else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>",
+                "ms_per_launch": round(kern_ms, 5), "launches_timed": args.steps * L,
+                "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * px_per_launch),
+                "algorithmic_bytes_per_px": round(ALG_BYTES_PER_PX, 4)}
+        if out_name != "JPEG420":
+            # The DXT encoders are VALU-issue bound, not HBM bound: `frac` above stays the contract's
+            # algorithmic-bytes / 8 TB/s figure; `hbm_read_frac` is the north star's own definition (input bytes only);
+            # `valu_frac` = wave-instructions issued per second / (256 CU x 2 wave-instr/clk x 2.4 GHz).
+            units = (W // 4 + (3 if wl["fmt"] == "v210" else 1) * 64 - 1) // ((3 if wl["fmt"] == "v210" else 1) * 64)
+            waves = F * units * (H // 4)
+            roof["bound"] = "valu"
+            roof["hbm_read_frac"] = round(read_bpp * px_per_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            ipw = pmc.get("valu_instr_per_wave")
+            roof["valu"] = {"instr_per_wave": ipw, "waves_per_launch": waves, "peak_wave_instr_per_s": VALU_PEAK,
+                            "peak_def": "256 CU x 2 wave64 VALU instr / clk / CU x 2.4 GHz", "source": pmc.get("source")}
+            if ipw:
+                rate = ipw * waves / (kern_ms * 1e-3)
+                roof["valu"]["wave_instr_per_s"] = round(rate, 0)
+                roof["valu_frac"] = round(rate / VALU_PEAK, 4)
+            roof["note"] = ("VALU-issue-bound kernel: the bit-exactness contract (every shader operation one separately rounded fp32 operation, no FMA) "
+                            "fixes ~65 VALU instructions per pixel against 3 B/px; HBM traffic = 1.000x the algorithmic bytes (DESIGN.md 4.1)")
+        else:
+            roof["note"] = "HBM-bound kernel (DESIGN.md 4.3)"
         out = {
             "metric": {"4k-uyvy": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)", "8k-v210": "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
                        "1080p-rgb-dxt1": "Mpixels/s encode (RGB->DXT1, 1080p)",
@@ -193,17 +305,14 @@ def main() -> None:
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"],
-                       "frames_per_step": F, "frame_bytes_in": frame_bytes, "frame_bytes_out": {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3}[out_name],
-                       "input": ("S1 uniform random bytes" if wl["fmt"] == "RGB" else "S2 legal-range video noise") + ", resident in HBM", "fps": round(value * 1e6 / (W * H), 1),
+                       "launches_per_step": L, "frames_per_launch": F, "resident_batches": B, "frame_bytes_in": frame_bytes, "frame_bytes_out": out_bytes,
+                       "input": ("S1 uniform random bytes" if wl["fmt"] == "RGB" else "S2 legal-range video noise") + f", {B * F} distinct frames resident in HBM",
+                       "fps": round(value * 1e6 / (W * H), 1), "ties": "even (library default, pinned to the executed reference shaders)",
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "uyvy_jpeg_fast_kernel<420>" if out_name == "JPEG420" else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>",
-                         "ms_per_launch": round(kern_ms / (F if out_name == "JPEG420" else 1), 5),
-                         "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * W * H * (1 if out_name == "JPEG420" else F)),
-                         "note": ("VALU-issue-bound kernel (SURVEY.md F9): 1049 VALU instructions per wave issue in about 660 slots = 80 % of the two-pipe VALU issue peak (PMC: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU2; DESIGN.md 4.1, 8); HBM traffic = 1.0004 x the algorithmic bytes"
-                                          if args.workload == "4k-uyvy" else ("HBM-bound kernel (DESIGN.md 4.3)" if out_name == "JPEG420" else "VALU-issue-bound kernel (SURVEY.md F9, DESIGN.md 4.1)"))},
+            "roofline": roof,
         }
+        if e2e is not None:
+            out["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline and out_name != "JPEG420":
             out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H, out=out_name)
         print(json.dumps(out), flush=True)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UG_HIP_ABI_VERSION 1
+#define UG_HIP_ABI_VERSION 2 /* 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points */
 
 /* error codes (cuda_dxt.cu:745-746,759 uses -1 bad size/alignment, -3 runtime failure) */
 #define UG_HIP_SUCCESS      0
@@ -82,6 +82,9 @@ int         ug_hip_device_count(int *count);
 /* 1 if ptr is device memory of this process (a device-resident video_frame, types.h:295-298 mem_location; the reference's
  * GPUJPEG module takes such frames without the upload, gpujpeg.cpp:617-622), 0 for host / unknown pointers. Never fails. */
 int         ug_hip_pointer_is_device(const void *ptr);
+/* index of the device that owns ptr, -1 for host / unknown pointers: a module state bound to device d reads a device-resident frame in
+ * place only when this returns d (a frame that lives on another GPU is copied over first). Never fails. */
+int         ug_hip_pointer_device(const void *ptr);
 int         ug_hip_set_device(int index);                              /* cuda_wrapper_set_device */
 int         ug_hip_malloc(void **buffer, size_t size);                 /* cuda_wrapper_malloc */
 int         ug_hip_free(void *buffer);                                 /* cuda_wrapper_free */
@@ -107,10 +110,26 @@ int         ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src
 /* ------------------------------------------------------------------------------------
  * DXT encoders (replace cuda_dxt/cuda_dxt.h:30-89)
  * ---------------------------------------------------------------------------------- */
+/* The reference's normative encoders are GLSL shaders (dxt_compress/compress_dxt5ycocg_fp.glsl, compress_dxt1_fp.glsl), and GLSL
+ * leaves two things they use to the implementation: the direction of exact .5 ties of round() and the order in which dot(vec3)
+ * is summed.  The choice is a run-time option:
+ *   UG_DXT_TIES_EVEN  (default) round() ties to even, dot(vec3) summed from the last component: what the shaders compute where
+ *                     they can actually be EXECUTED -- Mesa llvmpipe; every block of tests/golden/dxt_glsl_ref.npz (generated by
+ *                     running the reference's shader files) is reproduced in this mode.  On the decode side: float -> unorm8
+ *                     framebuffer writes of rgba_to_yuv422.glsl / display_dxt1_yuv_fp.glsl tie to even (Mesa again).
+ *   UG_DXT_TIES_AWAY  roundf() half away from zero, dot() left to right: the reference's CUDA text (cuda_dxt.cu:106-108,
+ *                     122-124), which cannot be executed here; decode side: floor(x * 255 + 0.5).
+ * The two differ in ~0.3 % of uniform-random blocks (one endpoint LSB or one palette index). */
+#define UG_DXT_TIES_EVEN    0
+#define UG_DXT_TIES_AWAY    1
+#define UG_DXT_TIES_DEFAULT UG_DXT_TIES_EVEN
+
 /* Fused pixel-format unpack + colour conversion + 4x4 block encode, one pass, no
  * intermediate buffer.  `in` in {RGB, RGBA, UYVY, UYVY_RAW, V210, YUV444}.
- * Requirements (cuda_dxt.cu:745): width % 4 == 0, |height| % 4 == 0 (V210 additionally
- * width % 12 == 0 for the 3-block groups), src 16-B aligned, dst 16-B aligned, pitch % 4 == 0. */
+ * Requirements (cuda_dxt.cu:745): width % 4 == 0, |height| % 4 == 0, src 16-B aligned, dst 16-B aligned, pitch % 4 == 0
+ * (V210: pitch % 16 == 0 and >= 32 * ceil(width / 12), which vc_get_linesize's 128-byte padding always satisfies; any
+ * width % 4 == 0 is taken, e.g. 1280 or 2048 -- the partial last 12-pixel unit of a line is read whole and encoded in part).
+ * These use UG_DXT_TIES_DEFAULT. */
 int ug_hip_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev, void *dst_dev,
                       int width, int height, int src_pitch, ug_hip_stream_t stream);
 /* Same, `frames` images per launch (tiles of one frame or consecutive frames):
@@ -119,6 +138,11 @@ int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev, v
                             int width, int height, int src_pitch, int frames,
                             size_t src_frame_stride, size_t dst_frame_stride,
                             ug_hip_stream_t stream);
+/* Same with the tie rule given explicitly (UG_DXT_TIES_*; anything else: UG_HIP_EINVAL). */
+int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev, void *dst_dev,
+                               int width, int height, int src_pitch, int frames,
+                               size_t src_frame_stride, size_t dst_frame_stride, int ties,
+                               ug_hip_stream_t stream);
 /* bytes produced for one image */
 size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height);
 
@@ -139,6 +163,10 @@ int ug_hip_yuv422_to_yuv444(const void *src, void *out, int pix_count, ug_hip_st
  * UYVY follows dxt_compress/rgba_to_yuv422.glsl.  width % 4 == 0, height % 4 == 0, dst_pitch 0 = packed. */
 int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
                       int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* Same with the tie rule given explicitly (UG_DXT_TIES_*): it decides the float -> unorm8 writes of the UYVY output pass and of the
+ * DXT1_YUV display matrix; the other outputs do not depend on it. */
+int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
+                         int dst_pitch, int rshift, int gshift, int bshift, int ties, ug_hip_stream_t stream);
 /* Device self-test: the decoders divide by the constants 255, 31, 63, 7, 5, 3 with a multiply + two fma (correctly rounded for
  * the numerators a DXT block can produce); this compares every such quotient with the IEEE division. *mismatches must be 0. */
 int ug_hip_selftest_dxt_decode(unsigned *mismatches, ug_hip_stream_t stream);
@@ -161,6 +189,12 @@ int ug_hip_pixfmt_best(ug_pixfmt_t in, const ug_pixfmt_t *candidates, ug_pixfmt_
 int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev,
                           int width, int height, int src_pitch, int dst_pitch,
                           int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* `frames` images per call, image i at src + i * src_frame_stride -> dst + i * dst_frame_stride.  When the frames follow each other
+ * exactly one picture apart on both sides (stride == pitch * height: tiles, frame rings) the batch is ONE launch -- a 4K frame is a
+ * 7-13 us launch, which cannot fill 256 CUs on its own; other layouts are converted frame by frame. */
+int ug_hip_pixfmt_convert_batch(ug_pixfmt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
+                                int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, int frames,
+                                size_t src_frame_stride, size_t dst_frame_stride, ug_hip_stream_t stream);
 /* The line converters pixfmt_conv.h:93-101 exports outside decoders[] (their callers reach them by name, e.g. video_capture/screen_x11.c:463,
  * decklink.cpp:1750), whole frame, line by line with the given dst_len (bytes to write per line) and pitches:
  *   "vc_copylineUYVYtoGrayscale" (:927-938), "vc_copylineABGRtoRGB" (:809-843), "vc_copylineBGRAtoRGB" (:845-857),
@@ -297,6 +331,14 @@ int ug_hip_uyvy_to_jpeg420_coeffs(const void *src_dev, int src_pitch, int width,
 int ug_hip_uyvy_to_jpeg422_coeffs(const void *src_dev, int src_pitch, int width, int height,
                                   const float *div_dev, int16_t *out_y, int16_t *out_cb,
                                   int16_t *out_cr, ug_hip_stream_t stream);
+
+/* Both of the above over `frames` images per launch (grid.z = image; tiles of a frame or consecutive frames): image i is read at
+ * src + i * src_frame_stride and its planes are written i * luma_frame_stride / i * chroma_frame_stride BYTES after out_y /
+ * out_cb, out_cr (multiples of 16).  subsampling = 420 or 422.  A 4K frame is a 13 us launch: batching is what fills the GPU. */
+int ug_hip_uyvy_to_jpeg42x_coeffs_batch(int subsampling, const void *src_dev, int src_pitch, int width, int height,
+                                        const float *div_dev, int16_t *out_y, int16_t *out_cb, int16_t *out_cr, int frames,
+                                        size_t src_frame_stride, size_t luma_frame_stride, size_t chroma_frame_stride,
+                                        ug_hip_stream_t stream);
 
 /* Complete baseline JPEG encoder (interleaved scan, restart intervals) = FDCT+quantise as above + Huffman coding (T.81
  * Annex K.3 tables) + headers.  Object shape of gpujpeg_encoder_create / _encode / _destroy

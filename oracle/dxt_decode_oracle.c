@@ -171,9 +171,10 @@ void oracle_dxt1yuv_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
  * operation one fp32 operation, texel fetch = v / 255.0f, output = floorf(clamp01(x) * 255 + 0.5)
  * (GL's unorm8 conversions are implementation-defined to that extent: parity unpinned).
  * ---------------------------------------------------------------------------------------------- */
-/* float -> unorm8 framebuffer write.  GL rounds to nearest and leaves exact .5 ties to the implementation: default here = half up;
- * oracle_set_unorm_ties_even(1) = ties to even, what Mesa llvmpipe does (pinning aid for tests/test_oracle_dxt.py) */
-static int g_unorm_ties_even = 0;
+/* float -> unorm8 framebuffer write.  GL rounds to nearest and leaves exact .5 ties to the implementation: default here = ties to
+ * even, what Mesa llvmpipe does when it runs rgba_to_yuv422.glsl (pinned byte for byte, tests/test_oracle_dxt.py);
+ * oracle_set_unorm_ties_even(0) / oracle_set_ties(1) = half up, floor(x * 255 + 0.5) */
+static int g_unorm_ties_even = 1;
 void oracle_set_unorm_ties_even(int on) { g_unorm_ties_even = on; }
 static inline uint8_t unorm8_out(float x)
 {

@@ -10,24 +10,24 @@
  * (test/misc_test.c:298 only round-trips the codec *name*) and its encoders are GLSL fragment shaders, so those very shaders
  * (dxt_compress/compress_dxt5ycocg_fp.glsl, compress_dxt1_fp.glsl, yuv422_to_yuv444.glsl, compress_vp.glsl, read from
  * /root/reference at run time) are executed on the CPU by Mesa llvmpipe through oracle/glsl_ref.c, with the GL call sequence of
- * dxt_compress/dxt_encoder.c.  With the two choices GLSL leaves to the implementation set the way Mesa makes them (round()
- * ties to even; dot(vec3) summed from the last component -- oracle_set_round_half_even / oracle_set_dot3_reverse) this
- * restatement reproduces EVERY block bit for bit: 212 992 blocks over S1-S4 x RGB / RGBA / UYVY x DXT5 / DXT1 / DXT1_YUV in the
- * build container, and the committed vectors tests/golden/dxt_glsl_ref.npz (tests/golden/make_glsl_golden.py) anywhere else.
- * The documented oracle (both knobs off) differs from the shaders-on-Mesa only in those implementation-defined cases (about
- * 0.3 % of uniform-random blocks: one endpoint LSB at an exact .5 tie, or one palette index at a distance near-tie) and there
- * follows the reference's CUDA port.  Further cross-checks: decoding with the restatement of the reference's CPU decoder
- * (cuda_dxt/dxt62tga.c, dxt_decode_oracle.c) and gating on PSNR, S3TC structural checks.  See DESIGN.md "Oracle".
+ * dxt_compress/dxt_encoder.c.  GLSL leaves two things these shaders use to the implementation: the direction of exact .5 ties of
+ * round() and the order in which dot(vec3) is summed.  With both set the way Mesa makes them (ties to even; summed from the last
+ * component) -- the DEFAULT here, "ties even", and the default of the product library (UG_DXT_TIES_EVEN) -- this restatement
+ * reproduces EVERY block bit for bit: 212 992 blocks over S1-S4 x RGB / RGBA / UYVY x DXT5 / DXT1 / DXT1_YUV in the build
+ * container, and the committed vectors tests/golden/dxt_glsl_ref.npz (tests/golden/make_glsl_golden.py) anywhere else.
+ * oracle_set_ties(1), "ties away" (UG_DXT_TIES_AWAY), follows the text of the reference's CUDA port instead (roundf, dot() left
+ * to right: cuda_dxt.cu:106-108,122-124), which cannot be executed here; it differs only in those implementation-defined cases
+ * (about 0.3 % of uniform-random blocks: one endpoint LSB at an exact .5 tie, or one palette index at a distance near-tie).
+ * Further cross-checks: decoding with the restatement of the reference's CPU decoder (cuda_dxt/dxt62tga.c,
+ * dxt_decode_oracle.c) and gating on PSNR, S3TC structural checks.  See DESIGN.md "Oracle".
  *
  * Normative choices:
  *   - every source-level operation of the shader is ONE IEEE-754 binary32 operation,
  *     rounded individually; no fused multiply-add (build: -ffp-contract=off);
  *   - input normalisation is  byte * 0.00392156862745f  (cuda_dxt/cuda_dxt.cu:666-683),
  *     the only form written out in the reference;
- *   - round() is roundf(): half away from zero, as the reference's CUDA port has it (cuda_dxt.cu:122-124, 284-285, 352).
- *     GLSL leaves the direction of exact .5 ties to the implementation; oracle_set_round_half_even(1) switches to ties-to-even,
- *     which is what Mesa llvmpipe does -- used only to pin this restatement against the reference's own shaders run there
- *     (oracle/glsl_ref.c, tests/test_oracle_dxt.py);
+ *   - round(): ties to even by default (what Mesa llvmpipe computes when it runs the shaders), roundf() half away from zero
+ *     under oracle_set_ties(1) (the CUDA port's text, cuda_dxt.cu:122-124, 284-285, 352); dot(vec3) likewise;
  *   - sub-expressions that cuda_dxt.cu evaluates in double because of un-suffixed
  *     literals (cuda_dxt.cu:143-145,178,184,364-372) are fp32 here, as in the GLSL
  *     (compress_dxt5ycocg_fp.glsl:29-31,82,88,266-274);
@@ -47,13 +47,20 @@
 typedef struct { float x, y, z; } v3;
 
 /* cuda_dxt.cu:666 / compress_*_fp.glsl unorm8 fetch (see header: D1) */
-/* GLSL round(): see the header comment */
-static int g_round_half_even = 0;
-static int g_dot3_reverse = 0;
+/* GLSL round() ties and dot(vec3) association: see the header comment.  Default = Mesa's choices (pinned to the executed shaders). */
+static int g_round_half_even = 1;
+static int g_dot3_reverse = 1;
 void oracle_set_round_half_even(int on) { g_round_half_even = on; }
-/* association of the three products of dot(vec3, vec3) in the DXT1 palette distances: GLSL does not define it; 0 (default) =
- * left to right as written in cuda_dxt.cu:106-108, 1 = (z*z + y*y) + x*x, Mesa's lowering -- pinning aid only */
+/* association of the three products of dot(vec3, vec3) in the DXT1 palette distances: 1 (default) = (z*z + y*y) + x*x, Mesa's
+ * lowering; 0 = left to right as written in cuda_dxt.cu:106-108 */
 void oracle_set_dot3_reverse(int on) { g_dot3_reverse = on; }
+/* both at once, plus the decode side's unorm8 ties: 0 = ties even (default, UG_DXT_TIES_EVEN), 1 = ties away (UG_DXT_TIES_AWAY) */
+void oracle_set_ties(int away)
+{
+        g_round_half_even = !away;
+        g_dot3_reverse = !away;
+        oracle_set_unorm_ties_even(!away);
+}
 static inline float glsl_round(float x) { return g_round_half_even ? rintf(x) : roundf(x); }
 
 static inline float unorm8(uint8_t p) { return (float) p * 0.00392156862745f; }

@@ -33,7 +33,11 @@ enum {
 void oracle_dxt5ycocg_encode_block(const float rgb[16][3], uint32_t out[4]);
 void oracle_dxt1_encode_block(const float rgb[16][3], uint32_t out[2]);
 /* h < 0: source read bottom-up. pitch = source line stride in bytes. 0 ok, -1 bad args */
-/* 0 (default): round() = roundf (CUDA port); 1: ties to even (Mesa llvmpipe's GLSL round) -- pinning aid only */
+/* GLSL's implementation-defined choices (round() ties, dot(vec3) order, unorm8 ties on the decode side):
+ * oracle_set_ties(0) = "ties even", Mesa's choices = the default, pinned to the reference's shaders executed on llvmpipe;
+ * oracle_set_ties(1) = "ties away", the text of the reference's CUDA port.  The three single knobs remain for the tests that
+ * take them apart. */
+void oracle_set_ties(int away);
 void oracle_set_round_half_even(int on);
 void oracle_set_dot3_reverse(int on);
 void oracle_set_unorm_ties_even(int on); /* decode side: float -> unorm8 ties (dxt_decode_oracle.c) */

@@ -130,8 +130,15 @@ def _ptr(a: np.ndarray):
 # ----------------------------------------------------------------------------------
 # DXT
 # ----------------------------------------------------------------------------------
+def set_ties(ties: str) -> None:
+    """GLSL's implementation-defined choices, all at once: "even" (default; Mesa llvmpipe's, pinned to the executed reference shaders:
+    round() ties to even, dot(vec3) from the last component, unorm8 writes tie to even) or "away" (the reference's CUDA text: roundf,
+    left-to-right dot, floor(x*255+0.5)).  Same meaning as UG_DXT_TIES_EVEN / UG_DXT_TIES_AWAY of the product library."""
+    lib().oracle_set_ties({"even": 0, "away": 1}[ties])
+
+
 def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch: int | None = None,
-               threads: int = 1) -> np.ndarray:
+               threads: int = 1, ties: str = "even") -> np.ndarray:
     """h < 0 => bottom-up source (cuda_dxt.cu:652-655).  threads != 1: OpenMP row bands (0 = all cores)."""
     src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
     if pitch is None:
@@ -139,6 +146,7 @@ def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch
                  IN_V210: (w + 47) // 48 * 128}[in_fmt]
     n = w * abs(h) // (2 if out_fmt == OUT_DXT1 else 1)
     out = np.zeros(n, dtype=np.uint8)
+    set_ties(ties)
     if threads == 1:
         rc = lib().oracle_dxt_encode(in_fmt, out_fmt, _ptr(src), _ptr(out), w, h, pitch)
     else:
@@ -163,28 +171,16 @@ def dxt_decode_rgb(out_fmt: int, blocks: np.ndarray, w: int, h: int) -> np.ndarr
     return out.reshape(h, w, 3)
 
 
-def dxt_decode(in_fmt: int, out_fmt: str, blocks: np.ndarray, w: int, h: int, shifts=(0, 8, 16)) -> np.ndarray:
+def dxt_decode(in_fmt: int, out_fmt: str, blocks: np.ndarray, w: int, h: int, shifts=(0, 8, 16), ties: str = "even") -> np.ndarray:
     """Frame decode to RGB / BGR / RGBA / UYVY (oracle/dxt_decode_oracle.c)."""
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8).ravel()
     pitch = linesize(w, out_fmt)
     out = np.zeros(pitch * h, np.uint8)
+    set_ties(ties)
     rc = lib().oracle_dxt_decode(in_fmt, OPF[out_fmt], _ptr(blocks), _ptr(out), w, h, pitch, *shifts)
     if rc:
         raise ValueError(f"oracle_dxt_decode rc={rc}")
     return out
-
-
-def set_round_half_even(on: bool) -> None:
-    """GLSL round() tie direction of the encoder restatement: False = roundf (default, the CUDA port), True = ties to even (llvmpipe)."""
-    lib().oracle_set_round_half_even(1 if on else 0)
-
-
-def set_mesa_variant(on: bool) -> None:
-    """Both implementation-defined choices as Mesa llvmpipe makes them: round() ties to even, dot(vec3) summed from the last component.
-    Only for pinning the restatement against the reference's shaders executed there; off = the documented oracle."""
-    lib().oracle_set_round_half_even(1 if on else 0)
-    lib().oracle_set_dot3_reverse(1 if on else 0)
-    lib().oracle_set_unorm_ties_even(1 if on else 0)
 
 
 GLSL_REF = os.path.join(_HERE, "_ref", "glsl_ref")

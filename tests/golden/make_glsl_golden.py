@@ -8,7 +8,7 @@ Run in the build container (needs /root/reference and Mesa's swrast_dri.so):
 
 These vectors PIN oracle/dxt_oracle.c to the reference implementation itself: tests/test_oracle_dxt.py requires the restatement --
 with the two choices GLSL leaves to the implementation set the way Mesa makes them (round() ties to even, dot(vec3) summed from the
-last component; pyoracle.set_mesa_variant) -- to reproduce every block bit for bit, on any machine.
+last component; the oracle's default mode, "ties even") -- to reproduce every block bit for bit, on any machine.
 """
 import os
 import sys

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     l = lib.load()  # raises if the .so or a symbol is missing
     for name in _declared():
         assert getattr(l, name) is not None
-    assert l.ug_hip_abi_version() == 1
+    assert l.ug_hip_abi_version() == 2
 
 
 def test_no_torch_or_cxx_types_in_the_abi():
@@ -39,7 +39,7 @@ def test_error_paths_without_a_gpu():
     assert l.ug_hip_dxt_encode(lib.PF_RGB, lib.DXT1, 8, 16, 16, 4, 0, None) == lib.EINVAL        # src alignment
     assert l.ug_hip_dxt_encode(lib.PF_RGB, lib.DXT1, None, 16, 16, 4, 0, None) == lib.EINVAL     # NULL
     assert l.ug_hip_dxt_encode(lib.PF_RG48, lib.DXT1, 16, 16, 16, 4, 0, None) == lib.EUNSUPP
-    assert l.ug_hip_dxt_encode(lib.PF_V210, lib.DXT1, 16, 16, 16, 4, 0, None) == lib.EINVAL      # v210 needs w % 12
+    assert l.ug_hip_dxt_encode(lib.PF_V210, lib.DXT1, 16, 16, 16, 4, 40, None) == lib.EINVAL     # v210 pitch % 16
     assert l.ug_hip_pixfmt_convert(lib.PF_RGB, lib.PF_V210, 16, 16, 8, 8, 0, 0, 0, 8, 16, None) == lib.EUNSUPP
     assert b"unsupported" in l.ug_hip_last_error_string()
     assert l.ug_hip_pixfmt_supported(lib.PF_V210, lib.PF_UYVY) == 1 and l.ug_hip_pixfmt_supported(lib.PF_RGB, lib.PF_V210) == 0

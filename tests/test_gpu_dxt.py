@@ -23,26 +23,31 @@ def _ids(po, L):
 
 def _src(kind, fmt, w, h, salt=0):
     base = {"YUV444": "RGB", "UYVY_RAW": "UYVY"}.get(fmt, fmt)
+    if base == "v210" and w % 6 and kind in ("S2", "S3"):   # the smooth generators write whole 6-pixel groups
+        return synth.s1_random("v210", w, h, salt + len(kind))
     return synth.frame(kind, base, w, h, salt) if kind != "S3" or base in ("UYVY", "RGB") else synth.frame("S2", base, w, h, salt)
 
 
-def _run(hip, po, fmt, out, src, w, h):
+def _run(hip, po, fmt, out, src, w, h, ties="even", threads=1):
+    """ties = "even": the library DEFAULT (plain ug_hip_dxt_encode) vs the oracle's default; "away": the explicit option on both sides"""
     import torch
     from ultragrid_amd import lib as L
     pin, lin = _ids(po, L)
     oid_p, oid_l = (po.OUT_DXT1, L.DXT1) if out == "dxt1" else (po.OUT_DXT5YCOCG, L.DXT5_YCOCG)
-    got = hip.dxt_encode(lin[fmt], oid_l, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
-    want = po.dxt_encode(pin[fmt], oid_p, src, w, h)
+    got = hip.dxt_encode(lin[fmt], oid_l, torch.from_numpy(src).cuda(), w, h, ties=None if ties == "even" else L.TIES_AWAY).cpu().numpy()
+    want = po.dxt_encode(pin[fmt], oid_p, src, w, h, ties=ties, threads=threads)
     return got, want
 
 
+@pytest.mark.parametrize("ties", ["even", "away"])
 @pytest.mark.parametrize("out", OUTS)
 @pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("kind", ["S1", "S2", "S3", "S4"])
-def test_bit_exact_small(hip, po, fmt, out, kind):
-    for (w, h) in [(48, 16), (192, 64), (1920, 36)] if fmt == "v210" else [(4, 4), (8, 8), (48, 16), (200, 64), (1920, 36)]:
+def test_bit_exact_small(hip, po, fmt, out, kind, ties):
+    # v210: widths that are not multiples of 12 (partial last unit of a line: 1280x720, 2048x1080 class) included
+    for (w, h) in [(48, 16), (192, 64), (1920, 36), (4, 4), (8, 8), (52, 8), (200, 16), (1280, 8), (2048, 4)] if fmt == "v210" else [(4, 4), (8, 8), (48, 16), (200, 64), (1920, 36)]:
         src = _src(kind, fmt, w, h, salt=w)
-        got, want = _run(hip, po, fmt, out, src, w, h)
+        got, want = _run(hip, po, fmt, out, src, w, h, ties)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, f"{fmt}->{out} {kind} {w}x{h}: {bad.size} bytes differ, first block {bad[0] // (8 if out == 'dxt1' else 16)}"
 
@@ -66,7 +71,8 @@ def test_committed_golden(hip, po):
         tag, kind, name, oname = k.split("_")
         src = GOLD[f"in_{kind}_{name}"]
         h = -16 if tag == "outm" else 16
-        got = hip.dxt_encode(lin[name], L.DXT1 if oname == "dxt1" else L.DXT5_YCOCG, torch.from_numpy(src).cuda(), 48, h)
+        got = hip.dxt_encode(lin[name], L.DXT1 if oname == "dxt1" else L.DXT5_YCOCG, torch.from_numpy(src).cuda(), 48, h,
+                             ties=L.TIES_AWAY if tag == "outa" else None)
         assert np.array_equal(got.cpu().numpy(), GOLD[k]), k
 
 
@@ -80,10 +86,9 @@ def test_baseline_configs_full_size(hip, po, cfg):
     assert np.array_equal(got, want)
 
 
-def test_8k_v210_properties(hip, po):
-    """configs[4] at 7680x4320: the oracle would take ~1 min on this frame, so check size-independent
-    properties: (1) a random sample of block rows equals the oracle on those rows, (2) v210 == (v210->UYVY
-    on the GPU) -> UYVY encoder, (3) batch == per-frame, (4) mirror == encode of the flipped frame."""
+def test_8k_v210_full_frame(hip, po):
+    """configs[4] at 7680x4320, the WHOLE frame against the oracle (run on all host cores by row bands), plus the size-independent
+    properties: v210 == (v210->UYVY on the GPU) -> UYVY encoder, batch == per-frame, mirror == encode of the flipped frame."""
     import torch
     from ultragrid_amd import lib as L
     w, h = 7680, 4320
@@ -91,15 +96,13 @@ def test_8k_v210_properties(hip, po):
     reps = h // 48
     frame = np.tile(one.reshape(48, -1), (reps, 1))
     rng = np.random.default_rng(9)
-    frame[:, :64] ^= rng.integers(0, 256, (h, 64), dtype=np.uint8) & 0x3F  # de-periodise a little (keeps pad bits 0: mask <= 0x3f on byte 0..)
-    frame = (frame.view(np.uint32) & 0x3FFFFFFF).view(np.uint8).ravel()
+    frame[:, :4096] ^= rng.integers(0, 256, (h, 4096), dtype=np.uint8)  # de-periodise: every block row differs
+    frame = (frame.view(np.uint32) & 0x3FFFFFFF).view(np.uint8).ravel()  # pad bits 0
     dev = torch.from_numpy(frame).cuda()
     full = hip.dxt_encode(L.PF_V210, L.DXT5_YCOCG, dev, w, h)
+    want = po.dxt_encode(po.IN_V210, po.OUT_DXT5YCOCG, frame, w, h, threads=0)
+    assert np.array_equal(full.cpu().numpy(), want)
     pitch = 20480
-    for by in rng.integers(0, h // 4, 6):
-        rows = frame.reshape(h, pitch)[4 * by: 4 * by + 4]
-        want = po.dxt_encode(po.IN_V210, po.OUT_DXT5YCOCG, rows, w, 4)
-        assert np.array_equal(full[by * (w // 4) * 16: (by + 1) * (w // 4) * 16].cpu().numpy(), want)
     uyvy = hip.pixfmt_convert(L.PF_V210, L.PF_UYVY, dev, w, h)
     assert torch.equal(hip.dxt_encode(L.PF_UYVY, L.DXT5_YCOCG, uyvy, w, h), full)
     two = torch.cat([dev, dev.flip(0).contiguous()])
@@ -107,6 +110,25 @@ def test_8k_v210_properties(hip, po):
     assert torch.equal(b[: full.numel()], full)
     flipped = torch.from_numpy(np.ascontiguousarray(frame.reshape(h, pitch)[::-1])).cuda().ravel()
     assert torch.equal(hip.dxt_encode(L.PF_V210, L.DXT5_YCOCG, dev, w, -h), hip.dxt_encode(L.PF_V210, L.DXT5_YCOCG, flipped, w, h))
+
+
+@pytest.mark.parametrize("size", [(1280, 720), (2048, 1080)])
+def test_v210_widths_not_divisible_by_12(hip, po, size):
+    """1280x720 and 2048x1080 v210 (the reference takes them: vc_copylinev210 with its partial-group tail, pixfmt_conv.c:121-130, then the
+    width % 4 encoder, cuda_dxt.cpp:206-220, cuda_dxt.cu:745): fused kernel == oracle == (compiled-reference-style v210->UYVY) -> UYVY
+    encoder, random 10-bit content."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = size
+    src = synth.s1_random("v210", w, h, salt=w)
+    dev = torch.from_numpy(src).cuda()
+    as_uyvy = po.convert_frame("v210", "UYVY", src, w, h)
+    for out_l, out_p in ((L.DXT5_YCOCG, po.OUT_DXT5YCOCG), (L.DXT1, po.OUT_DXT1)):
+        got = hip.dxt_encode(L.PF_V210, out_l, dev, w, h).cpu().numpy()
+        assert np.array_equal(got, po.dxt_encode(po.IN_UYVY, out_p, as_uyvy, w, h, threads=0))
+        assert np.array_equal(got, po.dxt_encode(po.IN_V210, out_p, src, w, h, threads=0))
+        got_m = hip.dxt_encode(L.PF_V210, out_l, dev, w, -h).cpu().numpy()
+        assert np.array_equal(got_m, po.dxt_encode(po.IN_V210, out_p, src, w, -h, threads=0))
 
 
 def test_cuda_dxt_h_shaped_entry_points(hip, po):
@@ -237,16 +259,17 @@ def test_concurrent_streams_threads(hip, po):
         assert np.array_equal(outs[i], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, srcs[i], w, h)), i
 
 
-def test_hip_encoders_vs_the_reference_glsl_shaders(hip, po):
-    """The HIP kernels against the reference's own GLSL encoders run on Mesa llvmpipe (tests/golden/dxt_glsl_ref.npz): identical
-    blocks except the handful where GLSL leaves the result to the implementation (an exact .5 tie of round(), the summation order of
-    dot(vec3)) -- there the product follows the reference's CUDA port (roundf, left to right), i.e. equals the documented oracle."""
+def test_shipped_library_reproduces_the_reference_glsl_shaders(hip, po):
+    """THE PIN.  The product library in its default mode against the reference's own GLSL encoders run on Mesa llvmpipe
+    (tests/golden/dxt_glsl_ref.npz, generated by executing compress_dxt5ycocg_fp.glsl / compress_dxt1_fp.glsl / yuv422_to_yuv444.glsl):
+    EVERY block identical, the 4096-block uniform-random frames included.  In "ties away" mode (the CUDA text's roundf / left-to-right
+    dot) the library equals the oracle's same mode and differs from the executed shaders only in a few tie blocks."""
     import os
     import torch
     from ultragrid_amd import lib as L
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "dxt_glsl_ref.npz"))
     w, h = (int(x) for x in gold["size"])
-    total = same = 0
+    total = same_away = n = 0
     for key in gold.files:
         if not key.startswith("out_"):
             continue
@@ -254,53 +277,35 @@ def test_hip_encoders_vs_the_reference_glsl_shaders(hip, po):
         src = gold[f"in_{kind}_{fmt}"]
         in_l = L.PF_UYVY_RAW if mode == "dxt1yuv" else L.PF_NAMES[fmt]
         out_l = L.DXT5_YCOCG if mode == "dxt5" else L.DXT1
-        got = hip.dxt_encode(in_l, out_l, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
-        pin = po.IN_UYVY_RAW if mode == "dxt1yuv" else {"RGB": po.IN_RGB, "RGBA": po.IN_RGBA, "UYVY": po.IN_UYVY}[fmt]
-        assert np.array_equal(got, po.dxt_encode(pin, po.OUT_DXT5YCOCG if mode == "dxt5" else po.OUT_DXT1, src, w, h)), key
-        bs = 16 if mode == "dxt5" else 8
-        eq = (got.reshape(-1, bs) == gold[key].reshape(-1, bs)).all(axis=1)
-        total += eq.size
-        same += int(eq.sum())
-    assert total > 7000 and same / total > 0.97, (same, total)   # S3 (flat colour bars) sits on round() ties in every white block
-
-
-def test_mesa_ties_build_equals_the_reference_glsl_shaders():
-    """The same kernels built with GLSL's two implementation-defined choices taken the way Mesa makes them
-    (-DUG_DXT_GLSL_MESA_TIES: round() ties to even, dot(vec3) summed from the last component) reproduce the reference's own
-    shaders -- executed by llvmpipe, tests/golden/dxt_glsl_ref.npz -- on EVERY block, big uniform-random frames included."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    alt = os.path.join(root, "ultragrid_amd", "libug_mi355x_mesaties.so")
-    if not os.path.exists(alt):
-        pytest.skip("mesaties test build missing (run __graft_entry__.build())")
-    code = r'''
-import os, sys, numpy as np, torch
-sys.path.insert(0, %r)
-from ultragrid_amd import codec, lib, synth
-assert "mesaties" in lib.LIB_PATH
-gold = np.load(os.path.join(%r, "tests", "golden", "dxt_glsl_ref.npz"))
-w, h = (int(x) for x in gold["size"])
-n = 0
-for key in gold.files:
-    if key.startswith("out_"):
-        _, kind, fmt, mode = key.split("_")
-        src = gold["in_%%s_%%s" %% (kind, fmt)]
-        in_l = lib.PF_UYVY_RAW if mode == "dxt1yuv" else lib.PF_NAMES[fmt]
-        got = codec.dxt_encode(in_l, lib.DXT5_YCOCG if mode == "dxt5" else lib.DXT1, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
+        dev = torch.from_numpy(src).cuda()
+        got = hip.dxt_encode(in_l, out_l, dev, w, h).cpu().numpy()            # plain ug_hip_dxt_encode: the default
         assert np.array_equal(got, gold[key]), key
+        assert np.array_equal(hip.dxt_encode(in_l, out_l, dev, w, h, ties=L.TIES_EVEN).cpu().numpy(), gold[key]), key
         n += got.size
-for fmt in ("RGB", "UYVY"):
-    src = synth.s1_random(fmt, 512, 128, salt=77)
-    for mode in ("dxt5", "dxt1"):
-        got = codec.dxt_encode(lib.PF_NAMES[fmt], lib.DXT5_YCOCG if mode == "dxt5" else lib.DXT1, torch.from_numpy(src).cuda(), 512, 128).cpu().numpy()
-        assert np.array_equal(got, gold["big_%%s_%%s" %% (fmt, mode)]), (fmt, mode)
-        n += got.size
-print("OK", n)
-''' % (root, root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UG_MI355X_LIB=alt), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+        away = hip.dxt_encode(in_l, out_l, dev, w, h, ties=L.TIES_AWAY).cpu().numpy()
+        pin = po.IN_UYVY_RAW if mode == "dxt1yuv" else {"RGB": po.IN_RGB, "RGBA": po.IN_RGBA, "UYVY": po.IN_UYVY}[fmt]
+        assert np.array_equal(away, po.dxt_encode(pin, po.OUT_DXT5YCOCG if mode == "dxt5" else po.OUT_DXT1, src, w, h, ties="away")), key
+        bs = 16 if mode == "dxt5" else 8
+        eq = (away.reshape(-1, bs) == gold[key].reshape(-1, bs)).all(axis=1)
+        total += eq.size
+        same_away += int(eq.sum())
+    for fmt in ("RGB", "UYVY"):
+        src = synth.s1_random(fmt, 512, 128, salt=77)
+        for mode in ("dxt5", "dxt1"):
+            got = hip.dxt_encode(L.PF_NAMES[fmt], L.DXT5_YCOCG if mode == "dxt5" else L.DXT1, torch.from_numpy(src).cuda(), 512, 128).cpu().numpy()
+            assert np.array_equal(got, gold["big_%s_%s" % (fmt, mode)]), (fmt, mode)
+            n += got.size
+    assert n > 1_000_000
+    assert total > 7000 and 0.97 < same_away / total < 1.0, (same_away, total)   # S3 (flat colour bars) sits on round() ties in every white block
+
+
+def test_unknown_tie_rule_is_rejected(hip):
+    import torch
+    from ultragrid_amd import lib as L
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(L.UgHipError) as e:
+        hip.dxt_encode(L.PF_RGB, L.DXT1, buf, 16, 4, ties=7)
+    assert e.value.rc == L.EINVAL
 
 
 def test_encoder_strength_reductions_are_ieee_exact(hip):

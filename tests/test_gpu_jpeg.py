@@ -305,3 +305,37 @@ def test_jpeg_small_output_buffer_reports_needed_size(hip, po):
     assert l.ug_hip_jpeg_encoder_encode(enc, L.PF_UYVY, uyvy.data_ptr(), 0, exact.data_ptr(), need, C.byref(n2), st) == 0
     assert bytes(exact.cpu().numpy()) == ref
     l.ug_hip_jpeg_encoder_destroy(enc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub", [420, 422])
+@pytest.mark.parametrize("dims", [(256, 64), (200, 50)])   # MCU-aligned fast path and the generic edge path
+def test_batched_front_end_equals_per_frame(hip, po, sub, dims):
+    """ug_hip_uyvy_to_jpeg42x_coeffs_batch (grid.z = frame): every frame of the batch == the single-frame entry point == the oracle."""
+    import torch
+    from ultragrid_amd import lib as L, synth
+    w, h = dims
+    n = 5
+    frames = [synth.s2_video("UYVY", w, h, salt=i) for i in range(n)]
+    fb = (frames[0].size + 15) // 16 * 16
+    src = torch.zeros(n * fb, dtype=torch.uint8, device="cuda")
+    for i, f in enumerate(frames):
+        src[i * fb: i * fb + f.size] = torch.from_numpy(f).cuda()
+    div = hip.jpeg_divisors_device(75, "cuda")
+    mw = (w + 15) // 16
+    mh, ybl = ((h + 15) // 16, 4) if sub == 420 else ((h + 7) // 8, 2)
+    nb = mw * mh
+    oy = torch.zeros((n, ybl * nb, 64), dtype=torch.int16, device="cuda")
+    ocb, ocr = torch.zeros((n, nb, 64), dtype=torch.int16, device="cuda"), torch.zeros((n, nb, 64), dtype=torch.int16, device="cuda")
+    rc = L.load().ug_hip_uyvy_to_jpeg42x_coeffs_batch(sub, src.data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), n, fb,
+                                                      ybl * nb * 128, nb * 128, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.last_error()
+    for i, f in enumerate(frames):
+        sy, scb, scr = hip.uyvy_to_jpeg_coeffs(torch.from_numpy(f).cuda(), w, h, div, sub)
+        assert torch.equal(oy[i], sy) and torch.equal(ocb[i], scb) and torch.equal(ocr[i], scr), i
+    y, u, v = po.uyvy_to_i420(frames[2], w, h) if sub == 420 else po.uyvy_to_i422(frames[2], w, h)
+    ql, qc = po.jpeg_qtable(75, 0), po.jpeg_qtable(75, 1)
+    assert np.array_equal(oy[2].cpu().numpy(), po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, (2 if sub == 420 else 1) * mh))
+    assert np.array_equal(ocb[2].cpu().numpy(), po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh))
+    assert L.load().ug_hip_uyvy_to_jpeg42x_coeffs_batch(411, src.data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), n, fb,
+                                                        ybl * nb * 128, nb * 128, None) == L.EINVAL

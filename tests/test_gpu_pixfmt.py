@@ -101,3 +101,42 @@ def test_planar(hip, po):
     y, uv = hip.v210_to_p010le(torch.from_numpy(src).cuda(), 1920, 8)
     wy, wuv = po.v210_to_p010le(src, 1920, 8)
     assert np.array_equal(y.cpu().numpy().view(np.uint16), wy) and np.array_equal(uv.cpu().numpy().view(np.uint16), wuv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", [("v210", "UYVY"), ("UYVY", "RGB"), ("RGB", "UYVY"), ("R10k", "RGB"), ("UYVY", "RGBA")])
+def test_batch_equals_per_frame(hip, po, pair):
+    """ug_hip_pixfmt_convert_batch: frames one picture apart (a single launch over frames * height lines) and frames at a padded stride
+    (frame-by-frame launches) both equal the single-frame conversions."""
+    import torch
+    from ultragrid_amd import lib as L
+    i, o = pair
+    l = L.load()
+    w, h, n = 96, 6, 4
+    sls, dls = l.ug_hip_linesize(L.PF_NAMES[i], w), l.ug_hip_linesize(L.PF_NAMES[o], w)
+    rng = np.random.default_rng(11)
+    for pad in (0, 64):
+        sfs, dfs = sls * h + pad, dls * h + pad
+        src = torch.from_numpy(rng.integers(0, 256, n * sfs + 64, dtype=np.uint8)).cuda()
+        dst = torch.zeros(n * dfs, dtype=torch.uint8, device="cuda")
+        rc = l.ug_hip_pixfmt_convert_batch(L.PF_NAMES[i], L.PF_NAMES[o], src.data_ptr(), dst.data_ptr(), w, h, 0, 0, 0, 8, 16, n, sfs, dfs, None)
+        assert rc == 0, L.last_error()
+        torch.cuda.synchronize()
+        for f in range(n):
+            one = torch.zeros(dls * h, dtype=torch.uint8, device="cuda")
+            assert l.ug_hip_pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], src[f * sfs:].data_ptr(), one.data_ptr(), w, h, 0, 0, 0, 8, 16, None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(dst[f * dfs: f * dfs + dls * h], one), (pair, pad, f)
+
+
+@pytest.mark.gpu
+def test_convert_rejects_wild_shifts_and_short_pitches(hip):
+    import torch
+    from ultragrid_amd import lib as L
+    l = L.load()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    assert l.ug_hip_pixfmt_convert(L.PF_RGB, L.PF_RGBA, buf.data_ptr(), buf[32768:].data_ptr(), 16, 4, 0, 0, 32, 8, 16, None) == L.EINVAL
+    assert l.ug_hip_pixfmt_convert(L.PF_RGB, L.PF_RGBA, buf.data_ptr(), buf[32768:].data_ptr(), 16, 4, 0, 0, 0, 8, -1, None) == L.EINVAL
+    assert l.ug_hip_pixfmt_convert(L.PF_RGB, L.PF_RGBA, buf.data_ptr(), buf[32768:].data_ptr(), 16, 4, 0, 60, 0, 8, 16, None) == L.EINVAL   # dst pitch < 64
+    assert l.ug_hip_pixfmt_convert(L.PF_RGB, L.PF_RGBA, buf.data_ptr(), buf[32768:].data_ptr(), 16, 4, 40, 0, 0, 8, 16, None) == L.EINVAL   # src pitch < 48
+    assert l.ug_hip_pixfmt_convert(L.PF_RGB, L.PF_RGBA, buf.data_ptr(), buf[32768:].data_ptr(), 16, 4, 48, 64, 0, 8, 16, None) == 0

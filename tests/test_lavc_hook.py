@@ -70,3 +70,58 @@ def test_reference_from_lavc_runs_on_the_gpu(hip, capfd, monkeypatch, uv):
         r.av_frame_free(C.byref(frp))
         assert np.array_equal(dst[: pitch * h_].reshape(h_, pitch), want), (uv, w, h_, cs, rng_)
     assert f"from_lavc {av} -> {uv} on the device" in capfd.readouterr().err
+
+
+@pytest.mark.gpu
+def test_hook_declines_geometry_the_device_row_cannot_take(hip, capfd, monkeypatch):
+    """v210 -> p010le on the device needs width % 6 == 0 and an even height; the reference's CPU function takes any size.
+    At 1280x720 (1280 % 6 == 2) the hook's init must DECLINE (NULL), so that the reference sets up its own CPU conversion
+    (to_lavc_vid_conv.c:1901-1906) and every frame still arrives -- equal to the plain CPU build -- instead of every
+    to_lavc_vid_conv_cuda() call returning NULL and all frames being lost."""
+    monkeypatch.setenv("UG_MI355X_VERBOSE", "1")
+    h, r = hook_lib(), T.ref()
+    uv, av = "v210", "p010le"
+    if not hip.L.load().ug_hip_uv_to_av_supported(uv.encode(), av.encode()):
+        pytest.skip("row not in the table")
+    for (w, h_), on_device in (((1280, 720), False), ((1920, 8), True), ((50, 6), False), ((48, 7), False)):
+        ls = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
+        src = (np.random.default_rng(w).integers(0, 256, ls * h_ + 64).astype(np.uint8).view(np.uint32) & 0x3FFFFFFF).view(np.uint8)
+        want = T.ref_uv_to_av(uv, av, src, w, h_)
+        st = h.to_lavc_vid_conv_init(h.get_codec_from_name(uv.encode()), w, h_, h.ug_stub_pixfmt_by_name(av.encode()), 1)
+        assert st
+        fr = h.to_lavc_vid_conv(st, src.ctypes.data)
+        assert fr, "no frame: the hook initialised for a geometry it cannot convert"
+        got = [p.copy() for p in T.plane_arrays(h, fr.contents, h_)]
+        stp = C.c_void_p(st)
+        h.to_lavc_vid_conv_destroy(C.byref(stp))
+        err = capfd.readouterr().err
+        assert (f"to_lavc {uv} -> {av} on the device" in err) == on_device, (w, h_, err)
+        if not on_device:
+            assert "left to the CPU path" in err
+        for k, (g, wnt) in enumerate(zip(got, want)):
+            assert np.array_equal(g, wnt), (w, h_, k)
+
+
+@pytest.mark.gpu
+def test_from_lavc_hook_with_a_display_pitch_touches_only_the_lines(hip):
+    """ADVICE r1: with pitch > linesize the caller's buffer may end right after the last LINE (pitch * (height - 1) + linesize bytes);
+    the hook must not read or write the pitch - linesize bytes behind it."""
+    h, r = hook_lib(), T.ref()
+    av, uv, w, h_ = "yuv422p", "UYVY", 48, 8
+    frp = T.make_frame(r, av, w, h_, 7, 1, 1)
+    ls = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
+    pitch = ls + 160
+    want = T.ref_av_to_uv(frp, av, uv, w, h_, ls, (0, 8, 16))
+    conv = h.get_av_to_uv_conversion(h.ug_stub_pixfmt_by_name(av.encode()), h.get_codec_from_name(uv.encode()))
+    assert conv
+    exact = pitch * (h_ - 1) + ls
+    dst = np.full(exact + 4096, 0xA5, np.uint8)   # guard zone behind the exact-size buffer
+    h.av_to_uv_convert(conv, dst.ctypes.data, frp, pitch, (C.c_int * 3)(0, 8, 16))
+    cp = C.c_void_p(conv)
+    h.av_to_uv_conversion_destroy(C.byref(cp))
+    r.av_frame_free(C.byref(frp))
+    assert (dst[exact:] == 0xA5).all(), "bytes behind the last line were written"
+    lines = np.stack([dst[y * pitch: y * pitch + ls] for y in range(h_)])
+    assert np.array_equal(lines, want.reshape(h_, ls))
+    gaps = np.stack([dst[y * pitch + ls: (y + 1) * pitch] for y in range(h_ - 1)])
+    assert (gaps == 0xA5).all()

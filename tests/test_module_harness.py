@@ -143,13 +143,116 @@ def test_tiled_4k_fanout(tmp_path, po):
         assert np.array_equal(got[t], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frames[t], w, h)), t
 
 
+def _ref_best_and_decode(po, codec, candidates, src, w, h):
+    """What the reference's compress modules do on the CPU before upload (cuda_dxt.cpp:152-158,206-220): get_best_decoder_from(codec,
+    candidates) of the COMPILED reference picks the target codec, its line decoder converts line by line (dst_len =
+    vc_get_linesize(width, target), shifts 0/8/16).  Returns (target name, converted frame)."""
+    import ctypes as C
+    r = po.ref()
+    r.get_codec_from_name.argtypes = [C.c_char_p]
+    r.get_codec_name.restype = C.c_char_p
+    r.get_best_decoder_from.restype = C.c_void_p
+    r.get_best_decoder_from.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    ci = r.get_codec_from_name(codec.encode())
+    cand = (C.c_int * (len(candidates) + 1))(*[r.get_codec_from_name(c.encode()) for c in candidates], 0)
+    out = C.c_int(0)
+    fn = r.get_best_decoder_from(ci, cand, C.byref(out))
+    if not fn:
+        return None, None
+    sls, dls = r.vc_get_linesize(w, ci), r.vc_get_linesize(w, out.value)
+    pad = np.concatenate([np.ascontiguousarray(src, np.uint8).ravel(), np.zeros(64, np.uint8)])
+    dst = np.zeros(dls * h + 64, np.uint8)
+    dec = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)(fn)
+    for y in range(h):
+        dec(dst.ctypes.data + y * dls, pad.ctypes.data + y * sls, dls, 0, 8, 16)
+    return r.get_codec_name(out.value).decode(), dst[: dls * h]
+
+
+def _random_frame(po, codec, w, h, salt):
+    import ctypes as C
+    r = po.ref()
+    r.get_codec_from_name.argtypes = [C.c_char_p]
+    n = r.vc_get_linesize(w, r.get_codec_from_name(codec.encode())) * h
+    buf = np.random.default_rng(1000 + salt).integers(0, 256, n, dtype=np.uint8)
+    if codec in ("v210", "DVS10"):
+        buf = (buf.view(np.uint32) & 0x3FFFFFFF).view(np.uint8)
+    return buf
+
+
 @needs_harness
 @pytest.mark.gpu
-def test_unsupported_input_is_refused_not_faked(tmp_path):
+@pytest.mark.parametrize("codec,w,h", [("R10k", 192, 64), ("R12L", 192, 64), ("RG48", 192, 64), ("Y216", 192, 64), ("Y416", 192, 64),
+                                       ("VUYA", 192, 64), ("DVS10", 192, 64), ("R12L", 200, 8), ("Y216", 100, 12), ("R10k", 52, 4),
+                                       ("v210", 1280, 720), ("v210", 2048, 1080), ("v210", 52, 8), ("RGBA", 200, 16), ("BGR", 100, 8)])
+@pytest.mark.parametrize("cfg", ["dxt:DXT5", "dxt:DXT1"])
+def test_every_codec_the_reference_module_takes(tmp_path, po, codec, w, h, cfg):
+    """`-c dxt` takes whatever cuda_dxt.cpp takes -- every codec with a decoder to RGB or UYVY
+    (get_best_decoder_from, cuda_dxt.cpp:152-158, pixfmt_conv.c:3126-3172), v210 at widths that are not multiples of 12 included
+    (1280x720, 2048x1080) -- and its output is bit-equal to the reference's own sequence: the COMPILED reference's choice of target
+    codec and its line decoder, then the DXT oracle on the result."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libugref.so not built")
+    src = _random_frame(po, codec, w, h, salt=w + h)
+    target, conv = _ref_best_and_decode(po, codec, ["RGB", "UYVY"], src, w, h)
+    assert target in ("RGB", "UYVY"), target
+    raw, out = tmp_path / "in.raw", tmp_path / "out.bin"
+    src.tofile(raw)
+    r = subprocess.run([HARNESS, cfg, codec, str(w), str(h), str(raw), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    oid = po.OUT_DXT5YCOCG if cfg.endswith("DXT5") else po.OUT_DXT1
+    want = po.dxt_encode(po.IN_RGB if target == "RGB" else po.IN_UYVY, oid, conv, w, h, threads=0)
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec", ["Y216", "R10k", "v210"])
+def test_dxt1_yuv_from_wide_codecs(tmp_path, po, codec):
+    """-c dxt:DXT1_YUV: UYVY is the only encoder input (dxt_glsl.cpp:104-110); every other codec goes through its decoder to UYVY."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libugref.so not built")
+    w, h = 200, 16
+    src = _random_frame(po, codec, w, h, salt=3)
+    target, conv = _ref_best_and_decode(po, codec, ["UYVY"], src, w, h)
+    assert target == "UYVY"
+    raw, out = tmp_path / "in.raw", tmp_path / "out.bin"
+    src.tofile(raw)
+    r = _run(["dxt:DXT1_YUV", codec, w, h, raw, out])
+    assert r.returncode == 0 and "DXT1_YUV" in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(out, np.uint8), po.dxt_encode(po.IN_UYVY_RAW, po.OUT_DXT1, conv, w, h))
+
+
+@needs_harness
+@pytest.mark.gpu
+def test_tie_rule_option(tmp_path, po):
+    """ties=even (default) / ties=away select UG_DXT_TIES_*: the S3 colour bars sit on round() ties in every white block."""
+    w, h = 192, 64
+    src = synth.s3_bars("UYVY", w, h)
     raw = tmp_path / "in.raw"
-    np.zeros(64 * 16 * 6, np.uint8).tofile(raw)
-    r = _run(["dxt:DXT5", "RG48", 64, 16, raw, tmp_path / "o.bin"])
-    assert r.returncode == 3 and "Unsupported codec" in (r.stdout + r.stderr)  # frame dropped, no CPU fallback
+    src.tofile(raw)
+    outs = {}
+    for opt, ties in (("", "even"), (":ties=even", "even"), (":ties=away", "away")):
+        out = tmp_path / f"o{len(outs)}.bin"
+        r = _run(["dxt:DXT5" + opt, "UYVY", w, h, raw, out])
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[opt] = out.read_bytes()
+        assert outs[opt] == po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, src, w, h, ties=ties).tobytes(), opt
+    assert outs[""] != outs[":ties=away"]
+    assert _run(["dxt:ties=sometimes", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 2
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec,nbytes", [("I420", 64 * 16 * 3 // 2), ("DXT1", 64 * 16 // 2), ("H.264", 64 * 16)])
+def test_only_what_the_reference_refuses_is_refused(tmp_path, po, codec, nbytes):
+    """Planar and compressed codecs have no decoder to RGB / UYVY: get_best_decoder_from() returns NULL in the reference, which prints
+    "Unsupported codec" and drops the frame (cuda_dxt.cpp:154-158) -- same here, and nothing is faked on the CPU."""
+    if po.have_ref():
+        assert _ref_best_and_decode(po, codec, ["RGB", "UYVY"], np.zeros(nbytes, np.uint8), 64, 16)[0] is None
+    raw = tmp_path / "in.raw"
+    np.zeros(max(nbytes, 64 * 16 * 4), np.uint8).tofile(raw)
+    r = _run(["dxt:DXT5", codec, 64, 16, raw, tmp_path / "o.bin"])
+    assert r.returncode in (1, 3) and (r.returncode == 1 or "Unsupported codec" in (r.stdout + r.stderr)), r.stdout + r.stderr
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -285,3 +388,114 @@ def test_tiles_dealt_over_device_list(tmp_path, po):
         assert np.array_equal(got[t], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frames[t], w, h)), t
     r = _run(["dxt:DXT5:dev=7", "UYVY", w, h, raw, out, tiles])   # no such device on a 1-GPU box: refused at init
     assert r.returncode == 2 and "cannot use HIP device 7" in (r.stdout + r.stderr)
+
+
+@needs_harness
+@pytest.mark.gpu
+def test_reference_jpeg_fixture_end_to_end(tmp_path):
+    """test/gpujpeg_test.cpp:68-106, the only fixture the reference holds at this boundary: a 1920x1080 RGB frame of all-127 bytes through
+    compress_init / compress_frame / compress_pop with the module's default parameters, decoded again (there: by the gpujpeg decompress
+    module; here: by libjpeg through Pillow, an independent decoder), max |diff| <= 1 over every byte."""
+    import io
+    from PIL import Image
+    w, h = 1920, 1080
+    raw, out = tmp_path / "in.raw", tmp_path / "out.jpg"
+    np.full(w * h * 3, 127, np.uint8).tofile(raw)
+    r = subprocess.run([HARNESS, "jpeg", "RGB", str(w), str(h), str(raw), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "JPEG" in r.stdout, r.stdout + r.stderr
+    img = Image.open(io.BytesIO(out.read_bytes()))
+    assert img.size == (w, h) and img.mode == "RGB"
+    dec = np.asarray(img).astype(int)
+    assert np.abs(dec - 127).max() <= 1
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec", ["RGB", "UYVY"])
+@pytest.mark.parametrize("kind", ["S2", "S3"])
+def test_jpeg_default_parameters_on_real_content(tmp_path, po, kind, codec):
+    """The same path on S2 (low-pass video noise) and S3 (colour bars + ramp) content at 1080p with the module defaults (q=75): decodes
+    with libjpeg to a PSNR floor against what went in (RGB: the frame itself; UYVY: its luma plane)."""
+    import io
+    from PIL import Image
+    w, h = 1920, 1080
+    src = synth.frame(kind, codec, w, h)
+    raw, out = tmp_path / "in.raw", tmp_path / "out.jpg"
+    src.tofile(raw)
+    r = subprocess.run([HARNESS, "jpeg", codec, str(w), str(h), str(raw), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = Image.open(io.BytesIO(out.read_bytes()))
+    if codec == "RGB":
+        ref = src.reshape(h, w, 3).astype(float)
+        dec = np.asarray(img).astype(float)
+    else:
+        img.draft("YCbCr", None)
+        dec = np.asarray(img)[..., 0].astype(float)
+        ref = src.reshape(h, w, 2)[..., 1].astype(float)
+    psnr = 10 * np.log10(255.0 ** 2 / max(np.mean((dec - ref) ** 2), 1e-9))
+    assert psnr > (30 if kind == "S2" else 36), psnr   # S2 carries N(0,2) per-pixel noise that q=75 removes
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec", ["R10k", "R12L", "RG48", "Y216", "Y416", "VUYA", "DVS10", "BGR"])
+def test_jpeg_every_codec_the_reference_module_takes(tmp_path, po, codec):
+    """-c jpeg vs gpujpeg.cpp:227-236,262-272,592-608: the frame is decoded to what get_best_decoder_from(codec, {UYVY, RGB, RGBA}) of the
+    COMPILED reference ranks first, with its line decoder, and coded with that codec's own subsampling (4:2:2 for UYVY, R,G,B 4:4:4 for
+    RGB / RGBA).  The stream must be what the test writer makes of the oracle's coefficients of exactly those samples."""
+    import sys
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libugref.so not built")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from jpeg_bitstream import write_jpeg
+    w, h = 192, 96
+    # smooth content in the codec's own format: start from an RGB picture, bring it into `codec` with the reference's converters
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1).clip(0, 255).astype(np.uint8)
+    src = _to_codec(po, rgb, codec, w, h)
+    target, conv = _ref_best_and_decode(po, codec, ["UYVY", "RGB", "RGBA"], src, w, h)
+    assert target in ("UYVY", "RGB", "RGBA")
+    raw, out = tmp_path / "in.raw", tmp_path / "out.jpg"
+    src.tofile(raw)
+    r = _run(["jpeg:q=80:restart=4", codec, w, h, raw, out])
+    assert r.returncode == 0 and "JPEG" in r.stdout, r.stdout + r.stderr
+    ql, qc = po.jpeg_qtable(80, 0), po.jpeg_qtable(80, 1)
+    if target == "UYVY":
+        y, u, v = po.uyvy_to_i422(conv, w, h)
+        mw, mh = (w + 15) // 16, (h + 7) // 8
+        want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, mh), po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh),
+                          po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh), restart=4, sub=422)
+    else:
+        comp = conv.reshape(h, w, 4 if target == "RGBA" else 3)
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comp[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        want = write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444)
+    assert out.read_bytes() == want
+
+
+def _to_codec(po, rgb, codec, w, h):
+    """an RGB picture in `codec`, through the compiled reference's own converters (whatever chain decoders[] offers)"""
+    import ctypes as C
+    r = po.ref()
+    r.get_codec_from_name.argtypes = [C.c_char_p]
+    r.get_decoder_from_to.restype = C.c_void_p
+
+    def conv(a, i, o):
+        ci, co = r.get_codec_from_name(i.encode()), r.get_codec_from_name(o.encode())
+        fn = r.get_decoder_from_to(ci, co)
+        assert fn, (i, o)
+        sls, dls = r.vc_get_linesize(w, ci), r.vc_get_linesize(w, co)
+        pad = np.concatenate([np.ascontiguousarray(a, np.uint8).ravel(), np.zeros(64, np.uint8)])
+        dst = np.zeros(dls * h + 64, np.uint8)
+        dec = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)(fn)
+        for y in range(h):
+            dec(dst.ctypes.data + y * dls, pad.ctypes.data + y * sls, r.vc_get_size(w, co), 0, 8, 16)
+        return dst[: dls * h]
+    chain = {"R10k": ["RGBA", "R10k"], "R12L": ["R12L"], "RG48": ["RG48"], "Y216": ["UYVY", "Y216"], "Y416": ["UYVY", "Y416"], "VUYA": ["RGBA", "VUYA"],
+             "DVS10": ["UYVY", "v210"], "BGR": None}[codec]
+    if chain is None:
+        return np.ascontiguousarray(rgb[..., ::-1]).ravel()
+    cur, name = rgb.ravel(), "RGB"
+    for nxt in chain:
+        cur = conv(cur, name, nxt)
+        name = nxt
+    return cur   # DVS10: v210 bytes are a valid DVS10 frame as far as the decoder is concerned (same 6 px / 16 B grouping)

@@ -1,8 +1,9 @@
-"""CPU: the strict-fp32 DXT restatement (oracle/dxt_oracle.c).  Parity is UNPINNED against the
-reference (no CPU DXT encoder, no known-answer test there); what can be checked is (a) regression
-against committed oracle outputs, (b) the bitstream decodes -- with the restated reference CPU decoder
-cuda_dxt/dxt62tga.c -- to an image close to the source, (c) structural S3TC invariants, and (d) a
-pure-Python/numpy-float32 re-derivation of one block from SURVEY.md Appendix A."""
+"""CPU: the strict-fp32 DXT restatement (oracle/dxt_oracle.c).  The reference has no CPU DXT encoder and no known-answer test, but
+its encoders are GLSL shaders and those run on Mesa llvmpipe: the restatement in its default mode ("ties even") is PINNED to them
+block for block (second half of this file, tests/golden/dxt_glsl_ref.npz).  Also checked: (a) regression against committed oracle
+outputs in both tie modes, (b) the bitstream decodes -- with the restated reference CPU decoder cuda_dxt/dxt62tga.c -- to an image
+close to the source, (c) structural S3TC invariants, and (d) a pure-Python/numpy-float32 re-derivation of one block from
+SURVEY.md Appendix A."""
 import os
 
 import numpy as np
@@ -20,6 +21,7 @@ def psnr(a, b):
 
 
 def test_regression_vs_committed_oracle_outputs(po):
+    """out_/outm_ = default mode (ties even), outa_ = ties away"""
     fmts = {"RGB": po.IN_RGB, "RGBA": po.IN_RGBA, "UYVY": po.IN_UYVY, "v210": po.IN_V210}
     n = 0
     for k in GOLD.files:
@@ -28,10 +30,10 @@ def test_regression_vs_committed_oracle_outputs(po):
         tag, kind, name, oname = k.split("_")
         src = GOLD[f"in_{kind}_{name}"]
         h = -16 if tag == "outm" else 16
-        got = po.dxt_encode(fmts[name], po.OUT_DXT1 if oname == "dxt1" else po.OUT_DXT5YCOCG, src, 48, h)
+        got = po.dxt_encode(fmts[name], po.OUT_DXT1 if oname == "dxt1" else po.OUT_DXT5YCOCG, src, 48, h, ties="away" if tag == "outa" else "even")
         assert np.array_equal(got, GOLD[k]), k
         n += 1
-    assert n == 48
+    assert n == 72
 
 
 @pytest.mark.parametrize("out", ["dxt1", "dxt5ycocg"])
@@ -93,7 +95,7 @@ def test_format_equivalences(po):
         assert np.array_equal(po.dxt_encode(po.IN_RGB, oid, rgb, w, -h), po.dxt_encode(po.IN_RGB, oid, flipped, w, h))
 
 
-def _dxt5_block_numpy(rgb):
+def _dxt5_block_numpy(rgb, ties="even"):
     """One block per SURVEY.md Appendix A in numpy float32 scalar arithmetic (independent re-derivation)."""
     f = F32
     off = f(128.0 / 255.0)
@@ -113,7 +115,10 @@ def _dxt5_block_numpy(rgb):
     if m < f(64.0 / 255.0): scale = 2
     if m < f(32.0 / 255.0): scale = 4
     fs = f(scale)
-    rnd = lambda x: int(np.floor(np.float64(x) + 0.5))  # x >= 0: half away == floor(x + .5) in fp64 (exact)
+    if ties == "away":
+        rnd = lambda x: int(np.floor(np.float64(x) + 0.5))  # x >= 0: half away == floor(x + .5) in fp64 (exact)
+    else:
+        rnd = lambda x: int(np.rint(np.float64(x)))         # ties to even (Mesa's GLSL round)
     q = [f(31), f(63)]
     imax, imin, emx, emn = [], [], [], []
     for k in range(2):
@@ -165,8 +170,9 @@ def test_independent_numpy_float32_rederivation(po):
                 blk = np.full((16, 3), rng.integers(0, 256), np.uint8)
             else:                 # smooth gradient
                 blk = (np.linspace(40, 200, 16)[:, None] + rng.integers(-3, 4, (16, 3))).clip(0, 255).astype(np.uint8)
-            got = po.dxt_encode(po.IN_RGB, po.OUT_DXT5YCOCG, blk.reshape(4, 12), 4, 4).view(np.uint32).tolist()
-            assert got == _dxt5_block_numpy(blk), trial
+            for ties in ("even", "away"):
+                got = po.dxt_encode(po.IN_RGB, po.OUT_DXT5YCOCG, blk.reshape(4, 12), 4, 4, ties=ties).view(np.uint32).tolist()
+                assert got == _dxt5_block_numpy(blk, ties), (trial, ties)
 
 
 def test_decode_oracle_pinned_to_reference_tool(po):
@@ -183,7 +189,7 @@ def test_decode_oracle_pinned_to_reference_tool(po):
 
 
 def test_round_u32_identity_used_by_the_hip_encoder():
-    """dxt_encode.hip computes (uint32_t) roundf(x) as `x < 0.5 ? 0 : (uint32_t)(x + 0.5f)`.  Pure IEEE arithmetic, so it is
+    """dxt_encode.hip (UG_DXT_TIES_AWAY) computes (uint32_t) roundf(x) as `x < 0.5 ? 0 : (uint32_t)(x + 0.5f)`.  Pure IEEE arithmetic, so it is
     checked here on the CPU: every float within 512 ulps of k and k + 0.5 (k = 0..256) and 4M random floats in [0, 256].
     (An exhaustive sweep of all floats in [0, 2^22] was run once with the same result: no mismatch.)"""
     rng = np.random.default_rng(7)
@@ -212,43 +218,33 @@ def _glsl_cases():
             yield kind, fmt, mode
 
 
-def _oracle_for(po, fmt, mode, src, w, h):
+def _oracle_for(po, fmt, mode, src, w, h, ties="even"):
     pin = po.IN_UYVY_RAW if mode == "dxt1yuv" else getattr(po, _PIN[fmt])
-    return po.dxt_encode(pin, po.OUT_DXT5YCOCG if mode == "dxt5" else po.OUT_DXT1, src, w, h)
+    return po.dxt_encode(pin, po.OUT_DXT5YCOCG if mode == "dxt5" else po.OUT_DXT1, src, w, h, ties=ties)
 
 
 @pytest.mark.parametrize("kind,fmt,mode", sorted(set(_glsl_cases())))
 def test_restatement_reproduces_the_reference_glsl_shaders(po, kind, fmt, mode):
     """Bit-for-bit, every block: oracle/dxt_oracle.c == compress_dxt5ycocg_fp.glsl / compress_dxt1_fp.glsl (+ yuv422_to_yuv444.glsl)
-    run on llvmpipe, with the two implementation-defined GLSL choices set as Mesa makes them."""
+    run on llvmpipe, in the oracle's default mode (the two implementation-defined GLSL choices set as Mesa makes them)."""
     w, h = (int(x) for x in GLSL_GOLD["size"])
     src = GLSL_GOLD[f"in_{kind}_{fmt}"]
-    po.set_mesa_variant(True)
-    try:
-        got = _oracle_for(po, fmt, mode, src, w, h)
-    finally:
-        po.set_mesa_variant(False)
-    assert np.array_equal(got, GLSL_GOLD[f"out_{kind}_{fmt}_{mode}"])
+    assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), GLSL_GOLD[f"out_{kind}_{fmt}_{mode}"])
 
 
 @pytest.mark.parametrize("fmt", ["RGB", "UYVY"])
 def test_restatement_vs_reference_glsl_big_frames_and_the_tie_rule(po, fmt):
-    """4096-block uniform-random frames: identical to the shaders under Mesa's choices; under the documented oracle (roundf as in the
-    reference's CUDA port, dot() left to right) only a few blocks differ, each by one endpoint LSB (an exact .5 tie of round()) or one
-    palette index (a distance near-tie)."""
+    """4096-block uniform-random frames: identical to the shaders in the default mode (Mesa's choices); in "ties away" mode (roundf as
+    in the reference's CUDA port, dot() left to right) only a few blocks differ, each by one endpoint LSB (an exact .5 tie of round())
+    or one palette index (a distance near-tie)."""
     w, h = 512, 128
     src = synth.s1_random(fmt, w, h, salt=77)
     crc = int(np.sum(src.astype(np.uint64) * (np.arange(src.size, dtype=np.uint64) % 251 + 1)))
     assert crc == int(GLSL_GOLD[f"big_{fmt}_crc"][0]), "synthetic frame generator changed: regenerate tests/golden/dxt_glsl_ref.npz"
     for mode in ("dxt5", "dxt1"):
         gold = GLSL_GOLD[f"big_{fmt}_{mode}"]
-        po.set_mesa_variant(True)
-        try:
-            mesa = _oracle_for(po, fmt, mode, src, w, h)
-        finally:
-            po.set_mesa_variant(False)
-        assert np.array_equal(mesa, gold), mode
-        dflt = _oracle_for(po, fmt, mode, src, w, h)
+        assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), gold), mode
+        dflt = _oracle_for(po, fmt, mode, src, w, h, ties="away")
         bs = 16 if mode == "dxt5" else 8
         differ = np.flatnonzero((dflt.reshape(-1, bs) != gold.reshape(-1, bs)).any(axis=1))
         assert differ.size <= 0.01 * gold.size // bs, (mode, differ.size)        # ties are rare
@@ -262,14 +258,10 @@ def test_live_reference_glsl_when_available(po):
     """In the build container the shaders are run live on other geometries than the committed vectors."""
     if not po.have_glsl_ref():
         pytest.skip("oracle/_ref/glsl_ref or /root/reference not available")
-    po.set_mesa_variant(True)
-    try:
-        for (w, h, fmt, mode, kind) in [(4, 4, "RGB", "dxt5", "S1"), (8, 4, "UYVY", "dxt5", "S1"), (200, 36, "RGBA", "dxt1", "S2"), (132, 60, "UYVY", "dxt1yuv", "S2"),
-                                        (1920, 64, "UYVY", "dxt5", "S2"), (256, 256, "RGB", "dxt1", "S1")]:
-            src = synth.frame(kind, fmt, w, h, 9)
-            assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), po.ref_glsl_dxt_encode(mode, fmt.lower(), src, w, h)), (w, h, fmt, mode)
-    finally:
-        po.set_mesa_variant(False)
+    for (w, h, fmt, mode, kind) in [(4, 4, "RGB", "dxt5", "S1"), (8, 4, "UYVY", "dxt5", "S1"), (200, 36, "RGBA", "dxt1", "S2"), (132, 60, "UYVY", "dxt1yuv", "S2"),
+                                    (1920, 64, "UYVY", "dxt5", "S2"), (256, 256, "RGB", "dxt1", "S1")]:
+        src = synth.frame(kind, fmt, w, h, 9)
+        assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), po.ref_glsl_dxt_encode(mode, fmt.lower(), src, w, h)), (w, h, fmt, mode)
 
 
 def test_decode_oracle_vs_the_reference_gl_decoder_when_available(po):
@@ -297,9 +289,8 @@ def test_decode_oracle_vs_the_reference_gl_decoder_when_available(po):
 
 def test_rgba_to_yuv422_restatement_vs_the_reference_shader_when_available(po):
     """The 4:2:2 output pass of the receiver (rgba_to_yuv422.glsl) alone, run on llvmpipe on the texels our decode oracle produces:
-    the oracle's restatement is byte-identical once the one implementation-defined choice (exact .5 ties of the float -> unorm8
-    framebuffer write: Mesa rounds to even, the oracle half up) is set Mesa's way; with the default it differs in a few bytes per
-    million, by one."""
+    the oracle's restatement is byte-identical in its default mode (exact .5 ties of the float -> unorm8 framebuffer write -- the one
+    implementation-defined choice here -- to even, as Mesa does); "ties away" (half up) differs in a few bytes per million, by one."""
     if not po.have_glsl_ref():
         pytest.skip("oracle/_ref/glsl_ref or /root/reference not available")
     import subprocess
@@ -313,12 +304,7 @@ def test_rgba_to_yuv422_restatement_vs_the_reference_shader_when_available(po):
             rgba.tofile(a)
             subprocess.check_call([po.GLSL_REF, "/root/reference", "rgba2uyvy", "rgba", str(w), str(h), a, b])
             gl = np.fromfile(b, np.uint8)
-        po.set_mesa_variant(True)
-        try:
-            mesa = po.dxt_decode(po.OUT_DXT5YCOCG, "UYVY", blocks, w, h)
-        finally:
-            po.set_mesa_variant(False)
-        assert np.array_equal(mesa, gl), kind
-        dflt = po.dxt_decode(po.OUT_DXT5YCOCG, "UYVY", blocks, w, h).astype(int)
+        assert np.array_equal(po.dxt_decode(po.OUT_DXT5YCOCG, "UYVY", blocks, w, h), gl), kind
+        dflt = po.dxt_decode(po.OUT_DXT5YCOCG, "UYVY", blocks, w, h, ties="away").astype(int)
         diff = np.abs(dflt - gl.astype(int))
         assert diff.max() <= 1 and np.count_nonzero(diff) < 1e-4 * diff.size

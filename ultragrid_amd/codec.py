@@ -30,25 +30,33 @@ def dxt_size(out: int, w: int, h: int) -> int:
 
 
 def dxt_encode(in_fmt: int, out_fmt: int, src: torch.Tensor, w: int, h: int, pitch: int = 0,
-               dst: torch.Tensor | None = None) -> torch.Tensor:
+               dst: torch.Tensor | None = None, ties: int | None = None) -> torch.Tensor:
     """Fused unpack + colour conversion + block encode of one image (cuda_{rgb,yuv}_to_dxt{1,6},
-    cuda_dxt.h:30-89, plus the decoder_t pre-pass).  h < 0 reads the source bottom-up."""
+    cuda_dxt.h:30-89, plus the decoder_t pre-pass).  h < 0 reads the source bottom-up.  ties: L.TIES_EVEN / L.TIES_AWAY
+    (None = the library default, ug_hip_dxt_encode)."""
     src = _u8(src)
     if dst is None:
         dst = torch.empty(dxt_size(out_fmt, w, h), dtype=torch.uint8, device=src.device)
-    rc = L.load().ug_hip_dxt_encode(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, _stream())
+    if ties is None:
+        rc = L.load().ug_hip_dxt_encode(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, _stream())
+    else:
+        rc = L.load().ug_hip_dxt_encode_batch_ex(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, 1, 0, 0, ties, _stream())
     L.check(rc, "ug_hip_dxt_encode")
     return dst
 
 
 def dxt_encode_batch(in_fmt: int, out_fmt: int, src: torch.Tensor, w: int, h: int, frames: int,
-                     src_frame_stride: int, dst: torch.Tensor | None = None, pitch: int = 0) -> torch.Tensor:
+                     src_frame_stride: int, dst: torch.Tensor | None = None, pitch: int = 0, ties: int | None = None) -> torch.Tensor:
     src = _u8(src)
     per = dxt_size(out_fmt, w, h)
     if dst is None:
         dst = torch.empty(per * frames, dtype=torch.uint8, device=src.device)
-    rc = L.load().ug_hip_dxt_encode_batch(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, frames,
-                                          src_frame_stride, per, _stream())
+    if ties is None:
+        rc = L.load().ug_hip_dxt_encode_batch(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, frames,
+                                              src_frame_stride, per, _stream())
+    else:
+        rc = L.load().ug_hip_dxt_encode_batch_ex(in_fmt, out_fmt, src.data_ptr(), dst.data_ptr(), w, h, pitch, frames,
+                                                 src_frame_stride, per, ties, _stream())
     L.check(rc, "ug_hip_dxt_encode_batch")
     return dst
 
@@ -64,11 +72,14 @@ def time_dxt_encode(in_fmt: int, out_fmt: int, src: torch.Tensor, dst: torch.Ten
     return ms.value
 
 
-def dxt_decode(in_fmt: int, out_fmt: int, blocks: torch.Tensor, w: int, h: int, shifts=(0, 8, 16)) -> torch.Tensor:
+def dxt_decode(in_fmt: int, out_fmt: int, blocks: torch.Tensor, w: int, h: int, shifts=(0, 8, 16), ties: int | None = None) -> torch.Tensor:
     """DXT1 / DXT5-YCoCg -> RGB / BGR / RGBA / UYVY (dxt_decoder_decompress behind video_decompress/dxt_glsl.c:142-189)."""
     blocks = _u8(blocks)
     dst = torch.empty(linesize(out_fmt, w) * h, dtype=torch.uint8, device=blocks.device)
-    rc = L.load().ug_hip_dxt_decode(in_fmt, out_fmt, blocks.data_ptr(), dst.data_ptr(), w, h, 0, *shifts, _stream())
+    if ties is None:
+        rc = L.load().ug_hip_dxt_decode(in_fmt, out_fmt, blocks.data_ptr(), dst.data_ptr(), w, h, 0, *shifts, _stream())
+    else:
+        rc = L.load().ug_hip_dxt_decode_ex(in_fmt, out_fmt, blocks.data_ptr(), dst.data_ptr(), w, h, 0, *shifts, ties, _stream())
     L.check(rc, "ug_hip_dxt_decode")
     return dst
 

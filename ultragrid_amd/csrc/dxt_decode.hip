@@ -23,14 +23,19 @@ __device__ __forceinline__ uint32_t clamp8(double s)
         return (uint32_t) (is > 255 ? 255 : (is < 0 ? 0 : is));
 }
 
+// float -> unorm8 framebuffer write of the receiver's shaders.  GL rounds to nearest and leaves exact .5 ties to the implementation:
+// AWAY = false (UG_DXT_TIES_EVEN, default): ties to even, what Mesa llvmpipe does when it executes the reference's rgba_to_yuv422.glsl
+// (pinned byte for byte, tests/test_oracle_dxt.py); AWAY = true (UG_DXT_TIES_AWAY): floor(x * 255 + 0.5).
+template <bool AWAY>
 __device__ __forceinline__ uint8_t unorm8_out(float x)
 {
         x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-        return (uint8_t) (int) (x * 255.0f + 0.5f);
+        return AWAY ? (uint8_t) (int) (x * 255.0f + 0.5f) : (uint8_t) (int) rintf(x * 255.0f);
 }
 
 // dxt_compress/rgba_to_yuv422.glsl:27-46 on two 8-bit RGB texels -> one UYVY word.  `unorm` = the 256 values v / 255.0f (the
 // texel fetch), computed once per workgroup with the IEEE division and kept in LDS: a table read instead of six divisions per pair.
+template <bool AWAY>
 __device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2, const float *unorm)
 {
         float yuv[2][3];
@@ -43,8 +48,8 @@ __device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2, c
                 yuv[i][2] = 0.5f + ((r * 0.5f - g * 0.4541f) - b * 0.0458f) * 0.8784f;
         }
         const float U = yuv[0][1] * 0.5f + yuv[1][1] * 0.5f, V = yuv[0][2] * 0.5f + yuv[1][2] * 0.5f;
-        return (uint32_t) unorm8_out(U) | (uint32_t) unorm8_out(yuv[0][0]) << 8 | (uint32_t) unorm8_out(V) << 16 |
-               (uint32_t) unorm8_out(yuv[1][0]) << 24;
+        return (uint32_t) unorm8_out<AWAY>(U) | (uint32_t) unorm8_out<AWAY>(yuv[0][0]) << 8 | (uint32_t) unorm8_out<AWAY>(V) << 16 |
+               (uint32_t) unorm8_out<AWAY>(yuv[1][0]) << 24;
 }
 
 // fill the v / 255.0f table (256 lanes of the 64x4 workgroup, one division each); call before any early return
@@ -80,7 +85,7 @@ struct OutArgs {
 };
 
 // store one decoded row (4 pixels, packed R | G<<8 | B<<16) of block column bx
-template <int OUT>
+template <int OUT, bool AWAY>
 __device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4], const float *unorm)
 {
         uint8_t *row = o.dst + (long) y * o.pitch;
@@ -103,11 +108,11 @@ __device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const
                 d[1] = (p[1] >> 8) | p[2] << 16;
                 d[2] = (p[2] >> 16) | p[3] << 8;
         } else { // UYVY
-                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy(px[0], px[1], unorm), rgb_pair_to_uyvy(px[2], px[3], unorm));
+                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy<AWAY>(px[0], px[1], unorm), rgb_pair_to_uyvy<AWAY>(px[2], px[3], unorm));
         }
 }
 
-template <int OUT>
+template <int OUT, bool AWAY>
 __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh)
 {
         // per-lane tables, entry-major so that a wave's accesses to one entry are contiguous
@@ -164,13 +169,13 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
                         const uint32_t B = clamp8(((a - Co) - Cg) * 255.0);
                         px[x] = R | G << 8 | B << 16;
                 }
-                store_row<OUT>(o, 4 * by + y, bx, px, unorm);
+                store_row<OUT, AWAY>(o, 4 * by + y, bx, px, unorm);
         }
 }
 
 // YUV = true: DXT1_YUV -- the palette holds Y, Cb, Cr and goes through the display matrix of
 // dxt_compress/display_dxt1_yuv_fp.glsl:21-32 (fp32, one operation per shader operation) before the 8-bit write.
-template <int OUT, bool YUV>
+template <int OUT, bool YUV, bool AWAY>
 __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restrict__ src, OutArgs o, int bw, int bh)
 {
         __shared__ float unorm[OUT == UG_PF_UYVY ? 256 : 1];
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                         const float col0 = (float) p[k][0], col1 = (float) p[k][1], col2 = (float) p[k][2];
                         const float Y = 1.1643f * (col0 - 0.0625f), U = 1.1384f * (col1 - 0.5f), V = 1.1384f * (col2 - 0.5f);
                         const float G = (Y - 0.39173f * U) - 0.81290f * V, B = Y + 2.017f * U, R = Y + 1.5958f * V;
-                        pal[k] = (uint32_t) unorm8_out(R) | (uint32_t) unorm8_out(G) << 8 | (uint32_t) unorm8_out(B) << 16;
+                        pal[k] = (uint32_t) unorm8_out<AWAY>(R) | (uint32_t) unorm8_out<AWAY>(G) << 8 | (uint32_t) unorm8_out<AWAY>(B) << 16;
                 } else {
                         pal[k] = clamp8(p[k][0] * 255.0) | clamp8(p[k][1] * 255.0) << 8 | clamp8(p[k][2] * 255.0) << 16;
                 }
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                         const uint32_t lo = (ci & 1) ? pal[1] : pal[0], hi = (ci & 1) ? pal[3] : pal[2];
                         px[x] = (ci & 2) ? hi : lo;
                 }
-                store_row<OUT>(o, 4 * by + y, bx, px, unorm);
+                store_row<OUT, AWAY>(o, 4 * by + y, bx, px, unorm);
         }
 }
 
@@ -254,27 +259,41 @@ __global__ void selftest_div_kernel(unsigned *mismatches)
         if (bad) atomicAdd(mismatches, bad);
 }
 
-template <int OUT>
-int launch_decode(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
+template <int OUT, bool AWAY>
+int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
 {
         const int bw = w / 4, bh = h / 4;
         const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
         if (in == UG_DXT5_YCOCG) {
-                hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT>), grid, block, 0, st, (const uint4 *) src, o, bw, bh);
+                hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY>), grid, block, 0, st, (const uint4 *) src, o, bw, bh);
         } else if (in == UG_DXT1_YUV) {
-                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true, AWAY>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         } else {
-                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, false>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, false, AWAY>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
 
+template <int OUT>
+int launch_decode(ug_dxt_t in, int ties, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
+{
+        // the tie rule only reaches the outputs that pass through a shader's unorm8 write: UYVY, and the DXT1_YUV display matrix
+        if (ties == UG_DXT_TIES_AWAY && (OUT == UG_PF_UYVY || in == UG_DXT1_YUV)) {
+                return launch_decode_t<OUT, true>(in, src, o, w, h, st);
+        }
+        return launch_decode_t<OUT, false>(in, src, o, w, h, st);
+}
+
 } // namespace
 
-extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
-                                 int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
+extern "C" int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
+                                    int dst_pitch, int rshift, int gshift, int bshift, int ties, ug_hip_stream_t stream)
 {
+        if (ties != UG_DXT_TIES_EVEN && ties != UG_DXT_TIES_AWAY) {
+                ug::set_last_error_msg("ug_hip_dxt_decode: unknown tie rule");
+                return UG_HIP_EINVAL;
+        }
         if (!src_dev || !dst_dev || width <= 0 || height <= 0 || (width & 3) || (height & 3) || (15 & (uintptr_t) dst_dev) ||
             ((in == UG_DXT5_YCOCG ? 15 : 7) & (uintptr_t) src_dev) || (height / 4 + 3) / 4 > 65535) {
                 ug::set_last_error_msg("ug_hip_dxt_decode: bad size or alignment");
@@ -292,22 +311,28 @@ extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_d
         switch (out) {
         case UG_PF_RGBA:
                 if (dst_pitch & 15) break;
-                return launch_decode<UG_PF_RGBA>(in, src_dev, o, width, height, st);
+                return launch_decode<UG_PF_RGBA>(in, ties, src_dev, o, width, height, st);
         case UG_PF_RGB:
                 if (dst_pitch & 3) break;
-                return launch_decode<UG_PF_RGB>(in, src_dev, o, width, height, st);
+                return launch_decode<UG_PF_RGB>(in, ties, src_dev, o, width, height, st);
         case UG_PF_BGR:
                 if (dst_pitch & 3) break;
-                return launch_decode<UG_PF_BGR>(in, src_dev, o, width, height, st);
+                return launch_decode<UG_PF_BGR>(in, ties, src_dev, o, width, height, st);
         case UG_PF_UYVY:
                 if (dst_pitch & 7) break;
-                return launch_decode<UG_PF_UYVY>(in, src_dev, o, width, height, st);
+                return launch_decode<UG_PF_UYVY>(in, ties, src_dev, o, width, height, st);
         default:
                 ug::set_last_error_msg("ug_hip_dxt_decode: unsupported output format");
                 return UG_HIP_EUNSUPP;
         }
         ug::set_last_error_msg("ug_hip_dxt_decode: destination pitch not aligned for this output format");
         return UG_HIP_EINVAL;
+}
+
+extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
+                                 int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
+{
+        return ug_hip_dxt_decode_ex(in, out, src_dev, dst_dev, width, height, dst_pitch, rshift, gshift, bshift, UG_DXT_TIES_DEFAULT, stream);
 }
 
 // Runs the exhaustive comparison of the decoders' constant-divisor quotients with the IEEE division; *mismatches must come back 0.

@@ -35,18 +35,23 @@ constexpr float kInsetY  = (float) ((16.0 / 255.0) / 32.0);
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(1.0f, fmaxf(0.0f, v)); }
 
-// (uint32_t) roundf(x) for 0 <= x < 2^22 (half away from zero, cuda_dxt.cu:122-124).  For x >= 0.5 the fp32 sum x + 0.5f
+// GLSL round() leaves the direction of exact .5 ties to the implementation, and so does the order in which dot(vec3) is summed.
+// Both choices are a RUN-TIME option of the library (UG_DXT_TIES_*, include/ug_mi355x.h), compiled as a template parameter:
+//   TIES_EVEN (default): round() ties to even, dot(vec3) summed from the last component -- what the reference's shaders compute when
+//                        they are EXECUTED (Mesa llvmpipe, oracle/glsl_ref.c; tests/golden/dxt_glsl_ref.npz pins every block);
+//   TIES_AWAY          : roundf() half away from zero, dot() left to right -- the reference's CUDA text (cuda_dxt.cu:106-108,122-124).
+// (uint32_t) rintf(x) is v_rndne_f32 + v_cvt_u32_f32.  (uint32_t) roundf(x) for 0 <= x < 2^22: for x >= 0.5 the fp32 sum x + 0.5f
 // truncates to the right integer: it is exact unless it lands in a higher binade than x, which only happens for
 // x in [2^k - 0.5, 2^k), where both roundf(x) and the (rounded) sum's integer part are 2^k.  Below 0.5 the sum can
 // round up to 1.0 (x = 0.5 - 2^-25), so that range is selected to 0 explicitly.  4 instructions instead of roundf's 7.
+template <bool AWAY>
 __device__ __forceinline__ uint32_t round_u32(float x)
 {
-#ifdef UG_DXT_GLSL_MESA_TIES // test build: GLSL round() as Mesa llvmpipe implements it (ties to even), tests/test_gpu_dxt.py
-        return (uint32_t) rintf(x);
-#else
+        if (!AWAY) {
+                return (uint32_t) rintf(x);
+        }
         const uint32_t r = (uint32_t) (x + 0.5f);
         return x < 0.5f ? 0u : r;
-#endif
 }
 
 // x / 14.0f without the IEEE division sequence (v_div_scale x2, v_rcp, v_div_fmas, v_div_fixup + 4 fma: five of them on the slow
@@ -319,6 +324,7 @@ struct Loader<UG_PF_V210> {
 // ---------------------------------------------------------------------------------------
 // DXT5-YCoCg block encode (compress_dxt5ycocg_fp.glsl:326-377 / cuda_dxt.cu:471-509)
 // ---------------------------------------------------------------------------------------
+template <bool AWAY>
 __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
 {
         // ConvertRGBToYCoCg (glsl:27-34).  2.0*x and *0.25 are exact (powers of two), so
@@ -385,8 +391,8 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                         const float inset = (a - b) * 0.0625f - kInsetC;
                         b = clamp01(b + inset);
                         a = clamp01(a - inset);
-                        imax[k] = round_u32(a * q[k]);
-                        imin[k] = round_u32(b * q[k]);
+                        imax[k] = round_u32<AWAY>(a * q[k]);
+                        imin[k] = round_u32<AWAY>(b * q[k]);
                 }
                 w_end = ((imax[0] << 11) | (imax[1] << 5) | (scale - 1)) |
                         (((imin[0] << 11) | (imin[1] << 5) | (scale - 1)) << 16);
@@ -409,7 +415,7 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 mxY = clamp01(mxY - inset);
         }
         // EmitAlphaEndPointsYCoCgDXT5 (glsl:252-259)
-        uint32_t w0 = (round_u32(mnY * 255.0f) << 8) | round_u32(mxY * 255.0f);
+        uint32_t w0 = (round_u32<AWAY>(mnY * 255.0f) << 8) | round_u32<AWAY>(mxY * 255.0f);
         uint32_t w1 = 0;
         // EmitAlphaIndicesYCoCgDXT5 (glsl:262-312): count c = #{k : a <= ab_k}, index = f(c).
         {
@@ -547,6 +553,7 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
 // ---------------------------------------------------------------------------------------
 // DXT1 block encode, normative = GLSL (compress_dxt1_fp.glsl:177-229)
 // ---------------------------------------------------------------------------------------
+template <bool AWAY>
 __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 {
         const float *R = p.a, *G = p.b, *B = p.c;
@@ -578,8 +585,8 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
                 for (int k = 0; k < 3; k++) {
                         const float inset = (mx[k] - mn[k]) * 0.0625f - kInsetC;
                         const float lo = clamp01(mn[k] + inset), hi = clamp01(mx[k] - inset);
-                        cm[k] = round_u32(hi * q[k]);
-                        cn[k] = round_u32(lo * q[k]);
+                        cm[k] = round_u32<AWAY>(hi * q[k]);
+                        cn[k] = round_u32<AWAY>(lo * q[k]);
                 }
         }
         const uint32_t code_max = (cm[0] << 11) | (cm[1] << 5) | cm[2];
@@ -624,11 +631,8 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                                 const f32x2 tx = r - cc[k][0], ty = g - cc[k][1], tz = bl - cc[k][2];
-#ifdef UG_DXT_GLSL_MESA_TIES // Mesa sums dot(vec3) from the last component
-                                d[k] = (tz * tz + ty * ty) + tx * tx;
-#else
-                                d[k] = (tx * tx + ty * ty) + tz * tz; // dot(v,v): x*x + y*y + z*z, left to right
-#endif
+                                d[k] = AWAY ? (tx * tx + ty * ty) + tz * tz  // dot(v,v): x*x + y*y + z*z, left to right (cuda_dxt.cu:106-108)
+                                            : (tz * tz + ty * ty) + tx * tx; // Mesa sums dot(vec3) from the last component
                         }
 #pragma unroll
                         for (int h = 1; h >= 0; h--) {
@@ -660,9 +664,9 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 // wave and latency hiding is left to the 4 resident waves per SIMD.
 constexpr int kRowsPerWave = UG_DXT_ROWS_PER_WAVE;
 
-template <int IN, int OUT, bool MIRROR>
+template <int IN, int OUT, bool MIRROR, bool AWAY>
 __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                         int units_per_row, int block_rows, int height, uint32_t pitch,
+                                                         int units_per_row, int blocks_per_row, int block_rows, int height, uint32_t pitch,
                                                          size_t src_frame_stride, size_t dst_frame_stride)
 {
         using L = Loader<IN>;
@@ -702,16 +706,21 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
                 }
                 // block raster order idx = bx + (w/4)*by (cuda_dxt.cu:633)
                 constexpr uint32_t kBlockBytes = OUT == UG_DXT5_YCOCG ? 16 : 8;
-                uint8_t *const dst_row = dst + (size_t) by * units_per_row * (L::kBlocks * kBlockBytes); // scalar
+                uint8_t *const dst_row = dst + (size_t) by * blocks_per_row * kBlockBytes; // scalar
                 const uint32_t dst_off = (uint32_t) ux * (L::kBlocks * kBlockBytes);
 #pragma unroll
                 for (int k = 0; k < L::kBlocks; k++) {
+                        // v210, width % 12 != 0 (1280, 2048 ...): the last 32-byte unit of a line holds one or two blocks; its loads
+                        // stay inside the 128-byte-padded line (video_codec.c:507-521), the blocks past the picture are not emitted
+                        if (L::kBlocks > 1 && k > 0 && ux * L::kBlocks + k >= blocks_per_row) {
+                                break;
+                        }
                         Px16 p;
                         cur.block(k, p);
                         if (OUT == UG_DXT5_YCOCG) {
-                                *(uint4 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt5ycocg(p);
+                                *(uint4 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt5ycocg<AWAY>(p);
                         } else {
-                                *(uint2 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt1(p);
+                                *(uint2 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt1<AWAY>(p);
                         }
                 }
                 if (more) {
@@ -731,43 +740,51 @@ __global__ void selftest_div14_kernel(unsigned *mismatches)
         if (__float_as_uint(div14(x)) != __float_as_uint(want)) atomicAdd(mismatches, 1u);
 }
 
-template <int IN, int OUT>
-int launch(const void *src, void *dst, int w, int h, int pitch, int frames, size_t sfs, size_t dfs, hipStream_t st)
+struct EncodeJob {
+        const void *src;
+        void *dst;
+        int w, h, pitch, frames;
+        size_t sfs, dfs;
+        hipStream_t st;
+};
+
+template <int IN, int OUT, bool AWAY>
+int launch(const EncodeJob &j)
 {
         using L = Loader<IN>;
-        const bool mirror = h < 0;
-        if (mirror) h = -h;
-        const int upr = (w / 4) / L::kBlocks, brows = h / 4;
-        if (upr == 0 || brows == 0 || frames == 0) return UG_HIP_SUCCESS;
+        const bool mirror = j.h < 0;
+        const int h = mirror ? -j.h : j.h;
+        const int bpr = j.w / 4, upr = (bpr + L::kBlocks - 1) / L::kBlocks, brows = h / 4;
+        if (upr == 0 || brows == 0 || j.frames == 0) return UG_HIP_SUCCESS;
         constexpr int wg_rows = 4; // waves per workgroup; 1, 2 and 4 measure the same (0.1878-0.1889 ms)
         const int rows_per_group = wg_rows * kRowsPerWave;
-        if ((uint64_t) pitch * (uint64_t) h > 0xffffffffull) { // in-frame byte offsets are 32-bit (scalar base + lane offset)
+        if ((uint64_t) j.pitch * (uint64_t) h > 0xffffffffull) { // in-frame byte offsets are 32-bit (scalar base + lane offset)
                 ug::set_last_error_msg("ug_hip_dxt_encode: image larger than 4 GiB");
                 return UG_HIP_EINVAL;
         }
-        if (frames > 65535 || (brows + rows_per_group - 1) / rows_per_group > 65535) {
+        if (j.frames > 65535 || (brows + rows_per_group - 1) / rows_per_group > 65535) {
                 ug::set_last_error_msg("ug_hip_dxt_encode: image too tall / too many frames for one launch");
                 return UG_HIP_EINVAL;
         }
-        const dim3 block(64, wg_rows), grid((unsigned) ((upr + 63) / 64), (unsigned) ((brows + rows_per_group - 1) / rows_per_group), (unsigned) frames);
+        const dim3 block(64, wg_rows), grid((unsigned) ((upr + 63) / 64), (unsigned) ((brows + rows_per_group - 1) / rows_per_group), (unsigned) j.frames);
         if (mirror) {
-                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, true>), grid, block, 0, st, (const uint8_t *) src,
-                                   (uint8_t *) dst, upr, brows, h, (uint32_t) pitch, sfs, dfs);
+                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, true, AWAY>), grid, block, 0, j.st, (const uint8_t *) j.src,
+                                   (uint8_t *) j.dst, upr, bpr, brows, h, (uint32_t) j.pitch, j.sfs, j.dfs);
         } else {
-                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, false>), grid, block, 0, st, (const uint8_t *) src,
-                                   (uint8_t *) dst, upr, brows, h, (uint32_t) pitch, sfs, dfs);
+                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, false, AWAY>), grid, block, 0, j.st, (const uint8_t *) j.src,
+                                   (uint8_t *) j.dst, upr, bpr, brows, h, (uint32_t) j.pitch, j.sfs, j.dfs);
         }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
 
 template <int IN>
-int launch_out(ug_dxt_t out, const void *src, void *dst, int w, int h, int pitch, int frames, size_t sfs, size_t dfs,
-               hipStream_t st)
+int launch_out(ug_dxt_t out, int ties, const EncodeJob &j)
 {
+        const bool away = ties == UG_DXT_TIES_AWAY;
         switch (out) {
-        case UG_DXT1: return launch<IN, UG_DXT1>(src, dst, w, h, pitch, frames, sfs, dfs, st);
-        case UG_DXT5_YCOCG: return launch<IN, UG_DXT5_YCOCG>(src, dst, w, h, pitch, frames, sfs, dfs, st);
+        case UG_DXT1: return away ? launch<IN, UG_DXT1, true>(j) : launch<IN, UG_DXT1, false>(j);
+        case UG_DXT5_YCOCG: return away ? launch<IN, UG_DXT5_YCOCG, true>(j) : launch<IN, UG_DXT5_YCOCG, false>(j);
         default: break; // UG_DXT1_YUV is rewritten to UG_DXT1 over raw UYVY by the caller
         }
         return UG_HIP_EUNSUPP;
@@ -784,9 +801,9 @@ size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height)
         return out == UG_DXT1 || out == UG_DXT1_YUV ? px / 2 : px;
 }
 
-int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
-                            int src_pitch, int frames, size_t src_frame_stride, size_t dst_frame_stride,
-                            ug_hip_stream_t stream)
+int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
+                               int src_pitch, int frames, size_t src_frame_stride, size_t dst_frame_stride, int ties,
+                               ug_hip_stream_t stream)
 {
         const int ah = height < 0 ? -height : height;
         if (out == UG_DXT1_YUV) { // DXT1 over the Y,Cb,Cr samples: UYVY is its only input (dxt_glsl.cpp:104-110)
@@ -796,6 +813,10 @@ int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void 
                 }
                 in = UG_PF_UYVY_RAW;
                 out = UG_DXT1;
+        }
+        if (ties != UG_DXT_TIES_EVEN && ties != UG_DXT_TIES_AWAY) {
+                ug::set_last_error_msg("ug_hip_dxt_encode: unknown tie rule");
+                return UG_HIP_EINVAL;
         }
         if (!src || !dst || width <= 0 || ah == 0 || (width & 3) || (ah & 3) || frames < 0 ||
             (15 & (uintptr_t) src) || (15 & (uintptr_t) dst)) { // cuda_dxt.cu:745
@@ -813,22 +834,24 @@ int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void 
                 ug::set_last_error_msg("ug_hip_dxt_encode: frame strides must be multiples of 16");
                 return UG_HIP_EINVAL;
         }
-        hipStream_t st = (hipStream_t) stream;
+        const EncodeJob j = { src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, (hipStream_t) stream };
         switch (in) {
-        case UG_PF_RGB: return launch_out<UG_PF_RGB>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+        case UG_PF_RGB: return launch_out<UG_PF_RGB>(out, ties, j);
         case UG_PF_RGBA:
                 if (src_pitch & 15) break;
-                return launch_out<UG_PF_RGBA>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
-        case UG_PF_YUV444: return launch_out<UG_PF_YUV444>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+                return launch_out<UG_PF_RGBA>(out, ties, j);
+        case UG_PF_YUV444: return launch_out<UG_PF_YUV444>(out, ties, j);
         case UG_PF_UYVY:
                 if (src_pitch & 7) break;
-                return launch_out<UG_PF_UYVY>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+                return launch_out<UG_PF_UYVY>(out, ties, j);
         case UG_PF_UYVY_RAW:
                 if (src_pitch & 7) break;
-                return launch_out<UG_PF_UYVY_RAW>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+                return launch_out<UG_PF_UYVY_RAW>(out, ties, j);
         case UG_PF_V210:
-                if ((src_pitch & 15) || width % 12) break;
-                return launch_out<UG_PF_V210>(out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride, st);
+                // 12 px = 32 B units; a last unit with fewer pixels is read whole, which the 128-byte line padding of v210
+                // (vc_get_linesize, video_codec.c:507-521) always covers -- a caller-supplied pitch must cover it too
+                if ((src_pitch & 15) || src_pitch < (width + 11) / 12 * 32) break;
+                return launch_out<UG_PF_V210>(out, ties, j);
         default:
                 ug::set_last_error_msg("ug_hip_dxt_encode: unsupported input format");
                 return UG_HIP_EUNSUPP;
@@ -837,10 +860,18 @@ int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void 
         return UG_HIP_EINVAL;
 }
 
+int ug_hip_dxt_encode_batch(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
+                            int src_pitch, int frames, size_t src_frame_stride, size_t dst_frame_stride,
+                            ug_hip_stream_t stream)
+{
+        return ug_hip_dxt_encode_batch_ex(in, out, src, dst, width, height, src_pitch, frames, src_frame_stride, dst_frame_stride,
+                                          UG_DXT_TIES_DEFAULT, stream);
+}
+
 int ug_hip_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height, int src_pitch,
                       ug_hip_stream_t stream)
 {
-        return ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, 1, 0, 0, stream);
+        return ug_hip_dxt_encode_batch_ex(in, out, src, dst, width, height, src_pitch, 1, 0, 0, UG_DXT_TIES_DEFAULT, stream);
 }
 
 // cuda_dxt.h-shaped entry points

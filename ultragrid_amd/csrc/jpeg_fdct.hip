@@ -232,6 +232,19 @@ __global__ __launch_bounds__(256) void rgb_jpeg444_kernel(const uint8_t *__restr
         }
 }
 
+// batches: frame f reads src + f * src bytes and writes its coefficient planes f * luma / chroma bytes further on
+struct FrameStrides {
+        size_t src, luma, chroma; // bytes
+        __device__ __forceinline__ void apply(unsigned f, const uint8_t *__restrict__ &s, int16_t *__restrict__ &y, int16_t *__restrict__ &cb,
+                                              int16_t *__restrict__ &cr) const
+        {
+                s += (size_t) f * src;
+                y = (int16_t *) ((uint8_t *) y + (size_t) f * luma);
+                cb = (int16_t *) ((uint8_t *) cb + (size_t) f * chroma);
+                cr = (int16_t *) ((uint8_t *) cr + (size_t) f * chroma);
+        }
+};
+
 // Fused UYVY -> 4:2:0 / 4:2:2 planar -> FDCT+quant.  Tasks [0, n_luma) are luma blocks (8 rows x 16 B of UYVY),
 // tasks [n_luma, n_luma + 2*n_chroma) are Cb then Cr blocks.  SUB = 420: chroma block = 16 rows x 32 B with the vertical
 // (a+b+1)/2 average of uyvy_to_i420 (to_planar.c:343-378), MCU 16x16.  SUB = 422: chroma block = 8 rows x 32 B, samples
@@ -240,8 +253,9 @@ template <int SUB>
 __global__ __launch_bounds__(256) void uyvy_jpeg_kernel(const uint8_t *__restrict__ src, int pitch, int width, int height,
                                                         int mcu_w, int mcu_h, const float *__restrict__ div,
                                                         int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
-                                                        int16_t *__restrict__ out_cr)
+                                                        int16_t *__restrict__ out_cr, FrameStrides fs)
 {
+        fs.apply(blockIdx.y, src, out_y, out_cb, out_cr); // blockIdx.y = frame of the batch
         const long n_chroma = (long) mcu_w * mcu_h, n_luma = (SUB == 420 ? 4L : 2L) * n_chroma;
         const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
         if (idx >= n_luma + 2 * n_chroma) return;
@@ -308,8 +322,9 @@ template <int SUB>
 __global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height,
                                                                                 int mcu_w, const float *__restrict__ div,
                                                                                 int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
-                                                                                int16_t *__restrict__ out_cr)
+                                                                                int16_t *__restrict__ out_cr, FrameStrides fs)
 {
+        fs.apply(blockIdx.z, src, out_y, out_cb, out_cr); // blockIdx.z = frame of the batch
         constexpr int kLumaWaves = SUB == 420 ? 2 : 1;
         __shared__ __attribute__((aligned(16))) uint8_t lds_all[(kLumaWaves + 1) * 64 * kLdsPitch];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -415,25 +430,26 @@ const double kAan[8] = { 1.0, 1.387039845, 1.306562965, 1.175875602, 1.0, 0.7856
 namespace {
 template <int SUB>
 int launch_uyvy_jpeg(const void *src, int src_pitch, int width, int height, const float *div, int16_t *out_y, int16_t *out_cb,
-                     int16_t *out_cr, ug_hip_stream_t stream, const char *who)
+                     int16_t *out_cr, int frames, const FrameStrides &fs, ug_hip_stream_t stream, const char *who)
 {
-        if (!src || !div || !out_y || !out_cb || !out_cr || width <= 0 || height <= 0 ||
-            ((uintptr_t) out_y | (uintptr_t) out_cb | (uintptr_t) out_cr) & 15) {
+        if (!src || !div || !out_y || !out_cb || !out_cr || width <= 0 || height <= 0 || frames < 0 || frames > 65535 ||
+            ((uintptr_t) out_y | (uintptr_t) out_cb | (uintptr_t) out_cr) & 15 || (frames > 1 && ((fs.luma | fs.chroma) & 15))) {
                 ug::set_last_error_msg(who);
                 return UG_HIP_EINVAL;
         }
+        if (frames == 0) return UG_HIP_SUCCESS;
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
         const int mcu_w = (width + 15) / 16, mcu_h = SUB == 420 ? (height + 15) / 16 : (height + 7) / 8;
-        if (width % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src)) {
-                hipLaunchKernelGGL((uyvy_jpeg_fast_kernel<SUB>), dim3((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h),
+        if (width % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src) && (frames == 1 || !(fs.src & 15))) {
+                hipLaunchKernelGGL((uyvy_jpeg_fast_kernel<SUB>), dim3((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h, (unsigned) frames),
                                    dim3(SUB == 420 ? 192 : 128), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w,
-                                   div, out_y, out_cb, out_cr);
+                                   div, out_y, out_cb, out_cr, fs);
                 UG_HIP_LAUNCH_CHECK();
                 return UG_HIP_SUCCESS;
         }
         const long total = (SUB == 420 ? 6L : 4L) * mcu_w * mcu_h;
-        hipLaunchKernelGGL((uyvy_jpeg_kernel<SUB>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                           (const uint8_t *) src, src_pitch, width, height, mcu_w, mcu_h, div, out_y, out_cb, out_cr);
+        hipLaunchKernelGGL((uyvy_jpeg_kernel<SUB>), dim3((unsigned) ((total + 255) / 256), (unsigned) frames), dim3(256), 0, (hipStream_t) stream,
+                           (const uint8_t *) src, src_pitch, width, height, mcu_w, mcu_h, div, out_y, out_cb, out_cr, fs);
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
@@ -503,15 +519,32 @@ int ug_hip_jpeg_fdct_quant_plane(const void *plane, int pitch, int width, int he
 int ug_hip_uyvy_to_jpeg420_coeffs(const void *src, int src_pitch, int width, int height, const float *div,
                                   int16_t *out_y, int16_t *out_cb, int16_t *out_cr, ug_hip_stream_t stream)
 {
-        return launch_uyvy_jpeg<420>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, stream,
+        return launch_uyvy_jpeg<420>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, 1, FrameStrides{ 0, 0, 0 }, stream,
                                      "ug_hip_uyvy_to_jpeg420_coeffs: bad arguments");
 }
 
 int ug_hip_uyvy_to_jpeg422_coeffs(const void *src, int src_pitch, int width, int height, const float *div,
                                   int16_t *out_y, int16_t *out_cb, int16_t *out_cr, ug_hip_stream_t stream)
 {
-        return launch_uyvy_jpeg<422>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, stream,
+        return launch_uyvy_jpeg<422>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, 1, FrameStrides{ 0, 0, 0 }, stream,
                                      "ug_hip_uyvy_to_jpeg422_coeffs: bad arguments");
+}
+
+int ug_hip_uyvy_to_jpeg42x_coeffs_batch(int subsampling, const void *src, int src_pitch, int width, int height, const float *div,
+                                        int16_t *out_y, int16_t *out_cb, int16_t *out_cr, int frames, size_t src_frame_stride,
+                                        size_t luma_frame_stride, size_t chroma_frame_stride, ug_hip_stream_t stream)
+{
+        const FrameStrides fs = { src_frame_stride, luma_frame_stride, chroma_frame_stride };
+        if (subsampling == 420) {
+                return launch_uyvy_jpeg<420>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, frames, fs, stream,
+                                             "ug_hip_uyvy_to_jpeg42x_coeffs_batch: bad arguments");
+        }
+        if (subsampling == 422) {
+                return launch_uyvy_jpeg<422>(src, src_pitch, width, height, div, out_y, out_cb, out_cr, frames, fs, stream,
+                                             "ug_hip_uyvy_to_jpeg42x_coeffs_batch: bad arguments");
+        }
+        ug::set_last_error_msg("ug_hip_uyvy_to_jpeg42x_coeffs_batch: subsampling must be 420 or 422");
+        return UG_HIP_EINVAL;
 }
 
 } // extern "C"

@@ -616,6 +616,39 @@ int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out)
 }
 
 int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height,
+                          int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+
+// `frames` images at constant strides.  Frames that follow each other exactly one picture apart (stride == pitch * height on both
+// sides -- tiles and frame rings are laid out like that) are ONE picture of frames * height lines to every line converter, so the
+// whole batch is a single launch; any other layout is converted frame by frame.
+int ug_hip_pixfmt_convert_batch(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height, int src_pitch,
+                                int dst_pitch, int rshift, int gshift, int bshift, int frames, size_t src_frame_stride,
+                                size_t dst_frame_stride, ug_hip_stream_t stream)
+{
+        if (frames < 0 || width <= 0 || height <= 0) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert_batch: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        if (frames == 0) return UG_HIP_SUCCESS;
+        const int sp = src_pitch ? src_pitch : ug::linesize(in, width), dp = dst_pitch ? dst_pitch : ug::linesize(out, width);
+        if (sp <= 0 || dp <= 0) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert_batch: unsupported format");
+                return UG_HIP_EUNSUPP;
+        }
+        if (frames == 1 || (src_frame_stride == (size_t) sp * height && dst_frame_stride == (size_t) dp * height &&
+                            (long long) height * frames <= 0x7fffffffLL)) {
+                return ug_hip_pixfmt_convert(in, out, src, dst, width, height * frames, sp, dp, rshift, gshift, bshift, stream);
+        }
+        for (int f = 0; f < frames; f++) {
+                const int rc = ug_hip_pixfmt_convert(in, out, (const uint8_t *) src + (size_t) f * src_frame_stride,
+                                                     (uint8_t *) dst + (size_t) f * dst_frame_stride, width, height, sp, dp, rshift, gshift,
+                                                     bshift, stream);
+                if (rc != UG_HIP_SUCCESS) return rc;
+        }
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height,
                           int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
 {
         if (!src || !dst || width <= 0 || height <= 0) {
@@ -625,6 +658,16 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
         if (!ug_hip_pixfmt_supported(in, out)) {
                 ug::set_last_error_msg("ug_hip_pixfmt_convert: unsupported conversion");
                 return UG_HIP_EUNSUPP;
+        }
+        // same argument checks as the decoders[] extension (pixfmt_ext_convert) and the lavc converters: a shift of 32 or more is
+        // undefined on host and device alike, and a pitch shorter than the line makes lines overwrite each other
+        if ((unsigned) rshift > 24 || (unsigned) gshift > 24 || (unsigned) bshift > 24) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert: component shifts must be in [0, 24]");
+                return UG_HIP_EINVAL;
+        }
+        if ((dst_pitch && dst_pitch < size_of(out, width)) || (src_pitch && src_pitch < size_of(in, width))) {
+                ug::set_last_error_msg("ug_hip_pixfmt_convert: pitch smaller than the line");
+                return UG_HIP_EINVAL;
         }
         Args a;
         a.src = (const uint8_t *) src; a.dst = (uint8_t *) dst; a.width = width; a.height = height;

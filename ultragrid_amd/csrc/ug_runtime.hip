@@ -40,6 +40,16 @@ int ug_hip_pointer_is_device(const void *ptr)
         return a.type == hipMemoryTypeDevice ? 1 : 0;
 }
 
+int ug_hip_pointer_device(const void *ptr)
+{
+        hipPointerAttribute_t a;
+        if (!ptr || hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+                (void) hipGetLastError();
+                return -1;
+        }
+        return a.type == hipMemoryTypeDevice ? a.device : -1;
+}
+
 int ug_hip_set_device(int index)
 {
         UG_HIP_TRY(hipSetDevice(index));

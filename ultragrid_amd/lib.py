@@ -21,6 +21,9 @@ PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "B
             "Y416": PF_Y416, "VUYA": PF_VUYA, "DVS10": PF_DVS10}
 # ug_dxt_t
 DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
+# UG_DXT_TIES_*
+TIES_EVEN, TIES_AWAY = 0, 1
+ABI_VERSION = 2
 
 SUCCESS, EINVAL, EUNSUPP, ERUNTIME = 0, -1, -2, -3
 
@@ -31,6 +34,7 @@ SYMBOLS = {
     "ug_hip_abi_version": (_i, []),
     "ug_hip_device_count": (_i, [C.POINTER(_i)]),
     "ug_hip_pointer_is_device": (_i, [_vp]),
+    "ug_hip_pointer_device": (_i, [_vp]),
     "ug_hip_set_device": (_i, [_i]),
     "ug_hip_malloc": (_i, [C.POINTER(_vp), _sz]),
     "ug_hip_free": (_i, [_vp]),
@@ -45,6 +49,7 @@ SYMBOLS = {
     "ug_hip_time_dxt_encode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _i, _vp, C.POINTER(C.c_float)]),
     "ug_hip_dxt_encode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ug_hip_dxt_encode_batch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _vp]),
+    "ug_hip_dxt_encode_batch_ex": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _i, _vp]),
     "ug_hip_dxt_size": (_sz, [_i, _i, _i]),
     "ug_hip_rgb_to_dxt1": (_i, [_vp, _vp, _i, _i, _vp]),
     "ug_hip_yuv_to_dxt1": (_i, [_vp, _vp, _i, _i, _vp]),
@@ -52,8 +57,10 @@ SYMBOLS = {
     "ug_hip_yuv_to_dxt6": (_i, [_vp, _vp, _i, _i, _vp]),
     "ug_hip_yuv422_to_yuv444": (_i, [_vp, _vp, _i, _vp]),
     "ug_hip_dxt_decode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ug_hip_dxt_decode_ex": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ug_hip_pixfmt_supported": (_i, [_i, _i]),
     "ug_hip_pixfmt_convert": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ug_hip_pixfmt_convert_batch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _sz, _sz, _vp]),
     "ug_hip_linesize": (_i, [_i, _i]),
     "ug_hip_uyvy_to_i420": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_v210_to_p010le": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
@@ -81,6 +88,7 @@ SYMBOLS = {
     "ug_hip_jpeg_fdct_quant_plane": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ug_hip_uyvy_to_jpeg420_coeffs": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ug_hip_uyvy_to_jpeg422_coeffs": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ug_hip_uyvy_to_jpeg42x_coeffs_batch": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _sz, _sz, _sz, _vp]),
     "ug_hip_jpeg_encoder_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
     "ug_hip_jpeg_encoder_create_sub": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ug_hip_jpeg_encoder_destroy": (None, [_vp]),
@@ -110,7 +118,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        if lib.ug_hip_abi_version() != 1:
+        if lib.ug_hip_abi_version() != ABI_VERSION:
             raise ImportError("libug_mi355x.so ABI version mismatch")
         _lib = lib
     return _lib

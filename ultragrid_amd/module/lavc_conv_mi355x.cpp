@@ -133,6 +133,22 @@ to_lavc_vid_conv_cuda_init(codec_t in_pixfmt, int width, int height, enum AVPixe
                 ug_hip_memcpy(s->dev.data[i], s->out_frame->data[i], (size_t) s->out_frame->linesize[i] * plane_rows(s->desc, i, height),
                               UG_HIP_MEMCPY_HOST_TO_DEVICE);
         }
+        // Some rows depend on the geometry (v210 -> p010le needs width % 6 == 0 and an even height on the device, the reference's
+        // CPU function has a ragged-edge path): a dry run of the conversion on the device buffers decides.  If it is refused the hook
+        // declines here -- NULL makes to_lavc_vid_conv_init() set up its own CPU conversion (to_lavc_vid_conv.c:1901-1906) -- instead
+        // of initialising and then returning NULL for every frame.
+        const ug_av_frame probe = s->dev.view(s->out_frame);
+        if (ug_hip_uv_to_av(s->uv, s->av, s->in_dev, &probe, s->stream) != UG_HIP_SUCCESS || ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
+                if (getenv("UG_MI355X_VERBOSE") != nullptr) {
+                        fprintf(stderr, "[lavc_conv_mi355x] %s -> %s at %dx%d is left to the CPU path: %s\n", uv, av, width, height, ug_hip_last_error_string());
+                }
+                to_lavc_vid_conv_cuda_destroy(&s);
+                return nullptr;
+        }
+        for (int i = 0; i < s->dev.planes; i++) { // the dry run wrote the planes: start again from the CPU path's initial frame
+                ug_hip_memcpy(s->dev.data[i], s->out_frame->data[i], (size_t) s->out_frame->linesize[i] * plane_rows(s->desc, i, height),
+                              UG_HIP_MEMCPY_HOST_TO_DEVICE);
+        }
         return s;
 }
 
@@ -200,13 +216,15 @@ void
 av_to_uv_convert_cuda(struct av_to_uv_convert_cuda *s, char *__restrict dst_buffer, struct AVFrame *__restrict in_frame, int width, int height,
                       int pitch, const int *__restrict rgb_shift)
 {
-        (void) width;
-        const size_t dst_need = (size_t) pitch * height;
+        // The caller's buffer holds `height` lines `pitch` apart, but its LAST line may be only vc_get_linesize() long (a display
+        // pitch larger than the line, video_display.h): move pitch * (height - 1) + linesize bytes, never pitch * height.
+        const size_t linesize = (size_t) vc_get_linesize(width, s->out_codec);
+        const size_t dst_need = (size_t) pitch * (height > 0 ? height - 1 : 0) + ((size_t) pitch < linesize ? (size_t) pitch : linesize);
         if (s->dst_size < dst_need) {
                 ug_hip_free(s->dst_dev);
                 s->dst_dev = nullptr;
                 s->dst_size = 0;
-                if (ug_hip_malloc(&s->dst_dev, dst_need + MAX_PADDING) != UG_HIP_SUCCESS) {
+                if (ug_hip_malloc(&s->dst_dev, dst_need + (size_t) pitch + MAX_PADDING) != UG_HIP_SUCCESS) {
                         return;
                 }
                 s->dst_size = dst_need;
@@ -214,22 +232,31 @@ av_to_uv_convert_cuda(struct av_to_uv_convert_cuda *s, char *__restrict dst_buff
         if (!s->dev.ensure(in_frame, s->desc)) {
                 return;
         }
-        for (int i = 0; i < s->dev.planes; i++) {
+        bool ok = true;
+        for (int i = 0; i < s->dev.planes && ok; i++) {
                 const size_t n = (size_t) in_frame->linesize[i] * plane_rows(s->desc, i, in_frame->height);
-                ug_hip_memcpy_async(s->dev.data[i], in_frame->data[i], n, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream);
+                ok = ug_hip_memcpy_async(s->dev.data[i], in_frame->data[i], n, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream) == UG_HIP_SUCCESS;
         }
         // what the converters leave untouched (odd last line, line padding) stays as the caller's buffer has it
-        ug_hip_memcpy_async(s->dst_dev, dst_buffer, dst_need, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream);
+        ok = ok && ug_hip_memcpy_async(s->dst_dev, dst_buffer, dst_need, UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream) == UG_HIP_SUCCESS;
+        if (!ok) { // a failed upload must not deliver a stale or garbage frame: leave the caller's buffer as it is
+                fprintf(stderr, "[lavc_conv_mi355x] %s -> %s: upload failed: %s\n", s->av, s->uv, ug_hip_last_error_string());
+                ug_hip_stream_sync(s->stream);
+                return;
+        }
         if (getenv("UG_MI355X_VERBOSE") != nullptr) {
                 fprintf(stderr, "[lavc_conv_mi355x] from_lavc %s -> %s on the device\n", s->av, s->uv);
         }
         const ug_av_frame in = s->dev.view(in_frame);
         if (ug_hip_av_to_uv(s->av, s->uv, s->dst_dev, pitch, &in, rgb_shift, s->stream) != UG_HIP_SUCCESS) {
                 fprintf(stderr, "[lavc_conv_mi355x] %s -> %s: %s\n", s->av, s->uv, ug_hip_last_error_string());
+                ug_hip_stream_sync(s->stream);
                 return;
         }
-        ug_hip_memcpy_async(dst_buffer, s->dst_dev, dst_need, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream);
-        ug_hip_stream_sync(s->stream);
+        if (ug_hip_memcpy_async(dst_buffer, s->dst_dev, dst_need, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) != UG_HIP_SUCCESS ||
+            ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
+                fprintf(stderr, "[lavc_conv_mi355x] %s -> %s: download failed: %s\n", s->av, s->uv, ug_hip_last_error_string());
+        }
 }
 
 void

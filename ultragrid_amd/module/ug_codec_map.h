@@ -18,6 +18,12 @@ static inline ug_pixfmt_t ug_pixfmt_from_codec(codec_t c)
         case v210: return UG_PF_V210;
         case RG48: return UG_PF_RG48;
         case I420: return UG_PF_I420;
+        case R10k: return UG_PF_R10K;
+        case R12L: return UG_PF_R12L;
+        case Y216: return UG_PF_Y216;
+        case Y416: return UG_PF_Y416;
+        case VUYA: return UG_PF_VUYA;
+        case DVS10: return UG_PF_DVS10;
         default:   return UG_PF_NONE;
         }
 }
@@ -33,6 +39,12 @@ static inline codec_t ug_codec_from_pixfmt(ug_pixfmt_t f)
         case UG_PF_V210: return v210;
         case UG_PF_RG48: return RG48;
         case UG_PF_I420: return I420;
+        case UG_PF_R10K: return R10k;
+        case UG_PF_R12L: return R12L;
+        case UG_PF_Y216: return Y216;
+        case UG_PF_Y416: return Y416;
+        case UG_PF_VUYA: return VUYA;
+        case UG_PF_DVS10: return DVS10;
         default:         return VIDEO_CODEC_NONE;
         }
 }

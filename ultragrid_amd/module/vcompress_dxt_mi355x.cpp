@@ -11,16 +11,20 @@
  *
  * What is different from cuda_dxt.cpp by design (MI355X-first):
  *  - no CPU decoder_t pre-pass (cuda_dxt.cpp:206-220) and no 4:2:2->4:4:4 intermediate (cuda_dxt.cpp:223-232): the frame is
- *    uploaded in its wire format (RGB / RGBA / UYVY / v210, YUYV and BGR via a device-side swizzle) and unpacked +
- *    colour-converted + encoded by ONE fused kernel; device-resident frames are encoded in place;
+ *    uploaded in its wire format.  The module takes EVERY codec cuda_dxt.cpp takes -- whatever get_best_decoder_from(codec,
+ *    {RGB, UYVY}) can reach (cuda_dxt.cpp:152-158, pixfmt_conv.c:3126-3172): RGB, RGBA, BGR, UYVY, YUYV, v210, R10k, R12L, RG48,
+ *    Y216, Y416, VUYA, DVS10 -- and produces the bytes the reference's "line decoder, then encoder" sequence would: RGB, RGBA,
+ *    UYVY and v210 (any width % 4 == 0) are unpacked + colour-converted + encoded by ONE fused kernel, the others go through the
+ *    same decoders[] arithmetic on the device (ug_hip_pixfmt_convert to the codec ug_hip_pixfmt_best picks, == the reference's
+ *    choice) and then the fused kernel; device-resident frames are encoded in place;
  *  - one HIP stream per encoder state, asynchronous H2D -> kernel -> D2H, a single stream synchronisation per tile
  *    (cuda_dxt.cu:759 synchronises after every launch);
  *  - devices come from the module option dev=<n>[,<n>...] (default 0); UltraGrid's -D list is capped at MAX_CUDA_DEVICES = 4
  *    (host.h:97), too small for an 8-GPU MI355X node.  Frames are dealt to one worker thread per listed device and delivered
  *    in order -- frames are independent, there is no inter-GPU traffic.
  *
- * There is deliberately no CPU fallback: if the GPU path cannot take a format, the module says
- * so and drops the frame (video_compress.cpp:394-398 semantics).
+ * There is deliberately no CPU fallback: a codec the reference refuses too (no decoder to RGB or UYVY: compressed and planar
+ * codecs) is refused with the reference's message and the frame is dropped (video_compress.cpp:394-398 semantics).
  */
 #include <atomic>
 #include <cstdio>
@@ -71,6 +75,7 @@ struct state_video_compress_dxt_mi355x {
         int               device = 0;
         codec_t           out_codec = DXT1;
         ug_dxt_t          out_fmt = UG_DXT1;
+        int               ties = UG_DXT_TIES_DEFAULT; ///< ties=even|away (include/ug_mi355x.h UG_DXT_TIES_*)
         ug_pixfmt_t       in_fmt = UG_PF_NONE;      ///< format the encoder kernel reads
         ug_pixfmt_t       pre_in = UG_PF_NONE;      ///< != NONE: device-side conversion first (YUYV->UYVY, BGR->RGB, DXT1_YUV: anything->UYVY)
         ug_pixfmt_t       pre_out = UG_PF_NONE;     ///< its target format
@@ -95,9 +100,11 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>]\n"
+               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:ties=even|away]\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
-               "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n");
+               "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n"
+               "\t\tties - what GLSL leaves to the implementation in the reference's encoder shaders: even (default) = round() ties to\n"
+               "\t\t       even, as the shaders compute on Mesa; away = roundf(), as the reference's CUDA port is written\n");
 }
 
 void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
@@ -129,6 +136,10 @@ void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
                         if (devs.empty()) devs.push_back(0);
                         static std::atomic<unsigned> instance_counter{0}; // one init per tile: deal the instances out
                         s->device = devs[instance_counter++ % devs.size()];
+                } else if (strcasecmp(tok.c_str(), "ties=even") == 0) {
+                        s->ties = UG_DXT_TIES_EVEN;
+                } else if (strcasecmp(tok.c_str(), "ties=away") == 0) {
+                        s->ties = UG_DXT_TIES_AWAY;
                 } else if (tok == "help") {
                         usage();
                         delete s;
@@ -157,34 +168,37 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
         cleanup(s);
         s->pre_in = s->pre_out = UG_PF_NONE;
         const ug_pixfmt_t wire = ug_pixfmt_from_codec(desc.color_spec);
-        if (s->out_codec == DXT1_YUV) {
-                // The DXT1 encoder runs on the 4:2:2 samples themselves (chroma replicated, no colour conversion:
-                // dxt_encoder.c:318-323); its only input is UYVY (dxt_glsl.cpp:104-110), everything else is converted to UYVY
-                // first -- here with the same pixfmt_conv.c arithmetic, on the device.
-                s->in_fmt = UG_PF_UYVY_RAW;
-                if (wire != UG_PF_UYVY) {
-                        if (wire == UG_PF_NONE || !ug_hip_pixfmt_supported(wire, UG_PF_UYVY)) {
-                                MSG(ERROR, "Unsupported codec for DXT1_YUV: %s\n", get_codec_name(desc.color_spec));
-                                return false;
-                        }
-                        s->pre_in = wire;
-                        s->pre_out = UG_PF_UYVY;
-                }
-        } else {
-                switch (wire) {
-                case UG_PF_RGB: case UG_PF_RGBA: case UG_PF_UYVY: case UG_PF_V210:
-                        s->in_fmt = wire;
-                        break;
-                case UG_PF_YUYV: s->pre_in = wire; s->pre_out = s->in_fmt = UG_PF_UYVY; break;
-                case UG_PF_BGR:  s->pre_in = wire; s->pre_out = s->in_fmt = UG_PF_RGB;  break;
-                default:
-                        MSG(ERROR, "Unsupported codec: %s (GPU path takes RGB, RGBA, BGR, UYVY, YUYV, v210)\n",
-                            get_codec_name(desc.color_spec));
-                        return false;
-                }
+        // The reference converts the wire format on the CPU to what get_best_decoder_from(codec, {RGB, UYVY}) ranks first
+        // (cuda_dxt.cpp:152-158; DXT1_YUV: UYVY only, dxt_glsl.cpp:104-110) and encodes that.  ug_hip_pixfmt_best is the same
+        // ranking over the same decoders[] table (equal to the compiled reference on random candidate sets, tests/), so `target`
+        // is the codec the reference would encode from.
+        const ug_pixfmt_t cand_dxt[] = { UG_PF_RGB, UG_PF_UYVY, UG_PF_NONE }, cand_yuv[] = { UG_PF_UYVY, UG_PF_NONE };
+        ug_pixfmt_t target = UG_PF_NONE;
+        if (wire == UG_PF_NONE || wire == UG_PF_I420 ||
+            ug_hip_pixfmt_best(wire, s->out_codec == DXT1_YUV ? cand_yuv : cand_dxt, &target) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "Unsupported codec: %s\n", get_codec_name(desc.color_spec)); // cuda_dxt.cpp:155-157
+                return false;
         }
-        if (desc.width % 4 != 0 || desc.height % 4 != 0 || (s->in_fmt == UG_PF_V210 && desc.width % 12 != 0)) {
-                MSG(ERROR, "Frame size %ux%u is not a multiple of the 4x4 block (v210: 12x4)\n", desc.width, desc.height);
+        // What the fused kernel reads natively gives the same bytes as "decode to target, then encode": RGBA -> RGB only drops
+        // alpha (vc_copylineRGBAtoRGB), v210 -> UYVY is the >> 2 the v210 loader applies (vc_copylinev210, incl. its partial-group
+        // tail: any width % 4 == 0).  Everything else is converted to `target` on the device first, with the decoders[] arithmetic.
+        const bool fused = wire == target || (wire == UG_PF_RGBA && target == UG_PF_RGB) || (wire == UG_PF_V210 && target == UG_PF_UYVY);
+        if (fused) {
+                s->in_fmt = wire;
+        } else {
+                s->pre_in = wire;
+                s->pre_out = s->in_fmt = target;
+        }
+        if (s->out_codec == DXT1_YUV && s->in_fmt == UG_PF_UYVY) {
+                // DXT1 over the 4:2:2 samples themselves (chroma replicated, no colour conversion: dxt_encoder.c:318-323)
+                s->in_fmt = UG_PF_UYVY_RAW;
+        } else if (s->out_codec == DXT1_YUV) { // v210: the encoder's v210 loader colour-converts, so go through UYVY here
+                s->pre_in = wire;
+                s->pre_out = UG_PF_UYVY;
+                s->in_fmt = UG_PF_UYVY_RAW;
+        }
+        if (desc.width % 4 != 0 || desc.height % 4 != 0) { // cuda_dxt.cu:745
+                MSG(ERROR, "Frame size %ux%u is not a multiple of the 4x4 block\n", desc.width, desc.height);
                 return false;
         }
         if (get_bits_per_component(desc.color_spec) > 8) {
@@ -228,7 +242,9 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
         // Device-resident frame (mem_location == CUDA_MEM, types.h:295-298; the tile fan-out of video_compress.cpp drops that flag,
         // so the pointer itself is asked as well): no upload -- the kernels read it in place (gpujpeg.cpp:617-622 does the same).
         const void *enc_src = s->dev_in;
-        if ((tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data)) && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
+        // In place only when the frame lives on THIS state's GPU: with dev=<list> / several workers a frame can be handed to a
+        // worker of another device, whose kernels must not dereference foreign memory -- that one is copied over (peer copy).
+        if (ug_hip_pointer_device(tx->tiles[0].data) == s->device && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
                 enc_src = tx->tiles[0].data;
         } else {
                 const bool dev = tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data);
@@ -241,7 +257,7 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
                           "device swizzle failed", return {});
                 enc_src = s->dev_pre;
         }
-        CHECK_HIP(ug_hip_dxt_encode(s->in_fmt, s->out_fmt, enc_src, s->dev_out, w, h, 0, s->stream),
+        CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, enc_src, s->dev_out, w, h, 0, 1, 0, 0, s->ties, s->stream),
                   "Encoding failed", return {});
 
         std::shared_ptr<video_frame> out = s->pool.get_frame();

@@ -48,10 +48,11 @@ struct state_video_compress_jpeg_mi355x {
         int                  device = 0, quality = 75, restart = 2;
         int                  subsampling = 0;  ///< 0 = autoselect: that of the input codec (gpujpeg.cpp:168,295-302)
         ug_pixfmt_t          wire = UG_PF_NONE;     ///< format of the uploaded frame
+        ug_pixfmt_t          target = UG_PF_NONE;   ///< what the reference's CPU line decoder would convert it to (UYVY, RGB or RGBA)
         ug_pixfmt_t          enc_in = UG_PF_NONE;   ///< what the encoder is fed: UYVY, RGB or I420
         ug_hip_stream_t      stream = nullptr;
         ug_hip_jpeg_encoder *enc = nullptr;
-        void                *dev_in = nullptr, *dev_uyvy = nullptr, *dev_out = nullptr;
+        void                *dev_in = nullptr, *dev_target = nullptr, *dev_uyvy = nullptr, *dev_out = nullptr;
         size_t               in_len = 0, max_out = 0;
         video_frame_pool     pool{0, hip_pinned_allocator()};
 };
@@ -59,7 +60,7 @@ struct state_video_compress_jpeg_mi355x {
 void cleanup(state_video_compress_jpeg_mi355x *s)
 {
         if (s->enc) { ug_hip_jpeg_encoder_destroy(s->enc); s->enc = nullptr; }
-        for (void **p : { &s->dev_in, &s->dev_uyvy, &s->dev_out }) {
+        for (void **p : { &s->dev_in, &s->dev_target, &s->dev_uyvy, &s->dev_out }) {
                 if (*p) { ug_hip_free(*p); *p = nullptr; }
         }
 }
@@ -68,8 +69,9 @@ void usage()
 {
         printf("MI355X JPEG compression usage:\n"
                "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:dev=<index>[,<index>...]][:workers=<per device>]\n"
-               "\t\tsubsampling - JPEG subsampling; default = that of the input: 422 for UYVY/YUYV/v210, 444 (R,G,B components)\n"
-               "\t\t              for RGB/RGBA/BGR, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
+               "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
+               "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
+               "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
 }
 
 void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
@@ -126,29 +128,39 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
 {
         cleanup(s);
         s->wire = ug_pixfmt_from_codec(desc.color_spec);
-        // What the encoder is fed and which sampling it codes (gpujpeg.cpp:227-236,295-305,333-344): autoselect = the input
-        // codec's own subsampling; RGB-family input stays R,G,B in 4:4:4, 4:2:2 input is coded as 4:2:2 (or 4:2:0 on request),
-        // I420 passes through.  RGB-family input with subsampling=422/420 goes through the pixfmt_conv.c RGB->UYVY arithmetic.
-        const bool rgb_family = codec_is_a_rgb(desc.color_spec);
-        int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (desc.color_spec == I420 ? 420 : 422));
+        s->target = s->wire;
+        // What the encoder is fed and which sampling it codes, as the reference decides it (gpujpeg.cpp:227-236,262-272,295-305,
+        // 333-344): I420 passes through; everything else is converted to what get_best_decoder_from(codec, {UYVY, RGB, RGBA}) ranks
+        // first (ug_hip_pixfmt_best: same ranking, same decoders[] table) -- here on the device, with the same arithmetic -- and
+        // autoselect codes that codec's own subsampling: R,G,B 4:4:4 for an RGB-family target (R10k, R12L, RG48, but also Y416 and
+        // VUYA: the ranking puts subsampling before colour space), 4:2:2 for UYVY (v210, Y216, YUYV, DVS10).  An RGBA target is fed as
+        // RGB (the pad byte is ignored by GPUJPEG's 444_U8_P012Z too).  RGB-family targets with subsampling=422/420 go through
+        // the pixfmt_conv.c RGB->UYVY arithmetic.
+        bool rgb_family = false;
         if (s->wire == UG_PF_I420) {
                 s->enc_in = UG_PF_I420;
+        } else {
+                const ug_pixfmt_t cand[] = { UG_PF_UYVY, UG_PF_RGB, UG_PF_RGBA, UG_PF_NONE };
+                if (s->wire == UG_PF_NONE || ug_hip_pixfmt_best(s->wire, cand, &s->target) != UG_HIP_SUCCESS) {
+                        MSG(ERROR, "Unsupported codec: %s\n", get_codec_name(desc.color_spec)); // gpujpeg.cpp:267-271
+                        return false;
+                }
+                rgb_family = s->target != UG_PF_UYVY;
+        }
+        const int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (s->wire == UG_PF_I420 ? 420 : 422));
+        if (s->wire == UG_PF_I420) {
                 if (sub != 420) {
                         MSG(ERROR, "I420 input can only be coded as 4:2:0\n");
                         return false;
                 }
         } else if (sub == 444) {
                 s->enc_in = UG_PF_RGB;
-                if (!rgb_family || (s->wire != UG_PF_RGB && !ug_hip_pixfmt_supported(s->wire, UG_PF_RGB))) {
-                        MSG(ERROR, "subsampling=444 needs RGB, RGBA or BGR input, not %s\n", get_codec_name(desc.color_spec));
+                if (!rgb_family) {
+                        MSG(ERROR, "subsampling=444 needs an RGB-family input, not %s\n", get_codec_name(desc.color_spec));
                         return false;
                 }
         } else {
                 s->enc_in = UG_PF_UYVY;
-                if (s->wire != UG_PF_UYVY && !ug_hip_pixfmt_supported(s->wire, UG_PF_UYVY)) {
-                        MSG(ERROR, "Unsupported codec: %s (GPU path takes UYVY, YUYV, v210, I420, RGB, RGBA, BGR, RG48)\n", get_codec_name(desc.color_spec));
-                        return false;
-                }
         }
         s->in_len = s->wire == UG_PF_I420 ? (size_t) desc.width * desc.height + 2 * (size_t) ((desc.width + 1) / 2) * ((desc.height + 1) / 2)
                                           : (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
@@ -161,7 +173,10 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         s->max_out = std::min(ug_hip_jpeg_encoder_max_size(s->enc), (size_t) desc.width * desc.height * 3 + 4096);
         bool ok = ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING) == UG_HIP_SUCCESS &&
                   ug_hip_malloc(&s->dev_out, s->max_out) == UG_HIP_SUCCESS;
-        if (ok && s->wire != s->enc_in) { // staging buffer for the device-side conversion to the encoder's input format
+        if (ok && s->wire != s->target) { // staging buffer for the device-side decoder_t pass (wire -> target)
+                ok = ug_hip_malloc(&s->dev_target, (size_t) vc_get_linesize(desc.width, ug_codec_from_pixfmt(s->target)) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
+        }
+        if (ok && s->target != s->enc_in) { // and for target -> encoder input (RGBA -> RGB; RGB-family -> UYVY on subsampling=422/420)
                 ok = ug_hip_malloc(&s->dev_uyvy, (size_t) vc_get_linesize(desc.width, s->enc_in == UG_PF_RGB ? RGB : UYVY) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
         }
         if (!ok) {
@@ -194,18 +209,25 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
                 }
         }
         const int w = (int) tx->tiles[0].width, h = (int) tx->tiles[0].height;
-        // device-resident frame (types.h:295-298; gpujpeg.cpp:617-622): used in place, no upload
+        // device-resident frame (types.h:295-298; gpujpeg.cpp:617-622): used in place, no upload -- when it lives on this state's GPU
         const bool on_dev = tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data);
         const void *enc_src = s->dev_in;
-        if (on_dev && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
+        if (ug_hip_pointer_device(tx->tiles[0].data) == s->device && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
                 enc_src = tx->tiles[0].data;
         } else if (ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, on_dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE,
                                        s->stream) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "upload failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
-        if (s->wire != s->enc_in) {
-                if (ug_hip_pixfmt_convert(s->wire, s->enc_in, enc_src, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
+        if (s->wire != s->target) {
+                if (ug_hip_pixfmt_convert(s->wire, s->target, enc_src, s->dev_target, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
+                        MSG(ERROR, "device conversion %s -> %s failed: %s\n", get_codec_name(tx->color_spec), get_codec_name(ug_codec_from_pixfmt(s->target)), ug_hip_last_error_string());
+                        return {};
+                }
+                enc_src = s->dev_target;
+        }
+        if (s->target != s->enc_in) {
+                if (ug_hip_pixfmt_convert(s->target, s->enc_in, enc_src, s->dev_uyvy, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
                         MSG(ERROR, "device conversion to the encoder input format failed: %s\n", ug_hip_last_error_string());
                         return {};
                 }
@@ -268,6 +290,13 @@ const struct video_compress_info jpeg_mi355x_info = {
         get_jpeg_mi355x_module_info,
 };
 
-REGISTER_MODULE(jpeg, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+// Always reachable as "jpeg_mi355x".  The short name "jpeg" is the hidden alias the reference gives its GPUJPEG module
+// (gpujpeg.cpp:791-792, REGISTER_HIDDEN_MODULE(jpeg, ...)): in a build that contains that module (config.h: HAVE_GPUJPEG,
+// configure.ac:2673) the two registrations would collide in lib_common's registry and "-c jpeg" would resolve to whichever
+// constructor ran first, so the alias is taken only when GPUJPEG is absent -- then "-c jpeg" is this module, as a drop-in.
+REGISTER_MODULE(jpeg_mi355x, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+#ifndef HAVE_GPUJPEG
+REGISTER_HIDDEN_MODULE(jpeg, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+#endif
 
 } // end of anonymous namespace

@@ -1,0 +1,110 @@
+"""Host-side frame pipeline of one GPU, as the UltraGrid modules drive it (module/mi355x_frame_sharder.h: `workers` frames in
+flight per device, each on its own stream): pinned host frame -> H2D -> fused encode kernel -> D2H of the compressed frame.
+Used by bench.py's `e2e` leg and tools/e2e_bench.py to measure the PCIe-inclusive rate (never bench.py's `value`).
+torch = device memory, pinned memory and streams only; the kernel goes through the C ABI (ultragrid_amd/codec.py)."""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import codec, lib, synth
+
+WORKLOADS = {
+    "8k-v210": ("v210", lib.PF_V210, lib.DXT5_YCOCG, 7680, 4320),     # BASELINE.json configs[4]
+    "4k-uyvy": ("UYVY", lib.PF_UYVY, lib.DXT5_YCOCG, 3840, 2160),     # configs[2]
+    "1080p-rgb-dxt1": ("RGB", lib.PF_RGB, lib.DXT1, 1920, 1080),      # configs[1]
+}
+
+
+def gpu_numa_node(device_index: int) -> int:
+    """NUMA node of the GPU's PCIe function (sysfs), -1 if unknown."""
+    try:
+        bdf = torch.cuda.get_device_properties(device_index).pci_bus_id
+    except Exception:
+        try:
+            import ctypes as C
+            buf = C.create_string_buffer(64)
+            hip = C.CDLL("libamdhip64.so")
+            if hip.hipDeviceGetPCIBusId(buf, 64, device_index) != 0:
+                return -1
+            bdf = buf.value.decode()
+        except Exception:
+            return -1
+    for cand in (bdf.lower(), "0000:" + bdf.lower() if bdf.count(":") == 1 else bdf.lower()):
+        p = f"/sys/bus/pci/devices/{cand}/numa_node"
+        if os.path.exists(p):
+            try:
+                return int(open(p).read().strip())
+            except ValueError:
+                return -1
+    return -1
+
+
+def bind_to_numa_node(node: int) -> int:
+    """Restrict this process to the CPUs of `node` (so that first-touch puts the pinned frames into node-local DRAM and the
+    submitting thread runs beside them).  Returns the number of CPUs bound to, 0 if nothing was changed."""
+    if node < 0 or not hasattr(os, "sched_setaffinity"):
+        return 0
+    p = f"/sys/devices/system/node/node{node}/cpulist"
+    if not os.path.exists(p):
+        return 0
+    cpus = set()
+    for part in open(p).read().strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    cpus &= os.sched_getaffinity(0)
+    if not cpus:
+        return 0
+    os.sched_setaffinity(0, cpus)
+    return len(cpus)
+
+
+def host_frame(workload: str, salt: int = 0) -> np.ndarray:
+    fmt, _, _, w, h = WORKLOADS[workload]
+    gen = synth.s1_random if fmt == "RGB" else synth.s2_video
+    one = gen(fmt, w, 48, salt=salt)
+    ls = one.size // 48
+    return np.tile(one.reshape(48, ls), (h // 48, 1)).ravel().copy()
+
+
+def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_frames: int = 30, distinct: int = 3, salt: int = 0) -> dict:
+    """`depth` frames in flight (one stream each: H2D, encode, D2H), `distinct` different pinned input frames cycled.
+    Runs for about `seconds`; returns fps, Mpixel/s and the PCIe traffic both ways."""
+    fmt, pf, oid, w, h = WORKLOADS[workload]
+    lib.load()
+    srcs = [torch.from_numpy(host_frame(workload, salt + i)).pin_memory() for i in range(distinct)]
+    in_len = srcs[0].numel()
+    out_len = codec.dxt_size(oid, w, h)
+    slots = [dict(st=torch.cuda.Stream(), dev_in=torch.empty(in_len, dtype=torch.uint8, device="cuda"),
+                  dev_out=torch.empty(out_len, dtype=torch.uint8, device="cuda"),
+                  host_out=torch.empty(out_len, dtype=torch.uint8).pin_memory(), busy=False) for _ in range(depth)]
+
+    def submit(s, i):
+        with torch.cuda.stream(s["st"]):
+            s["dev_in"].copy_(srcs[i % distinct], non_blocking=True)
+            codec.dxt_encode(pf, oid, s["dev_in"], w, h, dst=s["dev_out"])
+            s["host_out"].copy_(s["dev_out"], non_blocking=True)
+        s["busy"] = True
+
+    for i, s in enumerate(slots):   # warm-up
+        submit(s, i)
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while n < min_frames or time.perf_counter() - t0 < seconds:
+        s = slots[n % depth]
+        if s["busy"]:
+            s["st"].synchronize()
+        submit(s, n)
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fps = n / dt
+    return {"workload": workload, "fps": round(fps, 1), "mpixels_per_s": round(w * h * fps / 1e6, 1), "frames": n, "seconds": round(dt, 3),
+            "in_flight": depth, "pcie_gbs": round((in_len + out_len) * fps / 1e9, 2), "h2d_gbs": round(in_len * fps / 1e9, 2),
+            "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len}
