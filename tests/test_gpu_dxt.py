@@ -295,7 +295,7 @@ def test_shipped_library_reproduces_the_reference_glsl_shaders(hip, po):
             got = hip.dxt_encode(L.PF_NAMES[fmt], L.DXT5_YCOCG if mode == "dxt5" else L.DXT1, torch.from_numpy(src).cuda(), 512, 128).cpu().numpy()
             assert np.array_equal(got, gold["big_%s_%s" % (fmt, mode)]), (fmt, mode)
             n += got.size
-    assert n > 1_000_000
+    assert n > 250_000   # bytes of compressed blocks compared with the executed shaders
     assert total > 7000 and 0.97 < same_away / total < 1.0, (same_away, total)   # S3 (flat colour bars) sits on round() ties in every white block
 
 

@@ -22,24 +22,16 @@ WORKLOADS = {
 def gpu_numa_node(device_index: int) -> int:
     """NUMA node of the GPU's PCIe function (sysfs), -1 if unknown."""
     try:
-        bdf = torch.cuda.get_device_properties(device_index).pci_bus_id
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
     except Exception:
+        return -1
+    p = f"/sys/bus/pci/devices/{bdf}/numa_node"
+    if os.path.exists(p):
         try:
-            import ctypes as C
-            buf = C.create_string_buffer(64)
-            hip = C.CDLL("libamdhip64.so")
-            if hip.hipDeviceGetPCIBusId(buf, 64, device_index) != 0:
-                return -1
-            bdf = buf.value.decode()
-        except Exception:
+            return int(open(p).read().strip())
+        except ValueError:
             return -1
-    for cand in (bdf.lower(), "0000:" + bdf.lower() if bdf.count(":") == 1 else bdf.lower()):
-        p = f"/sys/bus/pci/devices/{cand}/numa_node"
-        if os.path.exists(p):
-            try:
-                return int(open(p).read().strip())
-            except ValueError:
-                return -1
     return -1
 
 
