@@ -113,14 +113,10 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
         if dist is not None:
             dist.barrier()
         r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank)
-        per = [r["fps"]]
-        pcie = [r["pcie_gbs"]]
-        if dist is not None:
-            t = torch.tensor([r["fps"], r["pcie_gbs"]], dtype=torch.float64, device=device_for_gather)
-            parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-            dist.all_gather(parts, t)
-            per = [round(float(p[0]), 1) for p in parts]
-            pcie = [round(float(p[1]), 2) for p in parts]
+        from ultragrid_amd import shard
+        rates = shard.gather_rates([r["fps"], r["pcie_gbs"]], dist, device_for_gather)
+        per = [round(x[0], 1) for x in rates]
+        pcie = [round(x[1], 2) for x in rates]
         w, h = pipeline.WORKLOADS[wl][3], pipeline.WORKLOADS[wl][4]
         res[wl] = {"fps_total": round(sum(per), 1), "fps_per_gpu": per, "mpixels_per_s_total": round(sum(per) * w * h / 1e6, 1),
                    "pcie_gbs_total": round(sum(pcie), 2), "pcie_gbs_per_gpu": pcie, "in_flight": r["in_flight"],
@@ -223,16 +219,13 @@ def main() -> None:
         torch.cuda.synchronize()
         est = c0.elapsed_time(c1) / (4 * B)
         L = max(B, int(np.ceil(50.0 / max(est, 1e-3) / B)) * B)
-    if dist is not None:   # same step on every rank
-        t = torch.tensor([L], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        L = int(t.item())
+    from ultragrid_amd import shard
+    L = shard.agree_max(L, dist, coll_dev)   # same step on every rank
 
     def step():
         for i in range(L):
             launch(i % B)
 
-    from ultragrid_amd import shard
     for _ in range(args.warmup):
         step()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

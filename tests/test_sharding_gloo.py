@@ -32,11 +32,20 @@ def _worker(rank, world, port, q):
             out.append((seq, po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, synth.s1_random("UYVY", W, H, salt=seq), W, H).tobytes()))
 
     wall = shard.timed_steps(step, 2, lambda: None, dist)
+    # what bench.py exchanges besides the barrier: the agreed step size and the per-rank rates of the e2e leg
+    agreed = shard.agree_max(100 + 7 * rank, dist)
+    rates = shard.gather_rates([10.0 * (rank + 1), 0.5 * (rank + 1)], dist)
+    assert agreed == 100 + 7 * (world - 1)
+    assert rates == [[10.0 * (r + 1), 0.5 * (r + 1)] for r in range(world)]
     gathered = [None] * world
     dist.all_gather_object(gathered, out)   # test-only gather; the product never exchanges frame data between ranks
     if rank == 0:
         q.put((wall, gathered))
     dist.destroy_process_group()
+
+
+def test_rate_helpers_without_a_process_group():
+    assert shard.gather_rates([3.0, 1.5]) == [[3.0, 1.5]] and shard.agree_max(42) == 42
 
 
 def test_round_robin_assignment():

@@ -53,3 +53,25 @@ def timed_steps(step: Callable[[], None], steps: int, sync: Callable[[], None], 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall
+
+
+def gather_rates(local: Sequence[float], dist=None, device=None) -> List[List[float]]:
+    """Per-rank rate vectors (fps, GB/s ...) of a leg every rank ran at the same time -> [[rank0...], [rank1...], ...] on every
+    rank.  The only thing ranks ever exchange besides the timing barrier: a handful of numbers, never frame data."""
+    import torch
+    if dist is None:
+        return [list(map(float, local))]
+    t = torch.tensor(list(local), dtype=torch.float64, device=device or "cpu")
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [[float(x) for x in p.tolist()] for p in parts]
+
+
+def agree_max(value: int, dist=None, device=None) -> int:
+    """The same integer on every rank (the maximum): ranks calibrate their step size locally and must then run the SAME step."""
+    import torch
+    if dist is None:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
