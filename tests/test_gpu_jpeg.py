@@ -339,3 +339,53 @@ def test_batched_front_end_equals_per_frame(hip, po, sub, dims):
     assert np.array_equal(ocb[2].cpu().numpy(), po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh))
     assert L.load().ug_hip_uyvy_to_jpeg42x_coeffs_batch(411, src.data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), n, fb,
                                                         ybl * nb * 128, nb * 128, None) == L.EINVAL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub", [420, 422, 444])
+def test_block_parallel_coder_equals_wave_per_segment_coder(hip, po, sub, monkeypatch):
+    """The two entropy coders of the library -- one lane per block (segments of <= 64 blocks), one wave per segment (any length; forced
+    with UG_JPEG_WAVE_KERNEL=1) -- must produce the same stream for every restart interval: segments that fill a wave exactly, leave
+    lanes idle, end short at the end of the picture, and the lengths only the wave coder takes."""
+    import torch
+    w, h = 208, 88   # 13 x 6 MCUs (4:2:0): a short last segment for most intervals
+    src = synth.s2_video("UYVY", w, h) if sub != 444 else synth.s1_random("RGB", w, h)
+    noisy = synth.s1_random("UYVY" if sub != 444 else "RGB", w, h, salt=3)
+    fmt = hip.L.PF_UYVY if sub != 444 else hip.L.PF_RGB
+    for q, frame in ((75, src), (100, noisy), (20, src)):    # q = 100 on noise: > 64 bytes per block, the multi-pass variant
+        dev = torch.from_numpy(frame).cuda()
+        for ri in (1, 2, 3, 4, 5, 7, 10, 16, 21, 22, 40):
+            monkeypatch.delenv("UG_JPEG_WAVE_KERNEL", raising=False)
+            a = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+            da = a.encode(dev, fmt)
+            a.close()
+            monkeypatch.setenv("UG_JPEG_WAVE_KERNEL", "1")
+            b = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+            db = b.encode(dev, fmt)
+            b.close()
+            assert da == db, (sub, q, ri, len(da), len(db))
+        if q == 100:
+            assert len(da) > 64 * (w // 8) * (h // 8)   # more than 64 B per luma block on average: windows overflow, several passes
+
+
+@pytest.mark.gpu
+def test_block_parallel_coder_full_4k_frame(hip, po):
+    """configs[3] size: a whole 3840x2160 frame (8100 segments at restart 4), both coders, identical streams, decodable."""
+    import io
+    import os
+    import torch
+    from PIL import Image
+    w, h = 3840, 2160
+    dev = torch.from_numpy(synth.s2_video("UYVY", w, h)).cuda()
+    a = hip.JpegEncoder(w, h, 75, 4)
+    da = a.encode(dev)
+    a.close()
+    os.environ["UG_JPEG_WAVE_KERNEL"] = "1"
+    try:
+        b = hip.JpegEncoder(w, h, 75, 4)
+        db = b.encode(dev)
+        b.close()
+    finally:
+        del os.environ["UG_JPEG_WAVE_KERNEL"]
+    assert da == db
+    assert Image.open(io.BytesIO(da)).size == (w, h)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 counter passes over the JPEG encoder (tools/jpeg_profile.py); GPU box.  Output: gpurun_out/pmc_jpeg/summary.txt
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_jpeg
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/tools/jpeg_profile.py 3840 2160 ${RI:-4}"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT -o sq1 -- $CMD > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT -o sq2 -- $CMD > $OUT/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_ATOMIC_RETURN SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL -d $OUT -o sq3 -- $CMD > $OUT/sq3.log 2>&1
+python $ROOT/tools/pmc_summary.py $OUT/*.db 2>&1 | grep -v "copyBuffer" > $OUT/summary.txt
+grep -iE "error|invalid|not found|fail" $OUT/*.log | head -5
+grep "entropy_block\|^==" $OUT/summary.txt

@@ -8,6 +8,7 @@
 // Restart intervals make the scan data-parallel: every segment starts byte-aligned with DC predictors reset, so
 // segments are coded independently (one lane per segment), then compacted by a prefix sum over segment sizes.
 // The byte stream is identical to the test writer tests/jpeg_bitstream.py, which Pillow/libjpeg decodes.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -199,6 +200,323 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Block-parallel Huffman coding (the default when a restart segment has at most 64 blocks, i.e. restart interval <= 10 MCUs for
+// 4:2:0, <= 16 for 4:2:2, <= 21 for 4:4:4): one LANE PER BLOCK, a wave = the G = 64 / S whole segments that fit its lanes
+// (S = blocks per segment).  The wave-per-segment kernel above spends ~230 wave instructions per block on one block at a time;
+// here 64 blocks share every instruction:
+//   1. each lane loads its block (64 int16 = 8 x 16 B, zig-zag order as the FDCT kernels write them) into 32 registers;
+//      the DC predictor comes from the lane that holds the previous block of the same component (ds_bpermute);
+//   2. length walk: a fully unrolled pass over the 63 AC coefficients (static register indices) adds up the block's code
+//      length -- groups of 8 coefficients that are zero in all 64 blocks are skipped with one scalar branch;
+//   3. a wave prefix sum, made segment-relative, gives every block its bit position in its segment;
+//   4. emission walk: the same pass again, appending code + value bits to a 64-bit accumulator whose full words are OR-ed
+//      (ds_or_b32) into the segment's window in LDS;
+//   5. the windows are padded with 1-bits to a byte, flushed byte-swapped with coalesced stores, 0xFF bytes counted.
+// Output (unstuffed scan bytes per segment, seg_len, seg_ff) is exactly what the wave-per-segment kernel produces.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS window of the block-parallel coder: 64 bytes per block on average (a 4K q75 frame needs ~10); a wave whose segments
+// need more goes through its window in several passes
+constexpr int kWinWordsPerBlock = 16;
+
+// coefficients per skip group of the walks (a group that is zero in all 64 blocks of the wave costs one scalar branch)
+#ifndef UG_JPEG_WALK_GROUP
+#define UG_JPEG_WALK_GROUP 8 // 4 measures the same on 4K S2 content at q75 (23.7 vs 23.1 us)
+#endif
+constexpr int kWalkGroup = UG_JPEG_WALK_GROUP;
+
+// Per-lane bit accumulator of the emission walk.  Branch-free: a lane that appends nothing shifts in zero bits, and a lane whose
+// accumulator has not filled a word ORs 0 into its current window word -- every lane runs the same instructions.
+// MULTI = false: the whole segment fits its window, `word` walks through it.  MULTI = true (a segment longer than its window:
+// near-lossless quality on noise): the window shows words [lo_idx, lo_idx + cap) of the segment in this pass; words outside it
+// go to a spare word nobody reads.
+template <bool MULTI>
+struct BitSink {
+        uint32_t hi, lo;   // 64-bit accumulator, left-aligned: the next bit goes to position 63 - fill
+        uint32_t fill;     // < 32 between appends
+        uint32_t *word;    // !MULTI: window word the top half of the accumulator belongs to; MULTI: the segment's window
+        uint32_t idx, lo_idx, cap; // MULTI: segment-relative index of that word; the range the window shows
+        uint32_t *spare;
+        __device__ __forceinline__ uint32_t *target() const
+        {
+                if (!MULTI) return word;
+                const uint32_t rel = idx - lo_idx;
+                return rel < cap ? word + rel : spare;
+        }
+        __device__ __forceinline__ void append(uint32_t str, uint32_t n) // n <= 27 bits; n == 0 (with str == 0) appends nothing
+        {
+                const uint32_t t = fill + n;
+                const unsigned long long sh = (unsigned long long) str << ((64u - t) & 63u); // t == 0: str == 0, any shift will do
+                hi |= (uint32_t) (sh >> 32);
+                lo |= (uint32_t) sh;
+                const uint32_t fl = t >> 5, m = 0u - fl; // fl = 1: the top word is complete
+                atomicOr(target(), hi & m);
+                hi = (lo & m) | (hi & ~m);
+                lo &= ~m;
+                fill = t & 31u;
+                if (MULTI) idx += fl;
+                else word += fl;
+        }
+        __device__ __forceinline__ void finish() { atomicOr(target(), hi); } // the last, partial word (0 if the block ended on a word boundary)
+};
+
+__device__ __forceinline__ int coef_at(const uint32_t (&w)[32], int k)
+{
+        return (k & 1) ? (int) w[k >> 1] >> 16 : (int) (w[k >> 1] << 16) >> 16;
+}
+
+// One pass over the 63 AC coefficients of every lane's block (static register indices).  EMIT = false: returns the number of bits
+// the AC part of the block codes to (EOB included) and sets `zrl_seen` if the block needs a ZRL symbol (a zero run longer than 15).
+// EMIT = true: appends the codes to `sink`; ZRL = false is the common variant for waves in which no block needs a ZRL symbol.
+// `tab` = the lane's AC table with the entries of EOB (0x00) and ZRL (0xF0) zeroed: a zero coefficient (size 0) then looks up an
+// empty code and appends / counts nothing without any predication.  The pass is cut into groups of 8 coefficients: a group that is
+// zero in all 64 blocks is skipped with one scalar branch, and inside a group there is no control flow at all, so the table
+// look-ups of its 8 coefficients (which depend only on the short `run` chain) are in flight together instead of one LDS latency
+// per coefficient.
+template <bool EMIT, bool ZRL, class Sink>
+__device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, Sink &sink,
+                                               bool &zrl_seen)
+{
+        const uint32_t zl = zrl >> 16, zc = zrl & 0xffffu;
+        uint32_t run = 0, nbits = 0, long_run = 0;
+#pragma unroll
+        for (int g = 0; g < 64 / kWalkGroup; g++) {
+                uint32_t any = g == 0 ? w[0] & 0xffff0000u : w[kWalkGroup / 2 * g]; // the DC value is not an AC coefficient
+#pragma unroll
+                for (int i = 1; i < kWalkGroup / 2; i++) any |= w[kWalkGroup / 2 * g + i];
+                if (__ballot(any != 0) == 0) { // wave-uniform: nobody has a coefficient in this group
+                        run += g == 0 ? kWalkGroup - 1 : kWalkGroup;
+                        continue;
+                }
+#pragma unroll
+                for (int k = g == 0 ? 1 : kWalkGroup * g; k < kWalkGroup * (g + 1); k++) {
+                        const int v = coef_at(w, k);
+                        const uint32_t neg = (uint32_t) (v >> 31);
+                        const uint32_t a = ((uint32_t) v ^ neg) - neg;
+                        const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
+                        const uint32_t e = tab[((run & 15u) << 4) | size];
+                        const uint32_t n = (e >> 16) + size;
+                        if (EMIT) {
+                                if (ZRL) { // 1..3 ZRL symbols in front of this coefficient
+#pragma unroll
+                                        for (uint32_t z = 0; z < 3; z++) {
+                                                const bool on = size != 0 && run > 15 + 16 * z;
+                                                sink.append(on ? zc : 0u, on ? zl : 0u);
+                                        }
+                                }
+                                const uint32_t vb = ((uint32_t) v + neg) & ((1u << size) - 1u); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
+                                sink.append(((e & 0xffffu) << size) | vb, n);
+                        } else {
+                                const uint32_t zruns = size ? run >> 4 : 0u;
+                                long_run |= zruns;
+                                nbits += n + zruns * zl;
+                        }
+                        run = size ? 0u : run + 1u;
+                }
+        }
+        // EOB after the last non-zero coefficient (not when position 63 is coded)
+        if (EMIT) sink.append(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u);
+        else nbits += run ? eob >> 16 : 0u;
+        if (!EMIT) zrl_seen = long_run != 0;
+        return nbits;
+}
+
+__global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
+                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs, int ctab, int ri,
+                                                           int n_seg, int S /* blocks per full segment, <= 64 */, int G /* segments per wave */,
+                                                           uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
+                                                           uint32_t *__restrict__ seg_ff)
+{
+        __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
+        // one buffer, two lives: first the staging area of the block loads (32 rows of 8 x 16 B, 144 B apart so that the row-wise
+        // reads are conflict-free), then the bit windows of the segments (+ one spare word per lane for the multi-pass variant)
+        constexpr int kStageRow = 9; // uint4 per row
+        __shared__ __attribute__((aligned(16))) uint32_t shared_words[32 * kStageRow * 4];
+        static_assert(32 * kStageRow * 4 >= 64 * kWinWordsPerBlock + 64, "window must fit the staging buffer");
+        uint32_t *const win = shared_words;
+        const int lane = threadIdx.x;
+        for (int i = lane; i < 512; i += 64) {
+                const int sym = i & 255;
+                ac_tab[i >> 8][sym] = (sym == 0x00 || sym == 0xF0) ? 0u : kAcTab[i >> 8][sym]; // EOB / ZRL are emitted explicitly
+        }
+        if (lane < 24) dc_tab[lane / 12][lane % 12] = kDcTab[lane / 12][lane % 12];
+        const int ybl = hs * vs, per_mcu = ybl + 2;
+        const int sl = lane / S, j = lane - sl * S;              // segment of the wave, block of the segment
+        const int seg = blockIdx.x * G + sl;
+        const int m_first = seg * ri;
+        const int n_blk = (sl < G && seg < n_seg) ? per_mcu * (min(n_mcu, m_first + ri) - m_first) : 0;
+        const bool active = j < n_blk;
+        const int ml = j / per_mcu, b = j - ml * per_mcu;        // MCU of the segment, block of the MCU
+        const int m = m_first + ml;
+        const int comp = b < ybl ? 0 : ctab;
+        uint32_t w[32];
+        {
+                const int my = m / mcu_w, mx = m - my * mcu_w;
+                const int yrow = vs * my + (hs == 2 ? b >> 1 : 0), ycol = hs * mx + (hs == 2 ? b & 1 : 0);
+                const int16_t *p = b < ybl ? cy + 64 * ((long) yrow * (hs * mcu_w) + ycol) : (b == ybl ? cb : cr) + 64L * m;
+                if (!active) p = cy;
+                // A block is one 128-byte line.  If every lane fetched its own block 16 bytes at a time, each of the 8 load
+                // instructions of the wave would touch 64 different lines and use an eighth of each: 8x the traffic between L2 and
+                // the CU (measured: the kernel then spends two thirds of its time waiting for these loads).  So 8 lanes share a
+                // block -- an instruction fetches 8 whole lines -- and the rows are handed to their owners through LDS.
+                const long off = (const char *) p - (const char *) cy;
+                const int off_lo = (int) off, off_hi = (int) (off >> 32);
+                uint4 *const stage = (uint4 *) shared_words;
+                // two halves of 32 blocks, so that the staging rows take 4.5 KB instead of 9: with the tables that is 6.7 KB per
+                // wave, and all waves of a 4K frame (15.8 per CU) are resident at once instead of leaving a tail of lone waves
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                        uint4 t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                                const int owner = 32 * half + (lane >> 3) + 8 * i; // lane that owns the block this lane helps to fetch
+                                const unsigned lo = (unsigned) __builtin_amdgcn_ds_bpermute(4 * owner, off_lo);
+                                const long hi = __builtin_amdgcn_ds_bpermute(4 * owner, off_hi);
+                                t[i] = ((const uint4 *) ((const char *) cy + ((hi << 32) | (long) lo)))[lane & 7];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) stage[((lane >> 3) + 8 * i) * kStageRow + (lane & 7)] = t[i];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        if ((lane >> 5) == half) {
+#pragma unroll
+                                for (int i = 0; i < 8; i++) {
+                                        uint4 r = stage[(lane & 31) * kStageRow + i];
+                                        if (!active) r = make_uint4(0, 0, 0, 0); // idle lanes must not keep the wave from skipping zero positions
+                                        w[4 * i] = r.x; w[4 * i + 1] = r.y; w[4 * i + 2] = r.z; w[4 * i + 3] = r.w;
+                                }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                }
+        }
+        __syncthreads(); // tables
+        // DC difference: the previous block of the same component sits `back` lanes below (luma: the previous luma block of the
+        // scan -- one lane back, or across the two chroma blocks of the previous MCU; chroma: one MCU back); none at a segment start
+        const int dc = coef_at(w, 0);
+        const int back = b < ybl ? (b > 0 ? 1 : 3) : per_mcu;
+        const bool has_pred = b < ybl ? j > 0 : ml > 0;
+        const int dc_prev = __builtin_amdgcn_ds_bpermute(4 * ((lane - back) & 63), dc);
+        const int diff = dc - (has_pred ? dc_prev : 0);
+        const uint32_t dneg = (uint32_t) (diff >> 31), da = ((uint32_t) diff ^ dneg) - dneg;
+        const uint32_t dsize = 32u - (uint32_t) __clz((int) da);
+        const uint32_t de = dc_tab[comp][dsize];
+        const uint32_t zrl = kAcTab[comp][0xF0], eob = kAcTab[comp][0x00];
+        const uint32_t *const tab = ac_tab[comp];
+        // ---- length walk ----
+        bool zrl_seen = false;
+        uint32_t nbits;
+        {
+                BitSink<false> none = {};
+                nbits = (de >> 16) + dsize + walk_block<false, false>(w, tab, zrl, eob, none, zrl_seen);
+        }
+        if (!active) nbits = 0;
+        // ---- bit position of every block inside its segment ----
+        const int incl = wave_inclusive_scan((int) nbits, lane);
+        const int excl = incl - (int) nbits;
+        const int first_lane = min(sl * S, 63);
+        const int seg_base = __builtin_amdgcn_ds_bpermute(4 * first_lane, excl);
+        const int seg_last = __builtin_amdgcn_ds_bpermute(4 * min(first_lane + max(n_blk, 1) - 1, 63), incl);
+        const int seg_bits = sl < G ? seg_last - seg_base : 0; // total bits of this lane's segment (same in all its lanes)
+        uint32_t *const mywin = win + first_lane * kWinWordsPerBlock; // the segment's window: kWinWordsPerBlock words per block of the segment
+        uint32_t *const spare = win + 64 * kWinWordsPerBlock;
+        const int cap = S * kWinWordsPerBlock;                  // words of a segment's window
+        const int seg_words = (seg_bits + 31) >> 5;
+        const int p0 = excl - seg_base;                          // bit position of this lane's block in its segment
+        const uint32_t dc_vb = ((uint32_t) diff + dneg) & ((1u << dsize) - 1u);
+        const uint32_t dc_str = active ? ((de & 0xffffu) << dsize) | dc_vb : 0u, dc_n = active ? (de >> 16) + dsize : 0u;
+        const bool multi = __any(seg_words > cap);               // some segment of the wave is longer than its window (rare)
+        int passes = 1;
+        if (multi) {
+                int mx = seg_words;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __builtin_amdgcn_ds_bpermute(4 * ((lane + o) & 63), mx));
+                passes = (__builtin_amdgcn_readfirstlane(mx) + cap - 1) / cap;
+        }
+        // zero the words the segment uses in a pass (+ one for the padding), cooperatively: lane j takes words j, j + S, ...
+        auto zero_window = [&](int lo_idx) {
+                if (sl < G) {
+                        const int nw = min(cap, seg_words + 1 - lo_idx);
+                        for (int i = j; i < nw; i += S) mywin[i] = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+        };
+        // pad, flush, count: segment after segment (wave-uniform loop), 64 words at a time
+        auto flush_window = [&](int pass, int lo_idx) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (int s2 = 0; s2 < G; s2++) {
+                        const int sg = blockIdx.x * G + s2;
+                        if (sg >= n_seg) break;
+                        const int fl = s2 * S;
+                        const int bits = __builtin_amdgcn_readlane(seg_bits, fl);
+                        uint32_t *const sw = win + fl * kWinWordsPerBlock;
+                        const int nbytes = (bits + 7) >> 3;
+                        const int padw = (bits >> 5) - lo_idx; // window word that holds the last, partial byte
+                        if (lane == 0 && (bits & 7) && padw >= 0 && padw < cap) { // pad it with 1-bits (T.81 F.1.2.3)
+                                const int pad = 8 - (bits & 7);
+                                sw[padw] |= ((1u << pad) - 1u) << (32 - (bits & 31) - pad);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        uint32_t *const out = raw + (size_t) sg * cap_words;
+                        const int nw = min(cap, ((nbytes + 3) >> 2) - lo_idx); // words of the segment in this pass
+                        int ff = 0;
+                        for (int i = lane; i < nw; i += 64) {
+                                const uint32_t word = sw[i];
+                                out[lo_idx + i] = __builtin_bswap32(word); // stream order in memory
+                                const int valid = min(4, nbytes - 4 * (lo_idx + i)); // bytes of this word that belong to the segment
+                                for (int t = 0; t < valid; t++) ff += ((word >> (24 - 8 * t)) & 0xff) == 0xff;
+                        }
+                        const int ff_all = __builtin_amdgcn_readlane(wave_inclusive_scan(ff, lane), 63);
+                        if (lane == 0) {
+                                uint32_t prev = 0;
+                                if (pass > 0) prev = seg_ff[sg];
+                                seg_ff[sg] = prev + (uint32_t) ff_all + (pass == 0 ? (uint32_t) nbytes + 2u : 0u); // stuffed size + marker
+                                if (pass == 0) seg_len[sg] = (uint32_t) nbytes;
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();
+        };
+        // ---- emission walk (idle lanes hold an all-zero block: they only OR zeros into the spare word) ----
+        if (__builtin_expect(!multi, 1)) {
+                zero_window(0);
+                const bool any_zrl = __any(zrl_seen);
+                if (active) { // idle lanes stay out: 16 of them OR-ing zeros into one spare word would serialise every LDS atomic of the wave
+                        BitSink<false> sink = { 0, 0, (uint32_t) p0 & 31u, mywin + (p0 >> 5), 0, 0, 0, spare };
+                        sink.append(dc_str, dc_n);
+                        if (__builtin_expect(!any_zrl, 1)) {
+                                (void) walk_block<true, false>(w, tab, zrl, eob, sink, zrl_seen);
+                        } else { // some block of the wave has a zero run longer than 15: the variant that can emit ZRL symbols
+                                asm volatile("; ZRL variant" ::: "memory");
+                                (void) walk_block<true, true>(w, tab, zrl, eob, sink, zrl_seen);
+                        }
+                        sink.finish();
+                }
+                flush_window(0, 0);
+        } else {
+                asm volatile("; multi-pass variant" ::: "memory");
+#pragma unroll 1
+                for (int pass = 0; pass < passes; pass++) {
+                        // everything the walk derives from the coefficients is invariant over the passes; left alone, the compiler
+                        // hoists all of it out of this loop (4 values x 63 coefficients: 237 VGPRs for a path that almost never runs)
+#pragma unroll
+                        for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
+                        zero_window(pass * cap);
+                        if (active) {
+                                // words outside this pass's window go to a spare word of the lane's own (no hot spot)
+                                BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) (pass * cap), (uint32_t) cap, spare + lane };
+                                sink.append(dc_str, dc_n);
+                                (void) walk_block<true, true>(w, tab, zrl, eob, sink, zrl_seen);
+                                sink.finish();
+                        }
+                        flush_window(pass, pass * cap);
+                }
+        }
+}
+
 // exclusive prefix sum of the final segment sizes, single workgroup, 4096 elements per pass (one 16-byte load per lane);
 // off[n_seg] = total stream length.  seg_tot is padded to a multiple of 4 entries.
 __global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_tot, int n_seg, uint32_t header_len,
@@ -273,6 +591,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
 
 struct Encoder {
         int width, height, quality, ri, sub, hs, vs, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
+        bool force_wave_kernel; // UG_JPEG_WAVE_KERNEL=1: A/B switch back to the wave-per-segment coder (it remains the path for long restart intervals)
         std::vector<uint8_t> header;
         // device workspace
         float *div;
@@ -356,6 +675,7 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         }
         Encoder *e = new Encoder();
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
+        e->force_wave_kernel = getenv("UG_JPEG_WAVE_KERNEL") != nullptr && getenv("UG_JPEG_WAVE_KERNEL")[0] == '1';
         e->sub = subsampling;
         e->hs = subsampling == 444 ? 1 : 2; e->vs = subsampling == 420 ? 2 : 1; e->ybl = e->hs * e->vs;
         e->mcu_w = (width + 8 * e->hs - 1) / (8 * e->hs); e->mcu_h = (height + 8 * e->vs - 1) / (8 * e->vs); e->n_mcu = e->mcu_w * e->mcu_h;
@@ -442,8 +762,15 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                 return UG_HIP_EUNSUPP;
         }
         if (rc != UG_HIP_SUCCESS) return rc;
-        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs, e->sub == 444 ? 0 : 1, e->ri,
-                           e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
+        const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
+        if (S <= 64 && !e->force_wave_kernel) {
+                const int G = 64 / S;
+                hipLaunchKernelGGL(entropy_block_kernel, dim3((e->n_seg + G - 1) / G), dim3(64), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
+                                   e->sub == 444 ? 0 : 1, e->ri, e->n_seg, S, G, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
+        } else {
+                hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs, e->sub == 444 ? 0 : 1, e->ri,
+                                   e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
+        }
         hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off,
                            e->total_host_dev);
         hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->off,
