@@ -14,7 +14,8 @@ PAIRS = [("DVS10", "v210"), ("R10k", "RGBA"), ("R10k", "RG48"), ("R10k", "Y416")
          ("Y416", "RG48"), ("RGBA", "VUYA"), ("YUYV", "RGB"), ("RGBA", "R10k"), ("UYVY", "Y216"), ("UYVY", "Y416"),
          ("VUYA", "Y416"), ("VUYA", "UYVY"), ("VUYA", "RGB"), ("Y216", "UYVY"), ("Y216", "v210"), ("Y416", "UYVY"), ("Y416", "v210"),
          ("Y416", "R12L"), ("Y416", "R10k"), ("Y416", "RGB"), ("Y416", "RGBA"), ("v210", "Y216"), ("v210", "Y416")]
-SIZES = [(48, 4), (50, 3), (127, 5), (96, 2), (1920, 2), (7, 3), (2, 1)]
+SIZES = [(48, 4), (50, 3), (127, 5), (96, 2), (1920, 2), (7, 3), (2, 1), (1936, 3), (4100, 2)]   # aligned lines take the 128-bit kernels, the others do not
+FILL = 0x5A   # what the destination holds beforehand: bytes a converter leaves alone must still hold it, on both sides
 DEC = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
 
 
@@ -35,6 +36,7 @@ def ref_frame(po, i, o, src, w, h, sh):
     assert fn, (i, o)
     sls, dls, dsz = r.vc_get_linesize(w, ci), r.vc_get_linesize(w, co), r.vc_get_size(w, co)
     out = aligned(dls * h + 64)
+    out[:] = FILL
     for y in range(h):
         DEC(fn)(out.ctypes.data + y * dls, src.ctypes.data + y * sls, dsz, *sh)
     return out[: dls * h], sls, dls
@@ -52,7 +54,7 @@ def run_pair(hip, po, i, o, sizes=SIZES):
             src = aligned(sls * h + 64, rng=np.random.default_rng(100 * k + sh[0]))
             want, sls, dls = ref_frame(po, i, o, src, w, h, sh)
             dsrc = torch.from_numpy(src.copy()).cuda()
-            ddst = torch.zeros(dls * h, dtype=torch.uint8, device="cuda")
+            ddst = torch.full((dls * h,), FILL, dtype=torch.uint8, device="cuda")
             rc = L.load().ug_hip_pixfmt_convert(L.PF_NAMES[i], L.PF_NAMES[o], dsrc.data_ptr(), ddst.data_ptr(), w, h, 0, 0, *sh, None)
             assert rc == 0, (i, o, L.last_error() if hasattr(L, "last_error") else rc)
             torch.cuda.synchronize()

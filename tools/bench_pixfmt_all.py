@@ -59,6 +59,7 @@ def main():
     rows.sort(key=lambda r: r["frac_of_8TBps"])
     print("slowest:", [(r["pair"], r["frac_of_8TBps"]) for r in rows[:12]])
     if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump({"width": w, "height": h, "rows": rows}, open(a.json, "w"), indent=1)
 
 

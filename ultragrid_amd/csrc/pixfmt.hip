@@ -42,6 +42,7 @@ struct Args {
         const uint8_t *src;
         uint8_t *dst;
         int width, height, spitch, dpitch, dst_len, rs, gs, bs;
+        int src_line; // bytes of a source line (vc_get_linesize of the input codec)
 };
 
 // ------------------------------ generic per-unit converters ------------------------------
@@ -182,7 +183,15 @@ struct V210toRGB { // pixfmt_conv.c:2884-2940 / :2942-3002
                 // overwritten by the next line / lands in MAX_PADDING); we clip to the line.
                 const int n = min(kObl, a.dst_len - kObl * k);
                 d += kObl * k;
-                for (int i = 0; i < n; i++) d[i] = o[i];
+                if (n == kObl) { // static indices only: o[] stays in registers and the stores merge
+#pragma unroll
+                        for (int i = 0; i < kObl; i++) d[i] = o[i];
+                } else {
+#pragma unroll
+                        for (int i = 0; i < kObl; i++) {
+                                if (i < n) d[i] = o[i];
+                        }
+                }
         }
 };
 struct RGBAtoRGB { // pixfmt_conv.c:866-900, portable path (vc_copylineRGBAtoRGBwithShift)
@@ -232,21 +241,66 @@ struct Copy { // vc_memcpy, pixfmt_conv.c:2529-2536
 };
 
 template <class CONV>
-__global__ __launch_bounds__(256) void generic_kernel(Args a, int upl, long total)
+__global__ __launch_bounds__(256) void generic_kernel(Args a, int upl, int k0, long total)
 {
         const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
         if (idx >= total) return;
-        const int line = (int) (idx / upl), k = (int) (idx - (long) line * upl);
+        const int line = (int) (idx / upl), k = k0 + (int) (idx - (long) line * upl); // upl = units of a line from k0 on
         CONV::run(a.dst + (long) line * a.dpitch, a.src + (long) line * a.spitch, k, a);
+}
+
+// The converters that have no hand-written fast path below take the wrapper pixfmt_ext.hip uses for the rest of decoders[]: K
+// iterations per lane, the K * SB source bytes and K * DB output bytes of a lane moved with 128-bit accesses (whole-wave contiguous
+// regions, ug::UnitIO), the unchanged run() working on private arrays.  VecTraits<CONV>::K == 0: no such form.
+template <class CONV> struct VecTraits { static constexpr int SB = 16, DB = 16, K = 0; };
+template <int RO, int GO, int BO> struct VecTraits<ToUYVY<RO, GO, BO, 4>> { static constexpr int SB = 8, DB = 4, K = 4; };   // RGBA pairs
+template <int RO, int GO, int BO> struct VecTraits<ToUYVY<RO, GO, BO, 6>> { static constexpr int SB = 12, DB = 4, K = 4; };  // RG48 pairs
+template <> struct VecTraits<V210toRGB<true>> { static constexpr int SB = 16, DB = 36, K = 4; };                               // v210 -> RG48
+template <> struct VecTraits<RGBshift> { static constexpr int SB = 3, DB = 3, K = 16; };                                        // BGR -> RGB, RGB with shifts
+template <> struct VecTraits<RGBAshift> { static constexpr int SB = 4, DB = 4, K = 4; };
+
+template <class CONV, int SB, int DB, int K>
+__global__ __launch_bounds__(256) void generic_vec_kernel(Args a, int nvec)
+{
+        static_assert((K * SB) % 16 == 0 && (K * DB) % 16 == 0, "a vector unit moves whole 16-byte words");
+        using In = ug::UnitIO<K * SB>;
+        using Out = ug::UnitIO<K * DB>;
+        constexpr int kLdsWords = In::LDS_WORDS > Out::LDS_WORDS ? In::LDS_WORDS : Out::LDS_WORDS;
+        __shared__ uint4 lds_all[kLdsWords ? 4 * kLdsWords : 1];
+        const int lane = threadIdx.x, y = blockIdx.y * 4 + threadIdx.y; // a wave = 64 consecutive units of one line
+        const int u0 = blockIdx.x * 64;
+        if (y >= a.height || u0 >= nvec) return; // wave-uniform
+        const int units = min(64, nvec - u0), u = u0 + lane;
+        uint4 *const lds = lds_all + threadIdx.y * kLdsWords;
+        __attribute__((aligned(16))) uint8_t ls[K * SB];
+        __attribute__((aligned(16))) uint8_t ld[K * DB];
+        In::load((const uint4 *) (a.src + (long) y * a.spitch + (long) u0 * (K * SB)), ls, lds, lane, units);
+        Args b = a;
+        b.dst_len = a.dst_len - u * (K * DB); // the line as this unit sees it
+#pragma unroll
+        for (int k = 0; k < K; k++) CONV::run(ld, ls, k, b);
+        Out::store((uint4 *) (a.dst + (long) y * a.dpitch + (long) u0 * (K * DB)), ld, lds, lane, units);
 }
 
 template <class CONV>
 int launch_generic(const Args &a, hipStream_t st)
 {
-        const int upl = CONV::units(a.dst_len);
+        using VT = VecTraits<CONV>;
+        int k0 = 0;
+        if constexpr (VT::K > 0) if (!((((uintptr_t) a.src | (uintptr_t) a.dst) | (uintptr_t) a.spitch | (uintptr_t) a.dpitch) & 15)) {
+                // whole units whose iterations write all their bytes and read inside the source line (the rest of the line: below)
+                const int nvec = min(a.dst_len / (VT::K * VT::DB), a.src_line / (VT::K * VT::SB));
+                if (nvec > 0) {
+                        hipLaunchKernelGGL((generic_vec_kernel<CONV, VT::SB, VT::DB, VT::K>), dim3((unsigned) ((nvec + 63) / 64), (unsigned) ((a.height + 3) / 4)),
+                                           dim3(64, 4), 0, st, a, nvec);
+                        UG_HIP_LAUNCH_CHECK();
+                        k0 = nvec * VT::K;
+                }
+        }
+        const int upl = CONV::units(a.dst_len) - k0;
         const long total = (long) upl * a.height;
         if (total <= 0) return UG_HIP_SUCCESS;
-        hipLaunchKernelGGL((generic_kernel<CONV>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, a, upl, total);
+        hipLaunchKernelGGL((generic_kernel<CONV>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, a, upl, k0, total);
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
@@ -674,6 +728,7 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
         a.spitch = src_pitch ? src_pitch : ug::linesize(in, width);
         a.dpitch = dst_pitch ? dst_pitch : ug::linesize(out, width);
         a.dst_len = size_of(out, width);
+        a.src_line = ug::linesize(in, width);
         a.rs = rshift; a.gs = gshift; a.bs = bshift;
         hipStream_t st = (hipStream_t) stream;
         int rc = UG_HIP_SUCCESS;

@@ -7,6 +7,7 @@
 // so ragged line ends come out as they do there.  The hand-unrolled R12L functions are written here as what they compute -- a
 // little-endian stream of 12-bit r, g, b -- and checked byte for byte against the compiled reference (tests/test_gpu_pixfmt_ext.py).
 // Integer / byte work, HBM-bound.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ug_common.h"
@@ -19,6 +20,7 @@ struct XArgs {
         long spitch, dpitch;
         int width, height;
         int L; // dst_len of a line
+        int x0; // first loop iteration this launch covers (the iterations below it went through the vector kernel)
         int rs, gs, bs;
         uint32_t am;
         int c[14];
@@ -26,14 +28,34 @@ struct XArgs {
 enum { Y_R, Y_G, Y_B, CB_R, CB_G, CB_B, CR_R, CR_G, CR_B, Y_SCALE, R_CR, G_CB, G_CR, B_CB };
 constexpr int kBase = 14;
 
-#define XK(name) __global__ void name(const XArgs a)
-#define XPRO()                                                      \
-        const int x = blockIdx.x * blockDim.x + threadIdx.x;        \
+// A converter is written once, as the body of one iteration of the reference function's loop: XK(name) { XPRO(); if (x >= <its
+// iteration count for a.L>) return; ... srow / drow ... }.  It is instantiated twice:
+//   name            one lane per iteration, accesses as the body states them (any alignment, ragged line ends);
+//   xvec_kernel<>   one lane per K consecutive iterations: the K * SB source bytes are fetched with 128-bit loads into a private
+//                   array, the unchanged body runs K times on that array and on a private output array (constant indices after
+//                   unrolling: the arrays live in registers, the byte accesses become bit-field operations), and the K * DB output
+//                   bytes leave with 128-bit stores.  Same statements, same results; taken for the 16-byte-aligned interior of
+//                   every line, the remaining iterations of a line go through `name` (XArgs::x0 = where they start).
+// XR: source and destination of a conversion never overlap (the one in-place converter, vc_copylineToRGBA_inplace, is written
+// without it); knowing that, the compiler merges the byte accesses of a body into dword / 128-bit ones
+#define XR __restrict__
+#define XK(name)                                                                                                                        \
+        struct name##_body {                                                                                                            \
+                static __device__ __forceinline__ void run(const XArgs &a, int x, const uint8_t *XR srow, uint8_t *XR drow);            \
+        };                                                                                                                              \
+        __global__ void name(const XArgs a)                                                                                             \
+        {                                                                                                                               \
+                XROW();                                                                                                                 \
+                name##_body::run(a, x, srow, drow);                                                                                     \
+        }                                                                                                                               \
+        __device__ __forceinline__ void name##_body::run(const XArgs &a, const int x, const uint8_t *XR const srow, uint8_t *XR const drow)
+#define XROW()                                                      \
+        const int x = a.x0 + blockIdx.x * blockDim.x + threadIdx.x; \
         const int y = blockIdx.y * blockDim.y + threadIdx.y;        \
         if (y >= a.height) return;                                  \
         const uint8_t *const srow = a.src + (long) y * a.spitch;    \
-        uint8_t *const drow = a.dst + (long) y * a.dpitch;          \
-        (void) srow, (void) drow
+        uint8_t *const drow = a.dst + (long) y * a.dpitch
+#define XPRO() (void) srow, (void) drow
 #define TO_Y(r, g, b) ((r) * a.c[Y_R] + (g) * a.c[Y_G] + (b) * a.c[Y_B])
 #define TO_CB(r, g, b) ((r) * a.c[CB_R] + (g) * a.c[CB_G] + (b) * a.c[CB_B])
 #define TO_CR(r, g, b) ((r) * a.c[CR_R] + (g) * a.c[CR_G] + (b) * a.c[CR_B])
@@ -55,11 +77,17 @@ __device__ __forceinline__ void r10k_get(const uint8_t *s, uint32_t &r, uint32_t
 // 36 bytes of R12L <-> 8 x (r, g, b) of 12 bits, little-endian bit stream
 __device__ __forceinline__ void r12l_get(const uint8_t *s, uint32_t (&v)[24])
 {
+        // value i = bits [12 i, 12 i + 12) of the 36-byte group (v[2k] = b0 | (b1 & 0xf) << 8, v[2k+1] = b1 >> 4 | b2 << 4 over bytes 3k..3k+2).
+        // The group is fetched as nine words in one go: left as 36 byte loads, the compiler merges them or not depending on
+        // how the body was inlined (24 two- and one-byte loads after the refactoring to body functions: 0.68 -> 0.34 of 8 TB/s).
+        uint32_t w[9];
+        __builtin_memcpy(w, s, 36);
 #pragma unroll
-        for (int k = 0; k < 12; k++) { // two values per three bytes
-                const uint32_t b0 = s[3 * k], b1 = s[3 * k + 1], b2 = s[3 * k + 2];
-                v[2 * k] = b0 | (b1 & 0xfu) << 8;
-                v[2 * k + 1] = b1 >> 4 | b2 << 4;
+        for (int i = 0; i < 24; i++) {
+                const int bit = 12 * i, j = bit >> 5, o = bit & 31;
+                uint32_t x = w[j] >> o;
+                if (o > 20) x |= w[j + 1] << (32 - o);
+                v[i] = x & 0xfffu;
         }
 }
 __device__ __forceinline__ void r12l_put(uint8_t *d, const uint32_t (&v)[24], int nbytes)
@@ -152,14 +180,18 @@ XK(k_r12l_to_rgba) // vc_copylineR12L :438-517: every started group, the last on
         r12l_get(srow + 36 * x, v);
         uint32_t *d = (uint32_t *) drow + 8 * x;
         const int n = min(8, (a.L - 32 * x) / 4);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-                if (i < n) d[i] = a.am | (v[3 * i] >> 4) << a.rs | (v[3 * i + 1] >> 4) << a.gs | (v[3 * i + 2] >> 4) << a.bs;
-        }
         const int rem = a.L - 32 * x - 4 * n; // memcpy(orig_d, tmpbuf, dstlen - x) may end inside a pixel
-        if (n < 8 && rem > 0) {
-                const uint32_t w = a.am | (v[3 * n] >> 4) << a.rs | (v[3 * n + 1] >> 4) << a.gs | (v[3 * n + 2] >> 4) << a.bs;
-                for (int k = 0; k < rem; k++) ((uint8_t *) (d + n))[k] = (uint8_t) (w >> (8 * k));
+#pragma unroll
+        for (int i = 0; i < 8; i++) { // static indices only: v[] stays in registers
+                const uint32_t w = a.am | (v[3 * i] >> 4) << a.rs | (v[3 * i + 1] >> 4) << a.gs | (v[3 * i + 2] >> 4) << a.bs;
+                if (i < n) {
+                        d[i] = w;
+                } else if (i == n) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                                if (k < rem) ((uint8_t *) (d + i))[k] = (uint8_t) (w >> (8 * k));
+                        }
+                }
         }
 }
 XK(k_r12l_to_rg48) // :1371-1476: whole groups, then the head of one more
@@ -234,7 +266,17 @@ XK(k_r12l_to_uyvy) // :1544-1638: 16-bit-scaled components, 8-bit coefficients, 
 
 // ---- -> R12L -------------------------------------------------------------------------------------------------------------------------
 template <int BPP>
-XK(k_rgb_to_r12l) // vc_copylineRGB_AtoR12L :1263-1322: whole groups only, component << 4
+struct k_rgb_to_r12l_body {
+        static __device__ __forceinline__ void run(const XArgs &a, int x, const uint8_t *XR srow, uint8_t *XR drow);
+};
+template <int BPP>
+__global__ void k_rgb_to_r12l(const XArgs a)
+{
+        XROW();
+        k_rgb_to_r12l_body<BPP>::run(a, x, srow, drow);
+}
+template <int BPP>
+__device__ __forceinline__ void k_rgb_to_r12l_body<BPP>::run(const XArgs &a, const int x, const uint8_t *XR const srow, uint8_t *XR const drow) // vc_copylineRGB_AtoR12L :1263-1322: whole groups only, component << 4
 {
         XPRO();
         if (x >= a.L / 36) return;
@@ -288,7 +330,17 @@ XK(k_rgb_to_rg48) // :1353-1363: one lane per component
         ((uint16_t *) drow)[x] = srow[x] << 8;
 }
 template <bool YUYV, bool RGB16>
-XK(k_yuv422_to_rgb) // copylineYUVtoRGB :1065-1094: vc_copylineUYVYtoRG48 (rgb16), vc_copylineYUYVtoRGB; clamp 0..255
+struct k_yuv422_to_rgb_body {
+        static __device__ __forceinline__ void run(const XArgs &a, int x, const uint8_t *XR srow, uint8_t *XR drow);
+};
+template <bool YUYV, bool RGB16>
+__global__ void k_yuv422_to_rgb(const XArgs a)
+{
+        XROW();
+        k_yuv422_to_rgb_body<YUYV, RGB16>::run(a, x, srow, drow);
+}
+template <bool YUYV, bool RGB16>
+__device__ __forceinline__ void k_yuv422_to_rgb_body<YUYV, RGB16>::run(const XArgs &a, const int x, const uint8_t *XR const srow, uint8_t *XR const drow) // copylineYUVtoRGB :1065-1094: vc_copylineUYVYtoRG48 (rgb16), vc_copylineYUYVtoRGB; clamp 0..255
 {
         XPRO();
         constexpr int kOut = RGB16 ? 12 : 6;
@@ -381,7 +433,17 @@ XK(k_rg48_to_y416) // :2451-2483
 
 // ---- Y416 sources (U Y V A, 16 bit) ------------------------------------------------------------------------------------------------
 template <int OUT> // 0 RG48 (:2485-2518), 1 R10k (:1917-1946), 2 RGB (:1948-1976), 3 RGBA (:1978-2006)
-XK(k_y416_to_rgb)
+struct k_y416_to_rgb_body {
+        static __device__ __forceinline__ void run(const XArgs &a, int x, const uint8_t *XR srow, uint8_t *XR drow);
+};
+template <int OUT> // 0 RG48 (:2485-2518), 1 R10k (:1917-1946), 2 RGB (:1948-1976), 3 RGBA (:1978-2006)
+__global__ void k_y416_to_rgb(const XArgs a)
+{
+        XROW();
+        k_y416_to_rgb_body<OUT>::run(a, x, srow, drow);
+}
+template <int OUT> // 0 RG48 (:2485-2518), 1 R10k (:1917-1946), 2 RGB (:1948-1976), 3 RGBA (:1978-2006)
+__device__ __forceinline__ void k_y416_to_rgb_body<OUT>::run(const XArgs &a, const int x, const uint8_t *XR const srow, uint8_t *XR const drow)
 {
         XPRO();
         constexpr int kBytes = OUT == 0 ? 6 : (OUT == 2 ? 3 : 4);
@@ -509,7 +571,17 @@ XK(k_y216_to_v210) // :2761-2790: (dst_len + 15) / 16 groups; Y216 = Y0 Cb Y1 Cr
         d[0] = U[0] | Y[0] << 10 | V[0] << 20, d[1] = Y[1] | U[1] << 10 | Y[2] << 20, d[2] = V[1] | Y[3] << 10 | U[2] << 20, d[3] = Y[4] | V[2] << 10 | Y[5] << 20;
 }
 template <bool Y416>
-XK(k_v210_to_y2xx) // vc_copylineV210toY216 :2792-2832 (dst_len / 24 groups), vc_copylineV210toY416 :2834-2882 (dst_len / 48)
+struct k_v210_to_y2xx_body {
+        static __device__ __forceinline__ void run(const XArgs &a, int x, const uint8_t *XR srow, uint8_t *XR drow);
+};
+template <bool Y416>
+__global__ void k_v210_to_y2xx(const XArgs a)
+{
+        XROW();
+        k_v210_to_y2xx_body<Y416>::run(a, x, srow, drow);
+}
+template <bool Y416>
+__device__ __forceinline__ void k_v210_to_y2xx_body<Y416>::run(const XArgs &a, const int x, const uint8_t *XR const srow, uint8_t *XR const drow) // vc_copylineV210toY216 :2792-2832 (dst_len / 24 groups), vc_copylineV210toY416 :2834-2882 (dst_len / 48)
 {
         XPRO();
         if (x >= a.L / (Y416 ? 48 : 24)) return;
@@ -564,67 +636,113 @@ XK(k_rgba_to_rgb_shift) // vc_copylineRGBAtoRGBwithShift :769-807 (a.rs/gs/bs = 
         uint8_t *d = drow + 3 * x;
         d[0] = (uint8_t) (in >> a.rs), d[1] = (uint8_t) (in >> a.gs), d[2] = (uint8_t) (in >> a.bs);
 }
-XK(k_to_rgba_inplace) // vc_copylineToRGBA_inplace :907-921 (source shifts; alpha byte 0)
+__global__ void k_to_rgba_inplace(const XArgs a) // vc_copylineToRGBA_inplace :907-921 (source shifts; alpha byte 0); dst may BE src: no XR here
 {
-        XPRO();
+        XROW();
         if (x >= a.L / 4) return;
         const uint32_t in = ((const uint32_t *) srow)[x];
         ((uint32_t *) drow)[x] = ((in >> a.rs) & 0xff) | ((in >> a.gs) & 0xff) << 8 | ((in >> a.bs) & 0xff) << 16;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// K iterations of a converter per lane, through private arrays (see XK above).  nvec = vector units per line.
+// A lane's unit is K * SB contiguous source bytes and K * DB contiguous output bytes.  When that is one 16-byte word the lanes of a
+// wave access consecutive words and nothing else is needed.  When it is several, per-lane accesses would be strided (every load
+// instruction touching 64 different cache lines and using 16 bytes of each -- measured: RG48->RGB fell from 0.31 to 0.19 of 8 TB/s that
+// way), so the wave moves its 64 units as ONE contiguous region: word c of the region is handled by lane c % 64, and the words change
+// hands through LDS (rows of an odd number of 16-byte words: conflict-free on both sides).
+template <class Body, int SB, int DB, int K>
+__global__ __launch_bounds__(256) void xvec_kernel(const XArgs a, int nvec)
+{
+        static_assert((K * SB) % 16 == 0 && (K * DB) % 16 == 0, "a vector unit moves whole 16-byte words");
+        using In = ug::UnitIO<K * SB>;
+        using Out = ug::UnitIO<K * DB>;
+        constexpr int kLdsWords = In::LDS_WORDS > Out::LDS_WORDS ? In::LDS_WORDS : Out::LDS_WORDS;
+        __shared__ uint4 lds_all[kLdsWords ? 4 * kLdsWords : 1];
+        const int lane = threadIdx.x, y = blockIdx.y * 4 + threadIdx.y; // a wave = 64 consecutive units of one line
+        const int u0 = blockIdx.x * 64;
+        if (y >= a.height || u0 >= nvec) return; // wave-uniform
+        const int units = min(64, nvec - u0), u = u0 + lane;
+        uint4 *const lds = lds_all + threadIdx.y * kLdsWords;
+        __attribute__((aligned(16))) uint8_t ls[K * SB];
+        __attribute__((aligned(16))) uint8_t ld[K * DB];
+        In::load((const uint4 *) (a.src + (long) y * a.spitch + (long) u0 * (K * SB)), ls, lds, lane, units);
+        XArgs b = a;
+        b.L = a.L - u * (K * DB); // the line as this unit sees it: its own iterations are 0 .. K - 1 of what is left
+#pragma unroll
+        for (int k = 0; k < K; k++) Body::run(b, k, ls, ld);
+        Out::store((uint4 *) (a.dst + (long) y * a.dpitch + (long) u0 * (K * DB)), ld, lds, lane, units);
+}
+template <class Body, int SB, int DB, int K>
+void launch_xvec(const XArgs &a, int nvec, hipStream_t st)
+{
+        const dim3 block(64, 4, 1), grid((unsigned) ((nvec + 63) / 64), (unsigned) ((a.height + 3) / 4), 1);
+        hipLaunchKernelGGL((xvec_kernel<Body, SB, DB, K>), grid, block, 0, st, a, nvec);
+}
+
+using uyvy_to_rg48_body = k_yuv422_to_rgb_body<false, true>;
+using yuyv_to_rgb_body = k_yuv422_to_rgb_body<true, false>;
 enum Iter { I_PX, I_PAIR, I_G6, I_G8, I_COMP, I_DVS };
+struct Vec { // the vector form of an entry: bytes in / out per iteration, iterations per lane
+        void (*launch)(const XArgs &, int, hipStream_t);
+        int sb, db, k;
+};
+#define VEC(body, SB, DB, K) { launch_xvec<body, SB, DB, K>, SB, DB, K }
+// NOVEC: the one-iteration-per-lane kernel measured faster at 8K (fraction of 8 TB/s: it vs the vector form) -- 9-word R12L units
+// cost more in LDS and registers than the compiler-merged accesses of the plain kernel
+#define NOVEC { nullptr, 1, 1, 1 }
 struct Entry {
         int in, out;
         void (*kernel)(const XArgs);
         Iter iter;
         int coeff_depth;
+        Vec vec;
 };
 const Entry kTable[] = {
-        { UG_PF_DVS10, UG_PF_UYVY, k_dvs10_to_uyvy, I_DVS, 0 },
-        { UG_PF_DVS10, UG_PF_V210, k_dvs10_to_v210, I_COMP, 0 },
-        { UG_PF_R10K, UG_PF_RGBA, k_r10k_to_rgba, I_PX, 0 },
-        { UG_PF_R10K, UG_PF_RG48, k_r10k_to_rg48, I_PX, 0 },
-        { UG_PF_R10K, UG_PF_Y416, k_r10k_to_y416, I_PX, 16 },
-        { UG_PF_R10K, UG_PF_RGB, k_r10k_to_rgb, I_PX, 0 },
-        { UG_PF_R10K, UG_PF_UYVY, k_r10k_to_uyvy, I_PAIR, 8 },
-        { UG_PF_R12L, UG_PF_RGBA, k_r12l_to_rgba, I_G8, 0 },
-        { UG_PF_R12L, UG_PF_RGB, k_r12l_to_rgb, I_G8, 0 },
-        { UG_PF_R12L, UG_PF_RG48, k_r12l_to_rg48, I_G8, 0 },
-        { UG_PF_R12L, UG_PF_R10K, k_r12l_to_r10k, I_G8, 0 },
-        { UG_PF_R12L, UG_PF_Y416, k_r12l_to_y416, I_G8, 16 },
-        { UG_PF_R12L, UG_PF_UYVY, k_r12l_to_uyvy, I_G8, 8 },
-        { UG_PF_RGBA, UG_PF_R12L, k_rgb_to_r12l<4>, I_G8, 0 },
-        { UG_PF_RGB, UG_PF_R12L, k_rgb_to_r12l<3>, I_G8, 0 },
-        { UG_PF_RGBA, UG_PF_RG48, k_rgba_to_rg48, I_PX, 0 },
-        { UG_PF_RGB, UG_PF_RG48, k_rgb_to_rg48, I_COMP, 0 },
-        { UG_PF_UYVY, UG_PF_RG48, k_yuv422_to_rgb<false, true>, I_PAIR, 8 },
-        { UG_PF_RG48, UG_PF_R12L, k_rg48_to_r12l, I_G8, 0 },
-        { UG_PF_RG48, UG_PF_R10K, k_rg48_to_r10k, I_PX, 0 },
-        { UG_PF_RG48, UG_PF_RGB, k_rg48_to_rgb, I_PX, 0 },
-        { UG_PF_RG48, UG_PF_RGBA, k_rg48_to_rgba, I_PX, 0 },
-        { UG_PF_RG48, UG_PF_V210, k_rg48_to_v210, I_G6, 10 },
-        { UG_PF_RG48, UG_PF_Y216, k_rg48_to_y216, I_PAIR, 16 },
-        { UG_PF_RG48, UG_PF_Y416, k_rg48_to_y416, I_PX, 16 },
-        { UG_PF_Y416, UG_PF_RG48, k_y416_to_rgb<0>, I_PX, 16 },
-        { UG_PF_RGBA, UG_PF_VUYA, k_rgba_to_vuya, I_PX, 8 },
-        { UG_PF_YUYV, UG_PF_RGB, k_yuv422_to_rgb<true, false>, I_PAIR, 8 },
-        { UG_PF_RGBA, UG_PF_R10K, k_rgba_to_r10k, I_PX, 0 },
-        { UG_PF_UYVY, UG_PF_Y216, k_uyvy_to_y216, I_PAIR, 0 },
-        { UG_PF_UYVY, UG_PF_Y416, k_uyvy_to_y416, I_PAIR, 0 },
-        { UG_PF_VUYA, UG_PF_Y416, k_vuya_to_y416, I_PX, 0 },
-        { UG_PF_VUYA, UG_PF_UYVY, k_vuya_to_uyvy, I_PAIR, 0 },
-        { UG_PF_VUYA, UG_PF_RGB, k_vuya_to_rgb, I_PX, 8 },
-        { UG_PF_Y216, UG_PF_UYVY, k_y216_to_uyvy, I_PAIR, 0 },
-        { UG_PF_Y216, UG_PF_V210, k_y216_to_v210, I_G6, 0 },
-        { UG_PF_Y416, UG_PF_UYVY, k_y416_to_uyvy, I_PAIR, 0 },
-        { UG_PF_Y416, UG_PF_V210, k_y416_to_v210, I_G6, 0 },
-        { UG_PF_Y416, UG_PF_R12L, k_y416_to_r12l, I_G8, 16 },
-        { UG_PF_Y416, UG_PF_R10K, k_y416_to_rgb<1>, I_PX, 16 },
-        { UG_PF_Y416, UG_PF_RGB, k_y416_to_rgb<2>, I_PX, 16 },
-        { UG_PF_Y416, UG_PF_RGBA, k_y416_to_rgb<3>, I_PX, 16 },
-        { UG_PF_V210, UG_PF_Y216, k_v210_to_y2xx<false>, I_G6, 0 },
-        { UG_PF_V210, UG_PF_Y416, k_v210_to_y2xx<true>, I_G6, 0 },
+        { UG_PF_DVS10, UG_PF_UYVY, k_dvs10_to_uyvy, I_DVS, 0, VEC(k_dvs10_to_uyvy_body, 4, 3, 16) },
+        { UG_PF_DVS10, UG_PF_V210, k_dvs10_to_v210, I_COMP, 0, VEC(k_dvs10_to_v210_body, 4, 4, 4) },
+        { UG_PF_R10K, UG_PF_RGBA, k_r10k_to_rgba, I_PX, 0, VEC(k_r10k_to_rgba_body, 4, 4, 4) },
+        { UG_PF_R10K, UG_PF_RG48, k_r10k_to_rg48, I_PX, 0, VEC(k_r10k_to_rg48_body, 4, 6, 8) },
+        { UG_PF_R10K, UG_PF_Y416, k_r10k_to_y416, I_PX, 16, VEC(k_r10k_to_y416_body, 4, 8, 4) },
+        { UG_PF_R10K, UG_PF_RGB, k_r10k_to_rgb, I_PX, 0, VEC(k_r10k_to_rgb_body, 4, 3, 16) },
+        { UG_PF_R10K, UG_PF_UYVY, k_r10k_to_uyvy, I_PAIR, 8, VEC(k_r10k_to_uyvy_body, 8, 4, 4) },
+        { UG_PF_R12L, UG_PF_RGBA, k_r12l_to_rgba, I_G8, 0, VEC(k_r12l_to_rgba_body, 36, 32, 4) },
+        { UG_PF_R12L, UG_PF_RGB, k_r12l_to_rgb, I_G8, 0, NOVEC /* 0.67 vs 0.55 */ },
+        { UG_PF_R12L, UG_PF_RG48, k_r12l_to_rg48, I_G8, 0, VEC(k_r12l_to_rg48_body, 36, 48, 4) },
+        { UG_PF_R12L, UG_PF_R10K, k_r12l_to_r10k, I_G8, 0, NOVEC /* 0.66 vs 0.52 */ },
+        { UG_PF_R12L, UG_PF_Y416, k_r12l_to_y416, I_G8, 16, VEC(k_r12l_to_y416_body, 36, 64, 4) },
+        { UG_PF_R12L, UG_PF_UYVY, k_r12l_to_uyvy, I_G8, 8, NOVEC /* 0.58 vs 0.48 */ },
+        { UG_PF_RGBA, UG_PF_R12L, k_rgb_to_r12l<4>, I_G8, 0, VEC(k_rgb_to_r12l_body<4>, 32, 36, 4) },
+        { UG_PF_RGB, UG_PF_R12L, k_rgb_to_r12l<3>, I_G8, 0, NOVEC /* 0.55 vs 0.53 */ },
+        { UG_PF_RGBA, UG_PF_RG48, k_rgba_to_rg48, I_PX, 0, VEC(k_rgba_to_rg48_body, 4, 6, 8) },
+        { UG_PF_RGB, UG_PF_RG48, k_rgb_to_rg48, I_COMP, 0, VEC(k_rgb_to_rg48_body, 1, 2, 16) },
+        { UG_PF_UYVY, UG_PF_RG48, k_yuv422_to_rgb<false, true>, I_PAIR, 8, VEC(uyvy_to_rg48_body, 4, 12, 4) },
+        { UG_PF_RG48, UG_PF_R12L, k_rg48_to_r12l, I_G8, 0, NOVEC /* 0.65 vs 0.42 */ },
+        { UG_PF_RG48, UG_PF_R10K, k_rg48_to_r10k, I_PX, 0, VEC(k_rg48_to_r10k_body, 6, 4, 8) },
+        { UG_PF_RG48, UG_PF_RGB, k_rg48_to_rgb, I_PX, 0, VEC(k_rg48_to_rgb_body, 6, 3, 16) },
+        { UG_PF_RG48, UG_PF_RGBA, k_rg48_to_rgba, I_PX, 0, VEC(k_rg48_to_rgba_body, 6, 4, 8) },
+        { UG_PF_RG48, UG_PF_V210, k_rg48_to_v210, I_G6, 10, NOVEC /* 0.73 vs 0.53 */ },
+        { UG_PF_RG48, UG_PF_Y216, k_rg48_to_y216, I_PAIR, 16, VEC(k_rg48_to_y216_body, 12, 8, 4) },
+        { UG_PF_RG48, UG_PF_Y416, k_rg48_to_y416, I_PX, 16, VEC(k_rg48_to_y416_body, 6, 8, 8) },
+        { UG_PF_Y416, UG_PF_RG48, k_y416_to_rgb<0>, I_PX, 16, VEC(k_y416_to_rgb_body<0>, 8, 6, 8) },
+        { UG_PF_RGBA, UG_PF_VUYA, k_rgba_to_vuya, I_PX, 8, VEC(k_rgba_to_vuya_body, 4, 4, 4) },
+        { UG_PF_YUYV, UG_PF_RGB, k_yuv422_to_rgb<true, false>, I_PAIR, 8, VEC(yuyv_to_rgb_body, 4, 6, 8) },
+        { UG_PF_RGBA, UG_PF_R10K, k_rgba_to_r10k, I_PX, 0, VEC(k_rgba_to_r10k_body, 4, 4, 4) },
+        { UG_PF_UYVY, UG_PF_Y216, k_uyvy_to_y216, I_PAIR, 0, VEC(k_uyvy_to_y216_body, 4, 8, 4) },
+        { UG_PF_UYVY, UG_PF_Y416, k_uyvy_to_y416, I_PAIR, 0, VEC(k_uyvy_to_y416_body, 4, 16, 4) },
+        { UG_PF_VUYA, UG_PF_Y416, k_vuya_to_y416, I_PX, 0, VEC(k_vuya_to_y416_body, 4, 8, 4) },
+        { UG_PF_VUYA, UG_PF_UYVY, k_vuya_to_uyvy, I_PAIR, 0, VEC(k_vuya_to_uyvy_body, 8, 4, 4) },
+        { UG_PF_VUYA, UG_PF_RGB, k_vuya_to_rgb, I_PX, 8, VEC(k_vuya_to_rgb_body, 4, 3, 16) },
+        { UG_PF_Y216, UG_PF_UYVY, k_y216_to_uyvy, I_PAIR, 0, VEC(k_y216_to_uyvy_body, 8, 4, 4) },
+        { UG_PF_Y216, UG_PF_V210, k_y216_to_v210, I_G6, 0, VEC(k_y216_to_v210_body, 24, 16, 2) },
+        { UG_PF_Y416, UG_PF_UYVY, k_y416_to_uyvy, I_PAIR, 0, VEC(k_y416_to_uyvy_body, 16, 4, 4) },
+        { UG_PF_Y416, UG_PF_V210, k_y416_to_v210, I_G6, 0, VEC(k_y416_to_v210_body, 48, 16, 1) },
+        { UG_PF_Y416, UG_PF_R12L, k_y416_to_r12l, I_G8, 16, VEC(k_y416_to_r12l_body, 64, 36, 4) },
+        { UG_PF_Y416, UG_PF_R10K, k_y416_to_rgb<1>, I_PX, 16, VEC(k_y416_to_rgb_body<1>, 8, 4, 4) },
+        { UG_PF_Y416, UG_PF_RGB, k_y416_to_rgb<2>, I_PX, 16, VEC(k_y416_to_rgb_body<2>, 8, 3, 16) },
+        { UG_PF_Y416, UG_PF_RGBA, k_y416_to_rgb<3>, I_PX, 16, VEC(k_y416_to_rgb_body<3>, 8, 4, 4) },
+        { UG_PF_V210, UG_PF_Y216, k_v210_to_y2xx<false>, I_G6, 0, VEC(k_v210_to_y2xx_body<false>, 16, 24, 2) },
+        { UG_PF_V210, UG_PF_Y416, k_v210_to_y2xx<true>, I_G6, 0, VEC(k_v210_to_y2xx_body<true>, 16, 48, 1) },
 };
 
 const Entry *find(int in, int out)
@@ -679,9 +797,29 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
         case I_COMP: nx = dst_len; break;
         case I_DVS: nx = (int) (dst_len / 1.5) / 16 * 8; break;
         }
-        const dim3 block(64, 4, 1), grid((unsigned) ((nx + 63) / 64), (unsigned) ((height + 3) / 4), 1);
-        hipLaunchKernelGGL(e->kernel, grid, block, 0, st, a);
-        UG_HIP_LAUNCH_CHECK();
+        // The 16-byte-aligned interior of every line goes K iterations per lane with 128-bit accesses (xvec_kernel): as many whole
+        // vector units as have all their iterations inside the line on both sides -- output bytes within dst_len, source bytes within
+        // the source line.  Whatever is left of a line (ragged ends, clipped last groups; the whole line when a pointer or pitch is
+        // not 16-byte aligned) takes the one-iteration-per-lane kernel from iteration x0 on.
+        int nvec = 0;
+        const Vec &v = e->vec;
+        static const bool no_vec = getenv("UG_PIXFMT_NO_VEC") != nullptr; // A/B switch
+        if (v.launch && !no_vec && !((((uintptr_t) src | (uintptr_t) dst) | (uintptr_t) src_pitch | (uintptr_t) dst_pitch) & 15)) {
+                const int iters = e->iter == I_DVS ? (int) (dst_len / 1.5) / 16 * 8 : dst_len / v.db; // iterations that write all their bytes
+                const int src_line = ug::linesize(in, width);
+                nvec = min(iters / v.k, src_line / (v.sb * v.k));
+                if (nvec > 0) {
+                        v.launch(a, nvec, st);
+                        UG_HIP_LAUNCH_CHECK();
+                }
+        }
+        a.x0 = nvec * v.k;
+        if (v.launch) nx = min(nx, (dst_len + v.db - 1) / v.db + 1); // no converter runs more iterations than its output bytes allow (+ the odd one)
+        if (nx > a.x0) {
+                const dim3 block(64, 4, 1), grid((unsigned) ((nx - a.x0 + 63) / 64), (unsigned) ((height + 3) / 4), 1);
+                hipLaunchKernelGGL(e->kernel, grid, block, 0, st, a);
+                UG_HIP_LAUNCH_CHECK();
+        }
         return UG_HIP_SUCCESS;
 }
 

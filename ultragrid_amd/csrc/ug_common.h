@@ -77,3 +77,56 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
                        int rshift, int gshift, int bshift, hipStream_t st);
 
 } // namespace ug
+#ifdef __HIPCC__
+namespace ug {
+// 128-bit unit I/O of the "K iterations per lane" converter kernels (pixfmt.hip, pixfmt_ext.hip).  A lane's unit is BYTES contiguous
+// bytes.  When that is one 16-byte word the lanes of a wave access consecutive words and nothing else is needed.  When it is
+// several, per-lane accesses would be strided (every load instruction touching 64 different cache lines and using 16 bytes of each --
+// measured: RG48->RGB fell from 0.31 to 0.19 of 8 TB/s that way), so the wave moves its 64 units as ONE contiguous region: word c of
+// the region is handled by lane c % 64, and the words change hands through LDS (rows of an odd number of 16-byte words:
+// conflict-free on both sides).
+template <int BYTES>
+struct UnitIO {
+        static constexpr int V = BYTES / 16;                    // 16-byte words per unit
+        static constexpr int ROW = V == 1 ? 1 : (V | 1);        // LDS row stride in words, odd
+        static constexpr int LDS_WORDS = V == 1 ? 0 : 64 * ROW; // per wave
+        // region = the wave's first unit in global memory; units = how many of the wave's 64 units exist
+        static __device__ __forceinline__ void load(const uint4 *region, uint8_t *priv, uint4 *lds, int lane, int units)
+        {
+                if (V == 1) {
+                        if (lane < units) *(uint4 *) priv = region[lane];
+                        return;
+                }
+#pragma unroll
+                for (int i = 0; i < V; i++) {
+                        const int c = i * 64 + lane;
+                        if (c < units * V) lds[(c / V) * ROW + c % V] = region[c];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < V; i++) ((uint4 *) priv)[i] = lds[lane * ROW + i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+        }
+        static __device__ __forceinline__ void store(uint4 *region, const uint8_t *priv, uint4 *lds, int lane, int units)
+        {
+                if (V == 1) {
+                        if (lane < units) region[lane] = *(const uint4 *) priv;
+                        return;
+                }
+#pragma unroll
+                for (int i = 0; i < V; i++) lds[lane * ROW + i] = ((const uint4 *) priv)[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < V; i++) {
+                        const int c = i * 64 + lane;
+                        if (c < units * V) region[c] = lds[(c / V) * ROW + c % V];
+                }
+        }
+};
+
+} // namespace ug
+#endif
+
