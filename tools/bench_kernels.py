@@ -97,6 +97,29 @@ def main():
         add(f"pixfmt {i}->{o}", w, h, 1, bpp, ms)
         del src, dsts
 
+    # ---- pixfmt, 8 frames of 4K per launch (ug_hip_pixfmt_convert_batch: frames one picture apart = one launch) ----
+    for (i, o, bpp) in [("v210", "UYVY", 16 / 6 + 2), ("UYVY", "RGB", 5.0), ("RGB", "UYVY", 5.0), ("v210", "RGB", 16 / 6 + 3), ("RGBA", "RGB", 7.0),
+                        ("UYVY", "RGBA", 6.0), ("UYVY", "v210", 2 + 16 / 6), ("UYVY", "Y216", 6.0), ("Y216", "UYVY", 6.0), ("R10k", "RGB", 7.0), ("RG48", "RGB", 9.0)]:
+        w, h, nb, sets = 3840, 2160, 8, 3
+        l = lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        sls, dls = l.ug_hip_linesize(L.PF_NAMES[i], w), l.ug_hip_linesize(L.PF_NAMES[o], w)
+        try:
+            src = torch.stack([frames(i, w, h, nb) for _ in range(sets)])
+        except (ValueError, AssertionError, KeyError):
+            src = torch.randint(0, 256, (sets, nb, sls * h), dtype=torch.uint8, device="cuda")
+        dsts = torch.empty((sets, nb * dls * h), dtype=torch.uint8, device="cuda")
+        k = [0]
+
+        def run_b():
+            j = k[0] % sets
+            k[0] += 1
+            rc = l.ug_hip_pixfmt_convert_batch(L.PF_NAMES[i], L.PF_NAMES[o], src[j].data_ptr(), dsts[j].data_ptr(), w, h, 0, 0, 0, 8, 16, nb, sls * h, dls * h, st)
+            assert rc == 0
+        ms = timeit(run_b, iters=9)
+        add(f"pixfmt {i}->{o} (batch of 8)", w, h, nb, bpp, ms)
+        del src, dsts
+
     # ---- planar + JPEG ----
     w, h, n = 3840, 2160, 16
     src = frames("UYVY", w, h, n)
@@ -116,6 +139,16 @@ def main():
         j = k[0] % n; k[0] += 1
         assert l.ug_hip_uyvy_to_jpeg420_coeffs(src[j].data_ptr(), 0, w, h, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), st) == 0
     add("uyvy->420->FDCT+quant (fused)", w, h, 1, 5.0, timeit(run_jpeg, iters=3 * n))
+    # the same front end over 8 frames per launch (ug_hip_uyvy_to_jpeg42x_coeffs_batch, grid.z = frame)
+    nb = 8
+    boy = torch.empty((nb, 4 * mw * mh, 64), dtype=torch.int16, device="cuda"); bocb = torch.empty((nb, mw * mh, 64), dtype=torch.int16, device="cuda"); bocr = torch.empty_like(bocb)
+
+    def run_jpeg_b():
+        j = (k[0] % 2) * nb; k[0] += 1
+        assert l.ug_hip_uyvy_to_jpeg42x_coeffs_batch(420, src[j].data_ptr(), 0, w, h, div.data_ptr(), boy.data_ptr(), bocb.data_ptr(), bocr.data_ptr(), nb, src.shape[1],
+                                                     4 * mw * mh * 128, mw * mh * 128, st) == 0
+    add("uyvy->420->FDCT+quant (fused, batch of 8)", w, h, nb, 5.0, timeit(run_jpeg_b, iters=10))
+    del boy, bocb, bocr
     plane = torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda")
     outp = torch.empty((w // 8 * h // 8, 64), dtype=torch.int16, device="cuda")
 
@@ -186,7 +219,14 @@ def main():
             j = k[0] % n; k[0] += 1
             assert l.ug_hip_dxt_decode(oid, L.PF_NAMES[outf], blocks.data_ptr() + j * per, dd.data_ptr(), w, h, 0, 0, 8, 16, st) == 0
         add(f"dxt_decode {name}->{outf}", w, h, 1, bpp, timeit(run_dec, iters=3 * n))
-        del blocks
+        # 8 frames per launch: compressed frames one picture apart decode as one image 8 times as tall
+        dd8 = torch.empty(8 * codec.linesize(L.PF_NAMES[outf], w) * h, dtype=torch.uint8, device="cuda")
+
+        def run_dec8():
+            j = (k[0] % 2) * 8; k[0] += 1
+            assert l.ug_hip_dxt_decode(oid, L.PF_NAMES[outf], blocks.data_ptr() + j * per, dd8.data_ptr(), w, 8 * h, 0, 0, 8, 16, st) == 0
+        add(f"dxt_decode {name}->{outf} (batch of 8)", w, h, 8, bpp, timeit(run_dec8, iters=10))
+        del blocks, dd8
     # from_planar.h / to_planar.h by name (planar_api.hip): 4K, rotating 4 plane sets so L2 does not hold the input
     NP = 4
     g16 = [[torch.randint(0, 4096, (h, w), dtype=torch.int16, device="cuda") for _ in range(3)] for _ in range(NP)]
