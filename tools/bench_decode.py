@@ -36,7 +36,16 @@ def main():
                     run(k)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                n = 30
+                e0.record()
+                for k in range(5):
+                    run(k)
+                e1.record()
+                torch.cuda.synchronize()
+                one = max(e0.elapsed_time(e1) / 5, 1e-3)
+                for k in range(int(40.0 / one)):      # warm-up: ~40 ms
+                    run(k)
+                n = max(20, int(120.0 / one))         # timed: >= 120 ms of launches
+                torch.cuda.synchronize()
                 e0.record()
                 for k in range(n):
                     run(k)

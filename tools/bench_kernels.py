@@ -17,17 +17,28 @@ L = lib
 PEAK = 8000.0
 
 
-def timeit(fn, iters=30, warm=3):
-    for _ in range(warm):
-        fn()
+def timeit(fn, iters=30, warm=3, min_ms=120.0):
+    """ms per call: HIP events on the launch stream around back-to-back calls, repeated until at least `min_ms` of GPU work has been
+    timed (a handful of 10 us launches measures the clock ramp, not the kernel: the same DXT encode reads 0.219 ms over 30 launches and
+    0.180 ms in steady state), after an untimed warm-up of a third of that."""
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
+    for _ in range(max(warm, 1)):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    one = max(e0.elapsed_time(e1) / max(warm, 1), 1e-3)
+    for _ in range(int(min_ms / 3 / one)):
+        fn()
+    n = max(iters, int(min_ms / one))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
 
 
 def frames(fmt, w, h, n):
