@@ -95,6 +95,7 @@ int         ug_hip_free_host(void *buffer);                            /* cuda_w
 #define UG_HIP_MEMCPY_DEVICE_TO_DEVICE 2
 int         ug_hip_memcpy(void *dst, const void *src, size_t count, int kind);       /* cuda_wrapper_memcpy */
 int         ug_hip_memcpy_async(void *dst, const void *src, size_t count, int kind, ug_hip_stream_t stream);
+int         ug_hip_memset_async(void *dst_dev, int value, size_t count, ug_hip_stream_t stream); /* device memory only */
 int         ug_hip_stream_create(ug_hip_stream_t *stream);
 int         ug_hip_stream_destroy(ug_hip_stream_t stream);
 int         ug_hip_stream_sync(ug_hip_stream_t stream);

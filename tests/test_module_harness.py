@@ -292,6 +292,24 @@ def test_decompress_through_reference_framework(tmp_path, po, comp, out):
     assert np.array_equal(got.ravel(), po.dxt_decode(oid, out, blocks, w, h))
 
 
+@needs_dec_harness
+@pytest.mark.gpu
+def test_short_frame_decodes_what_arrived_and_black_for_the_rest(tmp_path, po):
+    """the module accepts corrupted (short) frames; the blocks that did not arrive must decode as all-zero blocks, not as
+    whatever the freshly allocated device buffer held."""
+    w, h = 192, 64
+    blocks = po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, synth.s2_video("UYVY", w, h), w, h)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.raw"
+    blocks.tofile(src)
+    got_len = (blocks.size // 3) // 16 * 16
+    ls = po.linesize(w, "RGBA")
+    r = subprocess.run([DEC_HARNESS, "DXT5", "RGBA", str(w), str(h), str(src), str(dst), str(ls), str(got_len)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stdout + r.stderr
+    partial = blocks.copy()
+    partial[got_len:] = 0
+    assert np.array_equal(np.fromfile(dst, np.uint8), po.dxt_decode(po.OUT_DXT5YCOCG, "RGBA", partial, w, h))
+
+
 SHARDER_TEST = os.path.join(ROOT, "oracle", "_ref", "ug_sharder_test")
 
 

@@ -104,6 +104,12 @@ int ug_hip_memcpy_async(void *dst, const void *src, size_t count, int kind, ug_h
         return UG_HIP_SUCCESS;
 }
 
+int ug_hip_memset_async(void *dst, int value, size_t count, ug_hip_stream_t stream)
+{
+        UG_HIP_TRY(hipMemsetAsync(dst, value, count, (hipStream_t) stream));
+        return UG_HIP_SUCCESS;
+}
+
 int ug_hip_stream_create(ug_hip_stream_t *stream)
 {
         if (!stream) return UG_HIP_EINVAL;

@@ -23,7 +23,7 @@ int main(int argc, char **argv)
                 return 0;
         }
         if (argc < 7) {
-                fprintf(stderr, "usage: %s <DXT1|DXT1_YUV|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]\n", argv[0]);
+                fprintf(stderr, "usage: %s <DXT1|DXT1_YUV|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch] [src_len: hand over only that many bytes (a short frame)]\n", argv[0]);
                 return 1;
         }
         const codec_t in = get_codec_from_name(argv[1]), out = get_codec_from_name(argv[2]);
@@ -47,7 +47,8 @@ int main(int argc, char **argv)
                 fprintf(stderr, "reconfigure failed\n");
                 return 2;
         }
-        const decompress_status st = decompress_frame(s, dst, src, (unsigned) in_len, 0, NULL, NULL);
+        const unsigned src_len = argc > 8 ? (unsigned) atoi(argv[8]) : (unsigned) in_len; // < in_len: a frame that lost its tail on the way
+        const decompress_status st = decompress_frame(s, dst, src, src_len, 0, NULL, NULL);
         if (st != DECODER_GOT_FRAME) {
                 fprintf(stderr, "decompress_frame status %d\n", (int) st);
                 return 3;

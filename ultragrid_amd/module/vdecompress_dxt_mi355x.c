@@ -93,6 +93,13 @@ static int dxt_mi355x_decompress_reconfigure(void *state, struct video_desc desc
                 release_buffers(s);
                 return false;
         }
+        // a short (corrupted) frame uploads only the bytes that arrived and decodes the whole block grid: what did not arrive must not be
+        // whatever the allocation held -- start from all-zero blocks (black), later frames leave the previous picture there
+        if (ug_hip_memset_async(s->dev_in, 0, s->in_len, s->stream) != UG_HIP_SUCCESS || ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "Could not clear the device input buffer: %s\n", ug_hip_last_error_string());
+                release_buffers(s);
+                return false;
+        }
         s->configured = true;
         return true;
 }
