@@ -55,12 +55,20 @@ __device__ __forceinline__ int count_ff_bytes(uint32_t w)
 }
 
 constexpr int kRawBytesPerBlock = 224; // 56 words >= (31 carried + 64 x 27) bits
+// The position of a segment in the final stream = header + the sizes of all segments before it.  The coders add every segment's final
+// size to the total of its chunk of kChunk segments; a compaction wave then sums the chunk totals below its chunk and the segment
+// sizes below it inside the chunk (two short wave reductions) instead of a separate single-workgroup prefix-sum launch.
+constexpr int kChunk = 256;
+// Each chunk total sits in a cache line of its own: thousands of atomics into ONE 128-byte line serialise at a single L2 channel
+// (measured: the coder went from 21 to 80 us with the totals packed).
+constexpr int kChunkStride = 32; // uint32 words
 
 __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
                                                            const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs /* sampling factors of component 0: 2x2 (4:2:0), 2x1 (4:2:2), 1x1 (4:4:4) */,
                                                            int ctab /* Huffman table set of components 1,2: 1 = chroma (YCbCr), 0 = same as component 0 (RGB) */, int ri, int n_seg,
                                                            uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
-                                                           uint32_t *__restrict__ seg_ff /* final size of the segment */)
+                                                           uint32_t *__restrict__ seg_ff /* final size of the segment */,
+                                                           uint32_t *__restrict__ chunk_tot /* sums of seg_ff over chunks of kChunk segments */)
 {
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
         __shared__ uint32_t win[4][68];
@@ -197,6 +205,7 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         if (lane == 0) {
                 seg_len[seg] = (uint32_t) (4 * wbase + tail);
                 seg_ff[seg] = (uint32_t) (4 * wbase + tail + ff + 2); // bytes this segment occupies in the final stream (stuffed + marker)
+                atomicAdd(&chunk_tot[(seg / kChunk) * kChunkStride], (uint32_t) (4 * wbase + tail + ff + 2));
         }
 }
 
@@ -321,27 +330,34 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
         return nbits;
 }
 
-__global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
-                                                           const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs, int ctab, int ri,
-                                                           int n_seg, int S /* blocks per full segment, <= 64 */, int G /* segments per wave */,
-                                                           uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
-                                                           uint32_t *__restrict__ seg_ff)
+// WAVES = waves per workgroup: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES that
+// leaves the fewest lanes idle: S = 24 blocks -- restart 4, 4:2:0 -- fills 3 waves exactly where one wave would run 48 of 64 lanes).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
+                                                                   const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs, int ctab, int ri,
+                                                                   int n_seg, int S /* blocks per full segment, <= 64 * WAVES */, int G /* segments per workgroup */,
+                                                                   uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
+                                                                   uint32_t *__restrict__ seg_ff, uint32_t *__restrict__ chunk_tot)
 {
+        constexpr int W = 64 * WAVES;
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
-        // one buffer, two lives: first the staging area of the block loads (32 rows of 8 x 16 B, 144 B apart so that the row-wise
-        // reads are conflict-free), then the bit windows of the segments (+ one spare word per lane for the multi-pass variant)
+        // one buffer, two lives: first the staging area of the block loads (per wave 32 rows of 8 x 16 B, 144 B apart so that the
+        // row-wise reads are conflict-free), then the bit windows of the segments (+ one spare word per lane for the multi-pass variant)
         constexpr int kStageRow = 9; // uint4 per row
-        __shared__ __attribute__((aligned(16))) uint32_t shared_words[32 * kStageRow * 4];
-        static_assert(32 * kStageRow * 4 >= 64 * kWinWordsPerBlock + 64, "window must fit the staging buffer");
+        constexpr int kStageWords = 32 * kStageRow * 4; // per wave
+        __shared__ __attribute__((aligned(16))) uint32_t shared_words[WAVES * kStageWords];
+        static_assert(kStageWords >= 64 * kWinWordsPerBlock + 64, "window must fit the staging buffer");
+        __shared__ int lds_dc[W], lds_excl[W], lds_incl[W], lds_wave_total[WAVES], lds_seg_bits[W], lds_flag[2];
         uint32_t *const win = shared_words;
-        const int lane = threadIdx.x;
-        for (int i = lane; i < 512; i += 64) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        for (int i = tid; i < 512; i += W) {
                 const int sym = i & 255;
                 ac_tab[i >> 8][sym] = (sym == 0x00 || sym == 0xF0) ? 0u : kAcTab[i >> 8][sym]; // EOB / ZRL are emitted explicitly
         }
-        if (lane < 24) dc_tab[lane / 12][lane % 12] = kDcTab[lane / 12][lane % 12];
+        if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
+        if (tid < 2) lds_flag[tid] = 0;
         const int ybl = hs * vs, per_mcu = ybl + 2;
-        const int sl = lane / S, j = lane - sl * S;              // segment of the wave, block of the segment
+        const int sl = tid / S, j = tid - sl * S;                // segment of the workgroup, block of the segment
         const int seg = blockIdx.x * G + sl;
         const int m_first = seg * ri;
         const int n_blk = (sl < G && seg < n_seg) ? per_mcu * (min(n_mcu, m_first + ri) - m_first) : 0;
@@ -361,15 +377,14 @@ __global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__rest
                 // block -- an instruction fetches 8 whole lines -- and the rows are handed to their owners through LDS.
                 const long off = (const char *) p - (const char *) cy;
                 const int off_lo = (int) off, off_hi = (int) (off >> 32);
-                uint4 *const stage = (uint4 *) shared_words;
-                // two halves of 32 blocks, so that the staging rows take 4.5 KB instead of 9: with the tables that is 6.7 KB per
-                // wave, and all waves of a 4K frame (15.8 per CU) are resident at once instead of leaving a tail of lone waves
+                uint4 *const stage = (uint4 *) (shared_words + wv * kStageWords);
+                // two halves of 32 blocks, so that the staging rows take 4.5 KB per wave instead of 9
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                         uint4 t[4];
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                                const int owner = 32 * half + (lane >> 3) + 8 * i; // lane that owns the block this lane helps to fetch
+                                const int owner = 32 * half + (lane >> 3) + 8 * i; // lane (of this wave) that owns the block this lane helps to fetch
                                 const unsigned lo = (unsigned) __builtin_amdgcn_ds_bpermute(4 * owner, off_lo);
                                 const long hi = __builtin_amdgcn_ds_bpermute(4 * owner, off_hi);
                                 t[i] = ((const uint4 *) ((const char *) cy + ((hi << 32) | (long) lo)))[lane & 7];
@@ -390,14 +405,14 @@ __global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__rest
                         __builtin_amdgcn_wave_barrier();
                 }
         }
-        __syncthreads(); // tables
         // DC difference: the previous block of the same component sits `back` lanes below (luma: the previous luma block of the
         // scan -- one lane back, or across the two chroma blocks of the previous MCU; chroma: one MCU back); none at a segment start
         const int dc = coef_at(w, 0);
+        lds_dc[tid] = dc;
+        __syncthreads(); // tables, DC values; the staging rows have been read
         const int back = b < ybl ? (b > 0 ? 1 : 3) : per_mcu;
         const bool has_pred = b < ybl ? j > 0 : ml > 0;
-        const int dc_prev = __builtin_amdgcn_ds_bpermute(4 * ((lane - back) & 63), dc);
-        const int diff = dc - (has_pred ? dc_prev : 0);
+        const int diff = dc - (has_pred ? lds_dc[max(tid - back, 0)] : 0);
         const uint32_t dneg = (uint32_t) (diff >> 31), da = ((uint32_t) diff ^ dneg) - dneg;
         const uint32_t dsize = 32u - (uint32_t) __clz((int) da);
         const uint32_t de = dc_tab[comp][dsize];
@@ -411,48 +426,52 @@ __global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__rest
                 nbits = (de >> 16) + dsize + walk_block<false, false>(w, tab, zrl, eob, none, zrl_seen);
         }
         if (!active) nbits = 0;
-        // ---- bit position of every block inside its segment ----
-        const int incl = wave_inclusive_scan((int) nbits, lane);
-        const int excl = incl - (int) nbits;
-        const int first_lane = min(sl * S, 63);
-        const int seg_base = __builtin_amdgcn_ds_bpermute(4 * first_lane, excl);
-        const int seg_last = __builtin_amdgcn_ds_bpermute(4 * min(first_lane + max(n_blk, 1) - 1, 63), incl);
-        const int seg_bits = sl < G ? seg_last - seg_base : 0; // total bits of this lane's segment (same in all its lanes)
-        uint32_t *const mywin = win + first_lane * kWinWordsPerBlock; // the segment's window: kWinWordsPerBlock words per block of the segment
-        uint32_t *const spare = win + 64 * kWinWordsPerBlock;
+        // ---- bit position of every block inside its segment: prefix sum over the workgroup, made segment-relative ----
+        const int incl_w = wave_inclusive_scan((int) nbits, lane);
+        if (lane == 63) lds_wave_total[wv] = incl_w;
+        __syncthreads();
+        int wave_base = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) wave_base += k < wv ? lds_wave_total[k] : 0;
+        const int incl = wave_base + incl_w, excl = incl - (int) nbits;
+        lds_excl[tid] = excl;
+        lds_incl[tid] = incl;
+        __syncthreads();
+        const int first_tid = min(sl * S, W - 1);
+        const int seg_base = lds_excl[first_tid];
+        const int seg_bits = sl < G ? lds_incl[min(first_tid + max(n_blk, 1) - 1, W - 1)] - seg_base : 0; // total bits of this lane's segment
+        if (j == 0 && sl < G) lds_seg_bits[sl] = seg_bits;
+        uint32_t *const mywin = win + first_tid * kWinWordsPerBlock; // the segment's window: kWinWordsPerBlock words per block of the segment
+        uint32_t *const spare = win + W * kWinWordsPerBlock;
         const int cap = S * kWinWordsPerBlock;                  // words of a segment's window
         const int seg_words = (seg_bits + 31) >> 5;
         const int p0 = excl - seg_base;                          // bit position of this lane's block in its segment
         const uint32_t dc_vb = ((uint32_t) diff + dneg) & ((1u << dsize) - 1u);
         const uint32_t dc_str = active ? ((de & 0xffffu) << dsize) | dc_vb : 0u, dc_n = active ? (de >> 16) + dsize : 0u;
-        const bool multi = __any(seg_words > cap);               // some segment of the wave is longer than its window (rare)
-        int passes = 1;
-        if (multi) {
-                int mx = seg_words;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __builtin_amdgcn_ds_bpermute(4 * ((lane + o) & 63), mx));
-                passes = (__builtin_amdgcn_readfirstlane(mx) + cap - 1) / cap;
-        }
+        // some segment of the workgroup longer than its window (rare)?  then everybody goes through the windows in `passes` passes
+        if (seg_words > cap) atomicMax(&lds_flag[0], seg_words);
+        __syncthreads();
+        const int longest = lds_flag[0]; // 0: everything fits
+        const bool multi = longest != 0;
+        const int passes = multi ? (longest + cap - 1) / cap : 1;
+        const bool any_zrl = __any(zrl_seen);
         // zero the words the segment uses in a pass (+ one for the padding), cooperatively: lane j takes words j, j + S, ...
         auto zero_window = [&](int lo_idx) {
                 if (sl < G) {
                         const int nw = min(cap, seg_words + 1 - lo_idx);
                         for (int i = j; i < nw; i += S) mywin[i] = 0;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                __syncthreads();
         };
-        // pad, flush, count: segment after segment (wave-uniform loop), 64 words at a time
+        // pad, flush, count: the segments of the workgroup are dealt to its waves, 64 words at a time
         auto flush_window = [&](int pass, int lo_idx) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                __syncthreads();
 #pragma unroll 1
-                for (int s2 = 0; s2 < G; s2++) {
+                for (int s2 = wv; s2 < G; s2 += WAVES) {
                         const int sg = blockIdx.x * G + s2;
                         if (sg >= n_seg) break;
-                        const int fl = s2 * S;
-                        const int bits = __builtin_amdgcn_readlane(seg_bits, fl);
-                        uint32_t *const sw = win + fl * kWinWordsPerBlock;
+                        const int bits = lds_seg_bits[s2];
+                        uint32_t *const sw = win + s2 * S * kWinWordsPerBlock;
                         const int nbytes = (bits + 7) >> 3;
                         const int padw = (bits >> 5) - lo_idx; // window word that holds the last, partial byte
                         if (lane == 0 && (bits & 7) && padw >= 0 && padw < cap) { // pad it with 1-bits (T.81 F.1.2.3)
@@ -474,17 +493,18 @@ __global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__rest
                         if (lane == 0) {
                                 uint32_t prev = 0;
                                 if (pass > 0) prev = seg_ff[sg];
-                                seg_ff[sg] = prev + (uint32_t) ff_all + (pass == 0 ? (uint32_t) nbytes + 2u : 0u); // stuffed size + marker
+                                const uint32_t more = (uint32_t) ff_all + (pass == 0 ? (uint32_t) nbytes + 2u : 0u); // stuffed size + marker
+                                seg_ff[sg] = prev + more;
+                                atomicAdd(&chunk_tot[(sg / kChunk) * kChunkStride], more);
                                 if (pass == 0) seg_len[sg] = (uint32_t) nbytes;
                         }
                 }
-                __builtin_amdgcn_wave_barrier();
+                __syncthreads();
         };
-        // ---- emission walk (idle lanes hold an all-zero block: they only OR zeros into the spare word) ----
+        // ---- emission walk ----
         if (__builtin_expect(!multi, 1)) {
                 zero_window(0);
-                const bool any_zrl = __any(zrl_seen);
-                if (active) { // idle lanes stay out: 16 of them OR-ing zeros into one spare word would serialise every LDS atomic of the wave
+                if (active) { // idle lanes stay out of the walk
                         BitSink<false> sink = { 0, 0, (uint32_t) p0 & 31u, mywin + (p0 >> 5), 0, 0, 0, spare };
                         sink.append(dc_str, dc_n);
                         if (__builtin_expect(!any_zrl, 1)) {
@@ -507,7 +527,7 @@ __global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__rest
                         zero_window(pass * cap);
                         if (active) {
                                 // words outside this pass's window go to a spare word of the lane's own (no hot spot)
-                                BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) (pass * cap), (uint32_t) cap, spare + lane };
+                                BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) (pass * cap), (uint32_t) cap, spare + tid };
                                 sink.append(dc_str, dc_n);
                                 (void) walk_block<true, true>(w, tab, zrl, eob, sink, zrl_seen);
                                 sink.finish();
@@ -517,58 +537,31 @@ __global__ __launch_bounds__(64) void entropy_block_kernel(const int16_t *__rest
         }
 }
 
-// exclusive prefix sum of the final segment sizes, single workgroup, 4096 elements per pass (one 16-byte load per lane);
-// off[n_seg] = total stream length.  seg_tot is padded to a multiple of 4 entries.
-__global__ __launch_bounds__(1024) void segment_offsets_kernel(const uint32_t *__restrict__ seg_tot, int n_seg, uint32_t header_len,
-                                                               uint32_t *__restrict__ off, uint32_t *__restrict__ total_pinned)
-{
-        __shared__ uint32_t wave_sum[16];
-        __shared__ uint32_t carry_s;
-        const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-        if (t == 0) carry_s = header_len;
-        __syncthreads();
-        for (int base = 0; base < n_seg; base += 4096) {
-                const int i = base + 4 * t;
-                uint4 x = make_uint4(0, 0, 0, 0);
-                if (i < n_seg) x = *(const uint4 *) (seg_tot + i);
-                if (i + 1 >= n_seg) x.y = 0;
-                if (i + 2 >= n_seg) x.z = 0;
-                if (i + 3 >= n_seg) x.w = 0;
-                const uint32_t mine = x.x + x.y + x.z + x.w;
-                const uint32_t incl = (uint32_t) wave_inclusive_scan((int) mine, lane);
-                if (lane == 63) wave_sum[wv] = incl;
-                __syncthreads();
-                uint32_t before = carry_s;
-                for (int k = 0; k < wv; k++) before += wave_sum[k];
-                const uint32_t o0 = before + incl - mine;
-                if (i < n_seg) off[i] = o0;
-                if (i + 1 < n_seg) off[i + 1] = o0 + x.x;
-                if (i + 2 < n_seg) off[i + 2] = o0 + x.x + x.y;
-                if (i + 3 < n_seg) off[i + 3] = o0 + x.x + x.y + x.z;
-                __syncthreads();
-                if (t == 1023) carry_s = before + incl;
-                __syncthreads();
-        }
-        if (t == 0) {
-                off[n_seg] = carry_s;
-                *total_pinned = carry_s; // pinned host memory mapped into the device: the length needs no copy back
-        }
-}
-
-// one wave per segment: move its bytes to the final position, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
-// append RSTm (or EOI after the last segment)
+// one wave per segment: find its position (see kChunk), move its bytes there, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
+// append RSTm (or EOI after the last segment).  The wave of the last segment also reports the stream length, and the first
+// workgroup clears the chunk totals the NEXT frame's coder will add to (two sets, used alternately).
 __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ raw, int cap_bytes, const uint32_t *__restrict__ seg_len,
-                                                      const uint32_t *__restrict__ off, int n_seg, uint8_t *__restrict__ out,
-                                                      const uint8_t *__restrict__ header, int header_len, size_t capacity)
+                                                      const uint32_t *__restrict__ seg_ff, const uint32_t *__restrict__ chunk_tot,
+                                                      uint32_t *__restrict__ chunk_tot_next, int n_seg, uint8_t *__restrict__ out,
+                                                      const uint8_t *__restrict__ header, int header_len, size_t capacity,
+                                                      uint32_t *__restrict__ total_pinned)
 {
         if (blockIdx.x == 0) { // the first workgroup also lays down SOI .. SOS
                 for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
+                for (int i = threadIdx.x; i < (n_seg + kChunk - 1) / kChunk; i += 256) chunk_tot_next[i * kChunkStride] = 0;
         }
         const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (seg >= n_seg) return;
-        if ((size_t) off[seg + 1] > capacity) return; // would not fit: the host reports the needed size from off[n_seg]
+        uint32_t before = 0; // per lane; reduced below
+        const int chunk = seg / kChunk;
+        for (int i = lane; i < chunk; i += 64) before += chunk_tot[i * kChunkStride];
+        for (int i = chunk * kChunk + lane; i < seg; i += 64) before += seg_ff[i];
+        const uint32_t off = (uint32_t) header_len + (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan((int) before, lane), 63);
+        const uint32_t end = off + seg_ff[seg];
+        if (seg == n_seg - 1 && lane == 0) *total_pinned = end; // pinned host memory mapped into the device: the length needs no copy back
+        if ((size_t) end > capacity) return; // would not fit: the host reports the needed size from the total
         const uint8_t *s = raw + (size_t) seg * cap_bytes;
-        uint8_t *d = out + off[seg];
+        uint8_t *d = out + off;
         const uint32_t n = seg_len[seg];
         uint32_t extra = 0; // zeros inserted so far (wave-uniform)
         for (uint32_t base = 0; base < n; base += 64) {
@@ -576,10 +569,10 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
                 const bool valid = i < n;
                 const uint8_t b = valid ? s[i] : 0;
                 const unsigned long long ffm = __ballot(valid && b == 0xFF);
-                const uint32_t before = (uint32_t) __builtin_popcountll(ffm & ((1ull << lane) - 1ull));
+                const uint32_t bef = (uint32_t) __builtin_popcountll(ffm & ((1ull << lane) - 1ull));
                 if (valid) {
-                        d[i + extra + before] = b;
-                        if (b == 0xFF) d[i + extra + before + 1] = 0;
+                        d[i + extra + bef] = b;
+                        if (b == 0xFF) d[i + extra + bef + 1] = 0;
                 }
                 extra += (uint32_t) __builtin_popcountll(ffm);
         }
@@ -597,7 +590,9 @@ struct Encoder {
         float *div;
         int16_t *cy, *cb, *cr;
         uint32_t *scratch; // per-segment scan data before byte stuffing, cap bytes each
-        uint32_t *seg_len, *seg_ff, *off;
+        uint32_t *seg_len, *seg_ff;
+        uint32_t *chunk_tot[2]; // sums of seg_ff per kChunk segments: the coder of frame k adds to set k & 1, its compaction clears the other
+        unsigned frame_no;
         uint8_t *header_dev;
         uint32_t *total_host; // pinned, mapped
         uint32_t *total_host_dev; // the same word as the device sees it
@@ -650,7 +645,7 @@ void destroy(Encoder *e)
 {
         if (!e) return;
         for (void *p : { (void *) e->div, (void *) e->cy, (void *) e->cb, (void *) e->cr, (void *) e->scratch, (void *) e->seg_len,
-                         (void *) e->seg_ff, (void *) e->off, (void *) e->header_dev }) {
+                         (void *) e->seg_ff, (void *) e->chunk_tot[0], (void *) e->chunk_tot[1], (void *) e->header_dev }) {
                 if (p) (void) hipFree(p);
         }
         if (e->total_host) (void) hipHostFree(e->total_host);
@@ -697,7 +692,11 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         alloc((void **) &e->scratch, (size_t) e->n_seg * e->cap);
         alloc((void **) &e->seg_len, (size_t) e->n_seg * 4);
         alloc((void **) &e->seg_ff, ((size_t) e->n_seg + 4) * 4);
-        alloc((void **) &e->off, (size_t) (e->n_seg + 1) * 4);
+        const size_t chunk_bytes = (size_t) ((e->n_seg + kChunk - 1) / kChunk) * kChunkStride * 4;
+        alloc((void **) &e->chunk_tot[0], chunk_bytes);
+        alloc((void **) &e->chunk_tot[1], chunk_bytes);
+        if (err == hipSuccess) err = hipMemset(e->chunk_tot[0], 0, chunk_bytes);
+        if (err == hipSuccess) err = hipMemset(e->chunk_tot[1], 0, chunk_bytes);
         alloc((void **) &e->header_dev, e->header.size());
         if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocMapped);
         if (err == hipSuccess) err = hipHostGetDevicePointer((void **) &e->total_host_dev, e->total_host, 0);
@@ -763,18 +762,33 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
         }
         if (rc != UG_HIP_SUCCESS) return rc;
         const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
-        if (S <= 64 && !e->force_wave_kernel) {
-                const int G = 64 / S;
-                hipLaunchKernelGGL(entropy_block_kernel, dim3((e->n_seg + G - 1) / G), dim3(64), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
-                                   e->sub == 444 ? 0 : 1, e->ri, e->n_seg, S, G, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
+        uint32_t *const tot = e->chunk_tot[e->frame_no & 1], *const tot_next = e->chunk_tot[(e->frame_no + 1) & 1];
+        e->frame_no++;
+        if (S <= 256 && !e->force_wave_kernel) {
+                // waves per workgroup: the count that leaves the fewest lanes idle (fewer waves on a tie)
+                int waves = 1;
+                for (int k = 1; k <= 4; k++) {
+                        if (64 * k >= S && (64 * k / S) * S * (64 * waves) > (64 * waves / S) * S * (64 * k)) waves = k;
+                        if (64 * waves < S) waves = k;
+                }
+                const int G = 64 * waves / S;
+                const dim3 grid((e->n_seg + G - 1) / G);
+#define UG_LAUNCH_EBK(NW)                                                                                                                      \
+        hipLaunchKernelGGL(entropy_block_kernel<NW>, grid, dim3(64 * NW), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,      \
+                           e->sub == 444 ? 0 : 1, e->ri, e->n_seg, S, G, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot)
+                switch (waves) {
+                case 1: UG_LAUNCH_EBK(1); break;
+                case 2: UG_LAUNCH_EBK(2); break;
+                case 3: UG_LAUNCH_EBK(3); break;
+                default: UG_LAUNCH_EBK(4); break;
+                }
+#undef UG_LAUNCH_EBK
         } else {
                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs, e->sub == 444 ? 0 : 1, e->ri,
-                                   e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff);
+                                   e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot);
         }
-        hipLaunchKernelGGL(segment_offsets_kernel, dim3(1), dim3(1024), 0, st, e->seg_ff, e->n_seg, (uint32_t) e->header.size(), e->off,
-                           e->total_host_dev);
-        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->off,
-                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity);
+        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, tot, tot_next,
+                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev);
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipStreamSynchronize(st));
         *out_len = *e->total_host;
