@@ -519,3 +519,24 @@ def _to_codec(po, rgb, codec, w, h):
         cur = conv(cur, name, nxt)
         name = nxt
     return cur   # DVS10: v210 bytes are a valid DVS10 frame as far as the decoder is concerned (same 6 px / 16 B grouping)
+
+
+@needs_harness
+@pytest.mark.gpu
+def test_jpeg_option_forms_of_the_reference_module(tmp_path):
+    """gpujpeg.cpp:376-418: `<quality>[:<restart>]` positionally, quality= / restart=, interleaved, the internal colour space the module
+    would use anyway (RGB for RGB input, Y709 for 4:2:x input); what needs a colour conversion or alpha is refused / warned about."""
+    w, h = 64, 32
+    raw = tmp_path / "in.raw"
+    synth.s2_video("UYVY", w, h).tofile(raw)
+    outs = []
+    for cfg in ("jpeg:q=60:restart=3", "jpeg:60:3", "jpeg:quality=60:restart=3:interleaved:Y709"):
+        out = tmp_path / f"o{len(outs)}.jpg"
+        r = _run([cfg, "UYVY", w, h, raw, out])
+        assert r.returncode == 0, cfg + r.stdout + r.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] == outs[2]
+    assert _run(["jpeg:Y601", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 2
+    assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails: frame dropped
+    r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
+    assert r.returncode == 0 and "alpha" in (r.stdout + r.stderr)

@@ -11,6 +11,7 @@
  * line loop of gpujpeg.cpp:592-608; tile API with one stream per module instance; no CPU fallback.
  */
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,7 @@ struct state_video_compress_jpeg_mi355x {
         struct video_desc    saved_desc{};
         int                  device = 0, quality = 75, restart = 2;
         int                  subsampling = 0;  ///< 0 = autoselect: that of the input codec (gpujpeg.cpp:168,295-302)
+        int                  internal_cs = 0;  ///< 0 = as the input dictates, 1 = "RGB", 2 = "Y709" asked for (gpujpeg.cpp:398-405)
         ug_pixfmt_t          wire = UG_PF_NONE;     ///< format of the uploaded frame
         ug_pixfmt_t          target = UG_PF_NONE;   ///< what the reference's CPU line decoder would convert it to (UYVY, RGB or RGBA)
         ug_pixfmt_t          enc_in = UG_PF_NONE;   ///< what the encoder is fed: UYVY, RGB or I420
@@ -68,7 +70,7 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:dev=<index>[,<index>...]][:workers=<per device>]\n"
+               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y709][:dev=<index>[,<index>...]][:workers=<per device>]\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
                "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
                "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
@@ -80,10 +82,13 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
         auto *s = new state_video_compress_jpeg_mi355x();
         std::string cfg = fmt ? fmt : "";
         size_t pos = 0;
+        int numeric = 0;
         while (!cfg.empty() && pos <= cfg.size()) {
                 size_t end = cfg.find(':', pos);
                 std::string tok = cfg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
-                if (strncasecmp(tok.c_str(), "q=", 2) == 0) {
+                if (!tok.empty() && isdigit((unsigned char) tok[0])) { // gpujpeg.cpp:379-391: "-c gpujpeg:<quality>[:<restart interval>]"
+                        (numeric++ == 0 ? s->quality : s->restart) = atoi(tok.c_str());
+                } else if (strncasecmp(tok.c_str(), "q=", 2) == 0) {
                         s->quality = atoi(tok.c_str() + 2);
                 } else if (strncasecmp(tok.c_str(), "quality=", 8) == 0) {
                         s->quality = atoi(tok.c_str() + 8);
@@ -91,6 +96,18 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                         s->restart = atoi(tok.c_str() + 8);
                 } else if (strncasecmp(tok.c_str(), "subsampling=", 12) == 0 || strncasecmp(tok.c_str(), "sub=", 4) == 0) {
                         s->subsampling = atoi(strchr(tok.c_str(), '=') + 1); // gpujpeg.cpp:406-408
+                } else if (strncasecmp(tok.c_str(), "interleaved", 11) == 0) {
+                        // gpujpeg.cpp:396-397 forces one interleaved scan for RGB input: this encoder always writes one interleaved scan
+                } else if (strcasecmp(tok.c_str(), "RGB") == 0 || strcasecmp(tok.c_str(), "Y709") == 0) {
+                        // gpujpeg.cpp:398-405 (internal colour space): the two the module uses anyway -- R,G,B for RGB-family input, BT.709
+                        // limited-range YCbCr samples as they come for 4:2:x input (gpujpeg.cpp:303-305); checked against the input at configure
+                        s->internal_cs = strcasecmp(tok.c_str(), "RGB") == 0 ? 1 : 2;
+                } else if (strcasecmp(tok.c_str(), "Y601") == 0 || strcasecmp(tok.c_str(), "Y601full") == 0) {
+                        MSG(ERROR, "internal colour space %s needs a colour conversion this encoder does not do (samples are coded as they come)\n", tok.c_str());
+                        delete s;
+                        return nullptr;
+                } else if (tok == "alpha") {
+                        MSG(WARNING, "alpha is not coded by this encoder; the option is ignored\n"); // gpujpeg.cpp:409-414 warns likewise when unsupported
                 } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
                         s->device = atoi(tok.c_str() + 4);
                 } else if (tok == "help") {
@@ -148,6 +165,11 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 rgb_family = s->target != UG_PF_UYVY;
         }
         const int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (s->wire == UG_PF_I420 ? 420 : 422));
+        if (s->internal_cs != 0 && (s->internal_cs == 1) != (sub == 444)) {
+                MSG(ERROR, "internal colour space %s does not match what this input is coded as (%s): no colour conversion is done\n",
+                    s->internal_cs == 1 ? "RGB" : "Y709", sub == 444 ? "R,G,B 4:4:4" : "YCbCr 4:2:x");
+                return false;
+        }
         if (s->wire == UG_PF_I420) {
                 if (sub != 420) {
                         MSG(ERROR, "I420 input can only be coded as 4:2:0\n");
