@@ -362,6 +362,30 @@ size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc);
 int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch,
                                   void *out_dev, size_t out_capacity, size_t *out_len, ug_hip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * JPEG decoder (receive side: gpujpeg_decoder_create / _decode / _destroy behind
+ * src/video_decompress/gpujpeg.c:74-140,292-301)
+ * ---------------------------------------------------------------------------------- */
+/* Baseline JPEG (8-bit, Huffman; 3 components at 4:4:4 / 4:2:2 / 4:2:0, interleaved or one scan per component; restart intervals make the
+ * entropy-coded data parallel: one lane per restart segment) -> `out` in device memory:
+ *   YCbCr streams -> UG_PF_UYVY (4:2:2: samples as they are; 4:2:0: chroma lines repeated, yuv420p_to_uyvy; 4:4:4: chroma pairs averaged),
+ *                    UG_PF_RGB / UG_PF_RGBA (the UYVY form through vc_copylineUYVYtoRGB[A]: BT.709 limited range, as UltraGrid codes it),
+ *                    UG_PF_I420 (4:2:0 streams: planes back to back);
+ *   R,G,B streams (Adobe APP14 transform 0 or component ids 'R','G','B': what `-c jpeg` writes for RGB input) -> UG_PF_RGB / UG_PF_RGBA
+ *                    directly, UG_PF_UYVY through vc_copylineRGBtoUYVY's arithmetic.
+ * The component planes equal libjpeg's bit for bit (integer IDCT jidctint).  `jpeg_host` is host memory (compressed frames arrive from the
+ * network); everything after the header parse is asynchronous on `stream`.  UG_PF_NONE: decode to the internal planes only
+ * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout: UG_HIP_EUNSUPP. */
+typedef struct ug_hip_jpeg_decoder ug_hip_jpeg_decoder;
+int  ug_hip_jpeg_decoder_create(ug_hip_jpeg_decoder **out);
+void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec);
+/* header only: subsampling = 444 / 422 / 420 / 400 (greyscale); any pointer may be NULL */
+int  ug_hip_jpeg_read_info(const void *jpeg_host, size_t len, int *width, int *height, int *subsampling, int *is_rgb, int *restart_interval);
+int  ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, size_t len, ug_pixfmt_t out, void *dst_dev, int dst_pitch,
+                                int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* component plane of the last decode (device memory, padded to whole MCUs; width / height = the component's own size) */
+int  ug_hip_jpeg_decoder_plane(const ug_hip_jpeg_decoder *dec, int component, const void **plane_dev, int *pitch, int *width, int *height);
+
 #ifdef __cplusplus
 }
 #endif

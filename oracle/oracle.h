@@ -101,4 +101,9 @@ extern const uint8_t oracle_jpeg_zigzag[64];
 #ifdef __cplusplus
 }
 #endif
+/* jpeg_decode_oracle.c: baseline JPEG -> component planes (T.81 Huffman decoding + libjpeg's jidctint "islow" IDCT).  info[12] =
+ * width, height, components, h0, v0, h1, v1, h2, v2, restart interval, Adobe transform (-1 = no marker), scans.  planes[c]: MCU-padded
+ * plane of component c ((mcu_w * 8 * h_c) x (mcu_h * 8 * v_c)), pitch[c] bytes per line; planes == NULL: headers only. */
+int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *planes[3], const int pitch[3]);
+
 #endif

@@ -462,6 +462,30 @@ def jpeg_fdct_quant_plane(plane: np.ndarray, div: np.ndarray, blocks_w: int | No
     return (out, coef) if want_coef else out
 
 
+def jpeg_decode_planes(data: bytes):
+    """oracle/jpeg_decode_oracle.c: (info dict, [planes at their own resolution, cropped to the component size])."""
+    l = lib()
+    l.oracle_jpeg_decode.restype = C.c_int
+    l.oracle_jpeg_decode.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    info = (C.c_int * 12)()
+    rc = l.oracle_jpeg_decode(data, len(data), info, None, None)
+    if rc:
+        raise ValueError(f"oracle_jpeg_decode rc={rc}")
+    w, h, nc = info[0], info[1], info[2]
+    hs, vs = [info[3], info[5], info[7]][:nc], [info[4], info[6], info[8]][:nc]
+    hmax, vmax = max(hs), max(vs)
+    mw, mh = -(-w // (8 * hmax)), -(-h // (8 * vmax))
+    planes = [np.zeros((mh * 8 * vs[c], mw * 8 * hs[c]), np.uint8) for c in range(nc)]
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes] + [None] * (3 - nc))
+    pitch = (C.c_int * 3)(*[p.shape[1] for p in planes] + [0] * (3 - nc))
+    rc = l.oracle_jpeg_decode(data, len(data), info, ptrs, pitch)
+    if rc:
+        raise ValueError(f"oracle_jpeg_decode rc={rc}")
+    d = dict(width=w, height=h, components=nc, h=hs, v=vs, restart=info[9], adobe=info[10], scans=info[11])
+    crop = [planes[c][: -(-h * vs[c] // vmax), : -(-w * hs[c] // hmax)] for c in range(nc)]
+    return d, crop, planes
+
+
 ZIGZAG = np.array([
     0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34,
     27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,

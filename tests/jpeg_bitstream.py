@@ -153,3 +153,37 @@ def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, rest
     out.write(bytes(bw.buf))
     out.write(b"\xff\xd9")
     return out.getvalue()
+
+
+def write_jpeg_noninterleaved(width, height, qt, coefs, restart=0):
+    """Baseline R,G,B 4:4:4 stream with ONE SCAN PER COMPONENT (T.81 A.2.2: a non-interleaved scan walks the component's own
+    ceil(size / 8) block grid; the restart interval counts its data units) -- the layout GPUJPEG writes for RGB input by default
+    (gpujpeg.cpp:302: interleaved = 0).  coefs: three (n_blocks, 64) zig-zag arrays over the 8x8-block grid; table 0 for everything."""
+    bw_, bh_ = (width + 7) // 8, (height + 7) // 8
+    out = io.BytesIO()
+    out.write(b"\xff\xd8")
+    out.write(b"\xff\xee" + struct.pack(">H5sHHHB", 14, b"Adobe", 100, 0, 0, 0))
+    out.write(b"\xff\xdb" + struct.pack(">HB", 67, 0) + bytes(int(qt[i]) for i in ZIGZAG))
+    ids = (0x52, 0x47, 0x42)
+    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([ids[0], 0x11, 0, ids[1], 0x11, 0, ids[2], 0x11, 0]))
+    for (tc, th, (bits, vals)) in ((0, 0, DC_L), (1, 0, AC_L)):
+        out.write(b"\xff\xc4" + struct.pack(">HB", 19 + len(vals), (tc << 4) | th) + bytes(bits) + bytes(vals))
+    if restart:
+        out.write(b"\xff\xdd" + struct.pack(">HH", 4, restart))
+    dcl, acl = _codes(*DC_L), _codes(*AC_L)
+    for c in range(3):
+        out.write(b"\xff\xda" + struct.pack(">HB", 8, 1) + bytes([ids[c], 0x00, 0, 63, 0]))
+        bw = _Bits()
+        pred = 0
+        for u in range(bw_ * bh_):
+            if restart and u and u % restart == 0:
+                bw.flush()
+                out.write(bytes(bw.buf))
+                out.write(bytes([0xFF, 0xD0 + ((u // restart - 1) & 7)]))
+                bw = _Bits()
+                pred = 0
+            pred = _block(bw, coefs[c][u], pred, dcl, acl)
+        bw.flush()
+        out.write(bytes(bw.buf))
+    out.write(b"\xff\xd9")
+    return out.getvalue()

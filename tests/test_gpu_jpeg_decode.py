@@ -1,0 +1,134 @@
+"""GPU parity: the HIP JPEG decoder (through the C ABI) against oracle/jpeg_decode_oracle.c (itself pinned to libjpeg-turbo,
+tests/test_oracle_jpeg_decode.py): component planes bit for bit, then every output codec as the composition the header states."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_oracle_jpeg_decode import CASES, picture, pil_jpeg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+@pytest.mark.parametrize("size", [(200, 120), (17, 9), (640, 360)])
+def test_planes_equal_the_oracle(hip, po, kw, size):
+    w, h = size
+    data = pil_jpeg(picture(w, h, seed=w), **kw)
+    _, crop, _ = po.jpeg_decode_planes(data)
+    dec = hip.JpegDecoder()
+    got = dec.planes(data)
+    dec.close()
+    assert len(got) == 3
+    for c in range(3):
+        assert np.array_equal(got[c].cpu().numpy(), crop[c]), c
+
+
+def _own_stream(hip, src, fmt, w, h, q, ri, sub):
+    import torch
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+    data = enc.encode(torch.from_numpy(src).cuda(), fmt)
+    enc.close()
+    return data
+
+
+@pytest.mark.parametrize("sub,ri", [(422, 4), (420, 2), (420, 7), (444, 4), (422, 1), (422, 40)])
+def test_round_trip_of_the_repository_encoder(hip, po, sub, ri):
+    """`-c jpeg` streams (4:2:2 / 4:2:0 YCbCr, R,G,B 4:4:4; restart intervals) decode to the oracle's planes; the outputs are what the header says:
+    4:2:2 -> UYVY = the planes interleaved, RGB / RGBA = UltraGrid's own UYVY -> RGB of that, I420 from 4:2:0, R,G,B streams packed directly."""
+    from ultragrid_amd import lib as L, synth
+    w, h = 208, 88
+    rgb = picture(w, h, seed=9, noise=2.0)
+    if sub == 444:
+        data = _own_stream(hip, np.ascontiguousarray(rgb).ravel(), L.PF_RGB, w, h, 85, ri, 444)
+    else:
+        data = _own_stream(hip, po.convert_frame("RGB", "UYVY", rgb, w, h), L.PF_UYVY, w, h, 85, ri, sub)
+    info = hip.jpeg_read_info(data)
+    assert info == dict(width=w, height=h, subsampling=sub, is_rgb=sub == 444, restart=ri)
+    _, crop, _ = po.jpeg_decode_planes(data)
+    dec = hip.JpegDecoder()
+    for c, pl in enumerate(dec.planes(data)):
+        assert np.array_equal(pl.cpu().numpy(), crop[c]), c
+    if sub == 444:
+        want_rgb = np.stack(crop, -1)
+        assert np.array_equal(dec.decode(data, L.PF_RGB).cpu().numpy().reshape(h, w, 3), want_rgb)
+        for sh in ((0, 8, 16), (16, 8, 0)):
+            assert np.array_equal(dec.decode(data, L.PF_RGBA, sh).cpu().numpy(), po.convert_frame("RGB", "RGBA", want_rgb, w, h, sh))
+        assert np.array_equal(dec.decode(data, L.PF_UYVY).cpu().numpy(), po.convert_frame("RGB", "UYVY", want_rgb, w, h))
+        assert 10 * np.log10(255.0 ** 2 / np.mean((want_rgb.astype(float) - rgb) ** 2)) > 36
+    else:
+        y, u, v = crop
+        want_uyvy = po.planar_to_uyvy(y, u, v, w, h, chroma=sub)
+        assert np.array_equal(dec.decode(data, L.PF_UYVY).cpu().numpy(), want_uyvy)
+        assert np.array_equal(dec.decode(data, L.PF_RGB).cpu().numpy(), po.convert_frame("UYVY", "RGB", want_uyvy, w, h))
+        assert np.array_equal(dec.decode(data, L.PF_RGBA, (16, 8, 0)).cpu().numpy(), po.convert_frame("UYVY", "RGBA", want_uyvy, w, h, (16, 8, 0)))
+        if sub == 420:
+            assert np.array_equal(dec.decode(data, L.PF_I420).cpu().numpy(), np.concatenate([p.ravel() for p in crop]))
+        src_uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+        assert 10 * np.log10(255.0 ** 2 / np.mean((want_uyvy.reshape(h, -1)[:, 1::2].astype(float) - src_uyvy.reshape(h, -1)[:, 1::2]) ** 2)) > 38
+    dec.close()
+
+
+def test_yuv444_to_uyvy_averages_chroma_pairs(hip, po):
+    """4:4:4 YCbCr -> UYVY: luma as it is, chroma of a pixel pair = (a + b) / 2 (as UltraGrid's own 4:4:4 -> 4:2:2 converters do)."""
+    from ultragrid_amd import lib as L
+    w, h = 100, 36
+    data = pil_jpeg(picture(w, h, seed=2), quality=90, subsampling=0)
+    _, crop, _ = po.jpeg_decode_planes(data)
+    dec = hip.JpegDecoder()
+    got = dec.decode(data, L.PF_UYVY).cpu().numpy().reshape(h, w // 2, 4)
+    y, u, v = (c.astype(int) for c in crop)
+    assert np.array_equal(got[..., 1], y[:, 0::2]) and np.array_equal(got[..., 3], y[:, 1::2])
+    assert np.array_equal(got[..., 0], (u[:, 0::2] + u[:, 1::2]) // 2) and np.array_equal(got[..., 2], (v[:, 0::2] + v[:, 1::2]) // 2)
+    dec.close()
+
+
+@pytest.mark.parametrize("ri", [0, 5])
+def test_one_scan_per_component(hip, po, ri):
+    """The layout GPUJPEG writes for RGB input by default (gpujpeg.cpp:302, interleaved = 0): three non-interleaved scans, each over its own
+    block grid with its own restart segments (tests/jpeg_bitstream.py::write_jpeg_noninterleaved; libjpeg decodes it to the same planes,
+    tests/test_oracle_jpeg_decode.py)."""
+    from jpeg_bitstream import write_jpeg_noninterleaved
+    from ultragrid_amd import lib as L
+    w, h = 150, 70
+    rgb = picture(w, h, seed=4)
+    ql = po.jpeg_qtable(85, 0)
+    coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(rgb[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+    data = write_jpeg_noninterleaved(w, h, ql, coefs, restart=ri)
+    info, crop, _ = po.jpeg_decode_planes(data)
+    assert info["scans"] == 3
+    dec = hip.JpegDecoder()
+    for c, pl in enumerate(dec.planes(data)):
+        assert np.array_equal(pl.cpu().numpy(), crop[c]), c
+    assert np.array_equal(dec.decode(data, L.PF_RGB).cpu().numpy().reshape(h, w, 3), np.stack(crop, -1))
+    dec.close()
+
+
+def test_full_4k_frame_and_rejections(hip, po):
+    import torch
+    from ultragrid_amd import lib as L, synth
+    w, h = 3840, 2160
+    src = synth.s2_video("UYVY", w, h)
+    data = _own_stream(hip, src, L.PF_UYVY, w, h, 75, 4, 422)
+    _, crop, _ = po.jpeg_decode_planes(data)
+    dec = hip.JpegDecoder()
+    got = dec.decode(data, L.PF_UYVY).cpu().numpy()
+    assert np.array_equal(got, po.planar_to_uyvy(*crop, w, h, chroma=422))
+    assert 10 * np.log10(255.0 ** 2 / np.mean((got.astype(float) - src) ** 2)) > 36
+    b = io.BytesIO()
+    Image.fromarray(picture(64, 64)).save(b, "JPEG", progressive=True)
+    with pytest.raises(L.UgHipError) as e:
+        dec.decode(b.getvalue(), L.PF_UYVY)
+    assert e.value.rc == L.EUNSUPP
+    with pytest.raises(L.UgHipError):
+        dec.decode(data[: len(data) // 2][:100], L.PF_UYVY)      # headers cut off
+    with pytest.raises(L.UgHipError):
+        dec.decode(data, L.PF_V210)                              # no such output
+    # a stream that lost its tail decodes what arrived (the rest: zero coefficients = mid grey), no crash
+    cut = dec.decode(data[: len(data) // 2] + b"\xff\xd9", L.PF_UYVY).cpu().numpy()
+    assert np.array_equal(cut[: w * 2 * 400], got[: w * 2 * 400])
+    dec.close()

@@ -540,3 +540,51 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
     assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails: frame dropped
     r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
     assert r.returncode == 0 and "alpha" in (r.stdout + r.stderr)
+
+
+@needs_dec_harness
+def test_jpeg_decompress_module_registers():
+    r = subprocess.run([DEC_HARNESS, "list"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "jpeg_mi355x" in r.stdout.split()
+
+
+@needs_harness
+@needs_dec_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec,cfg,out", [("UYVY", "jpeg:q=85:restart=4", "UYVY"), ("UYVY", "jpeg:q=85:restart=4", "RGB"), ("UYVY", "jpeg:q=85:restart=2:subsampling=420", "I420"),
+                                           ("RGB", "jpeg:q=85:restart=4", "RGBA"), ("RGB", "jpeg:q=85:restart=4", "UYVY"), ("v210", "jpeg:q=90", "UYVY")])
+def test_sender_to_receiver_through_both_reference_frameworks(tmp_path, po, codec, cfg, out):
+    """The whole `-c jpeg` story inside UltraGrid's own frameworks: compress_init / compress_frame / compress_pop (video_compress.cpp) on the
+    sending side, then decompress_init_multi / reconfigure / decompress_frame (video_decompress.c: probe first, as the receiver does) on the
+    other; the module's output is the decode oracle's planes put together the way the header of the decoder states, and close to what went in."""
+    w, h = 192, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1).clip(0, 255).astype(np.uint8)
+    uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+    src = {"UYVY": uyvy, "RGB": rgb.ravel(), "v210": po.convert_frame("UYVY", "v210", uyvy, w, h)}[codec]
+    raw, jpg, dec = tmp_path / "in.raw", tmp_path / "f.jpg", tmp_path / "out.raw"
+    np.ascontiguousarray(src).tofile(raw)
+    assert _run([cfg, codec, w, h, raw, jpg]).returncode == 0
+    data = jpg.read_bytes()
+    ls = w * h if out == "I420" else po.linesize(w, out)
+    pitch = ls if out == "I420" else ls + (64 if out == "RGB" else 0)      # one case with a display pitch
+    r = subprocess.run([DEC_HARNESS, "JPEG", out, str(w), str(h), str(jpg), str(dec), str(pitch)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    is_rgb = codec == "RGB"
+    sub = 4200 if "420" in cfg else (4440 if is_rgb else 4220)
+    assert f"depth=8 subsampling={sub} rgb={int(is_rgb)}" in r.stdout, r.stdout
+    _, crop, _ = po.jpeg_decode_planes(data)
+    got = np.fromfile(dec, np.uint8)
+    if out != "I420":
+        got = got.reshape(h, pitch)[:, :ls].ravel()
+    if is_rgb:
+        packed = np.stack(crop, -1)
+        want = {"RGBA": lambda: po.convert_frame("RGB", "RGBA", packed, w, h), "UYVY": lambda: po.convert_frame("RGB", "UYVY", packed, w, h)}[out]()
+        ref_in = {"RGBA": lambda: po.convert_frame("RGB", "RGBA", rgb, w, h), "UYVY": lambda: uyvy}[out]()
+    else:
+        chroma = 420 if "420" in cfg else 422
+        as_uyvy = po.planar_to_uyvy(*crop, w, h, chroma=chroma)
+        want = {"UYVY": lambda: as_uyvy, "RGB": lambda: po.convert_frame("UYVY", "RGB", as_uyvy, w, h), "I420": lambda: np.concatenate([p.ravel() for p in crop])}[out]()
+        ref_in = {"UYVY": lambda: uyvy, "RGB": lambda: po.convert_frame("UYVY", "RGB", uyvy, w, h), "I420": lambda: np.concatenate([p.ravel() for p in po.uyvy_to_i420(uyvy, w, h)])}[out]()
+    assert np.array_equal(got, want)
+    assert 10 * np.log10(255.0 ** 2 / np.mean((got.astype(float) - ref_in.astype(float)) ** 2)) > 33

@@ -317,3 +317,53 @@ class JpegEncoder:
             self.close()
         except Exception:
             pass
+
+
+def jpeg_read_info(data: bytes) -> dict:
+    import ctypes as C
+    w, h, sub, rgb, ri = (C.c_int() for _ in range(5))
+    L.check(L.load().ug_hip_jpeg_read_info(data, len(data), C.byref(w), C.byref(h), C.byref(sub), C.byref(rgb), C.byref(ri)), "ug_hip_jpeg_read_info")
+    return dict(width=w.value, height=h.value, subsampling=sub.value, is_rgb=bool(rgb.value), restart=ri.value)
+
+
+class JpegDecoder:
+    """ug_hip_jpeg_decoder_* (gpujpeg_decoder_create / _decode / _destroy shape, video_decompress/gpujpeg.c:74-140,292-301)."""
+
+    def __init__(self):
+        import ctypes as C
+        self._h = C.c_void_p()
+        L.check(L.load().ug_hip_jpeg_decoder_create(C.byref(self._h)), "ug_hip_jpeg_decoder_create")
+
+    def decode(self, data: bytes, out_fmt: int, shifts=(0, 8, 16), device="cuda") -> torch.Tensor:
+        info = jpeg_read_info(data)
+        w, h = info["width"], info["height"]
+        n = w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2) if out_fmt == L.PF_I420 else linesize(out_fmt, w) * h
+        dst = torch.empty(n, dtype=torch.uint8, device=device)
+        L.check(L.load().ug_hip_jpeg_decoder_decode(self._h, data, len(data), out_fmt, dst.data_ptr(), 0, *shifts, _stream()), "ug_hip_jpeg_decoder_decode")
+        return dst
+
+    def planes(self, data: bytes):
+        """Decode to the component planes only; returns them cropped to the component sizes (device tensors)."""
+        import ctypes as C
+        L.check(L.load().ug_hip_jpeg_decoder_decode(self._h, data, len(data), L.PF_NONE, None, 0, 0, 8, 16, _stream()), "ug_hip_jpeg_decoder_decode")
+        torch.cuda.synchronize()
+        out = []
+        for c in range(3):
+            p, pitch, w, h = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+            if L.load().ug_hip_jpeg_decoder_plane(self._h, c, C.byref(p), C.byref(pitch), C.byref(w), C.byref(h)) != 0:
+                break
+            t = torch.empty((h.value, pitch.value), dtype=torch.uint8, device="cuda")
+            L.check(L.load().ug_hip_memcpy(t.data_ptr(), p.value, pitch.value * h.value, 2), "ug_hip_memcpy")
+            out.append(t[:, : w.value].contiguous())
+        return out
+
+    def close(self):
+        if self._h:
+            L.load().ug_hip_jpeg_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

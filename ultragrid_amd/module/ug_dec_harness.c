@@ -31,14 +31,29 @@ int main(int argc, char **argv)
         const int linesize = vc_get_linesize(w, out);
         const int pitch = argc > 7 ? atoi(argv[7]) : linesize;
         struct video_desc desc = { .width = w, .height = h, .color_spec = in, .fps = 30, .interlacing = PROGRESSIVE, .tile_count = 1 };
-        const size_t in_len = (size_t) w * h / (in == DXT1 || in == DXT1_YUV ? 2 : 1);
-        unsigned char *src = malloc(in_len), *dst = calloc((size_t) pitch * h + 64, 1);
+        size_t in_len = (size_t) w * h / (in == DXT1 || in == DXT1_YUV ? 2 : 1);
         FILE *f = fopen(argv[5], "rb");
-        if (!f || fread(src, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read input\n"); return 1; }
+        if (!f) { fprintf(stderr, "cannot read input\n"); return 1; }
+        if (in == JPEG) { // a compressed frame is as long as it is
+                fseek(f, 0, SEEK_END);
+                in_len = (size_t) ftell(f);
+                fseek(f, 0, SEEK_SET);
+        }
+        const size_t out_bytes = out == I420 ? (size_t) w * h + 2 * (size_t) ((w + 1) / 2) * ((h + 1) / 2) : (size_t) pitch * h;
+        unsigned char *src = malloc(in_len), *dst = calloc(out_bytes + 64, 1);
+        if (fread(src, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read input\n"); return 1; }
         fclose(f);
 
         struct state_decompress *s = NULL;
         struct pixfmt_desc internal = { 0 };
+        if (in == JPEG) { // what the receiver does first (video_decompress.c / rtp/video_decoders.cpp): a probe decoder tells the stream's internal format
+                struct state_decompress *probe = NULL;
+                if (decompress_init_multi(in, internal, VIDEO_CODEC_NONE, &probe, 1) && decompress_reconfigure(probe, desc, 0, 8, 16, 0, VIDEO_CODEC_NONE)) {
+                        const decompress_status ps = decompress_frame(probe, NULL, src, (unsigned) in_len, 0, NULL, &internal);
+                        printf("PROBE status=%d depth=%d subsampling=%d rgb=%d\n", (int) ps, internal.depth, internal.subsampling, (int) internal.rgb);
+                        decompress_done(probe);
+                }
+        }
         if (!decompress_init_multi(in, internal, out, &s, 1)) {
                 fprintf(stderr, "no decompressor for %s -> %s\n", argv[1], argv[2]);
                 return 2;
@@ -54,7 +69,7 @@ int main(int argc, char **argv)
                 return 3;
         }
         f = fopen(argv[6], "wb");
-        fwrite(dst, 1, (size_t) pitch * h, f);
+        fwrite(dst, 1, out_bytes, f);
         fclose(f);
         printf("OK %s -> %s %ux%u pitch=%d\n", argv[1], argv[2], w, h, pitch);
         decompress_done(s);

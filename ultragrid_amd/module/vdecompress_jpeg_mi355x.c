@@ -1,0 +1,182 @@
+/**
+ * @file vdecompress_jpeg_mi355x.c
+ * UltraGrid video_decompress module "jpeg_mi355x": JPEG -> UYVY / RGB / RGBA / I420 on an MI355X through libug_mi355x.so
+ * (include/ug_mi355x.h: ug_hip_jpeg_decoder_*).  Receiver-side counterpart of vcompress_jpeg_mi355x.cpp; plain C, the callback set and
+ * conventions of the reference's GPUJPEG decompress module (src/video_decompress/gpujpeg.c): out_codec VIDEO_CODEC_NONE = probe of the
+ * stream's internal pixel format (:202-266), the output codecs and priorities of :355-366, a display pitch different from the line size
+ * served line by line (:296-319), corrupted frames not accepted (:322-341).
+ */
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "debug.h"
+#include "lib_common.h"
+#include "types.h"
+#include "video_codec.h"
+#include "video_decompress.h"
+
+#include "../../include/ug_mi355x.h"
+
+#define MOD_NAME "[JPEG MI355X dec] "
+
+struct state_decompress_jpeg_mi355x {
+        struct video_desc    desc;
+        int                  rshift, gshift, bshift, pitch;
+        codec_t              out_codec;
+        ug_pixfmt_t          out_fmt;
+        ug_hip_stream_t      stream;
+        ug_hip_jpeg_decoder *dec;
+        void                *dev_out;
+        size_t               out_len;
+};
+
+static void *jpeg_mi355x_decompress_init(void)
+{
+        struct state_decompress_jpeg_mi355x *s = calloc(1, sizeof *s);
+        if (ug_hip_set_device(0) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS ||
+            ug_hip_jpeg_decoder_create(&s->dec) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "cannot set up the decoder on HIP device 0: %s\n", ug_hip_last_error_string());
+                free(s);
+                return NULL;
+        }
+        return s;
+}
+
+static int jpeg_mi355x_decompress_reconfigure(void *state, struct video_desc desc, int rshift, int gshift, int bshift, int pitch,
+                                              codec_t out_codec)
+{
+        struct state_decompress_jpeg_mi355x *s = state;
+        if (desc.color_spec != JPEG) {
+                MSG(ERROR, "Wrong compression to decompress: %s\n", get_codec_name(desc.color_spec));
+                return false;
+        }
+        switch (out_codec) {
+        case VIDEO_CODEC_NONE: s->out_fmt = UG_PF_NONE; break; // probe
+        case RGBA: s->out_fmt = UG_PF_RGBA; break;
+        case RGB:  s->out_fmt = UG_PF_RGB; break;
+        case UYVY: s->out_fmt = UG_PF_UYVY; break;
+        case I420: s->out_fmt = UG_PF_I420; break;
+        default:
+                MSG(ERROR, "Unsupported output codec: %s\n", get_codec_name(out_codec));
+                return false;
+        }
+        ug_hip_set_device(0);
+        if (s->dev_out) {
+                ug_hip_free(s->dev_out);
+                s->dev_out = NULL;
+        }
+        s->desc = desc;
+        s->rshift = rshift; s->gshift = gshift; s->bshift = bshift;
+        s->pitch = pitch;
+        s->out_codec = out_codec;
+        if (out_codec != VIDEO_CODEC_NONE) {
+                s->out_len = out_codec == I420 ? (size_t) desc.width * desc.height + 2 * (size_t) ((desc.width + 1) / 2) * ((desc.height + 1) / 2)
+                                               : (size_t) vc_get_linesize(desc.width, out_codec) * desc.height;
+                if (ug_hip_malloc(&s->dev_out, s->out_len + 64) != UG_HIP_SUCCESS) {
+                        MSG(ERROR, "Could not allocate the device output buffer: %s\n", ug_hip_last_error_string());
+                        return false;
+                }
+        }
+        return true;
+}
+
+/// gpujpeg_probe_internal_codec (gpujpeg.c:202-266): depth 8, RGB or not, subsampling in the 4xxx notation
+static decompress_status probe_internal_codec(unsigned char *buffer, size_t len, struct pixfmt_desc *internal_prop)
+{
+        int w = 0, h = 0, sub = 0, rgb = 0;
+        if (ug_hip_jpeg_read_info(buffer, len, &w, &h, &sub, &rgb, NULL) != UG_HIP_SUCCESS) {
+                MSG(WARNING, "probe - cannot get image info!\n");
+                return DECODER_NO_FRAME;
+        }
+        if (internal_prop != NULL) {
+                internal_prop->depth = 8;
+                internal_prop->rgb = rgb != 0;
+                internal_prop->subsampling = sub == 444 ? 4440 : (sub == 422 ? 4220 : (sub == 420 ? 4200 : 4000));
+        }
+        return DECODER_GOT_CODEC;
+}
+
+static decompress_status jpeg_mi355x_decompress(void *state, unsigned char *dst, unsigned char *buffer, unsigned int src_len, int frame_seq,
+                                                struct video_frame_callbacks *callbacks, struct pixfmt_desc *internal_prop)
+{
+        struct state_decompress_jpeg_mi355x *s = state;
+        (void) frame_seq, (void) callbacks;
+        if (s->out_codec == VIDEO_CODEC_NONE) {
+                return probe_internal_codec(buffer, src_len, internal_prop);
+        }
+        int w = 0, h = 0;
+        if (ug_hip_set_device(0) != UG_HIP_SUCCESS || ug_hip_jpeg_read_info(buffer, src_len, &w, &h, NULL, NULL, NULL) != UG_HIP_SUCCESS ||
+            (unsigned) w != s->desc.width || (unsigned) h != s->desc.height) {
+                MSG(ERROR, "not a JPEG frame of the configured size %ux%u\n", s->desc.width, s->desc.height);
+                return DECODER_NO_FRAME;
+        }
+        if (ug_hip_jpeg_decoder_decode(s->dec, buffer, src_len, s->out_fmt, s->dev_out, 0, s->rshift, s->gshift, s->bshift, s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "decode failed: %s\n", ug_hip_last_error_string());
+                ug_hip_stream_sync(s->stream);
+                return DECODER_NO_FRAME;
+        }
+        const int linesize = s->out_codec == I420 ? 0 : vc_get_linesize(s->desc.width, s->out_codec);
+        bool ok = true;
+        if (s->out_codec == I420 || s->pitch == linesize) {
+                ok = ug_hip_memcpy_async(dst, s->dev_out, s->out_len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) == UG_HIP_SUCCESS;
+        } else { // display pitch differs from the packed line size (gpujpeg.c:296-319 does a CPU line loop here)
+                for (unsigned i = 0; i < s->desc.height && ok; i++) {
+                        ok = ug_hip_memcpy_async(dst + (size_t) i * s->pitch, (char *) s->dev_out + (size_t) i * linesize, linesize,
+                                                 UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) == UG_HIP_SUCCESS;
+                }
+        }
+        if (ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS || !ok) {
+                MSG(ERROR, "download failed: %s\n", ug_hip_last_error_string());
+                return DECODER_NO_FRAME;
+        }
+        return DECODER_GOT_FRAME;
+}
+
+static int jpeg_mi355x_decompress_get_property(void *state, int property, void *val, size_t *len)
+{
+        (void) state;
+        if (property == DECOMPRESS_PROPERTY_ACCEPTS_CORRUPTED_FRAME && *len >= sizeof(int)) {
+                *(int *) val = false; // as gpujpeg.c:328-333
+                *len = sizeof(int);
+                return true;
+        }
+        return false;
+}
+
+static void jpeg_mi355x_decompress_done(void *state)
+{
+        struct state_decompress_jpeg_mi355x *s = state;
+        ug_hip_set_device(0);
+        if (s->dev_out) ug_hip_free(s->dev_out);
+        if (s->dec) ug_hip_jpeg_decoder_destroy(s->dec);
+        if (s->stream) ug_hip_stream_destroy(s->stream);
+        free(s);
+}
+
+static int jpeg_mi355x_decompress_get_priority(codec_t compression, struct pixfmt_desc internal, codec_t ugc)
+{
+        (void) internal;
+        if (compression != JPEG) {
+                return -1;
+        }
+        if (ugc == VIDEO_CODEC_NONE) {
+                return VDEC_PRIO_PROBE_HI; // gpujpeg.c:360-362
+        }
+        if (ugc == I420 || ugc == RGB || ugc == RGBA || ugc == UYVY) {
+                return VDEC_PRIO_PREFERRED;
+        }
+        return VDEC_PRIO_NA;
+}
+
+static const struct video_decompress_info jpeg_mi355x_dec_info = {
+        jpeg_mi355x_decompress_init,
+        jpeg_mi355x_decompress_reconfigure,
+        jpeg_mi355x_decompress,
+        jpeg_mi355x_decompress_get_property,
+        jpeg_mi355x_decompress_done,
+        jpeg_mi355x_decompress_get_priority,
+};
+
+REGISTER_MODULE(jpeg_mi355x, &jpeg_mi355x_dec_info, LIBRARY_CLASS_VIDEO_DECOMPRESS, VIDEO_DECOMPRESS_ABI_VERSION);
