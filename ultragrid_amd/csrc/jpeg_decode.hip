@@ -4,7 +4,7 @@
 //   host   marker syntax (T.81 B.2): DQT, SOF0, DHT, DRI, SOS, Adobe APP14; the restart segments of every scan are located by their RSTn
 //          markers (E.2.4) -- restart intervals are what makes the entropy-coded data parallel;
 //   GPU 1  Huffman decoding (F.2.2), one lane per restart segment: 9-bit look-up for the short codes, the canonical MAXCODE walk for the
-//          long ones, byte stuffing removed on the fly; quantised coefficients are scattered into zero-filled planes in natural order;
+//          long ones, byte stuffing removed on the fly; quantised coefficients are collected per block in LDS and written out 128 bytes at a time;
 //   GPU 2  dequantisation + inverse DCT, one lane per 8x8 block: libjpeg's jidctint ("slow but accurate integer": Loeffler-Ligtenberg-
 //          Moschytz, 13-bit constants, PASS1_BITS 2) -- integer arithmetic, so the component planes equal libjpeg's bit for bit;
 //   GPU 3  planes -> the output codec with the pixel-format kernels the library already has (planar 4:2:2 / 4:2:0 -> UYVY as
@@ -77,9 +77,15 @@ const uint8_t kZigzagHost[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 
 __device__ const uint8_t kZigzagDev[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
 
+enum ParseMode {
+        kHeadersOnly, // stop behind the first SOS header: everything a single-scan stream needs from the host (its restart markers are found on the GPU)
+        kWalkScans,   // walk the entropy-coded data of every scan on the host and record where each restart segment starts
+};
+
 // 0 ok, -1 not a baseline stream this decoder takes, -2 truncated
-int parse(const uint8_t *data, size_t len, Header &h, bool want_segments)
+int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
 {
+        const bool want_segments = mode == kWalkScans;
         if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
         memset(h.qt, 0, sizeof h.qt);
         for (auto &t : h.dc) t.present = false;
@@ -152,6 +158,11 @@ int parse(const uint8_t *data, size_t len, Header &h, bool want_segments)
                         }
                         if (sc.ns != 1 && sc.ns != h.ncomp) return -1;
                         sc.data_begin = pos + 2 + seglen;
+                        if (mode == kHeadersOnly) {
+                                sc.data_end = len;
+                                h.scans.push_back(std::move(sc));
+                                break;
+                        }
                         // walk the entropy-coded data: RSTn markers start new segments, any other marker ends the scan
                         size_t q = sc.data_begin;
                         if (want_segments) sc.seg_off.push_back((uint32_t) q);
@@ -180,6 +191,80 @@ int parse(const uint8_t *data, size_t len, Header &h, bool want_segments)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// ---- restart markers located on the GPU (single-scan streams) ---------------------------------------------------------------------
+// Inside entropy-coded data 0xFF is always followed by 0x00 (stuffing), another 0xFF (fill) or a marker's second byte, so a byte pair
+// FF D0..D7 is a restart marker wherever it stands.  Pass 1 counts the markers of every 4 KiB of the stream, pass 2 turns the counts into
+// positions in stream order: seg_off[0] = first byte of the scan, seg_off[1 + i] = the byte behind the i-th marker.
+constexpr int kScanWG = 256, kScanBytesPerLane = 16, kScanChunk = kScanWG * kScanBytesPerLane;
+
+// bit i set: bytes pos+i, pos+i+1 are a restart marker that lies in [begin, len); pos is 16-byte aligned
+__device__ __forceinline__ uint32_t rst_mask(const uint8_t *__restrict__ stream, size_t pos, size_t begin, size_t len)
+{
+        if (pos >= len) return 0;
+        const uint4 q = *(const uint4 *) (stream + pos);
+        const uint32_t w[5] = { q.x, q.y, q.z, q.w, stream[pos + 16] }; // the buffer is allocated with slack behind len
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+                const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff, b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
+                const bool hit = b0 == 0xFF && (b1 & 0xF8) == 0xD0 && pos + i >= begin && pos + i + 1 < len;
+                m |= (uint32_t) hit << i;
+        }
+        return m;
+}
+
+__device__ __forceinline__ int wg_sum_256(int v, int *lds4)
+{
+#pragma unroll
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const int t = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        __syncthreads();
+        return t;
+}
+
+__global__ __launch_bounds__(kScanWG) void rst_count_kernel(const uint8_t *__restrict__ stream, size_t base, size_t begin, size_t len, int *__restrict__ counts)
+{
+        __shared__ int part[4];
+        const size_t pos = base + (size_t) blockIdx.x * kScanChunk + threadIdx.x * kScanBytesPerLane;
+        const int t = wg_sum_256(__popc(rst_mask(stream, pos, begin, len)), part);
+        if (threadIdx.x == 0) counts[blockIdx.x] = t;
+}
+
+// found[0] = number of segments located (1 + markers); at most cap offsets are written
+__global__ __launch_bounds__(kScanWG) void rst_place_kernel(const uint8_t *__restrict__ stream, size_t base, size_t begin, size_t len, const int *__restrict__ counts,
+                                                            uint32_t *__restrict__ seg_off, int cap, int *__restrict__ found)
+{
+        __shared__ int part[4];
+        __shared__ int wave_tot[4];
+        int before = 0;
+        for (int j = threadIdx.x; j < (int) blockIdx.x; j += kScanWG) before += counts[j];
+        before = wg_sum_256(before, part);
+        const size_t pos = base + (size_t) blockIdx.x * kScanChunk + threadIdx.x * kScanBytesPerLane;
+        uint32_t m = rst_mask(stream, pos, begin, len);
+        const int mine = __popc(m);
+        int incl = mine; // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_up(incl, o);
+                if ((int) (threadIdx.x & 63) >= o) incl += n;
+        }
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int idx = 1 + before + incl - mine;
+        for (int w = 0; w < (int) (threadIdx.x >> 6); w++) idx += wave_tot[w];
+        while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                if (idx < cap) seg_off[idx] = (uint32_t) (pos + i + 2);
+                idx++;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) seg_off[0] = (uint32_t) begin;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanWG - 1) found[0] = idx;
+}
+
+// ---- Huffman decoding ----------------------------------------------------------------------------------------------------------------
 struct ScanDev {
         int ns, comp[3], td[3], ta[3], nbh[3], nbv[3], gw[3]; // blocks per unit and blocks per row of each component's grid
         int single, bw1, mcu_w, ri;
@@ -188,110 +273,190 @@ struct ScanDev {
         unsigned scan_end;
 };
 
+// what the codes longer than the look-up need, in LDS
+struct LongCodes {
+        uint32_t limit[17]; // (MAXCODE[n] + 1) << (16 - n), carried over lengths without codes
+        int16_t offset[17]; // VALPTR[n] - MINCODE[n]
+        uint8_t vals[256];
+};
+
+// The entropy-coded bytes of one segment.  The bit window is topped up 32 bits at a time from a word that was loaded one refill earlier
+// (the common case: four bytes, none of them 0xFF); a word with 0xFF in it, or the last bytes of the data, go through the byte-wise path
+// that removes the stuffing and stops at a marker.  Behind a marker or the end of the data the window fills with zero bits.
 struct BitReader {
-        const uint8_t *p, *end;
-        unsigned long long acc; // bits are consumed from the top
+        const uint8_t *base;     // the stream (the same for every lane)
+        uint32_t pos, end;       // next unread byte, end of the data
+        uint32_t nxt;            // the four bytes at pos, loaded ahead
+        bool over;
+        unsigned long long acc;  // bits are consumed from the top
         int cnt;
+        __device__ __forceinline__ uint32_t load32(uint32_t at) const
+        {
+                uint32_t w;
+                __builtin_memcpy(&w, base + at, 4); // the stream buffer has slack behind the data
+                return w;
+        }
+        __device__ __forceinline__ void open(const uint8_t *stream, uint32_t begin, uint32_t finish)
+        {
+                base = stream;
+                pos = begin;
+                end = finish;
+                over = begin >= finish;
+                acc = 0;
+                cnt = 0;
+                nxt = load32(pos);
+        }
         __device__ __forceinline__ void refill()
         {
-                while (cnt <= 56) {
-                        unsigned byte = 0;
-                        if (p < end) {
-                                byte = *p;
-                                if (byte == 0xFF) {
-                                        if (p + 1 < end && p[1] == 0x00) {
-                                                p += 2; // stuffed zero
-                                        } else {
-                                                p = end; // a marker: the segment is over, zeros from here on
-                                                byte = 0;
+                if (cnt > 32) return; // a code (<= 16 bits) and its extra bits (<= 15) fit in what is left
+                do {
+                        if (over) break;
+                        uint32_t w = nxt;
+                        const bool has_ff = ((~w - 0x01010101u) & w & 0x80808080u) != 0;
+                        if (pos + 4 <= end && !has_ff) {
+                                acc |= (unsigned long long) __builtin_bswap32(w) << (32 - cnt);
+                                cnt += 32;
+                                pos += 4;
+                        } else { // byte by byte, out of the same register
+                                int avail = end - pos < 4 ? (int) (end - pos) : 4;
+                                while (avail > 0) {
+                                        const uint32_t byte = w & 0xff;
+                                        int used = 1;
+                                        if (byte == 0xFF) {
+                                                if (avail < 2) {
+                                                        if (pos + 1 >= end) over = true; // the data ends in 0xFF
+                                                        break;                            // else: the byte behind it is in the next word
+                                                }
+                                                if ((w >> 8 & 0xff) != 0) { // a marker: the segment is over
+                                                        over = true;
+                                                        break;
+                                                }
+                                                used = 2; // a stuffed zero: the data byte is 0xFF
                                         }
-                                } else {
-                                        p++;
+                                        acc |= (unsigned long long) byte << (56 - cnt);
+                                        cnt += 8;
+                                        w >>= 8 * used;
+                                        avail -= used;
+                                        pos += used;
                                 }
+                                if (pos >= end) over = true;
                         }
-                        acc |= (unsigned long long) byte << (56 - cnt);
-                        cnt += 8;
-                }
-        }
-        __device__ __forceinline__ unsigned peek16() const { return (unsigned) (acc >> 48); }
-        __device__ __forceinline__ void skip(int n) { acc <<= n; cnt -= n; }
-        __device__ __forceinline__ int receive_extend(int t) // F.2.2.1: t bits, sign extension of T.81 Figure F.12
-        {
-                if (t == 0) return 0;
-                const int v = (int) (acc >> (64 - t));
-                skip(t);
-                return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v;
+                        nxt = load32(pos);
+                } while (cnt <= 32);
+                if (over && cnt <= 32) cnt = 64; // zero bits from here on (the window's low bits are zero already)
         }
 };
 
-__device__ __forceinline__ int decode_symbol(BitReader &br, const HuffDev &t, const uint16_t *lut)
+// One Huffman symbol and the `symbol & 15` extra bits behind it (F.2.2.1, sign extension of Figure F.12): returns the symbol, the extended
+// value in `value`.  Works on the top 32 bits of the window: code (<= 16) + extra bits (<= 15) always fit.
+__device__ __forceinline__ int decode_symbol(BitReader &br, const LongCodes &lc, const uint16_t *lut, int &value)
 {
-        const unsigned pk = br.peek16();
-        const unsigned e = lut[pk >> (16 - kLutBits)];
-        if (e) {
-                br.skip((int) (e >> 8));
-                return (int) (e & 0xff);
+        const uint32_t hi = (uint32_t) (br.acc >> 32);
+        const unsigned e = lut[hi >> (32 - kLutBits)];
+        int l = (int) (e >> 8), sym = (int) (e & 0xff);
+        if (__builtin_expect(e == 0, 0)) {
+                // a code longer than the look-up covers: codes of length n fill [.., limit[n]) of the 16-bit prefixes, limits ascending (F.2.2.3's
+                // MAXCODE walk without the loop)
+                const unsigned pk = hi >> 16;
+                l = kLutBits + 1;
+#pragma unroll
+                for (int n = kLutBits + 1; n <= 16; n++) l += pk >= lc.limit[n];
+                if (l > 16) { // corrupt data: consume the bits, decode nothing
+                        l = 16;
+                        sym = 0;
+                } else {
+                        sym = lc.vals[(int) (pk >> (16 - l)) + lc.offset[l] & 0xff];
+                }
         }
-        int l = kLutBits + 1;
-        int code = (int) (pk >> (16 - l));
-        while (l <= 16 && (t.maxcode[l] < 0 || code > t.maxcode[l])) {
-                l++;
-                code = (int) (pk >> (16 - l));
-        }
-        if (l > 16) { // corrupt data: consume the bits, decode nothing
-                br.skip(16);
-                return 0;
-        }
-        br.skip(l);
-        return t.vals[t.valptr[l] + code - t.mincode[l]];
+        const int sz = sym & 15;
+        const int v = (int) (((hi << l) >> 1) >> (31 - sz)); // the sz bits behind the code; 0 for sz == 0
+        value = v < ((1 << sz) >> 1) ? v + 1 - (1 << sz) : v;
+        br.acc <<= l + sz;
+        br.cnt -= l + sz;
+        return sym;
 }
 
-// one lane per restart segment
-__global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ stream, const uint32_t *__restrict__ seg_off, int n_seg, ScanDev sp,
+// One lane per restart segment, one wave per workgroup.  The lanes of a wave walk their segments block by block in step (every segment
+// holds the same blocks in the same order), each lane collecting the coefficients of its current block, in zigzag order, in a private
+// tile in LDS; when the block is done the wave writes the 64 tiles out together, 128 contiguous bytes per block, zeros included -- so the
+// coefficient planes need no clearing and no lane issues scattered 2-byte stores -- and leaves the tiles zeroed for the next block.
+// The coefficient planes are in zigzag order; the IDCT kernel undoes it with compile-time indices.
+constexpr int kTileWords = 36; // 32 words of coefficients, padded: 16-byte aligned rows that start in different LDS banks
+
+__global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ stream, const uint32_t *__restrict__ seg_off, int n_seg,
+                                                         const int *__restrict__ found /* segments located on the GPU, or null: all n_seg are there */, ScanDev sp,
                                                          const HuffDev *__restrict__ tabs /* [0..3] DC, [4..7] AC */)
 {
         __shared__ uint16_t luts[6][1 << kLutBits]; // the scan's DC tables then its AC tables
+        __shared__ LongCodes longs[6];
+        __shared__ __attribute__((aligned(16))) uint32_t tile[64 * kTileWords];
+        __shared__ long tile_dst[64]; // where the lane's tile goes (in coefficients), -1: nowhere
+        const int lane = threadIdx.x;
         for (int k = 0; k < sp.ns; k++) {
-                for (int i = threadIdx.x; i < (1 << kLutBits); i += 64) {
+                for (int i = lane; i < (1 << kLutBits); i += 64) {
                         luts[k][i] = tabs[sp.td[k]].lut[i];
                         luts[3 + k][i] = tabs[4 + sp.ta[k]].lut[i];
                 }
+                for (int half = 0; half < 2; half++) {
+                        const HuffDev &t = tabs[half ? 4 + sp.ta[k] : sp.td[k]];
+                        LongCodes &lc = longs[3 * half + k];
+                        for (int i = lane; i < 256; i += 64) lc.vals[i] = t.vals[i];
+                        if (lane == 0) {
+                                uint32_t limit = 0;
+                                for (int n = 1; n <= 16; n++) {
+                                        if (t.maxcode[n] >= 0) limit = (uint32_t) (t.maxcode[n] + 1) << (16 - n);
+                                        lc.limit[n] = limit;
+                                        lc.offset[n] = (int16_t) (t.valptr[n] - t.mincode[n]);
+                                }
+                        }
+                }
         }
+#pragma unroll
+        for (int j = 0; j < 8; j++) *(uint4 *) (tile + lane * kTileWords + 4 * j) = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        const int seg = blockIdx.x * 64 + threadIdx.x;
-        if (seg >= n_seg) return;
+        const int seg = blockIdx.x * 64 + lane;
+        const bool present = seg < n_seg && (!found || seg < found[0]); // a segment the stream does not have decodes to zero blocks
         BitReader br;
-        br.p = stream + seg_off[seg];
-        br.end = stream + (seg + 1 < n_seg ? seg_off[seg + 1] : sp.scan_end);
-        br.acc = 0;
-        br.cnt = 0;
+        br.open(stream, present ? seg_off[seg] : 0u, present ? sp.scan_end : 0u);
         int pred[3] = { 0, 0, 0 };
-        const long u0 = sp.ri ? (long) seg * sp.ri : 0, u1 = sp.ri ? min(sp.units, u0 + sp.ri) : sp.units;
-        for (long u = u0; u < u1; u++) {
+        const long per_seg = sp.ri ? sp.ri : sp.units;
+        const long u0 = (long) seg * per_seg;
+        int16_t *const my = (int16_t *) (tile + lane * kTileWords);
+        for (long i = 0; i < per_seg; i++) {
+                const long u = u0 + i;
+                const bool active = seg < n_seg && u < sp.units;
                 const long ux = sp.single ? u % sp.bw1 : u % sp.mcu_w, uy = sp.single ? u / sp.bw1 : u / sp.mcu_w;
                 for (int k = 0; k < sp.ns; k++) {
-                        const HuffDev &tdc = tabs[sp.td[k]], &tac = tabs[4 + sp.ta[k]];
+                        const LongCodes &tdc = longs[k], &tac = longs[3 + k];
                         for (int by = 0; by < sp.nbv[k]; by++) {
                                 for (int bx = 0; bx < sp.nbh[k]; bx++) {
-                                        int16_t *blk = sp.coef[k] + ((uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64;
-                                        br.refill();
-                                        const int t = decode_symbol(br, tdc, luts[k]);
-                                        pred[k] += br.receive_extend(t);
-                                        blk[0] = (int16_t) pred[k];
-                                        for (int z = 1; z < 64;) {
+                                        tile_dst[lane] = active ? ((uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64 : -1;
+                                        if (active && present) {
+                                                int v;
                                                 br.refill();
-                                                const int rs = decode_symbol(br, tac, luts[3 + k]);
-                                                const int r = rs >> 4, sz = rs & 15;
-                                                if (sz == 0) {
-                                                        if (r != 15) break; // EOB
-                                                        z += 16;
-                                                        continue;
+                                                decode_symbol(br, tdc, luts[k], v);
+                                                pred[k] += v;
+                                                my[0] = (int16_t) pred[k];
+                                                for (int z = 1; z < 64; z++) {
+                                                        br.refill();
+                                                        const int rs = decode_symbol(br, tac, luts[3 + k], v);
+                                                        if ((rs & 15) == 0 && rs != 0xF0) break; // EOB
+                                                        z += rs >> 4;
+                                                        my[(rs & 15) && z < 64 ? z : 64] = (int16_t) v; // slot 64 is the tile's padding
                                                 }
-                                                z += r;
-                                                if (z > 63) break;
-                                                blk[kZigzagDev[z]] = (int16_t) br.receive_extend(sz);
-                                                z++;
                                         }
+                                        __syncthreads();
+                                        // 8 lanes per tile, 16 bytes each: 8 tiles per round
+#pragma unroll
+                                        for (int round = 0; round < 8; round++) {
+                                                const int t = round * 8 + (lane >> 3), part = lane & 7;
+                                                const long dst = tile_dst[t];
+                                                uint4 *src = (uint4 *) (tile + t * kTileWords + part * 4);
+                                                const uint4 q = *src;
+                                                *src = make_uint4(0, 0, 0, 0);
+                                                if (dst >= 0) *(uint4 *) (sp.coef[k] + dst + part * 8) = q;
+                                        }
+                                        __syncthreads();
                                 }
                         }
                 }
@@ -339,9 +504,10 @@ __global__ __launch_bounds__(256) void idct_kernel(const int16_t *__restrict__ c
                 const uint4 q = src[i];
                 const uint32_t w[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                        v[8 * i + 2 * k] = (int) (int16_t) (w[k] & 0xffff) * (int) qt[8 * i + 2 * k];
-                        v[8 * i + 2 * k + 1] = (int) (int16_t) (w[k] >> 16) * (int) qt[8 * i + 2 * k + 1];
+                for (int k = 0; k < 4; k++) { // coefficient z of the zigzag sequence belongs at kZigzag[z]: indices known at compile time
+                        const int n0 = kZigzagDev[8 * i + 2 * k], n1 = kZigzagDev[8 * i + 2 * k + 1];
+                        v[n0] = (int) (int16_t) (w[k] & 0xffff) * (int) qt[n0];
+                        v[n1] = (int) (int16_t) (w[k] >> 16) * (int) qt[n1];
                 }
         }
 #pragma unroll
@@ -403,6 +569,8 @@ struct Decoder {
         size_t stream_cap = 0;
         uint32_t *seg_off = nullptr;
         size_t seg_cap = 0;
+        int *scan_counts = nullptr; // [0]: segments located by the GPU marker scan, [1..]: markers per 4 KiB of the stream
+        size_t scan_cap = 0;
         HuffDev *tabs = nullptr;     // 8 tables
         uint16_t *qt = nullptr;      // 4 x 64
         int16_t *coef[3] = { nullptr, nullptr, nullptr };
@@ -456,7 +624,7 @@ void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec)
 {
         Decoder *d = (Decoder *) dec;
         if (!d) return;
-        for (void *p : { (void *) d->stream, (void *) d->seg_off, (void *) d->tabs, (void *) d->qt, (void *) d->coef[0], (void *) d->coef[1], (void *) d->coef[2],
+        for (void *p : { (void *) d->stream, (void *) d->seg_off, (void *) d->scan_counts, (void *) d->tabs, (void *) d->qt, (void *) d->coef[0], (void *) d->coef[1], (void *) d->coef[2],
                          (void *) d->plane[0], (void *) d->plane[1], (void *) d->plane[2], (void *) d->tmp }) {
                 if (p) (void) hipFree(p);
         }
@@ -468,7 +636,7 @@ void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec)
 int ug_hip_jpeg_read_info(const void *jpeg_host, size_t len, int *width, int *height, int *subsampling, int *is_rgb, int *restart_interval)
 {
         Header h;
-        const int rc = parse((const uint8_t *) jpeg_host, len, h, false);
+        const int rc = parse((const uint8_t *) jpeg_host, len, h, kHeadersOnly);
         if (rc) {
                 ug::set_last_error_msg(rc == -2 ? "ug_hip_jpeg_read_info: truncated stream" : "ug_hip_jpeg_read_info: not a baseline JPEG stream this decoder takes");
                 return UG_HIP_EUNSUPP;
@@ -491,9 +659,20 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
         }
         Header &h = d->hdr;
         h = Header();
-        const int prc = parse((const uint8_t *) jpeg_host, len, h, true);
+        int prc = parse((const uint8_t *) jpeg_host, len, h, kHeadersOnly);
+        // one scan that carries every component (what UltraGrid's senders emit): its restart markers are found on the GPU, the host reads the
+        // headers only; streams with one scan per component are walked on the host
+        const bool gpu_scan = prc == 0 && h.scans[0].ns == h.ncomp;
+        if (prc == 0 && !gpu_scan) {
+                h = Header();
+                prc = parse((const uint8_t *) jpeg_host, len, h, kWalkScans);
+        }
         if (prc) {
                 ug::set_last_error_msg(prc == -2 ? "ug_hip_jpeg_decoder_decode: truncated stream" : "ug_hip_jpeg_decoder_decode: not a baseline JPEG stream this decoder takes");
+                return UG_HIP_EUNSUPP;
+        }
+        if (len > 0xFFFFFFF0u) {
+                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: stream too long");
                 return UG_HIP_EUNSUPP;
         }
         for (int c = 1; c < h.ncomp; c++) { // the sampling layouts the output stage knows: 4:4:4, 4:2:2, 4:2:0
@@ -504,9 +683,15 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
         }
         hipStream_t st = (hipStream_t) stream;
         // ---- workspace ----
-        size_t n_seg_total = 0;
+        const long mcus = (long) h.mcu_w * h.mcu_h;
+        const long gpu_expect = h.ri ? (mcus + h.ri - 1) / h.ri : 1;
+        const size_t scan_base = gpu_scan ? h.scans[0].data_begin & ~(size_t) 15 : 0;
+        const unsigned scan_grid = gpu_scan ? (unsigned) ((len - scan_base + kScanChunk - 1) / kScanChunk) : 0;
+        size_t n_seg_total = 0; // offsets the host uploads
         for (const Scan &sc : h.scans) n_seg_total += sc.seg_off.size();
-        bool ok = grow((void **) &d->stream, &d->stream_cap, len + 16) && grow((void **) &d->seg_off, &d->seg_cap, n_seg_total * sizeof(uint32_t));
+        bool ok = grow((void **) &d->stream, &d->stream_cap, len + 32) &&
+                  grow((void **) &d->seg_off, &d->seg_cap, (gpu_scan ? (size_t) gpu_expect : n_seg_total) * sizeof(uint32_t)) &&
+                  grow((void **) &d->scan_counts, &d->scan_cap, ((size_t) scan_grid + 1) * sizeof(int));
         long gw[3], gh[3];
         for (int c = 0; c < h.ncomp && ok; c++) {
                 gw[c] = (long) h.mcu_w * h.hs[c];
@@ -554,7 +739,14 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
         UG_HIP_TRY(hipMemcpyAsync(d->stream, jpeg_host, len, hipMemcpyHostToDevice, st));
         UG_HIP_TRY(hipEventRecord(d->uploaded, st));
         d->upload_pending = true;
-        for (int c = 0; c < h.ncomp; c++) UG_HIP_TRY(hipMemsetAsync(d->coef[c], 0, (size_t) (gw[c] * gh[c]) * 128, st));
+        if (gpu_scan) {
+                const Scan &sc = h.scans[0];
+                hipLaunchKernelGGL(rst_count_kernel, dim3(scan_grid), dim3(kScanWG), 0, st, d->stream, scan_base, sc.data_begin, len, d->scan_counts + 1);
+                hipLaunchKernelGGL(rst_place_kernel, dim3(scan_grid), dim3(kScanWG), 0, st, d->stream, scan_base, sc.data_begin, len, d->scan_counts + 1, d->seg_off,
+                                   (int) gpu_expect, d->scan_counts);
+        } else { // a scan of one component leaves the padding blocks of the MCU grid untouched, a short stream whole segments
+                for (int c = 0; c < h.ncomp; c++) UG_HIP_TRY(hipMemsetAsync(d->coef[c], 0, (size_t) (gw[c] * gh[c]) * 128, st));
+        }
         // ---- Huffman decoding, scan by scan ----
         size_t seg_base = 0;
         for (const Scan &sc : h.scans) {
@@ -585,8 +777,9 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
                 }
                 // only as many segments as the restart interval accounts for (a stream may carry fewer or more markers than it should)
                 const long expect = h.ri ? (sp.units + h.ri - 1) / h.ri : 1;
-                const int n_seg = (int) (expect < (long) sc.seg_off.size() ? expect : (long) sc.seg_off.size());
-                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + 63) / 64)), dim3(64), 0, st, d->stream, d->seg_off + seg_base, n_seg, sp, d->tabs);
+                const int n_seg = gpu_scan ? (int) expect : (int) (expect < (long) sc.seg_off.size() ? expect : (long) sc.seg_off.size());
+                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + 63) / 64)), dim3(64), 0, st, d->stream, d->seg_off + seg_base, n_seg,
+                                   gpu_scan ? d->scan_counts : nullptr, sp, d->tabs);
                 seg_base += sc.seg_off.size();
         }
         // ---- dequantisation + IDCT ----
