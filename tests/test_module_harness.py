@@ -588,3 +588,40 @@ def test_sender_to_receiver_through_both_reference_frameworks(tmp_path, po, code
         ref_in = {"UYVY": lambda: uyvy, "RGB": lambda: po.convert_frame("UYVY", "RGB", uyvy, w, h), "I420": lambda: np.concatenate([p.ravel() for p in po.uyvy_to_i420(uyvy, w, h)])}[out]()
     assert np.array_equal(got, want)
     assert 10 * np.log10(255.0 ** 2 / np.mean((got.astype(float) - ref_in.astype(float)) ** 2)) > 33
+
+
+@needs_dec_harness
+def test_jpeg_to_dxt_transcoder_registers():
+    r = subprocess.run([DEC_HARNESS, "list"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "jpeg_to_dxt_mi355x" in r.stdout.split()
+
+
+@needs_harness
+@needs_dec_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec,cfg", [("UYVY", "jpeg:q=85:restart=4"), ("RGB", "jpeg:q=85:restart=4"), ("UYVY", "jpeg:q=90:restart=2:subsampling=420")])
+@pytest.mark.parametrize("out", ["DXT1", "DXT5"])
+def test_jpeg_to_dxt_transcoder(tmp_path, po, codec, cfg, out):
+    """JPEG -> DXT1 / DXT5 inside the receiver's framework (decompress_init_multi picks the transcoder for a DXT display codec, priority 900 as
+    gpujpeg_to_dxt.cpp:368-373): decoded to packed RGB on the device, block-compressed bottom-up (negative height) with the CUDA kernels'
+    rounding -- the DXT oracle run on the decode oracle's picture."""
+    w, h = 192, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1).clip(0, 255).astype(np.uint8)
+    src = rgb.ravel() if codec == "RGB" else po.convert_frame("RGB", "UYVY", rgb, w, h)
+    raw, jpg, dec = tmp_path / "in.raw", tmp_path / "f.jpg", tmp_path / "out.dxt"
+    np.ascontiguousarray(src).tofile(raw)
+    assert _run([cfg, codec, w, h, raw, jpg]).returncode == 0
+    r = subprocess.run([DEC_HARNESS, "JPEG", out, str(w), str(h), str(jpg), str(dec)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, crop, _ = po.jpeg_decode_planes(jpg.read_bytes())
+    if codec == "RGB":
+        picture = np.stack(crop, -1).ravel()
+    else:
+        picture = po.convert_frame("UYVY", "RGB", po.planar_to_uyvy(*crop, w, h, chroma=420 if "420" in cfg else 422), w, h)
+    want = po.dxt_encode(po.IN_RGB, po.OUT_DXT1 if out == "DXT1" else po.OUT_DXT5YCOCG, picture, w, -h, ties="away")
+    got = np.fromfile(dec, np.uint8)
+    assert np.array_equal(got, want)
+    # and it is a picture: decoded again (flipped back) it is close to what went in
+    back = po.dxt_decode(po.OUT_DXT1 if out == "DXT1" else po.OUT_DXT5YCOCG, "RGB", got, w, h).reshape(h, w, 3)[::-1]
+    assert 10 * np.log10(255.0 ** 2 / np.mean((back.astype(float) - rgb.astype(float)) ** 2)) > 28

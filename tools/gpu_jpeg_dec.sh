@@ -11,3 +11,4 @@ R=$GRAFT_REPO_ROOT
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/trace -o t -- python $R/tools/bench_jpeg_decode.py --concurrent 1 > $R/$out/trace.log 2>&1)
 python tools/pmc_summary.py $out/trace/t_results.db > $out/kernel_trace.txt 2>&1; head -14 $out/kernel_trace.txt | cut -c1-170
 rm -rf $out/trace
+timeout 900 python -m pytest tests/test_module_harness.py -m gpu -x -q -k "jpeg" > $out/pytest_module.log 2>&1; tail -3 $out/pytest_module.log

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kLutBits = 9;
+constexpr int kLutBits = 10;
 
 struct HuffHost {
         uint8_t bits[17] = {};
@@ -28,38 +28,41 @@ struct HuffHost {
 // device form of one Huffman table
 struct HuffDev {
         uint16_t lut[1 << kLutBits]; // (length << 8) | symbol for codes of at most kLutBits bits, 0 = longer
-        int maxcode[18];             // per length; -1 = no code of that length
-        int mincode[17];
-        int valptr[17];
+        uint32_t limit[17];          // the longer codes: (MAXCODE[n] + 1) << (16 - n), carried over lengths without codes
+        int16_t offset[17];          // VALPTR[n] - MINCODE[n]
+        uint8_t vals[256];
+};
+// the part of it that the longer codes need, as it sits in LDS
+struct LongCodes {
+        uint32_t limit[17];
+        int16_t offset[17];
         uint8_t vals[256];
 };
 
 void build_dev(const HuffHost &h, HuffDev &d)
 {
         memset(&d, 0, sizeof d);
-        for (int l = 0; l < 18; l++) d.maxcode[l] = -1;
         if (!h.present) return;
         memcpy(d.vals, h.vals, sizeof d.vals);
         int code = 0, k = 0;
+        uint32_t limit = 0;
         for (int l = 1; l <= 16; l++) {
-                d.valptr[l] = k;
-                d.mincode[l] = code;
+                d.offset[l] = (int16_t) (k - code);
                 for (int i = 0; i < h.bits[l]; i++, k++, code++) {
                         if (l <= kLutBits) {
                                 const int lo = code << (kLutBits - l);
                                 for (int f = 0; f < (1 << (kLutBits - l)); f++) d.lut[lo + f] = (uint16_t) (l << 8 | h.vals[k]);
                         }
                 }
-                d.maxcode[l] = h.bits[l] ? code - 1 : -1;
+                if (h.bits[l]) limit = (uint32_t) code << (16 - l);
+                d.limit[l] = limit;
                 code <<= 1;
         }
-        d.maxcode[17] = 0x7fffffff;
 }
 
 struct Scan {
         int ns, comp[3], td[3], ta[3];
         size_t data_begin, data_end; // entropy-coded bytes [begin, end) in the stream (end = the marker that follows)
-        std::vector<uint32_t> seg_off; // start of every restart segment
 };
 
 struct Header {
@@ -78,14 +81,13 @@ __device__ const uint8_t kZigzagDev[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32
                                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
 
 enum ParseMode {
-        kHeadersOnly, // stop behind the first SOS header: everything a single-scan stream needs from the host (its restart markers are found on the GPU)
-        kWalkScans,   // walk the entropy-coded data of every scan on the host and record where each restart segment starts
+        kHeadersOnly, // stop behind the first SOS header: everything a single-scan stream needs from the host
+        kWalkScans,   // walk the entropy-coded data on the host to find where every scan ends and the next one starts (one scan per component)
 };
 
 // 0 ok, -1 not a baseline stream this decoder takes, -2 truncated
 int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
 {
-        const bool want_segments = mode == kWalkScans;
         if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
         memset(h.qt, 0, sizeof h.qt);
         for (auto &t : h.dc) t.present = false;
@@ -165,7 +167,6 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                         }
                         // walk the entropy-coded data: RSTn markers start new segments, any other marker ends the scan
                         size_t q = sc.data_begin;
-                        if (want_segments) sc.seg_off.push_back((uint32_t) q);
                         for (;;) {
                                 const uint8_t *f = (const uint8_t *) memchr(data + q, 0xFF, len - q);
                                 if (!f || f + 1 >= data + len) { q = len; break; }
@@ -174,8 +175,7 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                                 if (n == 0x00 || n == 0xFF) { q += n == 0 ? 2 : 1; continue; }
                                 if (n >= 0xD0 && n <= 0xD7) {
                                         q += 2;
-                                        if (want_segments) sc.seg_off.push_back((uint32_t) q);
-                                        continue;
+                                                        continue;
                                 }
                                 break; // a real marker
                         }
@@ -191,24 +191,43 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// ---- restart markers located on the GPU (single-scan streams) ---------------------------------------------------------------------
-// Inside entropy-coded data 0xFF is always followed by 0x00 (stuffing), another 0xFF (fill) or a marker's second byte, so a byte pair
-// FF D0..D7 is a restart marker wherever it stands.  Pass 1 counts the markers of every 4 KiB of the stream, pass 2 turns the counts into
-// positions in stream order: seg_off[0] = first byte of the scan, seg_off[1 + i] = the byte behind the i-th marker.
+// ---- pass 1: the entropy-coded data made plain, on the GPU -----------------------------------------------------------------------------
+// Inside entropy-coded data 0xFF is followed by 0x00 (a stuffed byte: the data byte is 0xFF), by D0..D7 (a restart marker: the next segment
+// starts behind it) or by anything else (a marker that ends the scan, or damage).  Two kernels over the bytes of a scan, 4 KiB per
+// workgroup, turn it into what the Huffman kernel wants to read: the same bytes with the stuffed zeros and the restart markers taken out
+// ("clean" stream, positions counted from the start of the scan), plus, per restart segment, where it starts and where it ends in there
+// (the end: the next restart marker, or an earlier marker of another kind, or the end of the data).  Pass A counts what every 4 KiB
+// removes and how many restart markers it holds, pass B turns the counts into positions.
 constexpr int kScanWG = 256, kScanBytesPerLane = 16, kScanChunk = kScanWG * kScanBytesPerLane;
 
-// bit i set: bytes pos+i, pos+i+1 are a restart marker that lies in [begin, len); pos is 16-byte aligned
-__device__ __forceinline__ uint32_t rst_mask(const uint8_t *__restrict__ stream, size_t pos, size_t begin, size_t len)
+struct PieceMasks {
+        uint32_t drop, rst, marker; // per byte of the 16: taken out / first byte of a restart marker / first byte of any other marker
+};
+// the 16 bytes at pos (16-byte aligned) of a scan that occupies [begin, limit)
+__device__ __forceinline__ PieceMasks classify(const uint8_t *__restrict__ stream, size_t pos, size_t begin, size_t limit, uint4 &bytes)
 {
-        if (pos >= len) return 0;
+        PieceMasks m = { 0, 0, 0 };
+        if (pos >= limit) return m;
         const uint4 q = *(const uint4 *) (stream + pos);
-        const uint32_t w[5] = { q.x, q.y, q.z, q.w, stream[pos + 16] }; // the buffer is allocated with slack behind len
-        uint32_t m = 0;
+        bytes = q;
+        const uint32_t before = pos > begin ? stream[pos - 1] : 0, after = stream[pos + 16]; // the buffer has slack behind the data
+        const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+        uint32_t prev = before;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-                const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff, b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
-                const bool hit = b0 == 0xFF && (b1 & 0xF8) == 0xD0 && pos + i >= begin && pos + i + 1 < len;
-                m |= (uint32_t) hit << i;
+                const uint32_t b = (w[i / 4] >> (8 * (i % 4))) & 0xff;
+                const uint32_t next = i < 15 ? (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff : after;
+                const bool in = pos + i >= begin && pos + i < limit;
+                const bool next_in = pos + i + 1 < limit;
+                const bool ff = b == 0xFF;
+                const bool rst1 = ff && next_in && (next & 0xF8) == 0xD0;
+                const bool rst2 = prev == 0xFF && (b & 0xF8) == 0xD0 && pos + i > begin;
+                const bool stuffed = prev == 0xFF && b == 0x00 && pos + i > begin;
+                const bool other = ff && !rst1 && !(next_in && next == 0x00);
+                m.drop |= (uint32_t) (in && (rst1 || rst2 || stuffed)) << i;
+                m.rst |= (uint32_t) (in && rst1) << i;
+                m.marker |= (uint32_t) (in && other) << i;
+                prev = b;
         }
         return m;
 }
@@ -224,222 +243,243 @@ __device__ __forceinline__ int wg_sum_256(int v, int *lds4)
         return t;
 }
 
-__global__ __launch_bounds__(kScanWG) void rst_count_kernel(const uint8_t *__restrict__ stream, size_t base, size_t begin, size_t len, int *__restrict__ counts)
+// counts[2 * wg] = bytes the workgroup's 4 KiB lose, counts[2 * wg + 1] = restart markers in them
+// also: seg_end[0 .. n_seg) = 0xFFFFFFFF, what pass B's atomicMin starts from
+__global__ __launch_bounds__(kScanWG) void clean_count_kernel(const uint8_t *__restrict__ stream, size_t base, size_t begin, size_t limit, int *__restrict__ counts,
+                                                              uint32_t *__restrict__ seg_end, int n_seg)
 {
         __shared__ int part[4];
+        for (int i = blockIdx.x * kScanWG + threadIdx.x; i < n_seg; i += gridDim.x * kScanWG) seg_end[i] = 0xFFFFFFFFu;
         const size_t pos = base + (size_t) blockIdx.x * kScanChunk + threadIdx.x * kScanBytesPerLane;
-        const int t = wg_sum_256(__popc(rst_mask(stream, pos, begin, len)), part);
-        if (threadIdx.x == 0) counts[blockIdx.x] = t;
+        uint4 bytes;
+        const PieceMasks m = classify(stream, pos, begin, limit, bytes);
+        const int dropped = wg_sum_256(__popc(m.drop), part), rsts = wg_sum_256(__popc(m.rst), part);
+        if (threadIdx.x == 0) {
+                counts[2 * blockIdx.x] = dropped;
+                counts[2 * blockIdx.x + 1] = rsts;
+        }
 }
 
-// found[0] = number of segments located (1 + markers); at most cap offsets are written
-__global__ __launch_bounds__(kScanWG) void rst_place_kernel(const uint8_t *__restrict__ stream, size_t base, size_t begin, size_t len, const int *__restrict__ counts,
-                                                            uint32_t *__restrict__ seg_off, int cap, int *__restrict__ found)
+// seg_end holds 0xFFFFFFFF on entry (pass A); found[0] = number of segments (1 + restart markers); entries at index >= cap are not written
+__global__ __launch_bounds__(kScanWG) void clean_place_kernel(const uint8_t *__restrict__ stream, size_t base, size_t begin, size_t limit, const int *__restrict__ counts,
+                                                              uint8_t *__restrict__ clean, uint32_t *__restrict__ seg_start, uint32_t *__restrict__ seg_end, int cap,
+                                                              int *__restrict__ found)
 {
         __shared__ int part[4];
-        __shared__ int wave_tot[4];
-        int before = 0;
-        for (int j = threadIdx.x; j < (int) blockIdx.x; j += kScanWG) before += counts[j];
-        before = wg_sum_256(before, part);
+        __shared__ int wave_drop[4], wave_rst[4];
+        int drop_before = 0, rst_before = 0;
+        for (int j = threadIdx.x; j < (int) blockIdx.x; j += kScanWG) {
+                drop_before += counts[2 * j];
+                rst_before += counts[2 * j + 1];
+        }
+        drop_before = wg_sum_256(drop_before, part);
+        rst_before = wg_sum_256(rst_before, part);
         const size_t pos = base + (size_t) blockIdx.x * kScanChunk + threadIdx.x * kScanBytesPerLane;
-        uint32_t m = rst_mask(stream, pos, begin, len);
-        const int mine = __popc(m);
-        int incl = mine; // inclusive scan over the wave
+        uint4 bytes = make_uint4(0, 0, 0, 0);
+        const PieceMasks m = classify(stream, pos, begin, limit, bytes);
+        const int my_drop = __popc(m.drop), my_rst = __popc(m.rst);
+        int inc_drop = my_drop, inc_rst = my_rst; // inclusive scans over the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-                const int n = __shfl_up(incl, o);
-                if ((int) (threadIdx.x & 63) >= o) incl += n;
+                const int a = __shfl_up(inc_drop, o), c = __shfl_up(inc_rst, o);
+                if ((int) (threadIdx.x & 63) >= o) {
+                        inc_drop += a;
+                        inc_rst += c;
+                }
         }
-        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+        if ((threadIdx.x & 63) == 63) {
+                wave_drop[threadIdx.x >> 6] = inc_drop;
+                wave_rst[threadIdx.x >> 6] = inc_rst;
+        }
         __syncthreads();
-        int idx = 1 + before + incl - mine;
-        for (int w = 0; w < (int) (threadIdx.x >> 6); w++) idx += wave_tot[w];
-        while (m) {
-                const int i = __ffs(m) - 1;
-                m &= m - 1;
-                if (idx < cap) seg_off[idx] = (uint32_t) (pos + i + 2);
-                idx++;
+        int dropped = drop_before + inc_drop - my_drop, seg = rst_before + inc_rst - my_rst; // before this lane's first byte
+        for (int w = 0; w < (int) (threadIdx.x >> 6); w++) {
+                dropped += wave_drop[w];
+                seg += wave_rst[w];
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) seg_off[0] = (uint32_t) begin;
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanWG - 1) found[0] = idx;
+        if (blockIdx.x == 0 && threadIdx.x == 0) seg_start[0] = 0;
+        if (pos < limit) {
+                // position in the clean stream of this lane's first byte, were it kept
+                const long first = (long) pos - (long) begin - dropped; // negative only for the bytes in front of the scan, which are not written
+                const int lo = pos < begin ? (int) (begin - pos) : 0, hi = limit - pos < 16 ? (int) (limit - pos) : 16;
+                if (m.drop == 0 && lo == 0 && hi == 16) {
+                        __builtin_memcpy(clean + first, &bytes, 16);
+                } else {
+                        const uint32_t w[4] = { bytes.x, bytes.y, bytes.z, bytes.w };
+                        long at = first + lo; // bytes in front of the scan count as neither kept nor dropped
+                        for (int i = lo; i < hi; i++) {
+                                if (!(m.drop >> i & 1)) clean[at++] = (uint8_t) (w[i / 4] >> (8 * (i % 4)));
+                        }
+                }
+                uint32_t events = m.rst | m.marker;
+                while (events) { // rare: a lane with a marker in its bytes
+                        const int i = __ffs(events) - 1;
+                        events &= events - 1;
+                        const int s_here = seg + __popc(m.rst & ((1u << i) - 1));
+                        const uint32_t at = (uint32_t) ((long) pos + i - (long) begin - dropped - __popc(m.drop & ((1u << i) - 1)));
+                        if (s_here < cap) atomicMin(seg_end + s_here, at); // whichever marker comes first ends the segment
+                        if ((m.rst >> i & 1) && s_here + 1 < cap) seg_start[s_here + 1] = at;
+                }
+        }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanWG - 1) {
+                const int total_drop = dropped + my_drop, total_rst = seg + my_rst;
+                found[0] = total_rst + 1;
+                if (total_rst < cap) atomicMin(seg_end + total_rst, (uint32_t) ((long) limit - (long) begin - total_drop));
+        }
 }
 
-// ---- Huffman decoding ----------------------------------------------------------------------------------------------------------------
+// ---- pass 2: Huffman decoding --------------------------------------------------------------------------------------------------------
 struct ScanDev {
         int ns, comp[3], td[3], ta[3], nbh[3], nbv[3], gw[3]; // blocks per unit and blocks per row of each component's grid
         int single, bw1, mcu_w, ri;
-        long units;
+        int units;
         int16_t *coef[3];
-        unsigned scan_end;
 };
 
-// what the codes longer than the look-up need, in LDS
-struct LongCodes {
-        uint32_t limit[17]; // (MAXCODE[n] + 1) << (16 - n), carried over lengths without codes
-        int16_t offset[17]; // VALPTR[n] - MINCODE[n]
-        uint8_t vals[256];
-};
-
-// The entropy-coded bytes of one segment.  The bit window is topped up 32 bits at a time from a word that was loaded one refill earlier
-// (the common case: four bytes, none of them 0xFF); a word with 0xFF in it, or the last bytes of the data, go through the byte-wise path
-// that removes the stuffing and stops at a marker.  Behind a marker or the end of the data the window fills with zero bits.
+// The bytes of one segment in the workgroup's LDS copy of the clean stream.  Every symbol: if 32 bits or fewer are left, the window takes
+// the four bytes that were fetched from LDS one symbol earlier -- no byte-stuffing logic, no branches; behind the end of the segment the
+// window fills with zero bits.
 struct BitReader {
-        const uint8_t *base;     // the stream (the same for every lane)
-        uint32_t pos, end;       // next unread byte, end of the data
-        uint32_t nxt;            // the four bytes at pos, loaded ahead
-        bool over;
-        unsigned long long acc;  // bits are consumed from the top
+        uint32_t pos, end; // next unread byte and end of the segment, as offsets into the staged bytes
+        uint32_t nxt_lo, nxt_hi; // the aligned words around pos
+        unsigned long long acc; // bits are consumed from the top
         int cnt;
-        __device__ __forceinline__ uint32_t load32(uint32_t at) const
-        {
-                uint32_t w;
-                __builtin_memcpy(&w, base + at, 4); // the stream buffer has slack behind the data
-                return w;
-        }
-        __device__ __forceinline__ void open(const uint8_t *stream, uint32_t begin, uint32_t finish)
-        {
-                base = stream;
-                pos = begin;
-                end = finish;
-                over = begin >= finish;
-                acc = 0;
-                cnt = 0;
-                nxt = load32(pos);
-        }
-        __device__ __forceinline__ void refill()
-        {
-                if (cnt > 32) return; // a code (<= 16 bits) and its extra bits (<= 15) fit in what is left
-                do {
-                        if (over) break;
-                        uint32_t w = nxt;
-                        const bool has_ff = ((~w - 0x01010101u) & w & 0x80808080u) != 0;
-                        if (pos + 4 <= end && !has_ff) {
-                                acc |= (unsigned long long) __builtin_bswap32(w) << (32 - cnt);
-                                cnt += 32;
-                                pos += 4;
-                        } else { // byte by byte, out of the same register
-                                int avail = end - pos < 4 ? (int) (end - pos) : 4;
-                                while (avail > 0) {
-                                        const uint32_t byte = w & 0xff;
-                                        int used = 1;
-                                        if (byte == 0xFF) {
-                                                if (avail < 2) {
-                                                        if (pos + 1 >= end) over = true; // the data ends in 0xFF
-                                                        break;                            // else: the byte behind it is in the next word
-                                                }
-                                                if ((w >> 8 & 0xff) != 0) { // a marker: the segment is over
-                                                        over = true;
-                                                        break;
-                                                }
-                                                used = 2; // a stuffed zero: the data byte is 0xFF
-                                        }
-                                        acc |= (unsigned long long) byte << (56 - cnt);
-                                        cnt += 8;
-                                        w >>= 8 * used;
-                                        avail -= used;
-                                        pos += used;
-                                }
-                                if (pos >= end) over = true;
-                        }
-                        nxt = load32(pos);
-                } while (cnt <= 32);
-                if (over && cnt <= 32) cnt = 64; // zero bits from here on (the window's low bits are zero already)
-        }
 };
 
-// One Huffman symbol and the `symbol & 15` extra bits behind it (F.2.2.1, sign extension of Figure F.12): returns the symbol, the extended
-// value in `value`.  Works on the top 32 bits of the window: code (<= 16) + extra bits (<= 15) always fit.
-__device__ __forceinline__ int decode_symbol(BitReader &br, const LongCodes &lc, const uint16_t *lut, int &value)
-{
-        const uint32_t hi = (uint32_t) (br.acc >> 32);
-        const unsigned e = lut[hi >> (32 - kLutBits)];
-        int l = (int) (e >> 8), sym = (int) (e & 0xff);
-        if (__builtin_expect(e == 0, 0)) {
-                // a code longer than the look-up covers: codes of length n fill [.., limit[n]) of the 16-bit prefixes, limits ascending (F.2.2.3's
-                // MAXCODE walk without the loop)
-                const unsigned pk = hi >> 16;
-                l = kLutBits + 1;
-#pragma unroll
-                for (int n = kLutBits + 1; n <= 16; n++) l += pk >= lc.limit[n];
-                if (l > 16) { // corrupt data: consume the bits, decode nothing
-                        l = 16;
-                        sym = 0;
-                } else {
-                        sym = lc.vals[(int) (pk >> (16 - l)) + lc.offset[l] & 0xff];
-                }
-        }
-        const int sz = sym & 15;
-        const int v = (int) (((hi << l) >> 1) >> (31 - sz)); // the sz bits behind the code; 0 for sz == 0
-        value = v < ((1 << sz) >> 1) ? v + 1 - (1 << sz) : v;
-        br.acc <<= l + sz;
-        br.cnt -= l + sz;
-        return sym;
-}
-
-// One lane per restart segment, one wave per workgroup.  The lanes of a wave walk their segments block by block in step (every segment
-// holds the same blocks in the same order), each lane collecting the coefficients of its current block, in zigzag order, in a private
-// tile in LDS; when the block is done the wave writes the 64 tiles out together, 128 contiguous bytes per block, zeros included -- so the
-// coefficient planes need no clearing and no lane issues scattered 2-byte stores -- and leaves the tiles zeroed for the next block.
-// The coefficient planes are in zigzag order; the IDCT kernel undoes it with compile-time indices.
+constexpr size_t kMaxStage = 40 * 1024; // with the tables and tiles: under the 64 KiB a kernel gets without asking
 constexpr int kTileWords = 36; // 32 words of coefficients, padded: 16-byte aligned rows that start in different LDS banks
 
-__global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ stream, const uint32_t *__restrict__ seg_off, int n_seg,
-                                                         const int *__restrict__ found /* segments located on the GPU, or null: all n_seg are there */, ScanDev sp,
+// One lane per restart segment, `lanes` (8..64) of them per one-wave workgroup: with the usual few thousand segments per frame that is
+// fewer lanes per wave than a wave has, on purpose -- the symbol loop runs as long as its slowest lane, the machine has 1024 SIMDs, and a
+// frame has no more than a few hundred full waves of segments to offer.  The workgroup copies the stretch of the clean stream that its
+// segments occupy into LDS first (they are adjacent), so the symbol loop never waits on global memory; lanes whose bytes did not fit read
+// them from memory.  The lanes walk their segments block by block in step (every segment holds the same blocks in the same order), each
+// collecting the coefficients of its current block, in zigzag order, in a private tile in LDS; when the block is done the wave writes the
+// tiles out together, 128 contiguous bytes per block, zeros included -- so the coefficient planes need no clearing and no lane issues
+// scattered 2-byte stores -- and leaves the tiles zeroed for the next block.  The coefficient planes are in zigzag order; the IDCT kernel
+// undoes it with compile-time indices.
+__global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
+                                                         int n_seg, const int *__restrict__ found, int lanes, int stage_bytes, ScanDev sp,
                                                          const HuffDev *__restrict__ tabs /* [0..3] DC, [4..7] AC */)
 {
+        extern __shared__ __attribute__((aligned(16))) uint8_t stage[]; // stage_bytes + 16
         __shared__ uint16_t luts[6][1 << kLutBits]; // the scan's DC tables then its AC tables
         __shared__ LongCodes longs[6];
         __shared__ __attribute__((aligned(16))) uint32_t tile[64 * kTileWords];
-        __shared__ long tile_dst[64]; // where the lane's tile goes (in coefficients), -1: nowhere
+        __shared__ int tile_dst[64]; // where the lane's tile goes (in blocks), -1: nowhere
         const int lane = threadIdx.x;
+        const int seg0 = blockIdx.x * lanes;
+        const int n_found = min(n_seg, found[0]);
+        // ---- the workgroup's stretch of the clean stream -> LDS ----
+        uint32_t stage_begin = 0, staged = 0;
+        if (seg0 < n_found) {
+                const int last = min(seg0 + lanes, n_found) - 1;
+                stage_begin = seg_start[seg0] & ~15u;
+                const uint32_t stretch = seg_end[last] - stage_begin;
+                staged = min((stretch + 15u) & ~15u, (uint32_t) stage_bytes);
+                for (uint32_t o = lane * 16; o < staged; o += 64 * 16) *(uint4 *) (stage + o) = *(const uint4 *) (clean + stage_begin + o);
+        }
         for (int k = 0; k < sp.ns; k++) {
-                for (int i = lane; i < (1 << kLutBits); i += 64) {
-                        luts[k][i] = tabs[sp.td[k]].lut[i];
-                        luts[3 + k][i] = tabs[4 + sp.ta[k]].lut[i];
-                }
                 for (int half = 0; half < 2; half++) {
                         const HuffDev &t = tabs[half ? 4 + sp.ta[k] : sp.td[k]];
+                        const uint4 *src = (const uint4 *) t.lut;
+                        uint4 *dst = (uint4 *) luts[3 * half + k];
+                        for (int i = lane; i < (int) (sizeof t.lut / 16); i += 64) dst[i] = src[i];
                         LongCodes &lc = longs[3 * half + k];
                         for (int i = lane; i < 256; i += 64) lc.vals[i] = t.vals[i];
-                        if (lane == 0) {
-                                uint32_t limit = 0;
-                                for (int n = 1; n <= 16; n++) {
-                                        if (t.maxcode[n] >= 0) limit = (uint32_t) (t.maxcode[n] + 1) << (16 - n);
-                                        lc.limit[n] = limit;
-                                        lc.offset[n] = (int16_t) (t.valptr[n] - t.mincode[n]);
-                                }
+                        if (lane < 17) {
+                                lc.limit[lane] = t.limit[lane];
+                                lc.offset[lane] = t.offset[lane];
                         }
                 }
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) *(uint4 *) (tile + lane * kTileWords + 4 * j) = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        const int seg = blockIdx.x * 64 + lane;
-        const bool present = seg < n_seg && (!found || seg < found[0]); // a segment the stream does not have decodes to zero blocks
+        const int seg = seg0 + lane;
+        const bool mine = lane < lanes && seg < n_seg;
+        const bool present = mine && seg < n_found; // a segment the stream does not have decodes to zero blocks
         BitReader br;
-        br.open(stream, present ? seg_off[seg] : 0u, present ? sp.scan_end : 0u);
+        br.pos = present ? seg_start[seg] - stage_begin : 0;
+        br.end = present ? seg_end[seg] - stage_begin : 0;
+        br.acc = 0;
+        br.cnt = 0;
+        const uint8_t *const far = clean + stage_begin; // for what did not fit in LDS
+        // the two aligned words that hold the four bytes at `at`; put together when they are used, one symbol later
+        auto fetch = [&](uint32_t at) {
+                if (__builtin_expect(at + 8 > staged, 0)) {
+                        const uint32_t *two = (const uint32_t *) (far + (at & ~3u)); // the clean buffer has slack behind the data
+                        br.nxt_lo = two[0];
+                        br.nxt_hi = two[1];
+                        asm volatile("" : "+v"(br.nxt_lo), "+v"(br.nxt_hi)); // completes here: the common path never waits on memory
+                } else {
+                        const uint32_t *two = (const uint32_t *) (stage + (at & ~3u));
+                        br.nxt_lo = two[0];
+                        br.nxt_hi = two[1];
+                }
+        };
+        fetch(br.pos);
+        // one Huffman symbol and the `symbol & 15` extra bits behind it (F.2.2.1, sign extension of Figure F.12): code (<= 16 bits) + extra bits
+        // (<= 15) always fit in the top 32 bits of the window after the top-up
+        auto symbol = [&](const uint16_t *lut, const LongCodes &lc, int &value) -> int {
+                {
+                        const bool need = br.cnt <= 32;
+                        uint32_t w = __builtin_amdgcn_alignbyte(br.nxt_hi, br.nxt_lo, br.pos);
+                        if (__builtin_expect(br.pos + 4 > br.end, 0)) { // the last bytes of the segment: zero bits behind them
+                                const int left = (int) br.end - (int) br.pos;
+                                w = left <= 0 ? 0 : w & (0xFFFFFFFFu >> (8 * (4 - left)));
+                        }
+                        const unsigned long long in = need ? __builtin_bswap32(w) : 0u;
+                        br.acc |= in << ((32 - br.cnt) & 63);
+                        br.cnt += need ? 32 : 0;
+                        br.pos += need && br.pos < br.end ? 4 : 0; // never far behind the end: what is fetched there is masked anyway
+                        fetch(br.pos);
+                }
+                const uint32_t hi = (uint32_t) (br.acc >> 32);
+                const unsigned e = lut[hi >> (32 - kLutBits)];
+                int l = (int) (e >> 8), sym = (int) (e & 0xff);
+                if (__builtin_expect(e == 0, 0)) {
+                        // a code longer than the look-up covers: codes of length n fill [.., limit[n]) of the 16-bit prefixes, limits ascending
+                        // (F.2.2.3's MAXCODE walk without the loop)
+                        const unsigned pk = hi >> 16;
+                        l = kLutBits + 1;
+#pragma unroll
+                        for (int n = kLutBits + 1; n <= 16; n++) l += pk >= lc.limit[n];
+                        if (l > 16) { // corrupt data: consume the bits, decode nothing
+                                l = 16;
+                                sym = 0;
+                        } else {
+                                sym = lc.vals[(int) (pk >> (16 - l)) + lc.offset[l] & 0xff];
+                        }
+                }
+                const int sz = sym & 15;
+                const int v = (int) (((hi << l) >> 1) >> (31 - sz)); // the sz bits behind the code; 0 for sz == 0
+                value = v < ((1 << sz) >> 1) ? v + 1 - (1 << sz) : v;
+                br.acc <<= l + sz;
+                br.cnt -= l + sz;
+                return sym;
+        };
         int pred[3] = { 0, 0, 0 };
-        const long per_seg = sp.ri ? sp.ri : sp.units;
-        const long u0 = (long) seg * per_seg;
+        const int per_seg = sp.ri ? sp.ri : sp.units;
+        const int u0 = seg * per_seg;
         int16_t *const my = (int16_t *) (tile + lane * kTileWords);
-        for (long i = 0; i < per_seg; i++) {
-                const long u = u0 + i;
-                const bool active = seg < n_seg && u < sp.units;
-                const long ux = sp.single ? u % sp.bw1 : u % sp.mcu_w, uy = sp.single ? u / sp.bw1 : u / sp.mcu_w;
+        const int rounds = (lanes + 7) / 8;
+        for (int i = 0; i < per_seg; i++) {
+                const int u = u0 + i;
+                const bool active = mine && u < sp.units;
+                const int row_units = sp.single ? sp.bw1 : sp.mcu_w;
+                const int uy = u / row_units, ux = u - uy * row_units;
                 for (int k = 0; k < sp.ns; k++) {
-                        const LongCodes &tdc = longs[k], &tac = longs[3 + k];
                         for (int by = 0; by < sp.nbv[k]; by++) {
                                 for (int bx = 0; bx < sp.nbh[k]; bx++) {
-                                        tile_dst[lane] = active ? ((uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64 : -1;
+                                        tile_dst[lane] = active ? (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx : -1;
                                         if (active && present) {
                                                 int v;
-                                                br.refill();
-                                                decode_symbol(br, tdc, luts[k], v);
+                                                symbol(luts[k], longs[k], v);
                                                 pred[k] += v;
                                                 my[0] = (int16_t) pred[k];
                                                 for (int z = 1; z < 64; z++) {
-                                                        br.refill();
-                                                        const int rs = decode_symbol(br, tac, luts[3 + k], v);
+                                                        const int rs = symbol(luts[3 + k], longs[3 + k], v);
                                                         if ((rs & 15) == 0 && rs != 0xF0) break; // EOB
                                                         z += rs >> 4;
                                                         my[(rs & 15) && z < 64 ? z : 64] = (int16_t) v; // slot 64 is the tile's padding
@@ -447,14 +487,13 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                                         }
                                         __syncthreads();
                                         // 8 lanes per tile, 16 bytes each: 8 tiles per round
-#pragma unroll
-                                        for (int round = 0; round < 8; round++) {
+                                        for (int round = 0; round < rounds; round++) {
                                                 const int t = round * 8 + (lane >> 3), part = lane & 7;
-                                                const long dst = tile_dst[t];
+                                                const int dst = tile_dst[t];
                                                 uint4 *src = (uint4 *) (tile + t * kTileWords + part * 4);
                                                 const uint4 q = *src;
                                                 *src = make_uint4(0, 0, 0, 0);
-                                                if (dst >= 0) *(uint4 *) (sp.coef[k] + dst + part * 8) = q;
+                                                if (dst >= 0) *(uint4 *) (sp.coef[k] + (size_t) dst * 64 + part * 8) = q;
                                         }
                                         __syncthreads();
                                 }
@@ -567,9 +606,11 @@ struct Decoder {
         // device workspace, grown on demand
         uint8_t *stream = nullptr;
         size_t stream_cap = 0;
-        uint32_t *seg_off = nullptr;
-        size_t seg_cap = 0;
-        int *scan_counts = nullptr; // [0]: segments located by the GPU marker scan, [1..]: markers per 4 KiB of the stream
+        uint8_t *clean = nullptr;   // the entropy-coded data of one scan without stuffed zeros and restart markers
+        size_t clean_cap = 0;
+        uint32_t *seg_start = nullptr, *seg_end = nullptr; // per restart segment, in the clean stream
+        size_t seg_start_cap = 0, seg_end_cap = 0;
+        int *scan_counts = nullptr; // [0]: segments found, [2 + 2 i], [3 + 2 i]: bytes taken out of / restart markers in the i-th 4 KiB of the scan
         size_t scan_cap = 0;
         HuffDev *tabs = nullptr;     // 8 tables
         uint16_t *qt = nullptr;      // 4 x 64
@@ -578,9 +619,11 @@ struct Decoder {
         size_t coef_cap[3] = { 0, 0, 0 }, plane_cap[3] = { 0, 0, 0 };
         uint8_t *tmp = nullptr;      // intermediate packed frame (UYVY or RGB) when the output needs a second conversion
         size_t tmp_cap = 0;
-        // pinned staging for the tables and segment offsets
+        // pinned staging for the tables; they are uploaded when they differ from the last frame's
         void *pinned = nullptr;
-        size_t pinned_cap = 0;
+        HuffHost dc_now[4], ac_now[4];
+        uint16_t qt_now[4][64];
+        bool tables_valid = false;
         Header hdr;
         int plane_pitch[3] = { 0, 0, 0 };
         hipEvent_t uploaded = nullptr; // the pinned staging area may be rewritten once this has happened
@@ -610,6 +653,7 @@ int ug_hip_jpeg_decoder_create(ug_hip_jpeg_decoder **out)
         Decoder *d = new Decoder();
         hipError_t err = hipMalloc((void **) &d->tabs, 8 * sizeof(HuffDev));
         if (err == hipSuccess) err = hipMalloc((void **) &d->qt, 4 * 64 * sizeof(uint16_t));
+        if (err == hipSuccess) err = hipHostMalloc(&d->pinned, 8 * sizeof(HuffDev) + sizeof d->qt_now, hipHostMallocDefault);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming);
         if (err != hipSuccess) {
                 ug::set_last_error(err, "ug_hip_jpeg_decoder_create");
@@ -624,7 +668,7 @@ void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec)
 {
         Decoder *d = (Decoder *) dec;
         if (!d) return;
-        for (void *p : { (void *) d->stream, (void *) d->seg_off, (void *) d->scan_counts, (void *) d->tabs, (void *) d->qt, (void *) d->coef[0], (void *) d->coef[1], (void *) d->coef[2],
+        for (void *p : { (void *) d->stream, (void *) d->clean, (void *) d->seg_start, (void *) d->seg_end, (void *) d->scan_counts, (void *) d->tabs, (void *) d->qt, (void *) d->coef[0], (void *) d->coef[1], (void *) d->coef[2],
                          (void *) d->plane[0], (void *) d->plane[1], (void *) d->plane[2], (void *) d->tmp }) {
                 if (p) (void) hipFree(p);
         }
@@ -683,79 +727,29 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
         }
         hipStream_t st = (hipStream_t) stream;
         // ---- workspace ----
-        const long mcus = (long) h.mcu_w * h.mcu_h;
-        const long gpu_expect = h.ri ? (mcus + h.ri - 1) / h.ri : 1;
-        const size_t scan_base = gpu_scan ? h.scans[0].data_begin & ~(size_t) 15 : 0;
-        const unsigned scan_grid = gpu_scan ? (unsigned) ((len - scan_base + kScanChunk - 1) / kScanChunk) : 0;
-        size_t n_seg_total = 0; // offsets the host uploads
-        for (const Scan &sc : h.scans) n_seg_total += sc.seg_off.size();
-        bool ok = grow((void **) &d->stream, &d->stream_cap, len + 32) &&
-                  grow((void **) &d->seg_off, &d->seg_cap, (gpu_scan ? (size_t) gpu_expect : n_seg_total) * sizeof(uint32_t)) &&
-                  grow((void **) &d->scan_counts, &d->scan_cap, ((size_t) scan_grid + 1) * sizeof(int));
+        struct ScanPlan {
+                ScanDev sp;
+                int n_seg;
+        };
+        ScanPlan plan[3];
         long gw[3], gh[3];
-        for (int c = 0; c < h.ncomp && ok; c++) {
+        for (int c = 0; c < h.ncomp; c++) {
                 gw[c] = (long) h.mcu_w * h.hs[c];
                 gh[c] = (long) h.mcu_h * h.vs[c];
-                d->plane_pitch[c] = (int) (gw[c] * 8);
-                ok = grow((void **) &d->coef[c], &d->coef_cap[c], (size_t) (gw[c] * gh[c]) * 128) && grow((void **) &d->plane[c], &d->plane_cap[c], (size_t) (gw[c] * gh[c]) * 64);
         }
-        const size_t pin_need = 8 * sizeof(HuffDev) + sizeof h.qt + n_seg_total * sizeof(uint32_t);
-        if (ok && d->pinned_cap < pin_need) {
-                if (d->upload_pending) (void) hipEventSynchronize(d->uploaded);
-                d->upload_pending = false;
-                if (d->pinned) (void) hipHostFree(d->pinned);
-                d->pinned = nullptr;
-                d->pinned_cap = 0;
-                ok = hipHostMalloc(&d->pinned, pin_need + 4096, hipHostMallocDefault) == hipSuccess;
-                if (ok) d->pinned_cap = pin_need + 4096;
+        if (gw[0] * gh[0] > 0x7FFFFFFF / 64 || h.scans.size() > 3) {
+                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: picture too large");
+                return UG_HIP_EUNSUPP;
         }
-        if (!ok) {
-                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: out of device memory");
-                return UG_HIP_ERUNTIME;
-        }
-        // ---- tables, segment offsets, stream -> device ----
-        if (d->upload_pending) { // the previous call's asynchronous copies read the staging area: let them finish before it is rewritten
-                UG_HIP_TRY(hipEventSynchronize(d->uploaded));
-                d->upload_pending = false;
-        }
-        HuffDev *tabs_h = (HuffDev *) d->pinned;
-        for (int t = 0; t < 4; t++) {
-                build_dev(h.dc[t], tabs_h[t]);
-                build_dev(h.ac[t], tabs_h[4 + t]);
-        }
-        uint16_t *qt_h = (uint16_t *) (tabs_h + 8);
-        memcpy(qt_h, h.qt, sizeof h.qt);
-        uint32_t *seg_h = (uint32_t *) (qt_h + 4 * 64);
-        {
-                size_t k = 0;
-                for (const Scan &sc : h.scans) {
-                        memcpy(seg_h + k, sc.seg_off.data(), sc.seg_off.size() * sizeof(uint32_t));
-                        k += sc.seg_off.size();
-                }
-        }
-        UG_HIP_TRY(hipMemcpyAsync(d->tabs, tabs_h, 8 * sizeof(HuffDev), hipMemcpyHostToDevice, st));
-        UG_HIP_TRY(hipMemcpyAsync(d->qt, qt_h, sizeof h.qt, hipMemcpyHostToDevice, st));
-        if (n_seg_total) UG_HIP_TRY(hipMemcpyAsync(d->seg_off, seg_h, n_seg_total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        UG_HIP_TRY(hipMemcpyAsync(d->stream, jpeg_host, len, hipMemcpyHostToDevice, st));
-        UG_HIP_TRY(hipEventRecord(d->uploaded, st));
-        d->upload_pending = true;
-        if (gpu_scan) {
-                const Scan &sc = h.scans[0];
-                hipLaunchKernelGGL(rst_count_kernel, dim3(scan_grid), dim3(kScanWG), 0, st, d->stream, scan_base, sc.data_begin, len, d->scan_counts + 1);
-                hipLaunchKernelGGL(rst_place_kernel, dim3(scan_grid), dim3(kScanWG), 0, st, d->stream, scan_base, sc.data_begin, len, d->scan_counts + 1, d->seg_off,
-                                   (int) gpu_expect, d->scan_counts);
-        } else { // a scan of one component leaves the padding blocks of the MCU grid untouched, a short stream whole segments
-                for (int c = 0; c < h.ncomp; c++) UG_HIP_TRY(hipMemsetAsync(d->coef[c], 0, (size_t) (gw[c] * gh[c]) * 128, st));
-        }
-        // ---- Huffman decoding, scan by scan ----
-        size_t seg_base = 0;
-        for (const Scan &sc : h.scans) {
-                ScanDev sp = {};
+        int max_seg = 1;
+        for (size_t i = 0; i < h.scans.size(); i++) {
+                const Scan &sc = h.scans[i];
+                ScanDev &sp = plan[i].sp;
+                sp = ScanDev();
                 sp.ns = sc.ns;
                 sp.single = sc.ns == 1 && h.ncomp > 1;
                 sp.mcu_w = h.mcu_w;
                 sp.ri = h.ri;
-                sp.scan_end = (unsigned) sc.data_end;
                 for (int k = 0; k < sc.ns; k++) {
                         const int c = sc.comp[k];
                         sp.comp[k] = c;
@@ -764,23 +758,81 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
                         sp.nbh[k] = sp.single ? 1 : h.hs[c];
                         sp.nbv[k] = sp.single ? 1 : h.vs[c];
                         sp.gw[k] = (int) gw[c];
-                        sp.coef[k] = d->coef[c];
                 }
                 if (sp.single) { // a non-interleaved scan walks the component's own block grid, ceil(size / 8) blocks (T.81 A.2.2)
                         const int c = sc.comp[0];
                         sp.bw1 = ((h.width * h.hs[c] + h.hmax - 1) / h.hmax + 7) / 8;
                         const int bh1 = ((h.height * h.vs[c] + h.vmax - 1) / h.vmax + 7) / 8;
-                        sp.units = (long) sp.bw1 * bh1;
+                        sp.units = sp.bw1 * bh1;
                 } else {
                         sp.bw1 = 1;
-                        sp.units = (long) h.mcu_w * h.mcu_h;
+                        sp.units = h.mcu_w * h.mcu_h;
                 }
-                // only as many segments as the restart interval accounts for (a stream may carry fewer or more markers than it should)
-                const long expect = h.ri ? (sp.units + h.ri - 1) / h.ri : 1;
-                const int n_seg = gpu_scan ? (int) expect : (int) (expect < (long) sc.seg_off.size() ? expect : (long) sc.seg_off.size());
-                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + 63) / 64)), dim3(64), 0, st, d->stream, d->seg_off + seg_base, n_seg,
-                                   gpu_scan ? d->scan_counts : nullptr, sp, d->tabs);
-                seg_base += sc.seg_off.size();
+                // as many segments as the restart interval accounts for (a stream may carry fewer or more markers than it should)
+                plan[i].n_seg = h.ri ? (sp.units + h.ri - 1) / h.ri : 1;
+                max_seg = plan[i].n_seg > max_seg ? plan[i].n_seg : max_seg;
+        }
+        const unsigned max_grid = (unsigned) ((len + kScanChunk - 1) / kScanChunk) + 1;
+        bool ok = grow((void **) &d->stream, &d->stream_cap, len + 32) && grow((void **) &d->clean, &d->clean_cap, len + 64) &&
+                  grow((void **) &d->seg_start, &d->seg_start_cap, (size_t) max_seg * sizeof(uint32_t)) &&
+                  grow((void **) &d->seg_end, &d->seg_end_cap, (size_t) max_seg * sizeof(uint32_t)) &&
+                  grow((void **) &d->scan_counts, &d->scan_cap, (2 * (size_t) max_grid + 2) * sizeof(int));
+        for (int c = 0; c < h.ncomp && ok; c++) {
+                d->plane_pitch[c] = (int) (gw[c] * 8);
+                ok = grow((void **) &d->coef[c], &d->coef_cap[c], (size_t) (gw[c] * gh[c]) * 128) && grow((void **) &d->plane[c], &d->plane_cap[c], (size_t) (gw[c] * gh[c]) * 64);
+        }
+        if (!ok) {
+                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: out of device memory");
+                return UG_HIP_ERUNTIME;
+        }
+        // ---- tables (when they differ from the last frame's) and the stream -> device ----
+        if (!d->tables_valid || memcmp(d->dc_now, h.dc, sizeof h.dc) != 0 || memcmp(d->ac_now, h.ac, sizeof h.ac) != 0 || memcmp(d->qt_now, h.qt, sizeof h.qt) != 0) {
+                if (d->upload_pending) { // an earlier call's asynchronous copy reads the staging area: let it finish before it is rewritten
+                        UG_HIP_TRY(hipEventSynchronize(d->uploaded));
+                        d->upload_pending = false;
+                }
+                HuffDev *tabs_h = (HuffDev *) d->pinned;
+                for (int t = 0; t < 4; t++) {
+                        build_dev(h.dc[t], tabs_h[t]);
+                        build_dev(h.ac[t], tabs_h[4 + t]);
+                }
+                uint16_t *qt_h = (uint16_t *) (tabs_h + 8);
+                memcpy(qt_h, h.qt, sizeof h.qt);
+                UG_HIP_TRY(hipMemcpyAsync(d->tabs, tabs_h, 8 * sizeof(HuffDev), hipMemcpyHostToDevice, st));
+                UG_HIP_TRY(hipMemcpyAsync(d->qt, qt_h, sizeof h.qt, hipMemcpyHostToDevice, st));
+                UG_HIP_TRY(hipEventRecord(d->uploaded, st));
+                d->upload_pending = true;
+                memcpy(d->dc_now, h.dc, sizeof h.dc);
+                memcpy(d->ac_now, h.ac, sizeof h.ac);
+                memcpy(d->qt_now, h.qt, sizeof h.qt);
+                d->tables_valid = true;
+        }
+        UG_HIP_TRY(hipMemcpyAsync(d->stream, jpeg_host, len, hipMemcpyHostToDevice, st));
+        if (!gpu_scan) { // a scan of one component leaves the padding blocks of the MCU grid untouched
+                for (int c = 0; c < h.ncomp; c++) UG_HIP_TRY(hipMemsetAsync(d->coef[c], 0, (size_t) (gw[c] * gh[c]) * 128, st));
+        }
+        // ---- scan by scan: clean stream + segment table, then Huffman decoding ----
+        for (size_t i = 0; i < h.scans.size(); i++) {
+                const Scan &sc = h.scans[i];
+                ScanDev &sp = plan[i].sp;
+                for (int k = 0; k < sc.ns; k++) sp.coef[k] = d->coef[sc.comp[k]];
+                const int n_seg = plan[i].n_seg;
+                const size_t base = sc.data_begin & ~(size_t) 15;
+                const unsigned grid = (unsigned) ((sc.data_end - base + kScanChunk - 1) / kScanChunk);
+                if (grid == 0) continue; // no data at all: the planes stay as they are
+                hipLaunchKernelGGL(clean_count_kernel, dim3(grid), dim3(kScanWG), 0, st, d->stream, base, sc.data_begin, sc.data_end, d->scan_counts + 2, d->seg_end,
+                                   n_seg);
+                hipLaunchKernelGGL(clean_place_kernel, dim3(grid), dim3(kScanWG), 0, st, d->stream, base, sc.data_begin, sc.data_end, d->scan_counts + 2, d->clean,
+                                   d->seg_start, d->seg_end, n_seg, d->scan_counts);
+                // lanes per workgroup: as few as keep every workgroup resident at once (LDS allows ~5 per CU); the stretch of the stream a workgroup
+                // stages in LDS is sized for twice the average segment
+                int lanes = 8;
+                while (lanes < 64 && (n_seg + lanes - 1) / lanes > 1280) lanes *= 2;
+                const size_t avg = (sc.data_end - sc.data_begin) / (size_t) n_seg + 1;
+                size_t stage = (2 * avg * (size_t) lanes + 256 + 255) & ~(size_t) 255;
+                stage = stage < 2048 ? 2048 : (stage > kMaxStage ? kMaxStage : stage);
+                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + lanes - 1) / lanes)), dim3(64), stage + 16, st, d->clean, d->seg_start, d->seg_end, n_seg,
+                                   d->scan_counts, lanes, (int) stage, sp, d->tabs);
         }
         // ---- dequantisation + IDCT ----
         for (int c = 0; c < h.ncomp; c++) {
