@@ -531,11 +531,23 @@ __device__ __forceinline__ void idct_1d(const int (&s)[8], int (&o)[8])
 }
 
 // one lane per block of one component's (MCU-padded) block grid
-__global__ __launch_bounds__(256) void idct_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ qt /* 64, natural order */, int gw, long n_blocks,
-                                                   uint8_t *__restrict__ plane, int pitch)
+struct IdctJob {
+        const int16_t *coef[3]; // zigzag order, as the Huffman kernel leaves them
+        const uint16_t *qt[3];  // 64, natural order
+        uint8_t *plane[3];
+        int gw[3], pitch[3];
+        long n_blocks[3];
+};
+// blockIdx.y = component
+__global__ __launch_bounds__(256) void idct_kernel(IdctJob job)
 {
+        const int comp = blockIdx.y;
         const long b = (long) blockIdx.x * 256 + threadIdx.x;
-        if (b >= n_blocks) return;
+        if (b >= job.n_blocks[comp]) return;
+        const int16_t *__restrict__ coef = job.coef[comp];
+        const uint16_t *__restrict__ qt = job.qt[comp];
+        uint8_t *__restrict__ plane = job.plane[comp];
+        const int gw = job.gw[comp], pitch = job.pitch[comp];
         const uint4 *src = (const uint4 *) (coef + b * 64);
         int v[64];
 #pragma unroll
@@ -835,10 +847,19 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
                                    d->scan_counts, lanes, (int) stage, sp, d->tabs);
         }
         // ---- dequantisation + IDCT ----
-        for (int c = 0; c < h.ncomp; c++) {
-                const long nb = gw[c] * gh[c];
-                hipLaunchKernelGGL(idct_kernel, dim3((unsigned) ((nb + 255) / 256)), dim3(256), 0, st, d->coef[c], d->qt + 64 * h.tq[c], (int) gw[c], nb, d->plane[c],
-                                   d->plane_pitch[c]);
+        {
+                IdctJob job = {};
+                long most = 0;
+                for (int c = 0; c < h.ncomp; c++) {
+                        job.coef[c] = d->coef[c];
+                        job.qt[c] = d->qt + 64 * h.tq[c];
+                        job.plane[c] = d->plane[c];
+                        job.gw[c] = (int) gw[c];
+                        job.pitch[c] = d->plane_pitch[c];
+                        job.n_blocks[c] = gw[c] * gh[c];
+                        most = job.n_blocks[c] > most ? job.n_blocks[c] : most;
+                }
+                hipLaunchKernelGGL(idct_kernel, dim3((unsigned) ((most + 255) / 256), (unsigned) h.ncomp), dim3(256), 0, st, job);
         }
         UG_HIP_LAUNCH_CHECK();
         if (out == UG_PF_NONE) return UG_HIP_SUCCESS; // planes only (tests)
