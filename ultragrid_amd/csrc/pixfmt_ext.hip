@@ -680,6 +680,202 @@ void launch_xvec(const XArgs &a, int nvec, hipStream_t st)
         hipLaunchKernelGGL((xvec_kernel<Body, SB, DB, K>), grid, block, 0, st, a, nvec);
 }
 
+// ---- R12L by the pixel -------------------------------------------------------------------------------------------------------------------
+// R12L is a little-endian stream of 12-bit samples, 36 bits per pixel, 8 pixels = 9 words.  The group-per-lane bodies above hold 24 samples
+// (and up to 16 output words) per lane; for the whole groups of a line these kernels go one lane per pixel instead: pixel p sits at bit
+// 36 p, i.e. in the two words from word 9p/8 on, shifted by 4 (p % 8) bits -- two aligned loads, one 64-bit shift, one coalesced store.
+// The arithmetic per pixel is that of the bodies above (k_r12l_to_rgba / _rg48 / _y416, k_rgb_to_r12l / k_rg48_to_r12l / k_y416_to_r12l).
+__device__ __forceinline__ void r12l_pixel(const uint8_t *XR srow, int p, uint32_t &r, uint32_t &g, uint32_t &b)
+{
+        const uint32_t *w = (const uint32_t *) srow + ((9 * p) >> 3);
+        const unsigned long long bits = ((unsigned long long) w[1] << 32 | w[0]) >> ((4 * p) & 31);
+        r = (uint32_t) bits & 0xfffu, g = (uint32_t) (bits >> 12) & 0xfffu, b = (uint32_t) (bits >> 24) & 0xfffu;
+}
+constexpr int kPxPerLane = 4; // a wave covers 4 x 64 consecutive pixels: the loads of all four are in flight together
+template <int OUT>
+__global__ __launch_bounds__(256) void r12l_px_kernel(const XArgs a, int npx) // npx = pixels of every line that belong to whole groups
+{
+        const int p0 = blockIdx.x * (64 * kPxPerLane) + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+        if (y >= a.height || p0 - (int) threadIdx.x >= npx) return;
+        const uint8_t *XR srow = a.src + (long) y * a.spitch;
+        uint8_t *XR drow = a.dst + (long) y * a.dpitch;
+        uint32_t r[kPxPerLane], g[kPxPerLane], b[kPxPerLane];
+#pragma unroll
+        for (int u = 0; u < kPxPerLane; u++) {
+                const int p = p0 + 64 * u;
+                r12l_pixel(srow, p < npx ? p : 0, r[u], g[u], b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kPxPerLane; u++) {
+                const int p = p0 + 64 * u;
+                if (p >= npx) break;
+                if (OUT == UG_PF_RGBA) {
+                        ((uint32_t *) drow)[p] = a.am | (r[u] >> 4) << a.rs | (g[u] >> 4) << a.gs | (b[u] >> 4) << a.bs;
+                } else if (OUT == UG_PF_Y416) {
+                        const int R = r[u] << 4, G = g[u] << 4, B = b[u] << 4;
+                        const uint32_t cb = (uint16_t) ((TO_CB(R, G, B) >> kBase) + (1 << 15)), yy = (uint16_t) ((TO_Y(R, G, B) >> kBase) + (1 << 12)),
+                                       cr = (uint16_t) ((TO_CR(R, G, B) >> kBase) + (1 << 15));
+                        ((uint2 *) drow)[p] = make_uint2(cb | yy << 16, cr | 0xFFFF0000u);
+                } else { // RG48: three 16-bit samples
+                        uint16_t *d = (uint16_t *) drow + 3 * p;
+                        d[0] = (uint16_t) (r[u] << 4), d[1] = (uint16_t) (g[u] << 4), d[2] = (uint16_t) (b[u] << 4);
+                }
+        }
+}
+template <int OUT, int DB>
+void launch_r12l_px(const XArgs &a, int ngroups, hipStream_t st)
+{
+        const int npx = 8 * ngroups, per_wave = 64 * kPxPerLane;
+        const dim3 block(64, 4, 1), grid((unsigned) ((npx + per_wave - 1) / per_wave), (unsigned) ((a.height + 3) / 4), 1);
+        hipLaunchKernelGGL((r12l_px_kernel<OUT>), grid, block, 0, st, a, npx);
+}
+
+// R12L -> RG48 / RGB / UYVY / R10k with 4 adjacent pixels per lane: 144 bits in (five words from word 9q/2 on, shifted by 16 bits for odd
+// q), 24 / 12 / 8 / 16 contiguous bytes out
+template <int OUT>
+__global__ __launch_bounds__(256) void r12l_quad_kernel(const XArgs a, int nquads)
+{
+        const int q = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+        if (y >= a.height || q >= nquads) return;
+        const uint32_t *XR s = (const uint32_t *) (a.src + (long) y * a.spitch) + ((9 * q) >> 1);
+        const uint32_t sh = (q & 1) * 16;
+        const uint32_t w[6] = { s[0], s[1], s[2], s[3], s[4], 0 };
+        uint32_t n[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) n[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], sh);
+        uint32_t v[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+                const int bit = 12 * i, j = bit >> 5, o = bit & 31;
+                uint32_t x = n[j] >> o;
+                if (o > 20) x |= n[j + 1] << (32 - o);
+                v[i] = x & 0xfffu;
+        }
+        uint8_t *XR drow = a.dst + (long) y * a.dpitch;
+        if (OUT == UG_PF_RG48) {
+                uint2 *d = (uint2 *) (drow + 24 * (long) q);
+#pragma unroll
+                for (int k = 0; k < 3; k++) d[k] = make_uint2(v[4 * k] << 4 | v[4 * k + 1] << 20, v[4 * k + 2] << 4 | v[4 * k + 3] << 20);
+        } else if (OUT == UG_PF_RGB) {
+                uint32_t *d = (uint32_t *) (drow + 12 * (long) q);
+#pragma unroll
+                for (int k = 0; k < 3; k++) d[k] = v[4 * k] >> 4 | (v[4 * k + 1] >> 4) << 8 | (v[4 * k + 2] >> 4) << 16 | (v[4 * k + 3] >> 4) << 24;
+        } else if (OUT == UG_PF_UYVY) { // k_r12l_to_uyvy's arithmetic
+                uint32_t out[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                        const int r1 = v[6 * i] << 4, g1 = v[6 * i + 1] << 4, b1 = v[6 * i + 2] << 4, r2 = v[6 * i + 3] << 4, g2 = v[6 * i + 4] << 4, b2 = v[6 * i + 5] << 4;
+                        const int u = ((TO_CB(r1, g1, b1) + TO_CB(r2, g2, b2)) >> (kBase + 9)) + 128, vv = ((TO_CR(r1, g1, b1) + TO_CR(r2, g2, b2)) >> (kBase + 9)) + 128;
+                        const int y1 = (TO_Y(r1, g1, b1) >> (kBase + 8)) + 16, y2 = (TO_Y(r2, g2, b2) >> (kBase + 8)) + 16;
+                        out[i] = (uint32_t) (u & 0xff) | (uint32_t) (y1 & 0xff) << 8 | (uint32_t) (vv & 0xff) << 16 | (uint32_t) (y2 & 0xff) << 24;
+                }
+                *(uint2 *) (drow + 8 * (long) q) = make_uint2(out[0], out[1]);
+        } else { // R10k: k_r12l_to_r10k's bytes, the slip in the second pixel of every group of 8 included
+                uint32_t out[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                        const uint32_t r = v[3 * i], g = v[3 * i + 1], b = v[3 * i + 2];
+                        uint32_t last = b & 0xff;
+                        if (i == 1 && !(q & 1)) last = (b & 0xf0) | (r & 0xf);
+                        out[i] = r >> 4 | ((r & 0xC) << 4 | g >> 6) << 8 | ((g & 0x3C) << 2 | b >> 8) << 16 | last << 24;
+                }
+                *(uint4 *) (drow + 16 * (long) q) = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+}
+template <int OUT>
+void launch_r12l_quad(const XArgs &a, int ngroups, hipStream_t st)
+{
+        const int nquads = 2 * ngroups;
+        const dim3 block(64, 4, 1), grid((unsigned) ((nquads + 63) / 64), (unsigned) ((a.height + 3) / 4), 1);
+        hipLaunchKernelGGL((r12l_quad_kernel<OUT>), grid, block, 0, st, a, nquads);
+}
+
+// -> R12L: a wave converts 4 x 64 pixels (32 groups), leaves their 36-bit values in LDS and writes the 288 words they make: word j takes
+// its bits from pixel 8j/9 and the next one.
+template <int IN>
+__global__ __launch_bounds__(256) void to_r12l_px_kernel(const XArgs a, int npx)
+{
+        constexpr int kPx = 64 * kPxPerLane;
+        __shared__ unsigned long long vals[4][kPx + 2];
+        const int lane = threadIdx.x, p0 = blockIdx.x * kPx, y = blockIdx.y * 4 + threadIdx.y;
+        if (y >= a.height || p0 >= npx) return; // wave-uniform
+        const uint8_t *XR srow = a.src + (long) y * a.spitch;
+        uint8_t *XR drow = a.dst + (long) y * a.dpitch;
+        unsigned long long *v = vals[threadIdx.y];
+        // RGBA / Y416: lane + 64 u (4 / 8 bytes per lane and load); RGB / RG48: the lane takes 4 adjacent pixels = 12 / 24 contiguous bytes
+        constexpr bool kAdjacent = IN == UG_PF_RGB || IN == UG_PF_RG48;
+        uint32_t r[kPxPerLane], g[kPxPerLane], b[kPxPerLane];
+        if (kAdjacent) {
+                const int first = p0 + 4 * lane;
+                const bool in = first < npx; // npx is a multiple of 8: a lane's four pixels are inside or outside together
+                if (IN == UG_PF_RGB) {
+                        const uint32_t *s = (const uint32_t *) (srow + 3 * (long) (in ? first : 0));
+                        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+                        const uint32_t px[4] = { w0 & 0xffffff, w0 >> 24 | (w1 & 0xffff) << 8, w1 >> 16 | (w2 & 0xff) << 16, w2 >> 8 };
+#pragma unroll
+                        for (int u = 0; u < 4; u++) r[u] = (px[u] & 0xff) << 4, g[u] = (px[u] >> 8 & 0xff) << 4, b[u] = (px[u] >> 16) << 4;
+                } else {
+                        const uint2 *s = (const uint2 *) (srow + 6 * (long) (in ? first : 0));
+                        const uint2 q0 = s[0], q1 = s[1], q2 = s[2];
+                        const uint32_t w[6] = { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                                const int i = 3 * u; // 16-bit sample index
+                                r[u] = ((w[i / 2] >> (16 * (i % 2))) & 0xffff) >> 4;
+                                g[u] = ((w[(i + 1) / 2] >> (16 * ((i + 1) % 2))) & 0xffff) >> 4;
+                                b[u] = ((w[(i + 2) / 2] >> (16 * ((i + 2) % 2))) & 0xffff) >> 4;
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[4 * lane + u] = (unsigned long long) b[u] << 24 | (unsigned long long) g[u] << 12 | r[u];
+        } else {
+                uint32_t in0[kPxPerLane], in1[kPxPerLane];
+#pragma unroll
+                for (int u = 0; u < kPxPerLane; u++) { // all loads first
+                        const int p = p0 + 64 * u + lane, q = p < npx ? p : 0;
+                        in1[u] = 0;
+                        if (IN == UG_PF_RGBA) {
+                                in0[u] = ((const uint32_t *) srow)[q];
+                        } else { // Y416
+                                const uint2 w = ((const uint2 *) srow)[q];
+                                in0[u] = w.x, in1[u] = w.y;
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < kPxPerLane; u++) {
+                        if (IN == UG_PF_RGBA) {
+                                r[u] = (in0[u] & 0xff) << 4, g[u] = (in0[u] >> 8 & 0xff) << 4, b[u] = (in0[u] >> 16 & 0xff) << 4;
+                        } else {
+                                const int uu = (int) (in0[u] & 0xffff) - (1 << 15), ys = a.c[Y_SCALE] * ((int) (in0[u] >> 16) - (1 << 12)), vv = (int) (in1[u] & 0xffff) - (1 << 15);
+                                r[u] = clamp_full(TO_R(ys, uu, vv) >> (kBase + 4), 12);
+                                g[u] = clamp_full(TO_G(ys, uu, vv) >> (kBase + 4), 12);
+                                b[u] = clamp_full(TO_B(ys, uu, vv) >> (kBase + 4), 12);
+                        }
+                        v[64 * u + lane] = (unsigned long long) b[u] << 24 | (unsigned long long) g[u] << 12 | r[u];
+                }
+        }
+        if (lane < 2) v[kPx + lane] = 0;
+        __syncthreads(); // waves that left above are not waited for
+        const int nwords = (min(kPx, npx - p0) / 8) * 9;
+        uint32_t *d = (uint32_t *) drow + (p0 / 8) * 9;
+#pragma unroll
+        for (int j0 = 0; j0 < kPx / 8 * 9; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < nwords) {
+                        const int q = (8 * j) / 9, o = 32 * j - 36 * q; // 0 <= o <= 32
+                        const unsigned long long lo = v[q], hi = v[q + 1];
+                        d[j] = (uint32_t) (lo >> o) | (uint32_t) (hi << (36 - o) & 0xFFFFFFFFull);
+                }
+        }
+}
+template <int IN, int SB>
+void launch_to_r12l_px(const XArgs &a, int ngroups, hipStream_t st)
+{
+        const int npx = 8 * ngroups, per_wave = 64 * kPxPerLane;
+        const dim3 block(64, 4, 1), grid((unsigned) ((npx + per_wave - 1) / per_wave), (unsigned) ((a.height + 3) / 4), 1);
+        hipLaunchKernelGGL((to_r12l_px_kernel<IN>), grid, block, 0, st, a, npx);
+}
+
 using uyvy_to_rg48_body = k_yuv422_to_rgb_body<false, true>;
 using yuyv_to_rgb_body = k_yuv422_to_rgb_body<true, false>;
 enum Iter { I_PX, I_PAIR, I_G6, I_G8, I_COMP, I_DVS };
@@ -691,6 +887,7 @@ struct Vec { // the vector form of an entry: bytes in / out per iteration, itera
 // NOVEC: the one-iteration-per-lane kernel measured faster at 8K (fraction of 8 TB/s: it vs the vector form) -- 9-word R12L units
 // cost more in LDS and registers than the compiler-merged accesses of the plain kernel
 #define NOVEC { nullptr, 1, 1, 1 }
+#define PXVEC(launcher, SB, DB) { launcher, SB, DB, 1 } // the R12L pairs: one lane per pixel over the whole groups of a line
 struct Entry {
         int in, out;
         void (*kernel)(const XArgs);
@@ -706,18 +903,18 @@ const Entry kTable[] = {
         { UG_PF_R10K, UG_PF_Y416, k_r10k_to_y416, I_PX, 16, VEC(k_r10k_to_y416_body, 4, 8, 4) },
         { UG_PF_R10K, UG_PF_RGB, k_r10k_to_rgb, I_PX, 0, VEC(k_r10k_to_rgb_body, 4, 3, 16) },
         { UG_PF_R10K, UG_PF_UYVY, k_r10k_to_uyvy, I_PAIR, 8, VEC(k_r10k_to_uyvy_body, 8, 4, 4) },
-        { UG_PF_R12L, UG_PF_RGBA, k_r12l_to_rgba, I_G8, 0, VEC(k_r12l_to_rgba_body, 36, 32, 4) },
-        { UG_PF_R12L, UG_PF_RGB, k_r12l_to_rgb, I_G8, 0, NOVEC /* 0.67 vs 0.55 */ },
-        { UG_PF_R12L, UG_PF_RG48, k_r12l_to_rg48, I_G8, 0, VEC(k_r12l_to_rg48_body, 36, 48, 4) },
-        { UG_PF_R12L, UG_PF_R10K, k_r12l_to_r10k, I_G8, 0, NOVEC /* 0.66 vs 0.52 */ },
-        { UG_PF_R12L, UG_PF_Y416, k_r12l_to_y416, I_G8, 16, VEC(k_r12l_to_y416_body, 36, 64, 4) },
-        { UG_PF_R12L, UG_PF_UYVY, k_r12l_to_uyvy, I_G8, 8, NOVEC /* 0.58 vs 0.48 */ },
-        { UG_PF_RGBA, UG_PF_R12L, k_rgb_to_r12l<4>, I_G8, 0, VEC(k_rgb_to_r12l_body<4>, 32, 36, 4) },
-        { UG_PF_RGB, UG_PF_R12L, k_rgb_to_r12l<3>, I_G8, 0, NOVEC /* 0.55 vs 0.53 */ },
+        { UG_PF_R12L, UG_PF_RGBA, k_r12l_to_rgba, I_G8, 0, PXVEC((launch_r12l_px<UG_PF_RGBA, 32>), 36, 32) },
+        { UG_PF_R12L, UG_PF_RGB, k_r12l_to_rgb, I_G8, 0, PXVEC(launch_r12l_quad<UG_PF_RGB>, 36, 24) },
+        { UG_PF_R12L, UG_PF_RG48, k_r12l_to_rg48, I_G8, 0, PXVEC(launch_r12l_quad<UG_PF_RG48>, 36, 48) },
+        { UG_PF_R12L, UG_PF_R10K, k_r12l_to_r10k, I_G8, 0, PXVEC(launch_r12l_quad<UG_PF_R10K>, 36, 32) },
+        { UG_PF_R12L, UG_PF_Y416, k_r12l_to_y416, I_G8, 16, PXVEC((launch_r12l_px<UG_PF_Y416, 64>), 36, 64) },
+        { UG_PF_R12L, UG_PF_UYVY, k_r12l_to_uyvy, I_G8, 8, PXVEC(launch_r12l_quad<UG_PF_UYVY>, 36, 16) },
+        { UG_PF_RGBA, UG_PF_R12L, k_rgb_to_r12l<4>, I_G8, 0, PXVEC((launch_to_r12l_px<UG_PF_RGBA, 32>), 32, 36) },
+        { UG_PF_RGB, UG_PF_R12L, k_rgb_to_r12l<3>, I_G8, 0, PXVEC((launch_to_r12l_px<UG_PF_RGB, 24>), 24, 36) },
         { UG_PF_RGBA, UG_PF_RG48, k_rgba_to_rg48, I_PX, 0, VEC(k_rgba_to_rg48_body, 4, 6, 8) },
         { UG_PF_RGB, UG_PF_RG48, k_rgb_to_rg48, I_COMP, 0, VEC(k_rgb_to_rg48_body, 1, 2, 16) },
         { UG_PF_UYVY, UG_PF_RG48, k_yuv422_to_rgb<false, true>, I_PAIR, 8, VEC(uyvy_to_rg48_body, 4, 12, 4) },
-        { UG_PF_RG48, UG_PF_R12L, k_rg48_to_r12l, I_G8, 0, NOVEC /* 0.65 vs 0.42 */ },
+        { UG_PF_RG48, UG_PF_R12L, k_rg48_to_r12l, I_G8, 0, PXVEC((launch_to_r12l_px<UG_PF_RG48, 48>), 48, 36) },
         { UG_PF_RG48, UG_PF_R10K, k_rg48_to_r10k, I_PX, 0, VEC(k_rg48_to_r10k_body, 6, 4, 8) },
         { UG_PF_RG48, UG_PF_RGB, k_rg48_to_rgb, I_PX, 0, VEC(k_rg48_to_rgb_body, 6, 3, 16) },
         { UG_PF_RG48, UG_PF_RGBA, k_rg48_to_rgba, I_PX, 0, VEC(k_rg48_to_rgba_body, 6, 4, 8) },
@@ -737,7 +934,7 @@ const Entry kTable[] = {
         { UG_PF_Y216, UG_PF_V210, k_y216_to_v210, I_G6, 0, VEC(k_y216_to_v210_body, 24, 16, 2) },
         { UG_PF_Y416, UG_PF_UYVY, k_y416_to_uyvy, I_PAIR, 0, VEC(k_y416_to_uyvy_body, 16, 4, 4) },
         { UG_PF_Y416, UG_PF_V210, k_y416_to_v210, I_G6, 0, VEC(k_y416_to_v210_body, 48, 16, 1) },
-        { UG_PF_Y416, UG_PF_R12L, k_y416_to_r12l, I_G8, 16, VEC(k_y416_to_r12l_body, 64, 36, 4) },
+        { UG_PF_Y416, UG_PF_R12L, k_y416_to_r12l, I_G8, 16, PXVEC((launch_to_r12l_px<UG_PF_Y416, 64>), 64, 36) },
         { UG_PF_Y416, UG_PF_R10K, k_y416_to_rgb<1>, I_PX, 16, VEC(k_y416_to_rgb_body<1>, 8, 4, 4) },
         { UG_PF_Y416, UG_PF_RGB, k_y416_to_rgb<2>, I_PX, 16, VEC(k_y416_to_rgb_body<2>, 8, 3, 16) },
         { UG_PF_Y416, UG_PF_RGBA, k_y416_to_rgb<3>, I_PX, 16, VEC(k_y416_to_rgb_body<3>, 8, 4, 4) },
