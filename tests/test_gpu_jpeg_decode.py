@@ -132,3 +132,55 @@ def test_full_4k_frame_and_rejections(hip, po):
     cut = dec.decode(data[: len(data) // 2] + b"\xff\xd9", L.PF_UYVY).cpu().numpy()
     assert np.array_equal(cut[: w * 2 * 400], got[: w * 2 * 400])
     dec.close()
+
+
+def _damage(data: bytes, rng, kind: str) -> bytes:
+    """One kind of damage to the entropy-coded part of a stream (headers stay intact)."""
+    b = bytearray(data)
+    sos = data.index(b"\xff\xda")
+    start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+    end = len(b) - 2
+    rst = [i for i in range(start, end) if b[i] == 0xFF and 0xD0 <= b[i + 1] <= 0xD7]
+    if kind == "cut":                      # the tail is lost, EOI appended
+        at = int(rng.integers(start + 1, end))
+        return bytes(b[:at]) + b"\xff\xd9"
+    if kind == "cut_raw":                  # the tail is lost, nothing appended
+        return bytes(b[: int(rng.integers(start + 1, end))])
+    if kind == "drop_rst" and rst:         # a restart marker disappears: one segment fewer
+        i = rst[int(rng.integers(len(rst)))]
+        return bytes(b[:i] + b[i + 2:])
+    if kind == "extra_rst":                # a restart marker too many
+        i = int(rng.integers(start + 1, end))
+        return bytes(b[:i] + b"\xff\xd5" + b[i:])
+    if kind == "marker":                   # some other marker in the data
+        i = int(rng.integers(start + 1, end))
+        return bytes(b[:i] + b"\xff\xc4" + b[i:])
+    for _ in range(int(rng.integers(1, 6))):   # "bytes": substitutions, with the values that matter to the syntax among them
+        b[int(rng.integers(start, end))] = int(rng.choice([0x00, 0xFF, 0xD3, 0xC4, 0x5A, int(rng.integers(256))]))
+    return bytes(b)
+
+
+@pytest.mark.parametrize("kind", ["cut", "cut_raw", "drop_rst", "extra_rst", "marker", "bytes"])
+def test_damaged_streams_decode_like_the_oracle(hip, po, kind):
+    """Damage in the entropy-coded data never faults and gives the planes the sequential decoder gives: a segment ends at the first marker
+    (zero bits from there), segment k starts behind the k-th restart marker whatever else stands in between, missing segments are empty."""
+    from ultragrid_amd import lib as L
+    w, h = 208, 88
+    rgb = picture(w, h, seed=11, noise=3.0)
+    data = _own_stream(hip, po.convert_frame("RGB", "UYVY", rgb, w, h), L.PF_UYVY, w, h, 85, 3, 422)
+    rng = np.random.default_rng(hash(kind) % 1000)
+    dec = hip.JpegDecoder()
+    for trial in range(12):
+        bad = _damage(data, rng, kind)
+        try:
+            info, crop, _ = po.jpeg_decode_planes(bad)
+        except Exception:
+            continue                        # the oracle refuses the stream: nothing to compare
+        got = dec.planes(bad)
+        for c in range(3):
+            assert np.array_equal(got[c].cpu().numpy(), crop[c]), (kind, trial, c)
+    # and the decoder is still good afterwards
+    _, crop, _ = po.jpeg_decode_planes(data)
+    for c, pl in enumerate(dec.planes(data)):
+        assert np.array_equal(pl.cpu().numpy(), crop[c])
+    dec.close()

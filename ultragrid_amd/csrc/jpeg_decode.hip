@@ -141,6 +141,7 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                                 o += 17 + (size_t) n;
                         }
                 } else if (m == 0xDD) {
+                        if (seglen < 4) return -1;
                         h.ri = s[0] << 8 | s[1];
                 } else if (m == 0xEE && seglen >= 14 && memcmp(s, "Adobe", 5) == 0) {
                         h.adobe = s[11];
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
         __syncthreads();
         const int seg = seg0 + lane;
         const bool mine = lane < lanes && seg < n_seg;
-        const bool present = mine && seg < n_found; // a segment the stream does not have decodes to zero blocks
+        const bool present = mine && seg < n_found; // a segment the stream does not have is an empty one: zero bits, decoded like any others
         BitReader br;
         br.pos = present ? seg_start[seg] - stage_begin : 0;
         br.end = present ? seg_end[seg] - stage_begin : 0;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                 return sym;
         };
         int pred[3] = { 0, 0, 0 };
-        const int per_seg = sp.ri ? sp.ri : sp.units;
+        const int per_seg = sp.ri && sp.ri < sp.units ? sp.ri : sp.units;
         const int u0 = seg * per_seg;
         int16_t *const my = (int16_t *) (tile + lane * kTileWords);
         const int rounds = (lanes + 7) / 8;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                         for (int by = 0; by < sp.nbv[k]; by++) {
                                 for (int bx = 0; bx < sp.nbh[k]; bx++) {
                                         tile_dst[lane] = active ? (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx : -1;
-                                        if (active && present) {
+                                        if (active) {
                                                 int v;
                                                 symbol(luts[k], longs[k], v);
                                                 pred[k] += v;
