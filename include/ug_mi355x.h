@@ -375,7 +375,9 @@ int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, cons
  *                    directly, UG_PF_UYVY through vc_copylineRGBtoUYVY's arithmetic.
  * The component planes equal libjpeg's bit for bit (integer IDCT jidctint).  `jpeg_host` is host memory (compressed frames arrive from the
  * network); everything after the header parse is asynchronous on `stream`.  UG_PF_NONE: decode to the internal planes only
- * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout: UG_HIP_EUNSUPP. */
+ * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout: UG_HIP_EUNSUPP.  Damage inside the entropy-coded data is not
+ * an error: a segment ends at its first marker, a missing one decodes as an empty one (what a sequential decoder does).  A decoder object
+ * holds the work buffers of one frame in flight: one object per thread / per frame in flight. */
 typedef struct ug_hip_jpeg_decoder ug_hip_jpeg_decoder;
 int  ug_hip_jpeg_decoder_create(ug_hip_jpeg_decoder **out);
 void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec);

@@ -21,8 +21,10 @@ def main():
     ap.add_argument("--concurrent", type=int, default=4)
     ap.add_argument("--configs", type=int, default=6, help="only the first N stream configurations")
     ap.add_argument("--seconds", type=float, default=0.5)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
     a = ap.parse_args()
-    w, h = 3840, 2160
+    w, h = a.width, a.height
     src = torch.from_numpy(synth.s2_video("UYVY", w, h)).cuda()
     rgb = torch.from_numpy(synth.s1_random("RGB", w, h)).cuda()
     rows = []
@@ -51,7 +53,7 @@ def main():
         for _ in range(20):
             codec.jpeg_read_info(data)
         parse_ms = (time.perf_counter() - t1) / 20 * 1e3
-        rows.append({"stream": f"4K {sub} q75 restart {ri} ({len(data)} B)", "out": out, "ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "header_parse_ms": round(parse_ms, 4)})
+        rows.append({"stream": f"{w}x{h} {sub} q75 restart {ri} ({len(data)} B)", "out": out, "ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "header_parse_ms": round(parse_ms, 4)})
         print(f"{sub} ri={ri:<2d} -> {out:<4s}: {ms * 1e3:8.1f} us per frame ({1e3 / ms:7.1f} fps), {len(data)} B; header-only parse {parse_ms * 1e3:6.1f} us", flush=True)
         dec.close()
         if a.concurrent > 1 and (sub, ri, out) == (422, 4, "UYVY"):  # frames of a stream decoded side by side: one decoder + HIP stream each
@@ -71,7 +73,7 @@ def main():
                 n += 1
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / n * 1e3
-            rows.append({"stream": f"4K {sub} q75 restart {ri}, {a.concurrent} frames in flight", "out": out, "ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1)})
+            rows.append({"stream": f"{w}x{h} {sub} q75 restart {ri}, {a.concurrent} frames in flight", "out": out, "ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1)})
             print(f"    {a.concurrent} decoders on {a.concurrent} streams: {ms * 1e3:8.1f} us per frame ({1e3 / ms:7.1f} fps)", flush=True)
             for d_ in decs:
                 d_.close()
