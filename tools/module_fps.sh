@@ -17,3 +17,9 @@ for cfg in "dxt:DXT5:workers=1" "dxt:DXT5"; do
   echo "== $cfg  8K v210"; $H $cfg v210 7680 4320 /tmp/8k_v210.raw /tmp/o.bin 1 host 4 25 | grep THROUGHPUT
   echo "== $cfg  1080p RGB -> DXT5"; $H $cfg RGB 1920 1080 /tmp/1080_rgb.raw /tmp/o.bin 1 host 16 60 | grep THROUGHPUT
 done
+# receiver side: the reference's decompress framework around our modules, host frame in, host frame out
+D=oracle/_ref/ug_dec_harness
+$H "jpeg:q=75:restart=4" UYVY 3840 2160 /tmp/4k_uyvy.raw /tmp/4k.jpg 1 host 1 1 > /dev/null
+$H "dxt:DXT5" UYVY 3840 2160 /tmp/4k_uyvy.raw /tmp/4k.dxt5 1 host 1 1 > /dev/null
+for out in UYVY RGBA DXT1; do echo "== decompress JPEG -> $out 4K"; UG_DEC_REPEAT=300 $D JPEG $out 3840 2160 /tmp/4k.jpg /tmp/o.raw | grep THROUGHPUT; done
+for out in UYVY RGBA; do echo "== decompress DXT5 -> $out 4K"; UG_DEC_REPEAT=300 $D DXT5 $out 3840 2160 /tmp/4k.dxt5 /tmp/o.raw | grep THROUGHPUT; done

@@ -4,9 +4,11 @@
  * lib_common.cpp) drives our decompress module:
  *     decompress_init_multi(DXT5, {}, RGBA, &s, 1); decompress_reconfigure(s, desc, 0, 8, 16, pitch, RGBA);
  *     decompress_frame(s, dst, src, len, 0, NULL, NULL); decompress_done(s);
- * usage: ug_dec_harness <DXT1|DXT1_YUV|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch]
+ * usage: ug_dec_harness <DXT1|DXT1_YUV|DXT5|JPEG> <out codec> <w> <h> <in.bin> <out.raw> [pitch] [src_len]
  *        ug_dec_harness list
+ * UG_DEC_REPEAT=<n>: the frame is decompressed n more times and the rate printed (THROUGHPUT ...), host frame in, host frame out.
  */
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -72,6 +74,17 @@ int main(int argc, char **argv)
         fwrite(dst, 1, out_bytes, f);
         fclose(f);
         printf("OK %s -> %s %ux%u pitch=%d\n", argv[1], argv[2], w, h, pitch);
+        const int repeat = getenv("UG_DEC_REPEAT") ? atoi(getenv("UG_DEC_REPEAT")) : 0;
+        if (repeat > 0) {
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                for (int i = 0; i < repeat; i++) {
+                        if (decompress_frame(s, dst, src, src_len, i + 1, NULL, NULL) != DECODER_GOT_FRAME) return 3;
+                }
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                const double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+                printf("THROUGHPUT frames=%d wall_s=%.4f fps=%.1f\n", repeat, sec, repeat / sec);
+        }
         decompress_done(s);
         return 0;
 }
