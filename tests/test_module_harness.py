@@ -625,3 +625,25 @@ def test_jpeg_to_dxt_transcoder(tmp_path, po, codec, cfg, out):
     # and it is a picture: decoded again (flipped back) it is close to what went in
     back = po.dxt_decode(po.OUT_DXT1 if out == "DXT1" else po.OUT_DXT5YCOCG, "RGB", got, w, h).reshape(h, w, 3)[::-1]
     assert 10 * np.log10(255.0 ** 2 / np.mean((back.astype(float) - rgb.astype(float)) ** 2)) > 28
+
+
+REF_UNIT_TEST = os.path.join(ROOT, "oracle", "_ref", "ug_ref_unit_test")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_UNIT_TEST), reason="oracle/_ref/ug_ref_unit_test not built")
+@pytest.mark.gpu
+def test_the_reference_s_own_gpujpeg_unit_test_passes():
+    """test/gpujpeg_test.cpp of the reference, compiled unmodified from the reference tree and linked with the reference's compress and
+    decompress frameworks, run against this repository's modules under the names it asks for (`GPUJPEG:check`, `GPUJPEG`,
+    `--param decompress=gpujpeg`): compress a 1920x1080 RGB frame, decompress it to RGB, every byte within 1 of the input."""
+    r = subprocess.run([REF_UNIT_TEST], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "gpujpeg_test_simple: PASSED" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REF_UNIT_TEST), reason="oracle/_ref/ug_ref_unit_test not built")
+def test_the_reference_unit_test_skips_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([REF_UNIT_TEST], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 77 and "SKIPPED" in r.stdout, r.stdout + r.stderr

@@ -114,6 +114,12 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                         usage();
                         delete s;
                         return INIT_NOERR;
+                } else if (tok == "check" || tok == "list_devices") { // gpujpeg.cpp:530-542: is there a device to run on / which ones
+                        int count = 0;
+                        const bool ok = ug_hip_device_count(&count) == UG_HIP_SUCCESS && count > 0;
+                        if (tok == "list_devices") printf("HIP devices: %d\n", ok ? count : 0);
+                        delete s;
+                        return ok ? INIT_NOERR : nullptr;
                 } else if (!tok.empty()) {
                         MSG(ERROR, "unknown option: %s\n", tok.c_str());
                         usage();
@@ -317,8 +323,11 @@ const struct video_compress_info jpeg_mi355x_info = {
 // configure.ac:2673) the two registrations would collide in lib_common's registry and "-c jpeg" would resolve to whichever
 // constructor ran first, so the alias is taken only when GPUJPEG is absent -- then "-c jpeg" is this module, as a drop-in.
 REGISTER_MODULE(jpeg_mi355x, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+// The same goes for the module's own name: without GPUJPEG in the build, "-c GPUJPEG[:<options>]" -- what users and the reference's own
+// unit test (test/gpujpeg_test.cpp:57-62) ask for -- is this module.
 #ifndef HAVE_GPUJPEG
 REGISTER_HIDDEN_MODULE(jpeg, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
+REGISTER_HIDDEN_MODULE(gpujpeg, &jpeg_mi355x_info, LIBRARY_CLASS_VIDEO_COMPRESS, VIDEO_COMPRESS_ABI_VERSION);
 #endif
 
 } // end of anonymous namespace

@@ -180,3 +180,8 @@ static const struct video_decompress_info jpeg_mi355x_dec_info = {
 };
 
 REGISTER_MODULE(jpeg_mi355x, &jpeg_mi355x_dec_info, LIBRARY_CLASS_VIDEO_DECOMPRESS, VIDEO_DECOMPRESS_ABI_VERSION);
+// In a build without GPUJPEG (config.h: HAVE_GPUJPEG undefined) the module also answers to the name of the one it stands in for
+// (gpujpeg.c:378), so that `--param decompress=gpujpeg` -- what the reference's unit test sets, test/gpujpeg_test.cpp:64 -- finds it.
+#ifndef HAVE_GPUJPEG
+REGISTER_MODULE(gpujpeg, &jpeg_mi355x_dec_info, LIBRARY_CLASS_VIDEO_DECOMPRESS, VIDEO_DECOMPRESS_ABI_VERSION);
+#endif
