@@ -125,3 +125,35 @@ def test_from_lavc_hook_with_a_display_pitch_touches_only_the_lines(hip):
     assert np.array_equal(lines, want.reshape(h_, ls))
     gaps = np.stack([dst[y * pitch + ls: (y + 1) * pitch] for y in range(h_ - 1)])
     assert (gaps == 0xA5).all()
+
+
+REF_LAVC_TEST = os.path.join(T.HERE, "..", "oracle", "_ref", "ug_ref_lavc_test")
+REF_LAVC_NAMES = ["yuv444pXXle_from_to_r10k", "yuv444pXXle_from_to_r12l", "yuv444p16le_from_to_rg48", "yuv444p16le_from_to_rg48_out_of_range", "pX10_from_to_v210"]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_LAVC_TEST + "_cpu"), reason="oracle/_ref/ug_ref_lavc_test_cpu not built")
+def test_reference_lavc_unit_tests_on_the_cpu_build():
+    """Control: the reference's own test/ff_codec_conversions_test.cpp (compiled unmodified over the FFmpeg stand-in) passes on the reference's
+    own CPU converters -- so the stand-in and the way the file is built do not bend it."""
+    import subprocess
+    r = subprocess.run([REF_LAVC_TEST + "_cpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for n in REF_LAVC_NAMES:
+        assert f"ff_codec_conversions_test_{n}: PASSED" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(REF_LAVC_TEST), reason="oracle/_ref/ug_ref_lavc_test not built")
+@pytest.mark.gpu
+def test_reference_lavc_unit_tests_through_the_gpu_hook():
+    """The same five reference tests against the hook build: to_lavc_vid_conv() / av_to_uv_convert() of the reference with this repository's
+    hook functions behind them, i.e. the R10k / R12L / RG48 / v210 <-> planar round trips of those tests run on the MI355X."""
+    import subprocess
+    r = subprocess.run([REF_LAVC_TEST, "hook"], capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    for n in REF_LAVC_NAMES:
+        assert f"ff_codec_conversions_test_{n}: PASSED" in r.stdout
+    # the reference's own message every time the hook has taken a conversion (to_lavc_vid_conv.c:1901-1906): all 22 to_lavc_vid_conv_init calls of
+    # the five tests.  The way back stays on the CPU there: the reference offers its from_lavc hook AV_PIX_FMT_YUV422P only
+    # (from_lavc_vid_conv_cuda.h:58-60), which these tests do not use -- that direction is covered by the tests above.
+    assert out.count("[to_lavc_vid_conv] Using CUDA FFmpeg conversions") == 22 and "hook enabled" in out
