@@ -105,14 +105,23 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
     so that at N > 1 the host-side limit (PCIe root complexes, DRAM bandwidth, NUMA) shows up instead of a trivially linear kernel
     curve (scheme: gpujpeg.cpp:446-466,643-722)."""
     from ultragrid_amd import pipeline
-    node = pipeline.gpu_numa_node(torch.cuda.current_device())
-    bound = pipeline.bind_to_numa_node(node)
+    affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    try:
+        node = pipeline.gpu_numa_node(torch.cuda.current_device())
+        bound = pipeline.bind_to_numa_node(node)
+    except (OSError, ValueError):
+        node, bound = -1, 0
     res = {}
     for wl in workloads:
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank)
+        try:
+            r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank)
+        except Exception as e:   # a rank that cannot run its leg reports 0 fps; the collectives below still see every rank
+            print(f"bench.py: e2e leg {wl} failed on rank {rank}: {e}", file=sys.stderr, flush=True)
+            _, _, oid, w_, h_ = pipeline.WORKLOADS[wl]
+            r = {"fps": 0.0, "pcie_gbs": 0.0, "in_flight": 3, "bytes_in_per_frame": 0, "bytes_out_per_frame": 0, "seconds": 0.0}
         from ultragrid_amd import shard
         rates = shard.gather_rates([r["fps"], r["pcie_gbs"]], dist, device_for_gather)
         per = [round(x[0], 1) for x in rates]
@@ -124,6 +133,8 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
     res["path"] = "pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU on 3 streams, all ranks concurrently"
     res["numa_node_rank0"] = node
     res["cpus_bound_rank0"] = bound
+    if affinity is not None and bound:
+        os.sched_setaffinity(0, affinity)   # the CPU baseline that follows is not meant to run on one NUMA node only
     return res
 
 
