@@ -10,7 +10,10 @@
 //   GPU 3  planes -> the output codec with the pixel-format kernels the library already has (planar 4:2:2 / 4:2:0 -> UYVY as
 //          from_planar.c does it, UYVY -> RGB / RGBA with pixfmt_conv.c's arithmetic), R,G,B planes packed directly.
 // Bit-identical to oracle/jpeg_decode_oracle.c, which is pinned to libjpeg-turbo (tests/test_oracle_jpeg_decode.py).
+#include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include <vector>
 
@@ -18,7 +21,8 @@
 
 namespace {
 
-constexpr int kLutBits = 10;
+constexpr int kLutBits = 10;  // AC tables: codes up to 10 bits are one look-up
+constexpr int kDcLutBits = 9; // DC tables (the standard ones have nothing longer than 9 / 11 bits)
 
 struct HuffHost {
         uint8_t bits[17] = {};
@@ -39,7 +43,7 @@ struct LongCodes {
         uint8_t vals[256];
 };
 
-void build_dev(const HuffHost &h, HuffDev &d)
+void build_dev(const HuffHost &h, HuffDev &d, int lut_bits)
 {
         memset(&d, 0, sizeof d);
         if (!h.present) return;
@@ -49,9 +53,9 @@ void build_dev(const HuffHost &h, HuffDev &d)
         for (int l = 1; l <= 16; l++) {
                 d.offset[l] = (int16_t) (k - code);
                 for (int i = 0; i < h.bits[l]; i++, k++, code++) {
-                        if (l <= kLutBits) {
-                                const int lo = code << (kLutBits - l);
-                                for (int f = 0; f < (1 << (kLutBits - l)); f++) d.lut[lo + f] = (uint16_t) (l << 8 | h.vals[k]);
+                        if (l <= lut_bits) {
+                                const int lo = code << (lut_bits - l);
+                                for (int f = 0; f < (1 << (lut_bits - l)); f++) d.lut[lo + f] = (uint16_t) (l << 8 | h.vals[k]);
                         }
                 }
                 if (h.bits[l]) limit = (uint32_t) code << (16 - l);
@@ -335,6 +339,8 @@ struct ScanDev {
         int single, bw1, mcu_w, ri;
         int units;
         int16_t *coef[3];
+        int n_dc, n_ac, dc_tab[3], ac_tab[3]; // the distinct tables of the scan ...
+        int dc_slot[3], ac_slot[3];           // ... and which of them each component uses
 };
 
 // The bytes of one segment in the workgroup's LDS copy of the clean stream.  Every symbol: if 32 bits or fewer are left, the window takes
@@ -347,6 +353,11 @@ struct BitReader {
         int cnt;
 };
 
+// offset of the tiles in the kernel's LDS, = what the tables in front of them take
+__host__ __device__ constexpr int lds_tile_offset(int n_dc, int n_ac)
+{
+        return (n_dc * (2 << kDcLutBits) + n_ac * (2 << kLutBits) + (n_dc + n_ac) * (int) sizeof(LongCodes) + 15) & ~15;
+}
 constexpr size_t kMaxStage = 40 * 1024; // with the tables and tiles: under the 64 KiB a kernel gets without asking
 constexpr int kTileWords = 36; // 32 words of coefficients, padded: 16-byte aligned rows that start in different LDS banks
 
@@ -363,11 +374,15 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                                                          int n_seg, const int *__restrict__ found, int lanes, int stage_bytes, ScanDev sp,
                                                          const HuffDev *__restrict__ tabs /* [0..3] DC, [4..7] AC */)
 {
-        extern __shared__ __attribute__((aligned(16))) uint8_t stage[]; // stage_bytes + 16
-        __shared__ uint16_t luts[6][1 << kLutBits]; // the scan's DC tables then its AC tables
-        __shared__ LongCodes longs[6];
-        __shared__ __attribute__((aligned(16))) uint32_t tile[64 * kTileWords];
+        // LDS, all of it sized at launch (lds_bytes() below): the scan's distinct DC look-ups (512 entries each), AC look-ups (1024 each),
+        // their long-code tables, one tile per lane in use, the staged stretch of the stream
+        extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
         __shared__ int tile_dst[64]; // where the lane's tile goes (in blocks), -1: nowhere
+        uint16_t *const lut_dc = (uint16_t *) lds;
+        uint16_t *const lut_ac = lut_dc + sp.n_dc * (1 << kDcLutBits);
+        LongCodes *const longs = (LongCodes *) (lut_ac + sp.n_ac * (1 << kLutBits)); // DC tables first
+        uint32_t *const tile = (uint32_t *) (lds + lds_tile_offset(sp.n_dc, sp.n_ac));
+        uint8_t *const stage = (uint8_t *) (tile + lanes * kTileWords);
         const int lane = threadIdx.x;
         const int seg0 = blockIdx.x * lanes;
         const int n_found = min(n_seg, found[0]);
@@ -380,22 +395,23 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                 staged = min((stretch + 15u) & ~15u, (uint32_t) stage_bytes);
                 for (uint32_t o = lane * 16; o < staged; o += 64 * 16) *(uint4 *) (stage + o) = *(const uint4 *) (clean + stage_begin + o);
         }
-        for (int k = 0; k < sp.ns; k++) {
-                for (int half = 0; half < 2; half++) {
-                        const HuffDev &t = tabs[half ? 4 + sp.ta[k] : sp.td[k]];
-                        const uint4 *src = (const uint4 *) t.lut;
-                        uint4 *dst = (uint4 *) luts[3 * half + k];
-                        for (int i = lane; i < (int) (sizeof t.lut / 16); i += 64) dst[i] = src[i];
-                        LongCodes &lc = longs[3 * half + k];
-                        for (int i = lane; i < 256; i += 64) lc.vals[i] = t.vals[i];
-                        if (lane < 17) {
-                                lc.limit[lane] = t.limit[lane];
-                                lc.offset[lane] = t.offset[lane];
-                        }
+        for (int j = 0; j < sp.n_dc + sp.n_ac; j++) {
+                const bool dc = j < sp.n_dc;
+                const HuffDev &t = tabs[dc ? sp.dc_tab[j] : 4 + sp.ac_tab[j - sp.n_dc]];
+                const uint4 *src = (const uint4 *) t.lut;
+                uint4 *dst = (uint4 *) (dc ? lut_dc + j * (1 << kDcLutBits) : lut_ac + (j - sp.n_dc) * (1 << kLutBits));
+                for (int i = lane; i < (dc ? (2 << kDcLutBits) : (2 << kLutBits)) / 16; i += 64) dst[i] = src[i];
+                LongCodes &lc = longs[j];
+                for (int i = lane; i < 256; i += 64) lc.vals[i] = t.vals[i];
+                if (lane < 17) {
+                        lc.limit[lane] = t.limit[lane];
+                        lc.offset[lane] = t.offset[lane];
                 }
         }
+        if (lane < lanes) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) *(uint4 *) (tile + lane * kTileWords + 4 * j) = make_uint4(0, 0, 0, 0);
+                for (int j = 0; j < 8; j++) *(uint4 *) (tile + lane * kTileWords + 4 * j) = make_uint4(0, 0, 0, 0);
+        }
         __syncthreads();
         const int seg = seg0 + lane;
         const bool mine = lane < lanes && seg < n_seg;
@@ -422,7 +438,8 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
         fetch(br.pos);
         // one Huffman symbol and the `symbol & 15` extra bits behind it (F.2.2.1, sign extension of Figure F.12): code (<= 16 bits) + extra bits
         // (<= 15) always fit in the top 32 bits of the window after the top-up
-        auto symbol = [&](const uint16_t *lut, const LongCodes &lc, int &value) -> int {
+        auto symbol = [&](auto bits_c, const uint16_t *lut, const LongCodes &lc, int &value) -> int {
+                constexpr int kBits = decltype(bits_c)::value;
                 {
                         const bool need = br.cnt <= 32;
                         uint32_t w = __builtin_amdgcn_alignbyte(br.nxt_hi, br.nxt_lo, br.pos);
@@ -437,15 +454,15 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                         fetch(br.pos);
                 }
                 const uint32_t hi = (uint32_t) (br.acc >> 32);
-                const unsigned e = lut[hi >> (32 - kLutBits)];
+                const unsigned e = lut[hi >> (32 - kBits)];
                 int l = (int) (e >> 8), sym = (int) (e & 0xff);
                 if (__builtin_expect(e == 0, 0)) {
                         // a code longer than the look-up covers: codes of length n fill [.., limit[n]) of the 16-bit prefixes, limits ascending
                         // (F.2.2.3's MAXCODE walk without the loop)
                         const unsigned pk = hi >> 16;
-                        l = kLutBits + 1;
+                        l = kBits + 1;
 #pragma unroll
-                        for (int n = kLutBits + 1; n <= 16; n++) l += pk >= lc.limit[n];
+                        for (int n = kBits + 1; n <= 16; n++) l += pk >= lc.limit[n];
                         if (l > 16) { // corrupt data: consume the bits, decode nothing
                                 l = 16;
                                 sym = 0;
@@ -475,12 +492,14 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                                 for (int bx = 0; bx < sp.nbh[k]; bx++) {
                                         tile_dst[lane] = active ? (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx : -1;
                                         if (active) {
+                                                const uint16_t *const ac_lut = lut_ac + sp.ac_slot[k] * (1 << kLutBits);
+                                                const LongCodes &ac_long = longs[sp.n_dc + sp.ac_slot[k]];
                                                 int v;
-                                                symbol(luts[k], longs[k], v);
+                                                symbol(std::integral_constant<int, kDcLutBits>(), lut_dc + sp.dc_slot[k] * (1 << kDcLutBits), longs[sp.dc_slot[k]], v);
                                                 pred[k] += v;
                                                 my[0] = (int16_t) pred[k];
                                                 for (int z = 1; z < 64; z++) {
-                                                        const int rs = symbol(luts[3 + k], longs[3 + k], v);
+                                                        const int rs = symbol(std::integral_constant<int, kLutBits>(), ac_lut, ac_long, v);
                                                         if ((rs & 15) == 0 && rs != 0xF0) break; // EOB
                                                         z += rs >> 4;
                                                         my[(rs & 15) && z < 64 ? z : 64] = (int16_t) v; // slot 64 is the tile's padding
@@ -490,11 +509,13 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                                         // 8 lanes per tile, 16 bytes each: 8 tiles per round
                                         for (int round = 0; round < rounds; round++) {
                                                 const int t = round * 8 + (lane >> 3), part = lane & 7;
-                                                const int dst = tile_dst[t];
-                                                uint4 *src = (uint4 *) (tile + t * kTileWords + part * 4);
-                                                const uint4 q = *src;
-                                                *src = make_uint4(0, 0, 0, 0);
-                                                if (dst >= 0) *(uint4 *) (sp.coef[k] + (size_t) dst * 64 + part * 8) = q;
+                                                if (t < lanes) {
+                                                        const int dst = tile_dst[t];
+                                                        uint4 *src = (uint4 *) (tile + t * kTileWords + part * 4);
+                                                        const uint4 q = *src;
+                                                        *src = make_uint4(0, 0, 0, 0);
+                                                        if (dst >= 0) *(uint4 *) (sp.coef[k] + (size_t) dst * 64 + part * 8) = q;
+                                                }
                                         }
                                         __syncthreads();
                                 }
@@ -771,6 +792,15 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
                         sp.nbh[k] = sp.single ? 1 : h.hs[c];
                         sp.nbv[k] = sp.single ? 1 : h.vs[c];
                         sp.gw[k] = (int) gw[c];
+                        // the distinct tables of the scan (usually two of each: luma, chroma)
+                        int j = 0;
+                        while (j < sp.n_dc && sp.dc_tab[j] != sc.td[k]) j++;
+                        if (j == sp.n_dc) sp.dc_tab[sp.n_dc++] = sc.td[k];
+                        sp.dc_slot[k] = j;
+                        j = 0;
+                        while (j < sp.n_ac && sp.ac_tab[j] != sc.ta[k]) j++;
+                        if (j == sp.n_ac) sp.ac_tab[sp.n_ac++] = sc.ta[k];
+                        sp.ac_slot[k] = j;
                 }
                 if (sp.single) { // a non-interleaved scan walks the component's own block grid, ceil(size / 8) blocks (T.81 A.2.2)
                         const int c = sc.comp[0];
@@ -806,8 +836,8 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
                 }
                 HuffDev *tabs_h = (HuffDev *) d->pinned;
                 for (int t = 0; t < 4; t++) {
-                        build_dev(h.dc[t], tabs_h[t]);
-                        build_dev(h.ac[t], tabs_h[4 + t]);
+                        build_dev(h.dc[t], tabs_h[t], kDcLutBits);
+                        build_dev(h.ac[t], tabs_h[4 + t], kLutBits);
                 }
                 uint16_t *qt_h = (uint16_t *) (tabs_h + 8);
                 memcpy(qt_h, h.qt, sizeof h.qt);
@@ -837,14 +867,23 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
                                    n_seg);
                 hipLaunchKernelGGL(clean_place_kernel, dim3(grid), dim3(kScanWG), 0, st, d->stream, base, sc.data_begin, sc.data_end, d->scan_counts + 2, d->clean,
                                    d->seg_start, d->seg_end, n_seg, d->scan_counts);
-                // lanes per workgroup: as few as keep every workgroup resident at once (LDS allows ~5 per CU); the stretch of the stream a workgroup
-                // stages in LDS is sized for twice the average segment
-                int lanes = 8;
-                while (lanes < 64 && (n_seg + lanes - 1) / lanes > 1280) lanes *= 2;
+                // Lanes per workgroup: a wave executes the same instructions whatever the number of its lanes in use, so the fewest waves that
+                // still give every SIMD one is the fastest launch -- measured at 4K (8 100 segments): whole frame with 16 / 8 / 4 / 2 / 1 lanes per wave
+                // 149 / 150 / 164 / 218 / 291 us (this kernel: 62 us at 8 lanes = 1 013 waves, 76 us at 4 = two waves per SIMD); more than 64 lanes' worth of segments per
+                // SIMD (8K and up) simply fills the waves.  The stretch of the stream a workgroup stages is sized for twice the average segment.
+                // UG_JPEG_DEC_LANES=<n> overrides (experiments).
                 const size_t avg = (sc.data_end - sc.data_begin) / (size_t) n_seg + 1;
-                size_t stage = (2 * avg * (size_t) lanes + 256 + 255) & ~(size_t) 255;
-                stage = stage < 2048 ? 2048 : (stage > kMaxStage ? kMaxStage : stage);
-                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + lanes - 1) / lanes)), dim3(64), stage + 16, st, d->clean, d->seg_start, d->seg_end, n_seg,
+                auto stage_for = [&](int lanes) {
+                        size_t stage = (2 * avg * (size_t) lanes + 256 + 255) & ~(size_t) 255;
+                        return stage < 512 ? (size_t) 512 : (stage > kMaxStage ? kMaxStage : stage);
+                };
+                auto lds_for = [&](int lanes) { return (size_t) lds_tile_offset(sp.n_dc, sp.n_ac) + (size_t) lanes * kTileWords * 4 + stage_for(lanes) + 16; };
+                int lanes = 8;
+                while (lanes < 64 && (n_seg + lanes - 1) / lanes > 1024) lanes *= 2;
+                static const int forced_lanes = getenv("UG_JPEG_DEC_LANES") ? atoi(getenv("UG_JPEG_DEC_LANES")) : 0;
+                if (forced_lanes >= 1 && forced_lanes <= 64) lanes = forced_lanes;
+                const size_t stage = stage_for(lanes);
+                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + lanes - 1) / lanes)), dim3(64), lds_for(lanes), st, d->clean, d->seg_start, d->seg_end, n_seg,
                                    d->scan_counts, lanes, (int) stage, sp, d->tabs);
         }
         // ---- dequantisation + IDCT ----
