@@ -1,0 +1,50 @@
+"""CPU: the host half of the JPEG decoder (ug_hip_jpeg_read_info: marker syntax, table and frame headers -- the code that meets bytes from the
+network first) under damage: mutated, spliced and truncated headers, each placed so that its last byte is the last byte before an
+inaccessible page -- an over-read of a single byte is a fault.  Any return code is fine, a crash is not."""
+import ctypes as C
+import io
+import mmap
+
+import numpy as np
+from PIL import Image
+
+
+def test_header_parser_never_reads_past_the_stream():
+    from ultragrid_amd import lib as L
+    lib = L.load()
+    libc = C.CDLL(None, use_errno=True)
+    page, npages = mmap.PAGESIZE, 8
+    m = mmap.mmap(-1, (npages + 1) * page)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert libc.mprotect(C.c_void_p(base + npages * page), C.c_size_t(page), 0) == 0
+    rng = np.random.default_rng(20260924)
+    img = (rng.random((48, 64, 3)) * 255).astype(np.uint8)
+    seeds = []
+    for kw in (dict(quality=80, subsampling=1), dict(quality=90, subsampling=2, restart_marker_blocks=2), dict(quality=70, subsampling=0, optimize=True)):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", **kw)
+        seeds.append(b.getvalue())
+    w, h, s, r, ri = (C.c_int() for _ in range(5))
+    accepted = 0
+    for it in range(6000):
+        d = bytearray(seeds[it % 3])
+        hdr_end = d.index(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 6))):
+            mode, pos = int(rng.integers(4)), int(rng.integers(2, hdr_end))
+            if mode == 0:
+                d[pos] = int(rng.integers(256))
+            elif mode == 1:
+                d[pos] = [0, 0xFF, 0x7F, 0x80, 1][int(rng.integers(5))]
+            elif mode == 2:
+                del d[pos:pos + int(rng.integers(1, 8))]
+            else:
+                d[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8))
+        if rng.random() < 0.5:
+            d = d[: int(rng.integers(2, min(len(d), hdr_end + 40)))]
+        n = len(d)
+        off = npages * page - n
+        m[off:off + n] = bytes(d)
+        rc = lib.ug_hip_jpeg_read_info(C.c_void_p(base + off), n, C.byref(w), C.byref(h), C.byref(s), C.byref(r), C.byref(ri))
+        accepted += rc == 0
+    assert 0 < accepted < 6000          # some mutations are harmless, most are refused
+    del w, h, s, r, ri
