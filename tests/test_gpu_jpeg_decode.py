@@ -184,3 +184,31 @@ def test_damaged_streams_decode_like_the_oracle(hip, po, kind):
     for c, pl in enumerate(dec.planes(data)):
         assert np.array_equal(pl.cpu().numpy(), crop[c])
     dec.close()
+
+
+def test_mutated_headers_never_fault(hip, po):
+    """Headers damaged at random (tables, frame and scan parameters, restart interval, lengths): every stream is either refused or decoded to
+    something, the process survives, and the decoder still decodes a good stream correctly afterwards."""
+    from ultragrid_amd import lib as L
+    w, h = 208, 88
+    rgb = picture(w, h, seed=5, noise=3.0)
+    data = _own_stream(hip, po.convert_frame("RGB", "UYVY", rgb, w, h), L.PF_UYVY, w, h, 85, 3, 422)
+    sos = data.index(b"\xff\xda")
+    hdr_end = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+    rng = np.random.default_rng(77)
+    dec = hip.JpegDecoder()
+    decoded = refused = 0
+    for _ in range(400):
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(2, hdr_end))] = int(rng.choice([0, 1, 2, 3, 0x11, 0x21, 0x22, 0x7F, 0xFF, int(rng.integers(256))]))
+        try:
+            dec.planes(bytes(b))
+            decoded += 1
+        except L.UgHipError:
+            refused += 1
+    assert decoded > 0 and refused > 0
+    _, crop, _ = po.jpeg_decode_planes(data)
+    for c, pl in enumerate(dec.planes(data)):
+        assert np.array_equal(pl.cpu().numpy(), crop[c])
+    dec.close()

@@ -48,3 +48,22 @@ def test_header_parser_never_reads_past_the_stream():
         accepted += rc == 0
     assert 0 < accepted < 6000          # some mutations are harmless, most are refused
     del w, h, s, r, ri
+
+
+def test_over_subscribed_huffman_table_is_refused():
+    """A DHT segment that declares more codes of a length than exist (here 200 codes of 1 bit) must be refused by the header parse: the
+    decoder's look-up tables are filled by code value."""
+    from ultragrid_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    b = io.BytesIO()
+    Image.fromarray((rng.random((16, 16, 3)) * 255).astype(np.uint8)).save(b, "JPEG", quality=80)
+    d = bytearray(b.getvalue())
+    at = d.index(b"\xff\xc4")                 # first DHT: marker, length, Tc/Th, 16 counts
+    assert lib.ug_hip_jpeg_read_info(bytes(d), len(d), None, None, None, None, None) == 0
+    d[at + 5] = 200                           # count of 1-bit codes
+    assert lib.ug_hip_jpeg_read_info(bytes(d), len(d), None, None, None, None, None) != 0
+    d = bytearray(b.getvalue())
+    sof = d.index(b"\xff\xc0")
+    d[sof + 5:sof + 7] = (40000).to_bytes(2, "big")   # a height no video frame has
+    assert lib.ug_hip_jpeg_read_info(bytes(d), len(d), None, None, None, None, None) != 0

@@ -117,6 +117,7 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                         h.width = s[3] << 8 | s[4];
                         h.ncomp = s[5];
                         if ((h.ncomp != 1 && h.ncomp != 3) || seglen < (size_t) 8 + 3 * h.ncomp || !h.width || !h.height) return -1;
+                        if (h.width > 16384 || h.height > 16384) return -1; // twice 8K: nothing UltraGrid carries; bounds the work buffers a header can ask for
                         for (int c = 0; c < h.ncomp; c++) {
                                 h.cid[c] = s[6 + 3 * c];
                                 h.hs[c] = s[7 + 3 * c] >> 4;
@@ -135,9 +136,14 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                                 const int tc = s[o] >> 4, th = s[o] & 15;
                                 if (th > 3 || tc > 1) return -1;
                                 HuffHost &t = tc ? h.ac[th] : h.dc[th];
-                                int n = 0;
+                                int n = 0, code = 0;
                                 t.bits[0] = 0;
-                                for (int l = 1; l <= 16; l++) n += (t.bits[l] = s[o + l]);
+                                for (int l = 1; l <= 16; l++) {
+                                        n += (t.bits[l] = s[o + l]);
+                                        code += t.bits[l];
+                                        if (code > (1 << l)) return -1; // more codes of this length than there are (C.2): the look-ups are sized by this
+                                        code <<= 1;
+                                }
                                 if (n > 256 || o + 17 + n > seglen - 2) return -1;
                                 memset(t.vals, 0, sizeof t.vals);
                                 memcpy(t.vals, s + o + 17, (size_t) n);
