@@ -298,7 +298,7 @@ int ug_hip_av_to_uv(const char *av_pixfmt, const char *uv_codec, void *dst_dev, 
                     ug_hip_stream_t stream);
 int ug_hip_uv_to_av_supported(const char *uv_codec, const char *av_pixfmt); /* 1 / 0 */
 int ug_hip_av_to_uv_supported(const char *av_pixfmt, const char *uv_codec);
-/* get_color_coeffs(cs, depth) (color_space.c:149-184): cs 1 = BT.601, 2 = BT.709; depth 0 (full range), 8, 10, 12, 16; out = the 14 fields
+/* get_color_coeffs(cs, depth) (color_space.c:149-184): cs 0 = CS_DFL (= BT.709, the reference's default), 1 = BT.601, 2 = BT.709; depth 0 (full range), 8, 10, 12, 16; out = the 14 fields
  * of struct color_coeffs in declaration order */
 int ug_hip_color_coeffs(int cs, int depth, int out[14]);
 /* compute_color_coeffs(kr, kb, depth) (color_space.c:193-197): the same 14 fields for arbitrary luma weights (host arithmetic in doubles) */

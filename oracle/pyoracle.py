@@ -44,7 +44,8 @@ def build(force: bool = False) -> None:
     if os.path.isdir("/root/reference/src") and (force or not have_ref() or not os.path.exists(os.path.join(_HERE, "_ref", "glsl_ref"))
                                                  or not os.path.exists(os.path.join(_HERE, "_ref", "libugref_lavc.so"))
                                                  or not os.path.exists(os.path.join(_HERE, "_ref", "libugref_lavc_hook.so"))
-                                                 or not os.path.exists(os.path.join(_HERE, "_ref", "ug_ref_lavc_test"))):
+                                                 or not os.path.exists(os.path.join(_HERE, "_ref", "ug_ref_lavc_test"))
+                                                 or not os.path.exists(os.path.join(_HERE, "_ref", "ug_ref_codec_test"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 

@@ -1267,6 +1267,7 @@ extern "C" {
 int ug_hip_color_coeffs(int cs, int depth, int out[14])
 {
         const int slot = depth_slot(depth);
+        if (cs == 0) cs = 2; // CS_DFL: BT.709 unless UltraGrid is started with --param color-601 (color_space.c:152-157)
         if ((cs != 1 && cs != 2) || slot < 0 || !out) return UG_HIP_EINVAL;
         memcpy(out, kCoeffs[cs - 1][slot], sizeof kCoeffs[0][0]);
         return UG_HIP_SUCCESS;
