@@ -1,13 +1,15 @@
 // jpeg_decode.hip -- baseline JPEG decoder on gfx950: the receive side of the JPEG path (the rows behind
 // src/video_decompress/gpujpeg.c:74-140,292-301, which hands the work to the external libgpujpeg).
 //
-//   host   marker syntax (T.81 B.2): DQT, SOF0, DHT, DRI, SOS, Adobe APP14; the restart segments of every scan are located by their RSTn
-//          markers (E.2.4) -- restart intervals are what makes the entropy-coded data parallel;
-//   GPU 1  Huffman decoding (F.2.2), one lane per restart segment: 9-bit look-up for the short codes, the canonical MAXCODE walk for the
-//          long ones, byte stuffing removed on the fly; quantised coefficients are collected per block in LDS and written out 128 bytes at a time;
-//   GPU 2  dequantisation + inverse DCT, one lane per 8x8 block: libjpeg's jidctint ("slow but accurate integer": Loeffler-Ligtenberg-
+//   host   the headers only (T.81 B.2): DQT, SOF0, DHT, DRI, SOS, Adobe APP14 -- a few microseconds; tables are uploaded when they change;
+//   GPU 1  the entropy-coded data made plain: stuffed zeros and restart markers taken out, a table of where every restart segment starts
+//          and ends (E.2.4) -- restart intervals are what makes the entropy-coded data parallel;
+//   GPU 2  Huffman decoding (F.2.2), one lane per restart segment on an LDS copy of its bytes: 10-bit look-up for the short codes, a
+//          branch-free form of the MAXCODE walk for the long ones; quantised coefficients are collected per block in LDS and written
+//          out 128 bytes at a time;
+//   GPU 3  dequantisation + inverse DCT, one lane per 8x8 block: libjpeg's jidctint ("slow but accurate integer": Loeffler-Ligtenberg-
 //          Moschytz, 13-bit constants, PASS1_BITS 2) -- integer arithmetic, so the component planes equal libjpeg's bit for bit;
-//   GPU 3  planes -> the output codec with the pixel-format kernels the library already has (planar 4:2:2 / 4:2:0 -> UYVY as
+//   GPU 4  planes -> the output codec with the pixel-format kernels the library already has (planar 4:2:2 / 4:2:0 -> UYVY as
 //          from_planar.c does it, UYVY -> RGB / RGBA with pixfmt_conv.c's arithmetic), R,G,B planes packed directly.
 // Bit-identical to oracle/jpeg_decode_oracle.c, which is pinned to libjpeg-turbo (tests/test_oracle_jpeg_decode.py).
 #include <stdlib.h>
