@@ -689,6 +689,8 @@ extern "C" {
 
 typedef struct ug_hip_jpeg_decoder ug_hip_jpeg_decoder;
 
+void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec);
+
 int ug_hip_jpeg_decoder_create(ug_hip_jpeg_decoder **out)
 {
         if (!out) return UG_HIP_EINVAL;
@@ -699,7 +701,7 @@ int ug_hip_jpeg_decoder_create(ug_hip_jpeg_decoder **out)
         if (err == hipSuccess) err = hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming);
         if (err != hipSuccess) {
                 ug::set_last_error(err, "ug_hip_jpeg_decoder_create");
-                delete d;
+                ug_hip_jpeg_decoder_destroy((ug_hip_jpeg_decoder *) d); // whatever was allocated so far
                 return UG_HIP_ERUNTIME;
         }
         *out = (ug_hip_jpeg_decoder *) d;
