@@ -189,6 +189,19 @@ def main():
             assert l.ug_hip_jpeg_encoder_encode(enc, pf, srcs[j].data_ptr(), 0, outb.data_ptr(), cap, C.byref(ln), st) == 0
         ms = timeit(run_enc, iters=2 * nn)
         add(f"jpeg encoder {fmt_in} {sub} q75 ri4 ({ln.value} B)", w, h, 1, {420: 5.0, 422: 6.0, 444: 9.0}[sub], ms)
+        if fmt_in == "UYVY":   # the receive side on the stream just made: whole ug_hip_jpeg_decoder_decode call, upload of the stream included
+            torch.cuda.synchronize()
+            stream_bytes = bytes(outb[: ln.value].cpu().numpy())
+            dec = C.c_void_p()
+            assert l.ug_hip_jpeg_decoder_create(C.byref(dec)) == 0
+            dst_uyvy = torch.empty(2 * w * h, dtype=torch.uint8, device="cuda")
+
+            def run_dec():
+                assert l.ug_hip_jpeg_decoder_decode(dec, stream_bytes, len(stream_bytes), L.PF_UYVY, dst_uyvy.data_ptr(), 0, 0, 8, 16, st) == 0
+            ms = timeit(run_dec, iters=16)
+            # algorithmic bytes per pixel: the stream in + UYVY out (2 B/px)
+            add(f"jpeg decoder {sub} q75 ri4 -> UYVY ({ln.value} B, upload included)", w, h, 1, 2.0 + ln.value / (w * h), ms)
+            l.ug_hip_jpeg_decoder_destroy(dec)
         l.ug_hip_jpeg_encoder_destroy(enc)
 
     # decode-direction shuffles
