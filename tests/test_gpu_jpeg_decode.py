@@ -212,3 +212,31 @@ def test_mutated_headers_never_fault(hip, po):
     for c, pl in enumerate(dec.planes(data)):
         assert np.array_equal(pl.cpu().numpy(), crop[c])
     dec.close()
+
+
+def test_decoder_memory_is_flat_over_many_frames(hip, po):
+    """A receiver decodes for hours: device memory in use does not grow while frames of alternating size and sampling keep coming (the work
+    buffers grow to the largest frame once and are reused), and closing the decoder gives everything back."""
+    import torch
+    from ultragrid_amd import lib as L
+    streams = []
+    for (w, h, sub) in ((208, 88, 422), (640, 360, 420), (320, 200, 422)):
+        rgb = picture(w, h, seed=w, noise=3.0)
+        streams.append(_own_stream(hip, po.convert_frame("RGB", "UYVY", rgb, w, h), L.PF_UYVY, w, h, 80, 4, sub))
+    torch.cuda.synchronize()
+    free_at_start = torch.cuda.mem_get_info()[0]
+    dec = hip.JpegDecoder()
+    for i in range(30):                      # reach the steady state
+        dec.decode(streams[i % 3], L.PF_UYVY)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free_steady = torch.cuda.mem_get_info()[0]
+    for i in range(600):
+        dec.decode(streams[i % 3], L.PF_UYVY)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert abs(torch.cuda.mem_get_info()[0] - free_steady) <= 4 << 20      # the allocator's granularity, not growth
+    dec.close()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert free_at_start - torch.cuda.mem_get_info()[0] <= 8 << 20
