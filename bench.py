@@ -99,6 +99,42 @@ def cpu_baseline(frame: np.ndarray, fmt: str, w: int, h: int, target_s: float = 
                       f"row bands; {best_t} threads = best of {cands} on {ncpu} visible CPUs), {dt:.1f} s"}
 
 
+def cpu_reference(fmt: str, w: int, h: int) -> dict | None:
+    """The reference's OWN CPU code for the pixel-format half of this workload, where it has one (the DXT encoders exist as GLSL / CUDA only):
+    the line converter its CPU path runs on such frames (UYVY -> RGB, v210 -> UYVY, RGB -> UYVY), from oracle/_ref/libugref.so -- pixfmt_conv.c
+    compiled from the reference tree with its -O3 -msse4.1 --, over even row bands with the reference's own parallel_pix_conv()
+    (src/utils/parallel_conv.c:64-85); the best thread count is reported.  None when the compiled reference is not there."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    if not po.have_ref():
+        return None
+    i, o = {"UYVY": ("UYVY", "RGB"), "v210": ("v210", "UYVY"), "RGB": ("RGB", "UYVY")}[fmt]
+    r = po.ref()
+    r.parallel_pix_conv.restype = None
+    r.parallel_pix_conv.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    ci, co = po.REF_CODEC[i], po.REF_CODEC[o]
+    fn = r.get_decoder_from_to(ci, co)
+    sls, dls = r.vc_get_linesize(w, ci), r.vc_get_linesize(w, co)
+    from ultragrid_amd import synth
+    src = np.concatenate([synth.s1_random(i, w, h, salt=1), np.zeros(64, np.uint8)])
+    dst = np.zeros(dls * h + 64, np.uint8)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({t for t in (1, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})
+    best_t, best = 1, float("inf")
+    for t in cands:
+        r.parallel_pix_conv(h, dst.ctypes.data, dls, src.ctypes.data, sls, fn, t)   # spawn / warm
+        n, t0 = 0, time.perf_counter()
+        while n < 5 or time.perf_counter() - t0 < 0.3:
+            r.parallel_pix_conv(h, dst.ctypes.data, dls, src.ctypes.data, sls, fn, t)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        if dt < best:
+            best_t, best = t, dt
+    return {"value": round(w * h / best / 1e6, 1), "unit": "Mpixels/s", "cores": best_t, "kind": "reference",
+            "sample": f"{w}x{h} {i}->{o} by the reference's own line converter (pixfmt_conv.c from the reference tree, -O3 -msse4.1) over parallel_pix_conv row bands; "
+                      f"{best_t} threads = best of {cands} on {ncpu} visible CPUs; the pixel-format half of the workload only (the reference has no CPU DXT encoder)"}
+
+
 def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) -> dict:
     """PCIe-inclusive leg (never `value`): every rank drives ITS GPU from pinned host frames -- allocated after the
     process is bound to the GPU's NUMA node -- with 3 frames in flight (H2D -> fused kernel -> D2H), all ranks at the same time,
@@ -327,6 +363,13 @@ def main() -> None:
             out["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline and out_name != "JPEG420":
             out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H, out=out_name)
+            try:
+                ref = cpu_reference(wl["fmt"], W, H)
+            except Exception as e:   # the compiled reference is optional equipment
+                ref = None
+                print(f"bench.py: cpu_reference skipped: {e}", file=sys.stderr, flush=True)
+            if ref is not None:
+                out["cpu_reference"] = ref
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
