@@ -374,7 +374,8 @@ int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, cons
  *   R,G,B streams (Adobe APP14 transform 0 or component ids 'R','G','B': what `-c jpeg` writes for RGB input) -> UG_PF_RGB / UG_PF_RGBA
  *                    directly, UG_PF_UYVY through vc_copylineRGBtoUYVY's arithmetic.
  * The component planes equal libjpeg's bit for bit (integer IDCT jidctint).  `jpeg_host` is host memory (compressed frames arrive from the
- * network); everything after the header parse is asynchronous on `stream`.  UG_PF_NONE: decode to the internal planes only
+ * network); everything after the header parse is asynchronous on `stream` (a stream in pinned memory is read by the copy engine when the stream
+ * gets there: keep it until then; pageable memory is staged before the call returns).  UG_PF_NONE: decode to the internal planes only
  * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout: UG_HIP_EUNSUPP.  Damage inside the entropy-coded data is not
  * an error: a segment ends at its first marker, a missing one decodes as an empty one (what a sequential decoder does).  A decoder object
  * holds the work buffers of one frame in flight: one object per thread / per frame in flight. */
