@@ -19,7 +19,7 @@ cp $S/e2e_bench.txt $D/r02_e2e_bench.jsonl
 cp $S/module_fps.txt $D/r02_module_fps.txt
 cp $S/soak.txt $D/r02_soak.txt
 cp $S/cpu_reference_pixfmt.json $D/r02_cpu_reference_pixfmt.json; cp $S/cpu_reference_pixfmt.txt $D/r02_cpu_reference_pixfmt.txt
-cp $S/jpeg_decode.json $D/r02_jpeg_decode.json; grep -v amdgpu.ids $S/jpeg_decode.txt > $D/r02_jpeg_decode.txt
+cp $S/jpeg_decode.json $D/r02_jpeg_decode.json; [ -f $S/jpeg_decode_8k.json ] && cp $S/jpeg_decode_8k.json $D/r02_jpeg_decode_8k.json; grep -v amdgpu.ids $S/jpeg_decode.txt > $D/r02_jpeg_decode.txt
 sed 's#/tmp/code/[^ ]*/gpurun_out/#gpurun_out/#' $S/jpeg_decoder_pmc.txt > $D/r02_jpeg_decoder_pmc.txt
 [ -f $S/16lane.txt ] && cp $S/16lane.txt $D/r02_16lane_experiment.txt
 tail -2 $S/pytest.log | head -1 > $D/r02_gpu_tests.txt

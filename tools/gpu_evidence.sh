@@ -33,4 +33,5 @@ python tools/cpu_reference_bench.py --json $OUT/cpu_reference_pixfmt.json > $OUT
 rm -rf $OUT/trace $OUT/trace_jpeg $OUT/trace_kernels $OUT/trace_jpegenc gpurun_out/pmc_$TAG/*.db
 ls $OUT
 python tools/bench_jpeg_decode.py --json $OUT/jpeg_decode.json > $OUT/jpeg_decode.txt 2>&1; head -3 $OUT/jpeg_decode.txt
+python tools/bench_jpeg_decode.py --width 7680 --height 4320 --configs 1 --json $OUT/jpeg_decode_8k.json >> $OUT/jpeg_decode.txt 2>&1
 bash tools/pmc_jpeg_dec.sh > $OUT/pmc_jpeg_dec.log 2>&1; cp gpurun_out/pmc_jpeg_dec/summary.txt $OUT/jpeg_decoder_pmc.txt
