@@ -244,7 +244,9 @@ int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *pla
                                                         int blk[64] = { 0 };
                                                         const int t = decode_symbol(&br, &dc[td[k]]);
                                                         pred[k] += extend(receive(&br, t), t);
-                                                        blk[0] = pred[k] * qt[tq[c]][0];
+                                                        /* a coefficient is 16 bits wide (libjpeg's JCOEF; jdhuff.c stores `(JCOEF) s`): only damaged
+                                                         * streams ever run the DC prediction out of that range */
+                                                        blk[0] = (int16_t) pred[k] * qt[tq[c]][0];
                                                         for (int z = 1; z < 64;) {
                                                                 const int rs = decode_symbol(&br, &ac[ta[k]]);
                                                                 const int r = rs >> 4, sz = rs & 15;
@@ -254,8 +256,11 @@ int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *pla
                                                                         continue;
                                                                 }
                                                                 z += r;
+                                                                /* the extra bits are read before the position is looked at, as in libjpeg (jdhuff.c: k += r;
+                                                                 * r = GET_BITS(s) ...): a run that leaves the block (damaged streams only) still eats them */
+                                                                const int value = extend(receive(&br, sz), sz);
                                                                 if (z > 63) break;
-                                                                blk[kZigzag[z]] = extend(receive(&br, sz), sz) * qt[tq[c]][kZigzag[z]];
+                                                                blk[kZigzag[z]] = value * qt[tq[c]][kZigzag[z]];
                                                                 z++;
                                                         }
                                                         if (coef) {

@@ -471,8 +471,8 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                         l = kBits + 1;
 #pragma unroll
                         for (int n = kBits + 1; n <= 16; n++) l += pk >= lc.limit[n];
-                        if (l > 16) { // corrupt data: consume the bits, decode nothing
-                                l = 16;
+                        if (l > 16) { // no such code (damaged data): the MAXCODE walk has read 17 bits by the time it gives up (libjpeg likewise), symbol 0
+                                l = 17;
                                 sym = 0;
                         } else {
                                 sym = lc.vals[(int) (pk >> (16 - l)) + lc.offset[l] & 0xff];
