@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Random search for a picture / parameter set on which the GPU JPEG encoder's byte stream differs from the test writer fed with the
+oracle's coefficients (tests/jpeg_bitstream.py): sizes from one MCU up (odd heights included), qualities 1..100, restart intervals 1..40,
+4:2:0 / 4:2:2 / R,G,B 4:4:4, smooth to pure-noise content.  Also decodes every stream with the GPU decoder and compares with the oracle.
+GPU box.  usage: python tools/find_encode_mismatch.py [n]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from oracle import pyoracle as po
+from ultragrid_amd import codec as hip, lib as L
+from jpeg_bitstream import write_jpeg, write_jpeg420
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+dec = hip.JpegDecoder()
+bad = 0
+for seed in range(n):
+    rng = np.random.default_rng(seed)
+    sub = [420, 422, 444][int(rng.integers(3))]
+    w, h = 2 * int(rng.integers(1, 130)), int(rng.integers(1, 150))
+    q, ri = int(rng.integers(1, 101)), int(rng.integers(1, 41))
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 100 * np.sin(xx / (3 + 40 * rng.random())) * np.cos(yy / (3 + 30 * rng.random())), 128 + 90 * np.cos(xx / 33.0 + yy / (5 + 20 * rng.random())),
+                     128 + 80 * np.sin(yy / (2 + 9 * rng.random()))], -1)
+    rgb = (base + rng.normal(0, [0.0, 2.0, 10.0, 60.0, 200.0][int(rng.integers(5))], base.shape)).clip(0, 255).astype(np.uint8)
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    dl, dc = po.jpeg_divisors(ql), po.jpeg_divisors(qc)
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+    if sub == 444:
+        data = enc.encode(torch.from_numpy(np.ascontiguousarray(rgb).ravel()).cuda(), L.PF_RGB)
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(rgb[..., c]), dl, (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        want = write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=444)
+    else:
+        uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+        data = enc.encode(torch.from_numpy(uyvy).cuda())
+        if sub == 422:
+            y, u, v = po.uyvy_to_i422(uyvy, w, h)
+            mw, mh = (w + 15) // 16, (h + 7) // 8
+            want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, dl, 2 * mw, mh), po.jpeg_fdct_quant_plane(u, dc, mw, mh), po.jpeg_fdct_quant_plane(v, dc, mw, mh), restart=ri, sub=422)
+        else:
+            y, u, v = po.uyvy_to_i420(uyvy, w, h)
+            mw, mh = (w + 15) // 16, (h + 15) // 16
+            want = write_jpeg420(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, dl, 2 * mw, 2 * mh), po.jpeg_fdct_quant_plane(u, dc, mw, mh), po.jpeg_fdct_quant_plane(v, dc, mw, mh), restart=ri)
+    enc.close()
+    if data != want:
+        print("ENCODE MISMATCH seed", seed, sub, w, h, q, ri, len(data), len(want), flush=True)
+        bad += 1
+    _, crop, _ = po.jpeg_decode_planes(data)
+    for c, pl in enumerate(dec.planes(data)):
+        if not np.array_equal(pl.cpu().numpy(), crop[c]):
+            print("DECODE MISMATCH seed", seed, sub, w, h, q, ri, "comp", c, flush=True)
+            bad += 1
+            break
+    if bad >= 4:
+        break
+print("pictures", seed + 1, "mismatches", bad)
