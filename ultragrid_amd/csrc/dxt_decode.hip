@@ -210,6 +210,39 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                 }
         }
         uint32_t idx = q.y;
+        if (OUT == UG_PF_UYVY) {
+                // rgba_to_yuv422.glsl on a block with four colours: Y', and the halves of Cb and Cr that the pair average adds up, are functions of
+                // the palette entry alone -- computed once per entry with the shader's own operations (rgb_pair_to_uyvy above), looked up per pixel
+                float hu[4], hv[4];
+                uint32_t y4 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                        const float r = unorm[pal[k] & 0xff], g = unorm[(pal[k] >> 8) & 0xff], b = unorm[(pal[k] >> 16) & 0xff];
+                        const float yy = (float) (1.0 / 16.0) + ((r * 0.2126f + g * 0.7152f) + b * 0.0722f) * 0.8588f;
+                        const float uu = 0.5f + ((-r * 0.1145f - g * 0.3854f) + b * 0.5f) * 0.8784f;
+                        const float vv = 0.5f + ((r * 0.5f - g * 0.4541f) - b * 0.0458f) * 0.8784f;
+                        y4 |= (uint32_t) unorm8_out<AWAY>(yy) << (8 * k);
+                        hu[k] = uu * 0.5f;
+                        hv[k] = vv * 0.5f;
+                }
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                        uint32_t word[2];
+#pragma unroll
+                        for (int p = 0; p < 2; p++) {
+                                const uint32_t ca = idx & 3, cb = (idx >> 2) & 3;
+                                idx >>= 4;
+                                const float ua = (ca & 2) ? ((ca & 1) ? hu[3] : hu[2]) : ((ca & 1) ? hu[1] : hu[0]);
+                                const float ub = (cb & 2) ? ((cb & 1) ? hu[3] : hu[2]) : ((cb & 1) ? hu[1] : hu[0]);
+                                const float va = (ca & 2) ? ((ca & 1) ? hv[3] : hv[2]) : ((ca & 1) ? hv[1] : hv[0]);
+                                const float vb = (cb & 2) ? ((cb & 1) ? hv[3] : hv[2]) : ((cb & 1) ? hv[1] : hv[0]);
+                                word[p] = (uint32_t) unorm8_out<AWAY>(ua + ub) | ((y4 >> (8 * ca)) & 0xff) << 8 | (uint32_t) unorm8_out<AWAY>(va + vb) << 16 |
+                                          ((y4 >> (8 * cb)) & 0xff) << 24;
+                        }
+                        ((uint2 *) (o.dst + (long) (4 * by + y) * o.pitch))[bx] = make_uint2(word[0], word[1]);
+                }
+                return;
+        }
 #pragma unroll
         for (int y = 0; y < 4; y++) {
                 uint32_t px[4];
