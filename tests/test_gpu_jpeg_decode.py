@@ -252,3 +252,41 @@ def test_damaged_stream_fixtures(hip, po, name):
     for c, pl in enumerate(dec.planes(bad)):
         assert np.array_equal(pl.cpu().numpy(), crop[c]), c
     dec.close()
+
+
+def test_decoders_in_parallel_host_threads(hip, po):
+    """One decoder object and one HIP stream per thread, four threads decoding different streams at once (ctypes drops the GIL during the
+    calls): every result equals the oracle's -- the library keeps no shared mutable state between decoder objects."""
+    import threading
+    import torch
+    from ultragrid_amd import lib as L
+    jobs = []
+    for k, (w, h, sub, ri) in enumerate(((208, 88, 422, 3), (320, 176, 420, 2), (160, 120, 422, 1), (640, 360, 420, 5))):
+        rgb = picture(w, h, seed=20 + k, noise=3.0)
+        data = _own_stream(hip, po.convert_frame("RGB", "UYVY", rgb, w, h), L.PF_UYVY, w, h, 85, ri, sub)
+        _, crop, _ = po.jpeg_decode_planes(data)
+        jobs.append((data, po.planar_to_uyvy(*crop, w, h, chroma=sub), w, h))
+    errors = []
+
+    def worker(job):
+        data, want, w, h = job
+        try:
+            lib = L.load()
+            st = torch.cuda.Stream()
+            dec = hip.JpegDecoder()
+            dst = torch.empty(2 * w * h, dtype=torch.uint8, device="cuda")
+            for _ in range(60):
+                rc = lib.ug_hip_jpeg_decoder_decode(dec._h, data, len(data), L.PF_UYVY, dst.data_ptr(), 0, 0, 8, 16, st.cuda_stream)
+                assert rc == 0, L.last_error()
+                st.synchronize()
+                assert np.array_equal(dst.cpu().numpy(), want)
+            dec.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
