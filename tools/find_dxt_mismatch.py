@@ -50,6 +50,22 @@ def main():
         if not np.array_equal(got, want):
             print("ENCODE MISMATCH", seed, name, "DXT1" if oid == L.DXT1 else "DXT5", w, hh, pitch, ties, kind, "bytes differing", int((got != want).sum()), flush=True)
             bad += 1
+        if seed % 3 == 0 and (w * h // (2 if oid == L.DXT1 else 1)) % 16 == 0:   # the batched entry point (frames start on 16-byte boundaries on both sides): 2-3 frames a stride apart, each must equal its own single-frame result
+            frames = int(rng.integers(2, 4))
+            stride = (pitch * h + 15) // 16 * 16 + 16 * int(rng.integers(0, 5))   # frames start on 16-byte boundaries (the API asks for it)
+            big = np.zeros(stride * frames + 64, np.uint8)
+            singles = []
+            for f in range(frames):
+                fr = np.roll(buf[: pitch * h], 97 * f)
+                if name == "v210":
+                    fr = fr.copy(); fr.view(np.uint32)[:] &= 0x3FFFFFFF
+                big[f * stride: f * stride + pitch * h] = fr
+                singles.append(po.dxt_encode(pin, pout, fr, w, hh, pitch=pitch, ties=ties))
+            gb = hip.dxt_encode_batch(pf, oid, torch.from_numpy(big).cuda(), w, hh, frames, stride, pitch=pitch,
+                                      ties=L.TIES_EVEN if ties == "even" else L.TIES_AWAY).cpu().numpy()
+            if not np.array_equal(gb, np.concatenate(singles)):
+                print("BATCH MISMATCH", seed, name, w, hh, pitch, frames, stride, flush=True)
+                bad += 1
         for out in ("RGBA", "RGB", "UYVY"):
             if out == "UYVY" and w % 2:
                 continue
