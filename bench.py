@@ -310,7 +310,8 @@ def main() -> None:
         value = px_per_step * args.steps / wall / 1e6
         achieved = ALG_BYTES_PER_PX * px_per_launch / (kern_ms * 1e-3) / 1e9
         read_bpp = {"UYVY": 2.0, "v210": 16 / 6, "RGB": 3.0}[wl["fmt"]]
-        pmc_key = {"4k-uyvy": f"uyvy_dxt5_4k_x{F}"}.get(args.workload)
+        pmc_key = {"4k-uyvy": f"uyvy_dxt5_4k_x{F}", "8k-v210": f"v210_dxt5_8k_x{F}", "1080p-rgb-dxt1": f"rgb_dxt1_1080p_x{F}",
+                   "4k-uyvy-jpeg420": f"uyvy_jpeg420_4k_x{F}"}.get(args.workload)
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes (tools/pmc_collect.sh)
         if pmc_key and os.path.exists(pmc_path):
@@ -341,10 +342,12 @@ def main() -> None:
                 rate = ipw * waves / (kern_ms * 1e-3)
                 roof["valu"]["wave_instr_per_s"] = round(rate, 0)
                 roof["valu_frac"] = round(rate / VALU_PEAK, 4)
+            ratio = f"{pmc['traffic'] / (ALG_BYTES_PER_PX * px_per_launch):.3f}x" if pmc.get("traffic") else "not measured for this workload"
             roof["note"] = ("VALU-issue-bound kernel: the bit-exactness contract (every shader operation one separately rounded fp32 operation, no FMA) "
-                            "fixes ~65 VALU instructions per pixel against 3 B/px; HBM traffic = 1.000x the algorithmic bytes (DESIGN.md 4.1)")
+                            f"fixes ~65 VALU instructions per pixel against 3 B/px; HBM traffic / algorithmic bytes = {ratio} (DESIGN.md 4.1)")
         else:
-            roof["note"] = "HBM-bound kernel (DESIGN.md 4.3)"
+            ratio = f"{pmc['traffic'] / (ALG_BYTES_PER_PX * px_per_launch):.3f}x" if pmc.get("traffic") else "not measured"
+            roof["note"] = f"HBM-bound kernel (DESIGN.md 4.3); HBM traffic / algorithmic bytes = {ratio}"
         out = {
             "metric": {"4k-uyvy": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)", "8k-v210": "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
                        "1080p-rgb-dxt1": "Mpixels/s encode (RGB->DXT1, 1080p)",
