@@ -708,6 +708,10 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
                 constexpr uint32_t kBlockBytes = OUT == UG_DXT5_YCOCG ? 16 : 8;
                 uint8_t *const dst_row = dst + (size_t) by * blocks_per_row * kBlockBytes; // scalar
                 const uint32_t dst_off = (uint32_t) ux * (L::kBlocks * kBlockBytes);
+                // A lane with several blocks (v210: 3) keeps them and stores them together at the end: stored one by one, a thousand instructions
+                // apart, the three 16-byte pieces of a lane's 48 bytes reached HBM as partial lines (WRITE_SIZE 1.5 x the output, rocprofv3)
+                uint4 res[L::kBlocks];
+                int n_res = 0;
 #pragma unroll
                 for (int k = 0; k < L::kBlocks; k++) {
                         // v210, width % 12 != 0 (1280, 2048 ...): the last 32-byte unit of a line holds one or two blocks; its loads
@@ -718,9 +722,21 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
                         Px16 p;
                         cur.block(k, p);
                         if (OUT == UG_DXT5_YCOCG) {
-                                *(uint4 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt5ycocg<AWAY>(p);
+                                res[k] = encode_dxt5ycocg<AWAY>(p);
                         } else {
-                                *(uint2 *) (dst_row + (dst_off + k * kBlockBytes)) = encode_dxt1<AWAY>(p);
+                                const uint2 e = encode_dxt1<AWAY>(p);
+                                res[k] = make_uint4(e.x, e.y, 0, 0);
+                        }
+                        n_res = k + 1;
+                }
+#pragma unroll
+                for (int k = 0; k < L::kBlocks; k++) {
+                        if (k < n_res) {
+                                if (OUT == UG_DXT5_YCOCG) {
+                                        *(uint4 *) (dst_row + (dst_off + k * kBlockBytes)) = res[k];
+                                } else {
+                                        *(uint2 *) (dst_row + (dst_off + k * kBlockBytes)) = make_uint2(res[k].x, res[k].y);
+                                }
                         }
                 }
                 if (more) {
