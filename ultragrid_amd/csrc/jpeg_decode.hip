@@ -396,11 +396,13 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
         const int n_found = min(n_seg, found[0]);
         // ---- the workgroup's stretch of the clean stream -> LDS ----
         uint32_t stage_begin = 0, staged = 0;
+        bool all_staged = true; // workgroup-uniform: every byte any lane can ask for is in LDS
         if (seg0 < n_found) {
                 const int last = min(seg0 + lanes, n_found) - 1;
                 stage_begin = seg_start[seg0] & ~15u;
                 const uint32_t stretch = seg_end[last] - stage_begin;
-                staged = min((stretch + 15u) & ~15u, (uint32_t) stage_bytes);
+                staged = min((stretch + 16u + 15u) & ~15u, (uint32_t) stage_bytes); // 16 more: the look-ahead of the last segment stays inside
+                all_staged = staged >= stretch + 12u;
                 for (uint32_t o = lane * 16; o < staged; o += 64 * 16) *(uint4 *) (stage + o) = *(const uint4 *) (clean + stage_begin + o);
         }
         for (int j = 0; j < sp.n_dc + sp.n_ac; j++) {
@@ -431,22 +433,23 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
         br.cnt = 0;
         const uint8_t *const far = clean + stage_begin; // for what did not fit in LDS
         // the two aligned words that hold the four bytes at `at`; put together when they are used, one symbol later
-        auto fetch = [&](uint32_t at) {
-                if (__builtin_expect(at + 8 > staged, 0)) {
-                        const uint32_t *two = (const uint32_t *) (far + (at & ~3u)); // the clean buffer has slack behind the data
-                        br.nxt_lo = two[0];
-                        br.nxt_hi = two[1];
-                        asm volatile("" : "+v"(br.nxt_lo), "+v"(br.nxt_hi)); // completes here: the common path never waits on memory
-                } else {
-                        const uint32_t *two = (const uint32_t *) (stage + (at & ~3u));
-                        br.nxt_lo = two[0];
-                        br.nxt_hi = two[1];
+        auto fetch = [&](auto far_c, uint32_t at) {
+                if constexpr (decltype(far_c)::value) {
+                        if (__builtin_expect(at + 8 > staged, 0)) {
+                                const uint32_t *two = (const uint32_t *) (far + (at & ~3u)); // the clean buffer has slack behind the data
+                                br.nxt_lo = two[0];
+                                br.nxt_hi = two[1];
+                                asm volatile("" : "+v"(br.nxt_lo), "+v"(br.nxt_hi)); // completes here: the common path never waits on memory
+                                return;
+                        }
                 }
+                const uint32_t *two = (const uint32_t *) (stage + (at & ~3u));
+                br.nxt_lo = two[0];
+                br.nxt_hi = two[1];
         };
-        fetch(br.pos);
         // one Huffman symbol and the `symbol & 15` extra bits behind it (F.2.2.1, sign extension of Figure F.12): code (<= 16 bits) + extra bits
         // (<= 15) always fit in the top 32 bits of the window after the top-up
-        auto symbol = [&](auto bits_c, const uint16_t *lut, const LongCodes &lc, int &value) -> int {
+        auto symbol = [&](auto far_c, auto bits_c, const uint16_t *lut, const LongCodes &lc, int &value) -> int {
                 constexpr int kBits = decltype(bits_c)::value;
                 {
                         const bool need = br.cnt <= 32;
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
                         br.acc |= in << ((32 - br.cnt) & 63);
                         br.cnt += need ? 32 : 0;
                         br.pos += need && br.pos < br.end ? 4 : 0; // never far behind the end: what is fetched there is masked anyway
-                        fetch(br.pos);
+                        fetch(far_c, br.pos);
                 }
                 const uint32_t hi = (uint32_t) (br.acc >> 32);
                 const unsigned e = lut[hi >> (32 - kBits)];
@@ -490,46 +493,53 @@ __global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restri
         const int u0 = seg * per_seg;
         int16_t *const my = (int16_t *) (tile + lane * kTileWords);
         const int rounds = (lanes + 7) / 8;
-        for (int i = 0; i < per_seg; i++) {
-                const int u = u0 + i;
-                const bool active = mine && u < sp.units;
-                const int row_units = sp.single ? sp.bw1 : sp.mcu_w;
-                const int uy = u / row_units, ux = u - uy * row_units;
-                for (int k = 0; k < sp.ns; k++) {
-                        for (int by = 0; by < sp.nbv[k]; by++) {
-                                for (int bx = 0; bx < sp.nbh[k]; bx++) {
-                                        tile_dst[lane] = active ? (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx : -1;
-                                        if (active) {
-                                                const uint16_t *const ac_lut = lut_ac + sp.ac_slot[k] * (1 << kLutBits);
-                                                const LongCodes &ac_long = longs[sp.n_dc + sp.ac_slot[k]];
-                                                int v;
-                                                symbol(std::integral_constant<int, kDcLutBits>(), lut_dc + sp.dc_slot[k] * (1 << kDcLutBits), longs[sp.dc_slot[k]], v);
-                                                pred[k] += v;
-                                                my[0] = (int16_t) pred[k];
-                                                for (int z = 1; z < 64; z++) {
-                                                        const int rs = symbol(std::integral_constant<int, kLutBits>(), ac_lut, ac_long, v);
-                                                        if ((rs & 15) == 0 && rs != 0xF0) break; // EOB
-                                                        z += rs >> 4;
-                                                        my[(rs & 15) && z < 64 ? z : 64] = (int16_t) v; // slot 64 is the tile's padding
+        // the walk over the segment, compiled twice: without the test for bytes outside LDS when the workgroup's whole stretch is staged (the
+        // usual case; the choice is workgroup-uniform), with it otherwise
+        auto walk = [&](auto far_c) {
+                fetch(far_c, br.pos);
+                for (int i = 0; i < per_seg; i++) {
+                        const int u = u0 + i;
+                        const bool active = mine && u < sp.units;
+                        const int row_units = sp.single ? sp.bw1 : sp.mcu_w;
+                        const int uy = u / row_units, ux = u - uy * row_units;
+                        for (int k = 0; k < sp.ns; k++) {
+                                for (int by = 0; by < sp.nbv[k]; by++) {
+                                        for (int bx = 0; bx < sp.nbh[k]; bx++) {
+                                                tile_dst[lane] = active ? (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx : -1;
+                                                if (active) {
+                                                        const uint16_t *const ac_lut = lut_ac + sp.ac_slot[k] * (1 << kLutBits);
+                                                        const LongCodes &ac_long = longs[sp.n_dc + sp.ac_slot[k]];
+                                                        int v;
+                                                        symbol(far_c, std::integral_constant<int, kDcLutBits>(), lut_dc + sp.dc_slot[k] * (1 << kDcLutBits), longs[sp.dc_slot[k]], v);
+                                                        pred[k] += v;
+                                                        my[0] = (int16_t) pred[k];
+                                                        for (int z = 1; z < 64; z++) {
+                                                                const int rs = symbol(far_c, std::integral_constant<int, kLutBits>(), ac_lut, ac_long, v);
+                                                                if ((rs & 15) == 0 && rs != 0xF0) break; // EOB
+                                                                z += rs >> 4;
+                                                                my[(rs & 15) && z < 64 ? z : 64] = (int16_t) v; // slot 64 is the tile's padding
+                                                        }
                                                 }
-                                        }
-                                        __syncthreads();
-                                        // 8 lanes per tile, 16 bytes each: 8 tiles per round
-                                        for (int round = 0; round < rounds; round++) {
-                                                const int t = round * 8 + (lane >> 3), part = lane & 7;
-                                                if (t < lanes) {
-                                                        const int dst = tile_dst[t];
-                                                        uint4 *src = (uint4 *) (tile + t * kTileWords + part * 4);
-                                                        const uint4 q = *src;
-                                                        *src = make_uint4(0, 0, 0, 0);
-                                                        if (dst >= 0) *(uint4 *) (sp.coef[k] + (size_t) dst * 64 + part * 8) = q;
+                                                __syncthreads();
+                                                // 8 lanes per tile, 16 bytes each: 8 tiles per round
+                                                for (int round = 0; round < rounds; round++) {
+                                                        const int t = round * 8 + (lane >> 3), part = lane & 7;
+                                                        if (t < lanes) {
+                                                                const int dst = tile_dst[t];
+                                                                uint4 *src = (uint4 *) (tile + t * kTileWords + part * 4);
+                                                                const uint4 q = *src;
+                                                                *src = make_uint4(0, 0, 0, 0);
+                                                                if (dst >= 0) *(uint4 *) (sp.coef[k] + (size_t) dst * 64 + part * 8) = q;
+                                                        }
                                                 }
+                                                __syncthreads();
                                         }
-                                        __syncthreads();
                                 }
                         }
                 }
-        }
+        };
+        if (all_staged) walk(std::false_type());
+        else walk(std::true_type());
 }
 
 // jidctint.c; see oracle/jpeg_decode_oracle.c
