@@ -109,3 +109,39 @@ def test_rejects_what_is_not_baseline(po):
         po.jpeg_decode_planes(b.getvalue())
     with pytest.raises(ValueError):
         po.jpeg_decode_planes(b"\x00\x01\x02\x03")
+
+
+def test_random_streams_equal_libjpeg(po):
+    """300 random valid streams (tools/find_oracle_vs_libjpeg.py runs the same search over thousands): sizes from 1x1, qualities 1..100, all
+    samplings and greyscale, optimised tables, restart intervals, smooth to pure-noise content."""
+    checked = 0
+    for seed in range(300):
+        rng = np.random.default_rng(seed)
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        noise = [0.0, 2.0, 10.0, 60.0, 200.0][int(rng.integers(5))]
+        img = (picture(w, h, seed=seed, noise=0.0).astype(float) + rng.normal(0, noise, (h, w, 3))).clip(0, 255).astype(np.uint8)
+        grey = rng.random() < 0.1
+        kw = dict(quality=int(rng.integers(1, 101)), optimize=bool(rng.integers(2)))
+        if not grey:
+            kw["subsampling"] = int(rng.integers(3))
+        r = int(rng.integers(4))
+        if r == 1:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        elif r == 2:
+            kw["restart_marker_rows"] = int(rng.integers(1, 3))
+        try:
+            data = pil_jpeg(img[..., 1] if grey else img, **kw)
+        except OSError:
+            continue
+        _, crop, _ = po.jpeg_decode_planes(data)
+        ref = Image.open(io.BytesIO(data))
+        if grey:
+            assert np.array_equal(crop[0], np.asarray(ref)), (seed, kw)
+        else:
+            ref.draft("YCbCr", None)
+            ref = np.asarray(ref)
+            assert np.array_equal(crop[0], ref[..., 0]), (seed, kw)
+            if kw["subsampling"] == 0:
+                assert np.array_equal(crop[1], ref[..., 1]) and np.array_equal(crop[2], ref[..., 2]), (seed, kw)
+        checked += 1
+    assert checked > 250
