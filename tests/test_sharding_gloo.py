@@ -60,11 +60,13 @@ def test_round_robin_assignment():
         shard.reorder([[(0, "a")], [(2, "b")]])
 
 
-def test_two_rank_gloo_sharding_matches_single_process(po):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharding_matches_single_process(po, world):
+    """world_size 2 (the contract's CPU case) and 4 (7 frames over 4 ranks: uneven shares)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 7 * world) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
     wall, gathered = q.get(timeout=120)
     [p.join(timeout=60) for p in procs]
