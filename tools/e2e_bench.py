@@ -26,6 +26,11 @@ def main():
         r = pipeline.run(wl, depth=a.depth, seconds=a.seconds)
         r.update({"gpu_numa_node": node, "cpus_bound": bound, "device": torch.cuda.get_device_name(0)})
         print(json.dumps(r), flush=True)
+    if a.workload == "all":   # and the receiving direction: JPEG in, raw frame out
+        for out in ("UYVY", "RGBA"):
+            r = pipeline.run_jpeg_decode(depth=a.depth, seconds=a.seconds, out=out)
+            r.update({"gpu_numa_node": node, "cpus_bound": bound})
+            print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":

@@ -100,3 +100,45 @@ def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_fra
     return {"workload": workload, "fps": round(fps, 1), "mpixels_per_s": round(w * h * fps / 1e6, 1), "frames": n, "seconds": round(dt, 3),
             "in_flight": depth, "pcie_gbs": round((in_len + out_len) * fps / 1e9, 2), "h2d_gbs": round(in_len * fps / 1e9, 2),
             "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len}
+
+
+def run_jpeg_decode(width: int = 3840, height: int = 2160, depth: int = 3, seconds: float = 2.0, out: str = "UYVY", quality: int = 75, restart: int = 4) -> dict:
+    """Receiver side, PCIe included: a compressed frame in pinned host memory -> ug_hip_jpeg_decoder_decode (upload + kernels) -> D2H of the
+    raw frame into pinned memory, `depth` frames in flight (one decoder object and one stream each, as the C ABI asks).  The stream is made
+    once with the repository's encoder from S2 content."""
+    import ctypes as C
+    lib.load()
+    src = torch.from_numpy(synth.s2_video("UYVY", width, height)).cuda()
+    enc = codec.JpegEncoder(width, height, quality, restart, subsampling=422)
+    data = enc.encode(src)
+    enc.close()
+    pinned = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+    out_len = codec.linesize(lib.PF_NAMES[out], width) * height
+    slots = [dict(st=torch.cuda.Stream(), dec=codec.JpegDecoder(), dev=torch.empty(out_len, dtype=torch.uint8, device="cuda"),
+                  host=torch.empty(out_len, dtype=torch.uint8).pin_memory(), busy=False) for _ in range(depth)]
+    l = lib.load()
+
+    def submit(s):
+        rc = l.ug_hip_jpeg_decoder_decode(s["dec"]._h, C.c_void_p(pinned.data_ptr()), len(data), lib.PF_NAMES[out], s["dev"].data_ptr(), 0, 0, 8, 16, s["st"].cuda_stream)
+        lib.check(rc, "ug_hip_jpeg_decoder_decode")
+        with torch.cuda.stream(s["st"]):
+            s["host"].copy_(s["dev"], non_blocking=True)
+        s["busy"] = True
+
+    for s in slots:
+        submit(s)
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while n < 30 or time.perf_counter() - t0 < seconds:
+        s = slots[n % depth]
+        if s["busy"]:
+            s["st"].synchronize()
+        submit(s)
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for s in slots:
+        s["dec"].close()
+    fps = n / dt
+    return {"workload": f"jpeg-decode {width}x{height} 4:2:2 q{quality} restart {restart} -> {out}", "fps": round(fps, 1), "frames": n, "seconds": round(dt, 3),
+            "in_flight": depth, "bytes_in_per_frame": len(data), "bytes_out_per_frame": out_len, "pcie_gbs": round((len(data) + out_len) * fps / 1e9, 2)}
