@@ -208,6 +208,11 @@ int ug_hip_linesize(ug_pixfmt_t fmt, int width);
 /* packed -> planar (to_planar.h:53-74) */
 int ug_hip_uyvy_to_i420(const void *src_dev, int src_pitch, void *y, int y_pitch, void *u, int u_pitch,
                         void *v, int v_pitch, int width, int height, ug_hip_stream_t stream); /* uyvy_to_i420, to_planar.c:343 */
+/* v210_to_p010le (to_planar.c:64-155) for every geometry the reference converts: any width, odd last line (:80-83), the
+ * width % 6 margin (:85-89 whole last group on interior line pairs -- written past `width`, and with a pitch shorter than
+ * roundup6(width) samples the even line's tail stays on the first samples of the odd line, as in the reference; :139-150 the
+ * margin of the last one or two lines copied from two lines above).  src_pitch 0 = vc_get_linesize(width, v210); pitches in
+ * bytes.  width % 6 != 0 with fewer than 5 lines -> UG_HIP_EUNSUPP (the reference reads in front of its planes there). */
 int ug_hip_v210_to_p010le(const void *src_dev, int src_pitch, void *y, int y_pitch, void *uv, int uv_pitch,
                           int width, int height, ug_hip_stream_t stream);
 
@@ -228,7 +233,7 @@ int ug_hip_uyvy_to_i422(const void *src_dev, int src_pitch, void *y_dev, int y_p
 /* uyvy_to_nv12 (to_planar.c:207-302) as the reference's default (-msse4.1) build computes it: chroma of a line pair is
  * (a + b + 1) >> 1 for the first 16 * (width / 16) pixels (_mm_avg_epu8) and (a + b) / 2 for the scalar tail. */
 int ug_hip_uyvy_to_nv12(const void *src_dev, int src_pitch, void *y_dev, int y_pitch, void *cbcr_dev, int cbcr_pitch,
-                        int width, int height, ug_hip_stream_t stream);                     /* v210_to_p010le, to_planar.c:64 */
+                        int width, int height, ug_hip_stream_t stream);
 
 /* The whole of src/from_planar.h and src/to_planar.h by the reference's own function names (these are the
  * building blocks of libavcodec/{from,to}_lavc_vid_conv.c).  The structs repeat the reference's field for field, all pointers

@@ -346,33 +346,46 @@ void oracle_uyvy_to_i420(uint8_t *yp, int y_ls, uint8_t *up, int u_ls, uint8_t *
         }
 }
 
-/* to_planar.c:64-155 -- restated for width % 6 == 0 and even height (the hot-path
- * configurations); the reference's ragged-edge copy-from-above path is not restated. */
+/* One v210 group (16 bytes) -> six luma and six chroma (Cb Cr Cb Cr Cb Cr) 10-bit samples; sample n of the group's
+ * twelve (U Y V Y ...) sits in word n / 3 at bit 10 * (n % 3) (the table of to_planar.c:92-103). */
+static void v210_group(const uint8_t *p, uint32_t luma[6], uint32_t chroma[6])
+{
+        for (int s = 0; s < 6; s++) {
+                luma[s] = (ld32(p + 4 * ((2 * s + 1) / 3)) >> (10 * ((2 * s + 1) % 3))) & 0x3ffu;
+                chroma[s] = (ld32(p + 4 * ((2 * s) / 3)) >> (10 * ((2 * s) % 3))) & 0x3ffu;
+        }
+}
+
+/* to_planar.c:64-155 for any geometry, the writes in the reference's order (they overlap when a line size is shorter than
+ * roundup6(width) samples, so the order is part of the result):
+ *   line pairs with more than two lines left (:85-86): (width + 5) / 6 whole groups, each group even line, odd line, chroma (:113-132);
+ *   the last one or two lines (:87-89): width / 6 groups, an odd last line converted against itself (:80-83, the odd luma
+ *   line goes to a scratch buffer), then the width % 6 samples behind them copied (:139-150) from `dst - out_linesize[]`, which on
+ *   a uint16_t pointer is TWO lines above -- the luma of both lines from line y - 2, the chroma from chroma line y / 2 - 2.
+ * y_ls / uv_ls in bytes.  With width % 6 != 0 and fewer than 5 lines the reference reads in front of the planes: not restated
+ * (returns without writing the margin). */
 void oracle_v210_to_p010le(uint16_t *yp, int y_ls, uint16_t *uvp, int uv_ls,
                            const uint8_t *src, int width, int height)
 {
         const long sls = oracle_linesize(width, OPF_V210);
-        for (int y = 0; y + 1 < height; y += 2) {
-                const uint8_t *s0 = src + y * sls, *s1 = s0 + sls;
-                uint16_t *d0 = (uint16_t *) ((uint8_t *) yp + (long) y * y_ls);
-                uint16_t *d1 = (uint16_t *) ((uint8_t *) yp + (long) (y + 1) * y_ls);
-                uint16_t *dc = (uint16_t *) ((uint8_t *) uvp + (long) (y / 2) * uv_ls);
-                for (int x = 0; x < width / 6; x++) {
-                        uint32_t a[4], b[4];
-                        for (int i = 0; i < 4; i++) { a[i] = ld32(s0 + 4 * i); b[i] = ld32(s1 + 4 * i); }
-                        s0 += 16; s1 += 16;
-#define S(w, k) (((w) >> (10 * (k))) & 0x3ffu)
-                        const uint32_t ya[6] = { S(a[0],1), S(a[1],0), S(a[1],2), S(a[2],1), S(a[3],0), S(a[3],2) };
-                        const uint32_t yb[6] = { S(b[0],1), S(b[1],0), S(b[1],2), S(b[2],1), S(b[3],0), S(b[3],2) };
-                        /* Cb Cr Cb Cr Cb Cr */
-                        const uint32_t ca[6] = { S(a[0],0), S(a[0],2), S(a[1],1), S(a[2],0), S(a[2],2), S(a[3],1) };
-                        const uint32_t cb[6] = { S(b[0],0), S(b[0],2), S(b[1],1), S(b[2],0), S(b[2],2), S(b[3],1) };
-#undef S
-                        for (int i = 0; i < 6; i++) {
-                                *d0++ = ya[i] << 6;
-                                *d1++ = yb[i] << 6;
-                                *dc++ = ((ca[i] + cb[i]) / 2) << 6;
-                        }
+        const long lw = y_ls / 2, lc = uv_ls / 2;
+        for (int y = 0; y < height; y += 2) {
+                const int left = height - y;
+                const uint8_t *s0 = src + y * sls, *s1 = left == 1 ? s0 : s0 + sls;
+                uint16_t *d0 = yp + y * lw, *d1 = yp + (y + 1) * lw, *dc = uvp + (y / 2) * lc;
+                const int groups = left > 2 ? (width + 5) / 6 : width / 6;
+                for (int g = 0; g < groups; g++) {
+                        uint32_t ya[6], yb[6], ca[6], cb[6];
+                        v210_group(s0 + 16 * g, ya, ca);
+                        v210_group(s1 + 16 * g, yb, cb);
+                        for (int i = 0; i < 6; i++) d0[6 * g + i] = (uint16_t) (ya[i] << 6);
+                        if (left != 1) for (int i = 0; i < 6; i++) d1[6 * g + i] = (uint16_t) (yb[i] << 6);
+                        for (int i = 0; i < 6; i++) dc[6 * g + i] = (uint16_t) (((ca[i] + cb[i]) / 2) << 6);
+                }
+                if (left <= 2 && width % 6 != 0 && height >= 5) {
+                        for (int x = 6 * groups; x < width; x++) d0[x] = d0[x - 2 * lw];
+                        if (left == 2) for (int x = 6 * groups; x < width; x++) d1[x] = d0[x - 2 * lw];
+                        for (int x = 6 * groups; x < width; x++) dc[x] = dc[x - 2 * lc];
                 }
         }
 }

@@ -148,7 +148,7 @@ def to_shapes(name: str, w: int, h: int):
     """[(rows, samples per row, dtype)] of the output planes, tightly packed"""
     cw, ch = (w + 1) // 2, (h + 1) // 2
     return {
-        "v210_to_p010le": [(h, w, np.uint16), (h // 2, w, np.uint16)],
+        "v210_to_p010le": [(h, w, np.uint16), (ch, w, np.uint16)],
         "y216_to_p010le": [(h, w, np.uint16), (ch, 2 * cw, np.uint16)],
         "uyvy_to_nv12": [(h, w, np.uint8), (ch, 2 * cw, np.uint8)],
         "rgba_to_bgra": [(h, 4 * w, np.uint8)],

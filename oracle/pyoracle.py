@@ -400,20 +400,24 @@ def yuv422p10le_to_v210(y: np.ndarray, u: np.ndarray, v: np.ndarray, w: int, h: 
     return out.view(np.uint8).ravel()
 
 
-def v210_to_p010le(src: np.ndarray, w: int, h: int, use_ref: bool = False):
+def v210_to_p010le(src: np.ndarray, w: int, h: int, use_ref: bool = False, y_pad: int = 0, uv_pad: int = 0, fill: int = 0):
+    """to_planar.c:64-155; planes of h x (w + y_pad) and ceil(h / 2) x (w + uv_pad) samples (pads = line padding in samples,
+    returned too: the reference writes the whole last group of a line there).  With width % 6 != 0 and a pad < roundup6(w) - w the
+    reference's line tails overlap the following lines; spare lines behind each plane take the last tail."""
     src = np.ascontiguousarray(src, dtype=np.uint8).ravel()
-    y = np.zeros((h, w), np.uint16)
-    uv = np.zeros((h // 2, w), np.uint16)
+    ch = (h + 1) // 2
+    ybuf = np.full((h + 1 + 6 // (w + y_pad), w + y_pad), fill, np.uint16)
+    uvbuf = np.full((ch + 1 + 6 // (w + uv_pad), w + uv_pad), fill, np.uint16)
     if use_ref:
         d = _ToPlanar()
         d.width, d.height = w, h
-        d.out_data[0], d.out_data[1] = y.ctypes.data, uv.ctypes.data
-        d.out_linesize[0], d.out_linesize[1] = 2 * w, 2 * w
+        d.out_data[0], d.out_data[1] = ybuf.ctypes.data, uvbuf.ctypes.data
+        d.out_linesize[0], d.out_linesize[1] = 2 * (w + y_pad), 2 * (w + uv_pad)
         d.in_data = src.ctypes.data
         ref().v210_to_p010le(d)
     else:
-        lib().oracle_v210_to_p010le(_ptr(y), 2 * w, _ptr(uv), 2 * w, _ptr(src), w, h)
-    return y, uv
+        lib().oracle_v210_to_p010le(_ptr(ybuf), 2 * (w + y_pad), _ptr(uvbuf), 2 * (w + uv_pad), _ptr(src), w, h)
+    return ybuf[:h], uvbuf[:ch]
 
 
 def color_coeffs(depth: int, bt601: bool = False) -> list[int]:

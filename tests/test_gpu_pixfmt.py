@@ -104,6 +104,31 @@ def test_planar(hip, po):
 
 
 @pytest.mark.gpu
+def test_v210_to_p010le_ragged_geometry(hip, po):
+    """every geometry the reference converts (to_planar.c:80-94,139-150) -- 1280x720, 2048x1080, 50x7, narrow and odd
+    ones -- whole planes incl. the bytes the reference writes into the line padding, for paddings that do and do not hold the whole
+    last group.  Checked against the restatement and, where oracle/_ref travelled, against the compiled reference itself."""
+    import torch
+    from test_oracle_pixfmt import P010_PADS, P010_RAGGED
+    for w, h in P010_RAGGED + [(3838, 2159)]:
+        src = synth.s1_random("v210", w, h, salt=w + h)
+        dsrc = torch.from_numpy(src).cuda()
+        for yp, up in P010_PADS:
+            y, uv = hip.v210_to_p010le(dsrc, w, h, yp, up, 0x5A5A)
+            got = (y.cpu().numpy().view(np.uint16), uv.cpu().numpy().view(np.uint16))
+            wants = [po.v210_to_p010le(src, w, h, False, yp, up, 0x5A5A)]
+            if po.have_ref():
+                wants.append(po.v210_to_p010le(src, w, h, True, yp, up, 0x5A5A))
+            for want in wants:
+                for k, (a, b) in enumerate(zip(got, want)):
+                    assert np.array_equal(a, b), (w, h, yp, up, k)
+    # what the reference cannot convert without reading in front of its planes is refused, not guessed
+    for w, h in [(50, 4), (7, 2), (1280, 3)]:
+        with pytest.raises(Exception):
+            hip.v210_to_p010le(torch.zeros(po.linesize(w, "v210") * h, dtype=torch.uint8, device="cuda"), w, h)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pair", [("v210", "UYVY"), ("UYVY", "RGB"), ("RGB", "UYVY"), ("R10k", "RGB"), ("UYVY", "RGBA")])
 def test_batch_equals_per_frame(hip, po, pair):
     """ug_hip_pixfmt_convert_batch: frames one picture apart (a single launch over frames * height lines) and frames at a padded stride

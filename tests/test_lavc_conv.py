@@ -219,6 +219,8 @@ def test_gpu_uv_to_av(hip, uv, av):
     sizes = [(48, 8), (96, 4), (1920, 2)]
     if (uv, av) not in FORWARDED_TO:
         sizes += [(54, 6)] + ([(49, 5), (7, 3)] if (uv, av) != ("v210", "yuv420p10le") else [(50, 6)])
+    if (uv, av) == ("v210", "p010le"):
+        sizes += [(50, 7), (1280, 10), (2048, 5), (54, 5), (7, 6)]  # to_planar.c:80-94,139-150: odd last line, width % 6 margin
     for i, (w, h) in enumerate(sizes):
         ls = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
         src = np.random.default_rng(i).integers(0, 256, ls * h + 64).astype(np.uint8)

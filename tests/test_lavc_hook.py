@@ -74,16 +74,17 @@ def test_reference_from_lavc_runs_on_the_gpu(hip, capfd, monkeypatch, uv):
 
 @pytest.mark.gpu
 def test_hook_declines_geometry_the_device_row_cannot_take(hip, capfd, monkeypatch):
-    """v210 -> p010le on the device needs width % 6 == 0 and an even height; the reference's CPU function takes any size.
-    At 1280x720 (1280 % 6 == 2) the hook's init must DECLINE (NULL), so that the reference sets up its own CPU conversion
-    (to_lavc_vid_conv.c:1901-1906) and every frame still arrives -- equal to the plain CPU build -- instead of every
-    to_lavc_vid_conv_cuda() call returning NULL and all frames being lost."""
+    """ADVICE r1 / VERDICT r2 #3: v210 -> p010le runs on the device for every geometry the reference's CPU function converts -- 1280x720
+    (1280 % 6 == 2), odd heights -- and equals the plain CPU build.  Where the device row refuses (width % 6 != 0 with fewer than 5 lines:
+    the reference reads in front of its planes) the hook's init must DECLINE (NULL), so that the reference sets up its own CPU
+    conversion (to_lavc_vid_conv.c:1901-1906) and every frame still arrives, instead of every to_lavc_vid_conv_cuda() call returning
+    NULL and all frames being lost."""
     monkeypatch.setenv("UG_MI355X_VERBOSE", "1")
     h, r = hook_lib(), T.ref()
     uv, av = "v210", "p010le"
     if not hip.L.load().ug_hip_uv_to_av_supported(uv.encode(), av.encode()):
         pytest.skip("row not in the table")
-    for (w, h_), on_device in (((1280, 720), False), ((1920, 8), True), ((50, 6), False), ((48, 7), False)):
+    for (w, h_), on_device in (((1280, 720), True), ((1920, 8), True), ((50, 6), True), ((48, 7), True), ((50, 7), True), ((48, 1), True), ((50, 4), False)):
         ls = r.vc_get_linesize(w, r.get_codec_from_name(uv.encode()))
         src = (np.random.default_rng(w).integers(0, 256, ls * h_ + 64).astype(np.uint8).view(np.uint32) & 0x3FFFFFFF).view(np.uint8)
         want = T.ref_uv_to_av(uv, av, src, w, h_)
@@ -98,6 +99,7 @@ def test_hook_declines_geometry_the_device_row_cannot_take(hip, capfd, monkeypat
         assert (f"to_lavc {uv} -> {av} on the device" in err) == on_device, (w, h_, err)
         if not on_device:
             assert "left to the CPU path" in err
+            continue  # the frame arrived from the reference's own CPU code; at this geometry it copies from in front of its planes
         for k, (g, wnt) in enumerate(zip(got, want)):
             assert np.array_equal(g, wnt), (w, h_, k)
 

@@ -125,3 +125,22 @@ def test_planar_vs_compiled_reference(po):
         src = synth.s1_random("v210", w, h, salt=4)
         for a, b in zip(po.v210_to_p010le(src, w, h), po.v210_to_p010le(src, w, h, use_ref=True)):
             assert np.array_equal(a, b)
+
+
+P010_RAGGED = [(1280, 720), (2048, 1080), (50, 7), (48, 7), (50, 6), (6, 1), (7, 5), (13, 9), (3, 5), (5, 8), (4, 7), (1, 6), (2, 5), (11, 6)]
+P010_PADS = [(0, 0), (1, 0), (0, 2), (3, 3), (5, 5), (8, 6)]
+
+
+def test_v210_to_p010le_ragged_geometry_vs_compiled_reference(po):
+    """to_planar.c:80-94,139-150: odd last line, whole last group written past `width` on interior line pairs, the margin of the
+    last one or two lines copied from two lines above.  Whole planes compared INCLUDING the line padding (pad < roundup6(w) - w:
+    the reference's line tails overlap the following lines, the order of its writes decides the result)."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built")
+    for w, h in P010_RAGGED:
+        src = synth.s1_random("v210", w, h, salt=w + h)
+        for yp, up in P010_PADS:
+            got = po.v210_to_p010le(src, w, h, False, yp, up, 0x5A5A)
+            want = po.v210_to_p010le(src, w, h, True, yp, up, 0x5A5A)
+            for k, (a, b) in enumerate(zip(got, want)):
+                assert np.array_equal(a, b), (w, h, yp, up, k)

@@ -89,8 +89,10 @@ def test_to_planar_restatement_vs_reference(po, name):
     if not po.have_ref():
         pytest.skip("oracle/_ref not built")
     for i, (w, h) in enumerate(SIZES):
-        if name in ("uyvy_to_nv12", "uyvy_to_i420", "v210_to_p010le") and (w % 2 or h % 2 or (name == "v210_to_p010le" and w % 6)):
-            continue  # these three have their own ragged-size tests (tests/test_pixfmt*.py, tests/test_planar.py)
+        if name in ("uyvy_to_nv12", "uyvy_to_i420") and (w % 2 or h % 2):
+            continue  # these two have their own ragged-size tests (tests/test_pixfmt*.py, tests/test_planar.py)
+        if name == "v210_to_p010le" and w % 6 and h < 5:
+            continue  # the reference reads in front of its planes (to_planar.c:142-148 with y < 4)
         src = to_case(name, w, h, i)
         got = PO.to_planar(name, src, w, h)
         want = PO.ref_to_planar(name, src, w, h)
@@ -176,8 +178,10 @@ def test_gpu_to_planar(hip, name):
     codec = hip
     assert hip.L.load().ug_hip_to_planar_supported(name.encode()) == 1
     for i, (w, h) in enumerate(GPU_SIZES):
-        if name in ("uyvy_to_nv12", "uyvy_to_i420", "v210_to_p010le") and (w % 2 or h % 2 or (name == "v210_to_p010le" and w % 6)):
+        if name in ("uyvy_to_nv12", "uyvy_to_i420") and (w % 2 or h % 2):
             continue
+        if name == "v210_to_p010le" and w % 6 and h < 5:
+            continue  # refused: the reference reads in front of its planes there (to_planar.c:142-148 with y < 4)
         for misalign in (False, True):
             src = to_case(name, w, h, 3 * i + misalign)
             want = PO.to_planar(name, src, w, h)

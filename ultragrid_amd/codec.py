@@ -117,11 +117,13 @@ def uyvy_to_i420(src: torch.Tensor, w: int, h: int):
     return y, u, v
 
 
-def v210_to_p010le(src: torch.Tensor, w: int, h: int):
+def v210_to_p010le(src: torch.Tensor, w: int, h: int, y_pad: int = 0, uv_pad: int = 0, fill: int = 0):
+    """v210_to_p010le (to_planar.c:64-155), any geometry; planes of h x (w + y_pad) and ceil(h / 2) x (w + uv_pad) int16 samples
+    (the pads are line padding the reference's whole-group writes reach), pre-filled with `fill`."""
     src = _u8(src)
-    y = torch.zeros((h, w), dtype=torch.int16, device=src.device)
-    uv = torch.zeros((h // 2, w), dtype=torch.int16, device=src.device)
-    rc = L.load().ug_hip_v210_to_p010le(src.data_ptr(), 0, y.data_ptr(), 2 * w, uv.data_ptr(), 2 * w, w, h, _stream())
+    y = torch.full((h, w + y_pad), fill, dtype=torch.int16, device=src.device)
+    uv = torch.full(((h + 1) // 2, w + uv_pad), fill, dtype=torch.int16, device=src.device)
+    rc = L.load().ug_hip_v210_to_p010le(src.data_ptr(), 0, y.data_ptr(), 2 * (w + y_pad), uv.data_ptr(), 2 * (w + uv_pad), w, h, _stream())
     L.check(rc, "ug_hip_v210_to_p010le")
     return y, uv
 

@@ -604,7 +604,8 @@ __global__ __launch_bounds__(256) void uyvy_to_i420_fast(const uint8_t *__restri
         ((uint32_t *) (up + (long) i * upitch))[c] = uu;
         ((uint32_t *) (vp + (long) i * vpitch))[c] = vv;
 }
-// v210_to_p010le, to_planar.c:64-155 (width % 6 == 0, even height): lane = one 6-px group of a row pair
+// v210_to_p010le, to_planar.c:64-155, the aligned regular case (width % 6 == 0, even height, 4-byte aligned planes): lane = one 6-px
+// group of a row pair, three 32-bit stores per line
 __global__ __launch_bounds__(256) void v210_to_p010le_kernel(const uint8_t *__restrict__ src, int spitch, uint8_t *__restrict__ yp,
                                                              int ypitch, uint8_t *__restrict__ uvp, int uvpitch, int gpl, long total)
 {
@@ -635,6 +636,91 @@ __global__ __launch_bounds__(256) void v210_to_p010le_kernel(const uint8_t *__re
         uint32_t *dc = (uint32_t *) (uvp + (long) i * uvpitch) + 3 * g;
 #pragma unroll
         for (int k = 0; k < 3; k++) { d0[k] = o0[k]; d1[k] = o1[k]; dc[k] = oc[k]; }
+}
+
+// One v210 group (4 words) -> its six luma samples and six chroma samples (Cb Cr Cb Cr Cb Cr), 10 bits each
+__device__ __forceinline__ void v210_group_samples(const uint32_t *__restrict__ row, int g, uint32_t luma[6], uint32_t chroma[6])
+{
+        const uint32_t w[4] = { row[4 * g], row[4 * g + 1], row[4 * g + 2], row[4 * g + 3] };
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+                luma[s] = (w[(2 * s + 1) / 3] >> (10 * ((2 * s + 1) % 3))) & 0x3ffu;
+                chroma[s] = (w[(2 * s) / 3] >> (10 * ((2 * s) % 3))) & 0x3ffu;
+        }
+}
+
+// v210_to_p010le for every geometry the reference converts (to_planar.c:64-155) with width >= 6: lane = one 6-px group of a row pair,
+// ceil(width / 6) groups per line.  What the reference's serial loop leaves in memory, restated per lane:
+//  * pairs with more than two lines below them ("interior", :85-89 w = roundup6(width)) write the WHOLE last group, i.e. up to 5
+//    samples past `width`.  With a pitch shorter than roundup6(width) samples, the even line's tail lands on the first samples of
+//    the odd line of the same pair and is written AFTER them (:113-125 run group by group), so it stays; the odd line's tail and
+//    the chroma tail land on lines the next pair rewrites, so they do not.
+//  * the last pair (one or two lines, :87-89 w = width) converts width / 6 whole groups; the width % 6 samples behind them are
+//    copied (:139-150) from `dst - out_linesize` -- a uint16_t pointer moved by a BYTE count, i.e. from two lines above: luma of
+//    both lines from line y - 2, chroma from chroma line y/2 - 2.  Those hold the own samples of interior pairs.
+//  * an odd last line is converted alone (:80-83): its chroma is (c + c) / 2.
+__global__ __launch_bounds__(256) void v210_to_p010le_any_kernel(const uint8_t *__restrict__ src, int spitch, uint16_t *__restrict__ yp,
+                                                                 int lw, uint16_t *__restrict__ uvp, int lc, int width, int height,
+                                                                 int gpl, long total)
+{
+        const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= total) return;
+        const int i = (int) (idx / gpl), g = (int) (idx - (long) i * gpl);
+        const int y = 2 * i, rem = height - y, whole = width / 6;
+        const bool last = rem <= 2, margin = last && g >= whole;
+        const int ra = margin ? y - 2 : y, rb = margin ? y - 2 : (rem == 1 ? y : y + 1); // luma source lines
+        const int ca = margin ? y - 4 : ra, cb = margin ? y - 3 : rb;                    // chroma source lines
+        uint32_t la[6], lb[6], ua[6], ub[6];
+        v210_group_samples((const uint32_t *) (src + (long) ra * spitch), g, la, ua);
+        v210_group_samples((const uint32_t *) (src + (long) rb * spitch), g, lb, ub);
+        if (margin) {
+                uint32_t unused[6];
+                v210_group_samples((const uint32_t *) (src + (long) ca * spitch), g, unused, ua);
+                v210_group_samples((const uint32_t *) (src + (long) cb * spitch), g, unused, ub);
+        }
+        const int n = margin ? width - 6 * whole : 6;
+        const int over = 6 * gpl - lw; // samples of an interior even line that run into the odd line
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+                const int col = 6 * g + s;
+                const uint16_t c = (uint16_t) (((ua[s] + ub[s]) / 2) << 6);
+                if (!last) {
+                        yp[(long) y * lw + col] = (uint16_t) (la[s] << 6); // col >= lw: the first samples of line y + 1
+                        if (col >= over && col < lw) yp[(long) (y + 1) * lw + col] = (uint16_t) (lb[s] << 6);
+                        if (col < lc) uvp[(long) i * lc + col] = c;
+                } else if (s < n) {
+                        yp[(long) y * lw + col] = (uint16_t) (la[s] << 6);
+                        if (rem == 2) yp[(long) (y + 1) * lw + col] = (uint16_t) (lb[s] << 6);
+                        uvp[(long) i * lc + col] = c;
+                }
+        }
+}
+
+// width < 6 (one group per line, no whole group on the last pair): the tails of BOTH luma lines overlap their neighbours and the
+// last pair is nothing but the copy from two lines above, so the outcome depends on the order of the writes -- one lane walks the
+// picture in the reference's order (to_planar.c:72-151).  Frames this narrow are a few hundred bytes.  With a pitch below 6 samples
+// the reference's last tails run past the end of its planes; those writes are dropped here (yend / uvend = samples in the plane).
+__global__ void v210_to_p010le_narrow_kernel(const uint8_t *__restrict__ src, int spitch, uint16_t *yp, int lw, uint16_t *uvp, int lc,
+                                             int width, int height)
+{
+        if (blockIdx.x || threadIdx.x) return;
+        const long yend = (long) height * lw, uvend = (long) ((height + 1) / 2) * lc;
+        for (int y = 0; y < height; y += 2) {
+                const int rem = height - y;
+                const long p0 = (long) y * lw, p1 = p0 + lw, pc = (long) (y / 2) * lc;
+                if (rem > 2) {
+                        uint32_t la[6], lb[6], ua[6], ub[6];
+                        v210_group_samples((const uint32_t *) (src + (long) y * spitch), 0, la, ua);
+                        v210_group_samples((const uint32_t *) (src + (long) (y + 1) * spitch), 0, lb, ub);
+                        for (int s = 0; s < 6; s++) if (p0 + s < yend) yp[p0 + s] = (uint16_t) (la[s] << 6);
+                        for (int s = 0; s < 6; s++) if (p1 + s < yend) yp[p1 + s] = (uint16_t) (lb[s] << 6);
+                        for (int s = 0; s < 6; s++) if (pc + s < uvend) uvp[pc + s] = (uint16_t) (((ua[s] + ub[s]) / 2) << 6);
+                } else {
+                        for (int s = 0; s < width; s++) yp[p0 + s] = yp[p0 + s - 2 * (long) lw];
+                        if (rem == 2) for (int s = 0; s < width; s++) yp[p1 + s] = yp[p0 + s - 2 * (long) lw];
+                        for (int s = 0; s < width; s++) uvp[pc + s] = uvp[pc + s - 2 * (long) lc];
+                }
+        }
 }
 
 // cuda_yuv422_to_yuv444 (cuda_dxt.cu:697-732): lane = 4 px (8 B -> 12 B)
@@ -816,18 +902,35 @@ int ug_hip_v210_to_p010le(const void *src, int src_pitch, void *y, int y_pitch, 
                           int height, ug_hip_stream_t stream)
 {
         if (!src || !y || !uv || width <= 0 || height <= 0) return UG_HIP_EINVAL;
-        if (width % 6 || height % 2) { // the reference's ragged-edge path (copy from the line above) is not provided
-                ug::set_last_error_msg("ug_hip_v210_to_p010le: width % 6 == 0 and even height required");
-                return UG_HIP_EUNSUPP;
-        }
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_V210, width);
-        if ((src_pitch & 15) || (y_pitch & 3) || (uv_pitch & 3) || (15 & (uintptr_t) src) || (3 & (uintptr_t) y) || (3 & (uintptr_t) uv)) {
+        const int gpl = (width + 5) / 6;
+        // to_planar.c:68-70 asserts a 4-byte aligned source and even output line sizes; a line must hold its own samples
+        if ((src_pitch & 3) || src_pitch < 16 * gpl || (y_pitch & 1) || (uv_pitch & 1) || y_pitch < 2 * width || uv_pitch < 2 * width ||
+            (3 & (uintptr_t) src) || (1 & (uintptr_t) y) || (1 & (uintptr_t) uv)) {
+                ug::set_last_error_msg("ug_hip_v210_to_p010le: misaligned plane, odd output pitch, or a pitch shorter than the line");
                 return UG_HIP_EINVAL;
         }
-        const int gpl = width / 6;
-        const long total = (long) gpl * (height / 2);
-        hipLaunchKernelGGL(v210_to_p010le_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                           (const uint8_t *) src, src_pitch, (uint8_t *) y, y_pitch, (uint8_t *) uv, uv_pitch, gpl, total);
+        if (width % 6 && height < 5) {
+                // to_planar.c:142-148 copies the width % 6 margin from two lines (two chroma lines) above: with fewer than 5 lines
+                // the reference reads in front of its output planes -- there is no defined result to reproduce
+                ug::set_last_error_msg("ug_hip_v210_to_p010le: width % 6 != 0 needs at least 5 lines (the reference reads out of bounds)");
+                return UG_HIP_EUNSUPP;
+        }
+        hipStream_t st = (hipStream_t) stream;
+        if (width % 6 == 0 && height % 2 == 0 && !((src_pitch & 15) || (y_pitch & 3) || (uv_pitch & 3) || (15 & (uintptr_t) src) ||
+                                                    (3 & (uintptr_t) y) || (3 & (uintptr_t) uv))) {
+                const long total = (long) gpl * (height / 2);
+                hipLaunchKernelGGL(v210_to_p010le_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
+                                   (const uint8_t *) src, src_pitch, (uint8_t *) y, y_pitch, (uint8_t *) uv, uv_pitch, gpl, total);
+        } else if (width < 6) {
+                hipLaunchKernelGGL(v210_to_p010le_narrow_kernel, dim3(1), dim3(1), 0, st, (const uint8_t *) src, src_pitch, (uint16_t *) y,
+                                   y_pitch / 2, (uint16_t *) uv, uv_pitch / 2, width, height);
+        } else {
+                const long total = (long) gpl * ((height + 1) / 2);
+                hipLaunchKernelGGL(v210_to_p010le_any_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
+                                   (const uint8_t *) src, src_pitch, (uint16_t *) y, y_pitch / 2, (uint16_t *) uv, uv_pitch / 2, width,
+                                   height, gpl, total);
+        }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
