@@ -381,7 +381,8 @@ int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, cons
  * The component planes equal libjpeg's bit for bit (integer IDCT jidctint).  `jpeg_host` is host memory (compressed frames arrive from the
  * network); everything after the header parse is asynchronous on `stream` (a stream in pinned memory is read by the copy engine when the stream
  * gets there: keep it until then; pageable memory is staged before the call returns).  UG_PF_NONE: decode to the internal planes only
- * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout: UG_HIP_EUNSUPP.  Damage inside the entropy-coded data is not
+ * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout (incl. a second frame header, or a table redefined between
+ * the scans of a one-scan-per-component stream): UG_HIP_EUNSUPP.  Damage inside the entropy-coded data is not
  * an error: a segment ends at its first marker, a missing one decodes as an empty one (what a sequential decoder does).  A decoder object
  * holds the work buffers of one frame in flight: one object per thread / per frame in flight. */
 typedef struct ug_hip_jpeg_decoder ug_hip_jpeg_decoder;
@@ -391,6 +392,11 @@ void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec);
 int  ug_hip_jpeg_read_info(const void *jpeg_host, size_t len, int *width, int *height, int *subsampling, int *is_rgb, int *restart_interval);
 int  ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, size_t len, ug_pixfmt_t out, void *dst_dev, int dst_pitch,
                                 int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+/* The same with the picture size the caller sized `dst_dev` for (0 = not checked): a stream whose frame header says otherwise is refused
+ * with UG_HIP_EINVAL before anything is written -- streams come from the network, and the size check must not depend on two separate
+ * header parses (ug_hip_jpeg_read_info, then this) agreeing. */
+int  ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_host, size_t len, int expect_width, int expect_height,
+                                      ug_pixfmt_t out, void *dst_dev, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
 /* component plane of the last decode (device memory, padded to whole MCUs; width / height = the component's own size) */
 int  ug_hip_jpeg_decoder_plane(const ug_hip_jpeg_decoder *dec, int component, const void **plane_dev, int *pitch, int *width, int *height);
 

@@ -108,6 +108,63 @@ def test_one_scan_per_component(hip, po, ri):
     dec.close()
 
 
+def test_frame_header_or_tables_between_scans_are_refused(hip, po):
+    """ADVICE r2 (high, low): in a stream with one scan per component the second header parse walks past the first SOS.  A frame header there
+    (new width / height / component count after the caller's size check, under scans already recorded) is refused, as libjpeg refuses it; so
+    is a Huffman or quantisation table that an earlier scan used and a later segment redefines (one table set is uploaded per frame).  And
+    the size the destination was made for is checked by the decoder itself."""
+    import ctypes as C
+    import torch
+    from jpeg_bitstream import write_jpeg_noninterleaved
+    from ultragrid_amd import lib as L
+    w, h = 150, 70
+    rgb = picture(w, h, seed=4)
+    ql = po.jpeg_qtable(85, 0)
+    coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(rgb[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+    data = bytearray(write_jpeg_noninterleaved(w, h, ql, coefs, restart=5))
+    dec = hip.JpegDecoder()
+    good = dec.decode(bytes(data), L.PF_RGB).cpu().numpy()
+    sof = data.index(b"\xff\xc0")
+    sof_seg = bytes(data[sof:sof + 2 + int.from_bytes(data[sof + 2:sof + 4], "big")])
+    big = bytearray(sof_seg)
+    big[5:7], big[7:9] = (4096).to_bytes(2, "big"), (4096).to_bytes(2, "big")    # 4096 x 4096 where the caller allocated 150 x 70
+    dht = data.index(b"\xff\xc4")
+    dht_seg = bytes(data[dht:dht + 2 + int.from_bytes(data[dht + 2:dht + 4], "big")])
+    dqt = data.index(b"\xff\xdb")
+    dqt_seg = bytes(data[dqt:dqt + 2 + int.from_bytes(data[dqt + 2:dqt + 4], "big")])
+    second_sos = data.index(b"\xff\xda", data.index(b"\xff\xda") + 2)
+    lib = L.load()
+    dst = torch.full((w * h * 3 + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    for extra in (bytes(big), sof_seg, dht_seg, dqt_seg):
+        bad = bytes(data[:second_sos]) + extra + bytes(data[second_sos:])
+        rc = lib.ug_hip_jpeg_decoder_decode(dec._h, bad, len(bad), L.PF_RGB, dst.data_ptr(), 0, 0, 8, 16, None)
+        torch.cuda.synchronize()
+        assert rc == L.EUNSUPP, extra[:2]
+        assert (dst[w * h * 3:] == 0xEE).all()
+    # the size check of the decoder itself: a destination made for another picture size
+    assert lib.ug_hip_jpeg_decoder_decode_sized(dec._h, bytes(data), len(data), w, h + 2, L.PF_RGB, dst.data_ptr(), 0, 0, 8, 16, None) == L.EINVAL
+    assert lib.ug_hip_jpeg_decoder_decode_sized(dec._h, bytes(data), len(data), w, h, L.PF_RGB, dst.data_ptr(), 0, 0, 8, 16, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(dst[: w * h * 3].cpu().numpy(), good)
+    dec.close()
+
+
+def test_greyscale_planes_ignore_the_sampling_factors(hip, po):
+    """a one-component scan is not interleaved whatever its factors say (T.81 A.2.2): 2x2 decodes to the plane 1x1 decodes to."""
+    rng = np.random.default_rng(5)
+    b = io.BytesIO()
+    Image.fromarray((rng.random((37, 50)) * 255).astype(np.uint8), "L").save(b, "JPEG", quality=85)
+    d = bytearray(b.getvalue())
+    want = np.asarray(Image.open(io.BytesIO(bytes(d))))
+    dec = hip.JpegDecoder()
+    one = dec.planes(bytes(d))[0].cpu().numpy()
+    sof = d.index(b"\xff\xc0")
+    d[sof + 11] = 0x22
+    two = dec.planes(bytes(d))[0].cpu().numpy()
+    dec.close()
+    assert one.shape == (37, 50) and np.array_equal(one, two) and np.array_equal(one, want)
+
+
 def test_full_4k_frame_and_rejections(hip, po):
     import torch
     from ultragrid_amd import lib as L, synth

@@ -67,3 +67,69 @@ def test_over_subscribed_huffman_table_is_refused():
     sof = d.index(b"\xff\xc0")
     d[sof + 5:sof + 7] = (40000).to_bytes(2, "big")   # a height no video frame has
     assert lib.ug_hip_jpeg_read_info(bytes(d), len(d), None, None, None, None, None) != 0
+
+
+def _guarded(data: bytes):
+    """(mmap, address) with `data` ending on the last byte before an inaccessible page"""
+    libc = C.CDLL(None, use_errno=True)
+    page = mmap.PAGESIZE
+    npages = (len(data) + page - 1) // page + 1
+    m = mmap.mmap(-1, (npages + 1) * page)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert libc.mprotect(C.c_void_p(base + npages * page), C.c_size_t(page), 0) == 0
+    off = npages * page - len(data)
+    m[off:off + len(data)] = data
+    return m, base + off
+
+
+def _seed(subsampling=2, **kw):
+    rng = np.random.default_rng(11)
+    b = io.BytesIO()
+    Image.fromarray((rng.random((32, 48, 3)) * 255).astype(np.uint8)).save(b, "JPEG", quality=85, subsampling=subsampling, **kw)
+    return bytearray(b.getvalue())
+
+
+def test_stream_ending_in_an_sos_of_length_two():
+    """a stream that ends in FF DA 00 02 behind a valid frame header passes the segment-length check with the scan header's
+    first byte one past the buffer.  Deterministic guard-page case (the random mutations above do not produce this exact truncation)."""
+    from ultragrid_amd import lib as L
+    lib = L.load()
+    d = _seed()
+    sos = d.index(b"\xff\xda")
+    for tail in (b"\xff\xda\x00\x02", b"\xff\xda\x00\x03\x03", b"\xff\xda\x00\x07\x03\x01\x00\x02\x11"):
+        data = bytes(d[:sos]) + tail
+        m, addr = _guarded(data)
+        assert lib.ug_hip_jpeg_read_info(C.c_void_p(addr), len(data), None, None, None, None, None) != 0
+        del m
+
+
+def test_second_frame_header_is_refused():
+    """one SOF0 per stream.  A second one with 1x1 factors behind a 2x2 one used to leave the MCU grid of the first under
+    the sampling of the second (planes a quarter of the size the output kernels then read); libjpeg refuses a duplicate SOF."""
+    from ultragrid_amd import lib as L
+    lib = L.load()
+    d = _seed(subsampling=2)
+    sof = d.index(b"\xff\xc0")
+    seglen = int.from_bytes(d[sof + 2:sof + 4], "big")
+    second = bytearray(d[sof:sof + 2 + seglen])
+    assert second[11] == 0x22
+    second[11] = 0x11                               # luma factors 1x1
+    data = bytes(d[:sof + 2 + seglen] + second + d[sof + 2 + seglen:])
+    assert lib.ug_hip_jpeg_read_info(bytes(d), len(d), None, None, None, None, None) == 0
+    assert lib.ug_hip_jpeg_read_info(data, len(data), None, None, None, None, None) != 0
+
+
+def test_greyscale_sampling_factors_are_ignored():
+    """a one-component frame is never interleaved, whatever its factors say (T.81 A.2.2): 2x2 must read as 4:0:0 of the same size."""
+    from ultragrid_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    b = io.BytesIO()
+    Image.fromarray((rng.random((24, 40)) * 255).astype(np.uint8), "L").save(b, "JPEG", quality=85)
+    d = bytearray(b.getvalue())
+    sof = d.index(b"\xff\xc0")
+    assert d[sof + 9] == 1 and d[sof + 11] == 0x11
+    d[sof + 11] = 0x22
+    w, h, sub = C.c_int(), C.c_int(), C.c_int()
+    assert lib.ug_hip_jpeg_read_info(bytes(d), len(d), C.byref(w), C.byref(h), C.byref(sub), None, None) == 0
+    assert (w.value, h.value, sub.value) == (40, 24, 400)

@@ -341,7 +341,9 @@ class JpegDecoder:
         w, h = info["width"], info["height"]
         n = w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2) if out_fmt == L.PF_I420 else linesize(out_fmt, w) * h
         dst = torch.empty(n, dtype=torch.uint8, device=device)
-        L.check(L.load().ug_hip_jpeg_decoder_decode(self._h, data, len(data), out_fmt, dst.data_ptr(), 0, *shifts, _stream()), "ug_hip_jpeg_decoder_decode")
+        # _sized: dst was made for the size the first look at the headers gave; the decoder refuses a stream whose own parse says otherwise
+        L.check(L.load().ug_hip_jpeg_decoder_decode_sized(self._h, data, len(data), w, h, out_fmt, dst.data_ptr(), 0, *shifts, _stream()),
+                "ug_hip_jpeg_decoder_decode_sized")
         return dst
 
     def planes(self, data: bytes):

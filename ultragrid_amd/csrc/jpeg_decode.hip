@@ -111,10 +111,22 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                         for (size_t o = 0; o + 65 <= seglen - 2; o += 65) {
                                 const int pq = s[o] >> 4, t = s[o] & 15;
                                 if (pq != 0 || t > 3) return -1;
+                                // One table set is uploaded for the whole frame.  A table redefined between the scans of a stream with one
+                                // scan per component would have to be applied per scan, as libjpeg does: such streams are refused rather than
+                                // decoded with the wrong table (UltraGrid's senders write all tables in front of the first scan).
+                                for (const Scan &done : h.scans) {
+                                        for (int k = 0; k < done.ns; k++) {
+                                                if (h.tq[done.comp[k]] == t) return -1;
+                                        }
+                                }
                                 for (int k = 0; k < 64; k++) h.qt[t][kZigzagHost[k]] = s[o + 1 + k];
                         }
                 } else if (m == 0xC0) {
+                        // one frame header per stream, in front of the first scan (T.81 B.2.1; libjpeg refuses both a duplicate SOF and one behind an SOS):
+                        // a later one would change the geometry under the scans already recorded and under the caller's size check
+                        if (h.width || !h.scans.empty()) return -1;
                         if (seglen < 8 || s[0] != 8) return -1;
+                        h.hmax = h.vmax = 1;
                         h.height = s[1] << 8 | s[2];
                         h.width = s[3] << 8 | s[4];
                         h.ncomp = s[5];
@@ -129,6 +141,7 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                                 h.hmax = h.hs[c] > h.hmax ? h.hs[c] : h.hmax;
                                 h.vmax = h.vs[c] > h.vmax ? h.vs[c] : h.vmax;
                         }
+                        if (h.ncomp == 1) h.hs[0] = h.vs[0] = h.hmax = h.vmax = 1; // one component is never interleaved: its factors mean nothing (T.81 A.2.2; libjpeg does the same)
                         h.mcu_w = (h.width + 8 * h.hmax - 1) / (8 * h.hmax);
                         h.mcu_h = (h.height + 8 * h.vmax - 1) / (8 * h.vmax);
                 } else if (m >= 0xC1 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
@@ -137,6 +150,11 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                         for (size_t o = 0; o + 17 <= seglen - 2;) {
                                 const int tc = s[o] >> 4, th = s[o] & 15;
                                 if (th > 3 || tc > 1) return -1;
+                                for (const Scan &done : h.scans) { // see DQT above: no per-scan table sets
+                                        for (int k = 0; k < done.ns; k++) {
+                                                if ((tc ? done.ta[k] : done.td[k]) == th) return -1;
+                                        }
+                                }
                                 HuffHost &t = tc ? h.ac[th] : h.dc[th];
                                 int n = 0, code = 0;
                                 t.bits[0] = 0;
@@ -158,7 +176,7 @@ int parse(const uint8_t *data, size_t len, Header &h, ParseMode mode)
                 } else if (m == 0xEE && seglen >= 14 && memcmp(s, "Adobe", 5) == 0) {
                         h.adobe = s[11];
                 } else if (m == 0xDA) {
-                        if (!h.width) return -1;
+                        if (!h.width || seglen < 8) return -1; // (seglen 2 would put s[0] behind the buffer)
                         Scan sc;
                         sc.ns = s[0];
                         if (sc.ns < 1 || sc.ns > h.ncomp || seglen < (size_t) 6 + 2 * sc.ns) return -1;
@@ -750,8 +768,14 @@ int ug_hip_jpeg_read_info(const void *jpeg_host, size_t len, int *width, int *he
 int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, size_t len, ug_pixfmt_t out, void *dst_dev, int dst_pitch, int rshift, int gshift,
                                int bshift, ug_hip_stream_t stream)
 {
+        return ug_hip_jpeg_decoder_decode_sized(dec, jpeg_host, len, 0, 0, out, dst_dev, dst_pitch, rshift, gshift, bshift, stream);
+}
+
+int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_host, size_t len, int expect_width, int expect_height, ug_pixfmt_t out,
+                                     void *dst_dev, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
+{
         Decoder *d = (Decoder *) dec;
-        if (!d || !jpeg_host || (!dst_dev && out != UG_PF_NONE)) {
+        if (!d || !jpeg_host || (!dst_dev && out != UG_PF_NONE) || expect_width < 0 || expect_height < 0) {
                 ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: bad arguments");
                 return UG_HIP_EINVAL;
         }
@@ -772,6 +796,11 @@ int ug_hip_jpeg_decoder_decode(ug_hip_jpeg_decoder *dec, const void *jpeg_host, 
         if (len > 0xFFFFFFF0u) {
                 ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: stream too long");
                 return UG_HIP_EUNSUPP;
+        }
+        // the caller sized dst_dev for this picture: the headers as THIS parse read them must agree, whatever an earlier parse said
+        if ((expect_width && h.width != expect_width) || (expect_height && h.height != expect_height)) {
+                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: the stream's picture size is not the size the destination was made for");
+                return UG_HIP_EINVAL;
         }
         for (int c = 1; c < h.ncomp; c++) { // the sampling layouts the output stage knows: 4:4:4, 4:2:2, 4:2:0
                 if (h.hs[c] != 1 || h.vs[c] != 1) {

@@ -98,6 +98,7 @@ SYMBOLS = {
     "ug_hip_jpeg_decoder_destroy": (None, [_vp]),
     "ug_hip_jpeg_read_info": (_i, [_vp, _sz, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "ug_hip_jpeg_decoder_decode": (_i, [_vp, _vp, _sz, _i, _vp, _i, _i, _i, _i, _vp]),
+    "ug_hip_jpeg_decoder_decode_sized": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "ug_hip_jpeg_decoder_plane": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "ug_hip_jpeg_encoder_encode": (_i, [_vp, _i, _vp, _i, _vp, _sz, C.POINTER(_sz), _vp]),
 }

@@ -32,13 +32,18 @@ struct state_decompress_jpeg_mi355x {
         size_t               out_len;
 };
 
+static void jpeg_mi355x_decompress_done(void *state);
+
 static void *jpeg_mi355x_decompress_init(void)
 {
         struct state_decompress_jpeg_mi355x *s = calloc(1, sizeof *s);
+        if (s == NULL) {
+                return NULL;
+        }
         if (ug_hip_set_device(0) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS ||
             ug_hip_jpeg_decoder_create(&s->dec) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "cannot set up the decoder on HIP device 0: %s\n", ug_hip_last_error_string());
-                free(s);
+                jpeg_mi355x_decompress_done(s); // releases whichever of the two was made
                 return NULL;
         }
         return s;
@@ -112,14 +117,17 @@ static decompress_status jpeg_mi355x_decompress(void *state, unsigned char *dst,
                 MSG(ERROR, "not a JPEG frame of the configured size %ux%u\n", s->desc.width, s->desc.height);
                 return DECODER_NO_FRAME;
         }
-        if (ug_hip_jpeg_decoder_decode(s->dec, buffer, src_len, s->out_fmt, s->dev_out, 0, s->rshift, s->gshift, s->bshift, s->stream) != UG_HIP_SUCCESS) {
+        // _sized: the decoder checks the frame header IT parses against the size dev_out was allocated for (a stream with one scan per component
+        // is parsed a second time, further than ug_hip_jpeg_read_info looks)
+        if (ug_hip_jpeg_decoder_decode_sized(s->dec, buffer, src_len, (int) s->desc.width, (int) s->desc.height, s->out_fmt, s->dev_out, 0, s->rshift,
+                                             s->gshift, s->bshift, s->stream) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "decode failed: %s\n", ug_hip_last_error_string());
                 ug_hip_stream_sync(s->stream);
                 return DECODER_NO_FRAME;
         }
         const int linesize = s->out_codec == I420 ? 0 : vc_get_linesize(s->desc.width, s->out_codec);
         bool ok = true;
-        if (s->out_codec == I420 || s->pitch == linesize) {
+        if (s->out_codec == I420 || s->pitch == linesize) { // I420: three planes back to back; `pitch` has no meaning for it and is not used
                 ok = ug_hip_memcpy_async(dst, s->dev_out, s->out_len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) == UG_HIP_SUCCESS;
         } else { // display pitch differs from the packed line size (gpujpeg.c:296-319 does a CPU line loop here)
                 for (unsigned i = 0; i < s->desc.height && ok; i++) {

@@ -36,15 +36,20 @@ struct state_decompress_jpeg_to_dxt_mi355x {
         size_t               dxt_len;
 };
 
+static void jpeg_to_dxt_mi355x_decompress_done(void *state);
+
 static void *jpeg_to_dxt_mi355x_decompress_init(void)
 {
         struct state_decompress_jpeg_to_dxt_mi355x *s = calloc(1, sizeof *s);
+        if (s == NULL) {
+                return NULL;
+        }
         const char *ties = getenv("UG_MI355X_DXT_TIES");
         s->ties = ties != NULL && strcmp(ties, "even") == 0 ? UG_DXT_TIES_EVEN : UG_DXT_TIES_AWAY;
         if (ug_hip_set_device(0) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS ||
             ug_hip_jpeg_decoder_create(&s->dec) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "cannot set up the decoder on HIP device 0: %s\n", ug_hip_last_error_string());
-                free(s);
+                jpeg_to_dxt_mi355x_decompress_done(s); // releases whichever of the two was made
                 return NULL;
         }
         return s;
@@ -101,7 +106,9 @@ static decompress_status jpeg_to_dxt_mi355x_decompress(void *state, unsigned cha
                 MSG(ERROR, "not a JPEG frame of the configured size %ux%u\n", s->desc.width, s->desc.height);
                 return DECODER_NO_FRAME;
         }
-        bool ok = ug_hip_jpeg_decoder_decode(s->dec, buffer, src_len, UG_PF_RGB, s->dev_rgb, 3 * w, 0, 8, 16, s->stream) == UG_HIP_SUCCESS &&
+        // _sized: the decoder checks the frame header IT parses against the size the buffers were allocated for
+        bool ok = ug_hip_jpeg_decoder_decode_sized(s->dec, buffer, src_len, (int) s->desc.width, (int) s->desc.height, UG_PF_RGB, s->dev_rgb, 3 * w, 0, 8, 16,
+                                                   s->stream) == UG_HIP_SUCCESS &&
                   ug_hip_dxt_encode_batch_ex(UG_PF_RGB, s->out_codec == DXT1 ? UG_DXT1 : UG_DXT5_YCOCG, s->dev_rgb, s->dev_dxt, w, -h, 3 * w, 1, 0, 0,
                                              s->ties, s->stream) == UG_HIP_SUCCESS &&
                   ug_hip_memcpy_async(dst, s->dev_dxt, s->dxt_len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) == UG_HIP_SUCCESS;
