@@ -647,3 +647,71 @@ def test_the_reference_unit_test_skips_without_a_device():
         pytest.skip("a GPU is present")
     r = subprocess.run([REF_UNIT_TEST], capture_output=True, text=True, timeout=60)
     assert r.returncode == 77 and "SKIPPED" in r.stdout, r.stdout + r.stderr
+
+
+# ---- the PLUGIN route of the boundary (VERDICT r2 missing #4): modules that arrive by dlopen only ---------------------------------------
+PLUGIN_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ug_plugin_harness")
+PLUGINS = ["ultragrid_vcompress_dxt.so", "ultragrid_vcompress_jpeg.so", "ultragrid_vdecompress_dxt_mi355x.so", "ultragrid_vdecompress_jpeg_mi355x.so",
+           "ultragrid_vdecompress_jpeg_to_dxt_mi355x.so"]
+needs_plugin_harness = pytest.mark.skipif(not os.path.exists(PLUGIN_HARNESS), reason="oracle/_ref/ug_plugin_harness not built (needs /root/reference)")
+
+
+def _installation(tmp_path):
+    """<tmp>/bin/ug_plugin_harness + <tmp>/lib/ultragrid/ultragrid_*.so: the layout open_all() searches relative to argv[0]
+    (lib_common.cpp:192-196).  Copies, not links; the kernel library is found through LD_LIBRARY_PATH as in an installation."""
+    import shutil
+    (tmp_path / "bin").mkdir()
+    (tmp_path / "lib" / "ultragrid").mkdir(parents=True)
+    shutil.copy(PLUGIN_HARNESS, tmp_path / "bin" / "ug_plugin_harness")
+    for p in PLUGINS:
+        shutil.copy(os.path.join(ROOT, "oracle", "_ref", p), tmp_path / "lib" / "ultragrid" / p)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "ultragrid_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+
+    def run(*args):
+        return subprocess.run([str(tmp_path / "bin" / "ug_plugin_harness")] + [str(a) for a in args], capture_output=True, text=True, timeout=60, env=env)
+    return run
+
+
+@needs_plugin_harness
+def test_plugins_load_through_open_all_and_register(tmp_path):
+    """lib_common.cpp:186-223 (-DBUILD_LIBRARIES): glob + dlopen(RTLD_NOW | RTLD_GLOBAL) of every ultragrid_*.so; RTLD_NOW means every
+    undefined symbol of a module resolved against the -rdynamic executable, and the REGISTER_MODULE constructors ran inside dlopen.  The
+    harness binary links no module object: without the plugins it knows no compression at all."""
+    run = _installation(tmp_path)
+    r = run("list")
+    assert r.returncode == 0 and "PLUGINS opened=5" in r.stdout, r.stdout + r.stderr
+    names = r.stdout.split()
+    for n in ("dxt", "jpeg", "gpujpeg", "dxt_mi355x", "jpeg_mi355x", "jpeg_to_dxt_mi355x"):
+        assert n in names, (n, r.stdout)
+    assert "opening warning" not in r.stdout + r.stderr
+    for p in PLUGINS:
+        (tmp_path / "lib" / "ultragrid" / p).unlink()
+    r = run("list")
+    assert r.returncode == 4 and "PLUGINS opened=0" in r.stdout
+
+
+@needs_plugin_harness
+@pytest.mark.gpu
+def test_frames_through_modules_that_arrived_by_dlopen(tmp_path, po):
+    """One frame each way through modules that exist in the process only because open_all() dlopen'ed them: compress_init("dxt:DXT5") ->
+    bit-equal to the oracle; decompress_init_multi(DXT5 -> RGBA) on those blocks -> bit-equal to the decoder oracle; `-c jpeg` then the JPEG
+    decompress plugin (probe first) -> the decode oracle's planes."""
+    run = _installation(tmp_path)
+    w, h = 192, 64
+    src = synth.s1_random("UYVY", w, h, salt=21)
+    raw, dxt, rgba = tmp_path / "in.raw", tmp_path / "out.dxt", tmp_path / "back.rgba"
+    src.tofile(raw)
+    r = run("compress", "dxt:DXT5", "UYVY", w, h, raw, dxt)
+    assert r.returncode == 0 and "PLUGINS opened=5" in r.stdout and "OK compress codec=DXT5" in r.stdout, r.stdout + r.stderr
+    blocks = np.fromfile(dxt, np.uint8)
+    assert np.array_equal(blocks, po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, src, w, h))
+    r = run("decompress", "DXT5", "RGBA", w, h, dxt, rgba)
+    assert r.returncode == 0 and "OK decompress DXT5 -> RGBA" in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(rgba, np.uint8), po.dxt_decode(po.OUT_DXT5YCOCG, "RGBA", blocks, w, h))
+    jpg, back = tmp_path / "f.jpg", tmp_path / "back.uyvy"
+    r = run("compress", "jpeg:q=85:restart=4", "UYVY", w, h, raw, jpg)
+    assert r.returncode == 0 and "OK compress codec=JPEG" in r.stdout, r.stdout + r.stderr
+    r = run("decompress", "JPEG", "UYVY", w, h, jpg, back)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, crop, _ = po.jpeg_decode_planes(jpg.read_bytes())
+    assert np.array_equal(np.fromfile(back, np.uint8), po.planar_to_uyvy(*crop, w, h, chroma=422))
