@@ -14,9 +14,10 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline     -- algorithmic bytes (3.0 B/px: 2 read + 1 written) x pixels per
                   launch / average launch duration measured with HIP events on the launch stream;
   e2e          -- the PCIe-inclusive rate (pinned host -> H2D -> kernel -> D2H, 3 frames in flight per GPU, all ranks at once) for
-                  8K v210 and 4K UYVY: fps per GPU and in total, PCIe GB/s -- reported beside `value`, never as `value`;
+                  8K UYVY (the target's literal configuration), 8K v210 and 4K UYVY: fps per GPU and in total, PCIe GB/s -- reported
+                  beside `value`, never as `value`;
   cpu_baseline -- the CPU oracle (oracle/dxt_oracle.c, "port": the reference has no CPU DXT encoder)
-                  timed on this box's host cores on a bounded sample (N=1 only).
+                  timed on this box's host cores on a bounded sample (rank 0, at every N).
 """
 from __future__ import annotations
 
@@ -188,6 +189,8 @@ def main() -> None:
     ap.add_argument("--e2e-seconds", type=float, default=2.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU smoke test of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="smoke test only: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group (RCCL) at world size 1 too, so that the barrier, "
+                    "agree_max, gather_rates and max-over-ranks collectives run on cuda tensors on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,9 +204,13 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist  # RCCL: used ONLY for the timing barrier + max-over-ranks, not on the data path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # --force-dist under plain `python bench.py`: a one-rank group
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -302,7 +309,8 @@ def main() -> None:
     if not args.no_e2e and out_name in ("DXT5", "DXT1"):
         del src, dst
         torch.cuda.empty_cache()
-        e2e = e2e_leg(["8k-v210", "4k-uyvy"], rank, dist, coll_dev, args.e2e_seconds)
+        # 8k-uyvy = the north star's literal target configuration (>= 60 fps 8K UYVY -> DXT5-YCoCg on one MI355X)
+        e2e = e2e_leg(["8k-uyvy", "8k-v210", "4k-uyvy"], rank, dist, coll_dev, args.e2e_seconds)
 
     if rank == 0:
         px_per_launch = F * W * H
@@ -364,7 +372,11 @@ def main() -> None:
         }
         if e2e is not None:
             out["e2e"] = e2e
-        if world == 1 and not args.no_cpu_baseline and out_name != "JPEG420":
+        if dist is not None:
+            out["config"]["dist"] = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""), "world": world,
+                                     "collectives": "barrier + all_reduce(MAX) around the timed steps, all_reduce(MAX) of the step size, all_gather of per-rank "
+                                                    "e2e rates; on " + coll_dev + " tensors; never frame data"}
+        if not args.no_cpu_baseline and out_name != "JPEG420":   # rank 0, at every world size (the other ranks wait in destroy_process_group)
             out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H, out=out_name)
             try:
                 ref = cpu_reference(wl["fmt"], W, H)

@@ -36,6 +36,35 @@ def test_single_gpu_line(hip):
     assert d["value"] <= px / (roof["ms_per_launch"] * 1e-3) / 1e6 * 1.02
     e = d["e2e"]
     assert e["8k-v210"]["fps_total"] > 60 and len(e["8k-v210"]["fps_per_gpu"]) == 1 and e["4k-uyvy"]["fps_total"] > 60   # the north star's floor, PCIe included
+    assert e["8k-uyvy"]["fps_total"] > 60 and e["8k-uyvy"]["bytes_in_per_frame"] == 7680 * 4320 * 2                       # the target's literal configuration
+    assert "dist" not in d["config"]
+
+
+def test_rccl_group_at_world_size_one(hip):
+    """the `nccl` (= RCCL) branch of bench.py -- init_process_group with a device id, barrier, all_reduce(MAX) of the step size
+    and of the wall time, all_gather of the e2e rates, all on cuda tensors -- runs here at world size 1, so that the driver's 8-GPU run is
+    not the first time any of it executes; and the CPU baseline is in the line whenever a group is up."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--launches-per-step", "8", "--e2e-seconds", "0.3",
+                        "--force-dist"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["dist"]["backend"].startswith("nccl") and d["config"]["dist"]["world"] == 1
+    assert "cuda" in d["config"]["dist"]["collectives"]
+    assert d["value"] > 0 and len(d["e2e"]["8k-uyvy"]["fps_per_gpu"]) == 1
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+
+
+def test_shard_collectives_on_cuda_tensors(hip):
+    """ultragrid_amd/shard.py's three collectives straight on an RCCL group of one rank (cuda tensors)."""
+    code = ("import os, torch, torch.distributed as dist; from ultragrid_amd import shard; "
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 2000), RANK='0', WORLD_SIZE='1'); "
+            "torch.cuda.set_device(0); dist.init_process_group('nccl', device_id=torch.device('cuda', 0)); "
+            "assert shard.agree_max(7, dist, 'cuda') == 7; assert shard.gather_rates([1.5, 2.5], dist, 'cuda') == [[1.5, 2.5]]; "
+            "w = shard.timed_steps(lambda: None, 3, torch.cuda.synchronize, dist, device='cuda'); assert 0 <= w < 5; "
+            "dist.destroy_process_group(); print('RCCL-OK')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_two_ranks_on_one_gpu_smoke(hip):
@@ -46,6 +75,7 @@ def test_two_ranks_on_one_gpu_smoke(hip):
                         "--dist-backend", "gloo", "--all-ranks-on-device0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["cpu_baseline"]["value"] > 0   # rank 0 times the CPU oracle at every world size
+    assert d["config"]["dist"]["world"] == 2 and d["config"]["dist"]["backend"] == "gloo"
     assert len(d["e2e"]["8k-v210"]["fps_per_gpu"]) == 2 and abs(sum(d["e2e"]["8k-v210"]["fps_per_gpu"]) - d["e2e"]["8k-v210"]["fps_total"]) < 0.2
     assert d["config"]["parallelism"].startswith("frames sharded over 2 GPU")

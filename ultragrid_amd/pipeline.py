@@ -14,6 +14,7 @@ from . import codec, lib, synth
 
 WORKLOADS = {
     "8k-v210": ("v210", lib.PF_V210, lib.DXT5_YCOCG, 7680, 4320),     # BASELINE.json configs[4]
+    "8k-uyvy": ("UYVY", lib.PF_UYVY, lib.DXT5_YCOCG, 7680, 4320),     # the north star's target: >= 60 fps 8K UYVY -> DXT5-YCoCg on one GPU
     "4k-uyvy": ("UYVY", lib.PF_UYVY, lib.DXT5_YCOCG, 3840, 2160),     # configs[2]
     "1080p-rgb-dxt1": ("RGB", lib.PF_RGB, lib.DXT1, 1920, 1080),      # configs[1]
 }
