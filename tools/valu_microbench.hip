@@ -113,7 +113,40 @@ __global__ __launch_bounds__(256) void benchp(float *out, int iters)
         out[blockIdx.x * blockDim.x + threadIdx.x] = p0.x + p1.y + p2.x + p3.y;
 }
 
+
+// fp64 / conversion / integer-multiply / LDS classes (the DXT decoders, dxt_decode.hip): operands are register pairs where the
+// instruction wants them.  UG_MB_F64=1
+#define BODYD(ASM)                                                                                        \
+        for (int it = 0; it < iters; it++) {                                                              \
+                REP8(asm volatile(ASM : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(e0), "v"(e1), "v"(j0), "v"(j1));) \
+        }
+template <int K>
+__global__ __launch_bounds__(256) void bench64(float *out, int iters)
+{
+        __shared__ double lds[2048];
+        for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = i;
+        __syncthreads();
+        double d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, e0 = 1.0000001, e1 = 0.9999999;
+        int i0 = threadIdx.x * 8, i1 = i0 + 1024, i2 = i0 + 2048, i3 = i0 + 4096, j0 = 12345, j1 = 777;
+        if (K == 0) BODYD("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %9\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %9\n v_add_f64 %0, %0, %9\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %9\n v_add_f64 %3, %3, %8")
+        if (K == 1) BODYD("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %9\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %9\n v_mul_f64 %0, %0, %9\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %9\n v_mul_f64 %3, %3, %8")
+        if (K == 2) BODYD("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %9, %8\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %9, %8\n v_fma_f64 %0, %0, %9, %8\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %9, %8\n v_fma_f64 %3, %3, %8, %9")
+        if (K == 3) BODYD("v_cvt_i32_f64 %4, %0\n v_cvt_i32_f64 %5, %1\n v_cvt_i32_f64 %6, %2\n v_cvt_i32_f64 %7, %3\n v_cvt_i32_f64 %4, %1\n v_cvt_i32_f64 %5, %0\n v_cvt_i32_f64 %6, %3\n v_cvt_i32_f64 %7, %2")
+        if (K == 4) BODYD("v_cvt_f64_i32 %0, %4\n v_cvt_f64_i32 %1, %5\n v_cvt_f64_i32 %2, %6\n v_cvt_f64_i32 %3, %7\n v_cvt_f64_u32 %0, %5\n v_cvt_f64_u32 %1, %4\n v_cvt_f64_u32 %2, %7\n v_cvt_f64_u32 %3, %6")
+        if (K == 5) BODYD("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3\n v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3")
+        if (K == 6) BODYD("v_rndne_f64 %0, %0\n v_trunc_f64 %1, %1\n v_rndne_f64 %2, %2\n v_trunc_f64 %3, %3\n v_rndne_f64 %0, %0\n v_floor_f64 %1, %1\n v_rndne_f64 %2, %2\n v_floor_f64 %3, %3")
+        if (K == 7) BODYD("v_mul_lo_u32 %4, %4, %10\n v_mul_lo_u32 %5, %5, %11\n v_mul_lo_u32 %6, %6, %10\n v_mul_lo_u32 %7, %7, %11\n v_mul_hi_u32 %4, %4, %10\n v_mul_hi_u32 %5, %5, %11\n v_mul_hi_u32 %6, %6, %10\n v_mul_hi_u32 %7, %7, %11")
+        if (K == 8) BODYD("v_med3_i32 %4, %4, %10, %11\n v_med3_i32 %5, %5, %11, %10\n v_med3_i32 %6, %6, %10, %11\n v_med3_i32 %7, %7, %11, %10\n v_min3_u32 %4, %4, %10, %11\n v_min3_u32 %5, %5, %11, %10\n v_min_u32 %6, %6, %10\n v_max_i32 %7, %7, %11")
+        if (K == 9) BODYD("ds_read_b32 %4, %4\n ds_read_b32 %5, %5\n ds_read_b32 %6, %6\n ds_read_b32 %7, %7\n s_waitcnt lgkmcnt(0)\n v_and_b32 %4, 0x3ff8, %4\n v_and_b32 %5, 0x3ff8, %5\n v_and_b32 %6, 0x3ff8, %6\n v_and_b32 %7, 0x3ff8, %7")
+        if (K == 10) BODYD("ds_read_b64 %0, %4\n ds_read_b64 %1, %5\n ds_read_b64 %2, %6\n ds_read_b64 %3, %7\n s_waitcnt lgkmcnt(0)\n v_xor_b32 %4, 8, %4\n v_xor_b32 %5, 8, %5\n v_xor_b32 %6, 8, %6\n v_xor_b32 %7, 8, %7")
+        if (K == 11) BODYD("v_cmp_gt_f64 vcc, %0, %8\n v_cmp_gt_f64 vcc, %1, %9\n v_cmp_gt_f64 vcc, %2, %8\n v_cmp_gt_f64 vcc, %3, %9\n v_cmp_gt_f64 vcc, %0, %9\n v_cmp_gt_f64 vcc, %1, %8\n v_cmp_gt_f64 vcc, %2, %9\n v_cmp_gt_f64 vcc, %3, %8")
+        if (K == 12) BODYD("v_mad_u64_u32 %0, vcc, %4, %10, %0\n v_mad_u64_u32 %1, vcc, %5, %11, %1\n v_mad_u64_u32 %2, vcc, %6, %10, %2\n v_mad_u64_u32 %3, vcc, %7, %11, %3\n v_mad_u64_u32 %0, vcc, %5, %10, %0\n v_mad_u64_u32 %1, vcc, %4, %11, %1\n v_mad_u64_u32 %2, vcc, %7, %10, %2\n v_mad_u64_u32 %3, vcc, %6, %11, %3")
+        if (K == 13) BODYD("v_cvt_pk_u8_f32 %4, %10, 1, %4\n v_cvt_pk_u8_f32 %5, %11, 2, %5\n v_cvt_pk_u8_f32 %6, %10, 3, %6\n v_cvt_pk_u8_f32 %7, %11, 0, %7\n v_cvt_pk_u8_f32 %4, %10, 0, %4\n v_cvt_pk_u8_f32 %5, %11, 1, %5\n v_cvt_pk_u8_f32 %6, %10, 2, %6\n v_cvt_pk_u8_f32 %7, %11, 3, %7")
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (float) (d0 + d1 + d2 + d3) + (float) (i0 + i1 + i2 + i3);
+}
+
 static int g_bpc = 8;
+static int g_scale = 1;   // kernels launched with iters / g_scale
 template <class F>
 static void run(const char *name, F launch)
 {
@@ -128,7 +161,7 @@ static void run(const char *name, F launch)
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double waves = 256.0 * g_bpc * 4;           // blocks * waves per block
-        const double instr = waves * iters * 64.0;         // 8 reps x 8 instructions
+        const double instr = waves * (iters / g_scale) * 64.0;         // 8 reps x 8 instructions
         const double per_s = instr / (ms * 1e-3);
         printf("%-28s %8.3f ms  %7.2f G wave-instr/s  = %5.3f wave-instr/clk/CU @2.4GHz (%.1f T lane-ops/s)\n", name, ms, per_s / 1e9,
                per_s / 256 / 2.4e9, per_s * 64 / 1e12);
@@ -153,5 +186,14 @@ int main()
         R("v_add_f32 (ref)", 0); R("v_cmp_gt_f32 (ref)", 3);
         if (getenv("UG_MB_INT")) { R("v_lshr/lshl/ashr_b32", 30); R("v_add/sub_u32", 31); R("v_alignbit_b32", 32); R("v_bfi_b32", 33); R("v_and_or_b32", 34); R("v_bcnt_u32_b32", 35);
         R("v_mul/mad_u32_u24", 36); R("v_sub_f32 + v_alignbit (dep)", 37); R("6 fast : 2 cmp", 38); R("4 cmp : 4 fast (blocked)", 39); R("v_lshl_add/add3/xad_u32", 40); R("v_cvt_f32_u32/i32", 41); R("v_or_b32_sdwa byte", 42); }
+#define R64(name, K) run(name, [&](int it) { hipLaunchKernelGGL(bench64<K>, g, b, 0, 0, out, it / 4); })
+        if (getenv("UG_MB_F64")) { // iters / 4: these are slow; the printed rate assumes `iters`, so multiply the printed rate by 1 (run() scales by its own iters) -- see below
+                g_scale = 4;
+                R64("v_add_f64", 0); R64("v_mul_f64", 1); R64("v_fma_f64", 2); R64("v_cvt_i32_f64", 3); R64("v_cvt_f64_i32/u32", 4); R64("v_rcp_f64", 5);
+                R64("v_rndne/trunc/floor_f64", 6); R64("v_mul_lo/hi_u32", 7); R64("v_med3_i32/min3_u32/min/max", 8); R64("v_cmp_gt_f64", 11); R64("v_mad_u64_u32", 12);
+                R64("v_cvt_pk_u8_f32", 13);
+                R64("ds_read_b32 x4 + 4 valu (instr = 8)", 9); R64("ds_read_b64 x4 + 4 valu (instr = 8)", 10);
+                g_scale = 1;
+        }
         return 0;
 }
