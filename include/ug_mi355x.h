@@ -366,6 +366,14 @@ void   ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc);
 size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc);
 int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch,
                                   void *out_dev, size_t out_capacity, size_t *out_len, ug_hip_stream_t stream);
+/* `frames` (1..16) frames of the same geometry in ONE call: the fused front end with grid.z = frame, the entropy coder and the
+ * compaction with grid.y = frame, one synchronisation, `frames` lengths.  Frame f is read at src_dev + f * src_stride and its stream
+ * written at out_dev + f * out_stride (a multiple of 16, >= out_capacity = what one stream may take); out_len[f] = its length.  Every
+ * stream is byte-identical to what ug_hip_jpeg_encoder_encode writes for that frame.  (gpujpeg.cpp:617-631 encodes one frame per
+ * call; this is for callers that hold several queued frames -- per-call launch + synchronise cost is ~14 us of a ~55 us 4K call.) */
+int    ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, int frames, const void *src_dev, int src_pitch,
+                                        size_t src_stride, void *out_dev, size_t out_stride, size_t out_capacity, size_t *out_len,
+                                        ug_hip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * JPEG decoder (receive side: gpujpeg_decoder_create / _decode / _destroy behind

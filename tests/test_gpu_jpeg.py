@@ -389,3 +389,55 @@ def test_block_parallel_coder_full_4k_frame(hip, po):
         del os.environ["UG_JPEG_WAVE_KERNEL"]
     assert da == db
     assert Image.open(io.BytesIO(da)).size == (w, h)
+
+
+@pytest.mark.parametrize("sub,fmt,ri", [(420, "UYVY", 4), (422, "UYVY", 4), (422, "UYVY", 40), (444, "RGB", 8), (420, "I420", 2)])
+def test_encode_batch_equals_single_frame_calls(hip, po, sub, fmt, ri):
+    """ug_hip_jpeg_encoder_encode_batch: n frames, grid.z / grid.y = frame, one synchronisation -- every stream byte-equal
+    to the single-frame call's, in order; a second batch on the same object (the alternating chunk totals), a smaller one, then a single
+    frame again; and a batch whose streams do not fit reports the needed sizes."""
+    import ctypes as C
+    import torch
+    from ultragrid_amd import lib as L
+    w, h, n = 208, 120, 5
+    rng = np.random.default_rng(sub + ri)
+    frames = []
+    for f in range(n):
+        rgb = np.clip(_smooth_rgb(w, h).astype(np.int32) + rng.integers(-12 * f, 12 * f + 1, (h, w, 3)), 0, 255).astype(np.uint8)
+        if fmt == "RGB":
+            frames.append(rgb.ravel())
+        else:
+            uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+            frames.append(uyvy if fmt == "UYVY" else np.concatenate([p.ravel() for p in po.uyvy_to_i420(uyvy, w, h)]))
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    pf = {"UYVY": L.PF_UYVY, "RGB": L.PF_RGB, "I420": L.PF_I420}[fmt]
+    single = hip.JpegEncoder(w, h, 80, ri, subsampling=sub)
+    want = [single.encode(dev[f], pf) for f in range(n)]
+    assert len({len(x) for x in want}) > 1          # the frames really differ
+    enc = hip.JpegEncoder(w, h, 80, ri, subsampling=sub)
+    assert enc.encode_batch(dev, pf) == want
+    assert enc.encode_batch(dev.flip(0).contiguous(), pf) == want[::-1]
+    assert enc.encode_batch(dev[1:3].contiguous(), pf) == want[1:3]
+    assert enc.encode(dev[4], pf) == want[4]
+    # too small an output: EINVAL and the needed sizes
+    lens = (C.c_size_t * n)()
+    cap = 1024
+    out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+    rc = L.load().ug_hip_jpeg_encoder_encode_batch(enc._h, pf, n, dev.data_ptr(), 0, dev.shape[1], out.data_ptr(), cap, cap, lens, None)
+    assert rc == L.EINVAL and [lens[f] for f in range(n)] == [len(x) for x in want]
+    assert L.load().ug_hip_jpeg_encoder_encode_batch(enc._h, pf, 17, dev.data_ptr(), 0, dev.shape[1], out.data_ptr(), cap, cap, lens, None) == L.EINVAL
+    enc.close()
+    single.close()
+
+
+def test_encode_batch_full_4k(hip, po):
+    """8 distinct 4K frames in one batch == 8 single calls (the size the throughput figure is quoted on)"""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h, n = 3840, 2160, 8
+    base = torch.from_numpy(synth.s2_video("UYVY", w, h)).cuda()
+    dev = torch.stack([torch.roll(base, 7680 * 37 * f) for f in range(n)])
+    enc = hip.JpegEncoder(w, h, 75, 4, subsampling=420)
+    want = [enc.encode(dev[f]) for f in range(n)]
+    assert enc.encode_batch(dev) == want
+    enc.close()

@@ -106,7 +106,7 @@ def test_rgb_444_streams_are_not_rtp_compatible_in_the_reference_either(po):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sub,ri,dims", [(422, 4, (1920, 1080)), (420, 4, (1920, 1080)), (422, 0, (200, 120)), (420, 7, (200, 120))])
+@pytest.mark.parametrize("sub,ri,dims", [(422, 4, (1920, 1080)), (420, 4, (1920, 1080)), (422, 1, (200, 120)), (420, 7, (200, 120))])
 def test_product_streams_pass_the_reference_rtp_gate(hip, po, sub, ri, dims):
     import torch
     w, h = dims

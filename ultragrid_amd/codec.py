@@ -309,6 +309,19 @@ class JpegEncoder:
         L.check(rc, "ug_hip_jpeg_encoder_encode")
         return bytes(self._out[: n.value].cpu().numpy())
 
+    def encode_batch(self, srcs: torch.Tensor, in_fmt: int = L.PF_UYVY) -> list:
+        """srcs: (n, frame bytes) -- n frames, one launch sequence, one synchronisation; returns the n streams."""
+        import ctypes as C
+        srcs = srcs if srcs.dtype == torch.uint8 else srcs.view(torch.uint8)
+        assert srcs.dim() == 2 and srcs.is_contiguous()
+        n = srcs.shape[0]
+        stride = (self.max_size + 15) // 16 * 16
+        out = torch.empty((n, stride), dtype=torch.uint8, device=srcs.device)
+        lens = (C.c_size_t * n)()
+        rc = L.load().ug_hip_jpeg_encoder_encode_batch(self._h, in_fmt, n, srcs.data_ptr(), 0, srcs.shape[1], out.data_ptr(), stride, self.max_size, lens, _stream())
+        L.check(rc, "ug_hip_jpeg_encoder_encode_batch")
+        return [bytes(out[f, : lens[f]].cpu().numpy()) for f in range(n)]
+
     def close(self):
         if self._h:
             L.load().ug_hip_jpeg_encoder_destroy(self._h)

@@ -63,15 +63,28 @@ constexpr int kChunk = 256;
 // (measured: the coder went from 21 to 80 us with the totals packed).
 constexpr int kChunkStride = 32; // uint32 words
 
+// A batch of frames in one launch: blockIdx.y = frame, every per-frame array of the coder `stride` elements (of its own type) behind the
+// previous frame's.  One frame: all zero, gridDim.y = 1.
+struct BatchStride {
+        long coef_y, coef_c;  // int16 elements between the frames' coefficient arrays (luma; each chroma plane)
+        long raw_words;       // the unstuffed segment data
+        long seg;             // seg_len / seg_ff entries
+        long tot_words;       // chunk totals
+        long out_bytes;       // final streams (compaction only)
+};
+constexpr int kMaxBatch = 16; // frames per encode_batch call (the pinned length words of an encoder)
+
 __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
                                                            const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs /* sampling factors of component 0: 2x2 (4:2:0), 2x1 (4:2:2), 1x1 (4:4:4) */,
                                                            int ctab /* Huffman table set of components 1,2: 1 = chroma (YCbCr), 0 = same as component 0 (RGB) */, int ri, int n_seg,
                                                            uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
                                                            uint32_t *__restrict__ seg_ff /* final size of the segment */,
-                                                           uint32_t *__restrict__ chunk_tot /* sums of seg_ff over chunks of kChunk segments */)
+                                                           uint32_t *__restrict__ chunk_tot /* sums of seg_ff over chunks of kChunk segments */, BatchStride bs)
 {
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
         __shared__ uint32_t win[4][68];
+        cy += blockIdx.y * bs.coef_y; cb += blockIdx.y * bs.coef_c; cr += blockIdx.y * bs.coef_c;
+        raw += blockIdx.y * bs.raw_words; seg_len += blockIdx.y * bs.seg; seg_ff += blockIdx.y * bs.seg; chunk_tot += blockIdx.y * bs.tot_words;
         for (int i = threadIdx.x; i < 512; i += 256) ac_tab[i >> 8][i & 255] = kAcTab[i >> 8][i & 255];
         if (threadIdx.x < 24) dc_tab[threadIdx.x / 12][threadIdx.x % 12] = kDcTab[threadIdx.x / 12][threadIdx.x % 12];
         __syncthreads();
@@ -337,9 +350,11 @@ __global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t
                                                                    const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs, int ctab, int ri,
                                                                    int n_seg, int S /* blocks per full segment, <= 64 * WAVES */, int G /* segments per workgroup */,
                                                                    uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
-                                                                   uint32_t *__restrict__ seg_ff, uint32_t *__restrict__ chunk_tot)
+                                                                   uint32_t *__restrict__ seg_ff, uint32_t *__restrict__ chunk_tot, BatchStride bs)
 {
         constexpr int W = 64 * WAVES;
+        cy += blockIdx.y * bs.coef_y; cb += blockIdx.y * bs.coef_c; cr += blockIdx.y * bs.coef_c;
+        raw += blockIdx.y * bs.raw_words; seg_len += blockIdx.y * bs.seg; seg_ff += blockIdx.y * bs.seg; chunk_tot += blockIdx.y * bs.tot_words;
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
         // one buffer, two lives: first the staging area of the block loads (per wave 32 rows of 8 x 16 B, 144 B apart so that the
         // row-wise reads are conflict-free), then the bit windows of the segments (+ one spare word per lane for the multi-pass variant)
@@ -544,8 +559,10 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
                                                       const uint32_t *__restrict__ seg_ff, const uint32_t *__restrict__ chunk_tot,
                                                       uint32_t *__restrict__ chunk_tot_next, int n_seg, uint8_t *__restrict__ out,
                                                       const uint8_t *__restrict__ header, int header_len, size_t capacity,
-                                                      uint32_t *__restrict__ total_pinned)
+                                                      uint32_t *__restrict__ total_pinned, BatchStride bs)
 {
+        raw += blockIdx.y * bs.raw_words * 4; seg_len += blockIdx.y * bs.seg; seg_ff += blockIdx.y * bs.seg;
+        chunk_tot += blockIdx.y * bs.tot_words; chunk_tot_next += blockIdx.y * bs.tot_words; out += blockIdx.y * bs.out_bytes; total_pinned += blockIdx.y;
         if (blockIdx.x == 0) { // the first workgroup also lays down SOI .. SOS
                 for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
                 for (int i = threadIdx.x; i < (n_seg + kChunk - 1) / kChunk; i += 256) chunk_tot_next[i * kChunkStride] = 0;
@@ -584,6 +601,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
 
 struct Encoder {
         int width, height, quality, ri, sub, hs, vs, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
+        int batch_cap; // frames the workspace below is sized for (1 after create; encode_batch grows it)
         bool force_wave_kernel; // UG_JPEG_WAVE_KERNEL=1: A/B switch back to the wave-per-segment coder (it remains the path for long restart intervals)
         std::vector<uint8_t> header;
         // device workspace
@@ -641,11 +659,53 @@ std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t
         return v;
 }
 
+BatchStride strides_of(const Encoder *e)
+{
+        BatchStride bs = {};
+        bs.coef_y = (long) e->ybl * e->n_mcu * 64;
+        bs.coef_c = (long) e->n_mcu * 64;
+        bs.raw_words = (long) e->n_seg * (e->cap / 4);
+        bs.seg = e->n_seg + 4;
+        bs.tot_words = (long) ((e->n_seg + kChunk - 1) / kChunk) * kChunkStride;
+        return bs;
+}
+
+void free_workspace(Encoder *e)
+{
+        for (void **p : { (void **) &e->cy, (void **) &e->cb, (void **) &e->cr, (void **) &e->scratch, (void **) &e->seg_len, (void **) &e->seg_ff,
+                          (void **) &e->chunk_tot[0], (void **) &e->chunk_tot[1] }) {
+                if (*p) (void) hipFree(*p);
+                *p = nullptr;
+        }
+        e->batch_cap = 0;
+}
+
+// the per-frame work buffers, for `frames` frames in flight inside one call
+hipError_t alloc_workspace(Encoder *e, int frames)
+{
+        free_workspace(e);
+        const BatchStride bs = strides_of(e);
+        hipError_t err = hipSuccess;
+        auto alloc = [&](void **p, size_t n) { if (err == hipSuccess) err = hipMalloc(p, n * (size_t) frames); };
+        alloc((void **) &e->cy, (size_t) bs.coef_y * 2);
+        alloc((void **) &e->cb, (size_t) bs.coef_c * 2);
+        alloc((void **) &e->cr, (size_t) bs.coef_c * 2);
+        alloc((void **) &e->scratch, (size_t) bs.raw_words * 4);
+        alloc((void **) &e->seg_len, (size_t) bs.seg * 4);
+        alloc((void **) &e->seg_ff, (size_t) bs.seg * 4);
+        alloc((void **) &e->chunk_tot[0], (size_t) bs.tot_words * 4);
+        alloc((void **) &e->chunk_tot[1], (size_t) bs.tot_words * 4);
+        if (err == hipSuccess) err = hipMemset(e->chunk_tot[0], 0, (size_t) bs.tot_words * 4 * frames);
+        if (err == hipSuccess) err = hipMemset(e->chunk_tot[1], 0, (size_t) bs.tot_words * 4 * frames);
+        if (err == hipSuccess) e->batch_cap = frames;
+        return err;
+}
+
 void destroy(Encoder *e)
 {
         if (!e) return;
-        for (void *p : { (void *) e->div, (void *) e->cy, (void *) e->cb, (void *) e->cr, (void *) e->scratch, (void *) e->seg_len,
-                         (void *) e->seg_ff, (void *) e->chunk_tot[0], (void *) e->chunk_tot[1], (void *) e->header_dev }) {
+        free_workspace(e);
+        for (void *p : { (void *) e->div, (void *) e->header_dev }) {
                 if (p) (void) hipFree(p);
         }
         if (e->total_host) (void) hipHostFree(e->total_host);
@@ -686,18 +746,9 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         hipError_t err = hipSuccess;
         auto alloc = [&](void **p, size_t n) { if (err == hipSuccess) err = hipMalloc(p, n); };
         alloc((void **) &e->div, sizeof div);
-        alloc((void **) &e->cy, (size_t) e->ybl * e->n_mcu * 128);
-        alloc((void **) &e->cb, (size_t) e->n_mcu * 128);
-        alloc((void **) &e->cr, (size_t) e->n_mcu * 128);
-        alloc((void **) &e->scratch, (size_t) e->n_seg * e->cap);
-        alloc((void **) &e->seg_len, (size_t) e->n_seg * 4);
-        alloc((void **) &e->seg_ff, ((size_t) e->n_seg + 4) * 4);
-        const size_t chunk_bytes = (size_t) ((e->n_seg + kChunk - 1) / kChunk) * kChunkStride * 4;
-        alloc((void **) &e->chunk_tot[0], chunk_bytes);
-        alloc((void **) &e->chunk_tot[1], chunk_bytes);
-        if (err == hipSuccess) err = hipMemset(e->chunk_tot[0], 0, chunk_bytes);
-        if (err == hipSuccess) err = hipMemset(e->chunk_tot[1], 0, chunk_bytes);
+        if (err == hipSuccess) err = alloc_workspace(e, 1);
         alloc((void **) &e->header_dev, e->header.size());
+        static_assert(kMaxBatch * sizeof(uint32_t) <= 64, "one length word per frame of a batch");
         if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocMapped);
         if (err == hipSuccess) err = hipHostGetDevicePointer((void **) &e->total_host_dev, e->total_host, 0);
         if (err == hipSuccess) err = hipMemcpy(e->div, div, sizeof div, hipMemcpyHostToDevice);
@@ -727,9 +778,16 @@ size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc)
 int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch, void *out_dev,
                                size_t out_capacity, size_t *out_len, ug_hip_stream_t stream)
 {
+        return ug_hip_jpeg_encoder_encode_batch(enc, in, 1, src_dev, src_pitch, 0, out_dev, 0, out_capacity, out_len, stream);
+}
+
+int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, int frames, const void *src_dev, int src_pitch, size_t src_stride,
+                                     void *out_dev, size_t out_stride, size_t out_capacity, size_t *out_len, ug_hip_stream_t stream)
+{
         Encoder *e = (Encoder *) enc;
-        if (!e || !src_dev || !out_dev || !out_len || (15 & (uintptr_t) out_dev)) {
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: bad arguments");
+        if (!e || !src_dev || !out_dev || !out_len || (15 & (uintptr_t) out_dev) || frames < 1 || frames > kMaxBatch ||
+            (frames > 1 && ((out_stride & 15) || out_stride < out_capacity))) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: bad arguments (1..16 frames; out_stride a multiple of 16, >= out_capacity)");
                 return UG_HIP_EINVAL;
         }
         if (out_capacity < e->header.size() + 2) {
@@ -737,24 +795,39 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                 return UG_HIP_EINVAL;
         }
         hipStream_t st = (hipStream_t) stream;
-        int rc;
+        if (frames > e->batch_cap) { // the work buffers of a frame, once per frame of the batch (grown once; kernels of earlier calls have finished: encode is synchronous)
+                const hipError_t err = alloc_workspace(e, frames);
+                if (err != hipSuccess) {
+                        ug::set_last_error(err, "ug_hip_jpeg_encoder_encode_batch: work buffers");
+                        if (alloc_workspace(e, 1) != hipSuccess) free_workspace(e);
+                        return UG_HIP_ERUNTIME;
+                }
+        }
+        BatchStride bs = strides_of(e);
+        bs.out_bytes = (long) out_stride;
+        int rc = UG_HIP_SUCCESS;
         const int w = e->width, h = e->height;
-        if (in == UG_PF_UYVY && e->sub != 444) {
-                rc = (e->sub == 420 ? ug_hip_uyvy_to_jpeg420_coeffs : ug_hip_uyvy_to_jpeg422_coeffs)(src_dev, src_pitch, w, h, e->div, e->cy, e->cb,
-                                                                                                     e->cr, stream);
+        if (in == UG_PF_UYVY && e->sub != 444) { // fused unpack + subsample + FDCT + quantise, grid.z = frame
+                rc = ug_hip_uyvy_to_jpeg42x_coeffs_batch(e->sub, src_dev, src_pitch, w, h, e->div, e->cy, e->cb, e->cr, frames, src_stride,
+                                                         (size_t) bs.coef_y * 2, (size_t) bs.coef_c * 2, stream);
         } else if (in == UG_PF_RGB && e->sub == 444) { // GPUJPEG_444_U8_P012, components kept as R, G, B (gpujpeg.cpp:303-305,336)
                 if (!src_pitch) src_pitch = 3 * w;
-                rc = ug::jpeg_fdct_quant_rgb444(src_dev, src_pitch, w, h, e->mcu_w, e->mcu_h, e->div, e->cy, e->cb, e->cr, stream);
+                for (int f = 0; f < frames && rc == UG_HIP_SUCCESS; f++) {
+                        rc = ug::jpeg_fdct_quant_rgb444((const uint8_t *) src_dev + f * src_stride, src_pitch, w, h, e->mcu_w, e->mcu_h, e->div, e->cy + f * bs.coef_y,
+                                                        e->cb + f * bs.coef_c, e->cr + f * bs.coef_c, stream);
+                }
         } else if (in == UG_PF_I420 && e->sub == 420) { // planar passthrough (GPUJPEG_420_U8_P0P1P2, gpujpeg.cpp:335): Y, U, V planes back to back
                 if (src_pitch && src_pitch != w) {
                         ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: I420 input must be tightly packed");
                         return UG_HIP_EINVAL;
                 }
                 const int cw = (w + 1) / 2, ch = (h + 1) / 2;
-                const uint8_t *y = (const uint8_t *) src_dev, *u = y + (size_t) w * h, *v = u + (size_t) cw * ch;
-                rc = ug::jpeg_fdct_quant_strided(y, w, 1, w, h, 2 * e->mcu_w, 2 * e->mcu_h, e->div, e->cy, nullptr, stream);
-                if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(u, cw, 1, cw, ch, e->mcu_w, e->mcu_h, e->div + 64, e->cb, nullptr, stream);
-                if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(v, cw, 1, cw, ch, e->mcu_w, e->mcu_h, e->div + 64, e->cr, nullptr, stream);
+                for (int f = 0; f < frames && rc == UG_HIP_SUCCESS; f++) {
+                        const uint8_t *y = (const uint8_t *) src_dev + f * src_stride, *u = y + (size_t) w * h, *v = u + (size_t) cw * ch;
+                        rc = ug::jpeg_fdct_quant_strided(y, w, 1, w, h, 2 * e->mcu_w, 2 * e->mcu_h, e->div, e->cy + f * bs.coef_y, nullptr, stream);
+                        if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(u, cw, 1, cw, ch, e->mcu_w, e->mcu_h, e->div + 64, e->cb + f * bs.coef_c, nullptr, stream);
+                        if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(v, cw, 1, cw, ch, e->mcu_w, e->mcu_h, e->div + 64, e->cr + f * bs.coef_c, nullptr, stream);
+                }
         } else {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: input must be UYVY (4:2:0 / 4:2:2 encoder), I420 (4:2:0) or RGB (4:4:4); "
                                        "convert other formats with ug_hip_pixfmt_convert");
@@ -772,10 +845,10 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                         if (64 * waves < S) waves = k;
                 }
                 const int G = 64 * waves / S;
-                const dim3 grid((e->n_seg + G - 1) / G);
+                const dim3 grid((e->n_seg + G - 1) / G, frames);
 #define UG_LAUNCH_EBK(NW)                                                                                                                      \
         hipLaunchKernelGGL(entropy_block_kernel<NW>, grid, dim3(64 * NW), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,      \
-                           e->sub == 444 ? 0 : 1, e->ri, e->n_seg, S, G, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot)
+                           e->sub == 444 ? 0 : 1, e->ri, e->n_seg, S, G, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot, bs)
                 switch (waves) {
                 case 1: UG_LAUNCH_EBK(1); break;
                 case 2: UG_LAUNCH_EBK(2); break;
@@ -784,15 +857,19 @@ int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const v
                 }
 #undef UG_LAUNCH_EBK
         } else {
-                hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs, e->sub == 444 ? 0 : 1, e->ri,
-                                   e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot);
+                hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
+                                   e->sub == 444 ? 0 : 1, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot, bs);
         }
-        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, tot, tot_next,
-                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev);
+        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, tot, tot_next,
+                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, bs);
         UG_HIP_LAUNCH_CHECK();
-        UG_HIP_TRY(hipStreamSynchronize(st));
-        *out_len = *e->total_host;
-        if (*out_len > out_capacity) { // segments past the end were not written; *out_len tells the caller what it takes
+        UG_HIP_TRY(hipStreamSynchronize(st)); // ONE synchronisation for the batch
+        bool fits = true;
+        for (int f = 0; f < frames; f++) {
+                out_len[f] = e->total_host[f];
+                fits = fits && out_len[f] <= out_capacity;
+        }
+        if (!fits) { // segments past the end were not written; out_len[] tells the caller what it takes
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: stream does not fit the output buffer (out_len = needed size)");
                 return UG_HIP_EINVAL;
         }

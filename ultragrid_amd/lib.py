@@ -101,6 +101,7 @@ SYMBOLS = {
     "ug_hip_jpeg_decoder_decode_sized": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "ug_hip_jpeg_decoder_plane": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "ug_hip_jpeg_encoder_encode": (_i, [_vp, _i, _vp, _i, _vp, _sz, C.POINTER(_sz), _vp]),
+    "ug_hip_jpeg_encoder_encode_batch": (_i, [_vp, _i, _i, _vp, _i, _sz, _vp, _sz, _sz, C.POINTER(_sz), _vp]),
 }
 
 
