@@ -171,6 +171,11 @@ int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void
 /* Device self-test: the decoders divide by the constants 255, 31, 63, 7, 5, 3 with a multiply + two fma (correctly rounded for
  * the numerators a DXT block can produce); this compares every such quotient with the IEEE division. *mismatches must be 0. */
 int ug_hip_selftest_dxt_decode(unsigned *mismatches, ug_hip_stream_t stream);
+/* Diagnostics (tests, profiling): which DXT5-YCoCg decode path the following ug_hip_dxt_decode calls of this process take --
+ * 0 = the product (32-bit fixed point with a guard band; blocks with a value inside the band are decoded again with dxt62tga.c's fp64
+ * statements: bit-identical by construction), 1 = the fp64 statements only, 2 = fixed point only (no fallback: shows what the guard is
+ * for) -- and, if not NULL, a device counter that every guarded block increments.  Reset with (0, NULL). */
+int ug_hip_dxt_decode_debug(int mode, unsigned *flagged_blocks_dev);
 /* Same for the encoder: x / 14.0f as multiply + two fma, compared with the IEEE division for x = 0 and every fp32 x in [2^-100, 1] (smaller
  * values take the division itself). */
 int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream);

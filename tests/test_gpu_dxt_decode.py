@@ -1,4 +1,6 @@
 """GPU parity: HIP DXT decoders vs oracle/dxt_decode_oracle.c (itself pinned to the reference's dxt62tga tool)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,3 +109,64 @@ def test_constant_divisor_quotients_are_ieee_exact(hip):
     n = C.c_uint(12345)
     assert L.load().ug_hip_selftest_dxt_decode(C.byref(n), torch.cuda.current_stream().cuda_stream) == 0
     assert n.value == 0
+
+
+@pytest.mark.parametrize("out", ["RGBA", "RGB", "UYVY"])
+def test_dxt5_fixed_point_path_equals_the_fp64_statements(hip, po, out):
+    """Round 3: the DXT5-YCoCg decoder computes every sample in 32-bit fixed point, keeps it where it lies clear of an integer boundary and
+    decodes the other blocks again with dxt62tga.c's fp64 statements.  Over 3.1 M blocks -- arbitrary bit patterns (both alpha modes,
+    every palette), encoder output of video noise, and blocks built to sit ON boundaries (equal endpoints: every sample an exact integer
+    + 0.5 ... ) -- the product (mode 0) equals the fp64-only kernel (mode 1) byte for byte; the guard fires (counter > 0) at about the
+    predicted rate; and the fixed-point-only kernel (mode 2) may differ from mode 1 ONLY inside blocks the guard fired on -- shown by
+    decoding the same frame twice and comparing block-wise.  The oracle pins mode 1 (test_decode_bit_exact runs in mode 0 too)."""
+    import ctypes as C
+    import torch
+    from ultragrid_amd import lib as L
+    lib = L.load()
+    w, h = 4096, 4096 * 3
+    nblk = (w // 4) * (h // 4)
+    g = torch.Generator(device="cuda").manual_seed(20260925)
+    rnd = torch.randint(0, 2 ** 31 - 1, (nblk, 4), generator=g, device="cuda", dtype=torch.int32) ^ (torch.randint(0, 2, (nblk, 4), generator=g, device="cuda", dtype=torch.int32) << 31)
+    third = nblk // 3
+    # second third: encoder output of S2 video noise (real streams)
+    noise = torch.from_numpy(synth.s2_video("UYVY", w, 256)).cuda().view(256, -1).repeat(16, 1)[: h // 3].contiguous()
+    enc = hip.dxt_encode(L.PF_UYVY, L.DXT5_YCOCG, noise.view(-1), w, h // 3)
+    rnd.view(torch.uint8).view(-1)[third * 16: third * 16 + enc.numel()] = enc
+    # last third: adversarial structure -- equal alpha endpoints and/or equal colour endpoints (samples that are integers or integers + 0.5 in exact arithmetic)
+    tail = rnd[2 * third:]
+    a = tail[:, 0] & 0xFF
+    tail[: tail.shape[0] // 2, 0] = (tail[: tail.shape[0] // 2, 0] & ~0xFFFF) | a[: tail.shape[0] // 2] | (a[: tail.shape[0] // 2] << 8)
+    c = tail[tail.shape[0] // 4:, 2] & 0xFFFF
+    tail[tail.shape[0] // 4:, 2] = c | (c << 16)
+    blocks = rnd.view(torch.uint8).view(-1)
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = {}
+    try:
+        for mode in (1, 0, 2):
+            counter.zero_()
+            assert lib.ug_hip_dxt_decode_debug(mode, counter.data_ptr()) == 0
+            res[mode] = hip.dxt_decode(L.DXT5_YCOCG, L.PF_NAMES[out], blocks, w, h)
+            torch.cuda.synchronize()
+            res[f"n{mode}"] = int(counter.item())
+    finally:
+        lib.ug_hip_dxt_decode_debug(0, None)
+    assert torch.equal(res[0], res[1]), "the product differs from dxt62tga.c's fp64 statements"
+    assert res["n1"] == 0 and res["n0"] == res["n2"] > 0
+    # up to 48 distinct samples per block, 8 of 2^20 positions guarded: a few blocks in 10^5
+    assert 1e-6 < res["n0"] / nblk < 0.01, res["n0"] / nblk
+    bpp = {"RGBA": 4, "RGB": 3, "UYVY": 2}[out]
+    diff = (res[2].view(h, w * bpp) != res[1].view(h, w * bpp))
+    bad_blocks = int(diff.view(h // 4, 4, w // 4, 4 * bpp).any(dim=3).any(dim=1).sum().item())
+    assert bad_blocks <= res["n0"], (bad_blocks, res["n0"])       # whatever differs without the fallback lies inside guarded blocks
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"dxt5_fixed_point_stats_{out}.txt"), "w") as f:
+            f.write(f"DXT5-YCoCg -> {out}: {nblk} blocks; guarded (decoded again exactly): {res['n0']} = {res['n0'] / nblk:.3e}; blocks that differ from the fp64 "
+                    f"statements when the fallback is switched off (mode 2): {bad_blocks}; product (mode 0) == fp64-only (mode 1): True\n")
+    # and a slice against the oracle (mode 0)
+    sl = blocks[: 16 * (w // 4) * 8].cpu().numpy()
+    assert np.array_equal(res[0][: w * bpp * 32].cpu().numpy(), po.dxt_decode(po.OUT_DXT5YCOCG, out, sl, w, 32))
+    sl = blocks[2 * third * 16: 2 * third * 16 + 16 * (w // 4) * 8].cpu().numpy()
+    row0 = (2 * third) // (w // 4) * 4
+    if (2 * third) % (w // 4) == 0:
+        assert np.array_equal(res[0][row0 * w * bpp: (row0 + 32) * w * bpp].cpu().numpy(), po.dxt_decode(po.OUT_DXT5YCOCG, out, sl, w, 32))

@@ -9,9 +9,19 @@
 //
 // Mapping: one lane = one 4x4 block, a wave = 64 consecutive blocks of a block row: the 16-byte (DXT5) /
 // 8-byte (DXT1) loads and the four row stores (64 x 16 B RGBA, 64 x 12 B RGB, 64 x 8 B UYVY) are contiguous
-// across lanes.  The 8-entry luma table and the 4-entry (Co,Cg) palette of a block live in LDS so that the
-// per-pixel lookups are one ds_read each instead of a chain of 64-bit selects.  HBM-bound:
-// algorithmic bytes per pixel = 1 (DXT5) or 0.5 (DXT1) read + 2 (UYVY) / 3 (RGB) / 4 (RGBA) written.
+// across lanes.  Algorithmic bytes per pixel = 1 (DXT5) or 0.5 (DXT1) read + 2 (UYVY) / 3 (RGB) / 4 (RGBA) written.
+//
+// DXT5-YCoCg, round 3: the 11 fp64 operations + 3 conversions per pixel of dxt62tga.c made the kernel VALU-issue bound
+// (667 VALU instructions per wave of 64 blocks, every fp64 / conversion / integer-multiply instruction ~4.4 cycles per SIMD:
+// profiles/r03_dxt_decode_pmc.txt, r03_valu_microbench_f64.txt).  The tool's result for a pixel is clamp(trunc(t)), t = a fp64 value
+// within 1e-12 of the rational  255 a_k + 255 (Co_c -+ Cg_c) + 0.5  (a_k one of 8 luma entries, (Co_c, Cg_c) one of 4 palette entries):
+// a cheaper association changes t in the last bits only, which reaches the output only where t lies that close to an integer --
+// "too rare to matter, impossible to exclude" (DESIGN.md r02).  It CAN be excluded at run time: the kernel computes
+// T = A_k + D_c in 32-bit fixed point (2^-20 units; |T / 2^20 - t| < 3.5 units by construction, see dxt5_tables_fixed), takes
+// floor(T / 2^20) wherever T lies at least 4 units away from an integer boundary, and re-decodes the blocks where some T
+// does not (about 8 in 2^20 values) with the tool's own fp64 statements (decode_block_exact) -- bit-identical output by
+// construction, ~1/2 of the instructions.  The same scheme turns rgba_to_yuv422.glsl's fp32 arithmetic for UYVY output into
+// 32-bit multiply-adds with the float path as the per-pair fallback.
 #include "ug_common.h"
 
 namespace {
@@ -52,6 +62,10 @@ __device__ __forceinline__ uint32_t rgb_pair_to_uyvy(uint32_t p1, uint32_t p2, c
                (uint32_t) unorm8_out<AWAY>(yuv[1][0]) << 24;
 }
 
+// one copy of the shader arithmetic for the rare pairs the fixed-point form hands back (a call inside a divergent branch)
+template <bool AWAY>
+__device__ __noinline__ uint32_t rgb_pair_to_uyvy_call(uint32_t p1, uint32_t p2, const float *unorm) { return rgb_pair_to_uyvy<AWAY>(p1, p2, unorm); }
+
 // fill the v / 255.0f table (256 lanes of the 64x4 workgroup, one division each); call before any early return
 template <int OUT>
 __device__ __forceinline__ void fill_unorm(float *unorm)
@@ -63,6 +77,41 @@ __device__ __forceinline__ void fill_unorm(float *unorm)
         }
 }
 
+
+// rgba_to_yuv422.glsl:27-46 on two 8-bit RGB texels in 32-bit fixed point (2^-24 of a code value), for the DXT5-YCoCg decoder.
+// In exact arithmetic the shader's values are linear in the bytes (the v / 255 of the texel fetch cancels against the * 255 of the write):
+//      Y'  = 15.9375 + cm (c1 R + c2 G + c3 B)                               cm = 0.8588f, c1..c3 = 0.2126f, 0.7152f, 0.0722f
+//      Cb  = 127.5 + 0.5 cu (0.5 SB - c4 SR - c5 SG),  SR = R0 + R1 ...      cu = 0.8784f, c4, c5 = 0.1145f, 0.3854f
+//      Cr  = 127.5 + 0.5 cu (0.5 SR - c6 SG - c7 SB)                         c6, c7 = 0.4541f, 0.0458f
+// The shader's fp32 evaluation (rgb_pair_to_uyvy above) stays within 1.1e-4 of these (Y': six roundings of 2^-24 on partial sums
+// <= 1, times 0.8588, one on the sum, times 255, one on the product; Cb / Cr: 1.04e-4 incl. the + 0.5f of the AWAY rule); the 24-bit
+// coefficients below add <= 0.5 * 255 * 3 (Y') or 0.5 * 510 * 3 (Cb, Cr) units = 2.3e-5 / 4.6e-5.  Guard: kGuardUyvy = 3072 units = 1.83e-4
+// on each side of a rounding boundary (x.5): outside it the rounded fixed-point value is the shader's byte whatever the tie rule; a pair
+// with a value inside it is converted again by the shader's own operations.  All sums stay in [15.5, 240] * 2^24 < 2^32, unsigned.
+constexpr int kGuardUyvy = 3072;
+constexpr double kCm = (double) 0.8588f, kCu = (double) 0.8784f, kTwo24 = 16777216.0;
+constexpr uint32_t kYr = (uint32_t) (kCm * (double) 0.2126f * kTwo24 + 0.5), kYg = (uint32_t) (kCm * (double) 0.7152f * kTwo24 + 0.5),
+                   kYb = (uint32_t) (kCm * (double) 0.0722f * kTwo24 + 0.5), kY0 = (uint32_t) (15.9375 * kTwo24) + (1u << 23) + kGuardUyvy;
+constexpr uint32_t kUb = (uint32_t) (0.5 * kCu * 0.5 * kTwo24 + 0.5), kUr = (uint32_t) (0.5 * kCu * (double) 0.1145f * kTwo24 + 0.5),
+                   kUg = (uint32_t) (0.5 * kCu * (double) 0.3854f * kTwo24 + 0.5);
+constexpr uint32_t kVr = (uint32_t) (0.5 * kCu * 0.5 * kTwo24 + 0.5), kVg = (uint32_t) (0.5 * kCu * (double) 0.4541f * kTwo24 + 0.5),
+                   kVb = (uint32_t) (0.5 * kCu * (double) 0.0458f * kTwo24 + 0.5);
+constexpr uint32_t kC0 = (uint32_t) (127.5 * kTwo24) + (1u << 23) + kGuardUyvy;
+
+// returns the UYVY word as the fixed-point values round; `near` = the smallest distance (in 2^-24 units, biased by the guard) of the four
+// values from a rounding boundary: < 2 * kGuardUyvy means the word must not be trusted
+__device__ __forceinline__ uint32_t uyvy_pair_fixed(uint32_t r0, uint32_t g0, uint32_t b0, uint32_t r1, uint32_t g1, uint32_t b1, uint32_t &near)
+{
+        const uint32_t y0 = __umul24(kYr, r0) + (__umul24(kYg, g0) + (__umul24(kYb, b0) + kY0));
+        const uint32_t y1 = __umul24(kYr, r1) + (__umul24(kYg, g1) + (__umul24(kYb, b1) + kY0));
+        const uint32_t sr = r0 + r1, sg = g0 + g1, sb = b0 + b1;
+        const uint32_t u = (__umul24(kUb, sb) + kC0) - (__umul24(kUr, sr) + __umul24(kUg, sg));
+        const uint32_t v = (__umul24(kVr, sr) + kC0) - (__umul24(kVg, sg) + __umul24(kVb, sb));
+        const uint32_t m = 0xFFFFFFu;
+        near = min(min(y0 & m, y1 & m), min(u & m, v & m));
+        // the integer parts are the top bytes: U | Y0 << 8 | V << 16 | Y1 << 24
+        return __builtin_amdgcn_perm(y0, u, 0x0c0c0703u) | __builtin_amdgcn_perm(y1, v, 0x07030c0cu);
+}
 
 // x / C for the constant divisors of the decoder (255, 31, 63, 7, 5, 3), correctly rounded without the generic IEEE division
 // sequence (v_div_scale x2, v_rcp, 4-5 fma, v_div_fmas, v_div_fixup): q = RN(x * RN(1/C)), one exact residual r = fma(-q, C, x),
@@ -84,92 +133,262 @@ struct OutArgs {
         int rs, gs, bs;
 };
 
-// store one decoded row (4 pixels, packed R | G<<8 | B<<16) of block column bx
+// one pixel in the form the row store wants it: RGBA = the final 32-bit pixel; RGB = R | G << 8 | B << 16; BGR = B | G << 8 | R << 16;
+// UYVY = R | G << 8 | B << 16 (the shader input)
+template <int OUT>
+__device__ __forceinline__ uint32_t pack_px(const OutArgs &o, uint32_t R, uint32_t G, uint32_t B)
+{
+        if (OUT == UG_PF_RGBA) {
+                const uint32_t am = 0xFFFFFFFFu ^ (0xFFu << o.rs) ^ (0xFFu << o.gs) ^ (0xFFu << o.bs);
+                return ((am | R << o.rs) | G << o.gs) | B << o.bs;
+        }
+        return OUT == UG_PF_BGR ? (B | G << 8 | R << 16) : (R | G << 8 | B << 16);
+}
+
+// store one decoded row (4 pixels as pack_px made them) of block column bx
 template <int OUT, bool AWAY>
-__device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4], const float *unorm)
+__device__ __forceinline__ void store_words(const OutArgs &o, int y, int bx, const uint32_t (&p)[4], const float *unorm)
 {
         uint8_t *row = o.dst + (long) y * o.pitch;
         if (OUT == UG_PF_RGBA) {
-                const uint32_t am = 0xFFFFFFFFu ^ (0xFFu << o.rs) ^ (0xFFu << o.gs) ^ (0xFFu << o.bs);
-                uint32_t v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                        v[i] = am | (px[i] & 0xff) << o.rs | ((px[i] >> 8) & 0xff) << o.gs | ((px[i] >> 16) & 0xff) << o.bs;
-                }
-                ((uint4 *) row)[bx] = make_uint4(v[0], v[1], v[2], v[3]);
+                ((uint4 *) row)[bx] = make_uint4(p[0], p[1], p[2], p[3]);
         } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
-                uint32_t p[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                        p[i] = OUT == UG_PF_RGB ? px[i] : ((px[i] & 0xff) << 16 | (px[i] & 0xff00) | (px[i] >> 16));
-                }
                 uint32_t *d = (uint32_t *) row + 3 * bx;
                 d[0] = p[0] | p[1] << 24;
                 d[1] = (p[1] >> 8) | p[2] << 16;
                 d[2] = (p[2] >> 16) | p[3] << 8;
         } else { // UYVY
-                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy<AWAY>(px[0], px[1], unorm), rgb_pair_to_uyvy<AWAY>(px[2], px[3], unorm));
+                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy<AWAY>(p[0], p[1], unorm), rgb_pair_to_uyvy<AWAY>(p[2], p[3], unorm));
         }
 }
 
+// the same from 4 pixels packed R | G<<8 | B<<16 (the DXT1 palettes)
 template <int OUT, bool AWAY>
-__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh)
+__device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4], const float *unorm)
 {
-        // per-lane tables, entry-major so that a wave's accesses to one entry are contiguous
-        __shared__ double lds_a[8][256];
-        __shared__ double lds_co[4][256], lds_cg[4][256];
-        __shared__ float unorm[OUT == UG_PF_UYVY ? 256 : 1];
-        fill_unorm<OUT>(unorm);
-        const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
-        const int t = threadIdx.y * 64 + threadIdx.x;
-        if (bx >= bw || by >= bh) return;
-        const uint4 q = src[(long) by * bw + bx];
+        uint32_t p[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) p[i] = (OUT == UG_PF_RGB || OUT == UG_PF_UYVY) ? px[i] : pack_px<OUT>(o, px[i] & 0xff, (px[i] >> 8) & 0xff, px[i] >> 16);
+        store_words<OUT, AWAY>(o, y, bx, p, unorm);
+}
+
+// ---- DXT5-YCoCg ------------------------------------------------------------------------------------------------------------------
+// dxt62tga.c:24-106 for one block, the tool's fp64 statements one for one (the reference semantics, and the fallback of the
+// fixed-point path below).  Tables in registers, selected with compare trees: this runs for a few blocks per thousand only.
+__device__ __forceinline__ double sel8(const double (&t)[8], int i)
+{
+        const double lo = (i & 2) ? ((i & 1) ? t[3] : t[2]) : ((i & 1) ? t[1] : t[0]);
+        const double hi = (i & 2) ? ((i & 1) ? t[7] : t[6]) : ((i & 1) ? t[5] : t[4]);
+        return (i & 4) ? hi : lo;
+}
+
+// `pal` = this lane's column of a [4][64] table of (Co, Cg) pairs in LDS
+template <int OUT, bool AWAY>
+__device__ __noinline__ void decode_block_exact(uint4 q, OutArgs o, int bx, int by, double2 *pal, const float *unorm) // (o by value: a reference would put the kernel's copy into scratch memory)
+{
         unsigned long long ac = (unsigned long long) q.x | (unsigned long long) q.y << 32;
         unsigned long long cc = (unsigned long long) q.z | (unsigned long long) q.w << 32;
-
         // dxt62tga.c:60-62 alpha endpoints, :36-58 the two interpolation modes
+        double ta[8];
         const double a0 = div_const<255>((double) (ac & 0xFF)), a1 = div_const<255>((double) ((ac >> 8) & 0xFF));
-        lds_a[0][t] = a0;
-        lds_a[1][t] = a1;
+        ta[0] = a0;
+        ta[1] = a1;
         if (a0 > a1) {
 #pragma unroll
-                for (int k = 2; k < 8; k++) lds_a[k][t] = div_const<7>((double) (8 - k) * a0 + (double) (k - 1) * a1);
+                for (int k = 2; k < 8; k++) ta[k] = div_const<7>((double) (8 - k) * a0 + (double) (k - 1) * a1);
         } else {
 #pragma unroll
-                for (int k = 2; k < 6; k++) lds_a[k][t] = div_const<5>((double) (6 - k) * a0 + (double) (k - 1) * a1);
-                lds_a[6][t] = 0.0;
-                lds_a[7][t] = 1.0;
+                for (int k = 2; k < 6; k++) ta[k] = div_const<5>((double) (6 - k) * a0 + (double) (k - 1) * a1);
+                ta[6] = 0.0;
+                ta[7] = 1.0;
         }
         // dxt62tga.c:63-74 colour endpoints and the two thirds; :24-27 per-entry scale / Co / Cg
-        double r[4], g[4], b[4];
-        b[0] = div_const<31>((double) (cc & 0x1F));         g[0] = div_const<63>((double) ((cc >> 5) & 0x3F));  r[0] = div_const<31>((double) ((cc >> 11) & 0x1F));
-        b[1] = div_const<31>((double) ((cc >> 16) & 0x1F)); g[1] = div_const<63>((double) ((cc >> 21) & 0x3F)); r[1] = div_const<31>((double) ((cc >> 27) & 0x1F));
-        b[2] = div_const<3>(2.0 * b[0] + b[1]); g[2] = div_const<3>(2.0 * g[0] + g[1]); r[2] = div_const<3>(2.0 * r[0] + r[1]);
-        b[3] = div_const<3>(b[0] + 2.0 * b[1]); g[3] = div_const<3>(g[0] + 2.0 * g[1]); r[3] = div_const<3>(r[0] + 2.0 * r[1]);
+        {
+                double r[4], g[4], b[4];
+                b[0] = div_const<31>((double) (cc & 0x1F));         g[0] = div_const<63>((double) ((cc >> 5) & 0x3F));  r[0] = div_const<31>((double) ((cc >> 11) & 0x1F));
+                b[1] = div_const<31>((double) ((cc >> 16) & 0x1F)); g[1] = div_const<63>((double) ((cc >> 21) & 0x3F)); r[1] = div_const<31>((double) ((cc >> 27) & 0x1F));
+                b[2] = div_const<3>(2.0 * b[0] + b[1]); g[2] = div_const<3>(2.0 * g[0] + g[1]); r[2] = div_const<3>(2.0 * r[0] + r[1]);
+                b[3] = div_const<3>(b[0] + 2.0 * b[1]); g[3] = div_const<3>(g[0] + 2.0 * g[1]); r[3] = div_const<3>(r[0] + 2.0 * r[1]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-                const double scale = 1.0 / (31.875 * b[k] + 1.0);
-                lds_co[k][t] = (r[k] - 5.01960814E-01) * scale;
-                lds_cg[k][t] = (g[k] - 5.01960814E-01) * scale;
+                for (int k = 0; k < 4; k++) {
+                        const double scale = 1.0 / (31.875 * b[k] + 1.0);
+                        pal[64 * k] = make_double2((r[k] - 5.01960814E-01) * scale, (g[k] - 5.01960814E-01) * scale);
+                }
         }
         ac >>= 16;
         cc >>= 32;
-        // (LDS traffic is lane-private: no barrier, a wave's own ds ops are ordered)
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-                uint32_t px[4];
+        for (int y = 0; y < 4; y++) { // (not unrolled: code size, this path is rare)
+                uint32_t p[4];
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
                         const int ai = (int) (ac & 7), ci = (int) (cc & 3);
                         ac >>= 3;
                         cc >>= 2;
-                        const double a = lds_a[ai][t], Co = lds_co[ci][t], Cg = lds_cg[ci][t];
+                        const double a = sel8(ta, ai);
+                        const double2 cocg = pal[64 * ci];
+                        const double Co = cocg.x, Cg = cocg.y;
                         const uint32_t R = clamp8(((a + Co) - Cg) * 255.0);
                         const uint32_t G = clamp8((a + Cg) * 255.0);
                         const uint32_t B = clamp8(((a - Co) - Cg) * 255.0);
-                        px[x] = R | G << 8 | B << 16;
+                        p[x] = pack_px<OUT>(o, R, G, B);
                 }
-                store_row<OUT, AWAY>(o, 4 * by + y, bx, px, unorm);
+                store_words<OUT, AWAY>(o, 4 * by + y, bx, p, unorm);
+        }
+}
+
+// The fixed-point tables of one block.  Units: 2^-20 of an 8-bit step ("ulp" below).
+//   A_k (8 luma entries)  ~ 2^20 (255 a_k + 0.5) + kGuard.  255 a_k is the rational (w0 a0 + w1 a1) / 7 (or / 5) of the two endpoint
+//                         BYTES, so A_k = (a0 << 20) + w1 * delta with delta = RN((a1 - a0) 2^20 / 7): error <= 6 * 0.5 = 3 ulp.
+//   D_c, E_c, F_c (4 palette entries) ~ 2^20 * 255 * (Co - Cg), Cg, (-Co - Cg).  With nb, nr in [0, 93], ng in [0, 189] the integers
+//                         3 x endpoint or 2 x one endpoint + the other:  b = nb / 93, r = nr / 93, g = ng / 189,
+//                         scale = 1 / (31.875 b + 1) = 744 / (255 nb + 744), so each is RN(fp64 product): error <= 0.5 ulp + 1e-8.
+// dxt62tga.c's own fp64 value t (before the truncation) differs from the rational it approximates by < 1e-12 (five roundings of
+// quantities below 512).  Hence |A_k + X_c - kGuard - 2^20 t| < 3.5 + 1e-6: wherever (A_k + X_c) mod 2^20 >= 2 kGuard = 8 the integer
+// part of (A_k + X_c) / 2^20 IS trunc(t) for t >= 0 and <= 0 for t < 0 (clamped to 0 either way); elsewhere the block is re-decoded exactly.
+constexpr int kFix = 20, kGuard = 4;
+constexpr int kOff = (1 << (kFix - 1)) + kGuard;
+
+__device__ __forceinline__ int rn_i32(double x) { return (int) __builtin_rint(x); }
+
+// gfx950's V_ASHR_PK_U8_I32: D.b[0] = sat_u8(S0 >> S2), D.b[1] = sat_u8(S1 >> S2) -- shift, clamp to [0, 255] and pack, for two values, in
+// one instruction.  It writes ONE HALF of the destination (the low one, or the high one with op_sel:[0,0,0,1]) and leaves the other as it
+// was (tools/ashr_pk_probe.hip, profiles/r03_ashr_pk_probe.txt).  ROCm 7.2's compiler also forms it from min(max(x >> s, 0), 255) pairs
+// and then takes bits 31:16 for zero, which they are not: that source pattern is avoided in this file (clamp_shift below is opaque to
+// the compiler), and the instruction is issued by hand: two of them make a finished 4-byte pixel.
+static_assert(kFix == 20, "the shift is spelled out in the instruction strings below");
+__device__ __forceinline__ uint32_t pk2_u8(int b0, int b1, int b2, int b3) // sat_u8(b_i >> 20) in byte i
+{
+        uint32_t d;
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, 20" : "=v"(d) : "v"(b0), "v"(b1));
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, 20 op_sel:[0,0,0,1]" : "+v"(d) : "v"(b2), "v"(b3));
+        return d;
+}
+__device__ __forceinline__ uint32_t clamp_shift(int t) // min(max(t >> 20, 0), 255), not recognisable as the pattern above
+{
+        int r;
+        asm("v_ashrrev_i32 %0, 20, %1\n\tv_med3_i32 %0, %0, 0, %2" : "=&v"(r) : "v"(t), "v"(255));
+        return (uint32_t) r;
+}
+
+// one block: fixed-point tables -> 16 pixels -> rows stored; guarded blocks decoded again exactly
+template <int OUT, bool AWAY, int MODE>
+__device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o, int bx, int by, int (*lds_a)[64], const double *lds_rs, const float *unorm, int lane,
+                                                unsigned *flagged)
+{
+        bool redo = MODE == 1;
+        if (MODE != 1) {
+                // ---- luma table ----
+                const int a0 = (int) (q.x & 0xFF), a1 = (int) ((q.x >> 8) & 0xFF);
+                const bool m7 = a0 > a1; // dxt62tga.c:36: a0 > a1 <=> the bytes compare so (x / 255 is monotone)
+                const int delta = rn_i32((double) (a1 - a0) * (m7 ? 1048576.0 / 7.0 : 1048576.0 / 5.0));
+                int e = (a0 << kFix) + kOff;
+                lds_a[0][lane] = e;
+                lds_a[1][lane] = (a1 << kFix) + kOff;
+#pragma unroll
+                for (int k = 2; k < 6; k++) {
+                        e += delta;
+                        lds_a[k][lane] = e;
+                }
+                e += delta;
+                lds_a[6][lane] = m7 ? e : kOff;                         // 5-interpolant mode: entry 6 = 0.0, entry 7 = 1.0 (:55-56)
+                lds_a[7][lane] = m7 ? e + delta : (255 << kFix) + kOff;
+                // ---- palette table: column j = the channel that goes to output byte j (RGBA: by the shifts; BGR: B, G, R; else R, G, B) ----
+                const int b0 = (int) (q.z & 0x1F), g0 = (int) ((q.z >> 5) & 0x3F), r0 = (int) ((q.z >> 11) & 0x1F);
+                const int b1 = (int) ((q.z >> 16) & 0x1F), g1 = (int) ((q.z >> 21) & 0x3F), r1 = (int) (q.z >> 27);
+                const int nb[4] = { 3 * b0, 3 * b1, 2 * b0 + b1, b0 + 2 * b1 }, ng[4] = { 3 * g0, 3 * g1, 2 * g0 + g1, g0 + 2 * g1 },
+                          nr[4] = { 3 * r0, 3 * r1, 2 * r0 + r1, r0 + 2 * r1 };
+                const int col_r = OUT == UG_PF_RGBA ? o.rs >> 3 : (OUT == UG_PF_BGR ? 2 : 0), col_b = OUT == UG_PF_RGBA ? o.bs >> 3 : (OUT == UG_PF_BGR ? 0 : 2);
+                const int col_g = OUT == UG_PF_RGBA ? o.gs >> 3 : 1; // (wave-uniform: the three stores below go through scalar address arithmetic)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                        const double s = lds_rs[nb[k]];
+                        const double u = __builtin_fma((double) nr[k], 1.0 / 93.0, -5.01960814E-01);  // r - c
+                        const double v = __builtin_fma((double) ng[k], 1.0 / 189.0, -5.01960814E-01); // g - c
+                        lds_a[8 + 4 * col_r + k][lane] = rn_i32((u - v) * s);
+                        lds_a[8 + 4 * col_g + k][lane] = rn_i32(v * s);
+                        lds_a[8 + 4 * col_b + k][lane] = rn_i32(-(u + v) * s);
+                }
+                // ---- pixels ---- (LDS traffic is lane-private: no barrier, a wave's own ds ops are ordered)
+                const uint32_t aidx[2] = { (q.x >> 16) | (q.y << 16), q.y >> 8 }; // alpha indices of pixels 0-7 (24 bits) / 8-15
+                const uint32_t mask = (1u << kFix) - 1u;
+                const char *const colbase = (const char *) &lds_a[0][lane];
+                const int opaque = 0x7FF00000; // >> 20 saturates to 255: the alpha byte
+                uint32_t near = 0xFFFFFFFFu;
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                        int t0[4], t1[4], t2[4];
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                                const int i = 4 * y + x;
+                                // row = 64 lanes x 4 B = 256 B: address = this lane's column + (index << 8); one v_bfe_u32 + one v_lshl_add_u32 per index
+                                // (the empty asm keeps the compiler from folding the field extraction into shift + and + add: three instructions)
+                                uint32_t ai = __builtin_amdgcn_ubfe(aidx[i >> 3], 3 * (i & 7), 3), ci = __builtin_amdgcn_ubfe(q.w, 2 * i, 2);
+                                asm("" : "+v"(ai), "+v"(ci));
+                                const int A = *(const int *) (colbase + (ai << 8));
+                                const char *pc = colbase + 8 * 256 + (ci << 8);
+                                t0[x] = A + *(const int *) pc;
+                                t1[x] = A + *(const int *) (pc + 4 * 256);
+                                t2[x] = A + *(const int *) (pc + 8 * 256);
+                                near = min(near, min(min((uint32_t) t0[x] & mask, (uint32_t) t1[x] & mask), (uint32_t) t2[x] & mask));
+                        }
+                        uint8_t *row = o.dst + (long) (4 * by + y) * o.pitch;
+                        if (OUT == UG_PF_RGBA) {
+                                ((uint4 *) row)[bx] = make_uint4(pk2_u8(t0[0], t1[0], t2[0], opaque), pk2_u8(t0[1], t1[1], t2[1], opaque),
+                                                                 pk2_u8(t0[2], t1[2], t2[2], opaque), pk2_u8(t0[3], t1[3], t2[3], opaque));
+                        } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
+                                uint32_t *d = (uint32_t *) row + 3 * bx;
+                                d[0] = pk2_u8(t0[0], t1[0], t2[0], t0[1]);
+                                d[1] = pk2_u8(t1[1], t2[1], t0[2], t1[2]);
+                                d[2] = pk2_u8(t2[2], t0[3], t1[3], t2[3]);
+                        } else { // UYVY: rgba_to_yuv422.glsl in fixed point; a pair with a value near a rounding boundary goes through the shader's own fp32 operations
+                                uint32_t w2[2];
+#pragma unroll
+                                for (int k = 0; k < 2; k++) {
+                                        const uint32_t ra = clamp_shift(t0[2 * k]), ga = clamp_shift(t1[2 * k]), ba = clamp_shift(t2[2 * k]);
+                                        const uint32_t rb = clamp_shift(t0[2 * k + 1]), gb = clamp_shift(t1[2 * k + 1]), bb = clamp_shift(t2[2 * k + 1]);
+                                        uint32_t un;
+                                        w2[k] = uyvy_pair_fixed(ra, ga, ba, rb, gb, bb, un);
+                                        if (un < 2u * kGuardUyvy) w2[k] = rgb_pair_to_uyvy_call<AWAY>(ra | ga << 8 | ba << 16, rb | gb << 8 | bb << 16, unorm);
+                                }
+                                ((uint2 *) row)[bx] = make_uint2(w2[0], w2[1]);
+                        }
+                }
+                redo = MODE == 0 && near < 2u * kGuard;
+                if (flagged != nullptr && near < 2u * kGuard) atomicAdd(flagged, 1u);
+        }
+        // the guarded blocks again, exactly (their rows are stored a second time, behind the first store of the same lane); the palette
+        // of the exact path overlays this lane's column of the fixed-point one, which is not read any more
+        if (redo) decode_block_exact<OUT, AWAY>(q, o, bx, by, (double2 *) &lds_a[0][0] + lane, unorm);
+}
+
+template <int OUT, bool AWAY, int MODE> // MODE 0: fixed point + guard + exact fallback (the product); 1: exact only; 2: fixed point only (tests)
+__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh, int rpw, unsigned *__restrict__ flagged)
+{
+        // per-lane tables, one region per wave, entry-major inside it so that a wave's accesses to one entry are contiguous (conflict-free
+        // whatever the indices): rows 0-7 the luma entries, rows 8 + 4 j + k = palette entry k of output byte j.  The exact path overlays
+        // the region of ITS wave with 4 x 64 (Co, Cg) pairs of doubles (4 KiB of the 5 KiB) once the wave has read its fixed-point tables.
+        __shared__ __attribute__((aligned(16))) int lds_tab[4][20][64];
+        __shared__ double lds_rs[96];
+        __shared__ float unorm[OUT == UG_PF_UYVY ? 256 : 1];
+        const int t = threadIdx.y * 64 + threadIdx.x, lane = threadIdx.x;
+        int (*const lds_a)[64] = lds_tab[threadIdx.y];
+        if (OUT == UG_PF_UYVY) unorm[t] = (float) t / 255.0f;
+        if (MODE != 1 && t < 94) lds_rs[t] = (1048576.0 * 255.0 * 744.0) / (255.0 * (double) t + 744.0); // 2^20 * 255 * scale(nb = t)
+        if (OUT == UG_PF_UYVY || MODE != 1) __syncthreads();
+        // A wave decodes `rpw` block rows, 4 apart (the 4 waves of the workgroup interleave), and has the next row's blocks in flight
+        // while it decodes the current one: with one row per wave the load latency (~2 us under load) is a quarter of a wave's life
+        // and 7 resident waves per SIMD leave the VALU idle 30 % of the time (profiles/r03_dxt_decode_pmc.txt).
+        const int bx = blockIdx.x * 64 + threadIdx.x;
+        int by = blockIdx.y * 4 * rpw + threadIdx.y;
+        if (bx >= bw || by >= bh) return;
+        uint4 q = src[(long) by * bw + bx];
+        for (int it = 0;; it++, by += 4) {
+                const bool more = it + 1 < rpw && by + 4 < bh; // wave-uniform
+                uint4 q_next = q;
+                if (more) q_next = src[(long) (by + 4) * bw + bx];
+                dxt5_decode_one<OUT, AWAY, MODE>(q, o, bx, by, lds_a, lds_rs, unorm, lane, flagged);
+                if (!more) break;
+                q = q_next;
         }
 }
 
@@ -292,13 +511,29 @@ __global__ void selftest_div_kernel(unsigned *mismatches)
         if (bad) atomicAdd(mismatches, bad);
 }
 
+// test hook (ug_hip_dxt_decode_debug): which DXT5-YCoCg path runs, and where the guarded blocks are counted
+int g_dxt5_mode = 0;
+unsigned *g_dxt5_flagged = nullptr;
+
 template <int OUT, bool AWAY>
 int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
 {
         const int bw = w / 4, bh = h / 4;
         const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
         if (in == UG_DXT5_YCOCG) {
-                hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY>), grid, block, 0, st, (const uint4 *) src, o, bw, bh);
+                // block rows per wave: 1 until the launch holds more than ~3 generations of resident waves (7 x 1024 wave slots), then up to 4
+                static const int forced_rpw = getenv("UG_DXT5_DEC_RPW") ? atoi(getenv("UG_DXT5_DEC_RPW")) : 0;
+                const long waves = (long) grid.x * bh;
+                int rpw = waves >= 16 * 7168 ? 4 : (waves >= 6 * 7168 ? 2 : 1);
+                if (forced_rpw >= 1 && forced_rpw <= 16) rpw = forced_rpw;
+                const dim3 g5(grid.x, (unsigned) ((bh + 4 * rpw - 1) / (4 * rpw)));
+                if (g_dxt5_mode == 1) {
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 1>), g5, block, 0, st, (const uint4 *) src, o, bw, bh, rpw, g_dxt5_flagged);
+                } else if (g_dxt5_mode == 2) {
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 2>), g5, block, 0, st, (const uint4 *) src, o, bw, bh, rpw, g_dxt5_flagged);
+                } else {
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 0>), g5, block, 0, st, (const uint4 *) src, o, bw, bh, rpw, g_dxt5_flagged);
+                }
         } else if (in == UG_DXT1_YUV) {
                 hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true, AWAY>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         } else {
@@ -366,6 +601,17 @@ extern "C" int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_d
                                  int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
 {
         return ug_hip_dxt_decode_ex(in, out, src_dev, dst_dev, width, height, dst_pitch, rshift, gshift, bshift, UG_DXT_TIES_DEFAULT, stream);
+}
+
+// Test hook, not part of the product API's contract: selects the DXT5-YCoCg decode path of the calls that follow (0 = product: fixed point
+// + guard + exact fallback; 1 = the exact fp64 statements only; 2 = fixed point only, no fallback) and, with a device counter, counts the
+// blocks whose fixed-point values came within the guard band of an integer.  Process-wide; tests restore mode 0 / nullptr.
+extern "C" int ug_hip_dxt_decode_debug(int mode, unsigned *flagged_blocks_dev)
+{
+        if (mode < 0 || mode > 2) return UG_HIP_EINVAL;
+        g_dxt5_mode = mode;
+        g_dxt5_flagged = flagged_blocks_dev;
+        return UG_HIP_SUCCESS;
 }
 
 // Runs the exhaustive comparison of the decoders' constant-divisor quotients with the IEEE division; *mismatches must come back 0.
