@@ -113,6 +113,25 @@ __device__ __forceinline__ uint32_t uyvy_pair_fixed(uint32_t r0, uint32_t g0, ui
         return __builtin_amdgcn_perm(y0, u, 0x0c0c0703u) | __builtin_amdgcn_perm(y1, v, 0x07030c0cu);
 }
 
+// The same on PACKED bytes (what V_ASHR_PK_U8_I32 leaves): d0 = R0 | G0 << 8 | B0 << 16 | R1 << 24, d1 = G1 | B1 << 8 | (anything) << 16.
+// SDWA operand selects read the bytes in place: a 24-bit multiply or an add takes its 8-bit operand straight out of the packed word.
+#define UG_MUL24_BYTE(dst, k, packed, n) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #n : "=v"(dst) : "v"(k), "v"(packed))
+#define UG_ADD_BYTES(dst, a, i, b, j) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #i " src1_sel:BYTE_" #j : "=v"(dst) : "v"(a), "v"(b))
+__device__ __forceinline__ uint32_t uyvy_pair_fixed_packed(uint32_t d0, uint32_t d1, uint32_t &near)
+{
+        const uint32_t cyr = kYr, cyg = kYg, cyb = kYb; // in registers: SDWA takes no literal
+        uint32_t a0, a1, a2, b0, b1, b2, sr, sg, sb;
+        UG_MUL24_BYTE(a0, cyr, d0, 0); UG_MUL24_BYTE(a1, cyg, d0, 1); UG_MUL24_BYTE(a2, cyb, d0, 2);
+        UG_MUL24_BYTE(b0, cyr, d0, 3); UG_MUL24_BYTE(b1, cyg, d1, 0); UG_MUL24_BYTE(b2, cyb, d1, 1);
+        UG_ADD_BYTES(sr, d0, 0, d0, 3); UG_ADD_BYTES(sg, d0, 1, d1, 0); UG_ADD_BYTES(sb, d0, 2, d1, 1);
+        const uint32_t y0 = (a0 + a1) + (a2 + kY0), y1 = (b0 + b1) + (b2 + kY0);
+        const uint32_t u = (__umul24(kUb, sb) + kC0) - (__umul24(kUr, sr) + __umul24(kUg, sg));
+        const uint32_t v = (__umul24(kVr, sr) + kC0) - (__umul24(kVg, sg) + __umul24(kVb, sb));
+        const uint32_t m = 0xFFFFFFu;
+        near = min(min(y0 & m, y1 & m), min(u & m, v & m));
+        return __builtin_amdgcn_perm(y0, u, 0x0c0c0703u) | __builtin_amdgcn_perm(y1, v, 0x07030c0cu);
+}
+
 // x / C for the constant divisors of the decoder (255, 31, 63, 7, 5, 3), correctly rounded without the generic IEEE division
 // sequence (v_div_scale x2, v_rcp, 4-5 fma, v_div_fmas, v_div_fixup): q = RN(x * RN(1/C)), one exact residual r = fma(-q, C, x),
 // one correction RN(q + r * RN(1/C)).  For these divisors and the (finite, small) sets of numerators the decoder produces the
@@ -151,14 +170,14 @@ __device__ __forceinline__ void store_words(const OutArgs &o, int y, int bx, con
 {
         uint8_t *row = o.dst + (long) y * o.pitch;
         if (OUT == UG_PF_RGBA) {
-                ((uint4 *) row)[bx] = make_uint4(p[0], p[1], p[2], p[3]);
+                ug::st_stream((uint4 *) row + bx, make_uint4(p[0], p[1], p[2], p[3]));
         } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
                 uint32_t *d = (uint32_t *) row + 3 * bx;
-                d[0] = p[0] | p[1] << 24;
-                d[1] = (p[1] >> 8) | p[2] << 16;
-                d[2] = (p[2] >> 16) | p[3] << 8;
+                ug::st_stream(d, p[0] | p[1] << 24);
+                ug::st_stream(d + 1, (p[1] >> 8) | p[2] << 16);
+                ug::st_stream(d + 2, (p[2] >> 16) | p[3] << 8);
         } else { // UYVY
-                ((uint2 *) row)[bx] = make_uint2(rgb_pair_to_uyvy<AWAY>(p[0], p[1], unorm), rgb_pair_to_uyvy<AWAY>(p[2], p[3], unorm));
+                ug::st_stream((uint2 *) row + bx, make_uint2(rgb_pair_to_uyvy<AWAY>(p[0], p[1], unorm), rgb_pair_to_uyvy<AWAY>(p[2], p[3], unorm)));
         }
 }
 
@@ -333,24 +352,33 @@ __device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o,
                         }
                         uint8_t *row = o.dst + (long) (4 * by + y) * o.pitch;
                         if (OUT == UG_PF_RGBA) {
-                                ((uint4 *) row)[bx] = make_uint4(pk2_u8(t0[0], t1[0], t2[0], opaque), pk2_u8(t0[1], t1[1], t2[1], opaque),
-                                                                 pk2_u8(t0[2], t1[2], t2[2], opaque), pk2_u8(t0[3], t1[3], t2[3], opaque));
+                                const uint4 v4 = make_uint4(pk2_u8(t0[0], t1[0], t2[0], opaque), pk2_u8(t0[1], t1[1], t2[1], opaque),
+                                                            pk2_u8(t0[2], t1[2], t2[2], opaque), pk2_u8(t0[3], t1[3], t2[3], opaque));
+                                ug::st_stream((uint4 *) row + bx, v4);
                         } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
                                 uint32_t *d = (uint32_t *) row + 3 * bx;
-                                d[0] = pk2_u8(t0[0], t1[0], t2[0], t0[1]);
-                                d[1] = pk2_u8(t1[1], t2[1], t0[2], t1[2]);
-                                d[2] = pk2_u8(t2[2], t0[3], t1[3], t2[3]);
+                                ug::st_stream(d, pk2_u8(t0[0], t1[0], t2[0], t0[1]));
+                                ug::st_stream(d + 1, pk2_u8(t1[1], t2[1], t0[2], t1[2]));
+                                ug::st_stream(d + 2, pk2_u8(t2[2], t0[3], t1[3], t2[3]));
                         } else { // UYVY: rgba_to_yuv422.glsl in fixed point; a pair with a value near a rounding boundary goes through the shader's own fp32 operations
                                 uint32_t w2[2];
 #pragma unroll
                                 for (int k = 0; k < 2; k++) {
+#ifndef UG_DXT5_UYVY_UNPACKED
+                                        const uint32_t d0 = pk2_u8(t0[2 * k], t1[2 * k], t2[2 * k], t0[2 * k + 1]); // R0 G0 B0 R1
+                                        uint32_t d1, un;                                                            // G1 B1 -  -
+                                        asm("v_ashr_pk_u8_i32 %0, %1, %2, 20" : "=v"(d1) : "v"(t1[2 * k + 1]), "v"(t2[2 * k + 1]));
+                                        w2[k] = uyvy_pair_fixed_packed(d0, d1, un);
+                                        if (un < 2u * kGuardUyvy) w2[k] = rgb_pair_to_uyvy_call<AWAY>(d0 & 0xFFFFFFu, d0 >> 24 | (d1 & 0xFFFFu) << 8, unorm);
+#else // A/B variant: clamp each sample on its own, multiply-adds on whole registers (12 % more instructions per block)
                                         const uint32_t ra = clamp_shift(t0[2 * k]), ga = clamp_shift(t1[2 * k]), ba = clamp_shift(t2[2 * k]);
                                         const uint32_t rb = clamp_shift(t0[2 * k + 1]), gb = clamp_shift(t1[2 * k + 1]), bb = clamp_shift(t2[2 * k + 1]);
                                         uint32_t un;
                                         w2[k] = uyvy_pair_fixed(ra, ga, ba, rb, gb, bb, un);
                                         if (un < 2u * kGuardUyvy) w2[k] = rgb_pair_to_uyvy_call<AWAY>(ra | ga << 8 | ba << 16, rb | gb << 8 | bb << 16, unorm);
+#endif
                                 }
-                                ((uint2 *) row)[bx] = make_uint2(w2[0], w2[1]);
+                                ug::st_stream((uint2 *) row + bx, make_uint2(w2[0], w2[1]));
                         }
                 }
                 redo = MODE == 0 && near < 2u * kGuard;
@@ -362,7 +390,7 @@ __device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o,
 }
 
 template <int OUT, bool AWAY, int MODE> // MODE 0: fixed point + guard + exact fallback (the product); 1: exact only; 2: fixed point only (tests)
-__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh, int rpw, unsigned *__restrict__ flagged)
+__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh, unsigned *__restrict__ flagged)
 {
         // per-lane tables, one region per wave, entry-major inside it so that a wave's accesses to one entry are contiguous (conflict-free
         // whatever the indices): rows 0-7 the luma entries, rows 8 + 4 j + k = palette entry k of output byte j.  The exact path overlays
@@ -375,21 +403,11 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
         if (OUT == UG_PF_UYVY) unorm[t] = (float) t / 255.0f;
         if (MODE != 1 && t < 94) lds_rs[t] = (1048576.0 * 255.0 * 744.0) / (255.0 * (double) t + 744.0); // 2^20 * 255 * scale(nb = t)
         if (OUT == UG_PF_UYVY || MODE != 1) __syncthreads();
-        // A wave decodes `rpw` block rows, 4 apart (the 4 waves of the workgroup interleave), and has the next row's blocks in flight
-        // while it decodes the current one: with one row per wave the load latency (~2 us under load) is a quarter of a wave's life
-        // and 7 resident waves per SIMD leave the VALU idle 30 % of the time (profiles/r03_dxt_decode_pmc.txt).
-        const int bx = blockIdx.x * 64 + threadIdx.x;
-        int by = blockIdx.y * 4 * rpw + threadIdx.y;
+        // (one block row per wave: a loop over several rows with the next row's blocks in flight was measured -- 9.3-9.8 us per 4K frame
+        // against 9.0 -- and dropped, profiles/r03_dxt_decode_after.txt)
+        const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
         if (bx >= bw || by >= bh) return;
-        uint4 q = src[(long) by * bw + bx];
-        for (int it = 0;; it++, by += 4) {
-                const bool more = it + 1 < rpw && by + 4 < bh; // wave-uniform
-                uint4 q_next = q;
-                if (more) q_next = src[(long) (by + 4) * bw + bx];
-                dxt5_decode_one<OUT, AWAY, MODE>(q, o, bx, by, lds_a, lds_rs, unorm, lane, flagged);
-                if (!more) break;
-                q = q_next;
-        }
+        dxt5_decode_one<OUT, AWAY, MODE>(src[(long) by * bw + bx], o, bx, by, lds_a, lds_rs, unorm, lane, flagged);
 }
 
 // YUV = true: DXT1_YUV -- the palette holds Y, Cb, Cr and goes through the display matrix of
@@ -458,7 +476,7 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                                 word[p] = (uint32_t) unorm8_out<AWAY>(ua + ub) | ((y4 >> (8 * ca)) & 0xff) << 8 | (uint32_t) unorm8_out<AWAY>(va + vb) << 16 |
                                           ((y4 >> (8 * cb)) & 0xff) << 24;
                         }
-                        ((uint2 *) (o.dst + (long) (4 * by + y) * o.pitch))[bx] = make_uint2(word[0], word[1]);
+                        ug::st_stream((uint2 *) (o.dst + (long) (4 * by + y) * o.pitch) + bx, make_uint2(word[0], word[1]));
                 }
                 return;
         }
@@ -521,18 +539,12 @@ int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h
         const int bw = w / 4, bh = h / 4;
         const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
         if (in == UG_DXT5_YCOCG) {
-                // block rows per wave: 1 until the launch holds more than ~3 generations of resident waves (7 x 1024 wave slots), then up to 4
-                static const int forced_rpw = getenv("UG_DXT5_DEC_RPW") ? atoi(getenv("UG_DXT5_DEC_RPW")) : 0;
-                const long waves = (long) grid.x * bh;
-                int rpw = waves >= 16 * 7168 ? 4 : (waves >= 6 * 7168 ? 2 : 1);
-                if (forced_rpw >= 1 && forced_rpw <= 16) rpw = forced_rpw;
-                const dim3 g5(grid.x, (unsigned) ((bh + 4 * rpw - 1) / (4 * rpw)));
                 if (g_dxt5_mode == 1) {
-                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 1>), g5, block, 0, st, (const uint4 *) src, o, bw, bh, rpw, g_dxt5_flagged);
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 1>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 } else if (g_dxt5_mode == 2) {
-                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 2>), g5, block, 0, st, (const uint4 *) src, o, bw, bh, rpw, g_dxt5_flagged);
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 2>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 } else {
-                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 0>), g5, block, 0, st, (const uint4 *) src, o, bw, bh, rpw, g_dxt5_flagged);
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 0>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 }
         } else if (in == UG_DXT1_YUV) {
                 hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true, AWAY>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);

@@ -733,9 +733,9 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
                 for (int k = 0; k < L::kBlocks; k++) {
                         if (k < n_res) {
                                 if (OUT == UG_DXT5_YCOCG) {
-                                        *(uint4 *) (dst_row + (dst_off + k * kBlockBytes)) = res[k];
+                                        ug::st_stream((uint4 *) (dst_row + (dst_off + k * kBlockBytes)), res[k]);
                                 } else {
-                                        *(uint2 *) (dst_row + (dst_off + k * kBlockBytes)) = make_uint2(res[k].x, res[k].y);
+                                        ug::st_stream((uint2 *) (dst_row + (dst_off + k * kBlockBytes)), make_uint2(res[k].x, res[k].y));
                                 }
                         }
                 }

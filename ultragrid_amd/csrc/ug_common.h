@@ -79,6 +79,26 @@ int pixfmt_ext_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *d
 } // namespace ug
 #ifdef __HIPCC__
 namespace ug {
+// Streaming ("non-temporal") stores.  Every kernel of this library writes its output once and never reads it back; without the `nt` hint
+// a store allocates its line in L2 and is written back when the line is evicted.  Measured (round 3, interleaved A/B on one box,
+// profiles/r03_nt_stores_ab.txt): DXT5-YCoCg -> RGBA, one 4K frame per launch 12.8 -> 9.15 us, 8 frames per launch 8.8 -> 8.05 us per frame.
+// -DUG_NO_STREAM_STORES builds the plain-store library for A/B runs.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#ifndef UG_NO_STREAM_STORES
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v) { __builtin_nontemporal_store(u32x4_t{ v.x, v.y, v.z, v.w }, (u32x4_t *) p); }
+__device__ __forceinline__ void st_stream(uint2 *p, const uint2 &v) { __builtin_nontemporal_store(u32x2_t{ v.x, v.y }, (u32x2_t *) p); }
+__device__ __forceinline__ void st_stream(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(uint16_t *p, uint16_t v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(uint8_t *p, uint8_t v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v) { *p = v; }
+__device__ __forceinline__ void st_stream(uint2 *p, const uint2 &v) { *p = v; }
+__device__ __forceinline__ void st_stream(uint32_t *p, uint32_t v) { *p = v; }
+__device__ __forceinline__ void st_stream(uint16_t *p, uint16_t v) { *p = v; }
+__device__ __forceinline__ void st_stream(uint8_t *p, uint8_t v) { *p = v; }
+#endif
+
 // 128-bit unit I/O of the "K iterations per lane" converter kernels (pixfmt.hip, pixfmt_ext.hip).  A lane's unit is BYTES contiguous
 // bytes.  When that is one 16-byte word the lanes of a wave access consecutive words and nothing else is needed.  When it is
 // several, per-lane accesses would be strided (every load instruction touching 64 different cache lines and using 16 bytes of each --
@@ -112,7 +132,7 @@ struct UnitIO {
         static __device__ __forceinline__ void store(uint4 *region, const uint8_t *priv, uint4 *lds, int lane, int units)
         {
                 if (V == 1) {
-                        if (lane < units) region[lane] = *(const uint4 *) priv;
+                        if (lane < units) st_stream(region + lane, *(const uint4 *) priv);
                         return;
                 }
 #pragma unroll
@@ -122,7 +142,7 @@ struct UnitIO {
 #pragma unroll
                 for (int i = 0; i < V; i++) {
                         const int c = i * 64 + lane;
-                        if (c < units * V) region[c] = lds[(c / V) * ROW + c % V];
+                        if (c < units * V) st_stream(region + c, lds[(c / V) * ROW + c % V]);
                 }
         }
 };
