@@ -65,9 +65,9 @@ __device__ __forceinline__ uint32_t v210w(uint32_t lo, uint32_t mid, uint32_t hi
 __device__ __forceinline__ void st4(uint32_t *dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
         if (((uintptr_t) dst & 15) == 0) {
-                *(uint4 *) dst = make_uint4(w0, w1, w2, w3);
+                ug::st_stream((uint4 *) dst, make_uint4(w0, w1, w2, w3));
         } else {
-                dst[0] = w0, dst[1] = w1, dst[2] = w2, dst[3] = w3;
+                ug::st_stream(dst, w0), ug::st_stream(dst + 1, w1), ug::st_stream(dst + 2, w2), ug::st_stream(dst + 3, w3);
         }
 }
 
@@ -131,10 +131,10 @@ __device__ __forceinline__ void st16(uint16_t *p, const uint32_t (&v)[N], int sh
         }
         if (((uintptr_t) p & 3) == 0 && N % 2 == 0) {
 #pragma unroll
-                for (int i = 0; i < N / 2; i++) ((uint32_t *) p)[i] = (v[2 * i] << shift) | (v[2 * i + 1] << shift) << 16;
+                for (int i = 0; i < N / 2; i++) ug::st_stream((uint32_t *) p + i, (v[2 * i] << shift) | (v[2 * i + 1] << shift) << 16);
         } else {
 #pragma unroll
-                for (int i = 0; i < N; i++) p[i] = (uint16_t) (v[i] << shift);
+                for (int i = 0; i < N; i++) ug::st_stream(p + i, (uint16_t) (v[i] << shift));
         }
 }
 

@@ -326,7 +326,7 @@ struct FastV210toUYVY {
 #undef S
                 }
                 uint2 *dp = (uint2 *) d + 3 * c;
-                dp[0] = make_uint2(o[0], o[1]); dp[1] = make_uint2(o[2], o[3]); dp[2] = make_uint2(o[4], o[5]);
+                ug::st_stream(&dp[0], make_uint2(o[0], o[1])); ug::st_stream(&dp[1], make_uint2(o[2], o[3])); ug::st_stream(&dp[2], make_uint2(o[4], o[5]));
         }
 };
 // UYVY -> RGB: lane 16 B (8 px) in, 24 B out
@@ -346,8 +346,8 @@ struct FastUYVYtoRGB {
                 uint2 *dp = (uint2 *) d + 3 * c;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                        dp[i] = make_uint2(o[8 * i] | o[8 * i + 1] << 8 | o[8 * i + 2] << 16 | (uint32_t) o[8 * i + 3] << 24,
-                                           o[8 * i + 4] | o[8 * i + 5] << 8 | o[8 * i + 6] << 16 | (uint32_t) o[8 * i + 7] << 24);
+                        ug::st_stream(&dp[i], make_uint2(o[8 * i] | o[8 * i + 1] << 8 | o[8 * i + 2] << 16 | (uint32_t) o[8 * i + 3] << 24,
+                                                         o[8 * i + 4] | o[8 * i + 5] << 8 | o[8 * i + 6] << 16 | (uint32_t) o[8 * i + 7] << 24));
                 }
         }
 };
@@ -381,7 +381,7 @@ struct FastRGBtoUYVY {
                         v = ((v / 2) >> kBase) + 128;
                         o[i] = ((uint32_t) (y2 & 0xFF) << 24) | ((v & 0xFF) << 16) | ((y1 & 0xFF) << 8) | (u & 0xFF);
                 }
-                ((uint4 *) d)[c] = make_uint4(o[0], o[1], o[2], o[3]);
+                ug::st_stream(&((uint4 *) d)[c], make_uint4(o[0], o[1], o[2], o[3]));
         }
 };
 // v210 -> RGB (8-bit): lane 32 B (12 px) in, 36 B out
@@ -410,7 +410,7 @@ struct FastV210toRGB {
                 uint32_t *dp = (uint32_t *) d + 9 * c;
 #pragma unroll
                 for (int i = 0; i < 9; i++) {
-                        dp[i] = o[4 * i] | o[4 * i + 1] << 8 | o[4 * i + 2] << 16 | (uint32_t) o[4 * i + 3] << 24;
+                        ug::st_stream(&dp[i], o[4 * i] | o[4 * i + 1] << 8 | o[4 * i + 2] << 16 | (uint32_t) o[4 * i + 3] << 24);
                 }
         }
 };
@@ -421,9 +421,9 @@ struct FastRGBAtoRGB {
         {
                 const uint4 q = ((const uint4 *) s)[c];
                 uint32_t *dp = (uint32_t *) d + 3 * c;
-                dp[0] = (q.x & 0xffffff) | (q.y << 24);
-                dp[1] = ((q.y >> 8) & 0xffff) | (q.z << 16);
-                dp[2] = ((q.z >> 16) & 0xff) | (q.w << 8);
+                ug::st_stream(&dp[0], (q.x & 0xffffff) | (q.y << 24));
+                ug::st_stream(&dp[1], ((q.y >> 8) & 0xffff) | (q.z << 16));
+                ug::st_stream(&dp[2], ((q.z >> 16) & 0xff) | (q.w << 8));
         }
 };
 
@@ -436,7 +436,7 @@ struct FastSwapYUYV {
 #define SW(w) ((((w) & 0x00ff00ffu) << 8) | (((w) >> 8) & 0x00ff00ffu))
                 q.x = SW(q.x); q.y = SW(q.y); q.z = SW(q.z); q.w = SW(q.w);
 #undef SW
-                ((uint4 *) d)[c] = q;
+                ug::st_stream(&((uint4 *) d)[c], q);
         }
 };
 // RGB -> RGBA with shifts: lane 12 B (4 px) in, 16 B out
@@ -453,7 +453,7 @@ struct FastRGBtoRGBA {
                 for (int i = 0; i < 4; i++) {
                         o[i] = am | (px[i] & 0xff) << a.rs | ((px[i] >> 8) & 0xff) << a.gs | (px[i] >> 16) << a.bs;
                 }
-                ((uint4 *) d)[c] = make_uint4(o[0], o[1], o[2], o[3]);
+                ug::st_stream(&((uint4 *) d)[c], make_uint4(o[0], o[1], o[2], o[3]));
         }
 };
 // UYVY -> v210: lane 24 B (12 px) in, 32 B out; consecutive bytes -> 10-bit fields (<< 2), three per word
@@ -476,8 +476,8 @@ struct FastUYVYtoV210 {
                         o[k] = v;
                 }
                 uint4 *dp = (uint4 *) d + 2 * c;
-                dp[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                dp[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                ug::st_stream(&dp[0], make_uint4(o[0], o[1], o[2], o[3]));
+                ug::st_stream(&dp[1], make_uint4(o[4], o[5], o[6], o[7]));
         }
 };
 // UYVY -> RGBA (fp64 arithmetic of vc_copylineUYVYtoRGBA, pixfmt_conv.c:1137-1163): lane 16 B (8 px) in, 32 B out
@@ -503,8 +503,8 @@ struct FastUYVYtoRGBA {
                         }
                 }
                 uint4 *dp = (uint4 *) d + 2 * c;
-                dp[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                dp[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                ug::st_stream(&dp[0], make_uint4(o[0], o[1], o[2], o[3]));
+                ug::st_stream(&dp[1], make_uint4(o[4], o[5], o[6], o[7]));
         }
 };
 
@@ -599,10 +599,10 @@ __global__ __launch_bounds__(256) void uyvy_to_i420_fast(const uint8_t *__restri
                 uu |= (((wa[k] & 0xff) + (wb[k] & 0xff) + 1) >> 1) << (8 * k);
                 vv |= ((((wa[k] >> 16) & 0xff) + ((wb[k] >> 16) & 0xff) + 1) >> 1) << (8 * k);
         }
-        ((uint2 *) (yp + (long) (2 * i) * ypitch))[c] = make_uint2(ya[0], ya[1]);
-        ((uint2 *) (yp + (long) (2 * i + 1) * ypitch))[c] = make_uint2(yb[0], yb[1]);
-        ((uint32_t *) (up + (long) i * upitch))[c] = uu;
-        ((uint32_t *) (vp + (long) i * vpitch))[c] = vv;
+        ug::st_stream(&((uint2 *) (yp + (long) (2 * i) * ypitch))[c], make_uint2(ya[0], ya[1]));
+        ug::st_stream(&((uint2 *) (yp + (long) (2 * i + 1) * ypitch))[c], make_uint2(yb[0], yb[1]));
+        ug::st_stream(&((uint32_t *) (up + (long) i * upitch))[c], uu);
+        ug::st_stream(&((uint32_t *) (vp + (long) i * vpitch))[c], vv);
 }
 // v210_to_p010le, to_planar.c:64-155, the aligned regular case (width % 6 == 0, even height, 4-byte aligned planes): lane = one 6-px
 // group of a row pair, three 32-bit stores per line
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void v210_to_p010le_kernel(const uint8_t *__re
         uint32_t *d1 = (uint32_t *) (yp + (long) (2 * i + 1) * ypitch) + 3 * g;
         uint32_t *dc = (uint32_t *) (uvp + (long) i * uvpitch) + 3 * g;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { d0[k] = o0[k]; d1[k] = o1[k]; dc[k] = oc[k]; }
+        for (int k = 0; k < 3; k++) { ug::st_stream(d0 + k, o0[k]); ug::st_stream(d1 + k, o1[k]); ug::st_stream(dc + k, oc[k]); }
 }
 
 // One v210 group (4 words) -> its six luma samples and six chroma samples (Cb Cr Cb Cr Cb Cr), 10 bits each

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void planar_to_uyvy_kernel(Planes p, uint8_t *
                         const int y = k ? y1 : y0;
                         if (k && y1 == y0) break;
                         const uint8_t *yl = p.y + (long) y * p.y_pitch;
-                        *(uint32_t *) (dst + (long) y * dst_pitch + 4 * i) = uyvy_word(cb, yl[2 * i], cr, tail ? 0 : yl[2 * i + 1]);
+                        ug::st_stream((uint32_t *) (dst + (long) y * dst_pitch + 4 * i), uyvy_word(cb, yl[2 * i], cr, tail ? 0 : yl[2 * i + 1]));
                 }
         }
 }
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void yuv422p10le_to_v210_kernel(Planes p, uint
         o.w = Y[4] | CR[2] << 10 | Y[5] << 20;
         uint8_t *d = dst + (long) y * dst_pitch + 16 * g;
         if (!(15 & (uintptr_t) d)) {
-                *(uint4 *) d = o;
+                ug::st_stream((uint4 *) d, o);
         } else {
                 uint32_t *dw = (uint32_t *) d;
                 dw[0] = o.x; dw[1] = o.y; dw[2] = o.z; dw[3] = o.w;
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void uyvy_to_i422_kernel(const uint8_t *__rest
                         const uint32_t two = ((w[k] >> 8) & 0xff) | (w[k] >> 24) << 8;
                         if (k < 2) yy.x |= two << (16 * k); else yy.y |= two << (16 * (k - 2));
                 }
-                *(uint2 *) (py + (long) y * y_pitch + 8 * i) = yy;
-                *(uint32_t *) (pcb + (long) y * cb_pitch + 4 * i) = cb;
-                *(uint32_t *) (pcr + (long) y * cr_pitch + 4 * i) = cr;
+                ug::st_stream((uint2 *) (py + (long) y * y_pitch + 8 * i), yy);
+                ug::st_stream((uint32_t *) (pcb + (long) y * cb_pitch + 4 * i), cb);
+                ug::st_stream((uint32_t *) (pcr + (long) y * cr_pitch + 4 * i), cr);
         } else {
                 if (i >= (width + 1) / 2) return;
                 const uint32_t w = *(const uint32_t *) (s + 4 * i);
@@ -186,9 +186,9 @@ __global__ __launch_bounds__(256) void uyvy_to_nv12_fast_kernel(const uint8_t *_
                 ya[k >> 1] |= la << (16 * (k & 1));
                 yb[k >> 1] |= lb << (16 * (k & 1));
         }
-        *(uint2 *) (pc + (long) cy * c_pitch + 8 * i) = make_uint2(c[0], c[1]);
-        *(uint2 *) (py + (long) y0 * y_pitch + 8 * i) = make_uint2(ya[0], ya[1]);
-        if (y1 != y0) *(uint2 *) (py + (long) y1 * y_pitch + 8 * i) = make_uint2(yb[0], yb[1]);
+        ug::st_stream((uint2 *) (pc + (long) cy * c_pitch + 8 * i), make_uint2(c[0], c[1]));
+        ug::st_stream((uint2 *) (py + (long) y0 * y_pitch + 8 * i), make_uint2(ya[0], ya[1]));
+        if (y1 != y0) ug::st_stream((uint2 *) (py + (long) y1 * y_pitch + 8 * i), make_uint2(yb[0], yb[1]));
 }
 
 template <int V>

@@ -74,13 +74,13 @@ __device__ __forceinline__ void store_words(uint8_t *dst, const uint32_t (&w)[K]
         if (nbytes == 4 * K && align >= 4) {
                 if (K % 4 == 0 && align >= 16) {
 #pragma unroll
-                        for (int i = 0; i < K / 4; i++) ((uint4 *) dst)[i] = make_uint4(w[4 * i], w[(4 * i + 1) % K], w[(4 * i + 2) % K], w[(4 * i + 3) % K]);
+                        for (int i = 0; i < K / 4; i++) ug::st_stream((uint4 *) dst + i, make_uint4(w[4 * i], w[(4 * i + 1) % K], w[(4 * i + 2) % K], w[(4 * i + 3) % K]));
                 } else if (K % 2 == 0 && align >= 8) {
 #pragma unroll
-                        for (int i = 0; i < K / 2; i++) ((uint2 *) dst)[i] = make_uint2(w[2 * i], w[(2 * i + 1) % K]);
+                        for (int i = 0; i < K / 2; i++) ug::st_stream((uint2 *) dst + i, make_uint2(w[2 * i], w[(2 * i + 1) % K]));
                 } else {
 #pragma unroll
-                        for (int i = 0; i < K; i++) ((uint32_t *) dst)[i] = w[i];
+                        for (int i = 0; i < K; i++) ug::st_stream((uint32_t *) dst + i, w[i]);
                 }
         } else {
 #pragma unroll
