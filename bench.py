@@ -155,19 +155,36 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
             dist.barrier()
         try:
             r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank)
+            # the same traffic without the kernel: what the link alone gives for this in/out byte mix (all ranks at once, like the leg itself)
+            ceil = pipeline.run(wl, depth=3, seconds=min(seconds, 1.0), salt=17 * rank, encode=False)["fps"]
         except Exception as e:   # a rank that cannot run its leg reports 0 fps; the collectives below still see every rank
             print(f"bench.py: e2e leg {wl} failed on rank {rank}: {e}", file=sys.stderr, flush=True)
             _, _, oid, w_, h_ = pipeline.WORKLOADS[wl]
             r = {"fps": 0.0, "pcie_gbs": 0.0, "in_flight": 3, "bytes_in_per_frame": 0, "bytes_out_per_frame": 0, "seconds": 0.0}
+            ceil = 0.0
         from ultragrid_amd import shard
-        rates = shard.gather_rates([r["fps"], r["pcie_gbs"]], dist, device_for_gather)
+        rates = shard.gather_rates([r["fps"], r["pcie_gbs"], ceil], dist, device_for_gather)
         per = [round(x[0], 1) for x in rates]
         pcie = [round(x[1], 2) for x in rates]
+        ceils = [round(x[2], 1) for x in rates]
         w, h = pipeline.WORKLOADS[wl][3], pipeline.WORKLOADS[wl][4]
         res[wl] = {"fps_total": round(sum(per), 1), "fps_per_gpu": per, "mpixels_per_s_total": round(sum(per) * w * h / 1e6, 1),
                    "pcie_gbs_total": round(sum(pcie), 2), "pcie_gbs_per_gpu": pcie, "in_flight": r["in_flight"],
+                   "copy_only_fps_per_gpu": ceils, "frac_of_copy_only": round(sum(per) / sum(ceils), 3) if sum(ceils) else None,
                    "bytes_in_per_frame": r["bytes_in_per_frame"], "bytes_out_per_frame": r["bytes_out_per_frame"], "seconds": r["seconds"]}
-    res["path"] = "pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU on 3 streams, all ranks concurrently"
+    try:   # the box's link by itself (rank 0's GPU; pure copies, 2 in flight per direction)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        lp = pipeline.link_probe(seconds=0.5, streams=2) if rank == 0 else None
+        if dist is not None:
+            dist.barrier()
+        if lp is not None:
+            res["link_gbs_h2d"], res["link_gbs_d2h"], res["link_gbs_bidir_each"] = lp["h2d_gbs"], lp["d2h_gbs"], lp["bidir_each_gbs"]
+    except Exception as e:
+        print(f"bench.py: link probe failed: {e}", file=sys.stderr, flush=True)
+    res["path"] = ("pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU on 3 streams, all ranks concurrently; "
+                   "copy_only_fps = the same copies without the kernel (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
     res["numa_node_rank0"] = node
     res["cpus_bound_rank0"] = bound
     if affinity is not None and bound:

@@ -19,10 +19,25 @@ def main():
     ap.add_argument("--workload", default="all", choices=sorted(pipeline.WORKLOADS) + ["all"])
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--sweep", action="store_true", help="link probe, copy-only ceiling, depth 2-6 and both stream layouts for every workload")
     a = ap.parse_args()
     node = pipeline.gpu_numa_node(torch.cuda.current_device())
     bound = pipeline.bind_to_numa_node(node)
-    for wl in (sorted(pipeline.WORKLOADS) if a.workload == "all" else [a.workload]):
+    wls = sorted(pipeline.WORKLOADS) if a.workload == "all" else [a.workload]
+    if a.sweep:
+        for streams in (1, 2, 4):
+            r = pipeline.link_probe(seconds=min(a.seconds, 1.5), streams=streams)
+            r.update({"probe": "link", "gpu_numa_node": node, "cpus_bound": bound})
+            print(json.dumps(r), flush=True)
+        for wl in wls:
+            for mode in ("per-frame-stream", "split"):
+                for depth in (2, 3, 4, 6):
+                    ceil = pipeline.run(wl, depth=depth, seconds=min(a.seconds, 1.5), mode=mode, encode=False)
+                    r = pipeline.run(wl, depth=depth, seconds=a.seconds, mode=mode)
+                    r.update({"copy_only_fps": ceil["fps"], "copy_only_pcie_gbs": ceil["pcie_gbs"], "frac_of_copy_only": round(r["fps"] / ceil["fps"], 3)})
+                    print(json.dumps(r), flush=True)
+        return
+    for wl in wls:
         r = pipeline.run(wl, depth=a.depth, seconds=a.seconds)
         r.update({"gpu_numa_node": node, "cpus_bound": bound, "device": torch.cuda.get_device_name(0)})
         print(json.dumps(r), flush=True)

@@ -66,41 +66,105 @@ def host_frame(workload: str, salt: int = 0) -> np.ndarray:
     return np.tile(one.reshape(48, ls), (h // 48, 1)).ravel().copy()
 
 
-def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_frames: int = 30, distinct: int = 3, salt: int = 0) -> dict:
-    """`depth` frames in flight (one stream each: H2D, encode, D2H), `distinct` different pinned input frames cycled.
-    Runs for about `seconds`; returns fps, Mpixel/s and the PCIe traffic both ways."""
-    fmt, pf, oid, w, h = WORKLOADS[workload]
-    lib.load()
-    srcs = [torch.from_numpy(host_frame(workload, salt + i)).pin_memory() for i in range(distinct)]
-    in_len = srcs[0].numel()
-    out_len = codec.dxt_size(oid, w, h)
-    slots = [dict(st=torch.cuda.Stream(), dev_in=torch.empty(in_len, dtype=torch.uint8, device="cuda"),
-                  dev_out=torch.empty(out_len, dtype=torch.uint8, device="cuda"),
-                  host_out=torch.empty(out_len, dtype=torch.uint8).pin_memory(), busy=False) for _ in range(depth)]
-
-    def submit(s, i):
-        with torch.cuda.stream(s["st"]):
-            s["dev_in"].copy_(srcs[i % distinct], non_blocking=True)
-            codec.dxt_encode(pf, oid, s["dev_in"], w, h, dst=s["dev_out"])
-            s["host_out"].copy_(s["dev_out"], non_blocking=True)
-        s["busy"] = True
-
+def _rate_loop(submit, slots, seconds: float, min_frames: int):
+    """submit(slot, n) enqueues frame n on a slot; slots are reused round-robin after a synchronise of their last stream"""
     for i, s in enumerate(slots):   # warm-up
         submit(s, i)
     torch.cuda.synchronize()
     n, t0 = 0, time.perf_counter()
     while n < min_frames or time.perf_counter() - t0 < seconds:
-        s = slots[n % depth]
-        if s["busy"]:
-            s["st"].synchronize()
+        s = slots[n % len(slots)]
+        s["done"].synchronize()
         submit(s, n)
         n += 1
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    return n, time.perf_counter() - t0
+
+
+def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_frames: int = 30, distinct: int = 3, salt: int = 0,
+        mode: str = "per-frame-stream", encode: bool = True) -> dict:
+    """`depth` frames in flight, `distinct` different pinned input frames cycled.  Runs for about `seconds`; returns fps, Mpixel/s and the
+    PCIe traffic both ways.
+      mode "per-frame-stream": every frame in flight has its own stream carrying H2D, encode, D2H in order (what the modules do);
+      mode "split": ONE upload stream, ONE compute stream, ONE download stream, events between the stages of a frame (copy engines never
+                    share a stream with the kernel);
+      encode=False: the same traffic without the kernel -- what the link alone gives for this in/out byte mix (the ceiling of the leg)."""
+    fmt, pf, oid, w, h = WORKLOADS[workload]
+    lib.load()
+    srcs = [torch.from_numpy(host_frame(workload, salt + i)).pin_memory() for i in range(distinct)]
+    in_len = srcs[0].numel()
+    out_len = codec.dxt_size(oid, w, h)
+    up, comp, down = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    slots = []
+    for _ in range(depth):
+        st = torch.cuda.Stream()
+        slots.append(dict(st=st, dev_in=torch.empty(in_len, dtype=torch.uint8, device="cuda"), dev_out=torch.empty(out_len, dtype=torch.uint8, device="cuda"),
+                          host_out=torch.empty(out_len, dtype=torch.uint8).pin_memory(), done=torch.cuda.Event(), e_up=torch.cuda.Event(), e_comp=torch.cuda.Event()))
+    for s in slots:
+        s["done"].record()
+
+    def submit(s, i):
+        if mode == "split":
+            with torch.cuda.stream(up):
+                s["dev_in"].copy_(srcs[i % distinct], non_blocking=True)
+                s["e_up"].record()
+            with torch.cuda.stream(comp):
+                comp.wait_event(s["e_up"])
+                if encode:
+                    codec.dxt_encode(pf, oid, s["dev_in"], w, h, dst=s["dev_out"])
+                s["e_comp"].record()
+            with torch.cuda.stream(down):
+                down.wait_event(s["e_comp"])
+                s["host_out"].copy_(s["dev_out"], non_blocking=True)
+                s["done"].record()
+        else:
+            with torch.cuda.stream(s["st"]):
+                s["dev_in"].copy_(srcs[i % distinct], non_blocking=True)
+                if encode:
+                    codec.dxt_encode(pf, oid, s["dev_in"], w, h, dst=s["dev_out"])
+                s["host_out"].copy_(s["dev_out"], non_blocking=True)
+                s["done"].record()
+
+    n, dt = _rate_loop(submit, slots, seconds, min_frames)
     fps = n / dt
     return {"workload": workload, "fps": round(fps, 1), "mpixels_per_s": round(w * h * fps / 1e6, 1), "frames": n, "seconds": round(dt, 3),
-            "in_flight": depth, "pcie_gbs": round((in_len + out_len) * fps / 1e9, 2), "h2d_gbs": round(in_len * fps / 1e9, 2),
+            "in_flight": depth, "mode": mode, "kernel": encode, "pcie_gbs": round((in_len + out_len) * fps / 1e9, 2), "h2d_gbs": round(in_len * fps / 1e9, 2),
             "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len}
+
+
+def link_probe(nbytes: int = 64 << 20, seconds: float = 1.0, streams: int = 2) -> dict:
+    """What the host link of THIS box gives, pure copies between pinned (first-touched after NUMA binding) and device memory:
+    H2D only, D2H only, and both directions at once, `streams` copies in flight per direction."""
+    hs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(streams)]
+    hd = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(streams)]
+    ds = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(streams)]
+    dd = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(streams)]
+    for h_ in hs:
+        h_.fill_(7)
+    sup = [torch.cuda.Stream() for _ in range(streams)]
+    sdn = [torch.cuda.Stream() for _ in range(streams)]
+
+    def loop(do_up: bool, do_down: bool):
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for k in range(streams):
+                if do_up:
+                    with torch.cuda.stream(sup[k]):
+                        ds[k].copy_(hs[k], non_blocking=True)
+                if do_down:
+                    with torch.cuda.stream(sdn[k]):
+                        hd[k].copy_(dd[k], non_blocking=True)
+            for k in range(streams):   # keep one round of copies queued per stream
+                sup[k].synchronize()
+                sdn[k].synchronize()
+            n += streams
+        dt = time.perf_counter() - t0
+        return n * nbytes / dt / 1e9
+    loop(True, True)
+    h2d, d2h, both = loop(True, False), loop(False, True), loop(True, True)
+    return {"copy_bytes": nbytes, "streams_per_direction": streams, "h2d_gbs": round(h2d, 2), "d2h_gbs": round(d2h, 2),
+            "bidir_each_gbs": round(both, 2), "bidir_total_gbs": round(2 * both, 2)}
 
 
 def run_jpeg_decode(width: int = 3840, height: int = 2160, depth: int = 3, seconds: float = 2.0, out: str = "UYVY", quality: int = 75, restart: int = 4) -> dict:
