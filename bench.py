@@ -154,9 +154,9 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
         if dist is not None:
             dist.barrier()
         try:
-            r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank)
+            r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank, mode="split")
             # the same traffic without the kernel: what the link alone gives for this in/out byte mix (all ranks at once, like the leg itself)
-            ceil = pipeline.run(wl, depth=3, seconds=min(seconds, 1.0), salt=17 * rank, encode=False)["fps"]
+            ceil = pipeline.run(wl, depth=3, seconds=min(seconds, 1.0), salt=17 * rank, mode="split", encode=False)["fps"]
         except Exception as e:   # a rank that cannot run its leg reports 0 fps; the collectives below still see every rank
             print(f"bench.py: e2e leg {wl} failed on rank {rank}: {e}", file=sys.stderr, flush=True)
             _, _, oid, w_, h_ = pipeline.WORKLOADS[wl]
@@ -183,8 +183,8 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
             res["link_gbs_h2d"], res["link_gbs_d2h"], res["link_gbs_bidir_each"] = lp["h2d_gbs"], lp["d2h_gbs"], lp["bidir_each_gbs"]
     except Exception as e:
         print(f"bench.py: link probe failed: {e}", file=sys.stderr, flush=True)
-    res["path"] = ("pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU on 3 streams, all ranks concurrently; "
-                   "copy_only_fps = the same copies without the kernel (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
+    res["path"] = ("pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU, all ranks concurrently; "
+                   "one upload, one compute and one download stream with events between the stages of a frame (tools/e2e_bench.py --sweep: better than a stream per frame); copy_only_fps = the same copies without the kernel (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
     res["numa_node_rank0"] = node
     res["cpus_bound_rank0"] = bound
     if affinity is not None and bound:

@@ -96,6 +96,12 @@ int         ug_hip_free_host(void *buffer);                            /* cuda_w
 int         ug_hip_memcpy(void *dst, const void *src, size_t count, int kind);       /* cuda_wrapper_memcpy */
 int         ug_hip_memcpy_async(void *dst, const void *src, size_t count, int kind, ug_hip_stream_t stream);
 int         ug_hip_memset_async(void *dst_dev, int value, size_t count, ug_hip_stream_t stream); /* device memory only */
+/* Copy lanes: the copy goes onto the ONE upload (download) stream of `device` -- shared by every caller in the process, so that concurrent
+ * frames do not split the link between two copies of the same direction -- and is ordered against `stream`: an upload starts after what
+ * `then_stream` holds so far and `then_stream` continues after it; a download starts after what `after_stream` holds so far, and
+ * ug_hip_stream_sync(after_stream) also waits for it.  The calling thread's current device must be `device`. */
+int         ug_hip_upload_ordered(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream);
+int         ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream);
 int         ug_hip_stream_create(ug_hip_stream_t *stream);
 int         ug_hip_stream_destroy(ug_hip_stream_t stream);
 int         ug_hip_stream_sync(ug_hip_stream_t stream);

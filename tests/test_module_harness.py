@@ -715,3 +715,32 @@ def test_frames_through_modules_that_arrived_by_dlopen(tmp_path, po):
     assert r.returncode == 0, r.stdout + r.stderr
     _, crop, _ = po.jpeg_decode_planes(jpg.read_bytes())
     assert np.array_equal(np.fromfile(back, np.uint8), po.planar_to_uyvy(*crop, w, h, chroma=422))
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,codec", [("jpeg:q=80:restart=4", "UYVY"), ("jpeg:q=85:restart=2:subsampling=420", "UYVY"), ("jpeg:q=80:restart=4", "RGB"), ("jpeg:q=80", "v210")])
+def test_batched_workers_deliver_the_same_streams_in_order(tmp_path, po, cfg, codec):
+    """`batch=<n>`: a busy worker queues up to n frames and hands them to ug_hip_jpeg_encoder_encode_batch in one go.
+    14 distinct frames pushed back to back through the reference's compress framework: the streams that come out -- and their order -- are
+    byte for byte those of the one-frame-per-call module (batch=1, what the reference does), with one worker (batches certainly form)
+    and with the default two."""
+    w, h, n = 192, 96, 14
+    frames = []
+    for f in range(n):
+        yy, xx = np.mgrid[0:h, 0:w]
+        rgb = np.stack([128 + 100 * np.sin(xx / (20.0 + f)) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / (21.0 + f)), 128 + 80 * np.sin(yy / 9.0 + f)], -1).clip(0, 255).astype(np.uint8)
+        uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+        frames.append({"UYVY": uyvy, "RGB": rgb.ravel(), "v210": po.convert_frame("UYVY", "v210", uyvy, w, h)}[codec])
+    raw = tmp_path / "in.raw"
+    np.concatenate([np.ascontiguousarray(x).ravel() for x in frames]).tofile(raw)
+    outs = {}
+    for tag, extra in (("one", ":batch=1:workers=1"), ("b4w1", ":batch=4:workers=1"), ("b16w2", ":batch=16"), ("b3w2", ":batch=3:workers=2")):
+        out = tmp_path / f"{tag}.bin"
+        r = _run([cfg + extra, codec, w, h, raw, out, 1, "host", n])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"frames={n}" in r.stdout and "seq=" + ",".join(str(i) for i in range(n)) + "," in r.stdout, r.stdout
+        outs[tag] = out.read_bytes()
+    assert len(set(outs.values())) == 1, {k: len(v) for k, v in outs.items()}
+    assert outs["one"].count(b"\xff\xd8\xff") >= n           # n JPEG streams one after the other
+    assert _run([cfg + ":batch=17", codec, w, h, raw, tmp_path / "x", 1, "host", 1]).returncode == 2   # refused at init

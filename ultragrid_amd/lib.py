@@ -43,6 +43,8 @@ SYMBOLS = {
     "ug_hip_memcpy": (_i, [_vp, _vp, _sz, _i]),
     "ug_hip_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ug_hip_memset_async": (_i, [_vp, _i, _sz, _vp]),
+    "ug_hip_upload_ordered": (_i, [_i, _vp, _vp, _sz, _i, _vp]),
+    "ug_hip_download_ordered": (_i, [_i, _vp, _vp, _sz, _vp]),
     "ug_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "ug_hip_stream_destroy": (_i, [_vp]),
     "ug_hip_stream_sync": (_i, [_vp]),

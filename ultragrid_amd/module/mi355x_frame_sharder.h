@@ -38,16 +38,25 @@ namespace mi355x {
 
 /// encodes one single-tile frame on `device` with the (lazily created) encoder state number `tile`; returns {} on error
 using tile_encoder_t = std::function<std::shared_ptr<video_frame>(int device, unsigned tile, std::shared_ptr<video_frame> in)>;
+/// encodes several single-tile frames of one geometry in one go (one launch sequence, one synchronisation); result i belongs to
+/// frame i, {} = that frame failed.  Optional: a worker without one encodes its queued frames one after another.
+using batch_encoder_t = std::function<std::vector<std::shared_ptr<video_frame>>(int device, std::vector<std::shared_ptr<video_frame>> in)>;
 
 class frame_sharder {
 public:
-        /// one worker per entry of `devices` (a device listed twice gets two workers, i.e. two frames in flight on it)
-        frame_sharder(const std::vector<int> &devices, std::function<tile_encoder_t(int device)> make_encoder)
+        /// one worker per entry of `devices` (a device listed twice gets two workers, i.e. two frames in flight on it).
+        /// max_pending > 1 ("batch=<n>"): a worker that is busy takes up to that many frames into its queue instead of making push()
+        /// wait, and encodes whatever has queued up as one batch -- throughput for sources that deliver faster than one frame per encode
+        /// (files, transcoding); a source at display rate never queues and sees the one-frame path, as with max_pending = 1.
+        frame_sharder(const std::vector<int> &devices, std::function<tile_encoder_t(int device)> make_encoder, unsigned max_pending = 1,
+                      std::function<batch_encoder_t(int device, tile_encoder_t)> make_batch_encoder = nullptr)
+            : m_max_pending(max_pending < 1 ? 1 : max_pending)
         {
                 for (int d : devices) {
                         auto *w = new worker();
                         w->device = d;
                         w->encode_tile = make_encoder(d);
+                        if (make_batch_encoder) w->encode_batch = make_batch_encoder(d, w->encode_tile);
                         m_workers.emplace_back(w);
                 }
                 for (auto &w : m_workers) {
@@ -80,15 +89,17 @@ public:
                 }
                 in->seq = m_in_seq++;
                 size_t index = 0;
-                {       // wait for / select a worker that is not occupied (gpujpeg.cpp:660-673)
+                {       // wait for / select a worker that is not occupied (gpujpeg.cpp:660-673); with batching, else the least loaded one with room
                         std::unique_lock<std::mutex> lk(m_occupancy_lock);
                         m_worker_finished.wait(lk, [&] {
-                                for (index = 0; index < m_workers.size(); index++) {
-                                        if (!m_workers[index]->occupied) return true;
+                                size_t best = m_workers.size();
+                                for (size_t i = 0; i < m_workers.size(); i++) {
+                                        if (m_workers[i]->pending < m_max_pending && (best == m_workers.size() || m_workers[i]->pending < m_workers[best]->pending)) best = i;
                                 }
-                                return false;
+                                index = best;
+                                return best != m_workers.size();
                         });
-                        m_workers[index]->occupied = true;
+                        m_workers[index]->pending++;
                 }
                 give(m_workers[index].get(), std::move(in), false);
         }
@@ -133,11 +144,13 @@ private:
         struct worker {
                 int device = 0;
                 tile_encoder_t encode_tile;
+                batch_encoder_t encode_batch;
+                unsigned pending = 0; // frames given to the worker and not yet delivered (guarded by m_occupancy_lock)
                 std::thread th;
                 std::mutex m;
                 std::condition_variable cv;
                 std::deque<std::pair<std::shared_ptr<video_frame>, bool>> q; // (frame, is_pill)
-                bool occupied = false, quit = false;
+                bool quit = false;
         };
 
         void give(worker *w, std::shared_ptr<video_frame> f, bool pill)
@@ -173,43 +186,69 @@ private:
                 return vf_merge_tiles(out);
         }
 
+        void finish(worker *w, std::shared_ptr<video_frame> out, uint32_t seq, const char *metadata)
+        {
+                result r;
+                r.seq = seq;
+                r.frame = std::move(out);
+                if (r.frame) {
+                        vf_restore_metadata(r.frame.get(), const_cast<char *>(metadata)); // gpujpeg.cpp:188-193
+                        r.frame->seq = r.seq;
+                        r.frame->compress_end = get_time_in_ns(); // the async frame API leaves this to the module (gpujpeg.cpp:188-195)
+                }
+                deliver(std::move(r));
+                {
+                        std::lock_guard<std::mutex> lk(m_occupancy_lock);
+                        w->pending--;
+                }
+                m_worker_finished.notify_one();
+        }
+
         void run(worker *w)
         {
                 for (;;) {
-                        std::pair<std::shared_ptr<video_frame>, bool> item;
+                        std::vector<std::shared_ptr<video_frame>> frames; // what has queued up, up to the pill
+                        bool pill = false;
                         {
                                 std::unique_lock<std::mutex> lk(w->m);
                                 w->cv.wait(lk, [&] { return w->quit || !w->q.empty(); });
                                 if (w->q.empty()) return; // quit
-                                item = std::move(w->q.front());
-                                w->q.pop_front();
+                                while (!w->q.empty() && !pill && frames.size() < m_max_pending) {
+                                        if (w->q.front().second) {
+                                                pill = frames.empty(); // a pill behind frames waits for the next round: order is kept
+                                                if (!pill) break;
+                                        } else {
+                                                frames.push_back(std::move(w->q.front().first));
+                                        }
+                                        w->q.pop_front();
+                                }
                         }
-                        if (item.second) {
+                        if (pill) {
                                 result r;
                                 r.pill = true;
                                 deliver(std::move(r));
                                 continue;
                         }
-                        result r;
-                        r.seq = item.first->seq;
-                        char metadata[VF_METADATA_SIZE];
-                        vf_store_metadata(item.first.get(), metadata);
-                        r.frame = encode_frame(w, std::move(item.first));
-                        if (r.frame) {
-                                vf_restore_metadata(r.frame.get(), metadata); // gpujpeg.cpp:188-193
-                                r.frame->seq = r.seq;
-                                r.frame->compress_end = get_time_in_ns(); // the async frame API leaves this to the module (gpujpeg.cpp:188-195)
+                        std::vector<uint32_t> seqs;
+                        std::vector<std::vector<char>> meta(frames.size(), std::vector<char>(VF_METADATA_SIZE));
+                        bool batchable = frames.size() > 1 && (bool) w->encode_batch;
+                        for (size_t i = 0; i < frames.size(); i++) {
+                                seqs.push_back(frames[i]->seq);
+                                vf_store_metadata(frames[i].get(), meta[i].data());
+                                batchable = batchable && frames[i]->tile_count == 1 &&
+                                            video_desc_eq(video_desc_from_frame(frames[i].get()), video_desc_from_frame(frames[0].get()));
                         }
-                        deliver(std::move(r));
-                        {
-                                std::lock_guard<std::mutex> lk(m_occupancy_lock);
-                                w->occupied = false;
+                        if (batchable) {
+                                std::vector<std::shared_ptr<video_frame>> outs = w->encode_batch(w->device, std::move(frames));
+                                for (size_t i = 0; i < seqs.size(); i++) finish(w, i < outs.size() ? std::move(outs[i]) : nullptr, seqs[i], meta[i].data());
+                        } else {
+                                for (size_t i = 0; i < seqs.size(); i++) finish(w, encode_frame(w, std::move(frames[i])), seqs[i], meta[i].data());
                         }
-                        m_worker_finished.notify_one();
                 }
         }
 
         std::vector<std::unique_ptr<worker>> m_workers;
+        const unsigned m_max_pending;
         std::mutex m_occupancy_lock;
         std::condition_variable m_worker_finished;
         uint32_t m_in_seq = 0;
@@ -243,6 +282,7 @@ inline std::vector<int> parse_device_list(const char *s)
 using tile_init_t = void *(*)(struct module *parent, const char *cfg);
 using tile_compress_t = std::shared_ptr<video_frame> (*)(void *state, std::shared_ptr<video_frame> in);
 using tile_done_t = void (*)(void *state);
+using tile_compress_batch_t = std::vector<std::shared_ptr<video_frame>> (*)(void *state, std::vector<std::shared_ptr<video_frame>> in);
 
 struct sharded_module {
         std::unique_ptr<frame_sharder> sharder;
@@ -256,16 +296,17 @@ struct tile_state_set {
         ~tile_state_set() { for (void *s : states) done(s); }
 };
 
-/// cfg = the module's option string; "dev=<n>[,<n>...]" and "workers=<per device>" are consumed here, everything else goes to tile_init unchanged
-/// (with ":dev=<n>" of the worker appended).  Returns what tile_init returns for a bad / help configuration.
+/// cfg = the module's option string; "dev=<n>[,<n>...]", "workers=<per device>" and "batch=<frames>" are consumed here, everything else goes to
+/// tile_init unchanged (with ":dev=<n>" of the worker appended).  Returns what tile_init returns for a bad / help configuration.
 inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t tile_init, tile_compress_t tile_compress, tile_done_t tile_done,
-                          int (*set_device)(int))
+                          int (*set_device)(int), tile_compress_batch_t tile_compress_batch = nullptr)
 {
         std::string rest, all = cfg ? cfg : "";
         std::vector<int> devices{ 0 };
         // Two workers per device by default: upload, kernels and download of consecutive frames overlap on one GPU (measured through
         // the reference framework over 4 000 4K frames: DXT5 1 979 -> 3 079 fps, JPEG 2 126 -> 2 393 fps, 8K v210 346 -> 445 fps); workers=1 gives the reference's one-per-device.
         int workers_per_device = 2;
+        int batch = 1; // frames a busy worker may queue and then encode together ("batch=<n>"); 1 = the reference's one frame per worker
         size_t pos = 0;
         while (pos <= all.size() && !all.empty()) {
                 const size_t end = all.find(':', pos);
@@ -277,6 +318,8 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
                         devices = parse_device_list(tok.c_str() + 4);
                 } else if (strncasecmp(tok.c_str(), "workers=", 8) == 0) {
                         workers_per_device = atoi(tok.c_str() + 8);
+                } else if (strncasecmp(tok.c_str(), "batch=", 6) == 0) {
+                        batch = atoi(tok.c_str() + 6);
                 } else if (!tok.empty()) {
                         rest += (rest.empty() ? "" : ":") + tok;
                 }
@@ -285,6 +328,10 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
         }
         if (workers_per_device < 1 || workers_per_device > 8) {
                 log_msg(LOG_LEVEL_ERROR, "[MI355X] workers=<n> must be 1..8\n");
+                return nullptr;
+        }
+        if (batch < 1 || batch > 16) {
+                log_msg(LOG_LEVEL_ERROR, "[MI355X] batch=<n> must be 1..16\n");
                 return nullptr;
         }
         {
@@ -306,17 +353,36 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
         }
         tile_done(probe);
         auto *m = new sharded_module();
+        // the per-tile encoder states of a worker are shared by its tile encoder and its batch encoder (which uses state 0)
+        auto ensure = [=](const std::shared_ptr<tile_state_set> &set, int dev, unsigned tile) -> void * {
+                while (set->states.size() <= tile) {
+                        void *st = tile_init(parent, cfg_for(dev).c_str());
+                        if (st == nullptr || st == INIT_NOERR) return nullptr;
+                        set->states.push_back(st);
+                }
+                return set->states[tile];
+        };
+        std::function<batch_encoder_t(int, tile_encoder_t)> make_batch;
+        auto current = std::make_shared<std::shared_ptr<tile_state_set>>(); // handed from make_encoder to make_batch of the same worker
+        if (tile_compress_batch != nullptr && batch > 1) {
+                make_batch = [=](int, tile_encoder_t) -> batch_encoder_t {
+                        std::shared_ptr<tile_state_set> set = *current;
+                        return [=](int dev, std::vector<std::shared_ptr<video_frame>> in) -> std::vector<std::shared_ptr<video_frame>> {
+                                void *st = ensure(set, dev, 0);
+                                if (st == nullptr) return {};
+                                return tile_compress_batch(st, std::move(in));
+                        };
+                };
+        }
         m->sharder.reset(new frame_sharder(devices, [=](int) -> tile_encoder_t {
                 auto set = std::make_shared<tile_state_set>(tile_done);
+                *current = set;
                 return [=](int dev, unsigned tile, std::shared_ptr<video_frame> in) -> std::shared_ptr<video_frame> {
-                        while (set->states.size() <= tile) {
-                                void *st = tile_init(parent, cfg_for(dev).c_str());
-                                if (st == nullptr || st == INIT_NOERR) return {};
-                                set->states.push_back(st);
-                        }
-                        return tile_compress(set->states[tile], std::move(in));
+                        void *st = ensure(set, dev, tile);
+                        if (st == nullptr) return {};
+                        return tile_compress(st, std::move(in));
                 };
-        }));
+        }, (unsigned) batch, make_batch));
         return m;
 }
 

@@ -248,7 +248,7 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
                 enc_src = tx->tiles[0].data;
         } else {
                 const bool dev = tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data);
-                CHECK_HIP(ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
+                CHECK_HIP(ug_hip_upload_ordered(s->device, s->dev_in, tx->tiles[0].data, s->in_len, dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
                           "upload failed", return {});
         }
         const void *const wire_src = enc_src;
@@ -261,8 +261,7 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
                   "Encoding failed", return {});
 
         std::shared_ptr<video_frame> out = s->pool.get_frame();
-        CHECK_HIP(ug_hip_memcpy_async(out->tiles[0].data, s->dev_out, s->out_len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream),
-                  "D2H copy failed", return {});
+        CHECK_HIP(ug_hip_download_ordered(s->device, out->tiles[0].data, s->dev_out, s->out_len, s->stream), "D2H copy failed", return {});
         CHECK_HIP(ug_hip_stream_sync(s->stream), "stream sync failed", return {});
         out->tiles[0].data_len = (unsigned int) s->out_len;
         return out;

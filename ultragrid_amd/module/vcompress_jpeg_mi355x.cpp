@@ -17,6 +17,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "debug.h"
 #include "host.h"
@@ -56,21 +57,27 @@ struct state_video_compress_jpeg_mi355x {
         ug_hip_jpeg_encoder *enc = nullptr;
         void                *dev_in = nullptr, *dev_target = nullptr, *dev_uyvy = nullptr, *dev_out = nullptr;
         size_t               in_len = 0, max_out = 0;
+        // the same buffers once per frame of a batch (batch=<n>): grown on first use
+        int                  batch_cap = 0;
+        size_t               b_in_stride = 0, b_target_stride = 0, b_enc_stride = 0, b_out_stride = 0;
+        void                *b_in = nullptr, *b_target = nullptr, *b_enc = nullptr, *b_out = nullptr;
         video_frame_pool     pool{0, hip_pinned_allocator()};
 };
 
 void cleanup(state_video_compress_jpeg_mi355x *s)
 {
         if (s->enc) { ug_hip_jpeg_encoder_destroy(s->enc); s->enc = nullptr; }
-        for (void **p : { &s->dev_in, &s->dev_target, &s->dev_uyvy, &s->dev_out }) {
+        for (void **p : { &s->dev_in, &s->dev_target, &s->dev_uyvy, &s->dev_out, &s->b_in, &s->b_target, &s->b_enc, &s->b_out }) {
                 if (*p) { ug_hip_free(*p); *p = nullptr; }
         }
+        s->batch_cap = 0;
 }
 
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y709][:dev=<index>[,<index>...]][:workers=<per device>]\n"
+               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y709][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>]\n"
+               "\t\tbatch       - frames a busy worker may queue and encode together (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
                "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
                "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
@@ -242,8 +249,8 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
         const void *enc_src = s->dev_in;
         if (ug_hip_pointer_device(tx->tiles[0].data) == s->device && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
                 enc_src = tx->tiles[0].data;
-        } else if (ug_hip_memcpy_async(s->dev_in, tx->tiles[0].data, s->in_len, on_dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE,
-                                       s->stream) != UG_HIP_SUCCESS) {
+        } else if (ug_hip_upload_ordered(s->device, s->dev_in, tx->tiles[0].data, s->in_len, on_dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE,
+                                         s->stream) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "upload failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
@@ -267,12 +274,92 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
                 return {};
         }
         std::shared_ptr<video_frame> out = s->pool.get_frame();
-        if (ug_hip_memcpy_async(out->tiles[0].data, s->dev_out, len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) != UG_HIP_SUCCESS ||
+        if (ug_hip_download_ordered(s->device, out->tiles[0].data, s->dev_out, len, s->stream) != UG_HIP_SUCCESS ||
             ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "D2H copy failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
         out->tiles[0].data_len = (unsigned int) len;
+        return out;
+}
+
+/// `frames` queued frames of one geometry in one go: per frame the upload (+ the device-side decoder_t passes) into its slice of the batch
+/// buffers, then ONE ug_hip_jpeg_encoder_encode_batch (fused front end grid.z = frame, entropy coder + compaction grid.y = frame, one
+/// synchronisation) and the downloads.  Streams are byte-identical to the one-frame path's.  Anything unusual -> the one-frame path.
+std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state, std::vector<std::shared_ptr<video_frame>> in)
+{
+        auto *s = static_cast<state_video_compress_jpeg_mi355x *>(state);
+        const int n = (int) in.size();
+        std::vector<std::shared_ptr<video_frame>> out(in.size());
+        auto one_by_one = [&] {
+                for (size_t i = 0; i < in.size(); i++) out[i] = jpeg_mi355x_compress_tile(state, std::move(in[i]));
+                return out;
+        };
+        if (n < 2 || n > 16 || ug_hip_set_device(s->device) != UG_HIP_SUCCESS) return one_by_one();
+        if (!video_desc_eq_excl_param(video_desc_from_frame(in[0].get()), s->saved_desc, PARAM_TILE_COUNT)) {
+                out[0] = jpeg_mi355x_compress_tile(state, in[0]); // (re)configures; the rest of this round follows one by one
+                for (size_t i = 1; i < in.size(); i++) out[i] = jpeg_mi355x_compress_tile(state, std::move(in[i]));
+                return out;
+        }
+        const int w = (int) in[0]->tiles[0].width, h = (int) in[0]->tiles[0].height;
+        if (n > s->batch_cap) {
+                for (void **p : { &s->b_in, &s->b_target, &s->b_enc, &s->b_out }) {
+                        if (*p) { ug_hip_free(*p); *p = nullptr; }
+                }
+                auto round16 = [](size_t v) { return (v + 15) / 16 * 16; };
+                s->b_in_stride = round16(s->in_len + MAX_PADDING);
+                s->b_target_stride = round16((size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->target == UG_PF_I420 ? UG_PF_UYVY : s->target)) * h + MAX_PADDING);
+                s->b_enc_stride = round16((size_t) vc_get_linesize(w, s->enc_in == UG_PF_RGB ? RGB : UYVY) * h + MAX_PADDING);
+                s->b_out_stride = round16(s->max_out);
+                bool ok = ug_hip_malloc(&s->b_in, s->b_in_stride * 16) == UG_HIP_SUCCESS && ug_hip_malloc(&s->b_out, s->b_out_stride * 16) == UG_HIP_SUCCESS;
+                if (ok && s->wire != s->target) ok = ug_hip_malloc(&s->b_target, s->b_target_stride * 16) == UG_HIP_SUCCESS;
+                if (ok && s->target != s->enc_in) ok = ug_hip_malloc(&s->b_enc, s->b_enc_stride * 16) == UG_HIP_SUCCESS;
+                if (!ok) {
+                        MSG(WARNING, "no device memory for the batch buffers (%s): frames are encoded one by one\n", ug_hip_last_error_string());
+                        return one_by_one();
+                }
+                s->batch_cap = 16;
+        }
+        // every frame into its slice: upload (or device-to-device), wire -> target -> encoder input with the pixfmt_conv.c arithmetic
+        const char *enc_base = (const char *) s->b_in;
+        size_t enc_stride = s->b_in_stride;
+        for (int f = 0; f < n; f++) {
+                const bool on_dev = in[f]->mem_location == CUDA_MEM || ug_hip_pointer_is_device(in[f]->tiles[0].data);
+                char *slice = (char *) s->b_in + f * s->b_in_stride;
+                if (ug_hip_upload_ordered(s->device, slice, in[f]->tiles[0].data, s->in_len, on_dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream) != UG_HIP_SUCCESS) {
+                        MSG(ERROR, "upload failed: %s\n", ug_hip_last_error_string());
+                        return out;
+                }
+                const void *cur = slice;
+                if (s->wire != s->target) {
+                        void *t = (char *) s->b_target + f * s->b_target_stride;
+                        if (ug_hip_pixfmt_convert(s->wire, s->target, cur, t, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) return out;
+                        cur = t;
+                }
+                if (s->target != s->enc_in) {
+                        void *t = (char *) s->b_enc + f * s->b_enc_stride;
+                        if (ug_hip_pixfmt_convert(s->target, s->enc_in, cur, t, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) return out;
+                }
+        }
+        if (s->target != s->enc_in) { enc_base = (const char *) s->b_enc; enc_stride = s->b_enc_stride; }
+        else if (s->wire != s->target) { enc_base = (const char *) s->b_target; enc_stride = s->b_target_stride; }
+        size_t lens[16] = {};
+        if (ug_hip_jpeg_encoder_encode_batch(s->enc, s->enc_in, n, enc_base, 0, enc_stride, s->b_out, s->b_out_stride, s->max_out, lens, s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "Encoding failed: %s\n", ug_hip_last_error_string());
+                return out;
+        }
+        for (int f = 0; f < n; f++) {
+                out[f] = s->pool.get_frame();
+                if (ug_hip_download_ordered(s->device, out[f]->tiles[0].data, (char *) s->b_out + f * s->b_out_stride, lens[f], s->stream) != UG_HIP_SUCCESS) {
+                        out[f].reset();
+                        continue;
+                }
+                out[f]->tiles[0].data_len = (unsigned int) lens[f];
+        }
+        if (ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
+                MSG(ERROR, "D2H copy failed: %s\n", ug_hip_last_error_string());
+                for (auto &o : out) o.reset();
+        }
         return out;
 }
 
@@ -303,7 +390,8 @@ compress_module_info get_jpeg_mi355x_module_info()
 /// module-level init: consumes dev=<list>, creates one worker (thread + per-tile encoder states) per listed device
 void *jpeg_mi355x_module_init(struct module *parent, const char *cfg)
 {
-        return mi355x::sharded_init(parent, cfg, jpeg_mi355x_compress_init, jpeg_mi355x_compress_tile, jpeg_mi355x_compress_done, ug_hip_set_device);
+        return mi355x::sharded_init(parent, cfg, jpeg_mi355x_compress_init, jpeg_mi355x_compress_tile, jpeg_mi355x_compress_done, ug_hip_set_device,
+                                    jpeg_mi355x_compress_batch);
 }
 
 const struct video_compress_info jpeg_mi355x_info = {
