@@ -322,6 +322,16 @@ def test_frame_sharder_cpu(workers, frames):
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not os.path.exists(SHARDER_TEST), reason="oracle/_ref/ug_sharder_test not built")
+@pytest.mark.parametrize("workers,frames,batch", [(1, 100, 4), (2, 300, 8), (3, 500, 16)])
+def test_frame_sharder_batching_cpu(workers, frames, batch):
+    """batch=<n>: a busy worker queues up to n frames and a batch encoder takes what has queued up; the same properties hold, batches
+    do form, tiled frames and mixed rounds fall back to one at a time, and a frame OBJECT pushed twice in a row (two sequence numbers)
+    comes out twice, in order -- the sequence number travels with the queue entry, not in the shared frame."""
+    r = subprocess.run([SHARDER_TEST, str(workers), str(frames), str(batch)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK") and "batch_calls=0" not in r.stdout, r.stdout + r.stderr
+
+
 @needs_harness
 def test_jpeg_module_registers():
     r = _run(["list"])

@@ -84,10 +84,13 @@ public:
         void push(std::shared_ptr<video_frame> in)
         {
                 if (!in) {
-                        for (auto &w : m_workers) give(w.get(), {}, true);
+                        for (auto &w : m_workers) give(w.get(), {}, true, 0);
                         return;
                 }
-                in->seq = m_in_seq++;
+                // The sequence number travels with the queue entry, not only in the frame: a caller may hand the same frame object in
+                // again while an earlier push of it is still queued (file sources, the test harness), and would overwrite it there.
+                const uint32_t seq = m_in_seq++;
+                in->seq = seq;
                 size_t index = 0;
                 {       // wait for / select a worker that is not occupied (gpujpeg.cpp:660-673); with batching, else the least loaded one with room
                         std::unique_lock<std::mutex> lk(m_occupancy_lock);
@@ -101,7 +104,7 @@ public:
                         });
                         m_workers[index]->pending++;
                 }
-                give(m_workers[index].get(), std::move(in), false);
+                give(m_workers[index].get(), std::move(in), false, seq);
         }
 
         /// consumer thread: frames in the order they were pushed; frames that failed to encode are skipped; {} after the pill
@@ -149,15 +152,20 @@ private:
                 std::thread th;
                 std::mutex m;
                 std::condition_variable cv;
-                std::deque<std::pair<std::shared_ptr<video_frame>, bool>> q; // (frame, is_pill)
+                struct entry {
+                        std::shared_ptr<video_frame> frame;
+                        bool pill;
+                        uint32_t seq;
+                };
+                std::deque<entry> q;
                 bool quit = false;
         };
 
-        void give(worker *w, std::shared_ptr<video_frame> f, bool pill)
+        void give(worker *w, std::shared_ptr<video_frame> f, bool pill, uint32_t seq)
         {
                 {
                         std::lock_guard<std::mutex> lk(w->m);
-                        w->q.emplace_back(std::move(f), pill);
+                        w->q.push_back({ std::move(f), pill, seq });
                 }
                 w->cv.notify_one();
         }
@@ -208,17 +216,19 @@ private:
         {
                 for (;;) {
                         std::vector<std::shared_ptr<video_frame>> frames; // what has queued up, up to the pill
+                        std::vector<uint32_t> seqs;
                         bool pill = false;
                         {
                                 std::unique_lock<std::mutex> lk(w->m);
                                 w->cv.wait(lk, [&] { return w->quit || !w->q.empty(); });
                                 if (w->q.empty()) return; // quit
                                 while (!w->q.empty() && !pill && frames.size() < m_max_pending) {
-                                        if (w->q.front().second) {
+                                        if (w->q.front().pill) {
                                                 pill = frames.empty(); // a pill behind frames waits for the next round: order is kept
                                                 if (!pill) break;
                                         } else {
-                                                frames.push_back(std::move(w->q.front().first));
+                                                frames.push_back(std::move(w->q.front().frame));
+                                                seqs.push_back(w->q.front().seq);
                                         }
                                         w->q.pop_front();
                                 }
@@ -229,11 +239,9 @@ private:
                                 deliver(std::move(r));
                                 continue;
                         }
-                        std::vector<uint32_t> seqs;
                         std::vector<std::vector<char>> meta(frames.size(), std::vector<char>(VF_METADATA_SIZE));
                         bool batchable = frames.size() > 1 && (bool) w->encode_batch;
                         for (size_t i = 0; i < frames.size(); i++) {
-                                seqs.push_back(frames[i]->seq);
                                 vf_store_metadata(frames[i].get(), meta[i].data());
                                 batchable = batchable && frames[i]->tile_count == 1 &&
                                             video_desc_eq(video_desc_from_frame(frames[i].get()), video_desc_from_frame(frames[0].get()));

@@ -3,7 +3,9 @@
  * CPU-only test of mi355x::frame_sharder: a fake tile encoder with random delays and injected failures
  * stands in for the GPU.  Checks: in-order delivery with the sequence numbers of the pushed frames, failed frames skipped,
  * tiled frames split / merged, every worker used, the poison pill ends pop() after all frames came out, metadata kept.
- * Links the reference's own video_frame / vf_split objects (no HIP).  usage: ug_sharder_test [workers] [frames]
+ * Links the reference's own video_frame / vf_split objects (no HIP).  usage: ug_sharder_test [workers] [frames] [batch]
+ * batch > 1: workers queue up to that many frames and a fake batch encoder takes what has queued up (single-tile frames of one
+ * geometry); every third single-tile frame OBJECT is pushed twice in a row (two sequence numbers, one object), as a file source would.
  */
 #include <atomic>
 #include <chrono>
@@ -21,6 +23,8 @@ int main(int argc, char **argv)
 {
         const int workers = argc > 1 ? atoi(argv[1]) : 4;
         const unsigned frames = argc > 2 ? atoi(argv[2]) : 200;
+        const unsigned batch = argc > 3 ? atoi(argv[3]) : 1;
+        std::atomic<unsigned> batch_calls{0}, batched_frames{0};
         std::vector<int> devices;
         for (int i = 0; i < workers; i++) devices.push_back(i);
         std::atomic<unsigned> calls{0};
@@ -44,6 +48,18 @@ int main(int argc, char **argv)
                         out->tiles[0].data[5] = (char) dev;
                         return out;
                 };
+        }, batch, [&](int, mi355x::tile_encoder_t one) -> mi355x::batch_encoder_t {
+                return [&, one](int dev, std::vector<std::shared_ptr<video_frame>> in) {
+                        batch_calls++;
+                        batched_frames += (unsigned) in.size();
+                        if (in.size() < 2 || in.size() > batch) abort();
+                        std::vector<std::shared_ptr<video_frame>> out;
+                        for (auto &f : in) {
+                                if (f->tile_count != 1) abort();
+                                out.push_back(one(dev, 0, std::move(f)));
+                        }
+                        return out;
+                };
         });
         std::vector<std::shared_ptr<video_frame>> got;
         std::thread consumer([&] {
@@ -59,6 +75,11 @@ int main(int argc, char **argv)
                 f->compress_start = 1000 + i;
                 if (i % 17 != 5) expected++;
                 sh.push(f);
+                if (batch > 1 && d.tile_count == 1 && i % 3 == 1 && i + 1 < frames && (i + 1) % 5 != 0) { // the same object again, as frame i + 1
+                        if (i % 17 != 5) expected++; // same payload (tag i): succeeds or fails like the first push
+                        i++;
+                        sh.push(f);
+                }
         }
         sh.push({});
         consumer.join();
@@ -69,19 +90,21 @@ int main(int argc, char **argv)
         for (auto &f : got) {
                 uint32_t tag;
                 memcpy(&tag, f->tiles[0].data, 4);
-                if (tag != f->seq) { fprintf(stderr, "payload %u under seq %u\n", tag, f->seq); rc = 1; }
+                if (tag != f->seq && !(batch > 1 && tag + 1 == f->seq)) { fprintf(stderr, "payload %u under seq %u\n", tag, f->seq); rc = 1; }
                 if (!first && f->seq <= last) { fprintf(stderr, "out of order: %u after %u\n", f->seq, last); rc = 1; }
-                if (f->seq % 17 == 5) { fprintf(stderr, "failed frame %u was delivered\n", f->seq); rc = 1; }
+                if (tag % 17 == 5) { fprintf(stderr, "failed frame %u was delivered\n", f->seq); rc = 1; }
                 if (f->tile_count != (f->seq % 5 == 0 ? 4u : 1u)) { fprintf(stderr, "tile count of %u\n", f->seq); rc = 1; }
                 for (unsigned t = 0; t < f->tile_count; t++) {
                         if ((unsigned char) f->tiles[t].data[4] != t) { fprintf(stderr, "tile order in %u\n", f->seq); rc = 1; }
                 }
-                if (f->compress_start != (time_ns_t) (1000 + f->seq)) { fprintf(stderr, "metadata of %u lost\n", f->seq); rc = 1; }
+                if (f->compress_start != (time_ns_t) (1000 + tag)) { fprintf(stderr, "metadata of %u lost\n", f->seq); rc = 1; }
                 if (f->compress_end <= f->compress_start) { fprintf(stderr, "compress_end of %u not set\n", f->seq); rc = 1; }
                 last = f->seq;
                 first = false;
         }
         if ((int) used.size() != workers && frames >= 50) { fprintf(stderr, "only %zu of %d workers used\n", used.size(), workers); rc = 1; }
-        printf("%s frames=%zu tile_encodes=%u workers_used=%zu\n", rc ? "FAIL" : "OK", got.size(), calls.load(), used.size());
+        if (batch > 1 && batch_calls == 0) { fprintf(stderr, "no batch ever formed\n"); rc = 1; }
+        printf("%s frames=%zu tile_encodes=%u workers_used=%zu batch_calls=%u batched_frames=%u\n", rc ? "FAIL" : "OK", got.size(), calls.load(), used.size(),
+               batch_calls.load(), batched_frames.load());
         return rc;
 }
