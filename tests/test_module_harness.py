@@ -754,3 +754,25 @@ def test_batched_workers_deliver_the_same_streams_in_order(tmp_path, po, cfg, co
     assert len(set(outs.values())) == 1, {k: len(v) for k, v in outs.items()}
     assert outs["one"].count(b"\xff\xd8\xff") >= n           # n JPEG streams one after the other
     assert _run([cfg + ":batch=17", codec, w, h, raw, tmp_path / "x", 1, "host", 1]).returncode == 2   # refused at init
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,codec", [("dxt:DXT5", "UYVY"), ("dxt:DXT1", "RGB"), ("dxt:DXT5", "YUYV"), ("dxt:DXT1_YUV", "v210")])
+def test_batched_dxt_workers_deliver_the_same_blocks_in_order(tmp_path, po, cfg, codec):
+    """`-c dxt:...:batch=<n>`: queued frames go through ONE ug_hip_dxt_encode_batch_ex launch (and the device-side conversions first, where
+    the input needs them); blocks and order equal the one-frame module's."""
+    w, h, n = 192, 64, 13
+    frames = [synth.s1_random(codec if codec != "YUYV" else "UYVY", w, h, salt=40 + f) for f in range(n)]
+    raw = tmp_path / "in.raw"
+    np.concatenate(frames).tofile(raw)
+    outs = {}
+    for tag, extra in (("one", ":batch=1:workers=1"), ("b4w1", ":batch=4:workers=1"), ("b16w2", ":batch=16")):
+        out = tmp_path / f"{tag}.bin"
+        r = _run([cfg + extra, codec, w, h, raw, out, 1, "host", n])
+        assert r.returncode == 0 and "seq=" + ",".join(str(i) for i in range(n)) + "," in r.stdout, r.stdout + r.stderr
+        outs[tag] = np.fromfile(out, np.uint8)
+    assert np.array_equal(outs["one"], outs["b4w1"]) and np.array_equal(outs["one"], outs["b16w2"])
+    per = outs["one"].size // n
+    if codec == "UYVY":
+        assert np.array_equal(outs["one"][:per], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frames[0], w, h))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""ug_hip_jpeg_encoder_encode (one frame per call) against ug_hip_jpeg_encoder_encode_batch (n frames per call), 3840x2160, device-resident
+input, per-frame time incl. the synchronisation each call ends with.  usage: python tools/bench_jpeg_batch.py [--sub 420] [--n 8]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from ultragrid_amd import lib as L, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sub", type=int, default=420)
+ap.add_argument("--n", type=int, default=8)
+ap.add_argument("--seconds", type=float, default=1.0)
+a = ap.parse_args()
+l = L.load()
+w, h = 3840, 2160
+base = torch.from_numpy(synth.s2_video("UYVY", w, h)).cuda()
+sets = 4
+src = torch.stack([torch.stack([torch.roll(base, 7680 * 37 * (f + a.n * s)) for f in range(a.n)]) for s in range(sets)])   # (sets, n, bytes): 4 x n distinct frames
+enc = C.c_void_p()
+assert l.ug_hip_jpeg_encoder_create_sub(w, h, 75, 4, a.sub, C.byref(enc)) == 0
+cap = l.ug_hip_jpeg_encoder_max_size(enc)
+stride = (min(cap, w * h * 3 + 4096) + 15) // 16 * 16
+out = torch.empty((a.n, stride), dtype=torch.uint8, device="cuda")
+lens = (C.c_size_t * a.n)()
+st = torch.cuda.current_stream().cuda_stream
+one = C.c_size_t(0)
+
+
+def single():
+    k = single.k = getattr(single, "k", 0) + 1
+    for f in range(a.n):
+        assert l.ug_hip_jpeg_encoder_encode(enc, L.PF_UYVY, src[k % sets, f].data_ptr(), 0, out[f].data_ptr(), stride, C.byref(one), st) == 0
+
+
+def batch():
+    k = batch.k = getattr(batch, "k", 0) + 1
+    assert l.ug_hip_jpeg_encoder_encode_batch(enc, L.PF_UYVY, a.n, src[k % sets].data_ptr(), 0, src.shape[2], out.data_ptr(), stride, stride, lens, st) == 0, L.last_error()
+
+
+for name, fn in (("one frame per call", single), (f"{a.n} frames per call", batch), ("one frame per call", single), (f"{a.n} frames per call", batch)):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < a.seconds:
+        fn()
+        n += 1
+    dt = time.perf_counter() - t0
+    print(f"jpeg encode 4K 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")

@@ -84,12 +84,15 @@ struct state_video_compress_dxt_mi355x {
         void             *dev_pre = nullptr;        ///< swizzle result (only if pre_in != NONE)
         void             *dev_out = nullptr;        ///< DXT blocks
         size_t            in_len = 0, out_len = 0;
+        // the same buffers once per frame of a batch (batch=<n>): allocated on first use, 16 slices
+        void             *b_in = nullptr, *b_pre = nullptr, *b_out = nullptr;
+        size_t            b_in_stride = 0, b_pre_stride = 0, b_out_stride = 0;
         video_frame_pool  pool{0, hip_pinned_allocator()};
 };
 
 void cleanup(state_video_compress_dxt_mi355x *s)
 {
-        for (void **p : { &s->dev_in, &s->dev_pre, &s->dev_out }) {
+        for (void **p : { &s->dev_in, &s->dev_pre, &s->dev_out, &s->b_in, &s->b_pre, &s->b_out }) {
                 if (*p) {
                         ug_hip_free(*p);
                         *p = nullptr;
@@ -100,7 +103,8 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:ties=even|away]\n"
+               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:ties=even|away]\n"
+               "\t\tbatch - frames a busy worker may queue and encode in one launch (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
                "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n"
                "\t\tties - what GLSL leaves to the implementation in the reference's encoder shaders: even (default) = round() ties to\n"
@@ -267,6 +271,63 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
         return out;
 }
 
+/// `frames` queued frames of one geometry: uploads (and device-side conversions) into the slices of the batch buffers, ONE encoder
+/// launch over all of them (ug_hip_dxt_encode_batch_ex, grid.z = frame), the downloads, one synchronisation.  Same bytes as one by one.
+std::vector<std::shared_ptr<video_frame>> dxt_mi355x_compress_batch(void *state, std::vector<std::shared_ptr<video_frame>> in)
+{
+        auto *s = static_cast<state_video_compress_dxt_mi355x *>(state);
+        const int n = (int) in.size();
+        std::vector<std::shared_ptr<video_frame>> out(in.size());
+        auto one_by_one = [&] {
+                for (size_t i = 0; i < in.size(); i++) out[i] = dxt_mi355x_compress_tile(state, std::move(in[i]));
+                return out;
+        };
+        if (n < 2 || n > 16 || ug_hip_set_device(s->device) != UG_HIP_SUCCESS ||
+            !video_desc_eq_excl_param(video_desc_from_frame(in[0].get()), s->saved_desc, PARAM_TILE_COUNT)) {
+                return one_by_one(); // (the first frame of a new geometry configures the state on the way)
+        }
+        const int w = (int) in[0]->tiles[0].width, h = (int) in[0]->tiles[0].height;
+        if (s->b_in == nullptr) {
+                auto round16 = [](size_t v) { return (v + 15) / 16 * 16; };
+                s->b_in_stride = round16(s->in_len + MAX_PADDING);
+                s->b_out_stride = round16(s->out_len);
+                bool ok = ug_hip_malloc(&s->b_in, s->b_in_stride * 16) == UG_HIP_SUCCESS && ug_hip_malloc(&s->b_out, s->b_out_stride * 16) == UG_HIP_SUCCESS;
+                if (ok && s->pre_in != UG_PF_NONE) {
+                        s->b_pre_stride = round16((size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->pre_out)) * h + MAX_PADDING);
+                        ok = ug_hip_malloc(&s->b_pre, s->b_pre_stride * 16) == UG_HIP_SUCCESS;
+                }
+                if (!ok) {
+                        MSG(WARNING, "no device memory for the batch buffers (%s): frames are encoded one by one\n", ug_hip_last_error_string());
+                        for (void **p : { &s->b_in, &s->b_pre, &s->b_out }) {
+                                if (*p) { ug_hip_free(*p); *p = nullptr; }
+                        }
+                        return one_by_one();
+                }
+        }
+        for (int f = 0; f < n; f++) {
+                const bool dev = in[f]->mem_location == CUDA_MEM || ug_hip_pointer_is_device(in[f]->tiles[0].data);
+                char *slice = (char *) s->b_in + f * s->b_in_stride;
+                CHECK_HIP(ug_hip_upload_ordered(s->device, slice, in[f]->tiles[0].data, s->in_len, dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
+                          "upload failed", return out);
+                if (s->pre_in != UG_PF_NONE) {
+                        CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, slice, (char *) s->b_pre + f * s->b_pre_stride, w, h, 0, 0, 0, 8, 16, s->stream),
+                                  "device swizzle failed", return out);
+                }
+        }
+        const bool pre = s->pre_in != UG_PF_NONE;
+        CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, pre ? s->b_pre : s->b_in, s->b_out, w, h, 0, n, pre ? s->b_pre_stride : s->b_in_stride, s->b_out_stride,
+                                             s->ties, s->stream),
+                  "Encoding failed", return out);
+        for (int f = 0; f < n; f++) {
+                out[f] = s->pool.get_frame();
+                CHECK_HIP(ug_hip_download_ordered(s->device, out[f]->tiles[0].data, (char *) s->b_out + f * s->b_out_stride, s->out_len, s->stream), "D2H copy failed",
+                          { for (auto &o : out) o.reset(); return out; });
+                out[f]->tiles[0].data_len = (unsigned int) s->out_len;
+        }
+        CHECK_HIP(ug_hip_stream_sync(s->stream), "stream sync failed", { for (auto &o : out) o.reset(); return out; });
+        return out;
+}
+
 void dxt_mi355x_compress_done(void *state)
 {
         auto *s = static_cast<state_video_compress_dxt_mi355x *>(state);
@@ -295,7 +356,8 @@ compress_module_info get_dxt_mi355x_module_info()
 /// module-level init: consumes dev=<list>, creates one worker (thread + per-tile encoder states) per listed device
 void *dxt_mi355x_module_init(struct module *parent, const char *cfg)
 {
-        return mi355x::sharded_init(parent, cfg, dxt_mi355x_compress_init, dxt_mi355x_compress_tile, dxt_mi355x_compress_done, ug_hip_set_device);
+        return mi355x::sharded_init(parent, cfg, dxt_mi355x_compress_init, dxt_mi355x_compress_tile, dxt_mi355x_compress_done, ug_hip_set_device,
+                                    dxt_mi355x_compress_batch);
 }
 
 const struct video_compress_info dxt_mi355x_info = {
