@@ -99,6 +99,11 @@ __device__ __forceinline__ void st_stream(uint16_t *p, uint16_t v) { *p = v; }
 __device__ __forceinline__ void st_stream(uint8_t *p, uint8_t v) { *p = v; }
 #endif
 
+// Streaming loads were A/B-measured too (profiles/r03_nt_loads_ab.txt): a loss for the one-word-per-lane kernels (UYVY->RGB 9.5 -> 10.6 us,
+// DXT5->RGBA 8.7 -> 10.0 us per 4K frame) and a gain of 4-5 % where a wave fetches its 64 multi-word units as one contiguous region
+// through LDS (RG48->RGB 19.2 -> 18.4 us, Y416->UYVY 14.7 -> 13.9): used there only.
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p) { const u32x4_t v = __builtin_nontemporal_load((const u32x4_t *) p); return make_uint4(v.x, v.y, v.z, v.w); }
+
 // 128-bit unit I/O of the "K iterations per lane" converter kernels (pixfmt.hip, pixfmt_ext.hip).  A lane's unit is BYTES contiguous
 // bytes.  When that is one 16-byte word the lanes of a wave access consecutive words and nothing else is needed.  When it is
 // several, per-lane accesses would be strided (every load instruction touching 64 different cache lines and using 16 bytes of each --
@@ -120,7 +125,7 @@ struct UnitIO {
 #pragma unroll
                 for (int i = 0; i < V; i++) {
                         const int c = i * 64 + lane;
-                        if (c < units * V) lds[(c / V) * ROW + c % V] = region[c];
+                        if (c < units * V) lds[(c / V) * ROW + c % V] = ld_stream(region + c);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
