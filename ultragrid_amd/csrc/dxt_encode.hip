@@ -98,6 +98,46 @@ __device__ __forceinline__ uint32_t shift_in(uint32_t acc, lanemask_t mask)
         return r;
 }
 
+// acc + carry (v_addc with a zero addend): adds the boolean of a lane mask to a count
+__device__ __forceinline__ uint32_t add_mask(uint32_t acc, lanemask_t mask)
+{
+        lanemask_t carry_out;
+        uint32_t r;
+        asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(acc), "s"(mask));
+        return r;
+}
+// v_cvt_u32_f32 as the hardware defines it (truncation, negative -> 0, no poison for out-of-range input as with a C cast)
+__device__ __forceinline__ uint32_t cvt_u32_sat(float x)
+{
+        uint32_t r;
+        asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+        return r;
+}
+// bit i of x -> bit 2i (x < 2^16)
+__device__ __forceinline__ uint32_t spread16(uint32_t x)
+{
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+}
+
+// Per-wave LDS tables of the fast index stages (UG_DXT_FAST_INDEX): every lane owns one column, nothing is shared
+// between lanes, so no barrier is involved.  Row-major by entry: a wave's access to one row is 64 consecutive words / 16-byte units.
+#ifndef UG_DXT_NO_FAST_INDEX
+#define UG_DXT_FAST_INDEX 1
+#else
+#define UG_DXT_FAST_INDEX 0
+#endif
+#ifndef UG_DXT1_FAST_GROUP
+#define UG_DXT1_FAST_GROUP 2
+#endif
+struct IndexTables {
+        float *alpha;     // [8][64] floats: thresholds in DESCENDING order, row 7 = -inf
+        float4 *colour;   // DXT5-YCoCg: [3][64] (A.x, A.y, B.x, B.y) of the palette pair whose bisector crosses zone k; DXT1: [6][64], rows 2k / 2k + 1 = A / B (xyz)
+};
+
 // ---------------------------------------------------------------------------------------
 // colour front ends: bytes -> normalised (c0,c1,c2) per pixel
 // ---------------------------------------------------------------------------------------
@@ -325,7 +365,7 @@ struct Loader<UG_PF_V210> {
 // DXT5-YCoCg block encode (compress_dxt5ycocg_fp.glsl:326-377 / cuda_dxt.cu:471-509)
 // ---------------------------------------------------------------------------------------
 template <bool AWAY>
-__device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
+__device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p, const IndexTables &tab)
 {
         // ConvertRGBToYCoCg (glsl:27-34).  2.0*x and *0.25 are exact (powers of two), so
         //   (r + 2g + b)*0.25      : fma(g,2,r) == r + 2g bit-for-bit (2g exact)
@@ -448,15 +488,52 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 // cannot be overturned.  After the inset the range is >= 16/255/16 unless both ends clamp to the same bound,
                 // so one compare decides for practically every block; only a wave that sees a narrower range evaluates the six
                 // explicit comparisons.
-                bool all_mono;
+                bool all_mono, all_wide = false; // both wave-uniform
                 if (__builtin_expect(__all(range > 0.0009765625f), 1)) {
                         all_mono = true;
+                        all_wide = true;
                 } else {
                         asm volatile("; explicit monotonicity check" ::: "memory");
                         all_mono = __all((T1 <= T2) & (T2 <= T3) & (T3 <= T4) & (T4 <= T5) & (T5 <= T6) & (T6 <= T7));
                 }
                 // raw counts, 3 bits per pixel: lo = px 0..9 (30 bits), hi = px 10..15 (18 bits)
                 uint32_t lo = 0, hi = 0;
+#if UG_DXT_FAST_INDEX && !defined(UG_FORCE_ALPHA_LINEAR)
+                // Fast form of the same count, valid under the wave-uniform range > 2^-10 test above.  The thresholds sit range/7
+                // apart (+- 2^-21), so the position of a among them is known from ONE multiply-add up to the nearest threshold:
+                //   t = 7 - (a - mnY) * 7/range (clamped to [0, 8)) puts threshold T(8-m) at t = m - 1/2  (m = 1..7, descending thresholds D_m = T(8-m));
+                //   g = trunc(t) (saturating at 0): every D_m with m <= g lies >= 0.49 steps above a, every D_m with m >= g + 2 lies
+                //   >= 0.49 steps below it (error of t < 6e-4 steps: rcp 1 ulp, mnY*inv rounded at magnitude <= 7168, fma rounding), so
+                //   c = #{m : a <= D_m} = g + (a <= D_(g+1)) -- and THAT comparison is the reference's own, on the reference's own
+                //   fp32 threshold (read back from the per-lane LDS column).  Row 7 = -inf serves g = 7 (a below every threshold).
+                // 1 fma + cvt + address + compare + 2 integer ops per pixel instead of 3 compares + 4 selects + 3 carries.
+                if (__builtin_expect(all_wide, 1)) {
+                        float *const ta = tab.alpha;
+                        ta[0 * 64] = T7; ta[1 * 64] = T6; ta[2 * 64] = T5; ta[3 * 64] = T4;
+                        ta[4 * 64] = T3; ta[5 * 64] = T2; ta[6 * 64] = T1; ta[7 * 64] = -__builtin_inff();
+                        // t / 8 with the clamp modifier (luma of YUV sources can lie far outside [mnY, mxY]: g must stay in 0..7), then * (8 - ulp)
+                        const float inv = 0.875f * __builtin_amdgcn_rcpf(range);
+                        const float t0 = __builtin_fmaf(mnY, inv, 0.875f), ninv = -inv;
+#pragma unroll
+                        for (int h = 1; h >= 0; h--) { // two groups of eight: eight table reads in flight, bounded register use
+                                float D[8];
+                                uint32_t g[8];
+#pragma unroll
+                                for (int j = 7; j >= 0; j--) {
+                                        g[j] = cvt_u32_sat(clamp01(__builtin_fmaf(Y[8 * h + j], ninv, t0)) * 7.9999995f);
+                                        D[j] = ta[g[j] * 64];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 7; j >= 0; j--) {
+                                        const int i = 8 * h + j;
+                                        uint32_t &acc = i >= 10 ? hi : lo;
+                                        acc = add_mask((acc << 3) + g[j], LANEMASK(Y[i] <= D[j]));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                        }
+                } else
+#endif
 #ifdef UG_FORCE_ALPHA_LINEAR // test build: always take the reference-form path (tests/test_gpu_dxt.py)
                 if (all_mono && lo == 0xffffffffu) {
 #else
@@ -520,6 +597,74 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                 cx[1] = cmn[0]; cy[1] = cmn[1];
                 cx[2] = lerp_w(cx[0], cx[1], w1, q1); cy[2] = lerp_w(cy[0], cy[1], w1, q1);
                 cx[3] = lerp_w(cx[0], cx[1], w2, q2); cy[3] = lerp_w(cy[0], cy[1], w2, q2);
+#if UG_DXT_FAST_INDEX
+                // Fast form (wave-uniform choice).  The palette lies on the segment c0 -> c1 in the order c0, c2, c3, c1 (s = 0, 1/3, 2/3, 1)
+                // and the index formula of glsl:237-244 is "nearest of the four": with s = the pixel's projection on the segment,
+                //   b2 = [d0 > d2] flips at s = 1/6, b0 = [d0 > d3] at 1/3, b4 = [d2 > d3] at 1/2, b1 = [d1 > d2] at 2/3, b3 = [d1 > d3] at 5/6,
+                //   bit0 = b0 & b4,  bit1 = (b1 & b2) | (b0 & b3).
+                // In the third of the segment that holds the pixel (zone k = trunc(3 s), s clamped to [0, 1)) exactly ONE of the three
+                // decisive comparisons (b2 | b4 | b3) is open; for the other bits either the pixel is >= 1/12 of the segment away
+                // from the comparison's bisector, or the bit cannot change the result (b0 near 1/3 and b1 near 2/3 are masked by
+                // their partners):   k = 0: index = 2 b2;   k = 1: index = 2 + b4;   k = 2: index = 1 + 2 b3.
+                // The open comparison is evaluated exactly as the reference does (both squared distances in the reference's
+                // operation order, strict >), so the result is the reference's whenever the "certain" bits are certain in fp32:
+                //   a computed distance is off by < 2^-22 |p - c|^2 <= 2^-22 dmax (dmax = squared diagonal of the box around pixels and
+                //   end points); two distances whose bisector is m segment-lengths away differ by >= (2/3) m vv (vv = |c1 - c0|^2).
+                //   With vv * 256 > dmax and m >= 1/12 - 4e-4 that is > 200 x the rounding error; c2 / c3 are off their ideal
+                //   places by < 2e-7 absolute = < 6e-5 of a segment with vv >= 1e-5 (a non-zero segment of 8-bit-expanded end points
+                //   has vv >= 1.5e-5), and s itself is estimated to < 3e-4 (reciprocal + 5 roundings at magnitudes <= 650).
+                // A wave that holds a block outside that precondition (coincident end points) runs the full form below for all lanes.
+                const float vx = cx[1] - cx[0], vy = cy[1] - cy[0];
+                const float vv = vx * vx + vy * vy;
+                const float e0 = fmaxf(fmaxf(mxCo, cx[0]), cx[1]) - fminf(fminf(mnCo, cx[0]), cx[1]);
+                const float e1 = fmaxf(fmaxf(fmaxf(mxCg, mnCg), cy[0]), cy[1]) - fminf(fminf(fminf(mxCg, mnCg), cy[0]), cy[1]);
+                const float dmax = e0 * e0 + e1 * e1;
+                if (__builtin_expect(__all((vv >= 1e-5f) & (vv * 256.0f > dmax)), 1)) {
+                        float4 *const tc = tab.colour;
+                        tc[0 * 64] = make_float4(cx[0], cy[0], cx[2], cy[2]); // zone 0: d0 > d2
+                        tc[1 * 64] = make_float4(cx[2], cy[2], cx[3], cy[3]); // zone 1: d2 > d3
+                        tc[2 * 64] = make_float4(cx[1], cy[1], cx[3], cy[3]); // zone 2: d1 > d3
+                        const float inv = __builtin_amdgcn_rcpf(vv);
+                        const float ka = vx * inv, kb = vy * inv;
+                        const float kc = -(cx[0] * ka + cy[0] * kb);
+                        uint32_t zones = 0, open = 0; // 2-bit zone per pixel; the open comparison's result, one bit per pixel
+                        // groups of four pixels, the table reads of the next group issued before the distances of this one
+                        float4 e[2][4];
+                        uint32_t kk[2][4];
+                        auto fetch = [&](int grp, int slot) {
+#pragma unroll
+                                for (int j = 3; j >= 0; j--) {
+                                        const int i = 4 * grp + j;
+                                        const float s = clamp01(__builtin_fmaf(Co[i], ka, __builtin_fmaf(Cg[i], kb, kc)));
+                                        kk[slot][j] = cvt_u32_sat(s * 2.9999998f); // 0, 1, 2
+                                        e[slot][j] = tc[kk[slot][j] * 64];
+                                }
+                        };
+                        fetch(3, 1);
+#pragma unroll
+                        for (int grp = 3; grp >= 0; grp--) {
+                                const int slot = grp & 1;
+                                if (grp > 0) {
+                                        fetch(grp - 1, slot ^ 1);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 3; j >= 0; j--) {
+                                        const int i = 4 * grp + j;
+                                        const float4 q = e[slot][j];
+                                        const float ax = Co[i] - q.x, ay = Cg[i] - q.y, bx = Co[i] - q.z, by = Cg[i] - q.w;
+                                        const float da = ax * ax + ay * ay, db = bx * bx + by * by; // glsl:231-235, same operation order
+                                        zones = (zones << 2) + kk[slot][j];
+                                        open = shift_in(open, LANEMASK(da > db));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const uint32_t c = spread16(open), k0 = zones & 0x55555555u, k1 = (zones >> 1) & 0x55555555u;
+                        w_cidx = ((k0 & c) | k1) | ((k0 | c) << 1);
+                } else
+#endif
+                {
+                asm volatile("; colour index full form" ::: "memory");
                 f32x2 cx2[4], cy2[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -545,6 +690,7 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
                                 w_cidx = shift_in(w_cidx, b0 & b4);               // bit 2i
                         }
                 }
+                }
         }
 
         return make_uint4(w0, w1, w_end, w_cidx);
@@ -554,7 +700,7 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p)
 // DXT1 block encode, normative = GLSL (compress_dxt1_fp.glsl:177-229)
 // ---------------------------------------------------------------------------------------
 template <bool AWAY>
-__device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
+__device__ __forceinline__ uint2 encode_dxt1(const Px16 &p, const IndexTables &tab)
 {
         const float *R = p.a, *G = p.b, *B = p.c;
         float mn[3] = { R[0], G[0], B[0] }, mx[3] = { R[0], G[0], B[0] };
@@ -615,6 +761,72 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
                         c2[k] = lerp_w(c0[k], c1[k], w1, q1);
                         c3[k] = lerp_w(c0[k], c1[k], w2, q2);
                 }
+#if UG_DXT_FAST_INDEX
+                // Fast form, as in encode_dxt5ycocg (the argument does not depend on the number of components): zone of the pixel's
+                // projection on c0 -> c1, the one open comparison evaluated exactly as the reference does.  A distance of three squares
+                // is off by < 2^-21 dmax, still > 100 x below the smallest certain difference under the same precondition; a non-zero
+                // segment of 8-bit-expanded end points has vv >= 2.4e-4.  Coincident end points (flat blocks): full form for the wave.
+                const float vx = c1[0] - c0[0], vy = c1[1] - c0[1], vz = c1[2] - c0[2];
+                const float vv = vx * vx + vy * vy + vz * vz;
+                float dmax = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { // mn / mx may be swapped by SelectDiagonal
+                        const float e = fmaxf(fmaxf(fmaxf(mx[k], mn[k]), c0[k]), c1[k]) - fminf(fminf(fminf(mx[k], mn[k]), c0[k]), c1[k]);
+                        dmax = dmax + e * e;
+                }
+                if (__builtin_expect(__all((vv >= 1e-5f) & (vv * 256.0f > dmax)), 1)) {
+                        float4 *const tc = tab.colour;
+                        tc[0 * 64] = make_float4(c0[0], c0[1], c0[2], 0.0f); tc[1 * 64] = make_float4(c2[0], c2[1], c2[2], 0.0f); // zone 0: d0 > d2
+                        tc[2 * 64] = make_float4(c2[0], c2[1], c2[2], 0.0f); tc[3 * 64] = make_float4(c3[0], c3[1], c3[2], 0.0f); // zone 1: d2 > d3
+                        tc[4 * 64] = make_float4(c1[0], c1[1], c1[2], 0.0f); tc[5 * 64] = make_float4(c3[0], c3[1], c3[2], 0.0f); // zone 2: d1 > d3
+                        const float inv = __builtin_amdgcn_rcpf(vv);
+                        const float ka = vx * inv, kb = vy * inv, kc = vz * inv;
+                        const float kd = -((c0[0] * ka + c0[1] * kb) + c0[2] * kc);
+                        uint32_t zones = 0, open = 0;
+                        // groups of kG pixels; the table reads (2 x 12 bytes per pixel) of the next group are issued before the distances of this one
+                        constexpr int kG = UG_DXT1_FAST_GROUP;
+                        struct alignas(16) F3 { float x, y, z; };
+                        F3 ea[2][kG], eb[2][kG];
+                        uint32_t kk[2][kG];
+                        auto fetch = [&](int grp, int slot) {
+#pragma unroll
+                                for (int j = kG - 1; j >= 0; j--) {
+                                        const int i = kG * grp + j;
+                                        const float t = clamp01(__builtin_fmaf(R[i], ka, __builtin_fmaf(G[i], kb, __builtin_fmaf(B[i], kc, kd))));
+                                        kk[slot][j] = cvt_u32_sat(t * 2.9999998f); // 0, 1, 2
+                                        const F3 *const q = (const F3 *) (tc + kk[slot][j] * 128);
+                                        ea[slot][j] = q[0];
+                                        eb[slot][j] = q[64];
+                                }
+                        };
+                        constexpr int kGroups = 16 / kG;
+                        fetch(kGroups - 1, (kGroups - 1) & 1);
+#pragma unroll
+                        for (int grp = kGroups - 1; grp >= 0; grp--) {
+                                const int slot = grp & 1;
+                                if (grp > 0) {
+                                        fetch(grp - 1, slot ^ 1);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = kG - 1; j >= 0; j--) {
+                                        const int i = kG * grp + j;
+                                        const F3 qa = ea[slot][j], qb = eb[slot][j];
+                                        const float ax = R[i] - qa.x, ay = G[i] - qa.y, az = B[i] - qa.z;
+                                        const float bx = R[i] - qb.x, by = G[i] - qb.y, bz = B[i] - qb.z;
+                                        const float da = AWAY ? (ax * ax + ay * ay) + az * az : (az * az + ay * ay) + ax * ax; // as d[k] below
+                                        const float db = AWAY ? (bx * bx + by * by) + bz * bz : (bz * bz + by * by) + bx * bx;
+                                        zones = (zones << 2) + kk[slot][j];
+                                        open = shift_in(open, LANEMASK(da > db));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const uint32_t c = spread16(open), k0 = zones & 0x55555555u, k1 = (zones >> 1) & 0x55555555u;
+                        w_idx = ((k0 & c) | k1) | ((k0 | c) << 1);
+                } else
+#endif
+                {
+                asm volatile("; colour index full form" ::: "memory");
                 const float *c[4] = { c0, c1, c2, c3 };
                 f32x2 cc[4][3];
 #pragma unroll
@@ -643,6 +855,7 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
                                 w_idx = shift_in(w_idx, b0 & b4);
                         }
                 }
+                }
         }
         return make_uint2(w_end, w_idx);
 }
@@ -652,8 +865,11 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 // blockIdx.y*4 + w (unit = Loader::kBlocks consecutive blocks), blockIdx.z = image of the batch.
 // No integer division anywhere; lanes idle only at the right/bottom edge of the block grid.
 // ---------------------------------------------------------------------------------------
+// Occupancy target of the register allocator.  With the fast index stages the DXT5-YCoCg kernels need 100 VGPRs at 4 waves per SIMD
+// or 96 at 5 (the five dwords that do not fit are spilled in the rarely taken full-form colour stage only): 5 measures 2.4 % faster
+// (profiles/r03_fast_index_ab.txt).  The v210 kernels (three blocks per lane) keep the allocator's own choice.
 #ifndef UG_DXT_MIN_WAVES
-#define UG_DXT_MIN_WAVES 1
+#define UG_DXT_MIN_WAVES (UG_DXT_FAST_INDEX ? 5 : 1)
 #endif
 #ifndef UG_DXT_ROWS_PER_WAVE
 #define UG_DXT_ROWS_PER_WAVE 1
@@ -665,11 +881,21 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p)
 constexpr int kRowsPerWave = UG_DXT_ROWS_PER_WAVE;
 
 template <int IN, int OUT, bool MIRROR, bool AWAY>
-__global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+__global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVES)) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                          int units_per_row, int blocks_per_row, int block_rows, int height, uint32_t pitch,
                                                          size_t src_frame_stride, size_t dst_frame_stride)
 {
         using L = Loader<IN>;
+        constexpr bool kTables = UG_DXT_FAST_INDEX, kAlpha = kTables && OUT == UG_DXT5_YCOCG;
+        constexpr int kColourRows = OUT == UG_DXT5_YCOCG ? 3 : 6;
+        __shared__ float lds_alpha[kAlpha ? 4 * 8 * 64 : 1];
+        __shared__ float4 lds_colour[kTables ? 4 * kColourRows * 64 : 1];
+        IndexTables tab;
+        {
+                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+                tab.alpha = lds_alpha + (kAlpha ? wave * (8 * 64) + (int) threadIdx.x : 0);
+                tab.colour = lds_colour + (kTables ? wave * (kColourRows * 64) + (int) threadIdx.x : 0);
+        }
         // threadIdx.y is wave-uniform (a wave is one 64-lane row of the group): keep the block row, the row base
         // pointers and the bounds test on the scalar unit -- no per-lane 64-bit multiplies in the prologue.
         const int ux = blockIdx.x * 64 + threadIdx.x;
@@ -722,9 +948,9 @@ __global__ __launch_bounds__(256, UG_DXT_MIN_WAVES) void dxt_encode_kernel(const
                         Px16 p;
                         cur.block(k, p);
                         if (OUT == UG_DXT5_YCOCG) {
-                                res[k] = encode_dxt5ycocg<AWAY>(p);
+                                res[k] = encode_dxt5ycocg<AWAY>(p, tab);
                         } else {
-                                const uint2 e = encode_dxt1<AWAY>(p);
+                                const uint2 e = encode_dxt1<AWAY>(p, tab);
                                 res[k] = make_uint4(e.x, e.y, 0, 0);
                         }
                         n_res = k + 1;
