@@ -185,6 +185,12 @@ int ug_hip_dxt_decode_debug(int mode, unsigned *flagged_blocks_dev);
 /* Same for the encoder: x / 14.0f as multiply + two fma, compared with the IEEE division for x = 0 and every fp32 x in [2^-100, 1] (smaller
  * values take the division itself). */
 int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream);
+/* Diagnostics (tests, profiling).  The encoders choose each pixel's ONE decisive comparison of compress_dxt5ycocg_fp.glsl:237-244 /
+ * :262-312 from the pixel's position on the palette segment / among the alpha thresholds and evaluate that comparison exactly as the
+ * reference does; a wave that holds a block outside the precondition (coincident colour end points over non-flat chroma; luma range < 2^-10) evaluates the
+ * reference's full form for all of its blocks.  Returns the number of such waves since the last reset on the current device:
+ * [0] colour stage, [1] alpha stage.  Synchronises the device. */
+int ug_hip_dxt_encode_stats(unsigned long long full_form_waves[2], int reset);
 
 /* ------------------------------------------------------------------------------------
  * Pixel-format conversion, whole frame on the device (replaces the decoder_t line loop,

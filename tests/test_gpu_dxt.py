@@ -235,6 +235,88 @@ def test_extreme_and_degenerate_content(hip, po):
             assert np.array_equal(got, po.dxt_encode(po.IN_RGB, out_p, rgb, w, h)), name
 
 
+def test_fast_index_stages_on_their_boundaries(hip, po):
+    """The encoders pick ONE exact comparison per pixel from the pixel's position on the palette segment / among the alpha thresholds
+    (dxt_encode.hip, UG_DXT_FAST_INDEX) and run the reference's full form for a whole wave that holds a block outside the
+    precondition.  Content built for the seams: waves that mix flat blocks (coincident end points -> full form) with busy ones,
+    two-colour blocks whose end points are one quantisation step apart (shortest non-zero segment), pixels ON the segment at
+    multiples of 1/6 of it (every zone border and every bisector), luma ramps that put alpha values on the thresholds, and
+    YUV-derived values outside [0, 1]."""
+    import torch
+    from ultragrid_amd import lib as L
+    rng = np.random.default_rng(77)
+    w, h = 512, 32  # 128 blocks per block row = two full waves per row
+    bw, bh = w // 4, h // 4
+
+    def blocks_to_rgb(bl):  # bl: (bh, bw, 4, 4, 3) uint8
+        return np.ascontiguousarray(bl.transpose(0, 2, 1, 3, 4).reshape(h, w, 3)).ravel()
+
+    frames = {}
+    # 1. every 7th block flat, the rest noise
+    bl = rng.integers(0, 256, (bh, bw, 4, 4, 3), dtype=np.uint8)
+    flat = (np.arange(bh * bw).reshape(bh, bw) % 7) == 3
+    bl[flat] = rng.integers(0, 256, (int(flat.sum()), 1, 1, 3), dtype=np.uint8)
+    frames["flat_among_noise"] = bl
+    # 2. two colours per block, 1..3 LSB apart in one or more channels
+    base = rng.integers(8, 247, (bh, bw, 1, 1, 3), dtype=np.int32)
+    delta = rng.integers(0, 4, (bh, bw, 1, 1, 3), dtype=np.int32)
+    pick = rng.integers(0, 2, (bh, bw, 4, 4, 1), dtype=np.int32)
+    frames["two_colours_close"] = (base + delta * pick).astype(np.uint8)
+    # 3. pixels on the segment between two random colours at k/6 (+- 1 LSB of rounding)
+    a = rng.integers(0, 256, (bh, bw, 1, 1, 3)).astype(np.float64)
+    b = rng.integers(0, 256, (bh, bw, 1, 1, 3)).astype(np.float64)
+    t = rng.integers(0, 7, (bh, bw, 4, 4, 1)).astype(np.float64) / 6.0
+    frames["on_the_segment"] = np.clip(np.rint(a + (b - a) * t) + rng.integers(-1, 2, (bh, bw, 4, 4, 3)), 0, 255).astype(np.uint8)
+    # 4. grey ramps of every slope: alpha (luma) values on and around the thresholds, chroma flat
+    lo = rng.integers(0, 200, (bh, bw, 1, 1, 1)); step = rng.integers(0, 4, (bh, bw, 1, 1, 1))
+    ramp = lo + step * np.arange(16).reshape(1, 1, 4, 4, 1)
+    frames["grey_ramps"] = np.broadcast_to(np.clip(ramp, 0, 255), (bh, bw, 4, 4, 3)).astype(np.uint8)
+    for name, bl in frames.items():
+        rgb = blocks_to_rgb(bl)
+        for out_l, out_p in ((L.DXT5_YCOCG, po.OUT_DXT5YCOCG), (L.DXT1, po.OUT_DXT1)):
+            for ties in ("even", "away"):
+                got = hip.dxt_encode(L.PF_RGB, out_l, torch.from_numpy(rgb).cuda(), w, h, ties=None if ties == "even" else L.TIES_AWAY).cpu().numpy()
+                want = po.dxt_encode(po.IN_RGB, out_p, rgb, w, h, ties=ties)
+                assert np.array_equal(got, want), (name, out_p, ties, int(np.count_nonzero(got != want)))
+        # the same bytes read as UYVY (2 B / px: the first two thirds of the buffer): unclamped YUV -> RGB, luma below 0 and above 1
+        uy = np.ascontiguousarray(rgb[: 2 * w * h])
+        for out_l, out_p in ((L.DXT5_YCOCG, po.OUT_DXT5YCOCG), (L.DXT1, po.OUT_DXT1)):
+            got = hip.dxt_encode(L.PF_UYVY, out_l, torch.from_numpy(uy).cuda(), w, h).cpu().numpy()
+            assert np.array_equal(got, po.dxt_encode(po.IN_UYVY, out_p, uy, w, h)), (name, "UYVY", out_p)
+
+
+def test_fast_index_stage_coverage_by_content(hip, po):
+    """Which form runs is a property of the content (ug_hip_dxt_encode_stats): video-like frames (S2) stay in the fast stages for all but
+    a few per cent of the waves (S2's saturated chroma drives the unclamped RGB, and with it the luma range of some blocks, out of
+    [0, 1]: end points clamp together) and flat frames for every wave (a one-colour block gets the full form for its one value inside the fast stage); a frame whose blocks hold
+    two chroma values one LSB apart (end points quantise to the same value over non-flat chroma) sends every wave through the
+    reference's full colour form.  The alpha stage never leaves the fast form on byte content.  All three are bit-equal to the oracle."""
+    import ctypes as C
+    import torch
+    from ultragrid_amd import lib as L
+    l = L.load()
+    w, h = 1920, 1080
+    waves = (h // 4) * ((w // 4 + 63) // 64)
+    st = (C.c_ulonglong * 2)()
+    almost = np.tile(np.array([200, 90, 60, 90, 201, 90, 60, 90], np.uint8), w * h // 4)
+    frames = {"S2": (synth.s2_video("UYVY", w, h), None), "flat": (np.full(2 * w * h, 90, np.uint8), 0), "almost_flat": (almost, waves)}
+    seen = []
+    for out, pout in ((L.DXT5_YCOCG, po.OUT_DXT5YCOCG), (L.DXT1, po.OUT_DXT1)):
+        for name, (src, want_full) in frames.items():
+            assert l.ug_hip_dxt_encode_stats(None, 1) == 0
+            got = hip.dxt_encode(L.PF_UYVY, out, torch.from_numpy(src).cuda(), w, h).cpu().numpy()
+            assert l.ug_hip_dxt_encode_stats(st, 1) == 0
+            seen.append(f"{name} -> {'DXT5-YCoCg' if out == L.DXT5_YCOCG else 'DXT1'}: colour full form {st[0]} / alpha full form {st[1]} of {waves} waves")
+            if want_full is None:
+                assert st[0] < 0.02 * waves and st[1] < 0.05 * waves, seen[-1]
+            else:
+                assert (st[0], st[1]) == (want_full, 0), seen[-1]
+            assert np.array_equal(got, po.dxt_encode(po.IN_UYVY, pout, src, w, h, threads=8)), (name, out)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/dxt_fast_index_coverage.txt", "w") as f:
+        f.write("\n".join(seen) + "\n")
+
+
 def test_concurrent_streams_threads(hip, po):
     """Distinct streams driven from distinct threads (the tile fan-out of video_compress.cpp:441-490)."""
     import threading

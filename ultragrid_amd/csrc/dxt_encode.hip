@@ -133,6 +133,14 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x)
 #ifndef UG_DXT1_FAST_GROUP
 #define UG_DXT1_FAST_GROUP 2
 #endif
+// Diagnostics (ug_hip_dxt_encode_stats): waves that left a fast index stage for the reference's full form, counted in those (cold) paths only
+__device__ unsigned long long g_full_form_waves[2]; // [0] colour indices, [1] alpha indices
+__device__ __forceinline__ void count_full_form(int which)
+{
+        if ((int) threadIdx.x == __builtin_amdgcn_readfirstlane((int) threadIdx.x)) {
+                atomicAdd(&g_full_form_waves[which], 1ull);
+        }
+}
 struct IndexTables {
         float *alpha;     // [8][64] floats: thresholds in DESCENDING order, row 7 = -inf
         float4 *colour;   // DXT5-YCoCg: [3][64] (A.x, A.y, B.x, B.y) of the palette pair whose bisector crosses zone k; DXT1: [6][64], rows 2k / 2k + 1 = A / B (xyz)
@@ -489,11 +497,15 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p, const IndexTables &ta
                 // so one compare decides for practically every block; only a wave that sees a narrower range evaluates the six
                 // explicit comparisons.
                 bool all_mono, all_wide = false; // both wave-uniform
+                (void) all_wide;
                 if (__builtin_expect(__all(range > 0.0009765625f), 1)) {
                         all_mono = true;
                         all_wide = true;
                 } else {
                         asm volatile("; explicit monotonicity check" ::: "memory");
+#if UG_DXT_FAST_INDEX
+                        count_full_form(1);
+#endif
                         all_mono = __all((T1 <= T2) & (T2 <= T3) & (T3 <= T4) & (T4 <= T5) & (T5 <= T6) & (T6 <= T7));
                 }
                 // raw counts, 3 bits per pixel: lo = px 0..9 (30 bits), hi = px 10..15 (18 bits)
@@ -613,13 +625,16 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p, const IndexTables &ta
                 //   With vv * 256 > dmax and m >= 1/12 - 4e-4 that is > 200 x the rounding error; c2 / c3 are off their ideal
                 //   places by < 2e-7 absolute = < 6e-5 of a segment with vv >= 1e-5 (a non-zero segment of 8-bit-expanded end points
                 //   has vv >= 1.5e-5), and s itself is estimated to < 3e-4 (reciprocal + 5 roundings at magnitudes <= 650).
-                // A wave that holds a block outside that precondition (coincident end points) runs the full form below for all lanes.
+                // A wave that holds a block outside that precondition (coincident end points over non-flat chroma) runs the full form below for all lanes.
                 const float vx = cx[1] - cx[0], vy = cy[1] - cy[0];
                 const float vv = vx * vx + vy * vy;
                 const float e0 = fmaxf(fmaxf(mxCo, cx[0]), cx[1]) - fminf(fminf(mnCo, cx[0]), cx[1]);
                 const float e1 = fmaxf(fmaxf(fmaxf(mxCg, mnCg), cy[0]), cy[1]) - fminf(fminf(fminf(mxCg, mnCg), cy[0]), cy[1]);
                 const float dmax = e0 * e0 + e1 * e1;
-                if (__builtin_expect(__all((vv >= 1e-5f) & (vv * 256.0f > dmax)), 1)) {
+                // A block whose 16 pixels share ONE chroma value (flat areas; its end points usually coincide) gets the reference's full
+                // form for that one value, replicated; only a wave that holds such a block pays for it.
+                const bool flat = (mnCo == mxCo) & (mnCg == mxCg);
+                if (__builtin_expect(__all(((vv >= 1e-5f) & (vv * 256.0f > dmax)) | flat), 1)) {
                         float4 *const tc = tab.colour;
                         tc[0 * 64] = make_float4(cx[0], cy[0], cx[2], cy[2]); // zone 0: d0 > d2
                         tc[1 * 64] = make_float4(cx[2], cy[2], cx[3], cy[3]); // zone 1: d2 > d3
@@ -661,10 +676,25 @@ __device__ __forceinline__ uint4 encode_dxt5ycocg(Px16 &p, const IndexTables &ta
                         }
                         const uint32_t c = spread16(open), k0 = zones & 0x55555555u, k1 = (zones >> 1) & 0x55555555u;
                         w_cidx = ((k0 & c) | k1) | ((k0 | c) << 1);
+                        if (__any(flat)) {
+                                asm volatile("; flat blocks" ::: "memory");
+                                const float4 p02 = tc[0 * 64], p13 = tc[2 * 64]; // the palette, back from the table (not kept in registers)
+                                const float px[4] = { p02.x, p13.x, p02.z, p13.z }, py[4] = { p02.y, p13.y, p02.w, p13.w };
+                                float d[4];
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                        const float tx = Co[0] - px[k], ty = Cg[0] - py[k];
+                                        d[k] = tx * tx + ty * ty;
+                                }
+                                w_cidx = flat ? palette_index(d[0], d[1], d[2], d[3]) * 0x55555555u : w_cidx;
+                        }
                 } else
 #endif
                 {
                 asm volatile("; colour index full form" ::: "memory");
+#if UG_DXT_FAST_INDEX
+                count_full_form(0);
+#endif
                 f32x2 cx2[4], cy2[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -774,7 +804,8 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p, const IndexTables &t
                         const float e = fmaxf(fmaxf(fmaxf(mx[k], mn[k]), c0[k]), c1[k]) - fminf(fminf(fminf(mx[k], mn[k]), c0[k]), c1[k]);
                         dmax = dmax + e * e;
                 }
-                if (__builtin_expect(__all((vv >= 1e-5f) & (vv * 256.0f > dmax)), 1)) {
+                const bool flat = (mn[0] == mx[0]) & (mn[1] == mx[1]) & (mn[2] == mx[2]); // one colour: full form for it, replicated
+                if (__builtin_expect(__all(((vv >= 1e-5f) & (vv * 256.0f > dmax)) | flat), 1)) {
                         float4 *const tc = tab.colour;
                         tc[0 * 64] = make_float4(c0[0], c0[1], c0[2], 0.0f); tc[1 * 64] = make_float4(c2[0], c2[1], c2[2], 0.0f); // zone 0: d0 > d2
                         tc[2 * 64] = make_float4(c2[0], c2[1], c2[2], 0.0f); tc[3 * 64] = make_float4(c3[0], c3[1], c3[2], 0.0f); // zone 1: d2 > d3
@@ -823,10 +854,24 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p, const IndexTables &t
                         }
                         const uint32_t c = spread16(open), k0 = zones & 0x55555555u, k1 = (zones >> 1) & 0x55555555u;
                         w_idx = ((k0 & c) | k1) | ((k0 | c) << 1);
+                        if (__any(flat)) {
+                                asm volatile("; flat blocks" ::: "memory");
+                                const float4 pal[4] = { tc[0 * 64], tc[4 * 64], tc[1 * 64], tc[3 * 64] }; // the palette, back from the table
+                                float d[4];
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                        const float tx = R[0] - pal[k].x, ty = G[0] - pal[k].y, tz = B[0] - pal[k].z;
+                                        d[k] = AWAY ? (tx * tx + ty * ty) + tz * tz : (tz * tz + ty * ty) + tx * tx;
+                                }
+                                w_idx = flat ? palette_index(d[0], d[1], d[2], d[3]) * 0x55555555u : w_idx;
+                        }
                 } else
 #endif
                 {
                 asm volatile("; colour index full form" ::: "memory");
+#if UG_DXT_FAST_INDEX
+                count_full_form(0);
+#endif
                 const float *c[4] = { c0, c1, c2, c3 };
                 f32x2 cc[4][3];
 #pragma unroll
@@ -1154,6 +1199,20 @@ int ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *
 }
 
 } // extern "C"
+
+// Diagnostics: waves of this process's ug_hip_dxt_encode* launches on the current device that took the full form of an index stage
+extern "C" int ug_hip_dxt_encode_stats(unsigned long long full_form_waves[2], int reset)
+{
+        UG_HIP_TRY(hipDeviceSynchronize());
+        if (full_form_waves) {
+                UG_HIP_TRY(hipMemcpyFromSymbol(full_form_waves, HIP_SYMBOL(g_full_form_waves), 2 * sizeof(unsigned long long)));
+        }
+        if (reset) {
+                const unsigned long long zero[2] = { 0, 0 };
+                UG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_full_form_waves), zero, sizeof zero));
+        }
+        return UG_HIP_SUCCESS;
+}
 
 // Device self-test of the encoder's exact strength reductions (div14): *mismatches must come back 0.
 extern "C" int ug_hip_selftest_dxt_encode(unsigned *mismatches, ug_hip_stream_t stream)

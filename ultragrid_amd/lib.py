@@ -74,6 +74,7 @@ SYMBOLS = {
     "ug_hip_selftest_dxt_decode": (_i, [C.POINTER(C.c_uint), _vp]),
     "ug_hip_dxt_decode_debug": (_i, [_i, _vp]),
     "ug_hip_selftest_dxt_encode": (_i, [C.POINTER(C.c_uint), _vp]),
+    "ug_hip_dxt_encode_stats": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "ug_hip_uyvy_to_nv12": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_pixfmt_best": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "ug_hip_pixfmt_line_func": (_i, [C.c_char_p, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
