@@ -19,7 +19,8 @@
 // wave's row loads are contiguous (64 x 8 B UYVY, 64 x 12 B RGB, 64 x 32 B v210) and its
 // 64 x 16 B (DXT5) / 64 x 8 B (DXT1) stores form one contiguous 1 KiB / 512 B burst.
 // The work is VALU-bound: no LDS staging is needed because each input
-// byte is read by exactly one lane.
+// byte is read by exactly one lane.  LDS only holds each lane's own lookup columns of the fast
+// index stages (IndexTables below): the threshold / palette pair a pixel's one open comparison needs.
 #include "ug_common.h"
 
 #ifndef UG_DXT_TBUF
