@@ -9,7 +9,7 @@ bash tools/pmc_collect.sh r03 > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_r03/summary
 python tools/pmc_to_json.py uyvy_dxt5_4k_x16 "dxt_encode_kernel<2, 6" "rocprof passes of round 3 (profiles/r03_pmc_uyvy_dxt5_4k_x16.txt), dxt_encode_kernel<UYVY,DXT5,ties even> with the fast index stages" $OUT/pmc_summary.txt
 bash tools/pmc_workloads.sh > $OUT/pmc_workloads.log 2>&1; cp gpurun_out/pmc_workloads/*.txt $OUT/
 python tools/pmc_to_json.py v210_dxt5_8k_x4 "dxt_encode_kernel<6, 6" "rocprof passes of round 3 (profiles/r03_pmc_8k_v210.txt), dxt_encode_kernel<v210,DXT5,ties even>" $OUT/8k-v210.txt
-python tools/pmc_to_json.py rgb_dxt1_1080p_x64 "dxt_encode_kernel<0, 1" "rocprof passes of round 3 (profiles/r03_pmc_1080p_rgb_dxt1.txt), dxt_encode_kernel<RGB,DXT1,ties even>" $OUT/1080p-rgb-dxt1.txt
+python tools/pmc_to_json.py rgb_dxt1_1080p_x64 "dxt_encode_kernel<4, 1" "rocprof passes of round 3 (profiles/r03_pmc_1080p_rgb_dxt1.txt), dxt_encode_kernel<RGB,DXT1,ties even>" $OUT/1080p-rgb-dxt1.txt
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench_line.json
 for wl in 8k-v210 1080p-rgb-dxt1 4k-uyvy-jpeg420; do python bench.py --workload $wl --no-e2e > $OUT/bench_$wl.json 2>> $OUT/bench.err; done

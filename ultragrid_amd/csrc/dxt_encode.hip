@@ -1004,10 +1004,16 @@ __global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVE
 #pragma unroll
                 for (int k = 0; k < L::kBlocks; k++) {
                         if (k < n_res) {
+                                // One block per lane: a store instruction covers whole lines (64 x 16 B / 64 x 8 B contiguous) and streams past L2.
+                                // Three blocks per lane (v210): an instruction writes 16 of every 48 bytes and the lines complete only with the
+                                // third one -- streamed, the pieces reached HBM separately (WRITE_SIZE 157 MB for 132.7 MB of output, rocprofv3),
+                                // so these go through L2 as plain stores and merge there (1.001 x).
+                                uint8_t *const at = dst_row + (dst_off + k * kBlockBytes);
                                 if (OUT == UG_DXT5_YCOCG) {
-                                        ug::st_stream((uint4 *) (dst_row + (dst_off + k * kBlockBytes)), res[k]);
+                                        if (L::kBlocks > 1) *(uint4 *) at = res[k]; else ug::st_stream((uint4 *) at, res[k]);
                                 } else {
-                                        ug::st_stream((uint2 *) (dst_row + (dst_off + k * kBlockBytes)), make_uint2(res[k].x, res[k].y));
+                                        const uint2 v = make_uint2(res[k].x, res[k].y);
+                                        if (L::kBlocks > 1) *(uint2 *) at = v; else ug::st_stream((uint2 *) at, v);
                                 }
                         }
                 }
