@@ -172,17 +172,20 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
                    "pcie_gbs_total": round(sum(pcie), 2), "pcie_gbs_per_gpu": pcie, "in_flight": r["in_flight"],
                    "copy_only_fps_per_gpu": ceils, "frac_of_copy_only": round(sum(per) / sum(ceils), 3) if sum(ceils) else None,
                    "bytes_in_per_frame": r["bytes_in_per_frame"], "bytes_out_per_frame": r["bytes_out_per_frame"], "seconds": r["seconds"]}
-    try:   # the box's link by itself (rank 0's GPU; pure copies, 2 in flight per direction)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        lp = pipeline.link_probe(seconds=0.5, streams=2) if rank == 0 else None
-        if dist is not None:
-            dist.barrier()
-        if lp is not None:
-            res["link_gbs_h2d"], res["link_gbs_d2h"], res["link_gbs_bidir_each"] = lp["h2d_gbs"], lp["d2h_gbs"], lp["bidir_each_gbs"]
-    except Exception as e:
-        print(f"bench.py: link probe failed: {e}", file=sys.stderr, flush=True)
+    # the box's link by itself (rank 0's GPU; pure copies, 2 in flight per direction); the other ranks wait: both barriers are reached whatever the probe does
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    lp = None
+    if rank == 0:
+        try:
+            lp = pipeline.link_probe(seconds=0.5, streams=2)
+        except Exception as e:
+            print(f"bench.py: link probe failed: {e}", file=sys.stderr, flush=True)
+    if dist is not None:
+        dist.barrier()
+    if lp is not None:
+        res["link_gbs_h2d"], res["link_gbs_d2h"], res["link_gbs_bidir_each"] = lp["h2d_gbs"], lp["d2h_gbs"], lp["bidir_each_gbs"]
     res["path"] = ("pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU, all ranks concurrently; "
                    "one upload, one compute and one download stream with events between the stages of a frame (tools/e2e_bench.py --sweep: better than a stream per frame); copy_only_fps = the same copies without the kernel (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
     res["numa_node_rank0"] = node
