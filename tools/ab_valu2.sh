@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for lib in "$@"; do
   n=$(basename $lib .so); O=/tmp/v2_$n; rm -rf $O
-  UG_MI355X_LIB=$R/$lib rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 SQ_WAVES -d $O -o a -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  UG_MI355X_LIB=$R/$lib rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 SQ_WAVES -d $O -o a -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-e2e > /dev/null 2>&1
   python - <<PY
 import sqlite3
 c = sqlite3.connect("$O/a_results.db")
