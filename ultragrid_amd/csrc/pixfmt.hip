@@ -311,11 +311,10 @@ int launch_generic(const Args &a, hipStream_t st)
 
 // v210 -> UYVY: 16 B (6 px) -> 12 B.  Lane: 2 groups = 32 B in, 24 B out.
 struct FastV210toUYVY {
-        static constexpr int PX = 12;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 12, W = 6;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &)
         {
                 const uint4 *sp = (const uint4 *) s + 2 * c;
-                uint32_t o[6];
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
                         const uint4 q = sp[g];
@@ -325,14 +324,12 @@ struct FastV210toUYVY {
                         o[3 * g + 2] = S(q.z, 2) | S(q.w, 0) << 8 | S(q.w, 1) << 16 | S(q.w, 2) << 24;
 #undef S
                 }
-                uint2 *dp = (uint2 *) d + 3 * c;
-                ug::st_stream(&dp[0], make_uint2(o[0], o[1])); ug::st_stream(&dp[1], make_uint2(o[2], o[3])); ug::st_stream(&dp[2], make_uint2(o[4], o[5]));
         }
 };
 // UYVY -> RGB: lane 16 B (8 px) in, 24 B out
 struct FastUYVYtoRGB {
-        static constexpr int PX = 8;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 8, W = 6;
+        static __device__ void run(const uint8_t *s, uint32_t (&ow)[W], int c, const Args &)
         {
                 const uint4 q = ((const uint4 *) s)[c];
                 const uint32_t w[4] = { q.x, q.y, q.z, q.w };
@@ -343,19 +340,15 @@ struct FastUYVYtoRGB {
                         yuv_to_rgb8(kCfs8.y_scale * ((int) ((w[i] >> 8) & 0xff) - 16), u, v, o + 6 * i);
                         yuv_to_rgb8(kCfs8.y_scale * ((int) (w[i] >> 24) - 16), u, v, o + 6 * i + 3);
                 }
-                uint2 *dp = (uint2 *) d + 3 * c;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                        ug::st_stream(&dp[i], make_uint2(o[8 * i] | o[8 * i + 1] << 8 | o[8 * i + 2] << 16 | (uint32_t) o[8 * i + 3] << 24,
-                                                         o[8 * i + 4] | o[8 * i + 5] << 8 | o[8 * i + 6] << 16 | (uint32_t) o[8 * i + 7] << 24));
-                }
+                for (int i = 0; i < 6; i++) ow[i] = o[4 * i] | o[4 * i + 1] << 8 | o[4 * i + 2] << 16 | (uint32_t) o[4 * i + 3] << 24;
         }
 };
 // RGB -> UYVY: lane 24 B (8 px) in, 16 B out
 template <int RO, int BO>
 struct FastRGBtoUYVY {
-        static constexpr int PX = 8;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 8, W = 4;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &)
         {
                 const uint2 *sp = (const uint2 *) s + 3 * c;
                 uint8_t b[24];
@@ -365,7 +358,6 @@ struct FastRGBtoUYVY {
 #pragma unroll
                         for (int j = 0; j < 4; j++) { b[8 * i + j] = q.x >> (8 * j); b[8 * i + 4 + j] = q.y >> (8 * j); }
                 }
-                uint32_t o[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                         const uint8_t *p = b + 6 * i;
@@ -381,13 +373,12 @@ struct FastRGBtoUYVY {
                         v = ((v / 2) >> kBase) + 128;
                         o[i] = ((uint32_t) (y2 & 0xFF) << 24) | ((v & 0xFF) << 16) | ((y1 & 0xFF) << 8) | (u & 0xFF);
                 }
-                ug::st_stream(&((uint4 *) d)[c], make_uint4(o[0], o[1], o[2], o[3]));
         }
 };
 // v210 -> RGB (8-bit): lane 32 B (12 px) in, 36 B out
 struct FastV210toRGB {
-        static constexpr int PX = 12;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 12, W = 9;
+        static __device__ void run(const uint8_t *s, uint32_t (&ow)[W], int c, const Args &)
         {
                 const uint4 *sp = (const uint4 *) s + 2 * c;
                 uint8_t o[36];
@@ -407,64 +398,57 @@ struct FastV210toRGB {
                                 o[18 * g + 3 * i + 2] = clampi((y + u * kCfs8.b_cb) >> kBase, 1, 254);
                         }
                 }
-                uint32_t *dp = (uint32_t *) d + 9 * c;
 #pragma unroll
-                for (int i = 0; i < 9; i++) {
-                        ug::st_stream(&dp[i], o[4 * i] | o[4 * i + 1] << 8 | o[4 * i + 2] << 16 | (uint32_t) o[4 * i + 3] << 24);
-                }
+                for (int i = 0; i < 9; i++) ow[i] = o[4 * i] | o[4 * i + 1] << 8 | o[4 * i + 2] << 16 | (uint32_t) o[4 * i + 3] << 24;
         }
 };
 // RGBA -> RGB: lane 16 B (4 px) in, 12 B out ; RGB -> RGBA the inverse
 struct FastRGBAtoRGB {
-        static constexpr int PX = 4;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 4, W = 3;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &)
         {
                 const uint4 q = ((const uint4 *) s)[c];
-                uint32_t *dp = (uint32_t *) d + 3 * c;
-                ug::st_stream(&dp[0], (q.x & 0xffffff) | (q.y << 24));
-                ug::st_stream(&dp[1], ((q.y >> 8) & 0xffff) | (q.z << 16));
-                ug::st_stream(&dp[2], ((q.z >> 16) & 0xff) | (q.w << 8));
+                o[0] = (q.x & 0xffffff) | (q.y << 24);
+                o[1] = ((q.y >> 8) & 0xffff) | (q.z << 16);
+                o[2] = ((q.z >> 16) & 0xff) | (q.w << 8);
         }
 };
 
 // UYVY <-> YUYV: lane 16 B, swap the bytes of every 16-bit pair
 struct FastSwapYUYV {
-        static constexpr int PX = 8;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 8, W = 4;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &)
         {
                 uint4 q = ((const uint4 *) s)[c];
 #define SW(w) ((((w) & 0x00ff00ffu) << 8) | (((w) >> 8) & 0x00ff00ffu))
                 q.x = SW(q.x); q.y = SW(q.y); q.z = SW(q.z); q.w = SW(q.w);
 #undef SW
-                ug::st_stream(&((uint4 *) d)[c], q);
+                o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
         }
 };
 // RGB -> RGBA with shifts: lane 12 B (4 px) in, 16 B out
 struct FastRGBtoRGBA {
-        static constexpr int PX = 4;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &a)
+        static constexpr int PX = 4, W = 4;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &a)
         {
                 const uint32_t *sp = (const uint32_t *) s + 3 * c;
                 const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2];
                 const uint32_t am = alpha_mask(a.rs, a.gs, a.bs);
                 const uint32_t px[4] = { w0 & 0xffffff, (w0 >> 24) | ((w1 & 0xffff) << 8), (w1 >> 16) | ((w2 & 0xff) << 16), w2 >> 8 };
-                uint32_t o[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                         o[i] = am | (px[i] & 0xff) << a.rs | ((px[i] >> 8) & 0xff) << a.gs | (px[i] >> 16) << a.bs;
                 }
-                ug::st_stream(&((uint4 *) d)[c], make_uint4(o[0], o[1], o[2], o[3]));
         }
 };
 // UYVY -> v210: lane 24 B (12 px) in, 32 B out; consecutive bytes -> 10-bit fields (<< 2), three per word
 struct FastUYVYtoV210 {
-        static constexpr int PX = 12;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &)
+        static constexpr int PX = 12, W = 8;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &)
         {
                 const uint2 *sp = (const uint2 *) s + 3 * c;
                 const uint2 q0 = sp[0], q1 = sp[1], q2 = sp[2];
                 const uint32_t w[6] = { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
-                uint32_t o[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                         uint32_t v = 0;
@@ -475,20 +459,16 @@ struct FastUYVYtoV210 {
                         }
                         o[k] = v;
                 }
-                uint4 *dp = (uint4 *) d + 2 * c;
-                ug::st_stream(&dp[0], make_uint4(o[0], o[1], o[2], o[3]));
-                ug::st_stream(&dp[1], make_uint4(o[4], o[5], o[6], o[7]));
         }
 };
 // UYVY -> RGBA (fp64 arithmetic of vc_copylineUYVYtoRGBA, pixfmt_conv.c:1137-1163): lane 16 B (8 px) in, 32 B out
 struct FastUYVYtoRGBA {
-        static constexpr int PX = 8;
-        static __device__ void run(const uint8_t *s, uint8_t *d, int c, const Args &a)
+        static constexpr int PX = 8, W = 8;
+        static __device__ void run(const uint8_t *s, uint32_t (&o)[W], int c, const Args &a)
         {
                 const uint4 q = ((const uint4 *) s)[c];
                 const uint32_t w[4] = { q.x, q.y, q.z, q.w };
                 const uint32_t am = alpha_mask(a.rs, a.gs, a.bs);
-                uint32_t o[8];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                         const int u = w[i] & 0xff, v = (w[i] >> 16) & 0xff;
@@ -502,18 +482,23 @@ struct FastUYVYtoRGBA {
                                 o[2 * i + h] = am | (uint32_t) r << a.rs | (uint32_t) g << a.gs | (uint32_t) b << a.bs;
                         }
                 }
-                uint4 *dp = (uint4 *) d + 2 * c;
-                ug::st_stream(&dp[0], make_uint4(o[0], o[1], o[2], o[3]));
-                ug::st_stream(&dp[1], make_uint4(o[4], o[5], o[6], o[7]));
         }
 };
 
+// A wave = 64 consecutive chunks of one line; the chunks' output words leave as one contiguous region (ug::WaveWords).
 template <class F>
 __global__ __launch_bounds__(256) void fast_kernel(Args a, int cpl)
 {
+        using WS = ug::WaveWords<F::W>;
+        __shared__ uint32_t lds_all[WS::LDS_DWORDS ? 4 * WS::LDS_DWORDS : 1];
         const int c = blockIdx.x * blockDim.x + threadIdx.x, line = blockIdx.y;
-        if (c >= cpl) return;
-        F::run(a.src + (long) line * a.spitch, a.dst + (long) line * a.dpitch, c, a);
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+        const int c0 = c - lane;
+        if (c0 >= cpl) return; // wave-uniform
+        const int units = min(64, cpl - c0);
+        uint32_t o[F::W];
+        if (lane < units) F::run(a.src + (long) line * a.spitch, o, c, a);
+        WS::store(a.dst + (long) line * a.dpitch + (long) c0 * (F::W * 4), o, lds_all + wave * WS::LDS_DWORDS, lane, units);
 }
 
 template <class F>

@@ -152,6 +152,45 @@ struct UnitIO {
         }
 };
 
+template <int N> struct WordVec;
+template <> struct WordVec<1> { typedef uint32_t type; template <int W> static __device__ __forceinline__ uint32_t make(const uint32_t (&w)[W], int i) { return w[i]; } };
+template <> struct WordVec<2> { typedef uint2 type; template <int W> static __device__ __forceinline__ uint2 make(const uint32_t (&w)[W], int i) { return make_uint2(w[i], w[i + 1]); } };
+template <> struct WordVec<4> { typedef uint4 type; template <int W> static __device__ __forceinline__ uint4 make(const uint32_t (&w)[W], int i) { return make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]); } };
+// The same for a unit of W 32-bit words that a lane holds in registers (24-, 36-, 12-byte units: W = 6, 9, 3 ...): stored lane by lane
+// the unit's words go out as W (or W / 2) strided instructions, each covering a fraction of every line it touches -- through L2 that
+// merges, streamed past it the pieces reach HBM one by one (rocprofv3 WRITE_SIZE 1.2-1.56 x the output for the 3-byte-pixel rows,
+// profiles/r03_write_by_row.txt).  Here the wave's 64 units leave as ONE contiguous region: memory word c of the region (16, 8 or 4 bytes,
+// whatever divides the unit) is stored by lane c % 64, so every store instruction covers whole lines; the words change hands through
+// LDS rows of an odd number of memory words.
+template <int W>
+struct WaveWords {
+        static constexpr int G = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1); // 32-bit words per memory word
+        static constexpr int V = W / G;                                  // memory words per unit
+        static constexpr int ROW = V == 1 ? 1 : (V | 1);
+        static constexpr int LDS_DWORDS = V == 1 ? 0 : 64 * ROW * G;     // per wave
+        // region = where the wave's first unit goes; units = how many of the wave's 64 units exist (lanes >= units hold nothing)
+        static __device__ __forceinline__ void store(uint8_t *region, const uint32_t (&w)[W], uint32_t *lds, int lane, int units)
+        {
+                using T = typename WordVec<G>::type;
+                if (V == 1) {
+                        if (lane < units) st_stream((T *) region + lane, WordVec<G>::make(w, 0));
+                        return;
+                }
+                T *const l = (T *) lds;
+#pragma unroll
+                for (int i = 0; i < V; i++) l[lane * ROW + i] = WordVec<G>::make(w, i * G);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < V; i++) {
+                        const int c = i * 64 + lane;
+                        if (c < units * V) st_stream((T *) region + c, l[(c / V) * ROW + c % V]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // the next use of the rows (a loop around this call) must not overtake the reads
+                __builtin_amdgcn_wave_barrier();
+        }
+};
+
 } // namespace ug
 #endif
 
