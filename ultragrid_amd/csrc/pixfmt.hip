@@ -591,14 +591,20 @@ __global__ __launch_bounds__(256) void uyvy_to_i420_fast(const uint8_t *__restri
 }
 // v210_to_p010le, to_planar.c:64-155, the aligned regular case (width % 6 == 0, even height, 4-byte aligned planes): lane = one 6-px
 // group of a row pair, three 32-bit stores per line
+// (blockIdx.y = the row pair; a wave = 64 consecutive groups of it, whose 12-byte pieces leave as contiguous runs: ug::WaveWords)
 __global__ __launch_bounds__(256) void v210_to_p010le_kernel(const uint8_t *__restrict__ src, int spitch, uint8_t *__restrict__ yp,
-                                                             int ypitch, uint8_t *__restrict__ uvp, int uvpitch, int gpl, long total)
+                                                             int ypitch, uint8_t *__restrict__ uvp, int uvpitch, int gpl)
 {
-        const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
-        if (idx >= total) return;
-        const int i = (int) (idx / gpl), g = (int) (idx - (long) i * gpl);
-        const uint4 a = ((const uint4 *) (src + (long) (2 * i) * spitch))[g];
-        const uint4 b = ((const uint4 *) (src + (long) (2 * i + 1) * spitch))[g];
+        using WS = ug::WaveWords<3>;
+        __shared__ uint32_t lds_all[4 * WS::LDS_DWORDS];
+        const int g = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+        const int lane = threadIdx.x & 63, g0 = g - lane;
+        if (g0 >= gpl) return; // wave-uniform
+        const int units = min(64, gpl - g0);
+        uint32_t *const lds = lds_all + __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6) * WS::LDS_DWORDS;
+        const int gl = min(g, gpl - 1); // lanes past the line read the last group again; their words are not stored
+        const uint4 a = ((const uint4 *) (src + (long) (2 * i) * spitch))[gl];
+        const uint4 b = ((const uint4 *) (src + (long) (2 * i + 1) * spitch))[gl];
         const uint32_t wa[4] = { a.x, a.y, a.z, a.w }, wb[4] = { b.x, b.y, b.z, b.w };
         uint32_t o0[3], o1[3], oc[3];
 #pragma unroll
@@ -616,11 +622,9 @@ __global__ __launch_bounds__(256) void v210_to_p010le_kernel(const uint8_t *__re
                 }
                 o0[k] = v0[0] | v0[1] << 16; o1[k] = v1[0] | v1[1] << 16; oc[k] = vc[0] | vc[1] << 16;
         }
-        uint32_t *d0 = (uint32_t *) (yp + (long) (2 * i) * ypitch) + 3 * g;
-        uint32_t *d1 = (uint32_t *) (yp + (long) (2 * i + 1) * ypitch) + 3 * g;
-        uint32_t *dc = (uint32_t *) (uvp + (long) i * uvpitch) + 3 * g;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { ug::st_stream(d0 + k, o0[k]); ug::st_stream(d1 + k, o1[k]); ug::st_stream(dc + k, oc[k]); }
+        WS::store(yp + (long) (2 * i) * ypitch + 12 * g0, o0, lds, lane, units);
+        WS::store(yp + (long) (2 * i + 1) * ypitch + 12 * g0, o1, lds, lane, units);
+        WS::store(uvp + (long) i * uvpitch + 12 * g0, oc, lds, lane, units);
 }
 
 // One v210 group (4 words) -> its six luma samples and six chroma samples (Cb Cr Cb Cr Cb Cr), 10 bits each
@@ -902,11 +906,11 @@ int ug_hip_v210_to_p010le(const void *src, int src_pitch, void *y, int y_pitch, 
                 return UG_HIP_EUNSUPP;
         }
         hipStream_t st = (hipStream_t) stream;
-        if (width % 6 == 0 && height % 2 == 0 && !((src_pitch & 15) || (y_pitch & 3) || (uv_pitch & 3) || (15 & (uintptr_t) src) ||
-                                                    (3 & (uintptr_t) y) || (3 & (uintptr_t) uv))) {
-                const long total = (long) gpl * (height / 2);
-                hipLaunchKernelGGL(v210_to_p010le_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
-                                   (const uint8_t *) src, src_pitch, (uint8_t *) y, y_pitch, (uint8_t *) uv, uv_pitch, gpl, total);
+        if (width % 6 == 0 && height % 2 == 0 && height / 2 <= 65535 && !((src_pitch & 15) || (y_pitch & 3) || (uv_pitch & 3) || (15 & (uintptr_t) src) ||
+                                                                          (3 & (uintptr_t) y) || (3 & (uintptr_t) uv))) {
+                const int bx = gpl > 128 ? 256 : (gpl > 64 ? 128 : 64);
+                hipLaunchKernelGGL(v210_to_p010le_kernel, dim3((unsigned) ((gpl + bx - 1) / bx), (unsigned) (height / 2)), dim3(bx), 0, st,
+                                   (const uint8_t *) src, src_pitch, (uint8_t *) y, y_pitch, (uint8_t *) uv, uv_pitch, gpl);
         } else if (width < 6) {
                 hipLaunchKernelGGL(v210_to_p010le_narrow_kernel, dim3(1), dim3(1), 0, st, (const uint8_t *) src, src_pitch, (uint16_t *) y,
                                    y_pitch / 2, (uint16_t *) uv, uv_pitch / 2, width, height);

@@ -90,6 +90,23 @@ __device__ __forceinline__ void store_words(uint8_t *dst, const uint32_t (&w)[K]
         }
 }
 
+// The group of lane `lane` of a wave whose lanes hold consecutive groups of one line (first group g0 at `first`): when every group of the
+// wave is whole and the line allows the wide accesses, the 64 groups leave as one contiguous region (ug::WaveWords: every store
+// instruction covers whole lines -- streamed lane by lane, K-word groups wrote up to 1.56 x their bytes, profiles/r03_write_by_row.txt);
+// a wave with a ragged last group, or an unaligned line, stores lane by lane as before.  blockDim = (64, 4): one LDS region per wave.
+template <int K>
+__device__ __forceinline__ void store_group(uint8_t *first, int lane, int units, const uint32_t (&w)[K], int nbytes, int align)
+{
+        using WS = ug::WaveWords<K>;
+        __shared__ uint32_t lds[WS::LDS_DWORDS ? 4 * WS::LDS_DWORDS : 1];
+        const bool whole = nbytes == 4 * K && align >= 4 * WS::G;
+        if (__all(whole)) {
+                WS::store(first, w, lds + threadIdx.y * WS::LDS_DWORDS, lane, units, units); // the lanes past the line have returned
+        } else {
+                store_words<K>(first + (size_t) lane * (4 * K), w, nbytes, align);
+        }
+}
+
 template <int NB>
 __device__ __forceinline__ void bytes_to_words(const uint32_t (&b)[NB], uint32_t (&w)[NB / 4])
 {
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(256) void rgbp_to_packed_kernel(RgbpArgs a)
         load_samples<T, 8>(a.in[2] + (size_t) y * a.ls[2], x0, n, a.in_align, b);
         if (OUT == O_RGBA_BYTES) load_samples<T, 8>(a.in[3] + (size_t) y * a.ls[3], x0, n, a.in_align, al);
         uint8_t *const row = a.out + (size_t) y * a.pitch;
+        const int lane = threadIdx.x, g0 = gx - lane, units = min(64, (a.width + 7) / 8 - g0); // the wave's groups: g0 .. g0 + units - 1
         const int d = a.depth;
         if (OUT == O_RGB) { // gbrpXXle_to_rgb, from_planar.c:477-497; gbrap_to_rgb_rgba :335-354
                 uint32_t bytes[24], w[6];
@@ -124,19 +142,19 @@ __global__ __launch_bounds__(256) void rgbp_to_packed_kernel(RgbpArgs a)
                         bytes[3 * i + 2] = b[i] >> (d - 8);
                 }
                 bytes_to_words<24>(bytes, w);
-                store_words<6>(row + (size_t) gx * 24, w, 3 * n, a.out_align);
+                store_group<6>(row + (size_t) g0 * 24, lane, units, w, 3 * n, a.out_align);
         } else if (OUT == O_RGBA_SHIFT) { // gbrpXXle_to_rgba, from_planar.c:499-529
                 uint32_t w[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                         w[i] = a.alpha_mask | (r[i] >> (d - 8)) << a.rs | (g[i] >> (d - 8)) << a.gs | (b[i] >> (d - 8)) << a.bs;
                 }
-                store_words<8>(row + (size_t) gx * 32, w, 4 * n, a.out_align);
+                store_group<8>(row + (size_t) g0 * 32, lane, units, w, 4 * n, a.out_align);
         } else if (OUT == O_RGBA_BYTES) { // gbrap_to_rgb_rgba with alpha plane, from_planar.c:335-354
                 uint32_t w[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) w[i] = r[i] | g[i] << 8 | b[i] << 16 | al[i] << 24;
-                store_words<8>(row + (size_t) gx * 32, w, 4 * n, a.out_align);
+                store_group<8>(row + (size_t) g0 * 32, lane, units, w, 4 * n, a.out_align);
         } else if (OUT == O_RG48) { // rgbpXXle_to_rg48_int, from_planar.c:159-178
                 uint32_t w[12];
                 uint32_t s[24];
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(256) void rgbp_to_packed_kernel(RgbpArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < 12; i++) w[i] = s[2 * i] | s[2 * i + 1] << 16;
-                store_words<12>(row + (size_t) gx * 48, w, 6 * n, a.out_align);
+                store_group<12>(row + (size_t) g0 * 48, lane, units, w, 6 * n, a.out_align);
         } else if (OUT == O_R10K) { // gbrpXXle_to_r10k, from_planar.c:204-230
                 uint32_t bytes[32], w[8];
 #pragma unroll
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256) void rgbp_to_packed_kernel(RgbpArgs a)
                         bytes[4 * i + 3] = ((b[i] >> (d - 10)) & 0x3fu) << 2 | 0x3u;
                 }
                 bytes_to_words<32>(bytes, w);
-                store_words<8>(row + (size_t) gx * 32, w, 4 * n, a.out_align);
+                store_group<8>(row + (size_t) g0 * 32, lane, units, w, 4 * n, a.out_align);
         } else { // O_R12L: gbrpXXle_to_r12l, from_planar.c:60-134 -- a little-endian stream of 12-bit r,g,b; the whole 36-byte group
                  // is written even when the line ends inside it (samples past the end read as 0 here, as stack garbage there)
                 uint32_t v[24], bytes[36], w[9];
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(256) void rgbp_to_packed_kernel(RgbpArgs a)
                         bytes[3 * k + 2] = o >> 4;
                 }
                 bytes_to_words<36>(bytes, w);
-                store_words<9>(row + (size_t) gx * 36, w, 36, a.out_align);
+                store_group<9>(row + (size_t) g0 * 36, lane, units, w, 36, a.out_align);
         }
 }
 
@@ -225,7 +243,8 @@ __global__ __launch_bounds__(256) void yuv444p_to_vuya_kernel(YuvArgs a)
         load_samples<uint8_t, 8>(a.in[2] + (size_t) y * a.ls[2], 8 * gx, n, a.in_align, cr);
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = cr[i] | cb[i] << 8 | ys[i] << 16 | 0xff000000u;
-        store_words<8>(a.out + (size_t) y * a.pitch + (size_t) gx * 32, w, 4 * n, a.out_align);
+        const int lane = threadIdx.x, g0 = gx - lane;
+        store_group<8>(a.out + (size_t) y * a.pitch + (size_t) g0 * 32, lane, min(64, (a.width + 7) / 8 - g0), w, 4 * n, a.out_align);
 }
 
 // ---- packed -> planar -------------------------------------------------------------------------------------------------------------
@@ -324,7 +343,8 @@ __global__ __launch_bounds__(256) void rgba_to_bgra_kernel(ToArgs a)
         load_words<8>(a.in + (size_t) y * a.in_ls + (size_t) gx * 32, 4 * n, a.in_align, w);
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = (w[i] & 0xff00ff00u) | (w[i] & 0xffu) << 16 | ((w[i] >> 16) & 0xffu);
-        store_words<8>(a.out[0] + (size_t) y * a.ls[0] + (size_t) gx * 32, w, 4 * n, a.out_align);
+        const int lane = threadIdx.x, g0 = gx - lane;
+        store_group<8>(a.out[0] + (size_t) y * a.ls[0] + (size_t) g0 * 32, lane, min(64, (a.width + 7) / 8 - g0), w, 4 * n, a.out_align);
 }
 
 // vuya_to_i444, to_planar.c:321-337

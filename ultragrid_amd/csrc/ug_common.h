@@ -168,8 +168,9 @@ struct WaveWords {
         static constexpr int V = W / G;                                  // memory words per unit
         static constexpr int ROW = V == 1 ? 1 : (V | 1);
         static constexpr int LDS_DWORDS = V == 1 ? 0 : 64 * ROW * G;     // per wave
-        // region = where the wave's first unit goes; units = how many of the wave's 64 units exist (lanes >= units hold nothing)
-        static __device__ __forceinline__ void store(uint8_t *region, const uint32_t (&w)[W], uint32_t *lds, int lane, int units)
+        // region = where the wave's first unit goes; units = how many of the wave's 64 units exist (lanes >= units hold nothing);
+        // live = the lanes that execute this call: 64 when the lanes past the end stay (idle) in the wave, `units` when they have returned
+        static __device__ __forceinline__ void store(uint8_t *region, const uint32_t (&w)[W], uint32_t *lds, int lane, int units, int live = 64)
         {
                 using T = typename WordVec<G>::type;
                 if (V == 1) {
@@ -183,7 +184,7 @@ struct WaveWords {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = 0; i < V; i++) {
-                        const int c = i * 64 + lane;
+                        const int c = i * live + lane;
                         if (c < units * V) st_stream((T *) region + c, l[(c / V) * ROW + c % V]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // the next use of the rows (a loop around this call) must not overtake the reads
