@@ -875,26 +875,32 @@ __global__ void k_vuyax_to_y416(const Args a) // :2001-2015
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
 
+// The W output words of unit x of a packed line (the fast variants: blockDim = (64, 4), a wave = 64 consecutive units, lanes past the line
+// have returned, 16-byte aligned lines): the wave's units leave as one contiguous run of whole lines, streamed (ug::WaveWords)
+template <int W>
+__device__ __forceinline__ void store_unit(uint8_t *row, int x, int nunits, const uint32_t (&w)[W])
+{
+        using WS = ug::WaveWords<W>;
+        __shared__ uint32_t lds[WS::LDS_DWORDS ? 4 * WS::LDS_DWORDS : 1];
+        const int lane = threadIdx.x, x0 = x - lane, units = min(64, nunits - x0);
+        WS::store(row + (long) x0 * (4 * W), w, lds + threadIdx.y * WS::LDS_DWORDS, lane, units, units);
+}
+
 template <bool RGBA>
-__device__ __forceinline__ void store_px8(const Args &a, uint8_t *row, int lane, const int (&r)[8], const int (&g)[8], const int (&b)[8])
+__device__ __forceinline__ void store_px8(const Args &a, uint8_t *row, int x, const int (&r)[8], const int (&g)[8], const int (&b)[8])
 {
         if (RGBA) {
                 uint32_t w[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) w[i] = mk_rgba(a, r[i], g[i], b[i]);
-                uint4 *d = (uint4 *) (row + 32L * lane);
-                d[0] = make_uint4(w[0], w[1], w[2], w[3]);
-                d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                store_unit<8>(row, x, a.w / 8, w);
         } else {
-                uint32_t by[24];
+                uint32_t by[24], w[6];
 #pragma unroll
                 for (int i = 0; i < 8; i++) by[3 * i] = clamp_full(r[i], 8), by[3 * i + 1] = clamp_full(g[i], 8), by[3 * i + 2] = clamp_full(b[i], 8);
-                uint2 *d = (uint2 *) (row + 24L * lane);
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                        d[i] = make_uint2(by[8 * i] | by[8 * i + 1] << 8 | by[8 * i + 2] << 16 | by[8 * i + 3] << 24,
-                                          by[8 * i + 4] | by[8 * i + 5] << 8 | by[8 * i + 6] << 16 | by[8 * i + 7] << 24);
-                }
+                for (int i = 0; i < 6; i++) w[i] = by[4 * i] | by[4 * i + 1] << 8 | by[4 * i + 2] << 16 | by[4 * i + 3] << 24;
+                store_unit<6>(row, x, a.w / 8, w);
         }
 }
 
@@ -932,7 +938,7 @@ __global__ void k_nv12_x8(const Args a) // nv12_to_uyvy / nv12_to_rgb, 4 pixel p
                         const uint32_t c2 = i < 2 ? cc.x : cc.y, y2 = i < 2 ? yy.x : yy.y;
                         w[i] = byte_of(c2, 2 * (i % 2)) | byte_of(y2, 2 * (i % 2)) << 8 | byte_of(c2, 2 * (i % 2) + 1) << 16 | byte_of(y2, 2 * (i % 2) + 1) << 24;
                 }
-                *(uint4 *) (BUF(uint8_t, y) + 16L * x) = make_uint4(w[0], w[1], w[2], w[3]);
+                ug::st_stream((uint4 *) (BUF(uint8_t, y) + 16L * x), make_uint4(w[0], w[1], w[2], w[3]));
         } else {
                 int r[8], g[8], b[8];
 #pragma unroll
@@ -966,9 +972,9 @@ __global__ void k_rgb_to_gbrp_x8(const Args a) // rgb_rgba_to_gbrp, 8 pixels per
                         c[k][i / 4] |= byte_of(w[bi / 4], bi % 4) << (8 * (i % 4));
                 }
         }
-        *(uint2 *) (ROW(uint8_t, 2, y) + 8 * x) = make_uint2(c[0][0], c[0][1]);
-        *(uint2 *) (ROW(uint8_t, 0, y) + 8 * x) = make_uint2(c[1][0], c[1][1]);
-        *(uint2 *) (ROW(uint8_t, 1, y) + 8 * x) = make_uint2(c[2][0], c[2][1]);
+        ug::st_stream((uint2 *) (ROW(uint8_t, 2, y) + 8 * x), make_uint2(c[0][0], c[0][1]));
+        ug::st_stream((uint2 *) (ROW(uint8_t, 0, y) + 8 * x), make_uint2(c[1][0], c[1][1]));
+        ug::st_stream((uint2 *) (ROW(uint8_t, 1, y) + 8 * x), make_uint2(c[2][0], c[2][1]));
 }
 
 template <int SRC> // S_420P8 / S_422P8: four 6-pixel groups per lane
@@ -991,7 +997,7 @@ __global__ void k_planar8_to_v210_x4(const Args a)
                         const uint2 v = py[i];
                         yw[2 * i] = v.x, yw[2 * i + 1] = v.y;
                 }
-                uint4 *dst = (uint4 *) (BUF(uint8_t, row) + 64L * x);
+                uint32_t ow[16];
 #pragma unroll
                 for (int gidx = 0; gidx < 4; gidx++) {
                         uint32_t Y[6], cb[3], cr[3];
@@ -1000,9 +1006,30 @@ __global__ void k_planar8_to_v210_x4(const Args a)
                         if (k420) Y[4] >>= 2; // unshifted in the reference (:599-600)
 #pragma unroll
                         for (int i = 0; i < 3; i++) cb[i] = byte_of(cbw[(3 * gidx + i) / 4], (3 * gidx + i) % 4) << 2, cr[i] = byte_of(crw[(3 * gidx + i) / 4], (3 * gidx + i) % 4) << 2;
-                        dst[gidx] = make_uint4(v210w(cb[0], Y[0], cr[0]), v210w(Y[1], cb[1], Y[2]), v210w(cr[1], Y[3], cb[2]), v210w(Y[4], cr[2], Y[5]));
+                        ow[4 * gidx] = v210w(cb[0], Y[0], cr[0]), ow[4 * gidx + 1] = v210w(Y[1], cb[1], Y[2]);
+                        ow[4 * gidx + 2] = v210w(cr[1], Y[3], cb[2]), ow[4 * gidx + 3] = v210w(Y[4], cr[2], Y[5]);
                 }
+                store_unit<16>(BUF(uint8_t, row), x, a.w / 24, ow);
         }
+}
+
+__global__ void k_uyvy_to_yuv444p_x8(const Args a) // k_uyvy_to_yuv444p, 8 pixels per lane: 16 bytes in, 8 bytes to each of the three planes
+{
+        UG_XY();
+        if (x >= a.w / 8 || y >= a.h) return;
+        const uint4 q = BUF(const uint4, y)[x];
+        const uint32_t s[4] = { q.x, q.y, q.z, q.w };
+        uint32_t yy[2], cb[2], cr[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+                const uint32_t a0 = s[2 * h], a1 = s[2 * h + 1];
+                yy[h] = byte_of(a0, 1) | byte_of(a0, 3) << 8 | byte_of(a1, 1) << 16 | byte_of(a1, 3) << 24;
+                cb[h] = byte_of(a0, 0) * 0x0101u | byte_of(a1, 0) * 0x01010000u;
+                cr[h] = byte_of(a0, 2) * 0x0101u | byte_of(a1, 2) * 0x01010000u;
+        }
+        ug::st_stream((uint2 *) (ROW(uint8_t, 0, y) + 8 * x), make_uint2(yy[0], yy[1]));
+        ug::st_stream((uint2 *) (ROW(uint8_t, 1, y) + 8 * x), make_uint2(cb[0], cb[1]));
+        ug::st_stream((uint2 *) (ROW(uint8_t, 2, y) + 8 * x), make_uint2(cr[0], cr[1]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1029,8 +1056,8 @@ const Conv kToAv[] = {
         { "UYVY", "yuvj420p", nullptr, NX_W, NY_H, 0, F_I420, nullptr, 3 },
         { "UYVY", "yuv422p", nullptr, NX_W, NY_H, 0, F_I422, nullptr, 3 },
         { "UYVY", "yuvj422p", nullptr, NX_W, NY_H, 0, F_I422, nullptr, 3 },
-        { "UYVY", "yuv444p", k_uyvy_to_yuv444p, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
-        { "UYVY", "yuvj444p", k_uyvy_to_yuv444p, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 },
+        { "UYVY", "yuv444p", k_uyvy_to_yuv444p, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 , k_uyvy_to_yuv444p_x8, 4 },
+        { "UYVY", "yuvj444p", k_uyvy_to_yuv444p, NX_W2UP, NY_H, 0, F_NONE, nullptr, 3 , k_uyvy_to_yuv444p_x8, 4 },
         { "UYVY", "nv12", nullptr, NX_W, NY_H, 0, F_TO_PLANAR, "uyvy_to_nv12", 2 },
         { "UYVY", "vuya", k_uyvy_to_vuya, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
         { "UYVY", "vuyx", k_uyvy_to_vuya, NX_W2UP, NY_H, 0, F_NONE, nullptr, 1 },
@@ -1202,6 +1229,7 @@ int launch(const Conv &c, const Args &a, hipStream_t st)
                 uintptr_t bits = (uintptr_t) a.buf | (uintptr_t) a.pitch;
                 for (int i = 0; i < c.min_planes; i++) bits |= (uintptr_t) a.d[i] | (uintptr_t) a.ls[i];
                 if (!strcmp(c.av, "gbrp") && !strcmp(c.uv, "RGB") && (a.w % 16)) bits |= 1; // 3 * width source lines must stay 16-aligned
+                if (c.fast == k_uyvy_to_yuv444p_x8 && (a.w % 8)) bits |= 1;                 // (w + 1) / 2 pairs: an odd width can pass the divisibility test
                 if ((bits & 15) == 0) {
                         const int fx = nx / c.fast_div;
                         hipLaunchKernelGGL(c.fast, dim3((unsigned) ((fx + 63) / 64), (unsigned) ((ny + 3) / 4), 1), block, 0, st, a);
