@@ -752,14 +752,20 @@ __global__ __launch_bounds__(256) void r12l_quad_kernel(const XArgs a, int nquad
                 v[i] = x & 0xfffu;
         }
         uint8_t *XR drow = a.dst + (long) y * a.dpitch;
+        // 24- and 12-byte units: the wave's quads leave as one contiguous run of whole lines (ug::WaveWords; the lanes past the line have returned)
+        constexpr int kW = OUT == UG_PF_RG48 ? 6 : 3;
+        __shared__ uint32_t stage[(OUT == UG_PF_RG48 || OUT == UG_PF_RGB) ? 4 * ug::WaveWords<kW>::LDS_DWORDS : 1];
+        const int lane = threadIdx.x, q0 = q - lane, units = min(64, nquads - q0);
         if (OUT == UG_PF_RG48) {
-                uint2 *d = (uint2 *) (drow + 24 * (long) q);
+                uint32_t o[6];
 #pragma unroll
-                for (int k = 0; k < 3; k++) d[k] = make_uint2(v[4 * k] << 4 | v[4 * k + 1] << 20, v[4 * k + 2] << 4 | v[4 * k + 3] << 20);
+                for (int k = 0; k < 6; k++) o[k] = v[2 * k] << 4 | v[2 * k + 1] << 20;
+                ug::WaveWords<6>::store(drow + 24 * (long) q0, o, stage + threadIdx.y * ug::WaveWords<6>::LDS_DWORDS, lane, units, units);
         } else if (OUT == UG_PF_RGB) {
-                uint32_t *d = (uint32_t *) (drow + 12 * (long) q);
+                uint32_t o[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) d[k] = v[4 * k] >> 4 | (v[4 * k + 1] >> 4) << 8 | (v[4 * k + 2] >> 4) << 16 | (v[4 * k + 3] >> 4) << 24;
+                for (int k = 0; k < 3; k++) o[k] = v[4 * k] >> 4 | (v[4 * k + 1] >> 4) << 8 | (v[4 * k + 2] >> 4) << 16 | (v[4 * k + 3] >> 4) << 24;
+                ug::WaveWords<3>::store(drow + 12 * (long) q0, o, stage + threadIdx.y * ug::WaveWords<3>::LDS_DWORDS, lane, units, units);
         } else if (OUT == UG_PF_UYVY) { // k_r12l_to_uyvy's arithmetic
                 uint32_t out[2];
 #pragma unroll
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(256) void r12l_quad_kernel(const XArgs a, int nquad
                         const int y1 = (TO_Y(r1, g1, b1) >> (kBase + 8)) + 16, y2 = (TO_Y(r2, g2, b2) >> (kBase + 8)) + 16;
                         out[i] = (uint32_t) (u & 0xff) | (uint32_t) (y1 & 0xff) << 8 | (uint32_t) (vv & 0xff) << 16 | (uint32_t) (y2 & 0xff) << 24;
                 }
-                *(uint2 *) (drow + 8 * (long) q) = make_uint2(out[0], out[1]);
+                ug::st_stream((uint2 *) (drow + 8 * (long) q), make_uint2(out[0], out[1]));
         } else { // R10k: k_r12l_to_r10k's bytes, the slip in the second pixel of every group of 8 included
                 uint32_t out[4];
 #pragma unroll
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(256) void r12l_quad_kernel(const XArgs a, int nquad
                         if (i == 1 && !(q & 1)) last = (b & 0xf0) | (r & 0xf);
                         out[i] = r >> 4 | ((r & 0xC) << 4 | g >> 6) << 8 | ((g & 0x3C) << 2 | b >> 8) << 16 | last << 24;
                 }
-                *(uint4 *) (drow + 16 * (long) q) = make_uint4(out[0], out[1], out[2], out[3]);
+                ug::st_stream((uint4 *) (drow + 16 * (long) q), make_uint4(out[0], out[1], out[2], out[3]));
         }
 }
 template <int OUT>

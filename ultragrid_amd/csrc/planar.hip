@@ -50,9 +50,9 @@ __global__ __launch_bounds__(256) void planar_to_uyvy_kernel(Planes p, uint8_t *
         if (FAST) { // 8 pixels per lane
                 if (8 * i >= width) return;
                 const uint32_t cb4 = *(const uint32_t *) (cbl + 4 * i), cr4 = *(const uint32_t *) (crl + 4 * i);
-                *(uint4 *) (dst + (long) y0 * dst_pitch + 16 * i) = interleave8(*(const uint2 *) (p.y + (long) y0 * p.y_pitch + 8 * i), cb4, cr4);
+                ug::st_stream((uint4 *) (dst + (long) y0 * dst_pitch + 16 * i), interleave8(*(const uint2 *) (p.y + (long) y0 * p.y_pitch + 8 * i), cb4, cr4));
                 if (V == 2 && y1 != y0) {
-                        *(uint4 *) (dst + (long) y1 * dst_pitch + 16 * i) = interleave8(*(const uint2 *) (p.y + (long) y1 * p.y_pitch + 8 * i), cb4, cr4);
+                        ug::st_stream((uint4 *) (dst + (long) y1 * dst_pitch + 16 * i), interleave8(*(const uint2 *) (p.y + (long) y1 * p.y_pitch + 8 * i), cb4, cr4));
                 }
         } else { // one pixel pair per lane
                 const int pairs = V == 2 ? (width + 1) / 2 : width / 2; // 4:2:2 source: width / 2 pairs, nothing for an odd tail
