@@ -1058,6 +1058,51 @@ __global__ void k_v210_to_planar_x2(const Args a)
         }
 }
 
+// k_planar_to_v210 for the 16-bit sources (yuv420p10le, P010, P210), two 6-pixel groups per lane: the 24 luma bytes and the 12 + 12 (P010 / P210:
+// 24 interleaved) chroma bytes read as 32-bit words, 32 bytes of v210 out through store_unit
+template <int SRC>
+__global__ void k_planar16_to_v210_x2(const Args a)
+{
+        UG_XY();
+        constexpr bool k420 = SRC == S_420P10 || SRC == S_P010;
+        const int nunits = a.w / 12;
+        if (x >= nunits || y >= (k420 ? a.h / 2 : a.h)) return;
+        uint32_t cb[6], cr[6];
+        if (SRC == S_420P10) {
+                const uint32_t *scb = (const uint32_t *) (ROW(const uint8_t, 1, y) + 12 * x), *scr = (const uint32_t *) (ROW(const uint8_t, 2, y) + 12 * x);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                        const uint32_t u = scb[i], v = scr[i];
+                        cb[2 * i] = u & 0xffffu, cb[2 * i + 1] = u >> 16, cr[2 * i] = v & 0xffffu, cr[2 * i + 1] = v >> 16;
+                }
+        } else {
+                const uint32_t *sc = (const uint32_t *) (ROW(const uint8_t, 1, y) + 24 * x);
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                        const uint32_t c = sc[i];
+                        cb[i] = (c & 0xffffu) >> 6, cr[i] = c >> 22;
+                }
+        }
+#pragma unroll
+        for (int l = 0; l < (k420 ? 2 : 1); l++) {
+                const int row = k420 ? 2 * y + l : y;
+                const uint32_t *sy = (const uint32_t *) (ROW(const uint8_t, 0, row) + 24 * x);
+                uint32_t Y[12], ow[8];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                        const uint32_t v = sy[i];
+                        Y[2 * i] = SRC == S_420P10 ? v & 0xffffu : (v & 0xffffu) >> 6;
+                        Y[2 * i + 1] = SRC == S_420P10 ? v >> 16 : v >> 22;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                        ow[4 * k] = v210w(cb[3 * k], Y[6 * k], cr[3 * k]), ow[4 * k + 1] = v210w(Y[6 * k + 1], cb[3 * k + 1], Y[6 * k + 2]);
+                        ow[4 * k + 2] = v210w(cr[3 * k + 1], Y[6 * k + 3], cb[3 * k + 2]), ow[4 * k + 3] = v210w(Y[6 * k + 4], cr[3 * k + 2], Y[6 * k + 5]);
+                }
+                store_unit<8>(BUF(uint8_t, row), x, nunits, ow);
+        }
+}
+
 __global__ void k_uyvy_to_yuv444p_x8(const Args a) // k_uyvy_to_yuv444p, 8 pixels per lane: 16 bytes in, 8 bytes to each of the three planes
 {
         UG_XY();
@@ -1159,7 +1204,7 @@ const Conv kToAv[] = {
 // av_to_uv_conversions table, from_lavc_vid_conv.c:2049-2172 (rows whose output is UYVY, v210, RGB, RGBA or R10k)
 #define UG_FP(av, uv, name) { uv, av, nullptr, NX_W, NY_H, 0, F_FROM_PLANAR, name, 3 }
 const Conv kFromAv[] = {
-        { "v210", "yuv420p10le", k_planar_to_v210<S_420P10>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 },
+        { "v210", "yuv420p10le", k_planar_to_v210<S_420P10>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 , k_planar16_to_v210_x2<S_420P10>, 2 },
         { "UYVY", "yuv420p10le", k_to_uyvy<U_420P10>, NX_W2, NY_H2, 0, F_NONE, nullptr, 3 },
         { "RGB", "yuv420p10le", k_yuvp10le_to_rgb<420, 24>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
         { "RGBA", "yuv420p10le", k_yuvp10le_to_rgb<420, 32>, NX_W2, NY_H2, 10, F_NONE, nullptr, 3 },
@@ -1177,9 +1222,9 @@ const Conv kFromAv[] = {
         { "UYVY", "yuv444p12le", k_to_uyvy<U_444P12>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
         { "v210", "yuv444p16le", k_yuv444_to_v210<16>, NX_W6, NY_H, 0, F_NONE, nullptr, 3 },
         { "UYVY", "yuv444p16le", k_to_uyvy<U_444P16>, NX_W2, NY_H, 0, F_NONE, nullptr, 3 },
-        { "v210", "p210le", k_planar_to_v210<S_P210>, NX_W6, NY_H, 0, F_NONE, nullptr, 2 },
+        { "v210", "p210le", k_planar_to_v210<S_P210>, NX_W6, NY_H, 0, F_NONE, nullptr, 2 , k_planar16_to_v210_x2<S_P210>, 2 },
         { "UYVY", "p210le", k_p210le_to_uyvy, NX_W2, NY_H, 0, F_NONE, nullptr, 2 },
-        { "v210", "p010le", k_planar_to_v210<S_P010>, NX_W6, NY_H2, 0, F_NONE, nullptr, 2 },
+        { "v210", "p010le", k_planar_to_v210<S_P010>, NX_W6, NY_H2, 0, F_NONE, nullptr, 2 , k_planar16_to_v210_x2<S_P010>, 2 },
         { "UYVY", "p010le", k_to_uyvy<U_P010>, NX_W2, NY_H2, 0, F_NONE, nullptr, 2 },
         { "v210", "yuv420p", k_planar_to_v210<S_420P8>, NX_W6, NY_H2, 0, F_NONE, nullptr, 3 , k_planar8_to_v210_x4<S_420P8>, 4 },
         UG_FP("yuv420p", "UYVY", "yuv420p_to_uyvy"),
