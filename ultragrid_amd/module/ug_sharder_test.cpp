@@ -6,6 +6,9 @@
  * Links the reference's own video_frame / vf_split objects (no HIP).  usage: ug_sharder_test [workers] [frames] [batch]
  * batch > 1: workers queue up to that many frames and a fake batch encoder takes what has queued up (single-tile frames of one
  * geometry); every third single-tile frame OBJECT is pushed twice in a row (two sequence numbers, one object), as a file source would.
+ * A round that holds a tiled frame is encoded one at a time, so in batch mode tiled frames are rare (every 40th, not every 5th) and every
+ * worker's first call takes 30 ms: the producer fills the queues meanwhile and the first round a worker drains after it is a pure one --
+ * that a batch forms does not depend on scheduling luck.
  */
 #include <atomic>
 #include <chrono>
@@ -24,6 +27,7 @@ int main(int argc, char **argv)
         const int workers = argc > 1 ? atoi(argv[1]) : 4;
         const unsigned frames = argc > 2 ? atoi(argv[2]) : 200;
         const unsigned batch = argc > 3 ? atoi(argv[3]) : 1;
+        const unsigned tiled_every = batch > 1 ? 40 : 5;
         std::atomic<unsigned> batch_calls{0}, batched_frames{0};
         std::vector<int> devices;
         for (int i = 0; i < workers; i++) devices.push_back(i);
@@ -32,10 +36,12 @@ int main(int argc, char **argv)
         std::set<int> used;
         mi355x::frame_sharder sh(devices, [&](int device) -> mi355x::tile_encoder_t {
                 auto rng = std::make_shared<std::mt19937>(1234 + device);
-                return [&, rng, device](int dev, unsigned tile, std::shared_ptr<video_frame> in) -> std::shared_ptr<video_frame> {
+                auto first = std::make_shared<std::atomic<bool>>(true);
+                return [&, rng, first, device](int dev, unsigned tile, std::shared_ptr<video_frame> in) -> std::shared_ptr<video_frame> {
                         if (dev != device) abort();
                         calls++;
                         { std::lock_guard<std::mutex> lk(used_lock); used.insert(dev); }
+                        if (batch > 1 && first->exchange(false)) std::this_thread::sleep_for(std::chrono::milliseconds(30)); // lets the queues fill
                         std::this_thread::sleep_for(std::chrono::microseconds((*rng)() % 3000));
                         uint32_t tag;
                         memcpy(&tag, in->tiles[0].data, 4);
@@ -69,13 +75,13 @@ int main(int argc, char **argv)
         for (unsigned i = 0; i < frames; i++) {
                 struct video_desc d{};
                 d.width = 64; d.height = 16; d.color_spec = UYVY; d.fps = 25; d.interlacing = PROGRESSIVE;
-                d.tile_count = i % 5 == 0 ? 4 : 1;
+                d.tile_count = i % tiled_every == 0 ? 4 : 1;
                 std::shared_ptr<video_frame> f(vf_alloc_desc_data(d), vf_free);
                 for (unsigned t = 0; t < d.tile_count; t++) memcpy(f->tiles[t].data, &i, 4);
                 f->compress_start = 1000 + i;
                 if (i % 17 != 5) expected++;
                 sh.push(f);
-                if (batch > 1 && d.tile_count == 1 && i % 3 == 1 && i + 1 < frames && (i + 1) % 5 != 0) { // the same object again, as frame i + 1
+                if (batch > 1 && d.tile_count == 1 && i % 3 == 1 && i + 1 < frames && (i + 1) % tiled_every != 0) { // the same object again, as frame i + 1
                         if (i % 17 != 5) expected++; // same payload (tag i): succeeds or fails like the first push
                         i++;
                         sh.push(f);
@@ -93,7 +99,7 @@ int main(int argc, char **argv)
                 if (tag != f->seq && !(batch > 1 && tag + 1 == f->seq)) { fprintf(stderr, "payload %u under seq %u\n", tag, f->seq); rc = 1; }
                 if (!first && f->seq <= last) { fprintf(stderr, "out of order: %u after %u\n", f->seq, last); rc = 1; }
                 if (tag % 17 == 5) { fprintf(stderr, "failed frame %u was delivered\n", f->seq); rc = 1; }
-                if (f->tile_count != (f->seq % 5 == 0 ? 4u : 1u)) { fprintf(stderr, "tile count of %u\n", f->seq); rc = 1; }
+                if (f->tile_count != (f->seq % tiled_every == 0 ? 4u : 1u)) { fprintf(stderr, "tile count of %u\n", f->seq); rc = 1; }
                 for (unsigned t = 0; t < f->tile_count; t++) {
                         if ((unsigned char) f->tiles[t].data[4] != t) { fprintf(stderr, "tile order in %u\n", f->seq); rc = 1; }
                 }
