@@ -2,7 +2,8 @@
 """bench.py -- headline benchmark: Mpixels/s encode (UYVY -> DXT5-YCoCg, 4K) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ..., or as plain
+     `python bench.py --gpus N`, which then starts the N ranks itself the same way)
 
 One "step" = passes of the hot path (fused UYVY unpack + YUV->RGB + RGB->YCoCg + DXT5 block encode,
 ug_hip_dxt_encode_batch: one launch = `--frames` = 16 distinct synthetic 3840x2160 UYVY frames, BASELINE.json
@@ -213,11 +214,21 @@ def main() -> None:
                     "agree_max, gather_rates and max-over-ranks collectives run on cuda tensors on a 1-GPU box")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run on
+    # 127.0.0.1); rank 0 of that job prints the one JSON line on our stdout, and its exit code is ours.
+    from ultragrid_amd import shard as _shard
+    relaunch = _shard.self_launch_command(args.gpus, os.environ, [os.path.abspath(__file__), *sys.argv[1:]], sys.executable)
+    if relaunch is not None:
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))   # the launcher would force 1: rank 0's CPU baseline is OpenMP
+        raise SystemExit(subprocess.call(relaunch, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} was started under a launcher with WORLD_SIZE={world}: the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.all_ranks_on_device0:

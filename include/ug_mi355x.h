@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UG_HIP_ABI_VERSION 2 /* 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points */
+#define UG_HIP_ABI_VERSION 3 /* 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions only) */
 
 /* error codes (cuda_dxt.cu:745-746,759 uses -1 bad size/alignment, -3 runtime failure) */
 #define UG_HIP_SUCCESS      0
@@ -106,6 +106,17 @@ int         ug_hip_stream_create(ug_hip_stream_t *stream);
 int         ug_hip_stream_destroy(ug_hip_stream_t stream);
 int         ug_hip_stream_sync(ug_hip_stream_t stream);
 const char *ug_hip_last_error_string(void);                            /* cuda_wrapper_last_error_string */
+/* NUMA placement of the host threads that feed a GPU (the reference has one worker thread per device, gpujpeg.cpp:446-466, and leaves
+ * its placement to the scheduler; on a two-socket, eight-GPU node that is the host-side limit SURVEY.md 8(e) expects).
+ * ug_hip_device_numa_node: *node = NUMA node of the device's PCI function (sysfs numa_node), -1 if the platform does not say.
+ * ug_hip_bind_thread_to_device: restricts the CALLING THREAD to the CPUs of that node (intersected with its current affinity, never
+ * widened); *cpus_bound = CPUs it now runs on, 0 if it was left alone (unknown node, empty intersection).  Call it before the thread
+ * allocates its pinned buffers, so that they are first touched on that node.  The *_of_pci / *_to_numa_node forms take the PCI
+ * address / node directly and an alternative sysfs root (NULL = "/sys"): what the two above are made of, testable without a GPU. */
+int         ug_hip_device_numa_node(int device, int *node);
+int         ug_hip_bind_thread_to_device(int device, int *cpus_bound);
+int         ug_hip_numa_node_of_pci(const char *bdf, const char *sysfs_root, int *node);
+int         ug_hip_bind_thread_to_numa_node(int node, const char *sysfs_root, int *cpus_bound);
 /* Average duration in milliseconds of `iters` back-to-back launches of the DXT encoder on
  * `stream`, measured with hipEvents on that stream (cuda_dxt/rgb2dxt1.c:87-108 is the
  * reference's equivalent harness).  Writes ms per launch to *ms_per_launch. */
@@ -385,7 +396,9 @@ int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, cons
                                   void *out_dev, size_t out_capacity, size_t *out_len, ug_hip_stream_t stream);
 /* `frames` (1..16) frames of the same geometry in ONE call: the fused front end with grid.z = frame, the entropy coder and the
  * compaction with grid.y = frame, one synchronisation, `frames` lengths.  Frame f is read at src_dev + f * src_stride and its stream
- * written at out_dev + f * out_stride (a multiple of 16, >= out_capacity = what one stream may take); out_len[f] = its length.  Every
+ * written at out_dev + f * out_stride (a multiple of 16, >= out_capacity = what one stream may take); out_len[f] = its length; with frames > 1
+ * a stream that does not fit is reported per frame -- out_len[f] > out_capacity = the size it needs, the other streams are complete and
+ * the call succeeds (the one-frame call returns UG_HIP_EINVAL for it).  Every
  * stream is byte-identical to what ug_hip_jpeg_encoder_encode writes for that frame.  (gpujpeg.cpp:617-631 encodes one frame per
  * call; this is for callers that hold several queued frames -- per-call launch + synchronise cost is ~14 us of a ~55 us 4K call.) */
 int    ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, int frames, const void *src_dev, int src_pitch,

@@ -79,3 +79,15 @@ def test_two_ranks_on_one_gpu_smoke(hip):
     assert d["config"]["dist"]["world"] == 2 and d["config"]["dist"]["backend"] == "gloo"
     assert len(d["e2e"]["8k-v210"]["fps_per_gpu"]) == 2 and abs(sum(d["e2e"]["8k-v210"]["fps_per_gpu"]) - d["e2e"]["8k-v210"]["fps_total"]) < 0.2
     assert d["config"]["parallelism"].startswith("frames sharded over 2 GPU")
+
+
+def test_gpus_flag_without_a_launcher_starts_its_own_ranks(hip):
+    """`python3 bench.py --gpus 2` as the driver might invoke it -- no torch.distributed.run, no WORLD_SIZE -- launches its two
+    ranks itself and still prints exactly one JSON line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--launches-per-step", "8", "--e2e-seconds", "0.3",
+                        "--dist-backend", "gloo", "--all-ranks-on-device0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["dist"]["world"] == 2 and d["value"] > 0

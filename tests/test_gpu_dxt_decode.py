@@ -33,6 +33,27 @@ def test_decode_bit_exact(hip, po, fmt, out):
                 assert np.array_equal(got, want), (fmt, out, w, h, sh)
 
 
+@pytest.mark.parametrize("fmt", ["dxt1", "dxt5ycocg"])
+def test_rgba_shifts_with_alpha_in_front(hip, po, fmt):
+    """component shifts that are not a permutation of {0, 8, 16} -- (8, 16, 24), (24, 16, 8), (24, 0, 8) -- place the channels
+    where vc_copylineRGBA would (dxt_glsl.c:178) and 0xFF in the free byte; shifts that are not whole bytes are refused."""
+    import torch
+    from ultragrid_amd import lib as L
+    in_p, in_l = {"dxt1": (po.OUT_DXT1, L.DXT1), "dxt5ycocg": (po.OUT_DXT5YCOCG, L.DXT5_YCOCG)}[fmt]
+    w, h = 512, 64
+    enc = po.dxt_encode(po.IN_RGB, in_p, synth.frame("S2", "RGB", w, h), w, h)
+    rnd = np.random.default_rng(5).integers(0, 256, enc.size, dtype=np.uint8)
+    for blocks in (enc, rnd):
+        for sh in [(8, 16, 24), (24, 16, 8), (24, 0, 8), (0, 16, 24), (16, 8, 0)]:
+            got = _dec(hip, L, in_l, "RGBA", blocks, w, h, sh)
+            want = po.dxt_decode(in_p, "RGBA", blocks, w, h, sh)
+            assert np.array_equal(got, want), (fmt, sh)
+    dst = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    src = torch.from_numpy(enc).cuda()
+    for sh in [(4, 8, 16), (0, 8, 32), (-8, 0, 8)]:
+        assert L.load().ug_hip_dxt_decode(in_l, L.PF_RGBA, src.data_ptr(), dst.data_ptr(), w, h, 0, *sh, None) == L.EINVAL
+
+
 def test_matches_reference_dxt62tga_tool(hip, po):
     from ultragrid_amd import lib as L
     if not po.have_ref():
@@ -163,10 +184,34 @@ def test_dxt5_fixed_point_path_equals_the_fp64_statements(hip, po, out):
         with open(os.path.join(out_dir, f"dxt5_fixed_point_stats_{out}.txt"), "w") as f:
             f.write(f"DXT5-YCoCg -> {out}: {nblk} blocks; guarded (decoded again exactly): {res['n0']} = {res['n0'] / nblk:.3e}; blocks that differ from the fp64 "
                     f"statements when the fallback is switched off (mode 2): {bad_blocks}; product (mode 0) == fp64-only (mode 1): True\n")
-    # and a slice against the oracle (mode 0)
-    sl = blocks[: 16 * (w // 4) * 8].cpu().numpy()
-    assert np.array_equal(res[0][: w * bpp * 32].cpu().numpy(), po.dxt_decode(po.OUT_DXT5YCOCG, out, sl, w, 32))
-    sl = blocks[2 * third * 16: 2 * third * 16 + 16 * (w // 4) * 8].cpu().numpy()
-    row0 = (2 * third) // (w // 4) * 4
-    if (2 * third) % (w // 4) == 0:
-        assert np.array_equal(res[0][row0 * w * bpp: (row0 + 32) * w * bpp].cpu().numpy(), po.dxt_decode(po.OUT_DXT5YCOCG, out, sl, w, 32))
+    # The ORACLE over the whole set (no path may rest on a self-comparison): all 3.1 M blocks, every guarded one included,
+    # product (mode 0) byte for byte against oracle/dxt_decode_oracle.c (OpenMP C; itself pinned to the reference's dxt62tga tool).
+    want = po.dxt_decode(po.OUT_DXT5YCOCG, out, blocks.cpu().numpy(), w, h)
+    got = res[0].cpu().numpy()
+    if not np.array_equal(got, want):
+        d = (got != want).reshape(h, w * bpp)
+        rows, cols = np.nonzero(d)
+        raise AssertionError(f"DXT5-YCoCg -> {out}: {int(d.sum())} bytes differ from the oracle, first at line {rows[0]} byte {cols[0]}")
+
+
+@pytest.mark.parametrize("fmt", ["dxt1", "dxt1_yuv"])
+@pytest.mark.parametrize("out", ["RGBA", "RGB", "UYVY"])
+def test_dxt1_decode_full_4k_vs_oracle(hip, po, fmt, out):
+    """A whole 3840x2160 frame of DXT1 / DXT1_YUV blocks -- half encoder output of video noise, half arbitrary bit patterns (3-colour mode,
+    equal endpoints) -- against the oracle (dxt62tga.c:24-106 semantics), every output format the module offers."""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 3840, 2160
+    in_p, in_l = {"dxt1": (po.OUT_DXT1, L.DXT1), "dxt1_yuv": (po.OUT_DXT1_YUV, L.DXT1_YUV)}[fmt]
+    src = torch.from_numpy(synth.s2_video("UYVY", w, h // 2)).cuda()
+    enc = hip.dxt_encode(L.PF_UYVY_RAW if fmt == "dxt1_yuv" else L.PF_UYVY, L.DXT1, src, w, h // 2)
+    g = torch.Generator(device="cuda").manual_seed(4 + len(out))
+    rnd = torch.randint(0, 256, (enc.numel(),), generator=g, device="cuda", dtype=torch.uint8)
+    eq = rnd.view(-1, 8)[::7]
+    eq[:, 2:4] = eq[:, 0:2]                                   # every 7th random block: equal endpoints
+    blocks = torch.cat([enc.view(-1), rnd])
+    got = hip.dxt_decode(in_l, L.PF_NAMES[out], blocks, w, h).cpu().numpy()
+    want = po.dxt_decode(in_p, out, blocks.cpu().numpy(), w, h)
+    assert np.array_equal(got, want), (fmt, out, int((got != want).sum()))
+
+

@@ -419,15 +419,51 @@ def test_encode_batch_equals_single_frame_calls(hip, po, sub, fmt, ri):
     assert enc.encode_batch(dev.flip(0).contiguous(), pf) == want[::-1]
     assert enc.encode_batch(dev[1:3].contiguous(), pf) == want[1:3]
     assert enc.encode(dev[4], pf) == want[4]
-    # too small an output: EINVAL and the needed sizes
+    # too small an output: a batch reports per frame -- the call succeeds, out_len[f] = the needed size (> capacity) for the streams that do
+    # not fit, and the streams that do fit are complete (one oversize frame must not cost the whole batch)
     lens = (C.c_size_t * n)()
     cap = 1024
     out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
     rc = L.load().ug_hip_jpeg_encoder_encode_batch(enc._h, pf, n, dev.data_ptr(), 0, dev.shape[1], out.data_ptr(), cap, cap, lens, None)
-    assert rc == L.EINVAL and [lens[f] for f in range(n)] == [len(x) for x in want]
+    assert rc == L.SUCCESS and [lens[f] for f in range(n)] == [len(x) for x in want] and min(lens) > cap
+    sizes = sorted(len(x) for x in want)
+    cap = (sizes[len(sizes) // 2] + 15) // 16 * 16      # the smaller streams fit, the larger ones do not
+    out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+    rc = L.load().ug_hip_jpeg_encoder_encode_batch(enc._h, pf, n, dev.data_ptr(), 0, dev.shape[1], out.data_ptr(), cap, cap, lens, None)
+    assert rc == L.SUCCESS and [lens[f] for f in range(n)] == [len(x) for x in want]
+    assert any(l > cap for l in lens) and any(l <= cap for l in lens)
+    for f in range(n):
+        if lens[f] <= cap:
+            assert bytes(out[f, : lens[f]].cpu().numpy()) == want[f]
+    one = C.c_size_t(0)
+    big = max(range(n), key=lambda f: len(want[f]))
+    assert L.load().ug_hip_jpeg_encoder_encode(enc._h, pf, dev[big].data_ptr(), 0, out.data_ptr(), cap, C.byref(one), None) == L.EINVAL and one.value == len(want[big])
     assert L.load().ug_hip_jpeg_encoder_encode_batch(enc._h, pf, 17, dev.data_ptr(), 0, dev.shape[1], out.data_ptr(), cap, cap, lens, None) == L.EINVAL
     enc.close()
     single.close()
+
+
+def test_batches_of_varying_size_on_one_encoder(hip, po):
+    """batch(4), batch(2), a single frame, batch(4) again on ONE encoder at a size with more than 256 restart segments
+    (1080p, restart 2: 4 080) -- per-call state of the stream placement (round 3: chunk totals left behind by a larger batch; now the
+    look-back status words, which carry the call's generation) must not leak from one call into the next."""
+    import torch
+    w, h = 1920, 1088
+    base = torch.from_numpy(synth.s2_video("UYVY", w, h)).cuda()
+    dev = torch.stack([torch.roll(base, 3840 * 29 * f) for f in range(4)])
+    for sub, ri in ((420, 2), (422, 4), (420, 64)):
+        single = hip.JpegEncoder(w, h, 75, ri, subsampling=sub)
+        want = [single.encode(dev[f]) for f in range(4)]
+        single.close()
+        assert len(set(want)) == 4
+        enc = hip.JpegEncoder(w, h, 75, ri, subsampling=sub)
+        assert enc.encode_batch(dev) == want
+        assert enc.encode_batch(dev[2:].contiguous()) == want[2:]
+        assert enc.encode(dev[1]) == want[1]
+        assert enc.encode_batch(dev) == want
+        assert enc.encode_batch(dev[1:].contiguous()) == want[1:]
+        assert enc.encode_batch(dev.flip(0).contiguous()) == want[::-1]
+        enc.close()
 
 
 def test_encode_batch_full_4k(hip, po):

@@ -776,3 +776,54 @@ def test_batched_dxt_workers_deliver_the_same_blocks_in_order(tmp_path, po, cfg,
     per = outs["one"].size // n
     if codec == "UYVY":
         assert np.array_equal(outs["one"][:per], po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, frames[0], w, h))
+
+
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["dxt:DXT5", "jpeg:q=80"])
+def test_workers_run_on_the_gpu_s_numa_node(tmp_path, po, cfg):
+    """NUMA placement in the PRODUCT.  Every worker thread of the frame sharder binds itself to the CPUs of its GPU's
+    NUMA node (ug_hip_bind_thread_to_device) before its encoder state -- and with it the pinned frame pool -- exists; the worker reports
+    where it may run (UG_MI355X_NUMA_REPORT) and the test checks that against sysfs.  On a box whose platform names no node (numa_node =
+    -1) the worker is left alone; numa=0 switches the binding off; the encoded bytes are the same either way."""
+    w, h, n = 192, 64, 6
+    frames = [synth.s1_random("UYVY", w, h, salt=70 + f) for f in range(n)]
+    raw = tmp_path / "in.raw"
+    np.concatenate(frames).tofile(raw)
+    env = dict(os.environ, UG_MI355X_NUMA_REPORT="1")
+    outs = {}
+    for tag, extra in (("numa", ""), ("off", ":numa=0")):
+        out = tmp_path / f"{tag}.bin"
+        r = _run([cfg + extra, "UYVY", w, h, raw, out, 1, "host", n], env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = out.read_bytes()
+        lines = [l for l in r.stdout.splitlines() if l.startswith("NUMA worker")]
+        if tag == "off":
+            assert not lines
+            continue
+        assert len(lines) == 2, r.stdout                      # two workers per device by default
+        for l in lines:
+            f = dict(kv.split("=") for kv in l.split()[2:])
+            assert f["dev"] == "0" and f["rc"] == "0"
+            node, bound, aff = int(f["node"]), int(f["bound"]), _cpulist(f["affinity"])
+            p = f"/sys/devices/system/node/node{node}/cpulist"
+            if node >= 0 and os.path.exists(p):
+                want = _cpulist(open(p).read()) & os.sched_getaffinity(0)
+                if want:
+                    assert aff == want and bound == len(want), (l, sorted(want))
+                else:
+                    assert bound == 0
+            else:                                             # the platform does not say: left where it was
+                assert bound == 0 and aff == os.sched_getaffinity(0)
+    assert outs["numa"] == outs["off"]

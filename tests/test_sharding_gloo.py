@@ -76,3 +76,31 @@ def test_gloo_sharding_matches_single_process(po, world):
     for seq, blob in enumerate(merged):
         want = po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, synth.s1_random("UYVY", W, H, salt=seq), W, H).tobytes()
         assert blob == want, seq
+
+
+def test_bench_self_launch_decision():
+    """`python bench.py --gpus N` without a launcher re-executes itself as N ranks under torch.distributed.run on
+    127.0.0.1; under a launcher (WORLD_SIZE / RANK present) and at N = 1 it runs in place."""
+    argv = ["/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = shard.self_launch_command(8, {}, argv, "/usr/bin/python3", 29512)
+    assert cmd[:3] == ["/usr/bin/python3", "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29512" and "--nnodes=1" in cmd and cmd[-len(argv):] == argv
+    assert shard.self_launch_command(1, {}, argv, "python") is None
+    assert shard.self_launch_command(8, {"WORLD_SIZE": "8", "RANK": "3"}, argv, "python") is None
+    assert shard.self_launch_command(2, {"LOCAL_RANK": "0"}, argv, "python") is None
+    p = shard.self_launch_command(2, {"PATH": "/bin"}, argv, "python")   # port picked here: a free one
+    assert 1024 < int(p[p.index("--master-port") + 1]) < 65536
+
+
+def test_bench_self_launch_runs_the_ranks(tmp_path):
+    """The re-exec itself, on CPU: bench.py --gpus 2 with no launcher starts two ranks; each gets as far as the GPU check (there is no GPU
+    here), i.e. both ran main() past the launch decision with WORLD_SIZE=2 -- and the parent returns the job's non-zero exit code."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the re-exec; the GPU form is tests/test_gpu_bench_contract.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, cwd=str(tmp_path), env=env)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 2, (r.stdout + r.stderr)[-3000:]

@@ -539,7 +539,11 @@ int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h
         const int bw = w / 4, bh = h / 4;
         const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
         if (in == UG_DXT5_YCOCG) {
-                if (g_dxt5_mode == 1) {
+                // The fixed-point RGBA path keeps one palette column per output byte 0..2 and writes alpha to byte 3: right for the shifts
+                // that are a permutation of {0, 8, 16}.  Any other byte placement (a shift of 24: alpha in front, as vc_copylineRGBA's callers
+                // may ask, dxt_glsl.c:178) goes through the exact kernel, whose pack_px places the channels by shifting.
+                const bool rgb_low = OUT != UG_PF_RGBA || ((1 << (o.rs >> 3)) | (1 << (o.gs >> 3)) | (1 << (o.bs >> 3))) == 7;
+                if (g_dxt5_mode == 1 || !rgb_low) {
                         hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 1>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 } else if (g_dxt5_mode == 2) {
                         hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 2>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
@@ -582,6 +586,10 @@ extern "C" int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *sr
         if (in != UG_DXT1 && in != UG_DXT1_YUV && in != UG_DXT5_YCOCG) {
                 ug::set_last_error_msg("ug_hip_dxt_decode: unknown compressed format");
                 return UG_HIP_EUNSUPP;
+        }
+        if (out == UG_PF_RGBA && (((rshift | gshift | bshift) & 7) || (unsigned) rshift > 24 || (unsigned) gshift > 24 || (unsigned) bshift > 24)) {
+                ug::set_last_error_msg("ug_hip_dxt_decode: RGBA component shifts must be 0, 8, 16 or 24");
+                return UG_HIP_EINVAL;
         }
         if (dst_pitch == 0) {
                 dst_pitch = ug::linesize(out, width);

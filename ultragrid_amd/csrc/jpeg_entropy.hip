@@ -837,6 +837,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
         uint32_t *const tot = e->chunk_tot[e->frame_no & 1], *const tot_next = e->chunk_tot[(e->frame_no + 1) & 1];
         e->frame_no++;
+        // the totals this call's coder adds into start from zero for EVERY frame of the call (the compaction of the previous call cleared only
+        // the slices that call used: a smaller batch in between left the others stale -- ADVICE r3)
+        UG_HIP_TRY(hipMemsetAsync(tot, 0, (size_t) bs.tot_words * 4 * frames, st));
         if (S <= 256 && !e->force_wave_kernel) {
                 // waves per workgroup: the count that leaves the fewest lanes idle (fewer waves on a tie)
                 int waves = 1;
@@ -869,10 +872,11 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 out_len[f] = e->total_host[f];
                 fits = fits && out_len[f] <= out_capacity;
         }
-        if (!fits) { // segments past the end were not written; out_len[] tells the caller what it takes
+        if (!fits && frames == 1) { // segments past the end were not written; out_len tells the caller what it takes
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: stream does not fit the output buffer (out_len = needed size)");
                 return UG_HIP_EINVAL;
         }
+        // a batch reports per frame: out_len[f] > out_capacity = that stream did not fit (the others are complete)
         return UG_HIP_SUCCESS;
 }
 

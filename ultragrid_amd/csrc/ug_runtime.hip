@@ -1,6 +1,8 @@
 // ug_runtime.hip -- runtime shim of libug_mi355x.so: device select, device / pinned-host
 // allocation, copies, streams, last-error text.  Own entry points for what UltraGrid's
 // modules get from src/cuda_wrapper.h:50-76 (that shim is CUDA-only and is not hipified).
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -206,5 +208,102 @@ int ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, siz
 }
 
 int ug_hip_linesize(ug_pixfmt_t fmt, int width) { return ug::linesize(fmt, width); }
+
+// ---- NUMA placement of the threads that feed a GPU ("expect host-side limits before 8x scaling") ----
+// A worker of the frame sharder copies frames into pinned memory, queues the transfers and waits for them; on a two-socket box with
+// eight GPUs it should do that on the socket the GPU's PCIe root complex hangs off, and its pinned pool should be first touched there.
+// The node comes from sysfs (numa_node of the PCI function), the CPUs from the node's cpulist; `sysfs_root` (NULL = "/sys") lets the
+// CPU tests point both at a fake tree.
+namespace {
+constexpr int kMaxCpus = 4096;
+const char *sysroot(const char *r) { return r && *r ? r : "/sys"; }
+} // namespace
+
+int ug_hip_numa_node_of_pci(const char *bdf, const char *sysfs_root, int *node)
+{
+        if (!bdf || !node || strchr(bdf, '/') || strlen(bdf) > 32) {
+                ug::set_last_error_msg("ug_hip_numa_node_of_pci: bad arguments");
+                return UG_HIP_EINVAL;
+        }
+        *node = -1;
+        char path[512], lower[40];
+        size_t i = 0;
+        for (; bdf[i]; i++) lower[i] = (char) (bdf[i] >= 'A' && bdf[i] <= 'F' ? bdf[i] - 'A' + 'a' : bdf[i]); // sysfs names are lower case
+        lower[i] = 0;
+        snprintf(path, sizeof path, "%s/bus/pci/devices/%s/numa_node", sysroot(sysfs_root), lower);
+        FILE *f = fopen(path, "r");
+        if (!f) return UG_HIP_SUCCESS; // not said: -1
+        int v = -1;
+        if (fscanf(f, "%d", &v) == 1 && v >= 0) *node = v; // single-node boxes say -1
+        fclose(f);
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_device_numa_node(int device, int *node)
+{
+        if (!node) return UG_HIP_EINVAL;
+        char bdf[64] = "";
+        UG_HIP_TRY(hipDeviceGetPCIBusId(bdf, (int) sizeof bdf, device));
+        return ug_hip_numa_node_of_pci(bdf, nullptr, node);
+}
+
+int ug_hip_bind_thread_to_numa_node(int node, const char *sysfs_root, int *cpus_bound)
+{
+        if (cpus_bound) *cpus_bound = 0;
+        if (node < 0) return UG_HIP_SUCCESS; // unknown node: the thread is left where it is
+        char path[512], list[8192];
+        snprintf(path, sizeof path, "%s/devices/system/node/node%d/cpulist", sysroot(sysfs_root), node);
+        FILE *f = fopen(path, "r");
+        if (!f) return UG_HIP_SUCCESS;
+        const size_t n = fread(list, 1, sizeof list - 1, f);
+        fclose(f);
+        list[n] = 0;
+        cpu_set_t *want = CPU_ALLOC(kMaxCpus), *have = CPU_ALLOC(kMaxCpus);
+        const size_t sz = CPU_ALLOC_SIZE(kMaxCpus);
+        if (!want || !have) {
+                if (want) CPU_FREE(want);
+                if (have) CPU_FREE(have);
+                ug::set_last_error_msg("ug_hip_bind_thread_to_numa_node: out of memory");
+                return UG_HIP_ERUNTIME;
+        }
+        CPU_ZERO_S(sz, want);
+        for (const char *p = list; *p;) { // "0-31,64-95"
+                char *e;
+                const long a = strtol(p, &e, 10);
+                if (e == p) break;
+                long b = a;
+                if (*e == '-') b = strtol(e + 1, &e, 10);
+                for (long c = a; c <= b && c < kMaxCpus; c++) {
+                        if (c >= 0) CPU_SET_S((size_t) c, sz, want);
+                }
+                p = *e == ',' ? e + 1 : e;
+                if (*e != ',') break;
+        }
+        int rc = UG_HIP_SUCCESS, count = 0;
+        if (sched_getaffinity(0, sz, have) == 0) { // 0 = the calling thread
+                CPU_AND_S(sz, want, want, have); // never widen what the process was given (cpusets, taskset)
+                count = CPU_COUNT_S(sz, want);
+                if (count > 0 && !CPU_EQUAL_S(sz, want, have)) {
+                        if (sched_setaffinity(0, sz, want) != 0) {
+                                ug::set_last_error_msg("ug_hip_bind_thread_to_numa_node: sched_setaffinity failed");
+                                rc = UG_HIP_ERUNTIME;
+                                count = 0;
+                        }
+                } // (already exactly there: nothing to change; the count still says where the thread runs)
+        }
+        CPU_FREE(want);
+        CPU_FREE(have);
+        if (cpus_bound) *cpus_bound = count;
+        return rc;
+}
+
+int ug_hip_bind_thread_to_device(int device, int *cpus_bound)
+{
+        if (cpus_bound) *cpus_bound = 0;
+        int node = -1;
+        const int rc = ug_hip_device_numa_node(device, &node);
+        if (rc != UG_HIP_SUCCESS) return rc;
+        return ug_hip_bind_thread_to_numa_node(node, nullptr, cpus_bound);
+}
 
 } // extern "C"

@@ -23,7 +23,7 @@ PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "B
 DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 # UG_DXT_TIES_*
 TIES_EVEN, TIES_AWAY = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SUCCESS, EINVAL, EUNSUPP, ERUNTIME = 0, -1, -2, -3
 
@@ -49,6 +49,10 @@ SYMBOLS = {
     "ug_hip_stream_destroy": (_i, [_vp]),
     "ug_hip_stream_sync": (_i, [_vp]),
     "ug_hip_last_error_string": (C.c_char_p, []),
+    "ug_hip_device_numa_node": (_i, [_i, C.POINTER(_i)]),
+    "ug_hip_bind_thread_to_device": (_i, [_i, C.POINTER(_i)]),
+    "ug_hip_numa_node_of_pci": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_i)]),
+    "ug_hip_bind_thread_to_numa_node": (_i, [_i, C.c_char_p, C.POINTER(_i)]),
     "ug_hip_time_dxt_encode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _i, _vp, C.POINTER(C.c_float)]),
     "ug_hip_dxt_encode": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ug_hip_dxt_encode_batch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _vp]),

@@ -24,6 +24,7 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <string>
 #include <strings.h>
 
@@ -48,9 +49,12 @@ public:
         /// max_pending > 1 ("batch=<n>"): a worker that is busy takes up to that many frames into its queue instead of making push()
         /// wait, and encodes whatever has queued up as one batch -- throughput for sources that deliver faster than one frame per encode
         /// (files, transcoding); a source at display rate never queues and sees the one-frame path, as with max_pending = 1.
+        /// on_worker_start(device) runs first thing on every worker thread -- before the worker's encoder state, and with it the pinned
+        /// frame pool, exists (states are created on the worker's first frame): the place to put the thread on the GPU's NUMA node.
         frame_sharder(const std::vector<int> &devices, std::function<tile_encoder_t(int device)> make_encoder, unsigned max_pending = 1,
-                      std::function<batch_encoder_t(int device, tile_encoder_t)> make_batch_encoder = nullptr)
-            : m_max_pending(max_pending < 1 ? 1 : max_pending)
+                      std::function<batch_encoder_t(int device, tile_encoder_t)> make_batch_encoder = nullptr,
+                      std::function<void(int device)> on_worker_start = nullptr)
+            : m_max_pending(max_pending < 1 ? 1 : max_pending), m_on_worker_start(std::move(on_worker_start))
         {
                 for (int d : devices) {
                         auto *w = new worker();
@@ -214,6 +218,7 @@ private:
 
         void run(worker *w)
         {
+                if (m_on_worker_start) m_on_worker_start(w->device);
                 for (;;) {
                         std::vector<std::shared_ptr<video_frame>> frames; // what has queued up, up to the pill
                         std::vector<uint32_t> seqs;
@@ -257,6 +262,7 @@ private:
 
         std::vector<std::unique_ptr<worker>> m_workers;
         const unsigned m_max_pending;
+        const std::function<void(int device)> m_on_worker_start;
         std::mutex m_occupancy_lock;
         std::condition_variable m_worker_finished;
         uint32_t m_in_seq = 0;
@@ -304,10 +310,13 @@ struct tile_state_set {
         ~tile_state_set() { for (void *s : states) done(s); }
 };
 
-/// cfg = the module's option string; "dev=<n>[,<n>...]", "workers=<per device>" and "batch=<frames>" are consumed here, everything else goes to
-/// tile_init unchanged (with ":dev=<n>" of the worker appended).  Returns what tile_init returns for a bad / help configuration.
+/// cfg = the module's option string; "dev=<n>[,<n>...]", "workers=<per device>", "batch=<frames>" and "numa=<0|1>" are consumed here, everything
+/// else goes to tile_init unchanged (with ":dev=<n>" of the worker -- and ":batch_slices=<frames>" when batching -- appended).  Returns what
+/// tile_init returns for a bad / help configuration.  bind_thread (ug_hip_bind_thread_to_device): puts the calling thread on the CPUs of the
+/// device's NUMA node; every worker calls it before its first frame unless numa=0.
 inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t tile_init, tile_compress_t tile_compress, tile_done_t tile_done,
-                          int (*set_device)(int), tile_compress_batch_t tile_compress_batch = nullptr)
+                          int (*set_device)(int), tile_compress_batch_t tile_compress_batch = nullptr, int (*bind_thread)(int device, int *cpus_bound) = nullptr,
+                          int (*numa_node)(int device, int *node) = nullptr)
 {
         std::string rest, all = cfg ? cfg : "";
         std::vector<int> devices{ 0 };
@@ -315,6 +324,7 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
         // the reference framework over 4 000 4K frames: DXT5 1 979 -> 3 079 fps, JPEG 2 126 -> 2 393 fps, 8K v210 346 -> 445 fps); workers=1 gives the reference's one-per-device.
         int workers_per_device = 2;
         int batch = 1; // frames a busy worker may queue and then encode together ("batch=<n>"); 1 = the reference's one frame per worker
+        bool numa = true; // workers run on the CPUs of their GPU's NUMA node ("numa=0": left to the scheduler, as the reference's workers are)
         size_t pos = 0;
         while (pos <= all.size() && !all.empty()) {
                 const size_t end = all.find(':', pos);
@@ -328,6 +338,9 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
                         workers_per_device = atoi(tok.c_str() + 8);
                 } else if (strncasecmp(tok.c_str(), "batch=", 6) == 0) {
                         batch = atoi(tok.c_str() + 6);
+                } else if (strncasecmp(tok.c_str(), "numa=", 5) == 0) {
+                        const char *v = tok.c_str() + 5;
+                        numa = !(strcmp(v, "0") == 0 || strcasecmp(v, "no") == 0 || strcasecmp(v, "off") == 0);
                 } else if (!tok.empty()) {
                         rest += (rest.empty() ? "" : ":") + tok;
                 }
@@ -347,7 +360,9 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
                 for (int k = 0; k < workers_per_device; k++) expanded.insert(expanded.end(), devices.begin(), devices.end());
                 devices.swap(expanded); // d0 d1 .. d0 d1 ..: consecutive frames go to different GPUs first
         }
-        auto cfg_for = [rest](int dev) { return rest + (rest.empty() ? "" : ":") + "dev=" + std::to_string(dev); };
+        auto cfg_for = [rest, batch](int dev) {
+                return rest + (rest.empty() ? "" : ":") + "dev=" + std::to_string(dev) + (batch > 1 ? ":batch_slices=" + std::to_string(batch) : "");
+        };
         void *probe = tile_init(parent, cfg_for(devices[0]).c_str()); // validates the options first, then the first device
         if (probe == nullptr || probe == INIT_NOERR) {
                 return probe;
@@ -390,7 +405,25 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
                         if (st == nullptr) return {};
                         return tile_compress(st, std::move(in));
                 };
-        }, (unsigned) batch, make_batch));
+        }, (unsigned) batch, make_batch, numa && bind_thread != nullptr ? std::function<void(int)>([bind_thread, numa_node](int dev) {
+                int cpus = 0, node = -1;
+                const int rc = bind_thread(dev, &cpus);
+                if (numa_node) (void) numa_node(dev, &node);
+                if (rc == 0 && cpus > 0) {
+                        log_msg(LOG_LEVEL_VERBOSE, "[MI355X] worker of device %d runs on the %d CPUs of NUMA node %d (the GPU's)\n", dev, cpus, node);
+                }
+                if (getenv("UG_MI355X_NUMA_REPORT")) { // test hook: where this worker thread may run now
+                        std::string cpus_now;
+                        cpu_set_t set;
+                        if (sched_getaffinity(0, sizeof set, &set) == 0) {
+                                for (int c = 0; c < CPU_SETSIZE; c++) {
+                                        if (CPU_ISSET(c, &set)) cpus_now += (cpus_now.empty() ? "" : ",") + std::to_string(c);
+                                }
+                        }
+                        printf("NUMA worker dev=%d node=%d bound=%d rc=%d affinity=%s\n", dev, node, cpus, rc, cpus_now.c_str());
+                        fflush(stdout);
+                }
+        }) : nullptr));
         return m;
 }
 

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <random>
 #include <set>
 #include <thread>
@@ -34,11 +35,20 @@ int main(int argc, char **argv)
         std::atomic<unsigned> calls{0};
         std::mutex used_lock;
         std::set<int> used;
+        // worker start hook (the product binds the thread to the GPU's NUMA node there): must have run on the SAME thread, before its first encode
+        std::mutex started_lock;
+        std::map<int, std::thread::id> started;
+        std::atomic<unsigned> hook_errors{0};
         mi355x::frame_sharder sh(devices, [&](int device) -> mi355x::tile_encoder_t {
                 auto rng = std::make_shared<std::mt19937>(1234 + device);
                 auto first = std::make_shared<std::atomic<bool>>(true);
                 return [&, rng, first, device](int dev, unsigned tile, std::shared_ptr<video_frame> in) -> std::shared_ptr<video_frame> {
                         if (dev != device) abort();
+                        {
+                                std::lock_guard<std::mutex> lk(started_lock);
+                                auto it = started.find(dev);
+                                if (it == started.end() || it->second != std::this_thread::get_id()) hook_errors++;
+                        }
                         calls++;
                         { std::lock_guard<std::mutex> lk(used_lock); used.insert(dev); }
                         if (batch > 1 && first->exchange(false)) std::this_thread::sleep_for(std::chrono::milliseconds(30)); // lets the queues fill
@@ -66,6 +76,9 @@ int main(int argc, char **argv)
                         }
                         return out;
                 };
+        }, [&](int device) {
+                std::lock_guard<std::mutex> lk(started_lock);
+                if (!started.emplace(device, std::this_thread::get_id()).second) hook_errors++; // once per worker
         });
         std::vector<std::shared_ptr<video_frame>> got;
         std::thread consumer([&] {
@@ -109,6 +122,7 @@ int main(int argc, char **argv)
                 first = false;
         }
         if ((int) used.size() != workers && frames >= 50) { fprintf(stderr, "only %zu of %d workers used\n", used.size(), workers); rc = 1; }
+        if (hook_errors != 0 || (int) started.size() != workers) { fprintf(stderr, "worker start hook: %u errors, ran on %zu of %d workers\n", hook_errors.load(), started.size(), workers); rc = 1; }
         if (batch > 1 && batch_calls == 0) { fprintf(stderr, "no batch ever formed\n"); rc = 1; }
         printf("%s frames=%zu tile_encodes=%u workers_used=%zu batch_calls=%u batched_frames=%u\n", rc ? "FAIL" : "OK", got.size(), calls.load(), used.size(),
                batch_calls.load(), batched_frames.load());

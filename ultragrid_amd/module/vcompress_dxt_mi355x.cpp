@@ -84,7 +84,9 @@ struct state_video_compress_dxt_mi355x {
         void             *dev_pre = nullptr;        ///< swizzle result (only if pre_in != NONE)
         void             *dev_out = nullptr;        ///< DXT blocks
         size_t            in_len = 0, out_len = 0;
-        // the same buffers once per frame of a batch (batch=<n>): allocated on first use, 16 slices
+        // the same buffers once per frame of a batch: allocated on first use, batch_slices slices (= the module's batch=<n>, handed down by
+        // the sharder as batch_slices=<n>; 16 if a caller hands batches to a state directly)
+        int               batch_slices = 16;
         void             *b_in = nullptr, *b_pre = nullptr, *b_out = nullptr;
         size_t            b_in_stride = 0, b_pre_stride = 0, b_out_stride = 0;
         video_frame_pool  pool{0, hip_pinned_allocator()};
@@ -103,7 +105,8 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:ties=even|away]\n"
+               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>][:ties=even|away]\n"
+               "\t\tnuma  - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node, so that its pinned frame pool is local to the GPU; 0: left to the scheduler\n"
                "\t\tbatch - frames a busy worker may queue and encode in one launch (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
                "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n"
@@ -140,6 +143,9 @@ void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
                         if (devs.empty()) devs.push_back(0);
                         static std::atomic<unsigned> instance_counter{0}; // one init per tile: deal the instances out
                         s->device = devs[instance_counter++ % devs.size()];
+                } else if (strncasecmp(tok.c_str(), "batch_slices=", 13) == 0) { // internal: from mi355x::sharded_init
+                        s->batch_slices = atoi(tok.c_str() + 13);
+                        if (s->batch_slices < 1 || s->batch_slices > 16) s->batch_slices = 16;
                 } else if (strcasecmp(tok.c_str(), "ties=even") == 0) {
                         s->ties = UG_DXT_TIES_EVEN;
                 } else if (strcasecmp(tok.c_str(), "ties=away") == 0) {
@@ -282,7 +288,7 @@ std::vector<std::shared_ptr<video_frame>> dxt_mi355x_compress_batch(void *state,
                 for (size_t i = 0; i < in.size(); i++) out[i] = dxt_mi355x_compress_tile(state, std::move(in[i]));
                 return out;
         };
-        if (n < 2 || n > 16 || ug_hip_set_device(s->device) != UG_HIP_SUCCESS ||
+        if (n < 2 || n > s->batch_slices || ug_hip_set_device(s->device) != UG_HIP_SUCCESS ||
             !video_desc_eq_excl_param(video_desc_from_frame(in[0].get()), s->saved_desc, PARAM_TILE_COUNT)) {
                 return one_by_one(); // (the first frame of a new geometry configures the state on the way)
         }
@@ -291,10 +297,11 @@ std::vector<std::shared_ptr<video_frame>> dxt_mi355x_compress_batch(void *state,
                 auto round16 = [](size_t v) { return (v + 15) / 16 * 16; };
                 s->b_in_stride = round16(s->in_len + MAX_PADDING);
                 s->b_out_stride = round16(s->out_len);
-                bool ok = ug_hip_malloc(&s->b_in, s->b_in_stride * 16) == UG_HIP_SUCCESS && ug_hip_malloc(&s->b_out, s->b_out_stride * 16) == UG_HIP_SUCCESS;
+                bool ok = ug_hip_malloc(&s->b_in, s->b_in_stride * s->batch_slices) == UG_HIP_SUCCESS &&
+                          ug_hip_malloc(&s->b_out, s->b_out_stride * s->batch_slices) == UG_HIP_SUCCESS;
                 if (ok && s->pre_in != UG_PF_NONE) {
                         s->b_pre_stride = round16((size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->pre_out)) * h + MAX_PADDING);
-                        ok = ug_hip_malloc(&s->b_pre, s->b_pre_stride * 16) == UG_HIP_SUCCESS;
+                        ok = ug_hip_malloc(&s->b_pre, s->b_pre_stride * s->batch_slices) == UG_HIP_SUCCESS;
                 }
                 if (!ok) {
                         MSG(WARNING, "no device memory for the batch buffers (%s): frames are encoded one by one\n", ug_hip_last_error_string());
@@ -357,7 +364,7 @@ compress_module_info get_dxt_mi355x_module_info()
 void *dxt_mi355x_module_init(struct module *parent, const char *cfg)
 {
         return mi355x::sharded_init(parent, cfg, dxt_mi355x_compress_init, dxt_mi355x_compress_tile, dxt_mi355x_compress_done, ug_hip_set_device,
-                                    dxt_mi355x_compress_batch);
+                                    dxt_mi355x_compress_batch, ug_hip_bind_thread_to_device, ug_hip_device_numa_node);
 }
 
 const struct video_compress_info dxt_mi355x_info = {

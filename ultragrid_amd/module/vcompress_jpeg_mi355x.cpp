@@ -59,6 +59,7 @@ struct state_video_compress_jpeg_mi355x {
         size_t               in_len = 0, max_out = 0;
         // the same buffers once per frame of a batch (batch=<n>): grown on first use
         int                  batch_cap = 0;
+        int                  batch_slices = 16; // slices to allocate: the module's batch=<n>, handed down by the sharder as batch_slices=<n>
         size_t               b_in_stride = 0, b_target_stride = 0, b_enc_stride = 0, b_out_stride = 0;
         void                *b_in = nullptr, *b_target = nullptr, *b_enc = nullptr, *b_out = nullptr;
         video_frame_pool     pool{0, hip_pinned_allocator()};
@@ -76,7 +77,8 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y709][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>]\n"
+               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y709][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
+               "\t\tnuma        - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node (pinned frame pool local to the GPU); 0: left to the scheduler\n"
                "\t\tbatch       - frames a busy worker may queue and encode together (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
                "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
@@ -117,6 +119,9 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                         MSG(WARNING, "alpha is not coded by this encoder; the option is ignored\n"); // gpujpeg.cpp:409-414 warns likewise when unsupported
                 } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
                         s->device = atoi(tok.c_str() + 4);
+                } else if (strncasecmp(tok.c_str(), "batch_slices=", 13) == 0) { // internal: from mi355x::sharded_init
+                        s->batch_slices = atoi(tok.c_str() + 13);
+                        if (s->batch_slices < 1 || s->batch_slices > 16) s->batch_slices = 16;
                 } else if (tok == "help") {
                         usage();
                         delete s;
@@ -295,7 +300,7 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
                 for (size_t i = 0; i < in.size(); i++) out[i] = jpeg_mi355x_compress_tile(state, std::move(in[i]));
                 return out;
         };
-        if (n < 2 || n > 16 || ug_hip_set_device(s->device) != UG_HIP_SUCCESS) return one_by_one();
+        if (n < 2 || n > s->batch_slices || ug_hip_set_device(s->device) != UG_HIP_SUCCESS) return one_by_one();
         if (!video_desc_eq_excl_param(video_desc_from_frame(in[0].get()), s->saved_desc, PARAM_TILE_COUNT)) {
                 out[0] = jpeg_mi355x_compress_tile(state, in[0]); // (re)configures; the rest of this round follows one by one
                 for (size_t i = 1; i < in.size(); i++) out[i] = jpeg_mi355x_compress_tile(state, std::move(in[i]));
@@ -311,14 +316,15 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
                 s->b_target_stride = round16((size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->target == UG_PF_I420 ? UG_PF_UYVY : s->target)) * h + MAX_PADDING);
                 s->b_enc_stride = round16((size_t) vc_get_linesize(w, s->enc_in == UG_PF_RGB ? RGB : UYVY) * h + MAX_PADDING);
                 s->b_out_stride = round16(s->max_out);
-                bool ok = ug_hip_malloc(&s->b_in, s->b_in_stride * 16) == UG_HIP_SUCCESS && ug_hip_malloc(&s->b_out, s->b_out_stride * 16) == UG_HIP_SUCCESS;
-                if (ok && s->wire != s->target) ok = ug_hip_malloc(&s->b_target, s->b_target_stride * 16) == UG_HIP_SUCCESS;
-                if (ok && s->target != s->enc_in) ok = ug_hip_malloc(&s->b_enc, s->b_enc_stride * 16) == UG_HIP_SUCCESS;
+                const size_t slices = (size_t) s->batch_slices;
+                bool ok = ug_hip_malloc(&s->b_in, s->b_in_stride * slices) == UG_HIP_SUCCESS && ug_hip_malloc(&s->b_out, s->b_out_stride * slices) == UG_HIP_SUCCESS;
+                if (ok && s->wire != s->target) ok = ug_hip_malloc(&s->b_target, s->b_target_stride * slices) == UG_HIP_SUCCESS;
+                if (ok && s->target != s->enc_in) ok = ug_hip_malloc(&s->b_enc, s->b_enc_stride * slices) == UG_HIP_SUCCESS;
                 if (!ok) {
                         MSG(WARNING, "no device memory for the batch buffers (%s): frames are encoded one by one\n", ug_hip_last_error_string());
                         return one_by_one();
                 }
-                s->batch_cap = 16;
+                s->batch_cap = s->batch_slices;
         }
         // every frame into its slice: upload (or device-to-device), wire -> target -> encoder input with the pixfmt_conv.c arithmetic
         const char *enc_base = (const char *) s->b_in;
@@ -349,6 +355,10 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
                 return out;
         }
         for (int f = 0; f < n; f++) {
+                if (lens[f] > s->max_out) { // only this frame is lost, as on the one-frame path
+                        MSG(ERROR, "Encoding failed: stream of %zu bytes does not fit the output buffer\n", lens[f]);
+                        continue;
+                }
                 out[f] = s->pool.get_frame();
                 if (ug_hip_download_ordered(s->device, out[f]->tiles[0].data, (char *) s->b_out + f * s->b_out_stride, lens[f], s->stream) != UG_HIP_SUCCESS) {
                         out[f].reset();
@@ -391,7 +401,7 @@ compress_module_info get_jpeg_mi355x_module_info()
 void *jpeg_mi355x_module_init(struct module *parent, const char *cfg)
 {
         return mi355x::sharded_init(parent, cfg, jpeg_mi355x_compress_init, jpeg_mi355x_compress_tile, jpeg_mi355x_compress_done, ug_hip_set_device,
-                                    jpeg_mi355x_compress_batch);
+                                    jpeg_mi355x_compress_batch, ug_hip_bind_thread_to_device, ug_hip_device_numa_node);
 }
 
 const struct video_compress_info jpeg_mi355x_info = {

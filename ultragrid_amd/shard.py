@@ -9,6 +9,28 @@ import time
 from typing import Callable, Iterable, List, Sequence, Tuple
 
 
+def self_launch_command(gpus: int, environ, argv: Sequence[str], python: str, port: int | None = None) -> List[str] | None:
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (no WORLD_SIZE / RANK in the environment) must still run N ranks:
+    returns the command that re-executes `argv` (script + its arguments) as one rank per GPU under torch.distributed.run on this node, or
+    None when no re-launch is needed (N = 1, or the launcher's environment is already there -- then WORLD_SIZE must equal N, checked by
+    the caller).  One process per GPU is the reference's one-worker-per-device scheme (gpujpeg.cpp:446-466) at process granularity."""
+    if gpus <= 1:
+        return None
+    if "WORLD_SIZE" in environ or "RANK" in environ or "LOCAL_RANK" in environ:
+        return None
+    if port is None:
+        port = free_port()
+    return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), *argv]
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
 def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
     """Sequence numbers handled by `rank`: seq % world == rank (round-robin, gpujpeg.cpp:661-675)."""
     if not (0 <= rank < world):
