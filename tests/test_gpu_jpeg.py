@@ -369,6 +369,42 @@ def test_block_parallel_coder_equals_wave_per_segment_coder(hip, po, sub, monkey
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sub", [420, 422])
+@pytest.mark.parametrize("dims", [(640, 88), (1040, 81), (512, 64), (48, 16)])
+def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypatch):
+    """Round 4: for UYVY input whose restart segments stay inside the 32-MCU strips (32 % ri == 0, mcu_w % ri == 0) ONE kernel does the
+    forward DCT, the quantiser, the Huffman coding and the stream placement -- the coefficients never reach HBM.  Its stream must be the
+    stream of the front end + placing coder pair (UG_JPEG_FUSED=0) and of the front end + wave-per-segment coder + compaction triple
+    (UG_JPEG_WAVE_KERNEL=1): full strips and a short last one (640 = 40 MCUs, 1040 = 65), one strip only, a picture narrower than a strip,
+    picture heights that are no MCU multiple, low quality, and noise at q = 100 (blocks that overflow their private strings: the general
+    path, several passes)."""
+    import torch
+    w, h = dims
+    mcu_w = w // 16
+    src = synth.s2_video("UYVY", w, h)
+    noisy = synth.s1_random("UYVY", w, h, salt=9)
+    for q, frame in ((75, src), (100, noisy), (20, src), (92, noisy)):
+        dev = torch.from_numpy(frame).cuda()
+        for ri in (1, 2, 4, 8, 16, 32):
+            if mcu_w % ri:
+                continue
+            out = {}
+            for tag, env in (("fused", {}), ("two", {"UG_JPEG_FUSED": "0"}), ("wave", {"UG_JPEG_WAVE_KERNEL": "1"})):
+                monkeypatch.delenv("UG_JPEG_FUSED", raising=False)
+                monkeypatch.delenv("UG_JPEG_WAVE_KERNEL", raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                e = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+                out[tag] = e.encode(dev)
+                out[tag + "2"] = e.encode(dev)     # the same object again: the status words of the call before must not be taken for this call's
+                e.close()
+            assert out["fused"] == out["wave"], (sub, dims, q, ri, len(out["fused"]), len(out["wave"]))
+            assert out["two"] == out["wave"] and out["fused2"] == out["wave"] and out["two2"] == out["wave"], (sub, dims, q, ri)
+    monkeypatch.delenv("UG_JPEG_FUSED", raising=False)
+    monkeypatch.delenv("UG_JPEG_WAVE_KERNEL", raising=False)
+
+
+@pytest.mark.gpu
 def test_block_parallel_coder_full_4k_frame(hip, po):
     """configs[3] size: a whole 3840x2160 frame (8100 segments at restart 4), both coders, identical streams, decodable."""
     import io

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sub", type=int, default=420)
 ap.add_argument("--n", type=int, default=8)
 ap.add_argument("--seconds", type=float, default=1.0)
+ap.add_argument("--only", choices=["both", "batch", "single"], default="both", help="profile runs: one call form only, so that per-kernel averages are not a blend")
+ap.add_argument("--calls", type=int, default=0, help="exactly this many timed calls per leg instead of --seconds (counter passes)")
 a = ap.parse_args()
 l = L.load()
 w, h = 3840, 2160
@@ -43,12 +45,17 @@ def batch():
     assert l.ug_hip_jpeg_encoder_encode_batch(enc, L.PF_UYVY, a.n, src[k % sets].data_ptr(), 0, src.shape[2], out.data_ptr(), stride, stride, lens, st) == 0, L.last_error()
 
 
-for name, fn in (("one frame per call", single), (f"{a.n} frames per call", batch), ("one frame per call", single), (f"{a.n} frames per call", batch)):
-    for _ in range(5):
+legs = (("one frame per call", single), (f"{a.n} frames per call", batch), ("one frame per call", single), (f"{a.n} frames per call", batch))
+if a.only == "batch":
+    legs = legs[1::2]
+elif a.only == "single":
+    legs = legs[0::2]
+for name, fn in legs:
+    for _ in range(2 if a.calls else 5):
         fn()
     torch.cuda.synchronize()
     n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < a.seconds:
+    while (n < a.calls) if a.calls else (time.perf_counter() - t0 < a.seconds):
         fn()
         n += 1
     dt = time.perf_counter() - t0

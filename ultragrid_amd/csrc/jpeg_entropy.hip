@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ug_common.h"
+#include "jpeg_fdct_device.h"
 
 namespace {
 
@@ -222,21 +223,6 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Block-parallel Huffman coding (the default when a restart segment has at most 64 blocks, i.e. restart interval <= 10 MCUs for
-// 4:2:0, <= 16 for 4:2:2, <= 21 for 4:4:4): one LANE PER BLOCK, a wave = the G = 64 / S whole segments that fit its lanes
-// (S = blocks per segment).  The wave-per-segment kernel above spends ~230 wave instructions per block on one block at a time;
-// here 64 blocks share every instruction:
-//   1. each lane loads its block (64 int16 = 8 x 16 B, zig-zag order as the FDCT kernels write them) into 32 registers;
-//      the DC predictor comes from the lane that holds the previous block of the same component (ds_bpermute);
-//   2. length walk: a fully unrolled pass over the 63 AC coefficients (static register indices) adds up the block's code
-//      length -- groups of 8 coefficients that are zero in all 64 blocks are skipped with one scalar branch;
-//   3. a wave prefix sum, made segment-relative, gives every block its bit position in its segment;
-//   4. emission walk: the same pass again, appending code + value bits to a 64-bit accumulator whose full words are OR-ed
-//      (ds_or_b32) into the segment's window in LDS;
-//   5. the windows are padded with 1-bits to a byte, flushed byte-swapped with coalesced stores, 0xFF bytes counted.
-// Output (unstuffed scan bytes per segment, seg_len, seg_ff) is exactly what the wave-per-segment kernel produces.
-// ---------------------------------------------------------------------------------------------------------------
 // LDS window of the block-parallel coder: 64 bytes per block on average (a 4K q75 frame needs ~10); a wave whose segments
 // need more goes through its window in several passes
 constexpr int kWinWordsPerBlock = 16;
@@ -343,48 +329,243 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
         return nbits;
 }
 
-// WAVES = waves per workgroup: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES that
-// leaves the fewest lanes idle: S = 24 blocks -- restart 4, 4:2:0 -- fills 3 waves exactly where one wave would run 48 of 64 lanes).
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
-                                                                   const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs, int ctab, int ri,
-                                                                   int n_seg, int S /* blocks per full segment, <= 64 * WAVES */, int G /* segments per workgroup */,
-                                                                   uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
-                                                                   uint32_t *__restrict__ seg_ff, uint32_t *__restrict__ chunk_tot, BatchStride bs)
+// ---------------------------------------------------------------------------------------------------------------
+// Block-parallel Huffman coding WITH stream placement (round 4; the default whenever a restart segment has at most 256 blocks).
+// One LANE PER BLOCK, a workgroup = the whole segments that fit its lanes; the workgroup finishes its part of the JPEG stream
+// itself -- byte stuffing, RSTm markers, final position -- so that the scan data is written once, where it belongs:
+//   1. every lane gets its block as 32 registers (64 int16, zig-zag order): from the coefficient arrays in HBM (SRC = 0: 8 lanes
+//      share a 128-byte line, rows handed to their owners through LDS) or, fused (SRC = 420 / 422), from the workgroup's own
+//      forward DCT + quantiser of a strip of 32 MCUs of the UYVY frame -- the coefficients then never exist in HBM;
+//   2. the DC predictor comes from the lane that holds the previous block of the same component;
+//   3. ONE walk over the 63 AC coefficients (static register indices; groups of 8 that are zero in all 64 blocks of the wave cost
+//      one scalar branch; a group in which some block needs ZRL symbols takes the variant that can emit them) appends code + value
+//      bits to a 64-bit accumulator whose words go to the lane's PRIVATE string in LDS (bit 0 = the block's first bit) and adds up
+//      the length -- rounds 2-3 walked twice, a length pass and an emission pass;
+//   4. a prefix sum of the lengths, made segment-relative, gives every block its bit position; every lane shifts its private
+//      string there and ORs it into the segment's window (ds_or_b32);
+//   5. the windows are padded with 1-bits to a byte, 0xFF bytes counted: final segment sizes; a decoupled look-back over the
+//      workgroups of the frame (one 64-bit status word per workgroup: generation of the call | aggregate / inclusive prefix |
+//      bytes) gives the workgroup its position in the stream without a second launch;
+//   6. the waves write their segments there, inserting 0x00 after every 0xFF (T.81 B.1.1.5) and appending RSTm / EOI; the last
+//      segment's wave reports the stream length to pinned host memory, workgroup 0 lays down the header.
+// A block whose code exceeds its 512-bit private string (near-lossless quality on noise) sends its workgroup down the general path:
+// emission straight into the windows at the known bit positions (BitSink), in several passes when a segment exceeds its window,
+// counted first and emitted again for the write-out.  The stream is byte-identical to the wave-per-segment coder + compaction.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPrivWords = 16;         // private string of a block: 512 bits (a 4K q75 frame needs ~80)
+constexpr int kPrivStride = 17;        // + one dump word for what does not fit; odd stride: the lanes' rows start in different banks
+
+// the lane's private bit string: 64-bit accumulator, left-aligned; completed words are stored at row[idx]
+struct PrivSink {
+        uint32_t hi, lo, fill; // fill < 32 between appends
+        uint32_t *row;
+        uint32_t idx;
+        __device__ __forceinline__ void append(uint32_t str, uint32_t n) // n <= 27 bits; n == 0 (with str == 0) appends nothing
+        {
+                const uint32_t t = fill + n;
+                const unsigned long long sh = (unsigned long long) str << ((64u - t) & 63u);
+                hi |= (uint32_t) (sh >> 32);
+                lo |= (uint32_t) sh;
+                const uint32_t fl = t >> 5, m = 0u - fl; // fl = 1: the top word is complete
+                row[min(idx, (uint32_t) kPrivWords)] = hi; // (a partial word is simply stored again later)
+                hi = (lo & m) | (hi & ~m);
+                lo &= ~m;
+                fill = t & 31u;
+                idx += fl;
+        }
+        __device__ __forceinline__ void finish() { row[min(idx, (uint32_t) kPrivWords)] = hi; }
+};
+
+// The AC part of every lane's block: appended to `sink`, length returned (EOB included).  Groups of kWalkGroup coefficients that are zero in
+// all 64 blocks of the wave cost one scalar branch; inside a group the table look-ups depend only on the short `run` chain.  The rare
+// coefficient behind a zero run longer than 15 is met by a wave-uniform branch at its position: 1..3 ZRL symbols go in front of it.
+__device__ __forceinline__ uint32_t walk_private(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, PrivSink &sink)
+{
+        const uint32_t zl = zrl >> 16, zc = zrl & 0xffffu;
+        uint32_t run = 0, nbits = 0;
+#pragma unroll
+        for (int g = 0; g < 64 / kWalkGroup; g++) {
+                uint32_t any = g == 0 ? w[0] & 0xffff0000u : w[kWalkGroup / 2 * g]; // the DC value is not an AC coefficient
+#pragma unroll
+                for (int i = 1; i < kWalkGroup / 2; i++) any |= w[kWalkGroup / 2 * g + i];
+                if (__ballot(any != 0) == 0) { // wave-uniform: nobody has a coefficient in this group
+                        run += g == 0 ? kWalkGroup - 1 : kWalkGroup;
+                        continue;
+                }
+#pragma unroll
+                for (int k = g == 0 ? 1 : kWalkGroup * g; k < kWalkGroup * (g + 1); k++) {
+                        const int v = coef_at(w, k);
+                        const uint32_t neg = (uint32_t) (v >> 31);
+                        const uint32_t a = ((uint32_t) v ^ neg) - neg;
+                        const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
+                        const uint32_t e = tab[((run & 15u) << 4) | size];    // EOB / ZRL entries are zero: a zero coefficient appends nothing
+                        const uint32_t n = (e >> 16) + size;
+                        if (k > 16 && __ballot(size != 0 && run > 15u) != 0) { // (a run of 16 zeros ends at position 17 at the earliest)
+                                const uint32_t zr = size ? run >> 4 : 0u; // one ZRL, then the other two together (<= 22 bits)
+                                sink.append(zr ? zc : 0u, zr ? zl : 0u);
+                                const uint32_t two = zr > 2u ? (zc << zl) | zc : zc;
+                                sink.append(zr > 1u ? two : 0u, zr > 1u ? (zr - 1u) * zl : 0u);
+                                nbits += zr * zl;
+                        }
+                        const uint32_t vb = ((uint32_t) v + neg) & ((1u << size) - 1u); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
+                        sink.append(((e & 0xffffu) << size) | vb, n);
+                        nbits += n;
+                        run = size ? 0u : run + 1u;
+                }
+        }
+        sink.append(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u); // EOB after the last non-zero coefficient (not when position 63 is coded)
+        nbits += run ? eob >> 16 : 0u;
+        return nbits;
+}
+
+__device__ __forceinline__ int count_ff_valid(uint32_t word, int valid) // 0xFF bytes among the first `valid` (stream order) bytes of a window word
+{
+        int c = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) c += (t < valid && ((word >> (24 - 8 * t)) & 0xffu) == 0xffu) ? 1 : 0;
+        return c;
+}
+
+// ---- position of a workgroup's bytes in the stream: decoupled look-back over the workgroups of the frame ----
+// status word = generation of the call << 34 | state << 32 | bytes ; state 1: the workgroup's own byte count, 2: the count of all
+// workgroups up to and including it.  Words of other generations (earlier calls, other batch sizes) read as "not there yet", so the
+// array is never cleared between calls.  Workgroups are dispatched in index order, so the predecessors a workgroup waits for are
+// running or done.  Device-scope atomic loads / stores: the word carries its own data, no other memory has to be ordered with it.
+constexpr unsigned long long status_word(uint32_t gen, uint32_t state, uint32_t bytes) { return ((unsigned long long) gen << 34) | ((unsigned long long) state << 32) | bytes; }
+
+// A wait that has not ended after kSpinLimit polls (~0.1 s; the whole kernel takes tens of microseconds) is given up and reported through *stuck
+// (the host fails the call): a defect must not be able to hang the GPU.
+constexpr int kSpinLimit = 1 << 19;
+__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *status, int wg, uint32_t aggregate, uint32_t gen, int lane, uint32_t *stuck) // one wave
+{
+        if (wg == 0) {
+                if (lane == 0) __hip_atomic_store(&status[0], status_word(gen, 2, aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0;
+        }
+        if (lane == 0) __hip_atomic_store(&status[wg], status_word(gen, 1, aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        for (int pos = wg - 1;; pos -= 64) { // 64 predecessors at a time, lane 0 = the nearest
+                const int idx = pos - lane;
+                unsigned long long s;
+                for (int polls = 0;; polls++) {
+                        s = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : status_word(gen, 2, 0);
+                        const bool there = (uint32_t) (s >> 34) == gen && ((uint32_t) (s >> 32) & 3u) != 0;
+                        if (__all(there)) break;
+                        if (polls == kSpinLimit) {
+                                if (lane == 0) *stuck = 1u;
+                                if (!there) s = status_word(gen, 2, 0);
+                                break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                }
+                const unsigned long long full = __ballot(((uint32_t) (s >> 32) & 3u) == 2u);
+                const int last = full ? __builtin_ctzll(full) : 63; // the nearest predecessor that knows its inclusive prefix ends the walk
+                const int v = lane <= last ? (int) (uint32_t) s : 0;
+                excl += (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan(v, lane), 63);
+                if (full) break;
+        }
+        if (lane == 0) __hip_atomic_store(&status[wg], status_word(gen, 2, excl + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return excl;
+}
+
+struct CodeArgs {
+        // scan geometry
+        int mcu_w, n_mcu, hs, vs, ctab, ri, n_seg, S /* blocks per full segment */, G /* segments per workgroup (SRC = 0) */, n_wg /* workgroups per frame */;
+        // SRC = 0: quantised blocks in HBM, per-frame strides in int16 elements
+        const int16_t *cy, *cb, *cr;
+        long coef_y, coef_c;
+        // SRC = 420 / 422: the UYVY frame(s) and the quantiser (luma 64 divisors, chroma 64)
+        const uint8_t *src;
+        int pitch, height, strips /* strips of 32 MCUs per MCU row */;
+        size_t src_stride;
+        // the stream(s)
+        uint8_t *out;
+        size_t out_stride, capacity;
+        const uint8_t *header;
+        int header_len;
+        uint32_t *total_pinned;         // pinned host memory mapped into the device: the lengths need no copy back; word kMaxBatch = "a wait was given up"
+        unsigned long long *status;     // n_status words per frame
+        long n_status;
+        uint32_t gen;
+        uint32_t *ticket;               // workgroups take their index from here, in the order they start (0 before and after every launch)
+};
+
+// WAVES = waves per workgroup.  SRC = 0: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES
+// that leaves the fewest lanes idle).  SRC = 420 (WAVES = 3) / 422 (WAVES = 2): a workgroup = one strip of 32 MCUs of an MCU row = 32 / ri
+// segments; needs 32 % ri == 0 and mcu_w % ri == 0 (no segment leaves its strip) and a 16-byte aligned frame of width % 16 == 0.
+template <int WAVES, int SRC>
+__global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
 {
         constexpr int W = 64 * WAVES;
-        cy += blockIdx.y * bs.coef_y; cb += blockIdx.y * bs.coef_c; cr += blockIdx.y * bs.coef_c;
-        raw += blockIdx.y * bs.raw_words; seg_len += blockIdx.y * bs.seg; seg_ff += blockIdx.y * bs.seg; chunk_tot += blockIdx.y * bs.tot_words;
+        // The look-back below waits for workgroups with smaller indices.  Index = blockIdx: the dispatcher starts the workgroups of a grid in
+        // index order (per XCD, which is all the argument needs: the lowest unfinished index is always running or next in line for a slot that
+        // only lower indices hold).  Should a wait ever be given up (kSpinLimit), the encoder switches to a.ticket != nullptr for good: the index
+        // is then a ticket drawn when the workgroup STARTS, so that every index it waits for belongs to a workgroup that is already running whatever
+        // the start order (one atomic round trip, ~2 us, at the head of every workgroup: measured 8 % of the kernel).  The workgroup that draws
+        // the last ticket puts the counter back to 0 for the next launch.
+        __shared__ uint32_t lds_ticket;
+        uint32_t index = blockIdx.x;
+        if (a.ticket != nullptr) { // wave-uniform
+                if (threadIdx.x == 0) {
+                        const uint32_t t = atomicAdd(a.ticket, 1u);
+                        if (t == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lds_ticket = t;
+                }
+                __syncthreads();
+                index = lds_ticket;
+        }
+        const int frame = (int) (index / (uint32_t) a.n_wg), wg = (int) (index - (uint32_t) frame * (uint32_t) a.n_wg);
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
-        // one buffer, two lives: first the staging area of the block loads (per wave 32 rows of 8 x 16 B, 144 B apart so that the
-        // row-wise reads are conflict-free), then the bit windows of the segments (+ one spare word per lane for the multi-pass variant)
+        // one buffer, three lives: the block hand-over (SRC = 0: per wave 32 rows of 8 x 16 B, 144 B apart; fused: the workgroup's blocks, 144 B
+        // apart), then [0, 17 W) the private strings and [17 W, 34 W) the segments' windows (16 words per block + one spare word per lane)
         constexpr int kStageRow = 9; // uint4 per row
-        constexpr int kStageWords = 32 * kStageRow * 4; // per wave
-        __shared__ __attribute__((aligned(16))) uint32_t shared_words[WAVES * kStageWords];
-        static_assert(kStageWords >= 64 * kWinWordsPerBlock + 64, "window must fit the staging buffer");
-        __shared__ int lds_dc[W], lds_excl[W], lds_incl[W], lds_wave_total[WAVES], lds_seg_bits[W], lds_flag[2];
-        uint32_t *const win = shared_words;
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        constexpr int kStageWords = 32 * kStageRow * 4; // per wave (SRC = 0)
+        constexpr int kBufWords = SRC == 0 ? 2 * kPrivStride * W : (ug_jpeg::kLdsPitch / 4) * W;
+        static_assert(kBufWords >= 2 * kPrivStride * W && kBufWords >= WAVES * kStageWords, "the three lives must fit");
+        __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
+        constexpr int kMaxSeg = W / 3 + 1; // segments per workgroup: a segment has at least 3 blocks (4:4:4, restart interval 1)
+        __shared__ int lds_dc[W] /* DC values, then the inclusive bit positions */, lds_wave_total[WAVES], lds_seg_bits[kMaxSeg], lds_flag[2];
+        __shared__ uint32_t lds_seg_ff[kMaxSeg], lds_seg_off[kMaxSeg], lds_seg_done[kMaxSeg], lds_base;
+        int *const lds_incl = lds_dc;
+        uint32_t *const priv = buf;
+        uint32_t *const win = buf + kPrivStride * W;
+        const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: say so, or the waves' branches compile as divergent ones)
         for (int i = tid; i < 512; i += W) {
                 const int sym = i & 255;
                 ac_tab[i >> 8][sym] = (sym == 0x00 || sym == 0xF0) ? 0u : kAcTab[i >> 8][sym]; // EOB / ZRL are emitted explicitly
         }
         if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
         if (tid < 2) lds_flag[tid] = 0;
-        const int ybl = hs * vs, per_mcu = ybl + 2;
-        const int sl = tid / S, j = tid - sl * S;                // segment of the workgroup, block of the segment
-        const int seg = blockIdx.x * G + sl;
-        const int m_first = seg * ri;
-        const int n_blk = (sl < G && seg < n_seg) ? per_mcu * (min(n_mcu, m_first + ri) - m_first) : 0;
+        if (tid < kMaxSeg) {
+                lds_seg_ff[tid] = 0;
+                lds_seg_done[tid] = 0;
+        }
+        const int ybl = a.hs * a.vs, per_mcu = ybl + 2, S = a.S, ri = a.ri;
+        // ---- which segments, which block ----
+        int seg0, nseg_wg, strip_mcu0 = 0, strip_my = 0, strip_mcus = 0;
+        if (SRC == 0) {
+                seg0 = wg * a.G;
+                nseg_wg = min(a.G, a.n_seg - seg0);
+        } else {
+                strip_my = wg / a.strips;
+                strip_mcu0 = 32 * (wg - strip_my * a.strips);
+                strip_mcus = min(32, a.mcu_w - strip_mcu0);
+                seg0 = (strip_my * a.mcu_w + strip_mcu0) / ri;
+                nseg_wg = strip_mcus / ri;
+        }
+        const int sl = tid / S, j = tid - sl * S;               // segment of the workgroup, block of the segment
+        const int m_first = (seg0 + sl) * ri;
+        const int n_blk = sl < nseg_wg ? per_mcu * (min(a.n_mcu, m_first + ri) - m_first) : 0;
         const bool active = j < n_blk;
         const int ml = j / per_mcu, b = j - ml * per_mcu;        // MCU of the segment, block of the MCU
-        const int m = m_first + ml;
-        const int comp = b < ybl ? 0 : ctab;
+        const int comp = b < ybl ? 0 : a.ctab;
         uint32_t w[32];
-        {
-                const int my = m / mcu_w, mx = m - my * mcu_w;
-                const int yrow = vs * my + (hs == 2 ? b >> 1 : 0), ycol = hs * mx + (hs == 2 ? b & 1 : 0);
-                const int16_t *p = b < ybl ? cy + 64 * ((long) yrow * (hs * mcu_w) + ycol) : (b == ybl ? cb : cr) + 64L * m;
+        if (SRC == 0) {
+                const int16_t *const cy = a.cy + frame * a.coef_y, *const cb = a.cb + frame * a.coef_c, *const cr = a.cr + frame * a.coef_c;
+                const int m = m_first + ml;
+                const int my = m / a.mcu_w, mx = m - my * a.mcu_w;
+                const int yrow = a.vs * my + (a.hs == 2 ? b >> 1 : 0), ycol = a.hs * mx + (a.hs == 2 ? b & 1 : 0);
+                const int16_t *p = b < ybl ? cy + 64 * ((long) yrow * (a.hs * a.mcu_w) + ycol) : (b == ybl ? cb : cr) + 64L * m;
                 if (!active) p = cy;
                 // A block is one 128-byte line.  If every lane fetched its own block 16 bytes at a time, each of the 8 load
                 // instructions of the wave would touch 64 different lines and use an eighth of each: 8x the traffic between L2 and
@@ -392,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t
                 // block -- an instruction fetches 8 whole lines -- and the rows are handed to their owners through LDS.
                 const long off = (const char *) p - (const char *) cy;
                 const int off_lo = (int) off, off_hi = (int) (off >> 32);
-                uint4 *const stage = (uint4 *) (shared_words + wv * kStageWords);
+                uint4 *const stage = (uint4 *) (buf + wv * kStageWords);
                 // two halves of 32 blocks, so that the staging rows take 4.5 KB per wave instead of 9
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
@@ -419,12 +600,97 @@ __global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                 }
+        } else {
+                // ---- fused front end: the arithmetic of uyvy_jpeg_fast_kernel (jpeg_fdct.hip), lane = block in FRAME order: the luma waves take
+                // one luma block row of the strip each (64 blocks), the last wave 32 Cb blocks (lanes 0-31) + 32 Cr blocks (lanes 32-63) ----
+                constexpr int kLumaWaves = SRC == 420 ? 2 : 1;
+                const uint8_t *const src = a.src + (size_t) frame * a.src_stride;
+                const int height = a.height, pitch = a.pitch;
+                {
+                        float q[64];
+                        bool valid; // lanes past the end of a short last strip hold no block
+                        if (wv < kLumaWaves) {
+                                const int bx = 2 * strip_mcu0 + lane;      // luma block column
+                                const int brow = kLumaWaves * strip_my + wv; // luma block row
+                                valid = lane < 2 * strip_mcus;
+                                if (valid) {
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+                                                const int y = min(8 * brow + r, height - 1);
+                                                const uint4 v4 = *(const uint4 *) (src + (long) y * pitch + 16 * bx);
+                                                const uint32_t ww[4] = { v4.x, v4.y, v4.z, v4.w };
+#pragma unroll
+                                                for (int k = 0; k < 4; k++) {
+                                                        q[8 * r + 2 * k] = (float) ((int) ((ww[k] >> 8) & 0xff) - 128);
+                                                        q[8 * r + 2 * k + 1] = (float) ((int) (ww[k] >> 24) - 128);
+                                                }
+                                        }
+                                        ug_jpeg::fdct8x8(q);
+                                        ug_jpeg::quant_pack(q, div, w);
+                                }
+                        } else {
+                                const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU within the strip
+                                valid = m < strip_mcus;
+                                if (valid) {
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+                                                int y0, y1;
+                                                if (SRC == 420) {
+                                                        const int cy2 = min(8 * strip_my + r, (height + 1) / 2 - 1); // edge replication on the chroma plane
+                                                        y0 = 2 * cy2; y1 = min(2 * cy2 + 1, height - 1);             // odd height: last line doubled
+                                                } else {
+                                                        y0 = y1 = min(8 * strip_my + r, height - 1);
+                                                }
+                                                const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * (strip_mcu0 + m));
+                                                const uint4 a0 = p0[0], a1 = p0[1];
+                                                const uint32_t wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                                                if (SRC == 420) {
+                                                        const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * (strip_mcu0 + m));
+                                                        const uint4 c0 = p1[0], c1 = p1[1];
+                                                        const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+#pragma unroll
+                                                        for (int x = 0; x < 8; x++) { // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367)
+                                                                const int sa = c ? (wa[x] >> 16) & 0xff : wa[x] & 0xff;
+                                                                const int sb = c ? (wc[x] >> 16) & 0xff : wc[x] & 0xff;
+                                                                q[8 * r + x] = (float) (((sa + sb + 1) >> 1) - 128);
+                                                        }
+                                                } else {
+#pragma unroll
+                                                        for (int x = 0; x < 8; x++) { // uyvy_to_i422 (video_codec.c:949-969): samples as they are
+                                                                const int sa = c ? (wa[x] >> 16) & 0xff : wa[x] & 0xff;
+                                                                q[8 * r + x] = (float) (sa - 128);
+                                                        }
+                                                }
+                                        }
+                                        ug_jpeg::fdct8x8(q);
+                                        ug_jpeg::quant_pack(q, div + 64, w);
+                                }
+                        }
+                        if (!valid) {
+#pragma unroll
+                                for (int i = 0; i < 32; i++) w[i] = 0;
+                        }
+                }
+                // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU)
+                uint4 *const store = (uint4 *) buf;
+                constexpr int kRow = ug_jpeg::kLdsPitch / 16;
+#pragma unroll
+                for (int i = 0; i < 8; i++) store[tid * kRow + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+                __syncthreads();
+                const int m = sl * ri + ml; // MCU of the strip
+                const int id = b < ybl ? (SRC == 420 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                        uint4 r = store[(active ? id : 0) * kRow + i];
+                        if (!active) r = make_uint4(0, 0, 0, 0);
+                        w[4 * i] = r.x; w[4 * i + 1] = r.y; w[4 * i + 2] = r.z; w[4 * i + 3] = r.w;
+                }
         }
         // DC difference: the previous block of the same component sits `back` lanes below (luma: the previous luma block of the
         // scan -- one lane back, or across the two chroma blocks of the previous MCU; chroma: one MCU back); none at a segment start
         const int dc = coef_at(w, 0);
         lds_dc[tid] = dc;
-        __syncthreads(); // tables, DC values; the staging rows have been read
+        __syncthreads(); // tables, DC values; the hand-over buffer has been read
         const int back = b < ybl ? (b > 0 ? 1 : 3) : per_mcu;
         const bool has_pred = b < ybl ? j > 0 : ml > 0;
         const int diff = dc - (has_pred ? lds_dc[max(tid - back, 0)] : 0);
@@ -433,14 +699,24 @@ __global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t
         const uint32_t de = dc_tab[comp][dsize];
         const uint32_t zrl = kAcTab[comp][0xF0], eob = kAcTab[comp][0x00];
         const uint32_t *const tab = ac_tab[comp];
-        // ---- length walk ----
-        bool zrl_seen = false;
-        uint32_t nbits;
+        const uint32_t dc_vb = ((uint32_t) diff + dneg) & ((1u << dsize) - 1u);
+        const uint32_t dc_str = active ? ((de & 0xffffu) << dsize) | dc_vb : 0u, dc_n = active ? (de >> 16) + dsize : 0u;
+        // the windows start out zero (this lane's 16 words; the hand-over buffer they overlay has been read: the barrier above)
         {
-                BitSink<false> none = {};
-                nbits = (de >> 16) + dsize + walk_block<false, false>(w, tab, zrl, eob, none, zrl_seen);
+                uint4 *const z = (uint4 *) (win + tid * kWinWordsPerBlock);
+#pragma unroll
+                for (int i = 0; i < kWinWordsPerBlock / 4; i++) z[i] = make_uint4(0, 0, 0, 0);
         }
-        if (!active) nbits = 0;
+        // ---- the walk: code into the private string, length as a by-product ----
+        uint32_t *const row = priv + tid * kPrivStride;
+        uint32_t nbits = 0;
+        if (active) { // idle lanes stay out of the walk
+                PrivSink sink = { 0, 0, 0, row, 0 };
+                sink.append(dc_str, dc_n);
+                nbits = dc_n + walk_private(w, tab, zrl, eob, sink);
+                sink.finish();
+                if (nbits > 32u * kPrivWords) lds_flag[0] = 1; // does not fit its private string: the general path for this workgroup
+        }
         // ---- bit position of every block inside its segment: prefix sum over the workgroup, made segment-relative ----
         const int incl_w = wave_inclusive_scan((int) nbits, lane);
         if (lane == 63) lds_wave_total[wv] = incl_w;
@@ -449,123 +725,191 @@ __global__ __launch_bounds__(64 * WAVES) void entropy_block_kernel(const int16_t
 #pragma unroll
         for (int k = 0; k < WAVES; k++) wave_base += k < wv ? lds_wave_total[k] : 0;
         const int incl = wave_base + incl_w, excl = incl - (int) nbits;
-        lds_excl[tid] = excl;
-        lds_incl[tid] = incl;
+        lds_incl[tid] = incl; // (the DC values have been read: two barriers ago)
         __syncthreads();
         const int first_tid = min(sl * S, W - 1);
-        const int seg_base = lds_excl[first_tid];
-        const int seg_bits = sl < G ? lds_incl[min(first_tid + max(n_blk, 1) - 1, W - 1)] - seg_base : 0; // total bits of this lane's segment
-        if (j == 0 && sl < G) lds_seg_bits[sl] = seg_bits;
+        const int seg_base = first_tid ? lds_incl[first_tid - 1] : 0;
+        const int seg_bits = sl < nseg_wg ? lds_incl[min(first_tid + max(n_blk, 1) - 1, W - 1)] - seg_base : 0; // total bits of this lane's segment
+        if (j == 0 && sl < nseg_wg) lds_seg_bits[sl] = seg_bits;
         uint32_t *const mywin = win + first_tid * kWinWordsPerBlock; // the segment's window: kWinWordsPerBlock words per block of the segment
-        uint32_t *const spare = win + W * kWinWordsPerBlock;
         const int cap = S * kWinWordsPerBlock;                  // words of a segment's window
         const int seg_words = (seg_bits + 31) >> 5;
         const int p0 = excl - seg_base;                          // bit position of this lane's block in its segment
-        const uint32_t dc_vb = ((uint32_t) diff + dneg) & ((1u << dsize) - 1u);
-        const uint32_t dc_str = active ? ((de & 0xffffu) << dsize) | dc_vb : 0u, dc_n = active ? (de >> 16) + dsize : 0u;
-        // some segment of the workgroup longer than its window (rare)?  then everybody goes through the windows in `passes` passes
-        if (seg_words > cap) atomicMax(&lds_flag[0], seg_words);
-        __syncthreads();
-        const int longest = lds_flag[0]; // 0: everything fits
-        const bool multi = longest != 0;
-        const int passes = multi ? (longest + cap - 1) / cap : 1;
-        const bool any_zrl = __any(zrl_seen);
+        const bool general = lds_flag[0] != 0;
+        if (general && seg_words > cap) atomicMax(&lds_flag[1], seg_words);
         // zero the words the segment uses in a pass (+ one for the padding), cooperatively: lane j takes words j, j + S, ...
         auto zero_window = [&](int lo_idx) {
-                if (sl < G) {
+                if (sl < nseg_wg) {
                         const int nw = min(cap, seg_words + 1 - lo_idx);
                         for (int i = j; i < nw; i += S) mywin[i] = 0;
                 }
                 __syncthreads();
         };
-        // pad, flush, count: the segments of the workgroup are dealt to its waves, 64 words at a time
-        auto flush_window = [&](int pass, int lo_idx) {
-                __syncthreads();
-#pragma unroll 1
-                for (int s2 = wv; s2 < G; s2 += WAVES) {
-                        const int sg = blockIdx.x * G + s2;
-                        if (sg >= n_seg) break;
-                        const int bits = lds_seg_bits[s2];
-                        uint32_t *const sw = win + s2 * S * kWinWordsPerBlock;
-                        const int nbytes = (bits + 7) >> 3;
-                        const int padw = (bits >> 5) - lo_idx; // window word that holds the last, partial byte
-                        if (lane == 0 && (bits & 7) && padw >= 0 && padw < cap) { // pad it with 1-bits (T.81 F.1.2.3)
-                                const int pad = 8 - (bits & 7);
-                                sw[padw] |= ((1u << pad) - 1u) << (32 - (bits & 31) - pad);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        uint32_t *const out = raw + (size_t) sg * cap_words;
-                        const int nw = min(cap, ((nbytes + 3) >> 2) - lo_idx); // words of the segment in this pass
-                        int ff = 0;
-                        for (int i = lane; i < nw; i += 64) {
-                                const uint32_t word = sw[i];
-                                out[lo_idx + i] = __builtin_bswap32(word); // stream order in memory
-                                const int valid = min(4, nbytes - 4 * (lo_idx + i)); // bytes of this word that belong to the segment
-                                for (int t = 0; t < valid; t++) ff += ((word >> (24 - 8 * t)) & 0xff) == 0xff;
-                        }
-                        const int ff_all = __builtin_amdgcn_readlane(wave_inclusive_scan(ff, lane), 63);
-                        if (lane == 0) {
-                                uint32_t prev = 0;
-                                if (pass > 0) prev = seg_ff[sg];
-                                const uint32_t more = (uint32_t) ff_all + (pass == 0 ? (uint32_t) nbytes + 2u : 0u); // stuffed size + marker
-                                seg_ff[sg] = prev + more;
-                                atomicAdd(&chunk_tot[(sg / kChunk) * kChunkStride], more);
-                                if (pass == 0) seg_len[sg] = (uint32_t) nbytes;
-                        }
+        // the general path's emission of one pass: straight into the windows, which show words [lo_idx, lo_idx + cap) of every segment
+        auto emit_general = [&](int lo_idx) {
+                // everything the walk derives from the coefficients is invariant over the passes; left alone, the compiler
+                // hoists all of it out of the pass loops (4 values x 63 coefficients: 237 VGPRs for a path that almost never runs)
+#pragma unroll
+                for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
+                zero_window(lo_idx);
+                if (active) { // words outside this pass's window go to a spare word of the lane's own (no hot spot)
+                        bool unused = false;
+                        BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) lo_idx, (uint32_t) cap, win + W * kWinWordsPerBlock + tid };
+                        sink.append(dc_str, dc_n);
+                        (void) walk_block<true, true>(w, tab, zrl, eob, sink, unused);
+                        sink.finish();
                 }
                 __syncthreads();
         };
-        // ---- emission walk ----
-        if (__builtin_expect(!multi, 1)) {
-                zero_window(0);
-                if (active) { // idle lanes stay out of the walk
-                        BitSink<false> sink = { 0, 0, (uint32_t) p0 & 31u, mywin + (p0 >> 5), 0, 0, 0, spare };
-                        sink.append(dc_str, dc_n);
-                        if (__builtin_expect(!any_zrl, 1)) {
-                                (void) walk_block<true, false>(w, tab, zrl, eob, sink, zrl_seen);
-                        } else { // some block of the wave has a zero run longer than 15: the variant that can emit ZRL symbols
-                                asm volatile("; ZRL variant" ::: "memory");
-                                (void) walk_block<true, true>(w, tab, zrl, eob, sink, zrl_seen);
-                        }
-                        sink.finish();
+        // pad the last byte of segment s2 with 1-bits (T.81 F.1.2.3) if this pass's window shows it (the wave that reads the segment afterwards)
+        auto pad_segment = [&](int s2, int lo_idx) {
+                const int bits = lds_seg_bits[s2];
+                const int padw = (bits >> 5) - lo_idx; // window word that holds the last, partial byte
+                if (lane == 0 && (bits & 7) && padw >= 0 && padw < cap) {
+                        const int pad = 8 - (bits & 7);
+                        win[s2 * S * kWinWordsPerBlock + padw] |= ((1u << pad) - 1u) << (32 - (bits & 31) - pad);
                 }
-                flush_window(0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+        };
+        // count the 0xFF bytes of the window words of this pass
+        auto count_pass = [&](int lo_idx) {
+#pragma unroll 1
+                for (int s2 = wv; s2 < nseg_wg; s2 += WAVES) {
+                        pad_segment(s2, lo_idx);
+                        const int bits = lds_seg_bits[s2];
+                        const uint32_t *const sw = win + s2 * S * kWinWordsPerBlock;
+                        const int nbytes = (bits + 7) >> 3;
+                        const int nw = min(cap, ((nbytes + 3) >> 2) - lo_idx); // words of the segment in this pass
+                        int ff = 0;
+                        for (int i = lane; i < nw; i += 64) ff += count_ff_valid(sw[i], min(4, nbytes - 4 * (lo_idx + i)));
+                        const int ff_all = __builtin_amdgcn_readlane(wave_inclusive_scan(ff, lane), 63);
+                        if (lane == 0) lds_seg_ff[s2] += (uint32_t) ff_all;
+                }
+        };
+        // final sizes -> positions of the segments inside the workgroup's stretch, the stretch's position in the stream (first wave)
+        auto place = [&]() {
+                __syncthreads();
+                if (wv == 0) {
+                        uint32_t carry = 0;
+#pragma unroll 1
+                        for (int base = 0; base < nseg_wg; base += 64) {
+                                const int s2 = base + lane;
+                                const int sz = s2 < nseg_wg ? ((lds_seg_bits[s2] + 7) >> 3) + (int) lds_seg_ff[s2] + 2 : 0; // stuffed bytes + marker
+                                const int inc = wave_inclusive_scan(sz, lane);
+                                if (s2 < nseg_wg) lds_seg_off[s2] = carry + (uint32_t) (inc - sz);
+                                carry += (uint32_t) __builtin_amdgcn_readlane(inc, 63);
+                        }
+                        const uint32_t before = lookback_exclusive(a.status + (long) frame * a.n_status, wg, carry, a.gen, lane, a.total_pinned + kMaxBatch);
+                        if (lane == 0) lds_base = (uint32_t) a.header_len + before;
+                }
+                __syncthreads();
+        };
+        uint8_t *const out = a.out + (size_t) frame * a.out_stride;
+        // the window words of this pass to their place in the stream, 0x00 after every 0xFF; after the last pass RSTm / EOI
+        auto write_pass = [&](int lo_idx, bool last_pass, bool pad) {
+#pragma unroll 1
+                for (int s2 = wv; s2 < nseg_wg; s2 += WAVES) {
+                        if (pad) pad_segment(s2, lo_idx); // (a pass that was emitted again for the write-out)
+                        const int sg = seg0 + s2;
+                        const int bits = lds_seg_bits[s2];
+                        const uint32_t *const sw = win + s2 * S * kWinWordsPerBlock;
+                        const int nbytes = (bits + 7) >> 3;
+                        const uint32_t start = lds_base + lds_seg_off[s2], end = start + (uint32_t) nbytes + lds_seg_ff[s2] + 2u;
+                        const bool fits = (size_t) end <= a.capacity; // would not fit: nothing of this segment is written, the host reports the needed size
+                        const uint32_t done = lds_seg_done[s2];
+                        uint8_t *const d = out + start + done;
+                        const int nw = min(cap, ((nbytes + 3) >> 2) - lo_idx);
+                        uint32_t written = 0; // wave-uniform
+                        for (int i0 = 0; i0 < nw; i0 += 64) {
+                                const int i = i0 + lane;
+                                const uint32_t word = i < nw ? sw[i] : 0u;
+                                const int valid = i < nw ? min(4, nbytes - 4 * (lo_idx + i)) : 0;
+                                const int mine = valid + count_ff_valid(word, valid);
+                                const int inc = wave_inclusive_scan(mine, lane);
+                                if (fits) {
+                                        uint8_t *p = d + written + (uint32_t) (inc - mine);
+#pragma unroll
+                                        for (int t = 0; t < 4; t++) {
+                                                if (t < valid) {
+                                                        const uint8_t byte = (uint8_t) (word >> (24 - 8 * t));
+                                                        *p++ = byte;
+                                                        if (byte == 0xFF) *p++ = 0;
+                                                }
+                                        }
+                                }
+                                written += (uint32_t) __builtin_amdgcn_readlane(inc, 63);
+                        }
+                        if (lane == 0) {
+                                lds_seg_done[s2] = done + written;
+                                if (last_pass) {
+                                        if (fits) {
+                                                out[end - 2] = 0xFF;
+                                                out[end - 1] = sg == a.n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (sg & 7));
+                                        }
+                                        if (sg == a.n_seg - 1) a.total_pinned[frame] = end;
+                                }
+                        }
+                }
+        };
+        if (wg == 0) { // the first workgroup also lays down SOI .. SOS
+                for (int i = tid; i < a.header_len; i += W) out[i] = a.header[i];
+        }
+        if (__builtin_expect(!general, 1)) {
+                if (active) { // the private string, shifted to the block's bit position, into the segment's window
+                        const uint32_t sh = (uint32_t) p0 & 31u;
+                        uint32_t *const dst = mywin + (p0 >> 5);
+                        const int nw = (int) ((nbits + 31u) >> 5), nsw = (int) ((sh + nbits + 31u) >> 5);
+                        uint32_t prev = 0;
+                        for (int k = 0; __ballot(k < nsw) != 0; k++) {
+                                const uint32_t cur = k < nw ? row[k] : 0u;
+                                const uint32_t o = __builtin_amdgcn_alignbit(prev, cur, sh); // ({prev, cur} >> sh): the word at k of the shifted string
+                                if (k < nsw) atomicOr(&dst[k], o);
+                                prev = cur;
+                        }
+                }
+                __syncthreads();
+                count_pass(0);
+                place();
+                write_pass(0, true, false);
         } else {
-                asm volatile("; multi-pass variant" ::: "memory");
+                asm volatile("; general path" ::: "memory");
+                __syncthreads(); // lds_flag[1]
+                const int longest = lds_flag[1]; // 0: every segment fits its window
+                const int passes = longest ? (longest + cap - 1) / cap : 1;
 #pragma unroll 1
                 for (int pass = 0; pass < passes; pass++) {
-                        // everything the walk derives from the coefficients is invariant over the passes; left alone, the compiler
-                        // hoists all of it out of this loop (4 values x 63 coefficients: 237 VGPRs for a path that almost never runs)
-#pragma unroll
-                        for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
-                        zero_window(pass * cap);
-                        if (active) {
-                                // words outside this pass's window go to a spare word of the lane's own (no hot spot)
-                                BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) (pass * cap), (uint32_t) cap, spare + tid };
-                                sink.append(dc_str, dc_n);
-                                (void) walk_block<true, true>(w, tab, zrl, eob, sink, zrl_seen);
-                                sink.finish();
+                        emit_general(pass * cap);
+                        count_pass(pass * cap);
+                        __syncthreads();
+                }
+                place();
+                if (passes == 1) {
+                        write_pass(0, true, false); // the windows still hold the one pass
+                } else {
+#pragma unroll 1
+                        for (int pass = 0; pass < passes; pass++) {
+                                emit_general(pass * cap);
+                                write_pass(pass * cap, pass == passes - 1, true);
+                                __syncthreads();
                         }
-                        flush_window(pass, pass * cap);
                 }
         }
 }
 
 // one wave per segment: find its position (see kChunk), move its bytes there, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
-// append RSTm (or EOI after the last segment).  The wave of the last segment also reports the stream length, and the first
-// workgroup clears the chunk totals the NEXT frame's coder will add to (two sets, used alternately).
+// append RSTm (or EOI after the last segment).  The wave of the last segment also reports the stream length.  (Round 4: the companion of
+// the wave-per-segment coder only -- long restart intervals; the block-parallel coder places its bytes itself.)
 __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ raw, int cap_bytes, const uint32_t *__restrict__ seg_len,
                                                       const uint32_t *__restrict__ seg_ff, const uint32_t *__restrict__ chunk_tot,
-                                                      uint32_t *__restrict__ chunk_tot_next, int n_seg, uint8_t *__restrict__ out,
+                                                      int n_seg, uint8_t *__restrict__ out,
                                                       const uint8_t *__restrict__ header, int header_len, size_t capacity,
                                                       uint32_t *__restrict__ total_pinned, BatchStride bs)
 {
         raw += blockIdx.y * bs.raw_words * 4; seg_len += blockIdx.y * bs.seg; seg_ff += blockIdx.y * bs.seg;
-        chunk_tot += blockIdx.y * bs.tot_words; chunk_tot_next += blockIdx.y * bs.tot_words; out += blockIdx.y * bs.out_bytes; total_pinned += blockIdx.y;
+        chunk_tot += blockIdx.y * bs.tot_words; out += blockIdx.y * bs.out_bytes; total_pinned += blockIdx.y;
         if (blockIdx.x == 0) { // the first workgroup also lays down SOI .. SOS
                 for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
-                for (int i = threadIdx.x; i < (n_seg + kChunk - 1) / kChunk; i += 256) chunk_tot_next[i * kChunkStride] = 0;
         }
         const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (seg >= n_seg) return;
@@ -602,15 +946,20 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
 struct Encoder {
         int width, height, quality, ri, sub, hs, vs, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
         int batch_cap; // frames the workspace below is sized for (1 after create; encode_batch grows it)
-        bool force_wave_kernel; // UG_JPEG_WAVE_KERNEL=1: A/B switch back to the wave-per-segment coder (it remains the path for long restart intervals)
+        int raw_cap;   // frames the buffers of the wave-per-segment path (scratch, seg_len, seg_ff, chunk totals) are sized for (0 until that path runs)
+        bool force_wave_kernel; // UG_JPEG_WAVE_KERNEL=1: A/B switch back to the wave-per-segment coder + compaction (it remains the path for long restart intervals)
+        bool allow_fused;       // UG_JPEG_FUSED=0: A/B switch, the front end always writes the coefficients to HBM
         std::vector<uint8_t> header;
         // device workspace
         float *div;
         int16_t *cy, *cb, *cr;
         uint32_t *scratch; // per-segment scan data before byte stuffing, cap bytes each
         uint32_t *seg_len, *seg_ff;
-        uint32_t *chunk_tot[2]; // sums of seg_ff per kChunk segments: the coder of frame k adds to set k & 1, its compaction clears the other
-        unsigned frame_no;
+        uint32_t *chunk_tot;    // sums of seg_ff per kChunk segments (cleared before every call's coder)
+        unsigned long long *status; // look-back words of the placing coder, n_mcu per frame (never cleared: they carry the call's generation)
+        uint32_t gen;
+        uint32_t *ticket;       // start-order counter of the placing coder's workgroups (self-resetting)
+        bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
         uint8_t *header_dev;
         uint32_t *total_host; // pinned, mapped
         uint32_t *total_host_dev; // the same word as the device sees it
@@ -670,14 +1019,23 @@ BatchStride strides_of(const Encoder *e)
         return bs;
 }
 
+void free_raw(Encoder *e)
+{
+        for (void **p : { (void **) &e->scratch, (void **) &e->seg_len, (void **) &e->seg_ff, (void **) &e->chunk_tot }) {
+                if (*p) (void) hipFree(*p);
+                *p = nullptr;
+        }
+        e->raw_cap = 0;
+}
+
 void free_workspace(Encoder *e)
 {
-        for (void **p : { (void **) &e->cy, (void **) &e->cb, (void **) &e->cr, (void **) &e->scratch, (void **) &e->seg_len, (void **) &e->seg_ff,
-                          (void **) &e->chunk_tot[0], (void **) &e->chunk_tot[1] }) {
+        for (void **p : { (void **) &e->cy, (void **) &e->cb, (void **) &e->cr, (void **) &e->status }) {
                 if (*p) (void) hipFree(*p);
                 *p = nullptr;
         }
         e->batch_cap = 0;
+        free_raw(e);
 }
 
 // the per-frame work buffers, for `frames` frames in flight inside one call
@@ -690,14 +1048,24 @@ hipError_t alloc_workspace(Encoder *e, int frames)
         alloc((void **) &e->cy, (size_t) bs.coef_y * 2);
         alloc((void **) &e->cb, (size_t) bs.coef_c * 2);
         alloc((void **) &e->cr, (size_t) bs.coef_c * 2);
+        alloc((void **) &e->status, (size_t) e->n_mcu * 8);
+        if (err == hipSuccess) err = hipMemset(e->status, 0, (size_t) e->n_mcu * 8 * frames);
+        if (err == hipSuccess) e->batch_cap = frames;
+        return err;
+}
+
+// the wave-per-segment coder writes unstuffed segments for the compaction pass: its buffers exist only once that path has run
+hipError_t alloc_raw(Encoder *e, int frames)
+{
+        free_raw(e);
+        const BatchStride bs = strides_of(e);
+        hipError_t err = hipSuccess;
+        auto alloc = [&](void **p, size_t n) { if (err == hipSuccess) err = hipMalloc(p, n * (size_t) frames); };
         alloc((void **) &e->scratch, (size_t) bs.raw_words * 4);
         alloc((void **) &e->seg_len, (size_t) bs.seg * 4);
         alloc((void **) &e->seg_ff, (size_t) bs.seg * 4);
-        alloc((void **) &e->chunk_tot[0], (size_t) bs.tot_words * 4);
-        alloc((void **) &e->chunk_tot[1], (size_t) bs.tot_words * 4);
-        if (err == hipSuccess) err = hipMemset(e->chunk_tot[0], 0, (size_t) bs.tot_words * 4 * frames);
-        if (err == hipSuccess) err = hipMemset(e->chunk_tot[1], 0, (size_t) bs.tot_words * 4 * frames);
-        if (err == hipSuccess) e->batch_cap = frames;
+        alloc((void **) &e->chunk_tot, (size_t) bs.tot_words * 4);
+        if (err == hipSuccess) e->raw_cap = frames;
         return err;
 }
 
@@ -705,7 +1073,7 @@ void destroy(Encoder *e)
 {
         if (!e) return;
         free_workspace(e);
-        for (void *p : { (void *) e->div, (void *) e->header_dev }) {
+        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket }) {
                 if (p) (void) hipFree(p);
         }
         if (e->total_host) (void) hipHostFree(e->total_host);
@@ -731,6 +1099,8 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         Encoder *e = new Encoder();
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
         e->force_wave_kernel = getenv("UG_JPEG_WAVE_KERNEL") != nullptr && getenv("UG_JPEG_WAVE_KERNEL")[0] == '1';
+        e->allow_fused = !(getenv("UG_JPEG_FUSED") != nullptr && getenv("UG_JPEG_FUSED")[0] == '0');
+        e->use_ticket = getenv("UG_JPEG_TICKET") != nullptr && getenv("UG_JPEG_TICKET")[0] == '1';
         e->sub = subsampling;
         e->hs = subsampling == 444 ? 1 : 2; e->vs = subsampling == 420 ? 2 : 1; e->ybl = e->hs * e->vs;
         e->mcu_w = (width + 8 * e->hs - 1) / (8 * e->hs); e->mcu_h = (height + 8 * e->vs - 1) / (8 * e->vs); e->n_mcu = e->mcu_w * e->mcu_h;
@@ -748,8 +1118,11 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         alloc((void **) &e->div, sizeof div);
         if (err == hipSuccess) err = alloc_workspace(e, 1);
         alloc((void **) &e->header_dev, e->header.size());
+        alloc((void **) &e->ticket, 64);
+        if (err == hipSuccess) err = hipMemset(e->ticket, 0, 64);
         static_assert(kMaxBatch * sizeof(uint32_t) <= 64, "one length word per frame of a batch");
-        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 64, hipHostMallocMapped);
+        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 128, hipHostMallocMapped); // [kMaxBatch] lengths, then the coder's error word
+        if (err == hipSuccess) memset(e->total_host, 0, 128);
         if (err == hipSuccess) err = hipHostGetDevicePointer((void **) &e->total_host_dev, e->total_host, 0);
         if (err == hipSuccess) err = hipMemcpy(e->div, div, sizeof div, hipMemcpyHostToDevice);
         if (err == hipSuccess) err = hipMemcpy(e->header_dev, e->header.data(), e->header.size(), hipMemcpyHostToDevice);
@@ -807,7 +1180,16 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         bs.out_bytes = (long) out_stride;
         int rc = UG_HIP_SUCCESS;
         const int w = e->width, h = e->height;
-        if (in == UG_PF_UYVY && e->sub != 444) { // fused unpack + subsample + FDCT + quantise, grid.z = frame
+        const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
+        const bool wave_path = S > 256 || e->force_wave_kernel;
+        if (!src_pitch && in == UG_PF_UYVY) src_pitch = ug::linesize(UG_PF_UYVY, w);
+        // Fused: forward DCT, quantiser, Huffman coding and stream placement in ONE kernel, a workgroup per strip of 32 MCUs -- the quantised
+        // coefficients never reach HBM.  Needs whole segments per strip (32 % ri == 0, mcu_w % ri == 0) and the aligned geometry of the fast front end.
+        const bool fused = !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
+                           (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0 && e->mcu_w % e->ri == 0;
+        if (fused) {
+                // nothing to do here: the coder below reads the frame itself
+        } else if (in == UG_PF_UYVY && e->sub != 444) { // fused unpack + subsample + FDCT + quantise, grid.z = frame
                 rc = ug_hip_uyvy_to_jpeg42x_coeffs_batch(e->sub, src_dev, src_pitch, w, h, e->div, e->cy, e->cb, e->cr, frames, src_stride,
                                                          (size_t) bs.coef_y * 2, (size_t) bs.coef_c * 2, stream);
         } else if (in == UG_PF_RGB && e->sub == 444) { // GPUJPEG_444_U8_P012, components kept as R, G, B (gpujpeg.cpp:303-305,336)
@@ -834,39 +1216,68 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 return UG_HIP_EUNSUPP;
         }
         if (rc != UG_HIP_SUCCESS) return rc;
-        const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
-        uint32_t *const tot = e->chunk_tot[e->frame_no & 1], *const tot_next = e->chunk_tot[(e->frame_no + 1) & 1];
-        e->frame_no++;
-        // the totals this call's coder adds into start from zero for EVERY frame of the call (the compaction of the previous call cleared only
-        // the slices that call used: a smaller batch in between left the others stale -- ADVICE r3)
-        UG_HIP_TRY(hipMemsetAsync(tot, 0, (size_t) bs.tot_words * 4 * frames, st));
-        if (S <= 256 && !e->force_wave_kernel) {
-                // waves per workgroup: the count that leaves the fewest lanes idle (fewer waves on a tie)
-                int waves = 1;
-                for (int k = 1; k <= 4; k++) {
-                        if (64 * k >= S && (64 * k / S) * S * (64 * waves) > (64 * waves / S) * S * (64 * k)) waves = k;
-                        if (64 * waves < S) waves = k;
+        e->total_host[kMaxBatch] = 0;
+        if (!wave_path) {
+                if (++e->gen >= (1u << 30)) { // the status words carry the call's generation in 30 bits: start over on clean words
+                        UG_HIP_TRY(hipMemsetAsync(e->status, 0, (size_t) e->n_mcu * 8 * e->batch_cap, st));
+                        e->gen = 1;
                 }
-                const int G = 64 * waves / S;
-                const dim3 grid((e->n_seg + G - 1) / G, frames);
-#define UG_LAUNCH_EBK(NW)                                                                                                                      \
-        hipLaunchKernelGGL(entropy_block_kernel<NW>, grid, dim3(64 * NW), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,      \
-                           e->sub == 444 ? 0 : 1, e->ri, e->n_seg, S, G, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot, bs)
-                switch (waves) {
-                case 1: UG_LAUNCH_EBK(1); break;
-                case 2: UG_LAUNCH_EBK(2); break;
-                case 3: UG_LAUNCH_EBK(3); break;
-                default: UG_LAUNCH_EBK(4); break;
+                CodeArgs a = {};
+                a.mcu_w = e->mcu_w; a.n_mcu = e->n_mcu; a.hs = e->hs; a.vs = e->vs; a.ctab = e->sub == 444 ? 0 : 1; a.ri = e->ri; a.n_seg = e->n_seg; a.S = S;
+                a.cy = e->cy; a.cb = e->cb; a.cr = e->cr; a.coef_y = bs.coef_y; a.coef_c = bs.coef_c;
+                a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.height = h; a.src_stride = src_stride;
+                a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
+                a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr;
+                if (fused) {
+                        a.strips = (e->mcu_w + 31) / 32;
+                        a.n_wg = a.strips * e->mcu_h;
+                        a.G = 32 / e->ri;
+                        if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), dim3((unsigned) a.n_wg * frames), dim3(192), 0, st, a, (const float *) e->div);
+                        else hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), dim3((unsigned) a.n_wg * frames), dim3(128), 0, st, a, (const float *) e->div);
+                } else {
+                        // waves per workgroup: the count that leaves the fewest lanes idle (fewer waves on a tie)
+                        int waves = 1;
+                        for (int k = 1; k <= 4; k++) {
+                                if (64 * k >= S && (64 * k / S) * S * (64 * waves) > (64 * waves / S) * S * (64 * k)) waves = k;
+                                if (64 * waves < S) waves = k;
+                        }
+                        a.G = 64 * waves / S;
+                        a.n_wg = (e->n_seg + a.G - 1) / a.G;
+                        const dim3 grid((unsigned) a.n_wg * frames);
+                        switch (waves) {
+                        case 1: hipLaunchKernelGGL((jpeg_code_kernel<1, 0>), grid, dim3(64), 0, st, a, (const float *) e->div); break;
+                        case 2: hipLaunchKernelGGL((jpeg_code_kernel<2, 0>), grid, dim3(128), 0, st, a, (const float *) e->div); break;
+                        case 3: hipLaunchKernelGGL((jpeg_code_kernel<3, 0>), grid, dim3(192), 0, st, a, (const float *) e->div); break;
+                        default: hipLaunchKernelGGL((jpeg_code_kernel<4, 0>), grid, dim3(256), 0, st, a, (const float *) e->div); break;
+                        }
                 }
-#undef UG_LAUNCH_EBK
         } else {
+                if (frames > e->raw_cap) {
+                        const hipError_t err = alloc_raw(e, e->batch_cap);
+                        if (err != hipSuccess) {
+                                ug::set_last_error(err, "ug_hip_jpeg_encoder_encode: work buffers of the wave-per-segment coder");
+                                free_raw(e);
+                                return UG_HIP_ERUNTIME;
+                        }
+                }
+                // the totals this call's coder adds into start from zero (a smaller batch in between must not leave stale slices behind)
+                UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
-                                   e->sub == 444 ? 0 : 1, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, tot, bs);
+                                   e->sub == 444 ? 0 : 1, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, e->chunk_tot,
+                                   e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, bs);
         }
-        hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, tot, tot_next,
-                           e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, bs);
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipStreamSynchronize(st)); // ONE synchronisation for the batch
+        if (e->total_host[kMaxBatch] != 0) { // a workgroup gave up waiting for an earlier one: reported, never waited out
+                (void) hipMemset(e->ticket, 0, 4);
+                if (!e->use_ticket) { // the start order was not the index order after all: from now on the index IS the start order; once more
+                        e->use_ticket = true;
+                        return ug_hip_jpeg_encoder_encode_batch(enc, in, frames, src_dev, src_pitch, src_stride, out_dev, out_stride, out_capacity, out_len, stream);
+                }
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: the stream placement gave up waiting for an earlier workgroup");
+                return UG_HIP_ERUNTIME;
+        }
         bool fits = true;
         for (int f = 0; f < frames; f++) {
                 out_len[f] = e->total_host[f];
