@@ -72,6 +72,8 @@ int  oracle_convert_line(int in_fmt, int out_fmt, uint8_t *dst, const uint8_t *s
 int  oracle_convert_frame(int in_fmt, int out_fmt, uint8_t *dst, const uint8_t *src,
                           int width, int height, int rshift, int gshift, int bshift);
 /* to_planar.c:343-378 */
+/* vc_deinterlace, video_codec.c:597-664 (SSE2 bodies): in place */
+void oracle_deinterlace_blend(uint8_t *src, long src_linesize, int lines);
 void oracle_uyvy_to_i420(uint8_t *y, int y_ls, uint8_t *u, int u_ls, uint8_t *v, int v_ls,
                          const uint8_t *src, int width, int height);
 /* to_planar.c:64-155 */

@@ -389,3 +389,31 @@ void oracle_v210_to_p010le(uint16_t *yp, int y_ls, uint16_t *uvp, int uv_ls,
                 }
         }
 }
+
+/* vc_deinterlace (src/video_codec.c:597-664) as the reference's x86-64 build computes it (its SSE2 bodies, :624-720; the plain C loop at
+ * :606-613 is never compiled where __SSE2__ is defined): IN PLACE, 16-byte column by 16-byte column, down the lines with pavgb
+ * ((a + b + 1) >> 1):
+ *     x0 = line 0, x1 = line 1;  for (j = 0; j < lines - 4; j += 2) {
+ *         x2 = line j+2;  x0 = avg(avg(x0, x2), x1);  x1 = line j+3;  line j+1 = x0;  x0 = avg(avg(x0, x1), x2);  line j+2 = x0;  }
+ * -- a recursive blend: every output feeds the next one; line 0 and the last two or three lines are left as they are.  A column whose 16
+ * bytes reach past the end of the line (src_linesize % 16 != 0) takes its last bytes from the BEGINNING of the next line, which column 0
+ * has filtered already (the columns are processed one after the other): restated literally, in that order. */
+void oracle_deinterlace_blend(uint8_t *src, long src_linesize, int lines)
+{
+        for (long i = 0; i < src_linesize; i += 16) {
+                for (int b = 0; b < 16; b++) {
+                        uint8_t *col = src + i + b;
+                        unsigned x0 = col[0], x1 = col[src_linesize], x2;
+                        for (int j = 0; j < lines - 4; j += 2) {
+                                x2 = col[(long) (j + 2) * src_linesize];
+                                x0 = (x0 + x2 + 1) >> 1;
+                                x0 = (x0 + x1 + 1) >> 1;
+                                x1 = col[(long) (j + 3) * src_linesize];
+                                col[(long) (j + 1) * src_linesize] = (uint8_t) x0;
+                                x0 = (x0 + x1 + 1) >> 1;
+                                x0 = (x0 + x2 + 1) >> 1;
+                                col[(long) (j + 2) * src_linesize] = (uint8_t) x0;
+                        }
+                }
+        }
+}

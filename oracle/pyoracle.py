@@ -185,6 +185,26 @@ def dxt_decode(in_fmt: int, out_fmt: str, blocks: np.ndarray, w: int, h: int, sh
     return out
 
 
+def deinterlace_blend(frame: np.ndarray, linesize: int, lines: int) -> np.ndarray:
+    """vc_deinterlace (video_codec.c:597-664, SSE2 bodies) on a copy of `frame`."""
+    out = np.ascontiguousarray(frame, dtype=np.uint8).ravel().copy()
+    assert out.size >= linesize * lines
+    lib().oracle_deinterlace_blend.restype = None
+    lib().oracle_deinterlace_blend.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    lib().oracle_deinterlace_blend(_ptr(out), linesize, lines)
+    return out
+
+
+def ref_deinterlace(frame: np.ndarray, linesize: int, lines: int) -> np.ndarray:
+    """The compiled reference's own vc_deinterlace (oracle/_ref/libugref.so) on a copy of `frame`."""
+    out = np.ascontiguousarray(frame, dtype=np.uint8).ravel().copy()
+    r = ref()
+    r.vc_deinterlace.restype = None
+    r.vc_deinterlace.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    r.vc_deinterlace(_ptr(out), linesize, lines)
+    return out
+
+
 GLSL_REF = os.path.join(_HERE, "_ref", "glsl_ref")
 
 

@@ -827,3 +827,40 @@ def test_workers_run_on_the_gpu_s_numa_node(tmp_path, po, cfg):
             else:                                             # the platform does not say: left where it was
                 assert bound == 0 and aff == os.sched_getaffinity(0)
     assert outs["numa"] == outs["off"]
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,codec,w,h", [("dxt:DXT5", "UYVY", 192, 64), ("dxt:DXT1", "RGB", 192, 64), ("dxt:DXT1", "RGBA", 200, 36), ("dxt:DXT5", "v210", 192, 64),
+                                           ("dxt:DXT5", "UYVY", 1924, 36), ("dxt:DXT1_YUV", "UYVY", 192, 64), ("dxt:DXT5", "YUYV", 200, 44)])
+def test_interlaced_input_is_blended_before_encoding(tmp_path, po, cfg, codec, w, h):
+    """on INTERLACED_MERGED input RTDXT -- the module `-c dxt` replaces -- blends the lines of the decoded frame (vc_deinterlace,
+    video_codec.c:597-664) before encoding and announces the stream as progressive (dxt_glsl.cpp:195-201,291-293).  The module does the same on
+    the device: blocks == encoder(oracle blend(line-decoded frame)), through the one-frame path, the batch path and from a device-resident frame;
+    deinterlace=no leaves the frame as it is (and interlaced); widths whose decoded line is no multiple of 16 bytes included."""
+    src = synth.s1_random(codec if codec != "YUYV" else "UYVY", w, h, salt=11)
+    raw = tmp_path / "in.raw"
+    np.concatenate([src, src]).tofile(raw)
+    env = dict(os.environ, UG_HARNESS_INTERLACING="merged")
+    yuv_out = cfg.endswith("DXT1_YUV")
+    target = "UYVY" if codec in ("UYVY", "YUYV", "v210") or yuv_out else "RGB"
+    decoded = src if codec == target else po.convert_frame(codec, target, src, w, h)
+    ls = {"UYVY": 2 * w, "RGB": 3 * w}[target]
+    oid = po.OUT_DXT5YCOCG if cfg.endswith("DXT5") else po.OUT_DXT1
+    pin = {"UYVY": po.IN_UYVY_RAW if yuv_out else po.IN_UYVY, "RGB": po.IN_RGB}[target]
+    want = po.dxt_encode(pin, oid, po.deinterlace_blend(decoded, ls, h), w, h)
+    plain = po.dxt_encode(pin, oid, decoded, w, h)
+    assert not np.array_equal(want, plain)
+    for extra, mem, n in (("", "host", 1), (":batch=4:workers=1", "host", 2), ("", "dev", 1)):
+        out = tmp_path / "out.bin"
+        r = _run([cfg + extra, codec, w, h, raw, out, 1, mem, n], env=env)
+        assert r.returncode == 0 and "interlacing=p " in r.stdout, r.stdout + r.stderr
+        got = np.fromfile(out, np.uint8)
+        assert np.array_equal(got[: want.size], want), (extra, mem)
+        if n == 2:
+            assert np.array_equal(got[want.size:], want)
+    out = tmp_path / "out_no.bin"
+    r = _run([cfg + ":deinterlace=no", codec, w, h, raw, out, 1, "host", 1], env=env)
+    assert r.returncode == 0 and "interlacing=i " in r.stdout and np.array_equal(np.fromfile(out, np.uint8), plain), r.stdout + r.stderr
+    r = _run([cfg, codec, w, h, raw, out, 1, "host", 1])                                   # a progressive source: nothing changes
+    assert r.returncode == 0 and np.array_equal(np.fromfile(out, np.uint8), plain)

@@ -25,7 +25,7 @@ def main():
             for frames in (1, 8):
                 hh = h * frames
                 n_in, n_out = int(w * hh * bpp_in), w * hh * bpp_out
-                nbuf = max(2, int(600e6 // (n_in + n_out)) + 1)
+                nbuf = max(2, int(2.4e9 // (n_in + n_out)) + 1)   # >= 2.4 GB rotating (profiles/r04_rotation_sweep.txt)
                 src = torch.randint(0, 256, (nbuf, n_in), dtype=torch.uint8, device="cuda")
                 dst = torch.empty((nbuf, n_out), dtype=torch.uint8, device="cuda")
 

@@ -60,3 +60,5 @@ for name, fn in legs:
         n += 1
     dt = time.perf_counter() - t0
     print(f"jpeg encode 4K 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
+
+l.ug_hip_jpeg_encoder_destroy(enc)

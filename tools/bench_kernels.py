@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel roofline table for every hot-path kernel (SURVEY.md 8(d) algorithmic bytes per pixel).
-Inputs resident in HBM; EVERY row rotates its sources AND its destinations over >= 600 MB of distinct buffers (nrot(); the rule of
-tools/bench_pixfmt_all.py), more than twice the 256 MB Infinity Cache, so that neither the reads nor the writes of a launch can be
-served by what an earlier launch left in the cache (the r02 table rotated 4 sources into ONE destination for the
-pixfmt_ext / planar / lavc rows, e.g. 221 MB for RG48->v210).  HIP events on the launch stream.
+Inputs resident in HBM; EVERY row rotates its sources AND its destinations over >= 2.4 GB of distinct buffers (nrot(); the rule of
+tools/bench_pixfmt_all.py).  Round 3 used 600 MB -- "more than twice the 256 MB Infinity Cache" -- and that was not enough: the cache does
+not replace least-recently-used lines, a 620 MB rotation still hits in it, and the rows above ~0.79 of 8 TB/s were upper bounds.
+tools/rotation_sweep.py (profiles/r04_rotation_sweep.txt): the rate is flat from 1.5 GB of rotating buffers up to 9.6 GB (UYVY->v210 x8:
+0.929 at 0.62 GB, 0.699 at 1.55 GB, 0.700 at 9.6 GB), so 2.4 GB is on the flat part.  HIP events on the launch stream.
 Usage (GPU box): python tools/bench_kernels.py [--json out.json]"""
 import argparse
 import json
@@ -18,11 +19,11 @@ from ultragrid_amd import codec, lib, synth
 
 L = lib
 PEAK = 8000.0
-ROT_BYTES = 600e6
+ROT_BYTES = 2.4e9
 
 
 def nrot(bytes_per_call: float) -> int:
-    """how many distinct (source, destination) buffer pairs a row cycles through: >= 600 MB in total, at least 2"""
+    """how many distinct (source, destination) buffer pairs a row cycles through: >= 2.4 GB in total, at least 2"""
     return max(2, int(ROT_BYTES // max(bytes_per_call, 1)) + 1)
 
 
@@ -59,8 +60,11 @@ def frames(fmt, w, h, n):
         one = synth.s1_random(base_fmt, w, min(h, 64))
     ls = one.size // min(h, 64)
     img = np.tile(one.reshape(min(h, 64), ls), ((h + 63) // 64, 1))[:h]
-    out = np.stack([np.roll(img, 4 * i, axis=0) for i in range(n)])
-    return torch.from_numpy(out.reshape(n, -1)).cuda()
+    base = torch.from_numpy(np.ascontiguousarray(img)).cuda()                 # (h, ls); the n frames are row rotations made on the device
+    out = torch.empty((n, h * ls), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        out[i] = torch.roll(base, 4 * i, dims=0).reshape(-1)
+    return out
 
 
 def main():

@@ -34,7 +34,7 @@ def main():
                 continue
             sls, dls = l.ug_hip_linesize(pi, w), l.ug_hip_linesize(po, w)
             per = (sls + dls) * h
-            nbuf = max(2, int(600e6 // per) + 1)
+            nbuf = max(2, int(2.4e9 // per) + 1)   # >= 2.4 GB of rotating buffers: the flat part of profiles/r04_rotation_sweep.txt (600 MB still hit in the Infinity Cache)
             src = torch.randint(0, 256, (nbuf, sls * h + 64), dtype=torch.uint8, device="cuda")
             dst = torch.empty((nbuf, dls * h + 64), dtype=torch.uint8, device="cuda")
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rotation sweep: do the table rows that sit above ~0.79 of 8 TB/s owe part of their rate to the 256 MB Infinity Cache?
-Each row is timed with its sources AND its destinations rotating over R bytes PER SIDE, R in {0.6, 1.2, 2.4, 4.8} GB (the tables use 0.6 GB in
-total).  If the cache replaced at random, a working set of R + R bytes would still hit in ~256 MB / 2R of its accesses; a rate that is flat in R
+Each row is timed with its sources AND its destinations rotating over R bytes PER SIDE, R in {0.15, 0.3, 0.6, 1.2, 2.4, 4.8} GB (round 3's tables used 0.6 GB in
+total = 0.3 GB per side).  If the cache replaced at random, a working set of R + R bytes would still hit in ~256 MB / 2R of its accesses; a rate that is flat in R
 says the tables' figure is the HBM figure.  HIP events on the launch stream, >= 150 ms of launches per point, points interleaved A B C D A B C D.
 usage (GPU box): python tools/rotation_sweep.py > gpurun_out/rotation_sweep.txt"""
 import os
@@ -14,7 +14,7 @@ from ultragrid_amd import lib as L
 
 l = L.load()
 st = torch.cuda.current_stream().cuda_stream
-SIZES = [0.6e9, 1.2e9, 2.4e9, 4.8e9]
+SIZES = [0.15e9, 0.3e9, 0.6e9, 1.2e9, 2.4e9, 4.8e9]
 
 
 def timeit(fn, min_ms=150.0):
@@ -60,7 +60,7 @@ def row(name, in_bytes, out_bytes, call):
     line = f"{name:34s}"
     for R in SIZES:
         gbs = (in_bytes + out_bytes) / (best[R] * 1e-3) / 1e9
-        line += f"  {R / 1e9:.1f} GB/side: {best[R]:7.4f} ms {gbs:7.1f} GB/s {gbs / 8000:5.3f}"
+        line += f"  {R / 1e9:.2f} GB/side: {best[R]:7.4f} ms {gbs:7.1f} GB/s {gbs / 8000:5.3f}"
     print(line, flush=True)
 
 

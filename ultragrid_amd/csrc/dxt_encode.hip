@@ -280,7 +280,64 @@ struct LoaderUYVY {
                 }
         }
 };
-#if UG_DXT_TBUF
+#ifndef UG_DXT_LDS_CONV
+#define UG_DXT_LDS_CONV 0 // experiment of round 4: 1 = the byte -> term maps of ConvertYUVToRGB are 256-entry tables in LDS
+#endif
+#if UG_DXT_LDS_CONV
+// Every term of ConvertYUVToRGB is a function of ONE byte: Y' = 1.1643 * (y / 255 - 0.0625), (1.7926, 0.5328) * (v / 255 - 0.5),
+// (0.2132, 2.1124) * (u / 255 - 0.5).  The workgroup builds the three tables once, with the very statements of yuv_pair_to_rgb -- the entries
+// are bit-identical by construction --, and a pixel pair then costs 4 table reads (the LDS pipe is idle in this kernel) + the 8 additions
+// instead of 22 VALU operations.  Raw word loads; the byte -> table offset is one shift with a byte selector.
+struct ConvTables {
+        float y[256];
+        float2 v[256]; // (rv, gv)
+        float2 u[256]; // (gu, bu)
+};
+template <bool CONVERT>
+struct LoaderUYVYLds {
+        static constexpr int kBlocks = 1;
+        static constexpr bool kLdsConv = CONVERT;
+        uint2 w[4];
+        const ConvTables *lut;
+        __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        w[r] = *(const uint2 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                }
+        }
+        __device__ __forceinline__ void block(int, Px16 &p) const
+        {
+                const char *const ty = (const char *) lut->y, *const tv = (const char *) lut->v, *const tu = (const char *) lut->u;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t q[2] = { w[r].x, w[r].y };
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                                const int i = 4 * r + 2 * k;
+                                if (CONVERT) {
+                                        const uint32_t ou = (q[k] & 0xffu) << 3, oy0 = ((q[k] >> 8) & 0xffu) << 2;
+                                        const uint32_t ov = ((q[k] >> 16) & 0xffu) << 3, oy1 = (q[k] >> 24) << 2;
+                                        const float2 gb = *(const float2 *) (tu + ou), rg = *(const float2 *) (tv + ov);
+                                        const float Y0 = *(const float *) (ty + oy0), Y1 = *(const float *) (ty + oy1);
+                                        p.a[i] = Y0 + rg.x;
+                                        p.b[i] = (Y0 - gb.x) - rg.y;
+                                        p.c[i] = Y0 + gb.y;
+                                        p.a[i + 1] = Y1 + rg.x;
+                                        p.b[i + 1] = (Y1 - gb.x) - rg.y;
+                                        p.c[i + 1] = Y1 + gb.y;
+                                } else {
+                                        const float u = byte_f(q[k], 0), y0 = byte_f(q[k], 1), v = byte_f(q[k], 2), y1 = byte_f(q[k], 3);
+                                        p.a[i] = y0; p.b[i] = u; p.c[i] = v;
+                                        p.a[i + 1] = y1; p.b[i + 1] = u; p.c[i + 1] = v;
+                                }
+                        }
+                }
+        }
+};
+template <> struct Loader<UG_PF_UYVY> : LoaderUYVYLds<true> {};
+template <> struct Loader<UG_PF_UYVY_RAW> : LoaderUYVYLds<false> {};
+#elif UG_DXT_TBUF
 // Same, but the texture-address unit does the byte -> float conversion: typed buffer loads with format 8_8_8_8 USCALED return
 // float(byte) for the four bytes of a word (exact), so the 32 v_cvt_f32_ubyte of a block -- slow-pipe VALU work -- disappear; the
 // multiplication by kInv255 stays in the shader arithmetic.  Costs 24 more VGPRs (the raw block is held as 32 floats).
@@ -952,6 +1009,18 @@ __global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVE
                 tab.alpha = lds_alpha + (kAlpha ? wave * (8 * 64) + (int) threadIdx.x : 0);
                 tab.colour = lds_colour + (kTables ? wave * (kColourRows * 64) + (int) threadIdx.x : 0);
         }
+#if UG_DXT_LDS_CONV
+        __shared__ ConvTables lds_conv;
+        if (IN == UG_PF_UYVY) { // 256 threads, one entry each: the statements of yuv_pair_to_rgb
+                const int b = (int) (threadIdx.y * 64 + threadIdx.x);
+                const float x = (float) b * kInv255;
+                const float U = x - 0.5f;
+                lds_conv.y[b] = 1.1643f * (x - 0.0625f);
+                lds_conv.v[b] = make_float2(1.7926f * U, 0.5328f * U);
+                lds_conv.u[b] = make_float2(0.2132f * U, 2.1124f * U);
+                __syncthreads();
+        }
+#endif
         // threadIdx.y is wave-uniform (a wave is one 64-lane row of the group): keep the block row, the row base
         // pointers and the bounds test on the scalar unit -- no per-lane 64-bit multiplies in the prologue.
         const int ux = blockIdx.x * 64 + threadIdx.x;
@@ -975,6 +1044,9 @@ __global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVE
                 ld.load(src, pitch, ux, rows);
         };
         L cur, nxt;
+#if UG_DXT_LDS_CONV
+        if constexpr (IN == UG_PF_UYVY) { cur.lut = &lds_conv; nxt.lut = &lds_conv; }
+#endif
         load_row(cur, by0);
 #pragma unroll 1
         for (int j = 0; j < kRowsPerWave; j++) {

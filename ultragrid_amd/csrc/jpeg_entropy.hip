@@ -355,25 +355,26 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
 constexpr int kPrivWords = 16;         // private string of a block: 512 bits (a 4K q75 frame needs ~80)
 constexpr int kPrivStride = 17;        // + one dump word for what does not fit; odd stride: the lanes' rows start in different banks
 
-// the lane's private bit string: 64-bit accumulator, left-aligned; completed words are stored at row[idx]
+// the lane's private bit string.  New bits enter a 64-bit accumulator at the bottom; `fill` (< 32 between appends) of its low bits have not
+// been stored as a complete word yet.  Every append stores the oldest 32 of them at row[idx] -- a complete word once fill reaches 32 (idx
+// then moves on), otherwise a value the next store to the same place replaces -- so there is no control flow and no masking: 10 operations.
 struct PrivSink {
-        uint32_t hi, lo, fill; // fill < 32 between appends
+        unsigned long long acc;
+        uint32_t fill;
         uint32_t *row;
         uint32_t idx;
         __device__ __forceinline__ void append(uint32_t str, uint32_t n) // n <= 27 bits; n == 0 (with str == 0) appends nothing
         {
-                const uint32_t t = fill + n;
-                const unsigned long long sh = (unsigned long long) str << ((64u - t) & 63u);
-                hi |= (uint32_t) (sh >> 32);
-                lo |= (uint32_t) sh;
-                const uint32_t fl = t >> 5, m = 0u - fl; // fl = 1: the top word is complete
-                row[min(idx, (uint32_t) kPrivWords)] = hi; // (a partial word is simply stored again later)
-                hi = (lo & m) | (hi & ~m);
-                lo &= ~m;
-                fill = t & 31u;
-                idx += fl;
+                acc = (acc << n) | str;
+                fill += n; // <= 31 + 27
+                row[min(idx, (uint32_t) kPrivWords)] = (uint32_t) (acc >> ((fill - 32u) & 63u)); // bits fill-1 .. fill-32 (fill < 32: not a word yet)
+                idx += fill >> 5;
+                fill &= 31u;
         }
-        __device__ __forceinline__ void finish() { row[min(idx, (uint32_t) kPrivWords)] = hi; }
+        __device__ __forceinline__ void finish() // the last, partial word, left-aligned (fill == 0: the string ended on a word boundary, nothing to add)
+        {
+                row[min(idx, (uint32_t) kPrivWords)] = (uint32_t) acc << ((32u - fill) & 31u);
+        }
 };
 
 // The AC part of every lane's block: appended to `sink`, length returned (EOB included).  Groups of kWalkGroup coefficients that are zero in
@@ -446,20 +447,25 @@ __device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *statu
         uint32_t excl = 0;
         for (int pos = wg - 1;; pos -= 64) { // 64 predecessors at a time, lane 0 = the nearest
                 const int idx = pos - lane;
-                unsigned long long s;
+                unsigned long long s, full;
+                int last;
+                // wait only for what the sum needs: the predecessors up to the nearest one that already knows its inclusive prefix (measured: waiting
+                // for all 64 of the window to have reported cost 12 k of a workgroup's 48 k cycles -- one late workgroup among 64 held up all behind it)
                 for (int polls = 0;; polls++) {
                         s = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : status_word(gen, 2, 0);
-                        const bool there = (uint32_t) (s >> 34) == gen && ((uint32_t) (s >> 32) & 3u) != 0;
-                        if (__all(there)) break;
+                        const uint32_t state = (uint32_t) (s >> 34) == gen ? (uint32_t) (s >> 32) & 3u : 0u;
+                        const unsigned long long there = __ballot(state != 0);
+                        full = __ballot(state == 2u);
+                        last = full ? __builtin_ctzll(full) : 63; // the nearest predecessor that knows its inclusive prefix ends the walk
+                        const unsigned long long need = last == 63 ? ~0ull : (2ull << last) - 1ull;
+                        if ((there & need) == need) break;
                         if (polls == kSpinLimit) {
                                 if (lane == 0) *stuck = 1u;
-                                if (!there) s = status_word(gen, 2, 0);
+                                if (state == 0) s = status_word(gen, 2, 0);
                                 break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                 }
-                const unsigned long long full = __ballot(((uint32_t) (s >> 32) & 3u) == 2u);
-                const int last = full ? __builtin_ctzll(full) : 63; // the nearest predecessor that knows its inclusive prefix ends the walk
                 const int v = lane <= last ? (int) (uint32_t) s : 0;
                 excl += (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan(v, lane), 63);
                 if (full) break;
@@ -488,11 +494,21 @@ struct CodeArgs {
         long n_status;
         uint32_t gen;
         uint32_t *ticket;               // workgroups take their index from here, in the order they start (0 before and after every launch)
+        unsigned long long *prof;       // UG_JPEG_PROF=1: kProfPhases accumulated s_memtime deltas + a workgroup count (tools/jpeg_phase_profile.py); else NULL
 };
+constexpr int kProfPhases = 10;
 
 // WAVES = waves per workgroup.  SRC = 0: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES
 // that leaves the fewest lanes idle).  SRC = 420 (WAVES = 3) / 422 (WAVES = 2): a workgroup = one strip of 32 MCUs of an MCU row = 32 / ri
 // segments; needs 32 % ri == 0 and mcu_w % ri == 0 (no segment leaves its strip) and a 16-byte aligned frame of width % 16 == 0.
+// phase clock of the profiling runs: thread 0 of every workgroup adds the time since the previous mark to phase `i` (a.prof == NULL: nothing)
+#define UG_PHASE(i)                                                                                                      \
+        if (a.prof != nullptr && threadIdx.x == 0) {                                                                     \
+                const unsigned long long now_ = __builtin_readcyclecounter();                                            \
+                a.prof[(size_t) blockIdx.x * (kProfPhases + 1) + i] = now_ - prof_t; /* a slot per workgroup: no contention */ \
+                prof_t = now_;                                                                                           \
+        }
+
 template <int WAVES, int SRC>
 __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
 {
@@ -503,6 +519,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         // is then a ticket drawn when the workgroup STARTS, so that every index it waits for belongs to a workgroup that is already running whatever
         // the start order (one atomic round trip, ~2 us, at the head of every workgroup: measured 8 % of the kernel).  The workgroup that draws
         // the last ticket puts the counter back to 0 for the next launch.
+        unsigned long long prof_t = a.prof != nullptr ? __builtin_readcyclecounter() : 0ull;
         __shared__ uint32_t lds_ticket;
         uint32_t index = blockIdx.x;
         if (a.ticket != nullptr) { // wave-uniform
@@ -671,6 +688,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                                 for (int i = 0; i < 32; i++) w[i] = 0;
                         }
                 }
+                UG_PHASE(0) // pixels -> quantised block (wave 0's view, like all the marks)
                 // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU)
                 uint4 *const store = (uint4 *) buf;
                 constexpr int kRow = ug_jpeg::kLdsPitch / 16;
@@ -691,6 +709,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         const int dc = coef_at(w, 0);
         lds_dc[tid] = dc;
         __syncthreads(); // tables, DC values; the hand-over buffer has been read
+        UG_PHASE(1) // hand-over (SRC = 0: the block loads)
         const int back = b < ybl ? (b > 0 ? 1 : 3) : per_mcu;
         const bool has_pred = b < ybl ? j > 0 : ml > 0;
         const int diff = dc - (has_pred ? lds_dc[max(tid - back, 0)] : 0);
@@ -711,12 +730,13 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         uint32_t *const row = priv + tid * kPrivStride;
         uint32_t nbits = 0;
         if (active) { // idle lanes stay out of the walk
-                PrivSink sink = { 0, 0, 0, row, 0 };
+                PrivSink sink = { 0ull, 0u, row, 0u };
                 sink.append(dc_str, dc_n);
                 nbits = dc_n + walk_private(w, tab, zrl, eob, sink);
                 sink.finish();
                 if (nbits > 32u * kPrivWords) lds_flag[0] = 1; // does not fit its private string: the general path for this workgroup
         }
+        UG_PHASE(2) // the walk
         // ---- bit position of every block inside its segment: prefix sum over the workgroup, made segment-relative ----
         const int incl_w = wave_inclusive_scan((int) nbits, lane);
         if (lane == 63) lds_wave_total[wv] = incl_w;
@@ -855,6 +875,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         if (wg == 0) { // the first workgroup also lays down SOI .. SOS
                 for (int i = tid; i < a.header_len; i += W) out[i] = a.header[i];
         }
+        UG_PHASE(3) // positions (two barriers: the other waves' walks end here)
         if (__builtin_expect(!general, 1)) {
                 if (active) { // the private string, shifted to the block's bit position, into the segment's window
                         const uint32_t sh = (uint32_t) p0 & 31u;
@@ -869,9 +890,14 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                         }
                 }
                 __syncthreads();
+                UG_PHASE(4) // merge
                 count_pass(0);
+                UG_PHASE(5) // 0xFF count
                 place();
+                UG_PHASE(6) // offsets + look-back
                 write_pass(0, true, false);
+                UG_PHASE(7) // write-out
+                if (a.prof != nullptr && threadIdx.x == 0) a.prof[(size_t) blockIdx.x * (kProfPhases + 1) + kProfPhases] = 1ull;
         } else {
                 asm volatile("; general path" ::: "memory");
                 __syncthreads(); // lds_flag[1]
@@ -959,6 +985,7 @@ struct Encoder {
         unsigned long long *status; // look-back words of the placing coder, n_mcu per frame (never cleared: they carry the call's generation)
         uint32_t gen;
         uint32_t *ticket;       // start-order counter of the placing coder's workgroups (self-resetting)
+        unsigned long long *prof; // UG_JPEG_PROF=1: phase clock sums of the placing coder (device memory, kProfPhases + 1 words)
         bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
         uint8_t *header_dev;
         uint32_t *total_host; // pinned, mapped
@@ -1073,7 +1100,23 @@ void destroy(Encoder *e)
 {
         if (!e) return;
         free_workspace(e);
-        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket }) {
+        if (e->prof) { // profiling run: the phase clock of the LAST call, averaged over its workgroups, as the encoder goes away
+                const size_t words = (size_t) kMaxBatch * e->n_mcu * (kProfPhases + 1);
+                std::vector<unsigned long long> h(words);
+                if (hipMemcpy(h.data(), e->prof, words * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                        double sum[kProfPhases] = {};
+                        unsigned long long n = 0;
+                        for (size_t g = 0; g < words / (kProfPhases + 1); g++) {
+                                if (!h[g * (kProfPhases + 1) + kProfPhases]) continue;
+                                n++;
+                                for (int i = 0; i < kProfPhases; i++) sum[i] += (double) h[g * (kProfPhases + 1) + i];
+                        }
+                        fprintf(stderr, "UG_JPEG_PROF workgroups=%llu clock_ticks_per_workgroup:", n);
+                        for (int i = 0; i < kProfPhases && n; i++) fprintf(stderr, " %.0f", sum[i] / (double) n);
+                        fprintf(stderr, "\n");
+                }
+        }
+        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket, (void *) e->prof }) {
                 if (p) (void) hipFree(p);
         }
         if (e->total_host) (void) hipHostFree(e->total_host);
@@ -1120,6 +1163,11 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         alloc((void **) &e->header_dev, e->header.size());
         alloc((void **) &e->ticket, 64);
         if (err == hipSuccess) err = hipMemset(e->ticket, 0, 64);
+        if (getenv("UG_JPEG_PROF") != nullptr && getenv("UG_JPEG_PROF")[0] == '1') {
+                const size_t bytes = (size_t) kMaxBatch * e->n_mcu * (kProfPhases + 1) * 8; // a slot per workgroup of the largest launch
+                alloc((void **) &e->prof, bytes);
+                if (err == hipSuccess) err = hipMemset(e->prof, 0, bytes);
+        }
         static_assert(kMaxBatch * sizeof(uint32_t) <= 64, "one length word per frame of a batch");
         if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 128, hipHostMallocMapped); // [kMaxBatch] lengths, then the coder's error word
         if (err == hipSuccess) memset(e->total_host, 0, 128);
@@ -1227,7 +1275,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.cy = e->cy; a.cb = e->cb; a.cr = e->cr; a.coef_y = bs.coef_y; a.coef_c = bs.coef_c;
                 a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
-                a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr;
+                a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
                 if (fused) {
                         a.strips = (e->mcu_w + 31) / 32;
                         a.n_wg = a.strips * e->mcu_h;

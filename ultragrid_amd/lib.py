@@ -69,6 +69,8 @@ SYMBOLS = {
     "ug_hip_pixfmt_convert": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ug_hip_pixfmt_convert_batch": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _sz, _sz, _vp]),
     "ug_hip_linesize": (_i, [_i, _i]),
+    "ug_hip_deinterlace_blend": (_i, [_vp, _sz, _i, _vp]),
+    "ug_hip_deinterlace_blend_batch": (_i, [_vp, _sz, _i, _i, _sz, _vp]),
     "ug_hip_uyvy_to_i420": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_v210_to_p010le": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_yuv420p_to_uyvy": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),

@@ -53,6 +53,9 @@ int main(int argc, char **argv)
         struct video_desc desc{};
         desc.width = w; desc.height = h; desc.color_spec = codec; desc.fps = 30; desc.interlacing = PROGRESSIVE;
         desc.tile_count = tiles;
+        if (const char *il = getenv("UG_HARNESS_INTERLACING")) { // "merged": an INTERLACED_MERGED source (both fields in one frame, as capture cards deliver 1080i)
+                if (strcmp(il, "merged") == 0) desc.interlacing = INTERLACED_MERGED;
+        }
         const unsigned nframes = argc > 9 ? atoi(argv[9]) : 1;
         const unsigned repeat = argc > 10 ? atoi(argv[10]) : 1;
         const bool devmem = argc > 8 && strcmp(argv[8], "dev") == 0;
@@ -131,7 +134,8 @@ int main(int argc, char **argv)
         fclose(o);
         {
                 std::shared_ptr<video_frame> out = popped[0];
-                printf("OK codec=%s frames=%zu tiles=%u tile0=%ux%u len=%u compress_ms=%.3f seq=", get_codec_name(out->color_spec), popped.size(),
+                printf("OK codec=%s interlacing=%s frames=%zu tiles=%u tile0=%ux%u len=%u compress_ms=%.3f seq=", get_codec_name(out->color_spec),
+                       get_interlacing_suffix(out->interlacing), popped.size(),
                        out->tile_count, out->tiles[0].width, out->tiles[0].height, out->tiles[0].data_len,
                        (double) (out->compress_end - out->compress_start) / 1e6);
                 for (auto &f2 : popped) printf("%u,", f2->seq);

@@ -76,6 +76,9 @@ struct state_video_compress_dxt_mi355x {
         codec_t           out_codec = DXT1;
         ug_dxt_t          out_fmt = UG_DXT1;
         int               ties = UG_DXT_TIES_DEFAULT; ///< ties=even|away (include/ug_mi355x.h UG_DXT_TIES_*)
+        bool              deinterlace = true;       ///< deinterlace=no switches off RTDXT's automatic de-interlacing of INTERLACED_MERGED input
+        bool              interlaced_input = false; ///< the current geometry is de-interlaced before encoding (dxt_glsl.cpp:195-201)
+        ug_pixfmt_t       target = UG_PF_NONE;      ///< the 8-bit line format the reference would encode from (RGB or UYVY)
         ug_pixfmt_t       in_fmt = UG_PF_NONE;      ///< format the encoder kernel reads
         ug_pixfmt_t       pre_in = UG_PF_NONE;      ///< != NONE: device-side conversion first (YUYV->UYVY, BGR->RGB, DXT1_YUV: anything->UYVY)
         ug_pixfmt_t       pre_out = UG_PF_NONE;     ///< its target format
@@ -105,7 +108,8 @@ void cleanup(state_video_compress_dxt_mi355x *s)
 void usage()
 {
         printf("MI355X DXT compression usage:\n"
-               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>][:ties=even|away]\n"
+               "\t-c dxt[:DXT1|:DXT1_YUV|:DXT5][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>][:ties=even|away][:deinterlace=no]\n"
+               "\t\tdeinterlace=no - do not blend the lines of interlaced (merged) input before encoding (default: blended and sent as progressive, as RTDXT does)\n"
                "\t\tnuma  - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node, so that its pinned frame pool is local to the GPU; 0: left to the scheduler\n"
                "\t\tbatch - frames a busy worker may queue and encode in one launch (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
@@ -146,6 +150,9 @@ void *dxt_mi355x_compress_init(struct module *parent, const char *fmt)
                 } else if (strncasecmp(tok.c_str(), "batch_slices=", 13) == 0) { // internal: from mi355x::sharded_init
                         s->batch_slices = atoi(tok.c_str() + 13);
                         if (s->batch_slices < 1 || s->batch_slices > 16) s->batch_slices = 16;
+                } else if (strncasecmp(tok.c_str(), "deinterlace=", 12) == 0) {
+                        const char *v = tok.c_str() + 12;
+                        s->deinterlace = !(strcasecmp(v, "no") == 0 || strcasecmp(v, "off") == 0 || strcmp(v, "0") == 0);
                 } else if (strcasecmp(tok.c_str(), "ties=even") == 0) {
                         s->ties = UG_DXT_TIES_EVEN;
                 } else if (strcasecmp(tok.c_str(), "ties=away") == 0) {
@@ -192,7 +199,15 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
         // What the fused kernel reads natively gives the same bytes as "decode to target, then encode": RGBA -> RGB only drops
         // alpha (vc_copylineRGBAtoRGB), v210 -> UYVY is the >> 2 the v210 loader applies (vc_copylinev210, incl. its partial-group
         // tail: any width % 4 == 0).  Everything else is converted to `target` on the device first, with the decoders[] arithmetic.
-        const bool fused = wire == target || (wire == UG_PF_RGBA && target == UG_PF_RGB) || (wire == UG_PF_V210 && target == UG_PF_UYVY);
+        // INTERLACED_MERGED input: RTDXT -- the module this one stands in for (BASELINE configs[1]) -- blends the lines of the DECODED 8-bit frame
+        // before it encodes and announces the result as progressive (dxt_glsl.cpp:195-201,291-293 -> vc_deinterlace); cuda_dxt.cpp has no such
+        // step.  Done here on the device, on the frame in the `target` format: the shortcuts that skip that intermediate are not taken then.
+        s->interlaced_input = s->deinterlace && desc.interlacing == INTERLACED_MERGED;
+        s->target = target;
+        if (s->interlaced_input) {
+                MSG(NOTICE, "Enabling automatic deinterlacing.\n");
+        }
+        const bool fused = wire == target || (!s->interlaced_input && ((wire == UG_PF_RGBA && target == UG_PF_RGB) || (wire == UG_PF_V210 && target == UG_PF_UYVY)));
         if (fused) {
                 s->in_fmt = wire;
         } else {
@@ -226,6 +241,9 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
         struct video_desc compressed_desc = desc;
         compressed_desc.color_spec = s->out_codec;
         compressed_desc.tile_count = 1;
+        if (s->interlaced_input) {
+                compressed_desc.interlacing = PROGRESSIVE; // dxt_glsl.cpp:196-198
+        }
         s->pool.reconfigure(compressed_desc, s->out_len);
         return true;
 }
@@ -254,7 +272,8 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
         const void *enc_src = s->dev_in;
         // In place only when the frame lives on THIS state's GPU: with dev=<list> / several workers a frame can be handed to a
         // worker of another device, whose kernels must not dereference foreign memory -- that one is copied over (peer copy).
-        if (ug_hip_pointer_device(tx->tiles[0].data) == s->device && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
+        const bool blend_in_place = s->interlaced_input && s->pre_in == UG_PF_NONE; // the blend works in place: never on the caller's frame
+        if (!blend_in_place && ug_hip_pointer_device(tx->tiles[0].data) == s->device && ((uintptr_t) tx->tiles[0].data & 15) == 0) {
                 enc_src = tx->tiles[0].data;
         } else {
                 const bool dev = tx->mem_location == CUDA_MEM || ug_hip_pointer_is_device(tx->tiles[0].data);
@@ -266,6 +285,10 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
                 CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, wire_src, s->dev_pre, w, h, 0, 0, 0, 8, 16, s->stream),
                           "device swizzle failed", return {});
                 enc_src = s->dev_pre;
+        }
+        if (s->interlaced_input) { // vc_deinterlace on the decoded frame (dxt_glsl.cpp:291-293): dev_pre, or the uploaded copy in dev_in
+                CHECK_HIP(ug_hip_deinterlace_blend(const_cast<void *>(enc_src), (size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->target)), h, s->stream),
+                          "de-interlacing failed", return {});
         }
         CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, enc_src, s->dev_out, w, h, 0, 1, 0, 0, s->ties, s->stream),
                   "Encoding failed", return {});
@@ -322,6 +345,11 @@ std::vector<std::shared_ptr<video_frame>> dxt_mi355x_compress_batch(void *state,
                 }
         }
         const bool pre = s->pre_in != UG_PF_NONE;
+        if (s->interlaced_input) {
+                CHECK_HIP(ug_hip_deinterlace_blend_batch(pre ? s->b_pre : s->b_in, (size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->target)), h, n,
+                                                         pre ? s->b_pre_stride : s->b_in_stride, s->stream),
+                          "de-interlacing failed", return out);
+        }
         CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, pre ? s->b_pre : s->b_in, s->b_out, w, h, 0, n, pre ? s->b_pre_stride : s->b_in_stride, s->b_out_stride,
                                              s->ties, s->stream),
                   "Encoding failed", return out);
