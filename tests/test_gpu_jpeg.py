@@ -373,7 +373,7 @@ def test_block_parallel_coder_equals_wave_per_segment_coder(hip, po, sub, monkey
 @pytest.mark.parametrize("dims", [(640, 88), (1040, 81), (512, 64), (48, 16)])
 def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypatch):
     """Round 4: for UYVY input whose restart segments stay inside the 32-MCU strips (32 % ri == 0, mcu_w % ri == 0) ONE kernel does the
-    forward DCT, the quantiser, the Huffman coding and the stream placement -- the coefficients never reach HBM.  Its stream must be the
+    forward DCT, the quantiser, the Huffman coding and the byte stuffing -- the coefficients never reach HBM.  Its stream must be the
     stream of the front end + placing coder pair (UG_JPEG_FUSED=0) and of the front end + wave-per-segment coder + compaction triple
     (UG_JPEG_WAVE_KERNEL=1): full strips and a short last one (640 = 40 MCUs, 1040 = 65), one strip only, a picture narrower than a strip,
     picture heights that are no MCU multiple, low quality, and noise at q = 100 (blocks that overflow their private strings: the general
@@ -389,9 +389,10 @@ def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypat
             if mcu_w % ri:
                 continue
             out = {}
-            for tag, env in (("fused", {}), ("two", {"UG_JPEG_FUSED": "0"}), ("wave", {"UG_JPEG_WAVE_KERNEL": "1"})):
-                monkeypatch.delenv("UG_JPEG_FUSED", raising=False)
-                monkeypatch.delenv("UG_JPEG_WAVE_KERNEL", raising=False)
+            for tag, env in (("fused", {}), ("two", {"UG_JPEG_FUSED": "0"}), ("wave", {"UG_JPEG_WAVE_KERNEL": "1"}),
+                             ("look", {"UG_JPEG_LOOKBACK": "1"}), ("twolook", {"UG_JPEG_FUSED": "0", "UG_JPEG_LOOKBACK": "1"}), ("ticket", {"UG_JPEG_LOOKBACK": "1", "UG_JPEG_TICKET": "1"})):
+                for k in ("UG_JPEG_FUSED", "UG_JPEG_WAVE_KERNEL", "UG_JPEG_LOOKBACK", "UG_JPEG_TICKET"):
+                    monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 e = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
@@ -400,8 +401,12 @@ def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypat
                 e.close()
             assert out["fused"] == out["wave"], (sub, dims, q, ri, len(out["fused"]), len(out["wave"]))
             assert out["two"] == out["wave"] and out["fused2"] == out["wave"] and out["two2"] == out["wave"], (sub, dims, q, ri)
-    monkeypatch.delenv("UG_JPEG_FUSED", raising=False)
-    monkeypatch.delenv("UG_JPEG_WAVE_KERNEL", raising=False)
+            # the placement in one launch (decoupled look-back; UG_JPEG_LOOKBACK=1) -- what the default two-launch placement (slots + gather) falls
+            # back to when a workgroup's bytes exceed its slot --, with the workgroup index from blockIdx and from a start-order ticket
+            for tag in ("look", "look2", "twolook", "twolook2", "ticket", "ticket2"):
+                assert out[tag] == out["wave"], (tag, sub, dims, q, ri)
+    for k in ("UG_JPEG_FUSED", "UG_JPEG_WAVE_KERNEL", "UG_JPEG_LOOKBACK", "UG_JPEG_TICKET"):
+        monkeypatch.delenv(k, raising=False)
 
 
 @pytest.mark.gpu

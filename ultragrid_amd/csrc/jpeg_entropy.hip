@@ -352,6 +352,9 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
 // emission straight into the windows at the known bit positions (BitSink), in several passes when a segment exceeds its window,
 // counted first and emitted again for the write-out.  The stream is byte-identical to the wave-per-segment coder + compaction.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef UG_JPEG_SKIP_POSITIONS
+#define UG_JPEG_SKIP_POSITIONS 1 // inside a group that is not empty, still skip the positions that are zero in all 64 blocks of the wave
+#endif
 constexpr int kPrivWords = 16;         // private string of a block: 512 bits (a 4K q75 frame needs ~80)
 constexpr int kPrivStride = 17;        // + one dump word for what does not fit; odd stride: the lanes' rows start in different banks
 
@@ -396,6 +399,12 @@ __device__ __forceinline__ uint32_t walk_private(const uint32_t (&w)[32], const 
 #pragma unroll
                 for (int k = g == 0 ? 1 : kWalkGroup * g; k < kWalkGroup * (g + 1); k++) {
                         const int v = coef_at(w, k);
+#if UG_JPEG_SKIP_POSITIONS
+                        if (__ballot(v != 0) == 0) { // wave-uniform: this position is zero in all 64 blocks (two operations against ~30)
+                                run += 1u;
+                                continue;
+                        }
+#endif
                         const uint32_t neg = (uint32_t) (v >> 31);
                         const uint32_t a = ((uint32_t) v ^ neg) - neg;
                         const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
@@ -494,6 +503,11 @@ struct CodeArgs {
         long n_status;
         uint32_t gen;
         uint32_t *ticket;               // workgroups take their index from here, in the order they start (0 before and after every launch)
+        // two-launch placement (the default): the workgroup leaves its finished bytes in a slot of its own and its byte count in wg_bytes; the gather
+        // launch behind it moves the stretches to their places.  slots == NULL: one launch, the position comes from the look-back (status, gen)
+        uint8_t *slots;
+        size_t slot_bytes;
+        uint32_t *wg_bytes;
         unsigned long long *prof;       // UG_JPEG_PROF=1: kProfPhases accumulated s_memtime deltas + a workgroup count (tools/jpeg_phase_profile.py); else NULL
 };
 constexpr int kProfPhases = 10;
@@ -510,7 +524,7 @@ constexpr int kProfPhases = 10;
         }
 
 template <int WAVES, int SRC>
-__global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC == 420 ? 5 : 4))) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
 {
         constexpr int W = 64 * WAVES;
         // The look-back below waits for workgroups with smaller indices.  Index = blockIdx: the dispatcher starts the workgroups of a grid in
@@ -533,19 +547,26 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         }
         const int frame = (int) (index / (uint32_t) a.n_wg), wg = (int) (index - (uint32_t) frame * (uint32_t) a.n_wg);
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
-        // one buffer, three lives: the block hand-over (SRC = 0: per wave 32 rows of 8 x 16 B, 144 B apart; fused: the workgroup's blocks, 144 B
-        // apart), then [0, 17 W) the private strings and [17 W, 34 W) the segments' windows (16 words per block + one spare word per lane)
+        // one buffer, three lives: the block hand-over (SRC = 0: per wave 32 rows of 8 x 16 B, 144 B apart; fused: the workgroup's blocks, half a
+        // block at a time, 80 B apart), then [0, 17 W) the private strings and behind them the segments' windows (kWin words per block + one spare
+        // word per lane)
         constexpr int kStageRow = 9; // uint4 per row
         constexpr int kStageWords = 32 * kStageRow * 4; // per wave (SRC = 0)
-        constexpr int kBufWords = SRC == 0 ? 2 * kPrivStride * W : (ug_jpeg::kLdsPitch / 4) * W;
-        static_assert(kBufWords >= 2 * kPrivStride * W && kBufWords >= WAVES * kStageWords, "the three lives must fit");
+        // window words per block: 16 = the private strings' size; the 4:2:0 fused kernel takes 12 (384 bits per block on a segment's average, 5 x
+        // what a 4K q75 frame needs; beyond: the general path) -- that is what lets a sixth workgroup onto the CU
+        constexpr int kWin = SRC == 420 ? 12 : kWinWordsPerBlock;
+        constexpr int kHalfPitch = 20; // words: half a block (64 B) + 16 B, conflict-free 128-bit accesses of consecutive lanes (fused hand-over)
+        constexpr int kBufWords = (kPrivStride + kWin + 1) * W;
+        static_assert(kBufWords >= WAVES * kStageWords && kBufWords >= kHalfPitch * W, "the three lives must fit");
         __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
         constexpr int kMaxSeg = W / 3 + 1; // segments per workgroup: a segment has at least 3 blocks (4:4:4, restart interval 1)
-        __shared__ int lds_dc[W] /* DC values, then the inclusive bit positions */, lds_wave_total[WAVES], lds_seg_bits[kMaxSeg], lds_flag[2];
+        __shared__ int lds_wave_total[WAVES], lds_seg_bits[kMaxSeg], lds_flag[2];
         __shared__ uint32_t lds_seg_ff[kMaxSeg], lds_seg_off[kMaxSeg], lds_seg_done[kMaxSeg], lds_base;
-        int *const lds_incl = lds_dc;
         uint32_t *const priv = buf;
         uint32_t *const win = buf + kPrivStride * W;
+        // the DC values, then the inclusive bit positions, live in the spare words behind the windows (which only the general path's emission
+        // uses, later): with them the 4:2:0 kernel stays under 26 KB, the size at which six workgroups fit a CU's 160 KB
+        int *const lds_dc = (int *) (win + W * kWin), *const lds_incl = lds_dc;
         const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: say so, or the waves' branches compile as divergent ones)
         for (int i = tid; i < 512; i += W) {
                 const int sym = i & 255;
@@ -689,19 +710,29 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                         }
                 }
                 UG_PHASE(0) // pixels -> quantised block (wave 0's view, like all the marks)
-                // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU)
+                // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU).  Half a
+                // block at a time -- every lane stores the first 64 bytes of the block it made and takes the first 64 of the block it will code into
+                // the registers just stored, then the same for the second halves: no second register set, and 15 KB of LDS instead of 27
                 uint4 *const store = (uint4 *) buf;
-                constexpr int kRow = ug_jpeg::kLdsPitch / 16;
-#pragma unroll
-                for (int i = 0; i < 8; i++) store[tid * kRow + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-                __syncthreads();
+                constexpr int kRow = kHalfPitch / 4; // uint4 per row
                 const int m = sl * ri + ml; // MCU of the strip
                 const int id = b < ybl ? (SRC == 420 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                        uint4 r = store[(active ? id : 0) * kRow + i];
-                        if (!active) r = make_uint4(0, 0, 0, 0);
-                        w[4 * i] = r.x; w[4 * i + 1] = r.y; w[4 * i + 2] = r.z; w[4 * i + 3] = r.w;
+                for (int half = 0; half < 2; half++) {
+                        if (half) __syncthreads(); // the first halves have been read
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                                const int k = 16 * half + 4 * i;
+                                store[tid * kRow + i] = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                                const int k = 16 * half + 4 * i;
+                                uint4 r = store[(active ? id : 0) * kRow + i];
+                                if (!active) r = make_uint4(0, 0, 0, 0);
+                                w[k] = r.x; w[k + 1] = r.y; w[k + 2] = r.z; w[k + 3] = r.w;
+                        }
                 }
         }
         // DC difference: the previous block of the same component sits `back` lanes below (luma: the previous luma block of the
@@ -722,9 +753,9 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         const uint32_t dc_str = active ? ((de & 0xffffu) << dsize) | dc_vb : 0u, dc_n = active ? (de >> 16) + dsize : 0u;
         // the windows start out zero (this lane's 16 words; the hand-over buffer they overlay has been read: the barrier above)
         {
-                uint4 *const z = (uint4 *) (win + tid * kWinWordsPerBlock);
+                uint4 *const z = (uint4 *) (win + tid * kWin);
 #pragma unroll
-                for (int i = 0; i < kWinWordsPerBlock / 4; i++) z[i] = make_uint4(0, 0, 0, 0);
+                for (int i = 0; i < kWin / 4; i++) z[i] = make_uint4(0, 0, 0, 0);
         }
         // ---- the walk: code into the private string, length as a by-product ----
         uint32_t *const row = priv + tid * kPrivStride;
@@ -751,12 +782,16 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
         const int seg_base = first_tid ? lds_incl[first_tid - 1] : 0;
         const int seg_bits = sl < nseg_wg ? lds_incl[min(first_tid + max(n_blk, 1) - 1, W - 1)] - seg_base : 0; // total bits of this lane's segment
         if (j == 0 && sl < nseg_wg) lds_seg_bits[sl] = seg_bits;
-        uint32_t *const mywin = win + first_tid * kWinWordsPerBlock; // the segment's window: kWinWordsPerBlock words per block of the segment
-        const int cap = S * kWinWordsPerBlock;                  // words of a segment's window
+        uint32_t *const mywin = win + first_tid * kWin; // the segment's window: kWin words per block of the segment
+        const int cap = S * kWin;                               // words of a segment's window
         const int seg_words = (seg_bits + 31) >> 5;
         const int p0 = excl - seg_base;                          // bit position of this lane's block in its segment
+        if (seg_words > cap) { // a segment beyond its window (possible where the windows are smaller than the private strings): general path, several passes
+                lds_flag[0] = 1;
+                atomicMax(&lds_flag[1], seg_words);
+        }
+        if (kWin < kWinWordsPerBlock) __syncthreads(); // (with full-size windows no segment of blocks that fit their strings can exceed them)
         const bool general = lds_flag[0] != 0;
-        if (general && seg_words > cap) atomicMax(&lds_flag[1], seg_words);
         // zero the words the segment uses in a pass (+ one for the padding), cooperatively: lane j takes words j, j + S, ...
         auto zero_window = [&](int lo_idx) {
                 if (sl < nseg_wg) {
@@ -774,7 +809,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                 zero_window(lo_idx);
                 if (active) { // words outside this pass's window go to a spare word of the lane's own (no hot spot)
                         bool unused = false;
-                        BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) lo_idx, (uint32_t) cap, win + W * kWinWordsPerBlock + tid };
+                        BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) lo_idx, (uint32_t) cap, win + W * kWin + tid };
                         sink.append(dc_str, dc_n);
                         (void) walk_block<true, true>(w, tab, zrl, eob, sink, unused);
                         sink.finish();
@@ -787,7 +822,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                 const int padw = (bits >> 5) - lo_idx; // window word that holds the last, partial byte
                 if (lane == 0 && (bits & 7) && padw >= 0 && padw < cap) {
                         const int pad = 8 - (bits & 7);
-                        win[s2 * S * kWinWordsPerBlock + padw] |= ((1u << pad) - 1u) << (32 - (bits & 31) - pad);
+                        win[s2 * S * kWin + padw] |= ((1u << pad) - 1u) << (32 - (bits & 31) - pad);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -798,7 +833,7 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                 for (int s2 = wv; s2 < nseg_wg; s2 += WAVES) {
                         pad_segment(s2, lo_idx);
                         const int bits = lds_seg_bits[s2];
-                        const uint32_t *const sw = win + s2 * S * kWinWordsPerBlock;
+                        const uint32_t *const sw = win + s2 * S * kWin;
                         const int nbytes = (bits + 7) >> 3;
                         const int nw = min(cap, ((nbytes + 3) >> 2) - lo_idx); // words of the segment in this pass
                         int ff = 0;
@@ -820,12 +855,21 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                                 if (s2 < nseg_wg) lds_seg_off[s2] = carry + (uint32_t) (inc - sz);
                                 carry += (uint32_t) __builtin_amdgcn_readlane(inc, 63);
                         }
-                        const uint32_t before = lookback_exclusive(a.status + (long) frame * a.n_status, wg, carry, a.gen, lane, a.total_pinned + kMaxBatch);
-                        if (lane == 0) lds_base = (uint32_t) a.header_len + before;
+                        if (a.slots != nullptr) { // wave-uniform
+                                if (lane == 0) {
+                                        a.wg_bytes[(size_t) frame * a.n_wg + wg] = carry;
+                                        lds_base = 0;
+                                        if ((size_t) carry > a.slot_bytes) a.total_pinned[kMaxBatch + 1] = 1u; // does not fit its slot: the host runs the call again, with the look-back
+                                }
+                        } else {
+                                const uint32_t before = lookback_exclusive(a.status + (long) frame * a.n_status, wg, carry, a.gen, lane, a.total_pinned + kMaxBatch);
+                                if (lane == 0) lds_base = (uint32_t) a.header_len + before;
+                        }
                 }
                 __syncthreads();
         };
-        uint8_t *const out = a.out + (size_t) frame * a.out_stride;
+        uint8_t *const out = a.slots != nullptr ? a.slots + ((size_t) frame * a.n_wg + wg) * a.slot_bytes : a.out + (size_t) frame * a.out_stride;
+        const size_t capacity = a.slots != nullptr ? a.slot_bytes : a.capacity;
         // the window words of this pass to their place in the stream, 0x00 after every 0xFF; after the last pass RSTm / EOI
         auto write_pass = [&](int lo_idx, bool last_pass, bool pad) {
 #pragma unroll 1
@@ -833,10 +877,10 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                         if (pad) pad_segment(s2, lo_idx); // (a pass that was emitted again for the write-out)
                         const int sg = seg0 + s2;
                         const int bits = lds_seg_bits[s2];
-                        const uint32_t *const sw = win + s2 * S * kWinWordsPerBlock;
+                        const uint32_t *const sw = win + s2 * S * kWin;
                         const int nbytes = (bits + 7) >> 3;
                         const uint32_t start = lds_base + lds_seg_off[s2], end = start + (uint32_t) nbytes + lds_seg_ff[s2] + 2u;
-                        const bool fits = (size_t) end <= a.capacity; // would not fit: nothing of this segment is written, the host reports the needed size
+                        const bool fits = (size_t) end <= capacity; // would not fit: nothing of this segment is written, the host reports the needed size
                         const uint32_t done = lds_seg_done[s2];
                         uint8_t *const d = out + start + done;
                         const int nw = min(cap, ((nbytes + 3) >> 2) - lo_idx);
@@ -867,12 +911,12 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                                                 out[end - 2] = 0xFF;
                                                 out[end - 1] = sg == a.n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (sg & 7));
                                         }
-                                        if (sg == a.n_seg - 1) a.total_pinned[frame] = end;
+                                        if (sg == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = end;
                                 }
                         }
                 }
         };
-        if (wg == 0) { // the first workgroup also lays down SOI .. SOS
+        if (wg == 0 && a.slots == nullptr) { // the first workgroup also lays down SOI .. SOS
                 for (int i = tid; i < a.header_len; i += W) out[i] = a.header[i];
         }
         UG_PHASE(3) // positions (two barriers: the other waves' walks end here)
@@ -921,6 +965,45 @@ __global__ __launch_bounds__(64 * WAVES) void jpeg_code_kernel(const CodeArgs a,
                         }
                 }
         }
+}
+
+// The second launch of the two-launch placement: one wave per workgroup of the coder.  Its stretch starts where the stretches before it end (the
+// byte counts of a frame's workgroups: 4 KB, summed by the wave itself); the bytes come out of the 16-byte aligned slot and go to an arbitrary
+// byte address: whole destination words assembled from two source words (v_alignbyte), the ragged ends byte by byte.
+// Why two launches: in one launch every workgroup waits ~5 us (of its ~20) for its position -- a cross-CU hand-off costs ~3 us under load, in the
+// consumer's memory queue (MI355X_MICROARCH.md "handoff-1to1") --, with its LDS held all the while; the kernel boundary orders the same data for free.
+__global__ __launch_bounds__(256) void jpeg_gather_kernel(const uint8_t *__restrict__ slots, size_t slot_bytes, const uint32_t *__restrict__ wg_bytes, int n_wg,
+                                                          uint8_t *__restrict__ out, size_t out_stride, size_t capacity, const uint8_t *__restrict__ header,
+                                                          int header_len, uint32_t *__restrict__ total_pinned)
+{
+        const int frame = blockIdx.y, lane = threadIdx.x & 63;
+        const int wg = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+        out += (size_t) frame * out_stride;
+        if (blockIdx.x == 0) { // SOI .. SOS
+                for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
+        }
+        if (wg >= n_wg) return; // wave-uniform
+        const uint32_t *const sizes = wg_bytes + (size_t) frame * n_wg;
+        int sum = 0;
+        for (int i = lane; i < wg; i += 64) sum += (int) sizes[i];
+        const uint32_t n = sizes[wg];
+        const uint32_t off = (uint32_t) header_len + (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan(sum, lane), 63), end = off + n;
+        if (wg == n_wg - 1 && lane == 0) total_pinned[frame] = end; // pinned host memory mapped into the device: the length needs no copy back
+        if ((size_t) end > capacity || (size_t) n > slot_bytes) return; // would not fit: the host reports the needed size from the total
+        const uint8_t *const s = slots + ((size_t) frame * n_wg + wg) * slot_bytes;
+        uint8_t *const d = out + off;
+        const uint32_t head = min(n, (uint32_t) ((4u - ((uintptr_t) d & 3u)) & 3u)); // bytes up to the first aligned destination word
+        if ((uint32_t) lane < head) d[lane] = s[lane];
+        const uint32_t rem = n - head, nd = rem >> 2, r = head & 3u;
+        const uint32_t *const sw = (const uint32_t *) s;
+        uint32_t *const dw = (uint32_t *) (d + head);
+        for (uint32_t i = lane; i < nd; i += 64) {
+                const uint32_t q = (head >> 2) + i; // source word that holds the first of the four bytes (head < 4: q = i)
+                const uint32_t lo = sw[q], hi = sw[q + 1]; // (the slot is padded: the word behind the last byte exists)
+                dw[i] = __builtin_amdgcn_alignbyte(hi, lo, r); // ({hi, lo} >> 8 r)
+        }
+        const uint32_t tail = rem & 3u;
+        if ((uint32_t) lane < tail) d[head + 4 * nd + lane] = s[head + 4 * nd + lane];
 }
 
 // one wave per segment: find its position (see kChunk), move its bytes there, inserting 0x00 after every 0xFF (T.81 B.1.1.5), then
@@ -985,6 +1068,10 @@ struct Encoder {
         unsigned long long *status; // look-back words of the placing coder, n_mcu per frame (never cleared: they carry the call's generation)
         uint32_t gen;
         uint32_t *ticket;       // start-order counter of the placing coder's workgroups (self-resetting)
+        uint8_t *slots;         // two-launch placement: a slot per workgroup of the coder (grown on demand), and the workgroups' byte counts
+        size_t slots_cap;
+        uint32_t *wg_bytes;
+        bool two_launch;        // UG_JPEG_LOOKBACK=1 switches to the one-launch placement (decoupled look-back) for A/B
         unsigned long long *prof; // UG_JPEG_PROF=1: phase clock sums of the placing coder (device memory, kProfPhases + 1 words)
         bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
         uint8_t *header_dev;
@@ -1057,11 +1144,12 @@ void free_raw(Encoder *e)
 
 void free_workspace(Encoder *e)
 {
-        for (void **p : { (void **) &e->cy, (void **) &e->cb, (void **) &e->cr, (void **) &e->status }) {
+        for (void **p : { (void **) &e->cy, (void **) &e->cb, (void **) &e->cr, (void **) &e->status, (void **) &e->slots, (void **) &e->wg_bytes }) {
                 if (*p) (void) hipFree(*p);
                 *p = nullptr;
         }
         e->batch_cap = 0;
+        e->slots_cap = 0;
         free_raw(e);
 }
 
@@ -1076,6 +1164,8 @@ hipError_t alloc_workspace(Encoder *e, int frames)
         alloc((void **) &e->cb, (size_t) bs.coef_c * 2);
         alloc((void **) &e->cr, (size_t) bs.coef_c * 2);
         alloc((void **) &e->status, (size_t) e->n_mcu * 8);
+        alloc((void **) &e->wg_bytes, (size_t) e->n_mcu * 4);
+        e->slots = nullptr; // (grown on first use)
         if (err == hipSuccess) err = hipMemset(e->status, 0, (size_t) e->n_mcu * 8 * frames);
         if (err == hipSuccess) e->batch_cap = frames;
         return err;
@@ -1144,6 +1234,7 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         e->force_wave_kernel = getenv("UG_JPEG_WAVE_KERNEL") != nullptr && getenv("UG_JPEG_WAVE_KERNEL")[0] == '1';
         e->allow_fused = !(getenv("UG_JPEG_FUSED") != nullptr && getenv("UG_JPEG_FUSED")[0] == '0');
         e->use_ticket = getenv("UG_JPEG_TICKET") != nullptr && getenv("UG_JPEG_TICKET")[0] == '1';
+        e->two_launch = !(getenv("UG_JPEG_LOOKBACK") != nullptr && getenv("UG_JPEG_LOOKBACK")[0] == '1');
         e->sub = subsampling;
         e->hs = subsampling == 444 ? 1 : 2; e->vs = subsampling == 420 ? 2 : 1; e->ybl = e->hs * e->vs;
         e->mcu_w = (width + 8 * e->hs - 1) / (8 * e->hs); e->mcu_h = (height + 8 * e->vs - 1) / (8 * e->vs); e->n_mcu = e->mcu_w * e->mcu_h;
@@ -1265,7 +1356,8 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         }
         if (rc != UG_HIP_SUCCESS) return rc;
         e->total_host[kMaxBatch] = 0;
-        if (!wave_path) {
+        // the block-parallel coder, fused or behind the front end; two_launch: slots + gather launch, else the one-launch placement (look-back)
+        auto launch_coder = [&](bool two_launch) -> int {
                 if (++e->gen >= (1u << 30)) { // the status words carry the call's generation in 30 bits: start over on clean words
                         UG_HIP_TRY(hipMemsetAsync(e->status, 0, (size_t) e->n_mcu * 8 * e->batch_cap, st));
                         e->gen = 1;
@@ -1276,22 +1368,51 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
                 a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
+                int waves, kwin = 16;
                 if (fused) {
                         a.strips = (e->mcu_w + 31) / 32;
                         a.n_wg = a.strips * e->mcu_h;
                         a.G = 32 / e->ri;
-                        if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), dim3((unsigned) a.n_wg * frames), dim3(192), 0, st, a, (const float *) e->div);
-                        else hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), dim3((unsigned) a.n_wg * frames), dim3(128), 0, st, a, (const float *) e->div);
+                        waves = e->sub == 420 ? 3 : 2;
+                        if (e->sub == 420) kwin = 12;
                 } else {
                         // waves per workgroup: the count that leaves the fewest lanes idle (fewer waves on a tie)
-                        int waves = 1;
+                        waves = 1;
                         for (int k = 1; k <= 4; k++) {
                                 if (64 * k >= S && (64 * k / S) * S * (64 * waves) > (64 * waves / S) * S * (64 * k)) waves = k;
                                 if (64 * waves < S) waves = k;
                         }
                         a.G = 64 * waves / S;
                         a.n_wg = (e->n_seg + a.G - 1) / a.G;
-                        const dim3 grid((unsigned) a.n_wg * frames);
+                }
+                if (two_launch) {
+                        // a slot holds whatever the one-pass path can produce: every window full, every byte stuffed, the markers (+ the padding the
+                        // gather's word reads may touch); a workgroup on the general path that needs more reports it and the call runs again, one launch
+                        a.slot_bytes = ((size_t) 64 * waves * kwin * 4 * 2 + 2 * (size_t) a.G + 16 + 255) / 256 * 256;
+                        const size_t need = a.slot_bytes * (size_t) a.n_wg * (size_t) frames;
+                        if (need > e->slots_cap) {
+                                if (e->slots) (void) hipFree(e->slots);
+                                e->slots = nullptr;
+                                e->slots_cap = 0;
+                                const size_t want = a.slot_bytes * (size_t) a.n_wg * (size_t) e->batch_cap;
+                                const hipError_t err = hipMalloc((void **) &e->slots, want);
+                                if (err != hipSuccess) {
+                                        (void) hipGetLastError();
+                                        two_launch = false; // no room for the slots: the one-launch placement needs none
+                                } else {
+                                        e->slots_cap = want;
+                                }
+                        }
+                }
+                if (two_launch) {
+                        a.slots = e->slots;
+                        a.wg_bytes = e->wg_bytes;
+                }
+                const dim3 grid((unsigned) a.n_wg * frames);
+                if (fused) {
+                        if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), grid, dim3(192), 0, st, a, (const float *) e->div);
+                        else hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), grid, dim3(128), 0, st, a, (const float *) e->div);
+                } else {
                         switch (waves) {
                         case 1: hipLaunchKernelGGL((jpeg_code_kernel<1, 0>), grid, dim3(64), 0, st, a, (const float *) e->div); break;
                         case 2: hipLaunchKernelGGL((jpeg_code_kernel<2, 0>), grid, dim3(128), 0, st, a, (const float *) e->div); break;
@@ -1299,6 +1420,17 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                         default: hipLaunchKernelGGL((jpeg_code_kernel<4, 0>), grid, dim3(256), 0, st, a, (const float *) e->div); break;
                         }
                 }
+                if (two_launch) {
+                        hipLaunchKernelGGL(jpeg_gather_kernel, dim3((unsigned) ((a.n_wg + 3) / 4), (unsigned) frames), dim3(256), 0, st, (const uint8_t *) e->slots, a.slot_bytes,
+                                           (const uint32_t *) e->wg_bytes, a.n_wg, (uint8_t *) out_dev, out_stride, out_capacity, (const uint8_t *) e->header_dev,
+                                           (int) e->header.size(), e->total_host_dev);
+                }
+                return UG_HIP_SUCCESS;
+        };
+        e->total_host[kMaxBatch + 1] = 0;
+        if (!wave_path) {
+                const int lrc = launch_coder(e->two_launch);
+                if (lrc != UG_HIP_SUCCESS) return lrc;
         } else {
                 if (frames > e->raw_cap) {
                         const hipError_t err = alloc_raw(e, e->batch_cap);
@@ -1317,6 +1449,13 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         }
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipStreamSynchronize(st)); // ONE synchronisation for the batch
+        if (!wave_path && e->total_host[kMaxBatch + 1] != 0) { // a workgroup's bytes did not fit its slot (near-lossless quality on noise): once more, in one launch
+                e->total_host[kMaxBatch + 1] = 0;
+                const int lrc = launch_coder(false);
+                if (lrc != UG_HIP_SUCCESS) return lrc;
+                UG_HIP_LAUNCH_CHECK();
+                UG_HIP_TRY(hipStreamSynchronize(st));
+        }
         if (e->total_host[kMaxBatch] != 0) { // a workgroup gave up waiting for an earlier one: reported, never waited out
                 (void) hipMemset(e->ticket, 0, 4);
                 if (!e->use_ticket) { // the start order was not the index order after all: from now on the index IS the start order; once more
