@@ -568,16 +568,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         // uses, later): with them the 4:2:0 kernel stays under 26 KB, the size at which six workgroups fit a CU's 160 KB
         int *const lds_dc = (int *) (win + W * kWin), *const lds_incl = lds_dc;
         const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: say so, or the waves' branches compile as divergent ones)
-        for (int i = tid; i < 512; i += W) {
-                const int sym = i & 255;
-                ac_tab[i >> 8][sym] = (sym == 0x00 || sym == 0xF0) ? 0u : kAcTab[i >> 8][sym]; // EOB / ZRL are emitted explicitly
-        }
-        if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
-        if (tid < 2) lds_flag[tid] = 0;
-        if (tid < kMaxSeg) {
-                lds_seg_ff[tid] = 0;
-                lds_seg_done[tid] = 0;
-        }
+        // (the Huffman tables are copied to LDS further down, behind the block loads: nothing ahead of the first barrier needs them, and their
+        // memory round trip then runs beside the pixels' instead of in front of it)
+        auto init_tables = [&]() {
+                for (int i = tid; i < 512; i += W) {
+                        const int sym = i & 255;
+                        ac_tab[i >> 8][sym] = (sym == 0x00 || sym == 0xF0) ? 0u : kAcTab[i >> 8][sym]; // EOB / ZRL are emitted explicitly
+                }
+                if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
+                if (tid < 2) lds_flag[tid] = 0;
+                if (tid < kMaxSeg) {
+                        lds_seg_ff[tid] = 0;
+                        lds_seg_done[tid] = 0;
+                }
+        };
         const int ybl = a.hs * a.vs, per_mcu = ybl + 2, S = a.S, ri = a.ri;
         // ---- which segments, which block ----
         int seg0, nseg_wg, strip_mcu0 = 0, strip_my = 0, strip_mcus = 0;
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         const int comp = b < ybl ? 0 : a.ctab;
         uint32_t w[32];
         if (SRC == 0) {
+                init_tables();
                 const int16_t *const cy = a.cy + frame * a.coef_y, *const cb = a.cb + frame * a.coef_c, *const cr = a.cr + frame * a.coef_c;
                 const int m = m_first + ml;
                 const int my = m / a.mcu_w, mx = m - my * a.mcu_w;
@@ -709,6 +714,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 for (int i = 0; i < 32; i++) w[i] = 0;
                         }
                 }
+                init_tables();
                 UG_PHASE(0) // pixels -> quantised block (wave 0's view, like all the marks)
                 // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU).  Half a
                 // block at a time -- every lane stores the first 64 bytes of the block it made and takes the first 64 of the block it will code into
@@ -984,24 +990,46 @@ __global__ __launch_bounds__(256) void jpeg_gather_kernel(const uint8_t *__restr
         }
         if (wg >= n_wg) return; // wave-uniform
         const uint32_t *const sizes = wg_bytes + (size_t) frame * n_wg;
-        int sum = 0;
-        for (int i = lane; i < wg; i += 64) sum += (int) sizes[i];
+        const uint8_t *const s = slots + ((size_t) frame * n_wg + wg) * slot_bytes;
+        const uint32_t *const sw = (const uint32_t *) s;
+        // everything the wave needs from memory is requested before anything is waited for: its own byte count, the counts before it, and the
+        // first kAhead x 64 words of its slot with their right-hand neighbours (a slot is larger than that whatever the count turns out to be) --
+        // one memory round trip instead of three dependent ones
+        constexpr int kAhead = 5; // 1280 bytes: a 4K q75 stretch is ~1.4 KB
+        uint32_t lo[kAhead], hi[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; k++) {
+                lo[k] = sw[lane + 64 * k];
+                hi[k] = sw[lane + 64 * k + 1];
+        }
         const uint32_t n = sizes[wg];
+        int sum = 0;
+#pragma unroll 1
+        for (int base = 0; base < wg; base += 512) { // eight loads in flight per lane (one at a time: up to 17 dependent L2 round trips per wave)
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                        const int i = base + lane + 64 * k;
+                        v[k] = i < wg ? sizes[i] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += (int) v[k];
+        }
         const uint32_t off = (uint32_t) header_len + (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan(sum, lane), 63), end = off + n;
         if (wg == n_wg - 1 && lane == 0) total_pinned[frame] = end; // pinned host memory mapped into the device: the length needs no copy back
         if ((size_t) end > capacity || (size_t) n > slot_bytes) return; // would not fit: the host reports the needed size from the total
-        const uint8_t *const s = slots + ((size_t) frame * n_wg + wg) * slot_bytes;
         uint8_t *const d = out + off;
         const uint32_t head = min(n, (uint32_t) ((4u - ((uintptr_t) d & 3u)) & 3u)); // bytes up to the first aligned destination word
         if ((uint32_t) lane < head) d[lane] = s[lane];
         const uint32_t rem = n - head, nd = rem >> 2, r = head & 3u;
-        const uint32_t *const sw = (const uint32_t *) s;
         uint32_t *const dw = (uint32_t *) (d + head);
-        for (uint32_t i = lane; i < nd; i += 64) {
-                const uint32_t q = (head >> 2) + i; // source word that holds the first of the four bytes (head < 4: q = i)
-                const uint32_t lo = sw[q], hi = sw[q + 1]; // (the slot is padded: the word behind the last byte exists)
-                dw[i] = __builtin_amdgcn_alignbyte(hi, lo, r); // ({hi, lo} >> 8 r)
+        // destination word i = slot bytes head + 4 i .. + 3 = ({sw[i + 1], sw[i]} >> 8 head)  (head < 4)
+#pragma unroll
+        for (int k = 0; k < kAhead; k++) {
+                const uint32_t i = lane + 64 * k;
+                if (i < nd) dw[i] = __builtin_amdgcn_alignbyte(hi[k], lo[k], r);
         }
+        for (uint32_t i = lane + 64 * kAhead; i < nd; i += 64) dw[i] = __builtin_amdgcn_alignbyte(sw[i + 1], sw[i], r);
         const uint32_t tail = rem & 3u;
         if ((uint32_t) lane < tail) d[head + 4 * nd + lane] = s[head + 4 * nd + lane];
 }
