@@ -1,0 +1,15 @@
+#!/bin/bash
+# gpurun_out/r04m/ (tools/gpu_r04_m.sh on the GPU box) -> profiles/r04_*
+set -e
+S=${1:-gpurun_out/r04m}; D=profiles
+cp $S/bench_line.json $D/r04_bench_line.json
+cp $S/bench_4k-uyvy-jpeg420.json $D/r04_bench_4k_jpeg420.json
+cp $S/8k-v210.txt $D/r04_pmc_8k_v210.txt; cp $S/1080p-rgb-dxt1.txt $D/r04_pmc_1080p_rgb_dxt1.txt; cp $S/4k-uyvy-jpeg420.txt $D/r04_pmc_4k_uyvy_jpeg420.txt
+cp $S/pmc_traffic.json $D/pmc_traffic.json
+cp $S/kernels.json $D/r04_kernels.json; grep -v amdgpu.ids $S/kernels_table.txt > $D/r04_all_kernels_table.txt
+cp $S/decode.json $D/r04_decode.json; grep -v amdgpu.ids $S/decode.txt > $D/r04_decode.txt
+cp $S/pixfmt_all_8k.json $D/r04_pixfmt_all_8k.json
+tail -2 $S/pytest.log | head -1 > $D/r04_gpu_tests.txt
+grep -E "^==|THROUGHPUT|^OK" $S/soak.txt | cut -c1-200 > $D/r04_soak_numa_ab.txt
+grep -v "CatArray\|at::native" $S/jpeg_batch_traffic.txt | sed 's#/tmp/code/[^ ]*/gpurun_out/#gpurun_out/#' > $D/r04_jpeg_batch_traffic.txt
+ls $D | grep -c r04

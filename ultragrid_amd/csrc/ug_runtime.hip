@@ -172,15 +172,33 @@ hipError_t lanes_of(int device, Lanes &out)
         out = l;
         return hipSuccess;
 }
-// `to` waits for everything queued on `from` so far
-hipError_t chain(hipStream_t from, hipStream_t to)
+// `to` waits for everything queued on `from` so far.  The event is the calling thread's own (two per device, one per direction of the
+// hand-over, created on first use and destroyed with the thread): a wait takes the event's state at the time of the call, so the next record
+// on the same event cannot disturb it, and a copy costs two records + two waits instead of two event creations and destructions on top.
+struct ThreadEvents {
+        hipEvent_t ev[kMaxDevices][2] = {};
+        ~ThreadEvents()
+        {
+                for (auto &d : ev) {
+                        for (hipEvent_t e : d) {
+                                if (e) (void) hipEventDestroy(e);
+                        }
+                }
+        }
+};
+thread_local ThreadEvents t_events;
+hipError_t chain(int device, int which, hipStream_t from, hipStream_t to)
 {
-        hipEvent_t ev;
-        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e != hipSuccess) return e;
-        e = hipEventRecord(ev, from);
+        hipEvent_t &ev = t_events.ev[device][which];
+        if (ev == nullptr) {
+                const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                        ev = nullptr;
+                        return e;
+                }
+        }
+        hipError_t e = hipEventRecord(ev, from);
         if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
-        (void) hipEventDestroy(ev); // released by the runtime once it has completed
         return e;
 }
 } // namespace
@@ -190,9 +208,9 @@ int ug_hip_upload_ordered(int device, void *dst_dev, const void *src, size_t cou
         if (!lanes_enabled()) return ug_hip_memcpy_async(dst_dev, src, count, kind, then_stream);
         Lanes l;
         UG_HIP_TRY(lanes_of(device, l));
-        UG_HIP_TRY(chain((hipStream_t) then_stream, l.up)); // the destination may still be read by what the caller queued before (its previous frame)
+        UG_HIP_TRY(chain(device, 0, (hipStream_t) then_stream, l.up)); // the destination may still be read by what the caller queued before (its previous frame)
         UG_HIP_TRY(hipMemcpyAsync(dst_dev, src, count, kind_of(kind), l.up));
-        UG_HIP_TRY(chain(l.up, (hipStream_t) then_stream));
+        UG_HIP_TRY(chain(device, 1, l.up, (hipStream_t) then_stream));
         return UG_HIP_SUCCESS;
 }
 
@@ -201,9 +219,9 @@ int ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, siz
         if (!lanes_enabled()) return ug_hip_memcpy_async(dst_host, src_dev, count, UG_HIP_MEMCPY_DEVICE_TO_HOST, after_stream);
         Lanes l;
         UG_HIP_TRY(lanes_of(device, l));
-        UG_HIP_TRY(chain((hipStream_t) after_stream, l.down));
+        UG_HIP_TRY(chain(device, 0, (hipStream_t) after_stream, l.down));
         UG_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, count, hipMemcpyDeviceToHost, l.down));
-        UG_HIP_TRY(chain(l.down, (hipStream_t) after_stream)); // ug_hip_stream_sync(after_stream) now also waits for the download
+        UG_HIP_TRY(chain(device, 1, l.down, (hipStream_t) after_stream)); // ug_hip_stream_sync(after_stream) now also waits for the download
         return UG_HIP_SUCCESS;
 }
 

@@ -334,15 +334,17 @@ std::vector<std::shared_ptr<video_frame>> dxt_mi355x_compress_batch(void *state,
                         return one_by_one();
                 }
         }
+        // all the uploads of the batch first, then the conversions: the upload lane of the device is shared by every worker, and an upload queued
+        // behind this worker's conversion kernels would keep the other workers' uploads waiting with it
         for (int f = 0; f < n; f++) {
                 const bool dev = in[f]->mem_location == CUDA_MEM || ug_hip_pointer_is_device(in[f]->tiles[0].data);
                 char *slice = (char *) s->b_in + f * s->b_in_stride;
                 CHECK_HIP(ug_hip_upload_ordered(s->device, slice, in[f]->tiles[0].data, s->in_len, dev ? UG_HIP_MEMCPY_DEVICE_TO_DEVICE : UG_HIP_MEMCPY_HOST_TO_DEVICE, s->stream),
                           "upload failed", return out);
-                if (s->pre_in != UG_PF_NONE) {
-                        CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, slice, (char *) s->b_pre + f * s->b_pre_stride, w, h, 0, 0, 0, 8, 16, s->stream),
-                                  "device swizzle failed", return out);
-                }
+        }
+        for (int f = 0; f < n && s->pre_in != UG_PF_NONE; f++) {
+                CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, (char *) s->b_in + f * s->b_in_stride, (char *) s->b_pre + f * s->b_pre_stride, w, h, 0, 0, 0, 8, 16, s->stream),
+                          "device swizzle failed", return out);
         }
         const bool pre = s->pre_in != UG_PF_NONE;
         if (s->interlaced_input) {

@@ -329,6 +329,7 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
         // every frame into its slice: upload (or device-to-device), wire -> target -> encoder input with the pixfmt_conv.c arithmetic
         const char *enc_base = (const char *) s->b_in;
         size_t enc_stride = s->b_in_stride;
+        // (all the uploads of the batch first, then the conversions: the device's upload lane is shared by every worker -- ADVICE r3)
         for (int f = 0; f < n; f++) {
                 const bool on_dev = in[f]->mem_location == CUDA_MEM || ug_hip_pointer_is_device(in[f]->tiles[0].data);
                 char *slice = (char *) s->b_in + f * s->b_in_stride;
@@ -336,7 +337,9 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
                         MSG(ERROR, "upload failed: %s\n", ug_hip_last_error_string());
                         return out;
                 }
-                const void *cur = slice;
+        }
+        for (int f = 0; f < n; f++) {
+                const void *cur = (char *) s->b_in + f * s->b_in_stride;
                 if (s->wire != s->target) {
                         void *t = (char *) s->b_target + f * s->b_target_stride;
                         if (ug_hip_pixfmt_convert(s->wire, s->target, cur, t, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) return out;
