@@ -13,7 +13,7 @@ import torch
 from ultragrid_amd import lib as L, synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--sub", type=int, default=420)
+ap.add_argument("--sub", type=int, default=420, help="420 / 422: UYVY input; 444: RGB input (R, G, B components, gpujpeg.cpp:303-305)")
 ap.add_argument("--n", type=int, default=8)
 ap.add_argument("--seconds", type=float, default=1.0)
 ap.add_argument("--only", choices=["both", "batch", "single"], default="both", help="profile runs: one call form only, so that per-kernel averages are not a blend")
@@ -21,9 +21,11 @@ ap.add_argument("--calls", type=int, default=0, help="exactly this many timed ca
 a = ap.parse_args()
 l = L.load()
 w, h = 3840, 2160
-base = torch.from_numpy(synth.s2_video("UYVY", w, h)).cuda()
+rgb = a.sub == 444
+fmt_in, pf_in, line = ("RGB", L.PF_RGB, 3 * w) if rgb else ("UYVY", L.PF_UYVY, 2 * w)
+base = torch.from_numpy(synth.s2_video("UYVY", w, h) if not rgb else synth.frame("S2", "RGB", w, h)).cuda()
 sets = 4
-src = torch.stack([torch.stack([torch.roll(base, 7680 * 37 * (f + a.n * s)) for f in range(a.n)]) for s in range(sets)])   # (sets, n, bytes): 4 x n distinct frames
+src = torch.stack([torch.stack([torch.roll(base, line * 37 * (f + a.n * s)) for f in range(a.n)]) for s in range(sets)])   # (sets, n, bytes): 4 x n distinct frames
 enc = C.c_void_p()
 assert l.ug_hip_jpeg_encoder_create_sub(w, h, 75, 4, a.sub, C.byref(enc)) == 0
 cap = l.ug_hip_jpeg_encoder_max_size(enc)
@@ -37,12 +39,12 @@ one = C.c_size_t(0)
 def single():
     k = single.k = getattr(single, "k", 0) + 1
     for f in range(a.n):
-        assert l.ug_hip_jpeg_encoder_encode(enc, L.PF_UYVY, src[k % sets, f].data_ptr(), 0, out[f].data_ptr(), stride, C.byref(one), st) == 0
+        assert l.ug_hip_jpeg_encoder_encode(enc, pf_in, src[k % sets, f].data_ptr(), 0, out[f].data_ptr(), stride, C.byref(one), st) == 0
 
 
 def batch():
     k = batch.k = getattr(batch, "k", 0) + 1
-    assert l.ug_hip_jpeg_encoder_encode_batch(enc, L.PF_UYVY, a.n, src[k % sets].data_ptr(), 0, src.shape[2], out.data_ptr(), stride, stride, lens, st) == 0, L.last_error()
+    assert l.ug_hip_jpeg_encoder_encode_batch(enc, pf_in, a.n, src[k % sets].data_ptr(), 0, src.shape[2], out.data_ptr(), stride, stride, lens, st) == 0, L.last_error()
 
 
 legs = (("one frame per call", single), (f"{a.n} frames per call", batch), ("one frame per call", single), (f"{a.n} frames per call", batch))
@@ -59,6 +61,6 @@ for name, fn in legs:
         fn()
         n += 1
     dt = time.perf_counter() - t0
-    print(f"jpeg encode 4K 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
+    print(f"jpeg encode 4K {fmt_in} 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
 
 l.ug_hip_jpeg_encoder_destroy(enc)

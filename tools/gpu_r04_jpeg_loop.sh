@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 4, session J: two-launch placement (slots + gather) against the one-launch look-back.
+# Round 4: the quick loop the JPEG encoder work ran on (sessions B..L): its tests, the rate of every placement / fusion variant, phase clock, SQ counters.
 cd ${GRAFT_REPO_ROOT:-.}
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04l; mkdir -p $OUT
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04jpeg; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_jpeg.py tests/test_jpeg_rtp_compat.py -q -x 2>&1 | grep -v lavc_vid_conv | tail -4 > $OUT/pytest_jpeg.log; tail -4 $OUT/pytest_jpeg.log
 for v in "" "UG_JPEG_LOOKBACK=1" "UG_JPEG_FUSED=0"; do echo "== $v"; env $v timeout 120 python tools/bench_jpeg_batch.py --only batch 2>&1 | grep "frames per call"; done > $OUT/jpeg_batch.txt; cat $OUT/jpeg_batch.txt
 timeout 120 python tools/bench_jpeg_batch.py 2>&1 | grep "per call" > $OUT/jpeg_batch_both.txt; cat $OUT/jpeg_batch_both.txt

@@ -1,0 +1,6 @@
+cd ${GRAFT_REPO_ROOT:-.}
+timeout 900 python -m pytest tests/test_gpu_jpeg.py tests/test_jpeg_rtp_compat.py -q -x 2>&1 | grep -v lavc_vid_conv | tail -4
+timeout 600 python -m pytest tests/test_module_harness.py tests/test_reference_unit_tests.py -k "jpeg or gpujpeg" -q -x 2>&1 | grep -v lavc_vid_conv | tail -2
+timeout 120 python tools/bench_jpeg_batch.py --sub 444 2>&1 | grep "per call"
+UG_JPEG_FUSED=0 timeout 120 python tools/bench_jpeg_batch.py --sub 444 --only batch 2>&1 | grep "per call"
+timeout 120 python tools/bench_jpeg_batch.py 2>&1 | grep "per call"

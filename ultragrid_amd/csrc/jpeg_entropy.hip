@@ -491,7 +491,7 @@ struct CodeArgs {
         long coef_y, coef_c;
         // SRC = 420 / 422: the UYVY frame(s) and the quantiser (luma 64 divisors, chroma 64)
         const uint8_t *src;
-        int pitch, height, strips /* strips of 32 MCUs per MCU row */;
+        int pitch, width, height, strips /* strips of 32 (4:4:4: 64) MCUs per MCU row */;
         size_t src_stride;
         // the stream(s)
         uint8_t *out;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         constexpr int kStageWords = 32 * kStageRow * 4; // per wave (SRC = 0)
         // window words per block: 16 = the private strings' size; the 4:2:0 fused kernel takes 12 (384 bits per block on a segment's average, 5 x
         // what a 4K q75 frame needs; beyond: the general path) -- that is what lets a sixth workgroup onto the CU
-        constexpr int kWin = SRC == 420 ? 12 : kWinWordsPerBlock;
+        constexpr int kWin = SRC == 420 || SRC == 444 ? 12 : kWinWordsPerBlock;
         constexpr int kHalfPitch = 20; // words: half a block (64 B) + 16 B, conflict-free 128-bit accesses of consecutive lanes (fused hand-over)
         constexpr int kBufWords = (kPrivStride + kWin + 1) * W;
         static_assert(kBufWords >= WAVES * kStageWords && kBufWords >= kHalfPitch * W, "the three lives must fit");
@@ -590,8 +590,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 nseg_wg = min(a.G, a.n_seg - seg0);
         } else {
                 strip_my = wg / a.strips;
-                strip_mcu0 = 32 * (wg - strip_my * a.strips);
-                strip_mcus = min(32, a.mcu_w - strip_mcu0);
+                constexpr int kStrip = SRC == 444 ? 64 : 32; // MCUs per strip: 192 (420, 444) / 128 (422) blocks
+                strip_mcu0 = kStrip * (wg - strip_my * a.strips);
+                strip_mcus = min(kStrip, a.mcu_w - strip_mcu0);
                 seg0 = (strip_my * a.mcu_w + strip_mcu0) / ri;
                 nseg_wg = strip_mcus / ri;
         }
@@ -649,7 +650,62 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 constexpr int kLumaWaves = SRC == 420 ? 2 : 1;
                 const uint8_t *const src = a.src + (size_t) frame * a.src_stride;
                 const int height = a.height, pitch = a.pitch;
-                {
+                if (SRC == 444) {
+                        // packed RGB, components kept as R, G, B (gpujpeg.cpp:303-305): a strip of 64 MCUs = 64 8x8 pixel blocks; wave c makes the blocks
+                        // of component c (the arithmetic of rgb_jpeg444_kernel, jpeg_fdct.hip; the three waves read the same pixels, HBM sees them once)
+                        const int bx = strip_mcu0 + lane, by = strip_my;
+                        const bool valid = lane < strip_mcus;
+                        if (valid) {
+                                uint32_t raw[8][6];
+                                const bool interior = 8 * bx + 8 <= a.width && 8 * by + 8 <= height && !(pitch & 3) && !(3 & (uintptr_t) src);
+                                if (interior) {
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+                                                const uint32_t *p = (const uint32_t *) (src + (long) (8 * by + r) * pitch + 24 * bx);
+#pragma unroll
+                                                for (int k = 0; k < 6; k++) raw[r][k] = p[k];
+                                        }
+                                } else { // edge replication, byte by byte into the same register layout
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+                                                const uint8_t *row = src + (long) min(8 * by + r, height - 1) * pitch;
+#pragma unroll
+                                                for (int k = 0; k < 6; k++) raw[r][k] = 0;
+#pragma unroll
+                                                for (int c = 0; c < 8; c++) {
+                                                        const uint8_t *px = row + 3L * min(8 * bx + c, a.width - 1);
+#pragma unroll
+                                                        for (int comp2 = 0; comp2 < 3; comp2++) {
+                                                                const int bi = 3 * c + comp2;
+                                                                raw[r][bi >> 2] |= (uint32_t) px[comp2] << (8 * (bi & 3));
+                                                        }
+                                                }
+                                        }
+                                }
+                                float q[64];
+                                auto take = [&](auto comp_c) { // static byte positions: one copy of the code per component, selected per WAVE
+                                        constexpr int cc = decltype(comp_c)::value;
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+#pragma unroll
+                                                for (int c = 0; c < 8; c++) {
+                                                        constexpr int dummy = 0;
+                                                        (void) dummy;
+                                                        const int bi = 3 * c + cc;
+                                                        q[8 * r + c] = (float) ((int) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff) - 128);
+                                                }
+                                        }
+                                };
+                                if (wv == 0) take(std::integral_constant<int, 0>{});
+                                else if (wv == 1) take(std::integral_constant<int, 1>{});
+                                else take(std::integral_constant<int, 2>{});
+                                ug_jpeg::fdct8x8(q);
+                                ug_jpeg::quant_pack(q, div, w); // R, G and B are all quantised with table 0
+                        } else {
+#pragma unroll
+                                for (int i = 0; i < 32; i++) w[i] = 0;
+                        }
+                } else {
                         float q[64];
                         bool valid; // lanes past the end of a short last strip hold no block
                         if (wv < kLumaWaves) {
@@ -722,7 +778,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 uint4 *const store = (uint4 *) buf;
                 constexpr int kRow = kHalfPitch / 4; // uint4 per row
                 const int m = sl * ri + ml; // MCU of the strip
-                const int id = b < ybl ? (SRC == 420 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m;
+                const int id = SRC == 444 ? 64 * b + m
+                                          : (b < ybl ? (SRC == 420 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                         if (half) __syncthreads(); // the first halves have been read
@@ -1100,6 +1157,7 @@ struct Encoder {
         size_t slots_cap;
         uint32_t *wg_bytes;
         bool two_launch;        // UG_JPEG_LOOKBACK=1 switches to the one-launch placement (decoupled look-back) for A/B
+        bool force_two_launch;  // UG_JPEG_LOOKBACK=0: the two-launch placement for one-frame calls too (tests: every path with every input)
         unsigned long long *prof; // UG_JPEG_PROF=1: phase clock sums of the placing coder (device memory, kProfPhases + 1 words)
         bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
         uint8_t *header_dev;
@@ -1263,6 +1321,7 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         e->allow_fused = !(getenv("UG_JPEG_FUSED") != nullptr && getenv("UG_JPEG_FUSED")[0] == '0');
         e->use_ticket = getenv("UG_JPEG_TICKET") != nullptr && getenv("UG_JPEG_TICKET")[0] == '1';
         e->two_launch = !(getenv("UG_JPEG_LOOKBACK") != nullptr && getenv("UG_JPEG_LOOKBACK")[0] == '1');
+        e->force_two_launch = getenv("UG_JPEG_LOOKBACK") != nullptr && getenv("UG_JPEG_LOOKBACK")[0] == '0';
         e->sub = subsampling;
         e->hs = subsampling == 444 ? 1 : 2; e->vs = subsampling == 420 ? 2 : 1; e->ybl = e->hs * e->vs;
         e->mcu_w = (width + 8 * e->hs - 1) / (8 * e->hs); e->mcu_h = (height + 8 * e->vs - 1) / (8 * e->vs); e->n_mcu = e->mcu_w * e->mcu_h;
@@ -1352,8 +1411,12 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         if (!src_pitch && in == UG_PF_UYVY) src_pitch = ug::linesize(UG_PF_UYVY, w);
         // Fused: forward DCT, quantiser, Huffman coding and stream placement in ONE kernel, a workgroup per strip of 32 MCUs -- the quantised
         // coefficients never reach HBM.  Needs whole segments per strip (32 % ri == 0, mcu_w % ri == 0) and the aligned geometry of the fast front end.
-        const bool fused = !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
-                           (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0 && e->mcu_w % e->ri == 0;
+        if (!src_pitch && in == UG_PF_RGB) src_pitch = 3 * w;
+        const bool fused_yuv = !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
+                               (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0 && e->mcu_w % e->ri == 0;
+        // packed RGB (4:4:4, R, G, B components): a strip = 64 MCUs; any width and alignment (the edge blocks of the picture are loaded byte by byte)
+        const bool fused_rgb = !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0 && e->mcu_w % e->ri == 0;
+        const bool fused = fused_yuv || fused_rgb;
         if (fused) {
                 // nothing to do here: the coder below reads the frame itself
         } else if (in == UG_PF_UYVY && e->sub != 444) { // fused unpack + subsample + FDCT + quantise, grid.z = frame
@@ -1393,16 +1456,17 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 CodeArgs a = {};
                 a.mcu_w = e->mcu_w; a.n_mcu = e->n_mcu; a.hs = e->hs; a.vs = e->vs; a.ctab = e->sub == 444 ? 0 : 1; a.ri = e->ri; a.n_seg = e->n_seg; a.S = S;
                 a.cy = e->cy; a.cb = e->cb; a.cr = e->cr; a.coef_y = bs.coef_y; a.coef_c = bs.coef_c;
-                a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.height = h; a.src_stride = src_stride;
+                a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.width = w; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
                 a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
                 int waves, kwin = 16;
                 if (fused) {
-                        a.strips = (e->mcu_w + 31) / 32;
+                        const int strip = fused_rgb ? 64 : 32;
+                        a.strips = (e->mcu_w + strip - 1) / strip;
                         a.n_wg = a.strips * e->mcu_h;
-                        a.G = 32 / e->ri;
-                        waves = e->sub == 420 ? 3 : 2;
-                        if (e->sub == 420) kwin = 12;
+                        a.G = strip / e->ri;
+                        waves = e->sub == 422 ? 2 : 3;
+                        if (e->sub != 422) kwin = 12;
                 } else {
                         // waves per workgroup: the count that leaves the fewest lanes idle (fewer waves on a tie)
                         waves = 1;
@@ -1439,7 +1503,8 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 const dim3 grid((unsigned) a.n_wg * frames);
                 if (fused) {
                         if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), grid, dim3(192), 0, st, a, (const float *) e->div);
-                        else hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), grid, dim3(128), 0, st, a, (const float *) e->div);
+                        else if (e->sub == 422) hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), grid, dim3(128), 0, st, a, (const float *) e->div);
+                        else hipLaunchKernelGGL((jpeg_code_kernel<3, 444>), grid, dim3(192), 0, st, a, (const float *) e->div);
                 } else {
                         switch (waves) {
                         case 1: hipLaunchKernelGGL((jpeg_code_kernel<1, 0>), grid, dim3(64), 0, st, a, (const float *) e->div); break;
@@ -1457,7 +1522,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         };
         e->total_host[kMaxBatch + 1] = 0;
         if (!wave_path) {
-                const int lrc = launch_coder(e->two_launch);
+                // one frame per call: the look-back's waits are short (every workgroup of the frame is resident at once) and the second launch
+                // costs more than it saves (measured 39.4 against 41.3 us per 4K frame); from two frames up the two-launch placement wins
+                const int lrc = launch_coder(e->two_launch && (frames > 1 || e->force_two_launch));
                 if (lrc != UG_HIP_SUCCESS) return lrc;
         } else {
                 if (frames > e->raw_cap) {
