@@ -20,6 +20,11 @@ for seed in range(n):
     sub = [420, 422, 444][int(rng.integers(3))]
     w, h = 2 * int(rng.integers(1, 130)), int(rng.integers(1, 150))
     q, ri = int(rng.integers(1, 101)), int(rng.integers(1, 41))
+    if seed % 2:  # round 4: half of the cases where the fused kernels run (width % 16 == 0 for UYVY, restart interval a power of two that divides the MCU row) ...
+        w = 16 * int(rng.integers(1, 70))
+        mcu_w = (w + 7) // 8 if sub == 444 else w // 16
+        ri = int(rng.choice([r for r in (1, 2, 4, 8, 16, 32, 64) if mcu_w % r == 0 and (sub == 444 or r <= 32)]))
+    two = seed % 4 >= 2   # ... and half of all cases as a batch of two frames (the two-launch placement; one-frame calls place in one launch)
     yy, xx = np.mgrid[0:h, 0:w]
     base = np.stack([128 + 100 * np.sin(xx / (3 + 40 * rng.random())) * np.cos(yy / (3 + 30 * rng.random())), 128 + 90 * np.cos(xx / 33.0 + yy / (5 + 20 * rng.random())),
                      128 + 80 * np.sin(yy / (2 + 9 * rng.random()))], -1)
@@ -28,12 +33,14 @@ for seed in range(n):
     dl, dc = po.jpeg_divisors(ql), po.jpeg_divisors(qc)
     enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
     if sub == 444:
-        data = enc.encode(torch.from_numpy(np.ascontiguousarray(rgb).ravel()).cuda(), L.PF_RGB)
+        dev = torch.from_numpy(np.ascontiguousarray(rgb).ravel()).cuda()
+        data = enc.encode_batch(torch.stack([dev, dev]), L.PF_RGB)[1] if two else enc.encode(dev, L.PF_RGB)
         coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(rgb[..., c]), dl, (w + 7) // 8, (h + 7) // 8) for c in range(3)]
         want = write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=444)
     else:
         uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
-        data = enc.encode(torch.from_numpy(uyvy).cuda())
+        dev = torch.from_numpy(uyvy).cuda()
+        data = enc.encode_batch(torch.stack([dev, dev]))[1] if two else enc.encode(dev)
         if sub == 422:
             y, u, v = po.uyvy_to_i422(uyvy, w, h)
             mw, mh = (w + 15) // 16, (h + 7) // 8
