@@ -6,7 +6,8 @@
 // Stream: SOI, APP0 (JFIF), DQT x2, SOF0 (8-bit, 3 components, Y 2x2 (4:2:0) or 2x1 (4:2:2) / 1x1 / 1x1), DHT x4 (T.81 Annex K.3
 // tables), DRI, SOS (interleaved), entropy-coded segments of `restart_interval` MCUs separated by RSTm, EOI.
 // Restart intervals make the scan data-parallel: every segment starts byte-aligned with DC predictors reset, so
-// segments are coded independently (one lane per segment), then compacted by a prefix sum over segment sizes.
+// segments are coded independently -- one lane per BLOCK, whole segments per workgroup, fused with the forward DCT for UYVY / RGB input
+// (jpeg_code_kernel, the default) or one wave per segment (entropy_wave_kernel, long restart intervals) -- and placed by their sizes.
 // The byte stream is identical to the test writer tests/jpeg_bitstream.py, which Pillow/libjpeg decodes.
 #include <stdlib.h>
 #include <string.h>
@@ -330,27 +331,30 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Block-parallel Huffman coding WITH stream placement (round 4; the default whenever a restart segment has at most 256 blocks).
-// One LANE PER BLOCK, a workgroup = the whole segments that fit its lanes; the workgroup finishes its part of the JPEG stream
-// itself -- byte stuffing, RSTm markers, final position -- so that the scan data is written once, where it belongs:
-//   1. every lane gets its block as 32 registers (64 int16, zig-zag order): from the coefficient arrays in HBM (SRC = 0: 8 lanes
-//      share a 128-byte line, rows handed to their owners through LDS) or, fused (SRC = 420 / 422), from the workgroup's own
-//      forward DCT + quantiser of a strip of 32 MCUs of the UYVY frame -- the coefficients then never exist in HBM;
+// Block-parallel Huffman coding with byte stuffing and stream placement (round 4; the default whenever a restart segment has at most 256
+// blocks).  One LANE PER BLOCK, a workgroup = the whole segments that fit its lanes; the workgroup finishes its part of the JPEG stream
+// itself -- code, byte stuffing, RSTm markers:
+//   1. every lane gets its block as 32 registers (64 int16, zig-zag order): from the coefficient arrays in HBM (SRC = 0: 8 lanes share a
+//      128-byte line, rows handed to their owners through LDS) or, fused (SRC = 420 / 422 / 444), from the workgroup's own forward DCT +
+//      quantiser of a strip of 32 (64) MCUs of the UYVY (RGB) frame, made in frame order and handed over in scan order through LDS, half a
+//      block at a time -- the coefficients then never exist in HBM;
 //   2. the DC predictor comes from the lane that holds the previous block of the same component;
-//   3. ONE walk over the 63 AC coefficients (static register indices; groups of 8 that are zero in all 64 blocks of the wave cost
-//      one scalar branch; a group in which some block needs ZRL symbols takes the variant that can emit them) appends code + value
-//      bits to a 64-bit accumulator whose words go to the lane's PRIVATE string in LDS (bit 0 = the block's first bit) and adds up
-//      the length -- rounds 2-3 walked twice, a length pass and an emission pass;
-//   4. a prefix sum of the lengths, made segment-relative, gives every block its bit position; every lane shifts its private
-//      string there and ORs it into the segment's window (ds_or_b32);
-//   5. the windows are padded with 1-bits to a byte, 0xFF bytes counted: final segment sizes; a decoupled look-back over the
-//      workgroups of the frame (one 64-bit status word per workgroup: generation of the call | aggregate / inclusive prefix |
-//      bytes) gives the workgroup its position in the stream without a second launch;
-//   6. the waves write their segments there, inserting 0x00 after every 0xFF (T.81 B.1.1.5) and appending RSTm / EOI; the last
-//      segment's wave reports the stream length to pinned host memory, workgroup 0 lays down the header.
-// A block whose code exceeds its 512-bit private string (near-lossless quality on noise) sends its workgroup down the general path:
-// emission straight into the windows at the known bit positions (BitSink), in several passes when a segment exceeds its window,
-// counted first and emitted again for the write-out.  The stream is byte-identical to the wave-per-segment coder + compaction.
+//   3. ONE walk over the 63 AC coefficients (static register indices; groups of 8 and single positions that are zero in all 64 blocks of the
+//      wave cost a scalar branch; the rare coefficient behind a zero run longer than 15 is met by a wave-uniform branch at its position)
+//      appends code + value bits to a 64-bit accumulator whose words go to the lane's PRIVATE string in LDS (bit 0 = the block's first bit)
+//      and adds up the length -- rounds 2-3 walked twice, a length pass and an emission pass;
+//   4. a prefix sum of the lengths, made segment-relative, gives every block its bit position; every lane shifts its private string there and
+//      ORs it into the segment's window (v_alignbit + ds_or_b32);
+//   5. the windows are padded with 1-bits to a byte, 0xFF bytes counted: final segment sizes;
+//   6. placement.  Two launches (the default from two frames per call up): the waves write their segments -- 0x00 after every 0xFF (T.81
+//      B.1.1.5), RSTm / EOI behind each -- into a slot of the workgroup's own, the byte count into wg_bytes, and jpeg_gather_kernel moves the
+//      stretches to their places.  One launch (one-frame calls; the fallback when a slot is too small; UG_JPEG_LOOKBACK=1): a decoupled
+//      look-back over the workgroups of the frame (one 64-bit status word per workgroup: generation of the call | aggregate / inclusive prefix |
+//      bytes) gives the workgroup its position in the stream, the waves write there; the last segment's wave reports the stream length to
+//      pinned host memory, workgroup 0 lays down the header.
+// A block whose code exceeds its 512-bit private string, or a segment beyond its window (near-lossless quality on noise), sends its workgroup
+// down the general path: emission straight into the windows at the known bit positions (BitSink), in several passes when a segment exceeds its
+// window, counted first and emitted again for the write-out.  The stream is byte-identical to the wave-per-segment coder + compaction.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef UG_JPEG_SKIP_POSITIONS
 #define UG_JPEG_SKIP_POSITIONS 1 // inside a group that is not empty, still skip the positions that are zero in all 64 blocks of the wave
@@ -508,7 +512,7 @@ struct CodeArgs {
         uint8_t *slots;
         size_t slot_bytes;
         uint32_t *wg_bytes;
-        unsigned long long *prof;       // UG_JPEG_PROF=1: kProfPhases accumulated s_memtime deltas + a workgroup count (tools/jpeg_phase_profile.py); else NULL
+        unsigned long long *prof;       // UG_JPEG_PROF=1: per workgroup, kProfPhases clock deltas + a mark (averaged and printed when the encoder is destroyed); else NULL
 };
 constexpr int kProfPhases = 10;
 
@@ -689,8 +693,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                         for (int r = 0; r < 8; r++) {
 #pragma unroll
                                                 for (int c = 0; c < 8; c++) {
-                                                        constexpr int dummy = 0;
-                                                        (void) dummy;
                                                         const int bi = 3 * c + cc;
                                                         q[8 * r + c] = (float) ((int) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff) - 128);
                                                 }
