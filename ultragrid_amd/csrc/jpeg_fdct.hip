@@ -21,10 +21,40 @@ using namespace ug_jpeg;
 // A wave holds 64 consecutive blocks (one per lane) = one contiguous 8 KiB stretch of the output.  Stored straight
 // from registers every store instruction would touch 64 different 128-byte lines (16 B each); instead the wave
 // transposes through LDS (row pitch 144 B: conflict-free 128-bit writes) so that each store instruction writes
-// 1 KiB of contiguous memory.  `lds` = this wave's private 64 x 144 B region; `n_valid` lanes hold real blocks.
+// 1 KiB of contiguous memory -- 32 blocks at a time (round 4): the lower half of the lanes hands its blocks over, all 64 lanes
+// store them, then the upper half: 4.5 KB of LDS per wave instead of 9, whole lines per store instruction as before, and a
+// sixth workgroup of the fused UYVY kernel fits the CU.  `lds` = this wave's private kStoreRows x 144 B region; `n_valid`
+// lanes hold real blocks.
+#ifndef UG_JPEG_STORE_HALVES
+#define UG_JPEG_STORE_HALVES 1
+#endif
+constexpr int kStoreRows = UG_JPEG_STORE_HALVES ? 32 : 64;
 __device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint8_t *lds, int16_t *__restrict__ out_wave,
                                                   int lane, int n_valid)
 {
+#if UG_JPEG_STORE_HALVES
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+                if ((lane >> 5) == half) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                                *(uint4 *) (lds + (lane & 31) * kLdsPitch + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+                        }
+                }
+                __builtin_amdgcn_wave_barrier(); // same wave wrote and reads: only ordering inside the wave is needed
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                        const int row = 8 * j + (lane >> 3), piece = lane & 7, blk = 32 * half + row;
+                        const uint4 v = *(const uint4 *) (lds + row * kLdsPitch + 16 * piece);
+                        if (blk < n_valid) {
+                                ((uint4 *) out_wave)[8 * blk + piece] = v;
+                        }
+                }
+                __builtin_amdgcn_wave_barrier(); // the rows are overwritten by the other half
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 8; j++) {
                 *(uint4 *) (lds + lane * kLdsPitch + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
@@ -38,6 +68,35 @@ __device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint8
                 if (blk < n_valid) {
                         ((uint4 *) out_wave)[8 * blk + piece] = v;
                 }
+        }
+#endif
+}
+
+// the same for a wave whose lower 32 lanes hold blocks of one plane and whose upper 32 lanes hold blocks of another (Cb | Cr of a strip)
+__device__ __forceinline__ void wave_store_blocks_two(const uint32_t (&w)[32], uint8_t *lds, int16_t *__restrict__ out_lo, int16_t *__restrict__ out_hi,
+                                                      int lane, int n_valid_each)
+{
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+                if ((lane >> 5) == half) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                                *(uint4 *) (lds + (lane & 31) * kLdsPitch + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                int16_t *const out = half ? out_hi : out_lo;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                        const int row = 8 * j + (lane >> 3), piece = lane & 7;
+                        const uint4 v = *(const uint4 *) (lds + row * kLdsPitch + 16 * piece);
+                        if (row < n_valid_each) {
+                                ((uint4 *) out)[8 * row + piece] = v;
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
         }
 }
 
@@ -57,7 +116,7 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
                                                                int blocks_w, long total, const float *__restrict__ div,
                                                                int16_t *__restrict__ out, float *__restrict__ coef)
 {
-        __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * 64 * kLdsPitch];
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * kStoreRows * kLdsPitch];
         const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const long wave_first = idx - lane;
@@ -96,7 +155,7 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
         }
         if (wave_first < total) {
                 const long left = total - wave_first;
-                wave_store_blocks(w, lds_all + wave * 64 * kLdsPitch, out + 64 * wave_first, lane, left < 64 ? (int) left : 64);
+                wave_store_blocks(w, lds_all + wave * kStoreRows * kLdsPitch, out + 64 * wave_first, lane, left < 64 ? (int) left : 64);
         }
 }
 
@@ -108,12 +167,12 @@ __global__ __launch_bounds__(256) void rgb_jpeg444_kernel(const uint8_t *__restr
                                                           long total, const float *__restrict__ div, int16_t *__restrict__ out0,
                                                           int16_t *__restrict__ out1, int16_t *__restrict__ out2)
 {
-        __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * 64 * kLdsPitch];
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * kStoreRows * kLdsPitch];
         const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const long wave_first = idx - lane;
         if (wave_first >= total) return; // wave-uniform
-        uint8_t *lds = lds_all + wave * 64 * kLdsPitch;
+        uint8_t *lds = lds_all + wave * kStoreRows * kLdsPitch;
         const long left = total - wave_first;
         const int n_valid = left < 64 ? (int) left : 64;
         uint32_t raw[8][6];
@@ -260,11 +319,11 @@ __global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(
 {
         fs.apply(blockIdx.z, src, out_y, out_cb, out_cr); // blockIdx.z = frame of the batch
         constexpr int kLumaWaves = SUB == 420 ? 2 : 1;
-        __shared__ __attribute__((aligned(16))) uint8_t lds_all[(kLumaWaves + 1) * 64 * kLdsPitch];
+        __shared__ __attribute__((aligned(16))) uint8_t lds_all[(kLumaWaves + 1) * kStoreRows * kLdsPitch];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int mcu0 = blockIdx.x * 32, my = blockIdx.y;
         const int mcus = min(32, mcu_w - mcu0); // MCUs of this strip that exist
-        uint8_t *lds = lds_all + wave * 64 * kLdsPitch;
+        uint8_t *lds = lds_all + wave * kStoreRows * kLdsPitch;
         float b[64];
         uint32_t w[32];
         if (wave < kLumaWaves) {
@@ -328,6 +387,9 @@ __global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(
                 }
                 // lanes 0-31 -> Cb blocks, lanes 32-63 -> Cr blocks of this strip: two contiguous 4 KiB stretches
                 const long first = (long) my * mcu_w + mcu0;
+#if UG_JPEG_STORE_HALVES
+                wave_store_blocks_two(w, lds, out_cb + 64 * first, out_cr + 64 * first, lane, mcus);
+#else
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                         *(uint4 *) (lds + lane * kLdsPitch + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
@@ -344,6 +406,7 @@ __global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(
                                 ((uint4 *) o)[piece] = v;
                         }
                 }
+#endif
         }
 }
 
