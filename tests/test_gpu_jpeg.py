@@ -372,26 +372,25 @@ def test_block_parallel_coder_equals_wave_per_segment_coder(hip, po, sub, monkey
 @pytest.mark.parametrize("sub", [420, 422, 444])
 @pytest.mark.parametrize("dims", [(640, 88), (1040, 81), (512, 64), (48, 16), (1100, 50)])
 def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypatch):
-    """Round 4: for UYVY input whose restart segments stay inside the 32-MCU strips (32 % ri == 0, mcu_w % ri == 0) ONE kernel does the
+    """Round 4: for UYVY (RGB) input with a restart interval that divides the 32 (64) consecutive MCUs a workgroup takes ONE kernel does the
     forward DCT, the quantiser, the Huffman coding and the byte stuffing -- the coefficients never reach HBM.  Its stream must be the
     stream of the front end + placing coder pair (UG_JPEG_FUSED=0) and of the front end + wave-per-segment coder + compaction triple
-    (UG_JPEG_WAVE_KERNEL=1): full strips and a short last one (640 = 40 MCUs, 1040 = 65), one strip only, a picture narrower than a strip,
-    picture heights that are no MCU multiple, low quality, and noise at q = 100 (blocks that overflow their private strings: the general
-    path, several passes)."""
+    (UG_JPEG_WAVE_KERNEL=1): MCU rows of 40, 65, 32 and 3 MCUs (a workgroup's run of MCUs wraps from one MCU row into the next, segments
+    straddle rows when the interval does not divide the row), a short last workgroup, picture heights that are no MCU multiple, low quality,
+    and noise at q = 100 (blocks that overflow their private strings: the general path, several passes)."""
     import torch
     w, h = dims
     if sub != 444 and w % 16:
         pytest.skip("the fused UYVY front end takes widths that are a multiple of 16 (others: the two-kernel path, covered elsewhere)")
     # 4:4:4 = packed RGB input, R, G, B components, strips of 64 MCUs (any width: 1100 = 137.5 blocks, edge blocks replicated); 4:2:x = UYVY
     fmt, pf = ("RGB", hip.L.PF_RGB) if sub == 444 else ("UYVY", hip.L.PF_UYVY)
-    mcu_w = (w + 7) // 8 if sub == 444 else w // 16
     src = synth.s2_video(fmt, w, h)
     noisy = synth.s1_random(fmt, w, h, salt=9)
     for q, frame in ((75, src), (100, noisy), (20, src), (92, noisy)):
         dev = torch.from_numpy(frame).cuda()
         for ri in (1, 2, 4, 8, 16, 32, 64):
-            if mcu_w % ri or (sub != 444 and ri == 64):
-                continue
+            if sub != 444 and ri == 64:
+                continue                # (beyond the 32 MCUs of a 4:2:x workgroup: the two-kernel path, covered by the other tests)
             out = {}
             for tag, env in (("fused", {}), ("two", {"UG_JPEG_FUSED": "0"}), ("wave", {"UG_JPEG_WAVE_KERNEL": "1"}),
                              ("look", {"UG_JPEG_LOOKBACK": "1"}), ("twolook", {"UG_JPEG_FUSED": "0", "UG_JPEG_LOOKBACK": "1"}), ("ticket", {"UG_JPEG_LOOKBACK": "1", "UG_JPEG_TICKET": "1"}), ("force", {"UG_JPEG_LOOKBACK": "0"})):

@@ -16,11 +16,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sub", type=int, default=420, help="420 / 422: UYVY input; 444: RGB input (R, G, B components, gpujpeg.cpp:303-305)")
 ap.add_argument("--n", type=int, default=8)
 ap.add_argument("--seconds", type=float, default=1.0)
+ap.add_argument("--size", default="3840x2160")
 ap.add_argument("--only", choices=["both", "batch", "single"], default="both", help="profile runs: one call form only, so that per-kernel averages are not a blend")
 ap.add_argument("--calls", type=int, default=0, help="exactly this many timed calls per leg instead of --seconds (counter passes)")
 a = ap.parse_args()
 l = L.load()
-w, h = 3840, 2160
+w, h = (int(x) for x in a.size.split("x"))
 rgb = a.sub == 444
 fmt_in, pf_in, line = ("RGB", L.PF_RGB, 3 * w) if rgb else ("UYVY", L.PF_UYVY, 2 * w)
 base = torch.from_numpy(synth.s2_video("UYVY", w, h) if not rgb else synth.frame("S2", "RGB", w, h)).cuda()
@@ -61,6 +62,6 @@ for name, fn in legs:
         fn()
         n += 1
     dt = time.perf_counter() - t0
-    print(f"jpeg encode 4K {fmt_in} 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
+    print(f"jpeg encode {w}x{h} {fmt_in} 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
 
 l.ug_hip_jpeg_encoder_destroy(enc)

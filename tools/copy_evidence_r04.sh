@@ -13,3 +13,15 @@ tail -2 $S/pytest.log | head -1 > $D/r04_gpu_tests.txt
 grep -E "^==|THROUGHPUT|^OK" $S/soak.txt | cut -c1-200 > $D/r04_soak_numa_ab.txt
 grep -v "CatArray\|at::native" $S/jpeg_batch_traffic.txt | sed 's#/tmp/code/[^ ]*/gpurun_out/#gpurun_out/#' > $D/r04_jpeg_batch_traffic.txt
 ls $D | grep -c r04
+# the end-of-round call (tools/gpu_r04_final.sh -> gpurun_out/r04n/): bench line + the kernel trace of the same command on the same box, the
+# other workloads' lines, the JPEG encoder's rates at every sampling / size, the per-kernel table, the random searches
+N=gpurun_out/r04n
+if [ -d $N ]; then
+  cp $N/bench_line.json $D/r04_bench_line.json
+  sed 's#/tmp/code/[^ ]*/gpurun_out/#gpurun_out/#' $N/kernel_trace.txt > $D/r04_kernel_trace.txt
+  cp $N/bench_4k-uyvy-jpeg420.json $D/r04_bench_4k_jpeg420.json; cp $N/bench_8k-v210.json $D/r04_bench_8k_v210.json; cp $N/bench_1080p-rgb-dxt1.json $D/r04_bench_1080p_rgb_dxt1.json
+  cp $N/jpeg_batch_all.txt $D/r04_jpeg_batch_all.txt
+  cp $N/kernels.json $D/r04_kernels.json; grep -v amdgpu.ids $N/kernels_table.txt > $D/r04_all_kernels_table.txt
+  tail -2 $N/pytest.log | head -1 > $D/r04_gpu_tests.txt
+  { echo "# end of round 4: tools/find_encode_mismatch.py 1500 (half of the cases on the fused kernels, half as two-frame batches), tools/find_dxt_mismatch.py 1500, tools/find_module_mismatch.py"; grep -v amdgpu.ids $N/find_encode.txt; grep -v amdgpu.ids $N/find_dxt.txt; grep -v amdgpu.ids $N/find_module.txt; } > $D/r04_random_searches.txt
+fi

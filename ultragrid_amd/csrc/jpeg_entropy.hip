@@ -336,7 +336,7 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
 // itself -- code, byte stuffing, RSTm markers:
 //   1. every lane gets its block as 32 registers (64 int16, zig-zag order): from the coefficient arrays in HBM (SRC = 0: 8 lanes share a
 //      128-byte line, rows handed to their owners through LDS) or, fused (SRC = 420 / 422 / 444), from the workgroup's own forward DCT +
-//      quantiser of a strip of 32 (64) MCUs of the UYVY (RGB) frame, made in frame order and handed over in scan order through LDS, half a
+//      quantiser of 32 (64) consecutive MCUs of the UYVY (RGB) frame, made in frame order and handed over in scan order through LDS, half a
 //      block at a time -- the coefficients then never exist in HBM;
 //   2. the DC predictor comes from the lane that holds the previous block of the same component;
 //   3. ONE walk over the 63 AC coefficients (static register indices; groups of 8 and single positions that are zero in all 64 blocks of the
@@ -495,7 +495,7 @@ struct CodeArgs {
         long coef_y, coef_c;
         // SRC = 420 / 422: the UYVY frame(s) and the quantiser (luma 64 divisors, chroma 64)
         const uint8_t *src;
-        int pitch, width, height, strips /* strips of 32 (4:4:4: 64) MCUs per MCU row */;
+        int pitch, width, height;
         size_t src_stride;
         // the stream(s)
         uint8_t *out;
@@ -517,8 +517,8 @@ struct CodeArgs {
 constexpr int kProfPhases = 10;
 
 // WAVES = waves per workgroup.  SRC = 0: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES
-// that leaves the fewest lanes idle).  SRC = 420 (WAVES = 3) / 422 (WAVES = 2): a workgroup = one strip of 32 MCUs of an MCU row = 32 / ri
-// segments; needs 32 % ri == 0 and mcu_w % ri == 0 (no segment leaves its strip) and a 16-byte aligned frame of width % 16 == 0.
+// that leaves the fewest lanes idle).  SRC = 420 (WAVES = 3) / 422 (WAVES = 2) / 444 (WAVES = 3): a workgroup = 32 (444: 64) consecutive MCUs of the
+// scan = 32 / ri whole segments (the restart interval must divide 32 / 64); UYVY: a 16-byte aligned frame of width % 16 == 0.
 // phase clock of the profiling runs: thread 0 of every workgroup adds the time since the previous mark to phase `i` (a.prof == NULL: nothing)
 #define UG_PHASE(i)                                                                                                      \
         if (a.prof != nullptr && threadIdx.x == 0) {                                                                     \
@@ -588,26 +588,33 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         };
         const int ybl = a.hs * a.vs, per_mcu = ybl + 2, S = a.S, ri = a.ri;
         // ---- which segments, which block ----
-        int seg0, nseg_wg, strip_mcu0 = 0, strip_my = 0, strip_mcus = 0;
+        int seg0, nseg_wg, m0 = 0; // m0 (fused): the workgroup's first MCU, raster order
         if (SRC == 0) {
                 seg0 = wg * a.G;
                 nseg_wg = min(a.G, a.n_seg - seg0);
         } else {
-                strip_my = wg / a.strips;
-                constexpr int kStrip = SRC == 444 ? 64 : 32; // MCUs per strip: 192 (420, 444) / 128 (422) blocks
-                strip_mcu0 = kStrip * (wg - strip_my * a.strips);
-                strip_mcus = min(kStrip, a.mcu_w - strip_mcu0);
-                seg0 = (strip_my * a.mcu_w + strip_mcu0) / ri;
-                nseg_wg = strip_mcus / ri;
+                // the workgroup's lanes = kMcus consecutive MCUs of the scan (raster order, whatever row they lie in: a run that reaches the end
+                // of an MCU row goes on in the next) = kMcus / ri whole segments
+                constexpr int kMcus = SRC == 444 ? 64 : 32; // 192 (420, 444) / 128 (422) blocks
+                m0 = kMcus * wg;
+                seg0 = m0 / ri;
+                nseg_wg = min(kMcus / ri, a.n_seg - seg0);
         }
-        const int sl = tid / S, j = tid - sl * S;               // segment of the workgroup, block of the segment
-        const int m_first = (seg0 + sl) * ri;
-        const int n_blk = sl < nseg_wg ? per_mcu * (min(a.n_mcu, m_first + ri) - m_first) : 0;
-        const bool active = j < n_blk;
-        const int ml = j / per_mcu, b = j - ml * per_mcu;        // MCU of the segment, block of the MCU
-        const int comp = b < ybl ? 0 : a.ctab;
+        // which block this lane CODES (scan order).  The fused variants work it out behind their front end -- six values that would otherwise
+        // sit in registers through the forward DCT, where the 4:2:0 kernel has none to spare at five waves per SIMD
+        int sl, j, m_first, n_blk, ml, b, comp;
+        bool active;
+        auto identify = [&]() {
+                sl = tid / S; j = tid - sl * S;                  // segment of the workgroup, block of the segment
+                m_first = (seg0 + sl) * ri;
+                n_blk = sl < nseg_wg ? per_mcu * (min(a.n_mcu, m_first + ri) - m_first) : 0;
+                active = j < n_blk;
+                ml = j / per_mcu; b = j - ml * per_mcu;          // MCU of the segment, block of the MCU
+                comp = b < ybl ? 0 : a.ctab;
+        };
         uint32_t w[32];
         if (SRC == 0) {
+                identify();
                 init_tables();
                 const int16_t *const cy = a.cy + frame * a.coef_y, *const cb = a.cb + frame * a.coef_c, *const cr = a.cr + frame * a.coef_c;
                 const int m = m_first + ml;
@@ -650,15 +657,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 }
         } else {
                 // ---- fused front end: the arithmetic of uyvy_jpeg_fast_kernel (jpeg_fdct.hip), lane = block in FRAME order: the luma waves take
-                // one luma block row of the strip each (64 blocks), the last wave 32 Cb blocks (lanes 0-31) + 32 Cr blocks (lanes 32-63) ----
+                // one luma block row of the workgroup's 32 MCUs each (64 blocks), the last wave 32 Cb blocks (lanes 0-31) + 32 Cr blocks (lanes 32-63) ----
                 constexpr int kLumaWaves = SRC == 420 ? 2 : 1;
                 const uint8_t *const src = a.src + (size_t) frame * a.src_stride;
                 const int height = a.height, pitch = a.pitch;
                 if (SRC == 444) {
-                        // packed RGB, components kept as R, G, B (gpujpeg.cpp:303-305): a strip of 64 MCUs = 64 8x8 pixel blocks; wave c makes the blocks
+                        // packed RGB, components kept as R, G, B (gpujpeg.cpp:303-305): 64 MCUs = 64 8x8 pixel blocks per workgroup; wave c makes the blocks
                         // of component c (the arithmetic of rgb_jpeg444_kernel, jpeg_fdct.hip; the three waves read the same pixels, HBM sees them once)
-                        const int bx = strip_mcu0 + lane, by = strip_my;
-                        const bool valid = lane < strip_mcus;
+                        const int mm = m0 + lane;
+                        const int by = mm / a.mcu_w, bx = mm - by * a.mcu_w;
+                        const bool valid = mm < a.n_mcu;
                         if (valid) {
                                 uint32_t raw[8][6];
                                 const bool interior = 8 * bx + 8 <= a.width && 8 * by + 8 <= height && !(pitch & 3) && !(3 & (uintptr_t) src);
@@ -709,11 +717,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         }
                 } else {
                         float q[64];
-                        bool valid; // lanes past the end of a short last strip hold no block
+                        bool valid; // lanes past the last MCU of the picture hold no block
                         if (wv < kLumaWaves) {
-                                const int bx = 2 * strip_mcu0 + lane;      // luma block column
-                                const int brow = kLumaWaves * strip_my + wv; // luma block row
-                                valid = lane < 2 * strip_mcus;
+                                const int mm = m0 + (lane >> 1), my = mm / a.mcu_w, mx = mm - my * a.mcu_w; // this lane's MCU
+                                const int bx = 2 * mx + (lane & 1);        // luma block column
+                                const int brow = kLumaWaves * my + wv;     // luma block row
+                                valid = mm < a.n_mcu;
                                 if (valid) {
 #pragma unroll
                                         for (int r = 0; r < 8; r++) {
@@ -730,23 +739,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                         ug_jpeg::quant_pack(q, div, w);
                                 }
                         } else {
-                                const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU within the strip
-                                valid = m < strip_mcus;
+                                const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU of the workgroup
+                                const int mm = m0 + m, my = mm / a.mcu_w, mx = mm - my * a.mcu_w;
+                                valid = mm < a.n_mcu;
                                 if (valid) {
 #pragma unroll
                                         for (int r = 0; r < 8; r++) {
                                                 int y0, y1;
                                                 if (SRC == 420) {
-                                                        const int cy2 = min(8 * strip_my + r, (height + 1) / 2 - 1); // edge replication on the chroma plane
+                                                        const int cy2 = min(8 * my + r, (height + 1) / 2 - 1); // edge replication on the chroma plane
                                                         y0 = 2 * cy2; y1 = min(2 * cy2 + 1, height - 1);             // odd height: last line doubled
                                                 } else {
-                                                        y0 = y1 = min(8 * strip_my + r, height - 1);
+                                                        y0 = y1 = min(8 * my + r, height - 1);
                                                 }
-                                                const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * (strip_mcu0 + m));
+                                                const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * mx);
                                                 const uint4 a0 = p0[0], a1 = p0[1];
                                                 const uint32_t wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
                                                 if (SRC == 420) {
-                                                        const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * (strip_mcu0 + m));
+                                                        const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * mx);
                                                         const uint4 c0 = p1[0], c1 = p1[1];
                                                         const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 #pragma unroll
@@ -773,13 +783,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         }
                 }
                 init_tables();
+                identify();
                 UG_PHASE(0) // pixels -> quantised block (wave 0's view, like all the marks)
                 // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU).  Half a
                 // block at a time -- every lane stores the first 64 bytes of the block it made and takes the first 64 of the block it will code into
                 // the registers just stored, then the same for the second halves: no second register set, and 15 KB of LDS instead of 27
                 uint4 *const store = (uint4 *) buf;
                 constexpr int kRow = kHalfPitch / 4; // uint4 per row
-                const int m = sl * ri + ml; // MCU of the strip
+                const int m = sl * ri + ml; // MCU of the workgroup
                 const int id = SRC == 444 ? 64 * b + m
                                           : (b < ybl ? (SRC == 420 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m);
 #pragma unroll
@@ -1411,13 +1422,14 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
         const bool wave_path = S > 256 || e->force_wave_kernel;
         if (!src_pitch && in == UG_PF_UYVY) src_pitch = ug::linesize(UG_PF_UYVY, w);
-        // Fused: forward DCT, quantiser, Huffman coding and stream placement in ONE kernel, a workgroup per strip of 32 MCUs -- the quantised
-        // coefficients never reach HBM.  Needs whole segments per strip (32 % ri == 0, mcu_w % ri == 0) and the aligned geometry of the fast front end.
+        // Fused: forward DCT, quantiser, Huffman coding and byte stuffing in ONE kernel, a workgroup per 32 consecutive MCUs -- the quantised
+        // coefficients never reach HBM.  Needs whole segments per workgroup (32 % ri == 0) and the aligned geometry of the fast front end.
         if (!src_pitch && in == UG_PF_RGB) src_pitch = 3 * w;
+        // a workgroup = 32 (RGB: 64) consecutive MCUs of the scan = whole segments: the restart interval must divide that
         const bool fused_yuv = !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
-                               (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0 && e->mcu_w % e->ri == 0;
-        // packed RGB (4:4:4, R, G, B components): a strip = 64 MCUs; any width and alignment (the edge blocks of the picture are loaded byte by byte)
-        const bool fused_rgb = !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0 && e->mcu_w % e->ri == 0;
+                               (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0;
+        // packed RGB (4:4:4, R, G, B components): any width and alignment (the edge blocks of the picture are loaded byte by byte)
+        const bool fused_rgb = !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0;
         const bool fused = fused_yuv || fused_rgb;
         if (fused) {
                 // nothing to do here: the coder below reads the frame itself
@@ -1463,10 +1475,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
                 int waves, kwin = 16;
                 if (fused) {
-                        const int strip = fused_rgb ? 64 : 32;
-                        a.strips = (e->mcu_w + strip - 1) / strip;
-                        a.n_wg = a.strips * e->mcu_h;
-                        a.G = strip / e->ri;
+                        const int mcus = fused_rgb ? 64 : 32; // MCUs per workgroup
+                        a.n_wg = (e->n_mcu + mcus - 1) / mcus;
+                        a.G = mcus / e->ri;
                         waves = e->sub == 422 ? 2 : 3;
                         if (e->sub != 422) kwin = 12;
                 } else {
