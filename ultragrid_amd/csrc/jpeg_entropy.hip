@@ -274,20 +274,25 @@ __device__ __forceinline__ int coef_at(const uint32_t (&w)[32], int k)
         return (k & 1) ? (int) w[k >> 1] >> 16 : (int) (w[k >> 1] << 16) >> 16;
 }
 
-// One pass over the 63 AC coefficients of every lane's block (static register indices).  EMIT = false: returns the number of bits
-// the AC part of the block codes to (EOB included) and sets `zrl_seen` if the block needs a ZRL symbol (a zero run longer than 15).
-// EMIT = true: appends the codes to `sink`; ZRL = false is the common variant for waves in which no block needs a ZRL symbol.
-// `tab` = the lane's AC table with the entries of EOB (0x00) and ZRL (0xF0) zeroed: a zero coefficient (size 0) then looks up an
-// empty code and appends / counts nothing without any predication.  The pass is cut into groups of 8 coefficients: a group that is
-// zero in all 64 blocks is skipped with one scalar branch, and inside a group there is no control flow at all, so the table
-// look-ups of its 8 coefficients (which depend only on the short `run` chain) are in flight together instead of one LDS latency
-// per coefficient.
-template <bool EMIT, bool ZRL, class Sink>
-__device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, Sink &sink,
-                                               bool &zrl_seen)
+// LDS copy of an AC table as the block-parallel coder reads it: entry of symbol (run << 4 | size) = code << size | (code length + size) << 27 --
+// the bits of the value go straight under the code and the total length needs no addition; the entries of EOB (0x00) and ZRL (0xF0), which
+// are emitted explicitly, and of the symbols T.81 does not define are zero: a zero coefficient (size 0) looks up an empty code and appends
+// nothing without any predication.
+__device__ __forceinline__ uint32_t packed_ac_entry(uint32_t e /* code | length << 16 */, int sym)
+{
+        const uint32_t size = (uint32_t) sym & 15u;
+        return (e == 0 || sym == 0x00 || sym == 0xF0) ? 0u : ((e & 0xffffu) << size) | (((e >> 16) + size) << 27);
+}
+constexpr uint32_t kCodeMask = (1u << 27) - 1u;
+
+// The general path's pass over the 63 AC coefficients of every lane's block (static register indices): appends the codes to `sink`, which
+// writes straight into the segment's window.  The pass is cut into groups of 8 coefficients: a group that is zero in all 64 blocks is
+// skipped with one scalar branch, and inside a group there is no control flow at all; every coefficient may have 1..3 ZRL symbols in front.
+template <class Sink>
+__device__ __forceinline__ void walk_block(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, Sink &sink)
 {
         const uint32_t zl = zrl >> 16, zc = zrl & 0xffffu;
-        uint32_t run = 0, nbits = 0, long_run = 0;
+        uint32_t run = 0;
 #pragma unroll
         for (int g = 0; g < 64 / kWalkGroup; g++) {
                 uint32_t any = g == 0 ? w[0] & 0xffff0000u : w[kWalkGroup / 2 * g]; // the DC value is not an AC coefficient
@@ -304,30 +309,17 @@ __device__ __forceinline__ uint32_t walk_block(const uint32_t (&w)[32], const ui
                         const uint32_t a = ((uint32_t) v ^ neg) - neg;
                         const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
                         const uint32_t e = tab[((run & 15u) << 4) | size];
-                        const uint32_t n = (e >> 16) + size;
-                        if (EMIT) {
-                                if (ZRL) { // 1..3 ZRL symbols in front of this coefficient
 #pragma unroll
-                                        for (uint32_t z = 0; z < 3; z++) {
-                                                const bool on = size != 0 && run > 15 + 16 * z;
-                                                sink.append(on ? zc : 0u, on ? zl : 0u);
-                                        }
-                                }
-                                const uint32_t vb = ((uint32_t) v + neg) & ((1u << size) - 1u); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
-                                sink.append(((e & 0xffffu) << size) | vb, n);
-                        } else {
-                                const uint32_t zruns = size ? run >> 4 : 0u;
-                                long_run |= zruns;
-                                nbits += n + zruns * zl;
+                        for (uint32_t z = 0; z < 3; z++) { // 1..3 ZRL symbols in front of this coefficient
+                                const bool on = size != 0 && run > 15 + 16 * z;
+                                sink.append(on ? zc : 0u, on ? zl : 0u);
                         }
+                        const uint32_t vb = __builtin_amdgcn_ubfe((uint32_t) v + neg, 0, size); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
+                        sink.append((e & kCodeMask) | vb, e >> 27);
                         run = size ? 0u : run + 1u;
                 }
         }
-        // EOB after the last non-zero coefficient (not when position 63 is coded)
-        if (EMIT) sink.append(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u);
-        else nbits += run ? eob >> 16 : 0u;
-        if (!EMIT) zrl_seen = long_run != 0;
-        return nbits;
+        sink.append(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u); // EOB after the last non-zero coefficient (not when position 63 is coded)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -369,12 +361,14 @@ struct PrivSink {
         unsigned long long acc;
         uint32_t fill;
         uint32_t *row;
-        uint32_t idx;
+        uint32_t idx; // complete words so far (keeps counting past the end of the row: 32 idx + fill = the bits appended)
+        // CLAMP = false: the caller knows the word cannot lie outside the row (idx <= 8 at the head of a group of 8 coefficients without ZRL symbols)
+        template <bool CLAMP = true>
         __device__ __forceinline__ void append(uint32_t str, uint32_t n) // n <= 27 bits; n == 0 (with str == 0) appends nothing
         {
                 acc = (acc << n) | str;
                 fill += n; // <= 31 + 27
-                row[min(idx, (uint32_t) kPrivWords)] = (uint32_t) (acc >> ((fill - 32u) & 63u)); // bits fill-1 .. fill-32 (fill < 32: not a word yet)
+                row[CLAMP ? min(idx, (uint32_t) kPrivWords) : idx] = (uint32_t) (acc >> ((fill - 32u) & 63u)); // bits fill-1 .. fill-32 (fill < 32: not a word yet)
                 idx += fill >> 5;
                 fill &= 31u;
         }
@@ -382,15 +376,46 @@ struct PrivSink {
         {
                 row[min(idx, (uint32_t) kPrivWords)] = (uint32_t) acc << ((32u - fill) & 31u);
         }
+        __device__ __forceinline__ uint32_t bits() const { return 32u * idx + fill; }
 };
 
-// The AC part of every lane's block: appended to `sink`, length returned (EOB included).  Groups of kWalkGroup coefficients that are zero in
-// all 64 blocks of the wave cost one scalar branch; inside a group the table look-ups depend only on the short `run` chain.  The rare
-// coefficient behind a zero run longer than 15 is met by a wave-uniform branch at its position: 1..3 ZRL symbols go in front of it.
-__device__ __forceinline__ uint32_t walk_private(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, PrivSink &sink)
+// 8 coefficients of the one-walk coder.  ZRL: some block of the wave may meet a coefficient behind a zero run longer than 15 in this group
+// (then a wave-uniform branch at that position puts the 1..3 ZRL symbols in front of it); CLAMP: some private string may reach its end here.
+template <bool ZRL, bool CLAMP>
+__device__ __forceinline__ void walk_group_private(const uint32_t (&w)[32], const int g, const uint32_t *tab, uint32_t zl, uint32_t zc, uint32_t &run, PrivSink &sink)
+{
+#pragma unroll
+        for (int k = g == 0 ? 1 : kWalkGroup * g; k < kWalkGroup * (g + 1); k++) {
+                const int v = coef_at(w, k);
+#if UG_JPEG_SKIP_POSITIONS
+                if (__ballot(v != 0) == 0) { // wave-uniform: this position is zero in all 64 blocks (two operations against ~25)
+                        run += 1u;
+                        continue;
+                }
+#endif
+                const uint32_t neg = (uint32_t) (v >> 31);
+                const uint32_t a = ((uint32_t) v ^ neg) - neg;
+                const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
+                const uint32_t e = tab[((run & 15u) << 4) | size];    // packed_ac_entry: a zero coefficient appends nothing
+                if (ZRL && k > 16 && __ballot(size != 0 && run > 15u) != 0) { // (a run of 16 zeros ends at position 17 at the earliest)
+                        const uint32_t zr = size ? run >> 4 : 0u; // one ZRL, then the other two together (<= 22 bits)
+                        sink.append<true>(zr ? zc : 0u, zr ? zl : 0u);
+                        const uint32_t two = zr > 2u ? (zc << zl) | zc : zc;
+                        sink.append<true>(zr > 1u ? two : 0u, zr > 1u ? (zr - 1u) * zl : 0u);
+                }
+                const uint32_t vb = __builtin_amdgcn_ubfe((uint32_t) v + neg, 0, size); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
+                sink.append<CLAMP>((e & kCodeMask) | vb, e >> 27);
+                run = size ? 0u : run + 1u;
+        }
+}
+
+// The AC part of every lane's block, appended to `sink` (whose bits() then says how long the block's code is, EOB included).  Groups of
+// kWalkGroup coefficients and single positions that are zero in all 64 blocks of the wave cost a scalar branch; what a group has to be able to
+// do -- ZRL symbols, strings that end -- is decided per group, wave-uniformly, so that the usual group carries neither test.
+__device__ __forceinline__ void walk_private(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, PrivSink &sink)
 {
         const uint32_t zl = zrl >> 16, zc = zrl & 0xffffu;
-        uint32_t run = 0, nbits = 0;
+        uint32_t run = 0;
 #pragma unroll
         for (int g = 0; g < 64 / kWalkGroup; g++) {
                 uint32_t any = g == 0 ? w[0] & 0xffff0000u : w[kWalkGroup / 2 * g]; // the DC value is not an AC coefficient
@@ -400,36 +425,16 @@ __device__ __forceinline__ uint32_t walk_private(const uint32_t (&w)[32], const 
                         run += g == 0 ? kWalkGroup - 1 : kWalkGroup;
                         continue;
                 }
-#pragma unroll
-                for (int k = g == 0 ? 1 : kWalkGroup * g; k < kWalkGroup * (g + 1); k++) {
-                        const int v = coef_at(w, k);
-#if UG_JPEG_SKIP_POSITIONS
-                        if (__ballot(v != 0) == 0) { // wave-uniform: this position is zero in all 64 blocks (two operations against ~30)
-                                run += 1u;
-                                continue;
-                        }
-#endif
-                        const uint32_t neg = (uint32_t) (v >> 31);
-                        const uint32_t a = ((uint32_t) v ^ neg) - neg;
-                        const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
-                        const uint32_t e = tab[((run & 15u) << 4) | size];    // EOB / ZRL entries are zero: a zero coefficient appends nothing
-                        const uint32_t n = (e >> 16) + size;
-                        if (k > 16 && __ballot(size != 0 && run > 15u) != 0) { // (a run of 16 zeros ends at position 17 at the earliest)
-                                const uint32_t zr = size ? run >> 4 : 0u; // one ZRL, then the other two together (<= 22 bits)
-                                sink.append(zr ? zc : 0u, zr ? zl : 0u);
-                                const uint32_t two = zr > 2u ? (zc << zl) | zc : zc;
-                                sink.append(zr > 1u ? two : 0u, zr > 1u ? (zr - 1u) * zl : 0u);
-                                nbits += zr * zl;
-                        }
-                        const uint32_t vb = ((uint32_t) v + neg) & ((1u << size) - 1u); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
-                        sink.append(((e & 0xffffu) << size) | vb, n);
-                        nbits += n;
-                        run = size ? 0u : run + 1u;
+                // a zero run longer than 15 can end inside this group only in a lane that enters it with run + (kWalkGroup - 1) > 15
+                if (kWalkGroup * (g + 1) > 17 && __ballot(any != 0 && run + (uint32_t) (kWalkGroup - 1) > 15u) != 0) {
+                        walk_group_private<true, true>(w, g, tab, zl, zc, run, sink);
+                } else if (__ballot(sink.idx > (uint32_t) (kPrivWords - kWalkGroup)) != 0) { // 8 codes of <= 27 bits: at most 8 more words
+                        walk_group_private<false, true>(w, g, tab, zl, zc, run, sink);
+                } else {
+                        walk_group_private<false, false>(w, g, tab, zl, zc, run, sink);
                 }
         }
-        sink.append(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u); // EOB after the last non-zero coefficient (not when position 63 is coded)
-        nbits += run ? eob >> 16 : 0u;
-        return nbits;
+        sink.append<true>(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u); // EOB after the last non-zero coefficient (not when position 63 is coded)
 }
 
 __device__ __forceinline__ int count_ff_valid(uint32_t word, int valid) // 0xFF bytes among the first `valid` (stream order) bytes of a window word
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         auto init_tables = [&]() {
                 for (int i = tid; i < 512; i += W) {
                         const int sym = i & 255;
-                        ac_tab[i >> 8][sym] = (sym == 0x00 || sym == 0xF0) ? 0u : kAcTab[i >> 8][sym]; // EOB / ZRL are emitted explicitly
+                        ac_tab[i >> 8][sym] = packed_ac_entry(kAcTab[i >> 8][sym], sym);
                 }
                 if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
                 if (tid < 2) lds_flag[tid] = 0;
@@ -838,8 +843,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         uint32_t nbits = 0;
         if (active) { // idle lanes stay out of the walk
                 PrivSink sink = { 0ull, 0u, row, 0u };
-                sink.append(dc_str, dc_n);
-                nbits = dc_n + walk_private(w, tab, zrl, eob, sink);
+                sink.append<false>(dc_str, dc_n);
+                walk_private(w, tab, zrl, eob, sink);
+                nbits = sink.bits();
                 sink.finish();
                 if (nbits > 32u * kPrivWords) lds_flag[0] = 1; // does not fit its private string: the general path for this workgroup
         }
@@ -884,10 +890,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
                 zero_window(lo_idx);
                 if (active) { // words outside this pass's window go to a spare word of the lane's own (no hot spot)
-                        bool unused = false;
                         BitSink<true> sink = { 0, 0, (uint32_t) p0 & 31u, mywin, (uint32_t) (p0 >> 5), (uint32_t) lo_idx, (uint32_t) cap, win + W * kWin + tid };
                         sink.append(dc_str, dc_n);
-                        (void) walk_block<true, true>(w, tab, zrl, eob, sink, unused);
+                        walk_block(w, tab, zrl, eob, sink);
                         sink.finish();
                 }
                 __syncthreads();
