@@ -369,7 +369,7 @@ def test_block_parallel_coder_equals_wave_per_segment_coder(hip, po, sub, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sub", [420, 422, 444])
+@pytest.mark.parametrize("sub", [420, 422, 444, 1420])
 @pytest.mark.parametrize("dims", [(640, 88), (1040, 81), (512, 64), (48, 16), (1100, 50)])
 def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypatch):
     """Round 4: for UYVY (RGB) input with a restart interval that divides the 32 (64) consecutive MCUs a workgroup takes ONE kernel does the
@@ -381,11 +381,17 @@ def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypat
     import torch
     w, h = dims
     if sub != 444 and w % 16:
-        pytest.skip("the fused UYVY front end takes widths that are a multiple of 16 (others: the two-kernel path, covered elsewhere)")
-    # 4:4:4 = packed RGB input, R, G, B components, strips of 64 MCUs (any width: 1100 = 137.5 blocks, edge blocks replicated); 4:2:x = UYVY
+        pytest.skip("the fused UYVY / I420 front ends take widths that are a multiple of 16 (others: the two-kernel path, covered elsewhere)")
+    # 4:4:4 = packed RGB input, R, G, B components, 64 MCUs per workgroup (any width: 1100 = 137.5 blocks, edge blocks replicated); 4:2:x = UYVY;
+    # 1420 = planar I420 input (Y, U, V planes back to back) into the 4:2:0 encoder
+    planar = sub == 1420
+    sub = 420 if planar else sub
     fmt, pf = ("RGB", hip.L.PF_RGB) if sub == 444 else ("UYVY", hip.L.PF_UYVY)
     src = synth.s2_video(fmt, w, h)
     noisy = synth.s1_random(fmt, w, h, salt=9)
+    if planar:
+        pf = hip.L.PF_I420
+        src, noisy = (np.concatenate([p_.ravel() for p_ in po.uyvy_to_i420(x, w, h)]) for x in (src, noisy))
     for q, frame in ((75, src), (100, noisy), (20, src), (92, noisy)):
         dev = torch.from_numpy(frame).cuda()
         for ri in (1, 2, 4, 8, 16, 32, 64):

@@ -522,7 +522,7 @@ struct CodeArgs {
 constexpr int kProfPhases = 10;
 
 // WAVES = waves per workgroup.  SRC = 0: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES
-// that leaves the fewest lanes idle).  SRC = 420 (WAVES = 3) / 422 (WAVES = 2) / 444 (WAVES = 3): a workgroup = 32 (444: 64) consecutive MCUs of the
+// that leaves the fewest lanes idle).  SRC = 420 (WAVES = 3) / 422 (WAVES = 2) / 444 (WAVES = 3) / 1420 (planar I420, WAVES = 3): a workgroup = 32 (444: 64) consecutive MCUs of the
 // scan = 32 / ri whole segments (the restart interval must divide 32 / 64); UYVY: a 16-byte aligned frame of width % 16 == 0.
 // phase clock of the profiling runs: thread 0 of every workgroup adds the time since the previous mark to phase `i` (a.prof == NULL: nothing)
 #define UG_PHASE(i)                                                                                                      \
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         constexpr int kStageWords = 32 * kStageRow * 4; // per wave (SRC = 0)
         // window words per block: 16 = the private strings' size; the 4:2:0 fused kernel takes 12 (384 bits per block on a segment's average, 5 x
         // what a 4K q75 frame needs; beyond: the general path) -- that is what lets a sixth workgroup onto the CU
-        constexpr int kWin = SRC == 420 || SRC == 444 ? 12 : kWinWordsPerBlock;
+        constexpr int kWin = SRC == 420 || SRC == 1420 || SRC == 444 ? 12 : kWinWordsPerBlock;
         constexpr int kHalfPitch = 20; // words: half a block (64 B) + 16 B, conflict-free 128-bit accesses of consecutive lanes (fused hand-over)
         constexpr int kBufWords = (kPrivStride + kWin + 1) * W;
         static_assert(kBufWords >= WAVES * kStageWords && kBufWords >= kHalfPitch * W, "the three lives must fit");
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         } else {
                 // ---- fused front end: the arithmetic of uyvy_jpeg_fast_kernel (jpeg_fdct.hip), lane = block in FRAME order: the luma waves take
                 // one luma block row of the workgroup's 32 MCUs each (64 blocks), the last wave 32 Cb blocks (lanes 0-31) + 32 Cr blocks (lanes 32-63) ----
-                constexpr int kLumaWaves = SRC == 420 ? 2 : 1;
+                constexpr int kLumaWaves = SRC == 420 || SRC == 1420 ? 2 : 1;
                 const uint8_t *const src = a.src + (size_t) frame * a.src_stride;
                 const int height = a.height, pitch = a.pitch;
                 if (SRC == 444) {
@@ -717,6 +717,52 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 ug_jpeg::fdct8x8(q);
                                 ug_jpeg::quant_pack(q, div, w); // R, G and B are all quantised with table 0
                         } else {
+#pragma unroll
+                                for (int i = 0; i < 32; i++) w[i] = 0;
+                        }
+                } else if (SRC == 1420) {
+                        // planar 4:2:0 (I420: Y, U, V planes back to back, tightly packed; GPUJPEG_420_U8_P0P1P2, gpujpeg.cpp:335): the samples as they are
+                        const int cw = (a.width + 1) / 2, ch = (height + 1) / 2;
+                        const uint8_t *const up = src + (size_t) a.width * height, *const vp = up + (size_t) cw * ch;
+                        float q[64];
+                        bool valid;
+                        if (wv < kLumaWaves) {
+                                const int mm = m0 + (lane >> 1), my = mm / a.mcu_w, mx = mm - my * a.mcu_w;
+                                const int bx = 2 * mx + (lane & 1), brow = 2 * my + wv;
+                                valid = mm < a.n_mcu;
+                                if (valid) {
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+                                                const uint2 v2 = *(const uint2 *) (src + (long) min(8 * brow + r, height - 1) * a.width + 8 * bx);
+#pragma unroll
+                                                for (int x = 0; x < 4; x++) {
+                                                        q[8 * r + x] = (float) ((int) ((v2.x >> (8 * x)) & 0xff) - 128);
+                                                        q[8 * r + 4 + x] = (float) ((int) ((v2.y >> (8 * x)) & 0xff) - 128);
+                                                }
+                                        }
+                                        ug_jpeg::fdct8x8(q);
+                                        ug_jpeg::quant_pack(q, div, w);
+                                }
+                        } else {
+                                const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU of the workgroup
+                                const int mm = m0 + m, my = mm / a.mcu_w, mx = mm - my * a.mcu_w;
+                                valid = mm < a.n_mcu;
+                                if (valid) {
+                                        const uint8_t *const plane = c ? vp : up;
+#pragma unroll
+                                        for (int r = 0; r < 8; r++) {
+                                                const uint2 v2 = *(const uint2 *) (plane + (long) min(8 * my + r, ch - 1) * cw + 8 * mx);
+#pragma unroll
+                                                for (int x = 0; x < 4; x++) {
+                                                        q[8 * r + x] = (float) ((int) ((v2.x >> (8 * x)) & 0xff) - 128);
+                                                        q[8 * r + 4 + x] = (float) ((int) ((v2.y >> (8 * x)) & 0xff) - 128);
+                                                }
+                                        }
+                                        ug_jpeg::fdct8x8(q);
+                                        ug_jpeg::quant_pack(q, div + 64, w);
+                                }
+                        }
+                        if (!valid) {
 #pragma unroll
                                 for (int i = 0; i < 32; i++) w[i] = 0;
                         }
@@ -797,7 +843,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 constexpr int kRow = kHalfPitch / 4; // uint4 per row
                 const int m = sl * ri + ml; // MCU of the workgroup
                 const int id = SRC == 444 ? 64 * b + m
-                                          : (b < ybl ? (SRC == 420 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m);
+                                          : (b < ybl ? (kLumaWaves == 2 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                         if (half) __syncthreads(); // the first halves have been read
@@ -1435,7 +1481,10 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                                (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0;
         // packed RGB (4:4:4, R, G, B components): any width and alignment (the edge blocks of the picture are loaded byte by byte)
         const bool fused_rgb = !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0;
-        const bool fused = fused_yuv || fused_rgb;
+        // planar I420: 8-byte row pieces of the three planes (width % 16 == 0 keeps the chroma rows 8-byte aligned too)
+        const bool fused_i420 = !wave_path && e->allow_fused && in == UG_PF_I420 && e->sub == 420 && w % 16 == 0 && (!src_pitch || src_pitch == w) && !(7 & (uintptr_t) src_dev) &&
+                                (frames == 1 || !(src_stride & 7)) && 32 % e->ri == 0;
+        const bool fused = fused_yuv || fused_rgb || fused_i420;
         if (fused) {
                 // nothing to do here: the coder below reads the frame itself
         } else if (in == UG_PF_UYVY && e->sub != 444) { // fused unpack + subsample + FDCT + quantise, grid.z = frame
@@ -1520,7 +1569,8 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 }
                 const dim3 grid((unsigned) a.n_wg * frames);
                 if (fused) {
-                        if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), grid, dim3(192), 0, st, a, (const float *) e->div);
+                        if (fused_i420) hipLaunchKernelGGL((jpeg_code_kernel<3, 1420>), grid, dim3(192), 0, st, a, (const float *) e->div);
+                        else if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), grid, dim3(192), 0, st, a, (const float *) e->div);
                         else if (e->sub == 422) hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), grid, dim3(128), 0, st, a, (const float *) e->div);
                         else hipLaunchKernelGGL((jpeg_code_kernel<3, 444>), grid, dim3(192), 0, st, a, (const float *) e->div);
                 } else {
