@@ -43,6 +43,9 @@ WORKLOADS = {
     "8k-v210": dict(w=7680, h=4320, fmt="v210", bpp=16 / 6 + 1, frames=4, name="7680x4320 v210 unpack->YCoCg->DXT5 fused encode (BASELINE.json configs[4])"),
     "4k-uyvy-jpeg420": dict(w=3840, h=2160, fmt="UYVY", out="JPEG420", bpp=5.0, frames=8,
                             name="3840x2160 UYVY->planar 4:2:0 + 8x8 FDCT + quantise, fused (BASELINE.json configs[3]); one launch per frame"),
+    "4k-uyvy-jpeg-encode": dict(w=3840, h=2160, fmt="UYVY", out="JPEGENC", bpp=2.0 + 1531222 / (3840 * 2160), frames=8,
+                                name="3840x2160 UYVY -> JPEG 4:2:0 q75 restart 4, the whole encoder (forward DCT + quantiser + Huffman coding + byte stuffing fused, "
+                                     "stream assembly; ug_hip_jpeg_encoder_encode_batch, 8 frames per call, one synchronisation per call inside the timed region)"),
     "1080p-rgb-dxt1": dict(w=1920, h=1080, fmt="RGB", out="DXT1", bpp=3.5, frames=64, name="1920x1080 RGB->DXT1 encode (BASELINE.json configs[1])"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
@@ -269,7 +272,7 @@ def main() -> None:
             src[b, i] = torch.roll(bases[k % bases.shape[0]], 4 * 37 * (k // bases.shape[0]), dims=0)
     del bases
     src = src.view(B, F * frame_bytes)
-    out_bytes = {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3}[out_name]
+    out_bytes = {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3, "JPEGENC": 16}[out_name]
     dst = torch.empty((B, F * out_bytes), dtype=torch.uint8, device="cuda")
     pf = lib.PF_NAMES[wl["fmt"]]
     oid = lib.DXT5_YCOCG if out_name == "DXT5" else lib.DXT1
@@ -289,6 +292,22 @@ def main() -> None:
             rc = fn(420, src[b].data_ptr(), 0, W, H, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), F, frame_bytes,
                     4 * nblk * 128, nblk * 128, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.last_error()
+
+    if out_name == "JPEGENC":   # the whole JPEG encoder: F frames per (synchronous) call, streams into a per-batch buffer
+        import ctypes as C
+        l_ = lib.load()
+        enc = C.c_void_p()
+        assert l_.ug_hip_jpeg_encoder_create_sub(W, H, 75, 4, 420, C.byref(enc)) == 0, lib.last_error()
+        stride = (W * H + 4096 + 15) // 16 * 16          # a 4K q75 stream is ~1.5 MB; the capacity a caller would give a 4:2:0 frame of video
+        jout = torch.empty((B, F, stride), dtype=torch.uint8, device="cuda")
+        lens = (C.c_size_t * F)()
+        stream_bytes = [0]
+
+        def launch(b: int):  # noqa: F811
+            rc = l_.ug_hip_jpeg_encoder_encode_batch(enc, pf, F, src[b].data_ptr(), 0, frame_bytes, jout[b].data_ptr(), stride, stride, lens,
+                                                     torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.last_error()
+            stream_bytes[0] = sum(lens[f] for f in range(F))
 
     # calibrate the launches of a step: >= 50 ms of GPU work per step, so that box noise averages out and gpu_busy registers
     for b in range(B):
@@ -362,11 +381,20 @@ def main() -> None:
                 pmc = {}
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
-                "kernel": "uyvy_jpeg_kernel<420> (batched)" if out_name == "JPEG420" else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>",
+                "kernel": ("uyvy_jpeg_kernel<420> (batched)" if out_name == "JPEG420" else "jpeg_code_kernel<3,420> + jpeg_gather_kernel (one call)" if out_name == "JPEGENC"
+                           else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>"),
                 "ms_per_launch": round(kern_ms, 5), "launches_timed": args.steps * L,
                 "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * px_per_launch),
                 "algorithmic_bytes_per_px": round(ALG_BYTES_PER_PX, 4)}
-        if out_name != "JPEG420":
+        if out_name == "JPEGENC":
+            roof["bound"] = "valu"
+            roof["algorithmic_bytes_per_launch"] = int(2 * px_per_launch + stream_bytes[0])
+            roof["achieved"] = round(roof["algorithmic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
+            roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+            roof["us_per_frame"] = round(kern_ms * 1e3 / F, 2)
+            roof["note"] = ("the whole encoder per call of F frames, the call's own synchronisation included (ms_per_launch = time per call); algorithmic bytes = 2 B/px in + "
+                            "the stream bytes out; VALU-bound (DESIGN.md 4.5): ~2 100 instructions per wave of 64 blocks, half of them the forward DCT + quantiser")
+        elif out_name != "JPEG420":
             # The DXT encoders are VALU-issue bound, not HBM bound: `frac` above stays the contract's
             # algorithmic-bytes / 8 TB/s figure; `hbm_read_frac` is the north star's own definition (input bytes only);
             # `valu_frac` = wave-instructions issued per second / (256 CU x 2 wave-instr/clk x 2.4 GHz).
@@ -387,10 +415,13 @@ def main() -> None:
         else:
             ratio = f"{pmc['traffic'] / (ALG_BYTES_PER_PX * px_per_launch):.3f}x" if pmc.get("traffic") else "not measured"
             roof["note"] = f"HBM-bound kernel (DESIGN.md 4.3); HBM traffic / algorithmic bytes = {ratio}"
+        if out_name == "JPEGENC":
+            out_bytes = stream_bytes[0] // F   # (average stream of the last call)
         out = {
             "metric": {"4k-uyvy": "Mpixels/s encode (UYVY->DXT5-YCoCg, 4K)", "8k-v210": "Mpixels/s encode (v210->DXT5-YCoCg, 8K)",
                        "1080p-rgb-dxt1": "Mpixels/s encode (RGB->DXT1, 1080p)",
-                       "4k-uyvy-jpeg420": "Mpixels/s (UYVY->4:2:0->FDCT+quantise, 4K)"}[args.workload],
+                       "4k-uyvy-jpeg420": "Mpixels/s (UYVY->4:2:0->FDCT+quantise, 4K)",
+                       "4k-uyvy-jpeg-encode": "Mpixels/s (UYVY->JPEG 4:2:0 q75 stream, 4K)"}[args.workload],
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -407,7 +438,7 @@ def main() -> None:
             out["config"]["dist"] = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""), "world": world,
                                      "collectives": "barrier + all_reduce(MAX) around the timed steps, all_reduce(MAX) of the step size, all_gather of per-rank "
                                                     "e2e rates; on " + coll_dev + " tensors; never frame data"}
-        if not args.no_cpu_baseline and out_name != "JPEG420":   # rank 0, at every world size (the other ranks wait in destroy_process_group)
+        if not args.no_cpu_baseline and out_name not in ("JPEG420", "JPEGENC"):   # rank 0, at every world size (the other ranks wait in destroy_process_group)
             out["cpu_baseline"] = cpu_baseline(host[0], wl["fmt"], W, H, out=out_name)
             try:
                 ref = cpu_reference(wl["fmt"], W, H)

@@ -91,3 +91,17 @@ def test_gpus_flag_without_a_launcher_starts_its_own_ranks(hip):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["dist"]["world"] == 2 and d["value"] > 0
+
+
+def test_whole_jpeg_encoder_workload(hip):
+    """`--workload 4k-uyvy-jpeg-encode`: the whole encoder (fused kernel + stream assembly) as a bench line of its own, so that its rate is
+    reproducible with the driver's tool and not only with tools/bench_jpeg_batch.py."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "4k-uyvy-jpeg-encode", "--steps", "2", "--warmup", "1", "--launches-per-step", "4",
+                        "--no-e2e"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = _line(r.stdout)
+    assert REQUIRED <= set(d) and "JPEG" in d["metric"] and d["config"]["frames_per_launch"] == 8
+    roof = d["roofline"]
+    assert roof["bound"] == "valu" and 5 < roof["us_per_frame"] < 60 and 0 < roof["frac"] < 1
+    assert 1_000_000 < d["config"]["frame_bytes_out"] < 3_000_000            # a 4K q75 4:2:0 stream of video noise: ~1.5 MB
+    assert roof["algorithmic_bytes_per_launch"] == 8 * 3840 * 2160 * 2 + 8 * d["config"]["frame_bytes_out"] or abs(roof["algorithmic_bytes_per_launch"] - (8 * 3840 * 2160 * 2 + 8 * d["config"]["frame_bytes_out"])) < 8
