@@ -59,6 +59,21 @@ def test_gpu_deinterlace_bit_exact(hip, po):
         got = dev.cpu().numpy()
         assert np.array_equal(got[: f.size], po.deinterlace_blend(f, ls, lines)), (ls, lines)
         assert (got[f.size:] == 0xA5).all()                                  # nothing behind the frame is touched
+    # the kernel cuts a column into segments that run side by side and chains their summaries (csrc/deinterlace.hip): every way the steps
+    # of a picture can be dealt to 16 waves of <= 34 steps, one round and several, on content that sits on the thresholds of the summary
+    # (two-valued pictures, nearly flat ones) as well as noise
+    for lines in list(range(5, 84)) + [1087, 1091, 1092, 1093, 1095, 2179, 2183, 2185, 3300]:
+        for ls in ((68, 37) if lines < 84 else (80,)):
+            kind = (lines + ls) % 3
+            if kind == 0:
+                f = rng.integers(0, 256, ls * lines, dtype=np.uint8)
+            elif kind == 1:
+                f = (rng.integers(0, 2, ls * lines, dtype=np.uint8) * 255).astype(np.uint8)
+            else:
+                f = np.clip(rng.integers(0, 256) + rng.integers(-1, 2, ls * lines), 0, 255).astype(np.uint8)
+            dev = torch.from_numpy(f.copy()).cuda()
+            assert l.ug_hip_deinterlace_blend(dev.data_ptr(), ls, lines, None) == 0, L.last_error()
+            assert np.array_equal(dev.cpu().numpy(), po.deinterlace_blend(f, ls, lines)), (ls, lines, kind)
     # video content, three frames per launch, frames 4096 bytes further apart than they are long
     w, h, n = 1920, 1080, 3
     fr = [synth.s2_video("UYVY", w, h, salt=s) for s in range(n)]

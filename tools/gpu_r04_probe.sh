@@ -1,23 +1,23 @@
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 900 python -m pytest tests/test_gpu_jpeg.py tests/test_jpeg_rtp_compat.py -q 2>&1 | grep -E "passed|failed|^FAILED|assert" | tail -6
-timeout 600 python -m pytest tests/test_module_harness.py -k "jpeg" -q 2>&1 | grep -E "passed|failed" | tail -2
+timeout 600 python -m pytest tests/test_deinterlace.py tests/test_module_harness.py -q -k "deinterlace or interlaced" 2>&1 | grep -E "passed|failed|assert|Error" | tail -5
 python - <<'PY'
-import time, torch, numpy as np
-from ultragrid_amd import codec as hip, lib as L, synth
-from oracle import pyoracle as po
-w,h,n=3840,2160,8
-uyvy=synth.s2_video("UYVY",w,h)
-i420=np.concatenate([p.ravel() for p in po.uyvy_to_i420(uyvy,w,h)])
-dev=torch.from_numpy(i420).cuda()
-batch=torch.stack([torch.roll(dev, 3840*37*f) for f in range(n)])
-for env in ("fused","unfused"):
-    import os
-    if env=="unfused": os.environ["UG_JPEG_FUSED"]="0"
-    e=hip.JpegEncoder(w,h,75,4,subsampling=420)
-    for _ in range(5): e.encode_batch(batch, L.PF_I420)
-    torch.cuda.synchronize(); t=time.perf_counter(); k=0
-    while time.perf_counter()-t<1.0: e.encode_batch(batch, L.PF_I420); k+=1
-    dt=time.perf_counter()-t
-    print(f"I420 4K 4:2:0 q75 ri4 {env}: {dt/(k*n)*1e6:.1f} us per frame (incl. the python copy of the streams)")
-    e.close()
+import torch, time
+from ultragrid_amd import lib as L
+l=L.load()
+for (w,h,bpp,name) in ((1920,1080,2,"1080i UYVY"),(1920,1080,3,"1080i RGB"),(3840,2160,2,"4K UYVY")):
+    ls=w*bpp
+    n=8
+    buf=torch.randint(0,256,(n,ls*h),dtype=torch.uint8,device="cuda")
+    st=torch.cuda.current_stream().cuda_stream
+    for _ in range(3): l.ug_hip_deinterlace_blend_batch(buf.data_ptr(), ls, h, n, ls*h, st)
+    torch.cuda.synchronize(); e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): l.ug_hip_deinterlace_blend_batch(buf.data_ptr(), ls, h, n, ls*h, st)
+    e1.record(); torch.cuda.synchronize()
+    tb=e0.elapsed_time(e1)/20/n*1e3
+    e0.record()
+    for _ in range(20): l.ug_hip_deinterlace_blend(buf.data_ptr(), ls, h, st)
+    e1.record(); torch.cuda.synchronize()
+    t1=e0.elapsed_time(e1)/20*1e3
+    print(f"deinterlace {name}: {t1:.1f} us one frame, {tb:.1f} us per frame at 8 per launch ({2*ls*h/tb/1e3:.0f} GB/s)")
 PY
