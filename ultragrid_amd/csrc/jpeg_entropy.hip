@@ -354,58 +354,65 @@ __device__ __forceinline__ void walk_block(const uint32_t (&w)[32], const uint32
 constexpr int kPrivWords = 16;         // private string of a block: 512 bits (a 4K q75 frame needs ~80)
 constexpr int kPrivStride = 17;        // + one dump word for what does not fit; odd stride: the lanes' rows start in different banks
 
-// the lane's private bit string.  New bits enter a 64-bit accumulator at the bottom; `fill` (< 32 between appends) of its low bits have not
-// been stored as a complete word yet.  Every append stores the oldest 32 of them at row[idx] -- a complete word once fill reaches 32 (idx
-// then moves on), otherwise a value the next store to the same place replaces -- so there is no control flow and no masking: 10 operations.
+// the lane's private bit string in LDS (words of `base`, MSB first).  New bits enter a 64-bit accumulator at the bottom.  `pos` is the bit
+// address (relative to `base`) of the next bit MINUS 32: pos >> 5 is the word in front of the one being filled, pos & 31 the bits the latter
+// has.  Every append stores acc >> (pos & 31) -- one v_alignbit -- at word pos >> 5: when the append completed a word, that is the word; when
+// it did not, it is the word completed before, written once more with the same bits (the accumulator still holds them; in front of the
+// string's first word that is the dump word of the row below, or the pad word in front of the rows).  No control flow, no masking, no separate
+// fill / index bookkeeping: 6 operations (round 4's first form kept fill and index apart and took 9).
 struct PrivSink {
         unsigned long long acc;
-        uint32_t fill;
-        uint32_t *row;
-        uint32_t idx; // complete words so far (keeps counting past the end of the row: 32 idx + fill = the bits appended)
-        // CLAMP = false: the caller knows the word cannot lie outside the row (idx <= 8 at the head of a group of 8 coefficients without ZRL symbols)
+        uint32_t pos;
+        uint32_t *base;
+        uint32_t first; // word index of the row's first word (the dump word: first + kPrivWords)
+        // CLAMP = false: the caller knows the word cannot lie outside the row (at most 8 complete words at the head of a group of 8 coefficients without ZRL symbols)
         template <bool CLAMP = true>
         __device__ __forceinline__ void append(uint32_t str, uint32_t n) // n <= 27 bits; n == 0 (with str == 0) appends nothing
         {
                 acc = (acc << n) | str;
-                fill += n; // <= 31 + 27
-                row[CLAMP ? min(idx, (uint32_t) kPrivWords) : idx] = (uint32_t) (acc >> ((fill - 32u) & 63u)); // bits fill-1 .. fill-32 (fill < 32: not a word yet)
-                idx += fill >> 5;
-                fill &= 31u;
+                pos += n;
+                const uint32_t word = __builtin_amdgcn_alignbit((uint32_t) (acc >> 32), (uint32_t) acc, pos);
+                base[CLAMP ? min(pos >> 5, first + (uint32_t) kPrivWords) : pos >> 5] = word;
         }
-        __device__ __forceinline__ void finish() // the last, partial word, left-aligned (fill == 0: the string ended on a word boundary, nothing to add)
+        __device__ __forceinline__ uint32_t bits() const { return pos + 32u - 32u * first; }
+        __device__ __forceinline__ uint32_t words() const { return bits() >> 5; } // complete words so far
+        __device__ __forceinline__ void finish() // the last, partial word, left-aligned (no partial word: a value beyond the string's end, never read)
         {
-                row[min(idx, (uint32_t) kPrivWords)] = (uint32_t) acc << ((32u - fill) & 31u);
+                base[min((pos >> 5) + 1u, first + (uint32_t) kPrivWords)] = (uint32_t) acc << ((32u - pos) & 31u);
         }
-        __device__ __forceinline__ uint32_t bits() const { return 32u * idx + fill; }
 };
 
 // 8 coefficients of the one-walk coder.  ZRL: some block of the wave may meet a coefficient behind a zero run longer than 15 in this group
 // (then a wave-uniform branch at that position puts the 1..3 ZRL symbols in front of it); CLAMP: some private string may reach its end here.
 template <bool ZRL, bool CLAMP>
-__device__ __forceinline__ void walk_group_private(const uint32_t (&w)[32], const int g, const uint32_t *tab, uint32_t zl, uint32_t zc, uint32_t &run, PrivSink &sink)
+__device__ __forceinline__ void walk_group_private(const uint32_t (&w)[32], const int g, const uint32_t *tab, uint32_t zl, uint32_t zc, uint32_t &run16, PrivSink &sink)
 {
 #pragma unroll
         for (int k = g == 0 ? 1 : kWalkGroup * g; k < kWalkGroup * (g + 1); k++) {
                 const int v = coef_at(w, k);
+                const bool nz = v != 0;
 #if UG_JPEG_SKIP_POSITIONS
-                if (__ballot(v != 0) == 0) { // wave-uniform: this position is zero in all 64 blocks (two operations against ~25)
-                        run += 1u;
+                if (__ballot(nz) == 0) { // wave-uniform: this position is zero in all 64 blocks (two operations against ~20)
+                        run16 += 16u;
                         continue;
                 }
 #endif
-                const uint32_t neg = (uint32_t) (v >> 31);
-                const uint32_t a = ((uint32_t) v ^ neg) - neg;
-                const uint32_t size = 32u - (uint32_t) __clz((int) a); // 0 for a zero coefficient
-                const uint32_t e = tab[((run & 15u) << 4) | size];    // packed_ac_entry: a zero coefficient appends nothing
-                if (ZRL && k > 16 && __ballot(size != 0 && run > 15u) != 0) { // (a run of 16 zeros ends at position 17 at the earliest)
-                        const uint32_t zr = size ? run >> 4 : 0u; // one ZRL, then the other two together (<= 22 bits)
+                // T.81 F.1.2.1 without the absolute value: t = v (v >= 0) or v - 1 (v < 0) has |v|'s bit count in front of its sign run and
+                // its low `size` bits are the value bits; v_ffbh_i32 counts the sign run (-1 for t = 0: the saturating subtraction makes that size 0)
+                const int t = v + (v >> 31);
+                uint32_t sign_run;
+                asm("v_ffbh_i32 %0, %1" : "=v"(sign_run) : "v"(t));
+                const uint32_t size = __builtin_elementwise_sub_sat(32u, sign_run);
+                const uint32_t e = tab[(run16 & 0xF0u) | size];       // packed_ac_entry: a zero coefficient appends nothing
+                if (ZRL && k > 16 && __ballot(nz && run16 > 15u * 16u) != 0) { // (a run of 16 zeros ends at position 17 at the earliest)
+                        const uint32_t zr = nz ? run16 >> 8 : 0u; // one ZRL, then the other two together (<= 22 bits)
                         sink.append<true>(zr ? zc : 0u, zr ? zl : 0u);
                         const uint32_t two = zr > 2u ? (zc << zl) | zc : zc;
                         sink.append<true>(zr > 1u ? two : 0u, zr > 1u ? (zr - 1u) * zl : 0u);
                 }
-                const uint32_t vb = __builtin_amdgcn_ubfe((uint32_t) v + neg, 0, size); // v < 0: the low bits of v - 1 (T.81 F.1.2.1)
+                const uint32_t vb = __builtin_amdgcn_ubfe((uint32_t) t, 0, size);
                 sink.append<CLAMP>((e & kCodeMask) | vb, e >> 27);
-                run = size ? 0u : run + 1u;
+                run16 = nz ? 0u : run16 + 16u;
         }
 }
 
@@ -415,26 +422,26 @@ __device__ __forceinline__ void walk_group_private(const uint32_t (&w)[32], cons
 __device__ __forceinline__ void walk_private(const uint32_t (&w)[32], const uint32_t *tab, uint32_t zrl, uint32_t eob, PrivSink &sink)
 {
         const uint32_t zl = zrl >> 16, zc = zrl & 0xffffu;
-        uint32_t run = 0;
+        uint32_t run16 = 0; // 16 x the zero run: the table row's offset as it is
 #pragma unroll
         for (int g = 0; g < 64 / kWalkGroup; g++) {
                 uint32_t any = g == 0 ? w[0] & 0xffff0000u : w[kWalkGroup / 2 * g]; // the DC value is not an AC coefficient
 #pragma unroll
                 for (int i = 1; i < kWalkGroup / 2; i++) any |= w[kWalkGroup / 2 * g + i];
                 if (__ballot(any != 0) == 0) { // wave-uniform: nobody has a coefficient in this group
-                        run += g == 0 ? kWalkGroup - 1 : kWalkGroup;
+                        run16 += 16u * (g == 0 ? kWalkGroup - 1 : kWalkGroup);
                         continue;
                 }
                 // a zero run longer than 15 can end inside this group only in a lane that enters it with run + (kWalkGroup - 1) > 15
-                if (kWalkGroup * (g + 1) > 17 && __ballot(any != 0 && run + (uint32_t) (kWalkGroup - 1) > 15u) != 0) {
-                        walk_group_private<true, true>(w, g, tab, zl, zc, run, sink);
-                } else if (__ballot(sink.idx > (uint32_t) (kPrivWords - kWalkGroup)) != 0) { // 8 codes of <= 27 bits: at most 8 more words
-                        walk_group_private<false, true>(w, g, tab, zl, zc, run, sink);
+                if (kWalkGroup * (g + 1) > 17 && __ballot(any != 0 && run16 + 16u * (uint32_t) (kWalkGroup - 1) > 16u * 15u) != 0) {
+                        walk_group_private<true, true>(w, g, tab, zl, zc, run16, sink);
+                } else if (__ballot(sink.words() > (uint32_t) (kPrivWords - kWalkGroup)) != 0) { // 8 codes of <= 27 bits: at most 8 more words
+                        walk_group_private<false, true>(w, g, tab, zl, zc, run16, sink);
                 } else {
-                        walk_group_private<false, false>(w, g, tab, zl, zc, run, sink);
+                        walk_group_private<false, false>(w, g, tab, zl, zc, run16, sink);
                 }
         }
-        sink.append<true>(run ? eob & 0xffffu : 0u, run ? eob >> 16 : 0u); // EOB after the last non-zero coefficient (not when position 63 is coded)
+        sink.append<true>(run16 ? eob & 0xffffu : 0u, run16 ? eob >> 16 : 0u); // EOB after the last non-zero coefficient (not when position 63 is coded)
 }
 
 __device__ __forceinline__ int count_ff_valid(uint32_t word, int valid) // 0xFF bytes among the first `valid` (stream order) bytes of a window word
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         const int frame = (int) (index / (uint32_t) a.n_wg), wg = (int) (index - (uint32_t) frame * (uint32_t) a.n_wg);
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
         // one buffer, three lives: the block hand-over (SRC = 0: per wave 32 rows of 8 x 16 B, 144 B apart; fused: the workgroup's blocks, half a
-        // block at a time, 80 B apart), then [0, 17 W) the private strings and behind them the segments' windows (kWin words per block + one spare
+        // block at a time, 80 B apart), then (behind 4 pad words) the private strings, 17 W words, and behind them the segments' windows (kWin words per block + one spare
         // word per lane)
         constexpr int kStageRow = 9; // uint4 per row
         constexpr int kStageWords = 32 * kStageRow * 4; // per wave (SRC = 0)
@@ -565,14 +572,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         // what a 4K q75 frame needs; beyond: the general path) -- that is what lets a sixth workgroup onto the CU
         constexpr int kWin = SRC == 420 || SRC == 1420 || SRC == 444 ? 12 : kWinWordsPerBlock;
         constexpr int kHalfPitch = 20; // words: half a block (64 B) + 16 B, conflict-free 128-bit accesses of consecutive lanes (fused hand-over)
-        constexpr int kBufWords = (kPrivStride + kWin + 1) * W;
+        constexpr int kBufWords = (kPrivStride + kWin + 1) * W + 4; // (+ the pad in front of the private strings: 4 words, the windows stay 16-byte aligned)
         static_assert(kBufWords >= WAVES * kStageWords && kBufWords >= kHalfPitch * W, "the three lives must fit");
         __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
         constexpr int kMaxSeg = W / 3 + 1; // segments per workgroup: a segment has at least 3 blocks (4:4:4, restart interval 1)
         __shared__ int lds_wave_total[WAVES], lds_seg_bits[kMaxSeg], lds_flag[2];
         __shared__ uint32_t lds_seg_ff[kMaxSeg], lds_seg_off[kMaxSeg], lds_seg_done[kMaxSeg], lds_base;
-        uint32_t *const priv = buf;
-        uint32_t *const win = buf + kPrivStride * W;
+        uint32_t *const priv = buf + 4; // buf[3]: where a string's first append rewrites "the word before" (PrivSink)
+        uint32_t *const win = priv + kPrivStride * W;
         // the DC values, then the inclusive bit positions, live in the spare words behind the windows (which only the general path's emission
         // uses, later): with them the 4:2:0 kernel stays under 26 KB, the size at which six workgroups fit a CU's 160 KB
         int *const lds_dc = (int *) (win + W * kWin), *const lds_incl = lds_dc;
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
 #pragma unroll
                                                 for (int c = 0; c < 8; c++) {
                                                         const int bi = 3 * c + cc;
-                                                        q[8 * r + c] = (float) ((int) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff) - 128);
+                                                        q[8 * r + c] = (float) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff);
                                                 }
                                         }
                                 };
@@ -736,8 +743,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                                 const uint2 v2 = *(const uint2 *) (src + (long) min(8 * brow + r, height - 1) * a.width + 8 * bx);
 #pragma unroll
                                                 for (int x = 0; x < 4; x++) {
-                                                        q[8 * r + x] = (float) ((int) ((v2.x >> (8 * x)) & 0xff) - 128);
-                                                        q[8 * r + 4 + x] = (float) ((int) ((v2.y >> (8 * x)) & 0xff) - 128);
+                                                        q[8 * r + x] = (float) ((v2.x >> (8 * x)) & 0xff);
+                                                        q[8 * r + 4 + x] = (float) ((v2.y >> (8 * x)) & 0xff);
                                                 }
                                         }
                                         ug_jpeg::fdct8x8(q);
@@ -754,8 +761,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                                 const uint2 v2 = *(const uint2 *) (plane + (long) min(8 * my + r, ch - 1) * cw + 8 * mx);
 #pragma unroll
                                                 for (int x = 0; x < 4; x++) {
-                                                        q[8 * r + x] = (float) ((int) ((v2.x >> (8 * x)) & 0xff) - 128);
-                                                        q[8 * r + 4 + x] = (float) ((int) ((v2.y >> (8 * x)) & 0xff) - 128);
+                                                        q[8 * r + x] = (float) ((v2.x >> (8 * x)) & 0xff);
+                                                        q[8 * r + 4 + x] = (float) ((v2.y >> (8 * x)) & 0xff);
                                                 }
                                         }
                                         ug_jpeg::fdct8x8(q);
@@ -782,12 +789,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                                 const uint32_t ww[4] = { v4.x, v4.y, v4.z, v4.w };
 #pragma unroll
                                                 for (int k = 0; k < 4; k++) {
-                                                        q[8 * r + 2 * k] = (float) ((int) ((ww[k] >> 8) & 0xff) - 128);
-                                                        q[8 * r + 2 * k + 1] = (float) ((int) (ww[k] >> 24) - 128);
+                                                        q[8 * r + 2 * k] = (float) ((ww[k] >> 8) & 0xff);
+                                                        q[8 * r + 2 * k + 1] = (float) (ww[k] >> 24);
                                                 }
                                         }
                                         ug_jpeg::fdct8x8(q);
                                         ug_jpeg::quant_pack(q, div, w);
+                                        // (the two front ends end differently on purpose: left alike, the compiler sinks their common tail -- forward DCT
+                                        // and quantiser -- behind the branch with the quantiser table chosen at run time, 128 scalar loads from computed
+                                        // addresses and SGPR spills: 1 890 instructions per wave instead of 1 340)
+                                        asm volatile("; luma blocks made" : "+v"(w[31]));
                                 }
                         } else {
                                 const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU of the workgroup
@@ -803,29 +814,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                                 } else {
                                                         y0 = y1 = min(8 * my + r, height - 1);
                                                 }
-                                                const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * mx);
-                                                const uint4 a0 = p0[0], a1 = p0[1];
-                                                const uint32_t wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-                                                if (SRC == 420) {
-                                                        const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * mx);
-                                                        const uint4 c0 = p1[0], c1 = p1[1];
-                                                        const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-#pragma unroll
-                                                        for (int x = 0; x < 8; x++) { // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367)
-                                                                const int sa = c ? (wa[x] >> 16) & 0xff : wa[x] & 0xff;
-                                                                const int sb = c ? (wc[x] >> 16) & 0xff : wc[x] & 0xff;
-                                                                q[8 * r + x] = (float) (((sa + sb + 1) >> 1) - 128);
-                                                        }
-                                                } else {
-#pragma unroll
-                                                        for (int x = 0; x < 8; x++) { // uyvy_to_i422 (video_codec.c:949-969): samples as they are
-                                                                const int sa = c ? (wa[x] >> 16) & 0xff : wa[x] & 0xff;
-                                                                q[8 * r + x] = (float) (sa - 128);
-                                                        }
-                                                }
+                                                // this lane's half of the MCU's 32-byte row piece (Cb lanes the first 16 bytes, Cr lanes the second)
+                                                const uint4 a0 = *(const uint4 *) (src + (long) y0 * pitch + 32 * mx + 16 * c);
+                                                uint32_t wa[4] = { a0.x, a0.y, a0.z, a0.w };
+                                                if (SRC == 420) { // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367), all four bytes of a word at once
+                                                        const uint4 c0 = *(const uint4 *) (src + (long) y1 * pitch + 32 * mx + 16 * c);
+                                                        wa[0] = ug_jpeg::avg_bytes(wa[0], c0.x); wa[1] = ug_jpeg::avg_bytes(wa[1], c0.y);
+                                                        wa[2] = ug_jpeg::avg_bytes(wa[2], c0.z); wa[3] = ug_jpeg::avg_bytes(wa[3], c0.w);
+                                                } // else uyvy_to_i422 (video_codec.c:949-969): samples as they are
+                                                ug_jpeg::chroma_row_from_uyvy(wa, q + 8 * r);
                                         }
                                         ug_jpeg::fdct8x8(q);
                                         ug_jpeg::quant_pack(q, div + 64, w);
+                                        asm volatile("; chroma blocks made" : "+v"(w[31]));
                                 }
                         }
                         if (!valid) {
@@ -888,7 +889,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         uint32_t *const row = priv + tid * kPrivStride;
         uint32_t nbits = 0;
         if (active) { // idle lanes stay out of the walk
-                PrivSink sink = { 0ull, 0u, row, 0u };
+                const uint32_t first = 4u + (uint32_t) tid * kPrivStride;
+                PrivSink sink = { 0ull, 32u * first - 32u, buf, first };
                 sink.append<false>(dc_str, dc_n);
                 walk_private(w, tab, zrl, eob, sink);
                 nbits = sink.bits();

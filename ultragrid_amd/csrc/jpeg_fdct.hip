@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
                                 const uint2 q = *(const uint2 *) (plane + (long) (8 * by + r) * pitch + 8 * bx);
 #pragma unroll
                                 for (int c = 0; c < 4; c++) {
-                                        b[8 * r + c] = (float) ((int) ((q.x >> (8 * c)) & 0xff) - 128);
-                                        b[8 * r + 4 + c] = (float) ((int) ((q.y >> (8 * c)) & 0xff) - 128);
+                                        b[8 * r + c] = (float) ((q.x >> (8 * c)) & 0xff);
+                                        b[8 * r + 4 + c] = (float) ((q.y >> (8 * c)) & 0xff);
                                 }
                         }
                 } else { // edge replication
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void fdct_quant_plane_kernel(const uint8_t *__
 #pragma unroll
                                 for (int c = 0; c < 8; c++) {
                                         const int x = min(8 * bx + c, width - 1);
-                                        b[8 * r + c] = (float) ((int) plane[(long) y * pitch + (long) x * xstride] - 128);
+                                        b[8 * r + c] = (float) plane[(long) y * pitch + (long) x * xstride];
                                 }
                         }
                 }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void rgb_jpeg444_kernel(const uint8_t *__restr
 #pragma unroll
                                 for (int c = 0; c < 8; c++) {
                                         const int bi = 3 * c + comp;
-                                        b[8 * r + c] = (float) ((int) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff) - 128);
+                                        b[8 * r + c] = (float) ((raw[r][bi >> 2] >> (8 * (bi & 3))) & 0xff);
                                 }
                         }
                         fdct8x8(b);
@@ -266,14 +266,14 @@ __global__ __launch_bounds__(256) void uyvy_jpeg_kernel(const uint8_t *__restric
                                 const uint32_t w[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
                                 for (int k = 0; k < 4; k++) {
-                                        b[8 * r + 2 * k] = (float) ((int) ((w[k] >> 8) & 0xff) - 128);
-                                        b[8 * r + 2 * k + 1] = (float) ((int) (w[k] >> 24) - 128);
+                                        b[8 * r + 2 * k] = (float) ((w[k] >> 8) & 0xff);
+                                        b[8 * r + 2 * k + 1] = (float) (w[k] >> 24);
                                 }
                         } else {
 #pragma unroll
                                 for (int c = 0; c < 8; c++) {
                                         const int x = min(8 * bx + c, width - 1);
-                                        b[8 * r + c] = (float) ((int) row[2 * x + 1] - 128);
+                                        b[8 * r + c] = (float) row[2 * x + 1];
                                 }
                         }
                 }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void uyvy_jpeg_kernel(const uint8_t *__restric
                         for (int c = 0; c < 8; c++) {
                                 const int cx = min(8 * bx + c, cw - 1);
                                 const int a = r0[4 * cx + 2 * comp], bb = r1[4 * cx + 2 * comp];
-                                b[8 * r + c] = (float) ((SUB == 420 ? (a + bb + 1) >> 1 : a) - 128);
+                                b[8 * r + c] = (float) (SUB == 420 ? (a + bb + 1) >> 1 : a);
                         }
                 }
                 fdct8x8(b);
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(
                                 const uint32_t ww[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
                                 for (int k = 0; k < 4; k++) {
-                                        b[8 * r + 2 * k] = (float) ((int) ((ww[k] >> 8) & 0xff) - 128);
-                                        b[8 * r + 2 * k + 1] = (float) ((int) (ww[k] >> 24) - 128);
+                                        b[8 * r + 2 * k] = (float) ((ww[k] >> 8) & 0xff);
+                                        b[8 * r + 2 * k + 1] = (float) (ww[k] >> 24);
                                 }
                         }
                         fdct8x8(b);
@@ -360,27 +360,15 @@ __global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(
                                 } else {
                                         y0 = y1 = min(8 * my + r, height - 1);
                                 }
-                                const uint4 *p0 = (const uint4 *) (src + (long) y0 * pitch + 32 * (mcu0 + m));
-                                const uint4 a0 = p0[0], a1 = p0[1];
-                                const uint32_t wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-                                if (SUB == 420) {
-                                        const uint4 *p1 = (const uint4 *) (src + (long) y1 * pitch + 32 * (mcu0 + m));
-                                        const uint4 c0 = p1[0], c1 = p1[1];
-                                        const uint32_t wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-#pragma unroll
-                                        for (int c = 0; c < 8; c++) {
-                                                // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367)
-                                                const int sa = comp ? (wa[c] >> 16) & 0xff : wa[c] & 0xff;
-                                                const int sb = comp ? (wc[c] >> 16) & 0xff : wc[c] & 0xff;
-                                                b[8 * r + c] = (float) (((sa + sb + 1) >> 1) - 128);
-                                        }
-                                } else {
-#pragma unroll
-                                        for (int c = 0; c < 8; c++) { // uyvy_to_i422 (video_codec.c:949-969): samples as they are
-                                                const int sa = comp ? (wa[c] >> 16) & 0xff : wa[c] & 0xff;
-                                                b[8 * r + c] = (float) (sa - 128);
-                                        }
-                                }
+                                // this lane's half of the MCU's 32-byte row piece (Cb lanes the first 16 bytes, Cr lanes the second)
+                                const uint4 a0 = *(const uint4 *) (src + (long) y0 * pitch + 32 * (mcu0 + m) + 16 * comp);
+                                uint32_t wa[4] = { a0.x, a0.y, a0.z, a0.w };
+                                if (SUB == 420) { // (a + b + 1) / 2 of uyvy_to_i420 (to_planar.c:364-367), all four bytes of a word at once
+                                        const uint4 c0 = *(const uint4 *) (src + (long) y1 * pitch + 32 * (mcu0 + m) + 16 * comp);
+                                        wa[0] = avg_bytes(wa[0], c0.x); wa[1] = avg_bytes(wa[1], c0.y);
+                                        wa[2] = avg_bytes(wa[2], c0.z); wa[3] = avg_bytes(wa[3], c0.w);
+                                } // else uyvy_to_i422 (video_codec.c:949-969): samples as they are
+                                chroma_row_from_uyvy(wa, b + 8 * r);
                         }
                         fdct8x8(b);
                         quant_pack(b, div + 64, w);

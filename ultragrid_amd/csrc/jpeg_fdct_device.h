@@ -1,6 +1,6 @@
 // jpeg_fdct_device.h -- the per-lane 8x8 forward DCT + quantiser of the JPEG path (one lane owns one block: 64 fp32 registers in, 32 packed
 // int16 pairs out, zig-zag order), shared by the stand-alone front-end kernels (jpeg_fdct.hip) and the fused encoder kernel
-// (jpeg_entropy.hip).  Specified by oracle/jpeg_oracle.c (level shift, AAN float FDCT rows-then-columns, fp32 reciprocal quantiser with the
+// (jpeg_entropy.hip).  Specified by oracle/jpeg_oracle.c (level shift -- folded into the row pass's DC term here, see fdct8x8 --, AAN float FDCT rows-then-columns, fp32 reciprocal quantiser with the
 // AAN scale folded in, rintf, zig-zag); same operation order, no FMA contraction (-ffp-contract=off).  In UltraGrid this stage is inside
 // gpujpeg_encoder_encode() (src/video_compress/gpujpeg.cpp:624, external libgpujpeg).
 #ifndef UG_JPEG_FDCT_DEVICE_H
@@ -42,15 +42,43 @@ __device__ __forceinline__ void aan_1d(float &d0, float &d1, float &d2, float &d
         d7 = z11 - z4;
 }
 
+// b = the samples AS THEY ARE (0..255).  The level shift of 128 (T.81 A.3.1; oracle/jpeg_oracle.c subtracts it from every sample) is applied
+// behind the row pass, as 8 subtractions per block instead of 64: the one row output it reaches is d0, the sum of the row's eight samples
+// (every other output is built from differences of samples, or of sums of equally many), and d0 and every value on the way to it are integers
+// below 2^24 -- exact in fp32 with or without the shift.  d0 - 1024 here and the d0 of shifted samples are the same float: same bits out.
 __device__ __forceinline__ void fdct8x8(float (&b)[64])
 {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
                 aan_1d(b[8 * r], b[8 * r + 1], b[8 * r + 2], b[8 * r + 3], b[8 * r + 4], b[8 * r + 5], b[8 * r + 6], b[8 * r + 7]);
+                b[8 * r] -= 1024.0f;
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
                 aan_1d(b[c], b[8 + c], b[16 + c], b[24 + c], b[32 + c], b[40 + c], b[48 + c], b[56 + c]);
+        }
+}
+
+// (a + b + 1) >> 1 on the four bytes of a word at once (v_lerp_u8): the vertical chroma average of uyvy_to_i420 (to_planar.c:364-367)
+__device__ __forceinline__ uint32_t avg_bytes(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
+
+// One row of a chroma block from UYVY, for a wave whose lanes L (Cb) and L + 32 (Cr) work on the same MCU: each of the two loads HALF of the
+// MCU's 32-byte row piece (lane L the first 16 bytes = pixel pairs 0-3, lane L + 32 the second = pairs 4-7; `w` = those four words, for 4:2:0
+// already averaged with the line below by avg_bytes) and they trade what the other needs -- U bytes against V bytes -- with ONE
+// v_permlane32_swap: packed U of all lanes in `u`, packed V in `v`; the swap exchanges u's upper half with v's lower half, after which u
+// holds samples 0-3 and v samples 4-7 of the lane's own component in both halves of the wave.  4 v_perm + 1 swap + 8 v_cvt_f32_ubyte per row,
+// and half the loads (and registers in flight) of every lane fetching all 32 bytes to use a quarter of them.
+__device__ __forceinline__ void chroma_row_from_uyvy(const uint32_t (&w)[4], float *q8)
+{
+        const uint32_t t0 = __builtin_amdgcn_perm(w[1], w[0], 0x06020400u); // U0 U1 V0 V1
+        const uint32_t t1 = __builtin_amdgcn_perm(w[3], w[2], 0x06020400u); // U2 U3 V2 V3
+        const uint32_t u = __builtin_amdgcn_perm(t1, t0, 0x05040100u), v = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, v, false, false); // [0]: u with its lanes 32-63 <- v's lanes 0-31; [1]: v with its lanes 0-31 <- u's lanes 32-63
+        const uint32_t lo = sw[0], hi = sw[1];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+                q8[x] = (float) ((lo >> (8 * x)) & 0xff);
+                q8[4 + x] = (float) ((hi >> (8 * x)) & 0xff);
         }
 }
 
