@@ -1064,11 +1064,78 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 }
                 __syncthreads();
                 UG_PHASE(4) // merge
-                count_pass(0);
-                UG_PHASE(5) // 0xFF count
-                place();
-                UG_PHASE(6) // offsets + look-back
-                write_pass(0, true, false);
+                // ---- byte stuffing and write-out, every lane at once: the S lanes of a segment's stretch of the workgroup take K consecutive
+                // words of its window each (K = words / S rounded up; the lanes of the segment's blocks or not: this is byte work).  One pass
+                // counts the bytes the lane will write (its bytes + one 0x00 per 0xFF; the segment's last lane + 2 for RSTm / EOI); ONE prefix sum
+                // over the workgroup turns the counts into positions in the workgroup's stretch of the stream -- segment sizes, segment
+                // offsets and the stretch's length all fall out of it --; a second pass over the same words writes.  (Rounds 2-4 went through
+                // the segments one by one, a wave each: a count with a wave scan per segment, a scan over the segments, a write-out with
+                // another wave scan per 64 words -- a third of the instructions behind the walk.)  The 1-bits that pad a segment's last byte
+                // (T.81 F.1.2.3) are ORed in where the word is read.
+                const int nbytes = (seg_bits + 7) >> 3, nwords = (nbytes + 3) >> 2; // (0 for lanes behind the workgroup's last segment)
+                const int K = (nwords + S - 1) / S, i_first = j * K;
+                const int padw = seg_bits >> 5, padn = 8 - (seg_bits & 7);
+                const uint32_t padmask = (seg_bits & 7) ? ((1u << padn) - 1u) << (32 - (seg_bits & 31) - padn) : 0u;
+                const bool seg_last = sl < nseg_wg && j == S - 1; // the lane that writes the marker behind the segment
+                uint32_t mine = seg_last ? 2u : 0u;
+                for (int k = 0; k < K; k++) {
+                        const int i = i_first + k;
+                        if (i < nwords) {
+                                const int valid = min(4, nbytes - 4 * i);
+                                mine += (uint32_t) (valid + count_ff_valid(mywin[i] | (i == padw ? padmask : 0u), valid));
+                        }
+                }
+                const uint32_t incl_b = (uint32_t) wave_inclusive_scan((int) mine, lane);
+                if (lane == 63) lds_wave_total[wv] = (int) incl_b; // (the bit totals were read two barriers ago)
+                __syncthreads();
+                uint32_t before_w = 0, stretch = 0;
+#pragma unroll
+                for (int k = 0; k < WAVES; k++) {
+                        const uint32_t t = (uint32_t) lds_wave_total[k];
+                        before_w += k < wv ? t : 0u;
+                        stretch += t;
+                }
+                UG_PHASE(5) // byte counts + prefix sum
+                uint32_t base = 0;
+                if (a.slots != nullptr) { // wave-uniform: the stretch goes to the workgroup's slot, the gather kernel places it
+                        if (tid == 0) {
+                                a.wg_bytes[(size_t) frame * a.n_wg + wg] = stretch;
+                                if ((size_t) stretch > a.slot_bytes) a.total_pinned[kMaxBatch + 1] = 1u; // does not fit its slot: the host runs the call again, with the look-back
+                        }
+                } else {
+                        if (wv == 0) {
+                                const uint32_t before = lookback_exclusive(a.status + (long) frame * a.n_status, wg, stretch, a.gen, lane, a.total_pinned + kMaxBatch);
+                                if (lane == 0) lds_base = (uint32_t) a.header_len + before;
+                        }
+                        __syncthreads();
+                        base = lds_base;
+                }
+                UG_PHASE(6) // the stretch's place (look-back)
+                const uint32_t at = base + before_w + incl_b - mine; // this lane's first byte
+                if ((size_t) at + mine <= capacity) { // (what would not fit is not written: the host reports the size the stream needs)
+                        uint8_t *p = out + at;
+                        for (int k = 0; k < K; k++) {
+                                const int i = i_first + k;
+                                if (i < nwords) {
+                                        const int valid = min(4, nbytes - 4 * i);
+                                        const uint32_t word = mywin[i] | (i == padw ? padmask : 0u);
+#pragma unroll
+                                        for (int t = 0; t < 4; t++) {
+                                                if (t < valid) {
+                                                        const uint8_t byte = (uint8_t) (word >> (24 - 8 * t));
+                                                        *p++ = byte;
+                                                        if (byte == 0xFF) *p++ = 0;
+                                                }
+                                        }
+                                }
+                        }
+                        if (seg_last) {
+                                const int sg = seg0 + sl;
+                                p[0] = 0xFF;
+                                p[1] = sg == a.n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (sg & 7));
+                        }
+                }
+                if (seg_last && seg0 + sl == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = at + mine; // the stream's length
                 UG_PHASE(7) // write-out
                 if (a.prof != nullptr && threadIdx.x == 0) a.prof[(size_t) blockIdx.x * (kProfPhases + 1) + kProfPhases] = 1ull;
         } else {
