@@ -577,12 +577,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
         constexpr int kMaxSeg = W / 3 + 1; // segments per workgroup: a segment has at least 3 blocks (4:4:4, restart interval 1)
         __shared__ int lds_wave_total[WAVES], lds_seg_bits[kMaxSeg], lds_flag[2];
-        __shared__ uint32_t lds_seg_ff[kMaxSeg], lds_seg_off[kMaxSeg], lds_seg_done[kMaxSeg], lds_base;
+        __shared__ uint32_t lds_base;
+        __shared__ int lds_nb[SRC == 0 ? 1 : W]; // fused: the code lengths, by scan index (the lanes hold their blocks in frame order)
         uint32_t *const priv = buf + 4; // buf[3]: where a string's first append rewrites "the word before" (PrivSink)
         uint32_t *const win = priv + kPrivStride * W;
+        // per segment, the general path only -- which has no use for the private strings: their place
+        uint32_t *const lds_seg_ff = priv, *const lds_seg_off = priv + kMaxSeg, *const lds_seg_done = priv + 2 * kMaxSeg;
+        static_assert(3 * kMaxSeg <= kPrivStride * W, "the general path's per-segment words fit the private strings' place");
         // the DC values, then the inclusive bit positions, live in the spare words behind the windows (which only the general path's emission
         // uses, later): with them the 4:2:0 kernel stays under 26 KB, the size at which six workgroups fit a CU's 160 KB
-        int *const lds_dc = (int *) (win + W * kWin), *const lds_incl = lds_dc;
+        __shared__ int lds_pos0[SRC == 0 ? W : 1];
+        // (SRC = 0 has no barrier between the DC reads and the positions' writes: a place of their own there)
+        int *const lds_dc = (int *) (win + W * kWin), *const lds_incl = SRC == 0 ? lds_pos0 : lds_dc;
         const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: say so, or the waves' branches compile as divergent ones)
         // (the Huffman tables are copied to LDS further down, behind the block loads: nothing ahead of the first barrier needs them, and their
         // memory round trip then runs beside the pixels' instead of in front of it)
@@ -593,10 +599,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 }
                 if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
                 if (tid < 2) lds_flag[tid] = 0;
-                if (tid < kMaxSeg) {
-                        lds_seg_ff[tid] = 0;
-                        lds_seg_done[tid] = 0;
-                }
         };
         const int ybl = a.hs * a.vs, per_mcu = ybl + 2, S = a.S, ri = a.ri;
         // ---- which segments, which block ----
@@ -612,12 +614,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 seg0 = m0 / ri;
                 nseg_wg = min(kMcus / ri, a.n_seg - seg0);
         }
-        // which block this lane CODES (scan order).  The fused variants work it out behind their front end -- six values that would otherwise
-        // sit in registers through the forward DCT, where the 4:2:0 kernel has none to spare at five waves per SIMD
-        int sl, j, m_first, n_blk, ml, b, comp;
+        // which block this lane CODES: `sid`, its index in scan order among the workgroup's blocks.  SRC = 0: the lanes are in scan order.  Fused:
+        // every lane codes the block it made -- the lanes are in FRAME order (a wave = a luma block row, or the chroma blocks, of the 32 MCUs;
+        // 4:4:4: a component of 64 MCUs) and stay there: what the scan order decides -- the DC predictions, the bit positions -- goes through
+        // small LDS arrays indexed by sid, the coefficients never change lanes.  (Round 4's first form handed the blocks over to scan-order lanes
+        // through LDS, 128 B per lane and four barriers: a tenth of the workgroup's time; and a wave of chroma blocks alone, or luma blocks alone,
+        // skips more of the zero positions than a mixed one.)  The fused variants work the identity out behind their front end -- values that
+        // would otherwise sit in registers through the forward DCT, where the 4:2:0 kernel has none to spare at five waves per SIMD
+        int sid = tid, sl, j, m_first, n_blk, ml, b, comp;
         bool active;
         auto identify = [&]() {
-                sl = tid / S; j = tid - sl * S;                  // segment of the workgroup, block of the segment
+                sl = sid / S; j = sid - sl * S;                  // segment of the workgroup, block of the segment
                 m_first = (seg0 + sl) * ri;
                 n_blk = sl < nseg_wg ? per_mcu * (min(a.n_mcu, m_first + ri) - m_first) : 0;
                 active = j < n_blk;
@@ -835,43 +842,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         }
                 }
                 init_tables();
+                sid = SRC == 444 ? 3 * lane + wv
+                                 : (wv < kLumaWaves ? per_mcu * (lane >> 1) + (kLumaWaves == 2 ? 2 * wv : 0) + (lane & 1) : per_mcu * (lane & 31) + ybl + (lane >> 5));
                 identify();
                 UG_PHASE(0) // pixels -> quantised block (wave 0's view, like all the marks)
-                // frame order -> scan order through LDS: block id = tid (luma row r, column c: 64 r + c; chroma: 64 kLumaWaves + 32 comp + MCU).  Half a
-                // block at a time -- every lane stores the first 64 bytes of the block it made and takes the first 64 of the block it will code into
-                // the registers just stored, then the same for the second halves: no second register set, and 15 KB of LDS instead of 27
-                uint4 *const store = (uint4 *) buf;
-                constexpr int kRow = kHalfPitch / 4; // uint4 per row
-                const int m = sl * ri + ml; // MCU of the workgroup
-                const int id = SRC == 444 ? 64 * b + m
-                                          : (b < ybl ? (kLumaWaves == 2 ? 64 * (b >> 1) + 2 * m + (b & 1) : 2 * m + b) : 64 * kLumaWaves + 32 * (b - ybl) + m);
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                        if (half) __syncthreads(); // the first halves have been read
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                                const int k = 16 * half + 4 * i;
-                                store[tid * kRow + i] = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
-                        }
-                        __syncthreads();
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                                const int k = 16 * half + 4 * i;
-                                uint4 r = store[(active ? id : 0) * kRow + i];
-                                if (!active) r = make_uint4(0, 0, 0, 0);
-                                w[k] = r.x; w[k + 1] = r.y; w[k + 2] = r.z; w[k + 3] = r.w;
-                        }
-                }
         }
         // DC difference: the previous block of the same component sits `back` lanes below (luma: the previous luma block of the
         // scan -- one lane back, or across the two chroma blocks of the previous MCU; chroma: one MCU back); none at a segment start
         const int dc = coef_at(w, 0);
-        lds_dc[tid] = dc;
-        __syncthreads(); // tables, DC values; the hand-over buffer has been read
-        UG_PHASE(1) // hand-over (SRC = 0: the block loads)
+        lds_dc[sid] = dc;
+        __syncthreads(); // tables, DC values; (SRC = 0) the staging rows have been read
+        UG_PHASE(1) // tables + DC values (SRC = 0: the block loads)
         const int back = b < ybl ? (b > 0 ? 1 : 3) : per_mcu;
         const bool has_pred = b < ybl ? j > 0 : ml > 0;
-        const int diff = dc - (has_pred ? lds_dc[max(tid - back, 0)] : 0);
+        const int diff = dc - (has_pred ? lds_dc[max(sid - back, 0)] : 0);
         const uint32_t dneg = (uint32_t) (diff >> 31), da = ((uint32_t) diff ^ dneg) - dneg;
         const uint32_t dsize = 32u - (uint32_t) __clz((int) da);
         const uint32_t de = dc_tab[comp][dsize];
@@ -879,7 +863,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         const uint32_t *const tab = ac_tab[comp];
         const uint32_t dc_vb = ((uint32_t) diff + dneg) & ((1u << dsize) - 1u);
         const uint32_t dc_str = active ? ((de & 0xffffu) << dsize) | dc_vb : 0u, dc_n = active ? (de >> 16) + dsize : 0u;
-        // the windows start out zero (this lane's 16 words; the hand-over buffer they overlay has been read: the barrier above)
+        // the windows start out zero (this lane's 16 words; SRC = 0: the staging rows they overlay have been read: the barrier above)
         {
                 uint4 *const z = (uint4 *) (win + tid * kWin);
 #pragma unroll
@@ -899,18 +883,29 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         }
         UG_PHASE(2) // the walk
         // ---- bit position of every block inside its segment: prefix sum over the workgroup, made segment-relative ----
-        const int incl_w = wave_inclusive_scan((int) nbits, lane);
+        int len_scan = (int) nbits; // the length of the block whose scan index is tid
+        if (SRC != 0) {
+                lds_nb[sid] = (int) nbits;
+                __syncthreads();
+                len_scan = lds_nb[tid];
+        }
+        const int incl_w = wave_inclusive_scan(len_scan, lane);
+        lds_incl[tid] = incl_w; // inclusive bit position inside the wave, by scan index (fused: the DC values were read a barrier ago)
         if (lane == 63) lds_wave_total[wv] = incl_w;
         __syncthreads();
-        int wave_base = 0;
+        int wave_total[WAVES];
 #pragma unroll
-        for (int k = 0; k < WAVES; k++) wave_base += k < wv ? lds_wave_total[k] : 0;
-        const int incl = wave_base + incl_w, excl = incl - (int) nbits;
-        lds_incl[tid] = incl; // (the DC values have been read: two barriers ago)
-        __syncthreads();
-        const int first_tid = min(sl * S, W - 1);
-        const int seg_base = first_tid ? lds_incl[first_tid - 1] : 0;
-        const int seg_bits = sl < nseg_wg ? lds_incl[min(first_tid + max(n_blk, 1) - 1, W - 1)] - seg_base : 0; // total bits of this lane's segment
+        for (int k = 0; k < WAVES; k++) wave_total[k] = lds_wave_total[k];
+        auto incl_at = [&](int i) { // inclusive bit position of scan index i in the workgroup: the waves in front are added by whoever asks
+                int v = lds_incl[i];
+#pragma unroll
+                for (int k = 0; k < WAVES - 1; k++) v += k < (i >> 6) ? wave_total[k] : 0;
+                return v;
+        };
+        const int excl = incl_at(sid) - (int) nbits;
+        const int first_tid = min(sl * S, W - 1); // scan index of the segment's first block
+        const int seg_base = first_tid ? incl_at(first_tid - 1) : 0;
+        const int seg_bits = sl < nseg_wg ? incl_at(min(first_tid + max(n_blk, 1) - 1, W - 1)) - seg_base : 0; // total bits of this lane's segment
         if (j == 0 && sl < nseg_wg) lds_seg_bits[sl] = seg_bits;
         uint32_t *const mywin = win + first_tid * kWin; // the segment's window: kWin words per block of the segment
         const int cap = S * kWin;                               // words of a segment's window
@@ -1072,17 +1067,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 // the segments one by one, a wave each: a count with a wave scan per segment, a scan over the segments, a write-out with
                 // another wave scan per 64 words -- a third of the instructions behind the walk.)  The 1-bits that pad a segment's last byte
                 // (T.81 F.1.2.3) are ORed in where the word is read.
-                const int nbytes = (seg_bits + 7) >> 3, nwords = (nbytes + 3) >> 2; // (0 for lanes behind the workgroup's last segment)
-                const int K = (nwords + S - 1) / S, i_first = j * K;
-                const int padw = seg_bits >> 5, padn = 8 - (seg_bits & 7);
-                const uint32_t padmask = (seg_bits & 7) ? ((1u << padn) - 1u) << (32 - (seg_bits & 31) - padn) : 0u;
-                const bool seg_last = sl < nseg_wg && j == S - 1; // the lane that writes the marker behind the segment
+                // (a partition of its own, by tid: lane tid = segment tid / S, part tid % S -- whatever block the lane coded)
+                const int wsl = tid / S, wj = tid - wsl * S;
+                const int wbits = wsl < nseg_wg ? lds_seg_bits[wsl] : 0; // (written before the merge's barrier)
+                const uint32_t *const wwin = win + min(wsl * S, W - 1) * kWin;
+                const int nbytes = (wbits + 7) >> 3, nwords = (nbytes + 3) >> 2; // (0 for lanes behind the workgroup's last segment)
+                const int K = (nwords + S - 1) / S, i_first = wj * K;
+                const int padw = wbits >> 5, padn = 8 - (wbits & 7);
+                const uint32_t padmask = (wbits & 7) ? ((1u << padn) - 1u) << (32 - (wbits & 31) - padn) : 0u;
+                const bool seg_last = wsl < nseg_wg && wj == S - 1; // the lane that writes the marker behind the segment
                 uint32_t mine = seg_last ? 2u : 0u;
                 for (int k = 0; k < K; k++) {
                         const int i = i_first + k;
                         if (i < nwords) {
                                 const int valid = min(4, nbytes - 4 * i);
-                                mine += (uint32_t) (valid + count_ff_valid(mywin[i] | (i == padw ? padmask : 0u), valid));
+                                mine += (uint32_t) (valid + count_ff_valid(wwin[i] | (i == padw ? padmask : 0u), valid));
                         }
                 }
                 const uint32_t incl_b = (uint32_t) wave_inclusive_scan((int) mine, lane);
@@ -1118,7 +1117,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 const int i = i_first + k;
                                 if (i < nwords) {
                                         const int valid = min(4, nbytes - 4 * i);
-                                        const uint32_t word = mywin[i] | (i == padw ? padmask : 0u);
+                                        const uint32_t word = wwin[i] | (i == padw ? padmask : 0u);
 #pragma unroll
                                         for (int t = 0; t < 4; t++) {
                                                 if (t < valid) {
@@ -1130,17 +1129,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 }
                         }
                         if (seg_last) {
-                                const int sg = seg0 + sl;
+                                const int sg = seg0 + wsl;
                                 p[0] = 0xFF;
                                 p[1] = sg == a.n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (sg & 7));
                         }
                 }
-                if (seg_last && seg0 + sl == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = at + mine; // the stream's length
+                if (seg_last && seg0 + wsl == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = at + mine; // the stream's length
                 UG_PHASE(7) // write-out
                 if (a.prof != nullptr && threadIdx.x == 0) a.prof[(size_t) blockIdx.x * (kProfPhases + 1) + kProfPhases] = 1ull;
         } else {
                 asm volatile("; general path" ::: "memory");
-                __syncthreads(); // lds_flag[1]
+                __syncthreads(); // lds_flag[1]; nobody reads a private string from here on
+                if (tid < kMaxSeg) { // (ordered before their first use by the barrier inside emit_general)
+                        lds_seg_ff[tid] = 0;
+                        lds_seg_done[tid] = 0;
+                }
                 const int longest = lds_flag[1]; // 0: every segment fits its window
                 const int passes = longest ? (longest + cap - 1) / cap : 1;
 #pragma unroll 1
