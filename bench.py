@@ -369,7 +369,7 @@ def main() -> None:
         achieved = ALG_BYTES_PER_PX * px_per_launch / (kern_ms * 1e-3) / 1e9
         read_bpp = {"UYVY": 2.0, "v210": 16 / 6, "RGB": 3.0}[wl["fmt"]]
         pmc_key = {"4k-uyvy": f"uyvy_dxt5_4k_x{F}", "8k-v210": f"v210_dxt5_8k_x{F}", "1080p-rgb-dxt1": f"rgb_dxt1_1080p_x{F}",
-                   "4k-uyvy-jpeg420": f"uyvy_jpeg420_4k_x{F}"}.get(args.workload)
+                   "4k-uyvy-jpeg420": f"uyvy_jpeg420_4k_x{F}", "4k-uyvy-jpeg-encode": f"uyvy_jpeg_encode_4k_x{F}"}.get(args.workload)
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes (tools/pmc_collect.sh)
         if pmc_key and os.path.exists(pmc_path):
@@ -392,8 +392,10 @@ def main() -> None:
             roof["achieved"] = round(roof["algorithmic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
             roof["us_per_frame"] = round(kern_ms * 1e3 / F, 2)
+            ipw = pmc.get("valu_instr_per_wave")
             roof["note"] = ("the whole encoder per call of F frames, the call's own synchronisation included (ms_per_launch = time per call); algorithmic bytes = 2 B/px in + "
-                            "the stream bytes out; VALU-bound (DESIGN.md 4.5): ~2 100 instructions per wave of 64 blocks, half of them the forward DCT + quantiser")
+                            f"the stream bytes out; VALU-bound (DESIGN.md 4.5): {ipw if ipw else '~1 800'} instructions per wave of 64 blocks in jpeg_code_kernel, half of them the "
+                            "forward DCT + quantiser; `traffic` = that kernel's HBM bytes per launch (the gather kernel moves the stream once more)")
         elif out_name != "JPEG420":
             # The DXT encoders are VALU-issue bound, not HBM bound: `frac` above stays the contract's
             # algorithmic-bytes / 8 TB/s figure; `hbm_read_frac` is the north star's own definition (input bytes only);

@@ -25,3 +25,25 @@ if [ -d $N ]; then
   tail -2 $N/pytest.log | head -1 > $D/r04_gpu_tests.txt
   { echo "# end of round 4: tools/find_encode_mismatch.py 1500 (half of the cases on the fused kernels, half as two-frame batches), tools/find_dxt_mismatch.py 1500, tools/find_module_mismatch.py"; grep -v amdgpu.ids $N/find_encode.txt; grep -v amdgpu.ids $N/find_dxt.txt; grep -v amdgpu.ids $N/find_module.txt; } > $D/r04_random_searches.txt
 fi
+# the closing call of the round (tools/gpu_r04_final.sh as it stands -> gpurun_out/r04z/), on the build the round ends on: it replaces what the
+# earlier calls left wherever both have the file
+Z=gpurun_out/r04z
+if [ -d $Z ]; then
+  cp $Z/bench_line.json $D/r04_bench_line.json
+  cp $Z/kernel_trace.txt $D/r04_kernel_trace.txt
+  cp $Z/bench_4k-uyvy-jpeg420.json $D/r04_bench_4k_jpeg420.json; cp $Z/bench_8k-v210.json $D/r04_bench_8k_v210.json; cp $Z/bench_1080p-rgb-dxt1.json $D/r04_bench_1080p_rgb_dxt1.json
+  cp $Z/bench_4k-uyvy-jpeg-encode.json $D/r04_bench_4k_jpeg_encode.json
+  cp $Z/pmc_uyvy_dxt5_4k_x16.txt $D/r04_pmc_uyvy_dxt5_4k_x16.txt
+  cp $Z/8k-v210.txt $D/r04_pmc_8k_v210.txt; cp $Z/1080p-rgb-dxt1.txt $D/r04_pmc_1080p_rgb_dxt1.txt; cp $Z/4k-uyvy-jpeg420.txt $D/r04_pmc_4k_uyvy_jpeg420.txt
+  cp $Z/pmc_traffic.json $D/pmc_traffic.json
+  cp $Z/jpeg_batch_all.txt $D/r04_jpeg_batch_all.txt
+  cp $Z/jpeg_batch_pmc.txt $D/r04_jpeg_batch_pmc.txt; cp $Z/jpeg_batch_trace_422_444.txt $D/r04_jpeg_batch_trace_422_444.txt
+  cp $Z/jpeg_phase_clock.txt $D/r04_jpeg_batch.txt
+  cp $Z/kernels.json $D/r04_kernels.json; grep -v amdgpu.ids $Z/kernels_table.txt > $D/r04_all_kernels_table.txt
+  cp $Z/decode.json $D/r04_decode.json; grep -v amdgpu.ids $Z/decode.txt > $D/r04_decode.txt
+  cp $Z/pixfmt_all_8k.json $D/r04_pixfmt_all_8k.json
+  grep -v amdgpu.ids $Z/deinterlace.txt > $D/r04_deinterlace.txt
+  tail -2 $Z/pytest.log | head -1 > $D/r04_gpu_tests.txt
+  { echo "# end of round 4: tools/find_encode_mismatch.py 2000 (half of the cases on the fused kernels, half as two-frame batches), tools/find_dxt_mismatch.py 1500, tools/find_module_mismatch.py, tools/find_decode_mismatch_valid.py 3000"
+    grep -v amdgpu.ids $Z/find_encode.txt; grep -v amdgpu.ids $Z/find_dxt.txt; grep -v amdgpu.ids $Z/find_module.txt; grep -v amdgpu.ids $Z/find_decode_valid.txt; } > $D/r04_random_searches.txt
+fi
