@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """ug_hip_deinterlace_blend / _batch on the GPU: one frame per launch and eight (csrc/deinterlace.hip).  In place; algorithmic
 bytes = 2 x the frame (every line read once, written once)."""
+import os, sys
+
 import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ultragrid_amd import lib as L
 
 l = L.load()
