@@ -1,12 +1,4 @@
 cd ${GRAFT_REPO_ROOT:-.}
-ROOT=$(pwd)
-timeout 900 python -m pytest tests/test_gpu_jpeg.py tests/test_jpeg_rtp_compat.py -q -x 2>&1 | grep -E "passed|failed|Error|assert" | grep -v "JPEG\]\|APP14" | tail -3
-for i in 1 2 3; do
-  for lib in libug_mi355x_prev.so libug_mi355x.so; do
-    echo -n "$lib  "; UG_MI355X_LIB=$ROOT/ultragrid_amd/$lib timeout 120 python tools/bench_jpeg_batch.py --only batch 2>&1 | grep "frames per call" | tail -1
-  done
-done
-for lib in libug_mi355x_prev.so libug_mi355x.so; do
-    echo -n "$lib 422 "; UG_MI355X_LIB=$ROOT/ultragrid_amd/$lib timeout 120 python tools/bench_jpeg_batch.py --sub 422 --only batch 2>&1 | grep "frames per call" | tail -1
-    echo -n "$lib 444 "; UG_MI355X_LIB=$ROOT/ultragrid_amd/$lib timeout 120 python tools/bench_jpeg_batch.py --sub 444 --only batch 2>&1 | grep "frames per call" | tail -1
-done
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04z; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 2>&1 | grep -v "lavc_vid_conv" | tail -15 > $OUT/pytest.log; tail -2 $OUT/pytest.log
+timeout 120 python tools/bench_deinterlace.py > $OUT/deinterlace.txt 2>&1; cat $OUT/deinterlace.txt
