@@ -17,6 +17,8 @@ ap.add_argument("--sub", type=int, default=420, help="420 / 422: UYVY input; 444
 ap.add_argument("--n", type=int, default=8)
 ap.add_argument("--seconds", type=float, default=1.0)
 ap.add_argument("--size", default="3840x2160")
+ap.add_argument("--q", type=int, default=75)
+ap.add_argument("--ri", type=int, default=4, help="restart interval (MCUs)")
 ap.add_argument("--only", choices=["both", "batch", "single"], default="both", help="profile runs: one call form only, so that per-kernel averages are not a blend")
 ap.add_argument("--calls", type=int, default=0, help="exactly this many timed calls per leg instead of --seconds (counter passes)")
 a = ap.parse_args()
@@ -28,7 +30,7 @@ base = torch.from_numpy(synth.s2_video("UYVY", w, h) if not rgb else synth.frame
 sets = 4
 src = torch.stack([torch.stack([torch.roll(base, line * 37 * (f + a.n * s)) for f in range(a.n)]) for s in range(sets)])   # (sets, n, bytes): 4 x n distinct frames
 enc = C.c_void_p()
-assert l.ug_hip_jpeg_encoder_create_sub(w, h, 75, 4, a.sub, C.byref(enc)) == 0
+assert l.ug_hip_jpeg_encoder_create_sub(w, h, a.q, a.ri, a.sub, C.byref(enc)) == 0
 cap = l.ug_hip_jpeg_encoder_max_size(enc)
 stride = (min(cap, w * h * 3 + 4096) + 15) // 16 * 16
 out = torch.empty((a.n, stride), dtype=torch.uint8, device="cuda")
@@ -62,6 +64,6 @@ for name, fn in legs:
         fn()
         n += 1
     dt = time.perf_counter() - t0
-    print(f"jpeg encode {w}x{h} {fmt_in} 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q75 restart 4, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
+    print(f"jpeg encode {w}x{h} {fmt_in} 4:{str(a.sub)[1:2]}:{str(a.sub)[2:]} q{a.q} restart {a.ri}, {name}: {dt / (n * a.n) * 1e6:.1f} us per frame ({n * a.n / dt:.0f} fps), stream {lens[0] or one.value} B")
 
 l.ug_hip_jpeg_encoder_destroy(enc)

@@ -1,4 +1,8 @@
 cd ${GRAFT_REPO_ROOT:-.}
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04z; mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 2>&1 | grep -v "lavc_vid_conv" | tail -15 > $OUT/pytest.log; tail -2 $OUT/pytest.log
-timeout 120 python tools/bench_deinterlace.py > $OUT/deinterlace.txt 2>&1; cat $OUT/deinterlace.txt
+for sub in 420 422; do
+for q in 50 75 90 95 98 100; do
+  for ri in 2 4 8 16; do
+    timeout 60 python tools/bench_jpeg_batch.py --sub $sub --q $q --ri $ri --only batch --seconds 0.3 2>&1 | grep "per call" | tail -1
+  done
+done
+done
