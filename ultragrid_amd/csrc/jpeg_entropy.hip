@@ -326,27 +326,31 @@ __device__ __forceinline__ void walk_block(const uint32_t (&w)[32], const uint32
 // Block-parallel Huffman coding with byte stuffing and stream placement (round 4; the default whenever a restart segment has at most 256
 // blocks).  One LANE PER BLOCK, a workgroup = the whole segments that fit its lanes; the workgroup finishes its part of the JPEG stream
 // itself -- code, byte stuffing, RSTm markers:
-//   1. every lane gets its block as 32 registers (64 int16, zig-zag order): from the coefficient arrays in HBM (SRC = 0: 8 lanes share a
-//      128-byte line, rows handed to their owners through LDS) or, fused (SRC = 420 / 422 / 444), from the workgroup's own forward DCT +
-//      quantiser of 32 (64) consecutive MCUs of the UYVY (RGB) frame, made in frame order and handed over in scan order through LDS, half a
-//      block at a time -- the coefficients then never exist in HBM;
-//   2. the DC predictor comes from the lane that holds the previous block of the same component;
+//   1. every lane gets its block as 32 registers (64 int16, zig-zag order): from the coefficient arrays in HBM (SRC = 0: lanes in scan order,
+//      8 lanes share a 128-byte line, rows handed to their owners through LDS) or, fused (SRC = 420 / 422 / 444 / 1420), from the workgroup's
+//      own forward DCT + quantiser of 32 (64) consecutive MCUs of the UYVY (RGB, I420) frame, made in FRAME order -- a wave = a luma block row,
+//      or the chroma blocks, of the MCUs -- and coded by the lane that made it: the coefficients never exist in HBM and never change lanes;
+//      what the scan order decides goes through LDS arrays indexed by the block's scan index `sid`;
+//   2. the DC predictor = the DC value at sid - 1 / - 3 / - blocks per MCU (the previous block of the same component);
 //   3. ONE walk over the 63 AC coefficients (static register indices; groups of 8 and single positions that are zero in all 64 blocks of the
 //      wave cost a scalar branch; the rare coefficient behind a zero run longer than 15 is met by a wave-uniform branch at its position)
-//      appends code + value bits to a 64-bit accumulator whose words go to the lane's PRIVATE string in LDS (bit 0 = the block's first bit)
+//      appends code + value bits to a 64-bit accumulator whose words go to the lane's PRIVATE string in LDS (PrivSink)
 //      and adds up the length -- rounds 2-3 walked twice, a length pass and an emission pass;
-//   4. a prefix sum of the lengths, made segment-relative, gives every block its bit position; every lane shifts its private string there and
-//      ORs it into the segment's window (v_alignbit + ds_or_b32);
-//   5. the windows are padded with 1-bits to a byte, 0xFF bytes counted: final segment sizes;
-//   6. placement.  Two launches (the default from two frames per call up): the waves write their segments -- 0x00 after every 0xFF (T.81
-//      B.1.1.5), RSTm / EOI behind each -- into a slot of the workgroup's own, the byte count into wg_bytes, and jpeg_gather_kernel moves the
+//   4. a prefix sum of the lengths in scan order, made segment-relative, gives every block its bit position; every lane shifts its private
+//      string there and ORs it into the segment's window (v_alignbit + ds_or_b32);
+//   5. byte stuffing and write-out by all lanes at once: K consecutive window words per lane, the bytes each will write counted (0x00 after
+//      every 0xFF, T.81 B.1.1.5; RSTm / EOI behind each segment; the last byte's padding ORed in on the way), one prefix sum over the
+//      workgroup = every position in the workgroup's stretch of the stream, then the bytes;
+//   6. placement.  Two launches (the default from two frames per call up): the stretch goes into a slot of the workgroup's own, its byte
+//      count into wg_bytes, and jpeg_gather_kernel moves the
 //      stretches to their places.  One launch (one-frame calls; the fallback when a slot is too small; UG_JPEG_LOOKBACK=1): a decoupled
 //      look-back over the workgroups of the frame (one 64-bit status word per workgroup: generation of the call | aggregate / inclusive prefix |
-//      bytes) gives the workgroup its position in the stream, the waves write there; the last segment's wave reports the stream length to
+//      bytes) gives the workgroup its position in the stream, the lanes write there; the last segment's last lane reports the stream length to
 //      pinned host memory, workgroup 0 lays down the header.
 // A block whose code exceeds its 512-bit private string, or a segment beyond its window (near-lossless quality on noise), sends its workgroup
 // down the general path: emission straight into the windows at the known bit positions (BitSink), in several passes when a segment exceeds its
-// window, counted first and emitted again for the write-out.  The stream is byte-identical to the wave-per-segment coder + compaction.
+// window, counted first and emitted again for the write-out (segment by segment, a wave each: count_pass / place / write_pass).  The stream is
+// byte-identical to the wave-per-segment coder + compaction.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef UG_JPEG_SKIP_POSITIONS
 #define UG_JPEG_SKIP_POSITIONS 1 // inside a group that is not empty, still skip the positions that are zero in all 64 blocks of the wave
@@ -563,17 +567,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         }
         const int frame = (int) (index / (uint32_t) a.n_wg), wg = (int) (index - (uint32_t) frame * (uint32_t) a.n_wg);
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
-        // one buffer, three lives: the block hand-over (SRC = 0: per wave 32 rows of 8 x 16 B, 144 B apart; fused: the workgroup's blocks, half a
-        // block at a time, 80 B apart), then (behind 4 pad words) the private strings, 17 W words, and behind them the segments' windows (kWin words per block + one spare
-        // word per lane)
+        // one buffer, two lives: (SRC = 0) the staging rows of the block loads (per wave 32 rows of 8 x 16 B, 144 B apart), then (behind 4 pad
+        // words) the private strings, 17 W words, and behind them the segments' windows (kWin words per block + one spare word per lane)
         constexpr int kStageRow = 9; // uint4 per row
         constexpr int kStageWords = 32 * kStageRow * 4; // per wave (SRC = 0)
         // window words per block: 16 = the private strings' size; the 4:2:0 fused kernel takes 12 (384 bits per block on a segment's average, 5 x
         // what a 4K q75 frame needs; beyond: the general path) -- that is what lets a sixth workgroup onto the CU
         constexpr int kWin = SRC == 420 || SRC == 1420 || SRC == 444 ? 12 : kWinWordsPerBlock;
-        constexpr int kHalfPitch = 20; // words: half a block (64 B) + 16 B, conflict-free 128-bit accesses of consecutive lanes (fused hand-over)
         constexpr int kBufWords = (kPrivStride + kWin + 1) * W + 4; // (+ the pad in front of the private strings: 4 words, the windows stay 16-byte aligned)
-        static_assert(kBufWords >= WAVES * kStageWords && kBufWords >= kHalfPitch * W, "the three lives must fit");
+        static_assert(kBufWords >= WAVES * kStageWords, "both lives must fit");
         __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
         constexpr int kMaxSeg = W / 3 + 1; // segments per workgroup: a segment has at least 3 blocks (4:4:4, restart interval 1)
         __shared__ int lds_wave_total[WAVES], lds_seg_bits[kMaxSeg], lds_flag[2];
