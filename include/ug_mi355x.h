@@ -234,8 +234,9 @@ int ug_hip_pixfmt_line_func(const char *func, const void *src_dev, void *dst_dev
 int ug_hip_linesize(ug_pixfmt_t fmt, int width);
 /* vc_deinterlace (src/video_codec.c:597-664) IN PLACE on a device frame of `lines` lines of `linesize` bytes (pitch == linesize, as there):
  * the linear-blend de-interlace RTDXT applies to INTERLACED_MERGED input before encoding (dxt_glsl.cpp:195-201,291-293), computed as the
- * reference's x86-64 build computes it (its SSE2 bodies: a recursive pavgb blend down the lines; lines < 5: nothing) -- any line size,
- * including those that are no multiple of 16, whose last column reaches into the next line there.  _batch: `frames` frames frame_stride apart. */
+ * reference's x86-64 build computes it (its SSE2 bodies: a recursive pavgb blend down the lines; lines < 5: nothing) -- any line size from 16
+ * bytes, including those that are no multiple of 16, whose last column reaches into the next line there.  linesize < 16 (where the reference's
+ * 16-byte columns overlap themselves and, below 6 bytes, are stored past the frame): UG_HIP_EINVAL.  _batch: `frames` frames frame_stride apart. */
 int ug_hip_deinterlace_blend(void *frame_dev, size_t linesize, int lines, ug_hip_stream_t stream);
 int ug_hip_deinterlace_blend_batch(void *frame_dev, size_t linesize, int lines, int frames, size_t frame_stride, ug_hip_stream_t stream);
 

@@ -397,7 +397,10 @@ void oracle_v210_to_p010le(uint16_t *yp, int y_ls, uint16_t *uvp, int uv_ls,
  *         x2 = line j+2;  x0 = avg(avg(x0, x2), x1);  x1 = line j+3;  line j+1 = x0;  x0 = avg(avg(x0, x1), x2);  line j+2 = x0;  }
  * -- a recursive blend: every output feeds the next one; line 0 and the last two or three lines are left as they are.  A column whose 16
  * bytes reach past the end of the line (src_linesize % 16 != 0) takes its last bytes from the BEGINNING of the next line, which column 0
- * has filtered already (the columns are processed one after the other): restated literally, in that order. */
+ * has filtered already (the columns are processed one after the other): restated literally, in that order.
+ * Valid for src_linesize >= 16: the bytes of a column are then 16 different memory columns and may be walked one after the other.  Below
+ * that the reference's 16-byte vectors overlap themselves from line to line (and are stored past the frame below 6 bytes); that is not
+ * restated -- oracle/pyoracle.py refuses it, the library returns UG_HIP_EINVAL (tests/test_deinterlace.py). */
 void oracle_deinterlace_blend(uint8_t *src, long src_linesize, int lines)
 {
         for (long i = 0; i < src_linesize; i += 16) {

@@ -189,6 +189,7 @@ def deinterlace_blend(frame: np.ndarray, linesize: int, lines: int) -> np.ndarra
     """vc_deinterlace (video_codec.c:597-664, SSE2 bodies) on a copy of `frame`."""
     out = np.ascontiguousarray(frame, dtype=np.uint8).ravel().copy()
     assert out.size >= linesize * lines
+    assert linesize >= 16 or lines < 5, "the restatement holds from one 16-byte column up (oracle/pixfmt_oracle.c)"
     lib().oracle_deinterlace_blend.restype = None
     lib().oracle_deinterlace_blend.argtypes = [C.c_void_p, C.c_long, C.c_int]
     lib().oracle_deinterlace_blend(_ptr(out), linesize, lines)

@@ -88,3 +88,5 @@ def test_gpu_deinterlace_bit_exact(hip, po):
         assert np.array_equal(got[i * stride: i * stride + x.size], po.deinterlace_blend(x, 2 * w, h))
         assert (got[i * stride + x.size: (i + 1) * stride] == 0x5A).all()
     assert l.ug_hip_deinterlace_blend(None, 64, 10, None) == L.EINVAL and l.ug_hip_deinterlace_blend(dev.data_ptr(), 0, 10, None) == L.EINVAL
+    # a line shorter than one 16-byte column is refused (the reference's columns overlap themselves there); below 5 lines nothing happens at any size
+    assert l.ug_hip_deinterlace_blend(dev.data_ptr(), 15, 10, None) == L.EINVAL and l.ug_hip_deinterlace_blend(dev.data_ptr(), 8, 4, None) == 0

@@ -1,8 +1,4 @@
 cd ${GRAFT_REPO_ROOT:-.}
-for sub in 420 422; do
-for q in 50 75 90 95 98 100; do
-  for ri in 2 4 8 16; do
-    timeout 60 python tools/bench_jpeg_batch.py --sub $sub --q $q --ri $ri --only batch --seconds 0.3 2>&1 | grep "per call" | tail -1
-  done
-done
-done
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04z; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_deinterlace.py tests/test_module_harness.py -q -k "deinterlace or interlaced" 2>&1 | grep -E "passed|failed" | tail -2
+timeout 900 python tools/find_deinterlace_mismatch.py 3000 2>&1 | grep -v amdgpu.ids | tail -12 > $OUT/find_deinterlace.txt; cat $OUT/find_deinterlace.txt

@@ -135,6 +135,13 @@ extern "C" int ug_hip_deinterlace_blend_batch(void *frame_dev, size_t linesize, 
                 return UG_HIP_EINVAL;
         }
         if (lines < 5 || frames == 0) return UG_HIP_SUCCESS; // vc_deinterlace changes nothing below 5 lines (its loop runs for j < lines - 4)
+        if (linesize < 16) {
+                // A line shorter than one 16-byte column: the reference's vectors then overlap THEMSELVES from line to line (what one iteration
+                // stores the next one loads again inside the same column) and, below 6 bytes, are stored past the end of the frame.  Not a
+                // picture (8 UYVY pixels are 16 bytes), not a contract: refused.
+                ug::set_last_error_msg("ug_hip_deinterlace_blend: lines shorter than 16 bytes are not supported (the reference's 16-byte columns overlap themselves there)");
+                return UG_HIP_EINVAL;
+        }
         hipStream_t st = (hipStream_t) stream;
         uint8_t *base = (uint8_t *) frame_dev;
         const long full = (long) (linesize / 16) * 16; // the bytes of a line that lie in whole 16-byte columns

@@ -204,6 +204,11 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
         // step.  Done here on the device, on the frame in the `target` format: the shortcuts that skip that intermediate are not taken then.
         s->interlaced_input = s->deinterlace && desc.interlacing == INTERLACED_MERGED;
         s->target = target;
+        if (s->interlaced_input && vc_get_linesize(desc.width, ug_codec_from_pixfmt(target)) < 16) {
+                // (below one 16-byte column vc_deinterlace's vectors overlap themselves: ug_hip_deinterlace_blend refuses such lines)
+                MSG(WARNING, "Pictures %u pixels wide are not de-interlaced.\n", desc.width);
+                s->interlaced_input = false;
+        }
         if (s->interlaced_input) {
                 MSG(NOTICE, "Enabling automatic deinterlacing.\n");
         }
