@@ -38,7 +38,10 @@ if [ -d $Z ]; then
   cp $Z/pmc_traffic.json $D/pmc_traffic.json
   cp $Z/jpeg_batch_all.txt $D/r04_jpeg_batch_all.txt
   cp $Z/jpeg_batch_pmc.txt $D/r04_jpeg_batch_pmc.txt; cp $Z/jpeg_batch_trace_422_444.txt $D/r04_jpeg_batch_trace_422_444.txt
-  cp $Z/jpeg_phase_clock.txt $D/r04_jpeg_batch.txt
+  { echo "# phase clock of the fused encoder kernel on the closing build of round 4 (UG_JPEG_PROF=1 python tools/bench_jpeg_batch.py --sub S --only batch --calls 40): cycles per"
+    echo "# workgroup, wave 0's view: front end | tables + DC values (waiting for the other waves' front ends) | walk | positions | merge | byte counts + prefix | slot / look-back | write-out"
+    echo "# (the mid-round file with the look-back A/B and the phase clock of the segment-by-segment write-out: r04_jpeg_batch_midround.txt)"
+    cat $Z/jpeg_phase_clock.txt; } > $D/r04_jpeg_batch.txt
   cp $Z/kernels.json $D/r04_kernels.json; grep -v amdgpu.ids $Z/kernels_table.txt > $D/r04_all_kernels_table.txt
   cp $Z/decode.json $D/r04_decode.json; grep -v amdgpu.ids $Z/decode.txt > $D/r04_decode.txt
   cp $Z/pixfmt_all_8k.json $D/r04_pixfmt_all_8k.json
