@@ -24,6 +24,13 @@
  *     rule  s = q < 50 ? 5000/q : 200 - 2q ;  t = clamp((base*s + 50)/100, 1, 255);
  *   - coefficients are emitted in zig-zag order (T.81 Figure A.6).
  *
+ * What CAN be pinned is pinned (tests/test_oracle_jpeg.py::test_fdct_is_ijg_float_dct_bit_for_bit): the forward DCT below gives the same
+ * BITS as IJG's own float DCT -- jpeg_fdct_float (jfdctflt.c) as compiled in the distribution's libjpeg-turbo 2.1.2, called through its
+ * exported symbol on the level-shifted samples of every block -- and the quality rule equals jpeg_quality_scaling + jpeg_add_quant_table's
+ * clamp for q = 1 .. 100.  That ties the restatement to the published implementation it restates; towards UltraGrid's libgpujpeg the stage
+ * stays unpinned (the reciprocal quantiser's rounding in particular: rintf here, as a GPU's __float2int_rn; IJG's C path rounds
+ * (int)(x + 16384.5) - 16384, which differs on exact ties).
+ *
  * Tolerance contract (tests/test_jpeg_*.py):
  *   (a) HIP kernel vs this file: unquantised fp32 coefficients identical (0 ULP; the
  *       north-star bound is 1 ULP) and quantised int16 output identical -- same op order,

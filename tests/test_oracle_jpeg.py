@@ -1,6 +1,7 @@
 """CPU: the JPEG FDCT+quantise specification (oracle/jpeg_oracle.c).  PARITY UNPINNED against the
 reference (the stage lives in the external, un-vendored libgpujpeg); checked against an fp64
-scipy DCT, the T.81 tables, and committed regression outputs."""
+scipy DCT, the T.81 tables, committed regression outputs, and -- bit for bit -- IJG's own float DCT
+and quality rule as the image's libjpeg-turbo exports them."""
 import os
 
 import numpy as np
@@ -105,3 +106,55 @@ def test_coefficients_decode_with_an_independent_jpeg_decoder(po):
         for plane, ch in ((u, 1), (v, 2)):
             mse = np.mean((dec[..., ch].astype(float) - up(plane)) ** 2)
             assert 10 * np.log10(255 ** 2 / mse) > 36, (q, ch)
+
+
+def _system_libjpeg():
+    """the distribution's libjpeg-turbo (IJG API 8), whose plain-C forward DCTs and quality rule are exported symbols"""
+    import ctypes as C
+    for name in ("libjpeg.so.8", "/usr/lib/x86_64-linux-gnu/libjpeg.so.8", "libjpeg.so.62"):
+        try:
+            lj = C.CDLL(name)
+            lj.jpeg_fdct_float, lj.jpeg_quality_scaling
+            return lj
+        except (OSError, AttributeError):
+            continue
+    return None
+
+
+def test_fdct_is_ijg_float_dct_bit_for_bit(po):
+    """The forward DCT this oracle specifies is "the AAN factorisation as IJG's float DCT has it" (oracle/jpeg_oracle.c).  That sentence is
+    checked here against IJG's own code: jpeg_fdct_float (jfdctflt.c) as compiled in the system's libjpeg-turbo, called on the level-shifted
+    samples of every block -- the unquantised fp32 coefficients are the same BITS on noise, two-valued, smooth and ramp content.  (This pins
+    the restatement to the published implementation it restates; it does not pin UltraGrid's external libgpujpeg, which stays unobtainable:
+    the stage remains "parity unpinned" towards the reference.)  The quality rule is pinned the same way: jpeg_quality_scaling."""
+    import ctypes as C
+
+    import pytest
+    lj = _system_libjpeg()
+    if lj is None:
+        pytest.skip("no libjpeg with jpeg_fdct_float in this image")
+    fdct = lj.jpeg_fdct_float
+    fdct.restype = None
+    fdct.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(11)
+    h, w = 128, 256
+    planes = [rng.integers(0, 256, (h, w), dtype=np.uint8), (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8),
+              np.clip(128 + 30 * rng.standard_normal((h, w)), 0, 255).astype(np.uint8),
+              ((np.add.outer(np.arange(h), np.arange(w)) * 3) % 256).astype(np.uint8), synth.s2_video("UYVY", w // 2, h).reshape(h, w)]
+    div = po.jpeg_divisors(po.jpeg_qtable(75, 0))
+    for plane in planes:
+        _, coef = po.jpeg_fdct_quant_plane(plane, div, want_coef=True)
+        blocks = _blocks(plane).astype(np.float32) - np.float32(128.0)
+        for b in range(blocks.shape[0]):
+            blk = np.ascontiguousarray(blocks[b])
+            fdct(blk.ctypes.data)
+            assert np.array_equal(blk.ravel().view(np.uint32), coef[b].view(np.uint32)), b
+    lj.jpeg_quality_scaling.restype = C.c_int
+    lj.jpeg_quality_scaling.argtypes = [C.c_int]
+    k1 = po.jpeg_qtable(50, 0).astype(np.int64)   # quality 50 = the Annex K table itself
+    k2 = po.jpeg_qtable(50, 1).astype(np.int64)
+    for q in range(1, 101):
+        s = lj.jpeg_quality_scaling(q)
+        for comp, base in ((0, k1), (1, k2)):
+            want = np.clip((base * s + 50) // 100, 1, 255)   # jpeg_add_quant_table, force_baseline (jcparam.c)
+            assert np.array_equal(po.jpeg_qtable(q, comp), want), (q, comp)
