@@ -24,12 +24,21 @@
  *     rule  s = q < 50 ? 5000/q : 200 - 2q ;  t = clamp((base*s + 50)/100, 1, 255);
  *   - coefficients are emitted in zig-zag order (T.81 Figure A.6).
  *
- * What CAN be pinned is pinned (tests/test_oracle_jpeg.py::test_fdct_is_ijg_float_dct_bit_for_bit): the forward DCT below gives the same
- * BITS as IJG's own float DCT -- jpeg_fdct_float (jfdctflt.c) as compiled in the distribution's libjpeg-turbo 2.1.2, called through its
- * exported symbol on the level-shifted samples of every block -- and the quality rule equals jpeg_quality_scaling + jpeg_add_quant_table's
- * clamp for q = 1 .. 100.  That ties the restatement to the published implementation it restates; towards UltraGrid's libgpujpeg the stage
- * stays unpinned (the reciprocal quantiser's rounding in particular: rintf here, as a GPU's __float2int_rn; IJG's C path rounds
- * (int)(x + 16384.5) - 16384, which differs on exact ties).
+ * What CAN be pinned is pinned -- to IJG's float DCT pipeline as the image's libjpeg-turbo 2.1.2 executes it (tests/libjpeg_float.py
+ * drives the library through ctypes with dct_method = JDCT_FLOAT):
+ *   - tests/test_oracle_jpeg.py::test_fdct_is_ijg_float_dct_bit_for_bit: the forward DCT below gives the same BITS as jpeg_fdct_float
+ *     (jfdctflt.c, exported symbol) on the level-shifted samples of every block; the quality rule equals jpeg_quality_scaling +
+ *     jpeg_add_quant_table's baseline clamp for q = 1 .. 100;
+ *   - ::test_plane_to_scan_equals_libjpeg_turbo_float_pipeline: a grey plane compressed by libjpeg-turbo (float DCT + its float
+ *     quantiser, standard Huffman tables) and this file's coefficients coded by the test writer give the same entropy-coded bytes -- i.e.
+ *     the same quantised coefficients, rounding of the reciprocal quantiser included (libjpeg-turbo's SSE2 quantiser converts with
+ *     cvtps2dq, round-to-nearest-even = rintf; IJG's plain C would round (int)(x + 16384.5) - 16384, different on exact ties) -- for 240
+ *     cases, picture sizes that are no multiple of 8 and noise at q = 100 included;
+ *   - tests/test_gpu_jpeg.py::test_streams_equal_libjpeg_turbo_with_its_float_dct: the PRODUCT's RGB 4:4:4, UYVY 4:2:2 and 4:2:0 streams
+ *     against libjpeg-turbo on the same samples (the 4:2:x planes through jpeg_write_raw_data), same entropy-coded bytes.
+ * That ties the restatement, and the product, to a published executable implementation of the formulation restated here; towards
+ * UltraGrid's libgpujpeg itself the stage stays unpinned (one known freedom: blocks that lie wholly outside the picture -- MCU padding --
+ * are DCTs of the replicated edge here, "dummy" blocks (neighbour's DC, no AC) in libjpeg; they are never displayed).
  *
  * Tolerance contract (tests/test_jpeg_*.py):
  *   (a) HIP kernel vs this file: unquantised fp32 coefficients identical (0 ULP; the

@@ -529,3 +529,46 @@ def test_encode_batch_full_4k(hip, po):
     want = [enc.encode(dev[f]) for f in range(n)]
     assert enc.encode_batch(dev) == want
     enc.close()
+
+
+@pytest.mark.gpu
+def test_streams_equal_libjpeg_turbo_with_its_float_dct(hip, po):
+    """Round 4: the PRODUCT's streams against an executable published implementation of the same arithmetic -- the image's libjpeg-turbo
+    with dct_method = JDCT_FLOAT (IJG's float AAN DCT + float quantiser, tests/libjpeg_float.py) -- on the same samples, the same quality,
+    the same restart interval: the entropy-coded bytes between SOS and EOI are IDENTICAL.
+      * packed RGB -> R, G, B components 4:4:4 (libjpeg: JCS_RGB kept as JCS_RGB): any size, edge blocks included;
+      * UYVY -> 4:2:2 / 4:2:0: libjpeg is handed the planes the reference's own converters make of the frame (uyvy_to_i422 / uyvy_to_i420:
+        the oracle's, pinned to the compiled reference) through jpeg_write_raw_data, so that only forward DCT, quantiser and entropy
+        coding are compared.  Sizes whose block grid fills whole MCUs: a block that lies wholly outside the picture is content-free
+        padding, which libjpeg fills with "dummy" blocks (DC of the neighbour, no AC) and this encoder with the DCT of the replicated
+        edge -- both legal, neither visible; blocks that merely straddle the edge are compared.
+    libjpeg-turbo is not the library UltraGrid links (libgpujpeg, unobtainable here): towards the reference the stage stays unpinned;
+    this pins it to IJG's float DCT, the formulation oracle/jpeg_oracle.c restates."""
+    import torch
+
+    import libjpeg_float as ljf
+    lj = ljf.load()
+    if lj is None:
+        pytest.skip("no libjpeg-turbo with the IJG v8 API in this image")
+    rng = np.random.default_rng(5)
+    for (w, h) in ((64, 48), (1100, 50), (203, 33), (1920, 64), (8, 8), (3840, 40)):
+        for q, ri in ((75, 4), (50, 8), (92, 1), (100, 16), (20, 64)):
+            img = synth.frame("S2", "RGB", w, h).reshape(h, w, 3) if q != 100 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            e = hip.JpegEncoder(w, h, q, ri, subsampling=444)
+            got = e.encode(torch.from_numpy(np.ascontiguousarray(img).ravel()).cuda(), hip.L.PF_RGB)
+            e.close()
+            assert ljf.scan_bytes(got) == ljf.scan_bytes(ljf.compress(lj, img, q, restart=ri)), ("rgb", w, h, q, ri)
+    for sub, sizes in ((422, ((64, 48), (1040, 81), (1920, 1080), (28, 5), (3840, 24))), (420, ((64, 48), (1040, 80), (1036, 90), (48, 16), (1920, 1072), (3840, 32)))):
+        for (w, h) in sizes:
+            for q, ri in ((75, 4), (92, 1), (50, 8), (100, 2)):
+                uyvy = synth.s2_video("UYVY", w, h) if q != 100 else synth.s1_random("UYVY", w, h, salt=q)
+                if sub == 420:
+                    y, u, v = po.uyvy_to_i420(uyvy, w, h)
+                else:
+                    a = uyvy.reshape(h, 2 * w)
+                    y, u, v = a[:, 1::2], a[:, 0::4], a[:, 2::4]
+                e = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+                got = e.encode(torch.from_numpy(uyvy).cuda(), hip.L.PF_UYVY)
+                e.close()
+                want = ljf.compress_planes(lj, y, u, v, w, h, sub, q, restart=ri)
+                assert ljf.scan_bytes(got) == ljf.scan_bytes(want), (sub, w, h, q, ri)

@@ -1,7 +1,7 @@
 """CPU: the JPEG FDCT+quantise specification (oracle/jpeg_oracle.c).  PARITY UNPINNED against the
 reference (the stage lives in the external, un-vendored libgpujpeg); checked against an fp64
-scipy DCT, the T.81 tables, committed regression outputs, and -- bit for bit -- IJG's own float DCT
-and quality rule as the image's libjpeg-turbo exports them."""
+scipy DCT, the T.81 tables, committed regression outputs, and -- bit for bit -- IJG's float DCT
+pipeline as the image's libjpeg-turbo executes it (forward DCT, quality rule, plane -> coefficients)."""
 import os
 
 import numpy as np
@@ -158,3 +158,46 @@ def test_fdct_is_ijg_float_dct_bit_for_bit(po):
         for comp, base in ((0, k1), (1, k2)):
             want = np.clip((base * s + 50) // 100, 1, 255)   # jpeg_add_quant_table, force_baseline (jcparam.c)
             assert np.array_equal(po.jpeg_qtable(q, comp), want), (q, comp)
+
+
+def test_plane_to_scan_equals_libjpeg_turbo_float_pipeline(po):
+    """Round 4: the WHOLE stage this oracle specifies -- level shift, forward DCT, reciprocal quantiser with its rounding, quantiser tables --
+    against an executable published implementation: the image's libjpeg-turbo compressing the same grey plane with its FLOAT DCT
+    (dct_method = JDCT_FLOAT: convsamp_float + jfdctflt.c / its SSE form + the float quantiser).  Huffman coding is injective and both
+    sides use the Annex K tables, so equal scan bytes mean equal coefficients: libjpeg-turbo's entropy-coded data == the oracle's
+    coefficients coded by the test writer, byte for byte -- picture sizes that are no multiple of 8 (edge replication), noise up to
+    q = 100, flat, ramps.  (libjpeg-turbo is not the library UltraGrid links -- that is libgpujpeg, unobtainable here --, but it is IJG's
+    float DCT, the formulation the oracle claims to restate: the claim is checked, not just made.)"""
+    import pytest
+
+    import jpeg_bitstream as jb
+    import libjpeg_float as ljf
+    lj = ljf.load()
+    if lj is None:
+        pytest.skip("no libjpeg-turbo with the IJG v8 API in this image")
+    dcl, acl = jb._codes(*jb.DC_L), jb._codes(*jb.AC_L)
+    cases = 0
+    for seed in range(48):
+        rng = np.random.default_rng(seed)
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 150))
+        kind = seed % 5
+        if kind == 0:
+            plane = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:
+            plane = np.clip(128 + 40 * rng.standard_normal((h, w)), 0, 255).astype(np.uint8)
+        elif kind == 2:
+            plane = ((np.add.outer(np.arange(h), np.arange(w)) * int(rng.integers(1, 9))) % 256).astype(np.uint8)
+        elif kind == 3:
+            plane = np.full((h, w), int(rng.integers(256)), np.uint8)
+        else:
+            plane = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+        plane = np.ascontiguousarray(plane)
+        for q in (10, 50, 75, 92, 100):
+            coef = po.jpeg_fdct_quant_plane(plane, po.jpeg_divisors(po.jpeg_qtable(q, 0)))
+            bw, pred = jb._Bits(), 0
+            for u in range(coef.shape[0]):
+                pred = jb._block(bw, coef[u], pred, dcl, acl)
+            bw.flush()
+            assert bytes(bw.buf) == ljf.scan_bytes(ljf.compress(lj, plane, q)), (seed, h, w, q)
+            cases += 1
+    assert cases == 240
