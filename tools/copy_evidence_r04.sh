@@ -49,5 +49,6 @@ if [ -d $Z ]; then
   tail -2 $Z/pytest.log | head -1 > $D/r04_gpu_tests.txt
   { echo "# end of round 4: tools/find_encode_mismatch.py 2000 (half of the cases on the fused kernels, half as two-frame batches), tools/find_dxt_mismatch.py 1500, tools/find_module_mismatch.py, tools/find_decode_mismatch_valid.py 3000"
     grep -v amdgpu.ids $Z/find_encode.txt; grep -v amdgpu.ids $Z/find_dxt.txt; grep -v amdgpu.ids $Z/find_module.txt; grep -v amdgpu.ids $Z/find_decode_valid.txt
-    if [ -f $Z/find_deinterlace.txt ]; then echo "# after the closing call: tools/find_deinterlace_mismatch.py 3000 (random geometries of ug_hip_deinterlace_blend[_batch] against the oracle), tools/find_encode_mismatch.py 6000"; tail -1 $Z/find_deinterlace.txt; tail -1 $Z/find_encode_6000.txt; fi; } > $D/r04_random_searches.txt
+    if [ -f $Z/find_deinterlace.txt ]; then echo "# after the closing call: tools/find_deinterlace_mismatch.py 3000 (random geometries of ug_hip_deinterlace_blend[_batch] against the oracle), tools/find_encode_mismatch.py 6000"; tail -1 $Z/find_deinterlace.txt; tail -1 $Z/find_encode_6000.txt; fi
+    if [ -f $Z/find_libjpeg.txt ]; then echo "# tools/find_libjpeg_mismatch.py 3000: the product's RGB 4:4:4 / UYVY 4:2:2 / 4:2:0 streams against libjpeg-turbo (float DCT) on random sizes, qualities 1..100, restart intervals 1..64"; tail -1 $Z/find_libjpeg.txt; fi; } > $D/r04_random_searches.txt
 fi

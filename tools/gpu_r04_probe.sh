@@ -1,2 +1,2 @@
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 900 python -m pytest tests/test_gpu_jpeg.py -q -x -k "libjpeg_turbo" 2>&1 | grep -v "JPEG\]\|APP14\|lavc_vid" | tail -15
+time (timeout 900 python tools/find_libjpeg_mismatch.py 200 selftest 2>&1 | grep -v "amdgpu.ids\|JPEG\]\|APP14" | tail -4)
