@@ -529,7 +529,13 @@ struct CodeArgs {
         size_t slot_bytes;
         uint32_t *wg_bytes;
         unsigned long long *prof;       // UG_JPEG_PROF=1: per workgroup, kProfPhases clock deltas + a mark (averaged and printed when the encoder is destroyed); else NULL
+        // divisions by the scan's constants as multiplications: x / d = (x * m16) >> 16 with m16 = 65536 / d + 1 where x * d < 2^16 (lane and block
+        // numbers by S <= 256 and by the blocks of an MCU), = the high word of x * m32 with m32 = 2^32 / d + 1 where x * d < 2^32 (window words by S;
+        // MCU numbers by the MCUs of a row -- the host takes the fused kernels only where that holds and the row has more than one MCU)
+        uint32_t S_m16, per_mcu_m16, S_m32, mcu_w_m32;
 };
+__device__ __forceinline__ int div16(int x, uint32_t m16) { return (int) (__umul24((uint32_t) x, m16) >> 16); }
+__device__ __forceinline__ int div32(int x, uint32_t m32) { return (int) __umulhi((uint32_t) x, m32); }
 constexpr int kProfPhases = 10;
 
 // WAVES = waves per workgroup.  SRC = 0: a workgroup codes the G = 64 * WAVES / S whole segments that fit its lanes (the host picks the WAVES
@@ -539,7 +545,7 @@ constexpr int kProfPhases = 10;
 #define UG_PHASE(i)                                                                                                      \
         if (a.prof != nullptr && threadIdx.x == 0) {                                                                     \
                 const unsigned long long now_ = __builtin_readcyclecounter();                                            \
-                a.prof[(size_t) blockIdx.x * (kProfPhases + 1) + i] = now_ - prof_t; /* a slot per workgroup: no contention */ \
+                a.prof[((size_t) blockIdx.y * gridDim.x + blockIdx.x) * (kProfPhases + 1) + i] = now_ - prof_t; /* a slot per workgroup: no contention */ \
                 prof_t = now_;                                                                                           \
         }
 
@@ -547,7 +553,7 @@ template <int WAVES, int SRC>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC == 420 ? 5 : 4))) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
 {
         constexpr int W = 64 * WAVES;
-        // The look-back below waits for workgroups with smaller indices.  Index = blockIdx: the dispatcher starts the workgroups of a grid in
+        // The look-back below waits for workgroups with smaller indices.  Index = blockIdx.x within the frame blockIdx.y: the dispatcher starts the workgroups of a grid in
         // index order (per XCD, which is all the argument needs: the lowest unfinished index is always running or next in line for a slot that
         // only lower indices hold).  Should a wait ever be given up (kSpinLimit), the encoder switches to a.ticket != nullptr for good: the index
         // is then a ticket drawn when the workgroup STARTS, so that every index it waits for belongs to a workgroup that is already running whatever
@@ -555,17 +561,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         // the last ticket puts the counter back to 0 for the next launch.
         unsigned long long prof_t = a.prof != nullptr ? __builtin_readcyclecounter() : 0ull;
         __shared__ uint32_t lds_ticket;
-        uint32_t index = blockIdx.x;
+        int frame = (int) blockIdx.y, wg = (int) blockIdx.x; // grid = (workgroups per frame, frames): x runs fastest, the frames follow each other
         if (a.ticket != nullptr) { // wave-uniform
                 if (threadIdx.x == 0) {
                         const uint32_t t = atomicAdd(a.ticket, 1u);
-                        if (t == gridDim.x - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (t == gridDim.x * gridDim.y - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         lds_ticket = t;
                 }
                 __syncthreads();
-                index = lds_ticket;
+                const uint32_t index = lds_ticket;
+                frame = (int) (index / (uint32_t) a.n_wg);
+                wg = (int) (index - (uint32_t) frame * (uint32_t) a.n_wg);
         }
-        const int frame = (int) (index / (uint32_t) a.n_wg), wg = (int) (index - (uint32_t) frame * (uint32_t) a.n_wg);
         __shared__ uint32_t ac_tab[2][256], dc_tab[2][12];
         // one buffer, two lives: (SRC = 0) the staging rows of the block loads (per wave 32 rows of 8 x 16 B, 144 B apart), then (behind 4 pad
         // words) the private strings, 17 W words, and behind them the segments' windows (kWin words per block + one spare word per lane)
@@ -613,8 +620,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 // of an MCU row goes on in the next) = kMcus / ri whole segments
                 constexpr int kMcus = SRC == 444 ? 64 : 32; // 192 (420, 444) / 128 (422) blocks
                 m0 = kMcus * wg;
-                seg0 = m0 / ri;
-                nseg_wg = min(kMcus / ri, a.n_seg - seg0);
+                seg0 = wg * a.G; // G = kMcus / ri
+                nseg_wg = min(a.G, a.n_seg - seg0);
         }
         // which block this lane CODES: `sid`, its index in scan order among the workgroup's blocks.  SRC = 0: the lanes are in scan order.  Fused:
         // every lane codes the block it made -- the lanes are in FRAME order (a wave = a luma block row, or the chroma blocks, of the 32 MCUs;
@@ -626,11 +633,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         int sid = tid, sl, j, m_first, n_blk, ml, b, comp;
         bool active;
         auto identify = [&]() {
-                sl = sid / S; j = sid - sl * S;                  // segment of the workgroup, block of the segment
+                sl = div16(sid, a.S_m16); j = sid - sl * S;   // segment of the workgroup, block of the segment
                 m_first = (seg0 + sl) * ri;
                 n_blk = sl < nseg_wg ? per_mcu * (min(a.n_mcu, m_first + ri) - m_first) : 0;
                 active = j < n_blk;
-                ml = j / per_mcu; b = j - ml * per_mcu;          // MCU of the segment, block of the MCU
+                ml = div16(j, a.per_mcu_m16); b = j - ml * per_mcu; // MCU of the segment, block of the MCU
                 comp = b < ybl ? 0 : a.ctab;
         };
         uint32_t w[32];
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         // packed RGB, components kept as R, G, B (gpujpeg.cpp:303-305): 64 MCUs = 64 8x8 pixel blocks per workgroup; wave c makes the blocks
                         // of component c (the arithmetic of rgb_jpeg444_kernel, jpeg_fdct.hip; the three waves read the same pixels, HBM sees them once)
                         const int mm = m0 + lane;
-                        const int by = mm / a.mcu_w, bx = mm - by * a.mcu_w;
+                        const int by = div32(mm, a.mcu_w_m32), bx = mm - by * a.mcu_w;
                         const bool valid = mm < a.n_mcu;
                         if (valid) {
                                 uint32_t raw[8][6];
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         float q[64];
                         bool valid;
                         if (wv < kLumaWaves) {
-                                const int mm = m0 + (lane >> 1), my = mm / a.mcu_w, mx = mm - my * a.mcu_w;
+                                const int mm = m0 + (lane >> 1), my = div32(mm, a.mcu_w_m32), mx = mm - my * a.mcu_w;
                                 const int bx = 2 * mx + (lane & 1), brow = 2 * my + wv;
                                 valid = mm < a.n_mcu;
                                 if (valid) {
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 }
                         } else {
                                 const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU of the workgroup
-                                const int mm = m0 + m, my = mm / a.mcu_w, mx = mm - my * a.mcu_w;
+                                const int mm = m0 + m, my = div32(mm, a.mcu_w_m32), mx = mm - my * a.mcu_w;
                                 valid = mm < a.n_mcu;
                                 if (valid) {
                                         const uint8_t *const plane = c ? vp : up;
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         float q[64];
                         bool valid; // lanes past the last MCU of the picture hold no block
                         if (wv < kLumaWaves) {
-                                const int mm = m0 + (lane >> 1), my = mm / a.mcu_w, mx = mm - my * a.mcu_w; // this lane's MCU
+                                const int mm = m0 + (lane >> 1), my = div32(mm, a.mcu_w_m32), mx = mm - my * a.mcu_w; // this lane's MCU
                                 const int bx = 2 * mx + (lane & 1);        // luma block column
                                 const int brow = kLumaWaves * my + wv;     // luma block row
                                 valid = mm < a.n_mcu;
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 }
                         } else {
                                 const int c = lane >> 5, m = lane & 31; // 0 = Cb, 1 = Cr ; MCU of the workgroup
-                                const int mm = m0 + m, my = mm / a.mcu_w, mx = mm - my * a.mcu_w;
+                                const int mm = m0 + m, my = div32(mm, a.mcu_w_m32), mx = mm - my * a.mcu_w;
                                 valid = mm < a.n_mcu;
                                 if (valid) {
 #pragma unroll
@@ -1070,11 +1077,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 // another wave scan per 64 words -- a third of the instructions behind the walk.)  The 1-bits that pad a segment's last byte
                 // (T.81 F.1.2.3) are ORed in where the word is read.
                 // (a partition of its own, by tid: lane tid = segment tid / S, part tid % S -- whatever block the lane coded)
-                const int wsl = tid / S, wj = tid - wsl * S;
+                const int wsl = div16(tid, a.S_m16), wj = tid - wsl * S;
                 const int wbits = wsl < nseg_wg ? lds_seg_bits[wsl] : 0; // (written before the merge's barrier)
                 const uint32_t *const wwin = win + min(wsl * S, W - 1) * kWin;
                 const int nbytes = (wbits + 7) >> 3, nwords = (nbytes + 3) >> 2; // (0 for lanes behind the workgroup's last segment)
-                const int K = (nwords + S - 1) / S, i_first = wj * K;
+                const int K = div32(nwords + S - 1, a.S_m32), i_first = wj * K;
                 const int padw = wbits >> 5, padn = 8 - (wbits & 7);
                 const uint32_t padmask = (wbits & 7) ? ((1u << padn) - 1u) << (32 - (wbits & 31) - padn) : 0u;
                 const bool seg_last = wsl < nseg_wg && wj == S - 1; // the lane that writes the marker behind the segment
@@ -1138,7 +1145,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 }
                 if (seg_last && seg0 + wsl == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = at + mine; // the stream's length
                 UG_PHASE(7) // write-out
-                if (a.prof != nullptr && threadIdx.x == 0) a.prof[(size_t) blockIdx.x * (kProfPhases + 1) + kProfPhases] = 1ull;
+                if (a.prof != nullptr && threadIdx.x == 0) a.prof[((size_t) blockIdx.y * gridDim.x + blockIdx.x) * (kProfPhases + 1) + kProfPhases] = 1ull;
         } else {
                 asm volatile("; general path" ::: "memory");
                 __syncthreads(); // lds_flag[1]; nobody reads a private string from here on
@@ -1550,13 +1557,16 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         // Fused: forward DCT, quantiser, Huffman coding and byte stuffing in ONE kernel, a workgroup per 32 consecutive MCUs -- the quantised
         // coefficients never reach HBM.  Needs whole segments per workgroup (32 % ri == 0) and the aligned geometry of the fast front end.
         if (!src_pitch && in == UG_PF_RGB) src_pitch = 3 * w;
-        // a workgroup = 32 (RGB: 64) consecutive MCUs of the scan = whole segments: the restart interval must divide that
-        const bool fused_yuv = !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
+        // a workgroup = 32 (RGB: 64) consecutive MCUs of the scan = whole segments: the restart interval must divide that.  fused_ok: the fused
+        // kernels divide MCU numbers by the MCUs of a row with a multiplication (CodeArgs::mcu_w_m32), exact while (n_mcu + 64) * mcu_w < 2^32
+        // and the row has more than one MCU -- every picture from 9 (17) pixels wide up to ~16K x 16K; others take the two-kernel path
+        const bool fused_ok = e->mcu_w > 1 && ((long) e->n_mcu + 64) * e->mcu_w < (1L << 32);
+        const bool fused_yuv = fused_ok && !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
                                (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0;
         // packed RGB (4:4:4, R, G, B components): any width and alignment (the edge blocks of the picture are loaded byte by byte)
-        const bool fused_rgb = !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0;
+        const bool fused_rgb = fused_ok && !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0;
         // planar I420: 8-byte row pieces of the three planes (width % 16 == 0 keeps the chroma rows 8-byte aligned too)
-        const bool fused_i420 = !wave_path && e->allow_fused && in == UG_PF_I420 && e->sub == 420 && w % 16 == 0 && (!src_pitch || src_pitch == w) && !(7 & (uintptr_t) src_dev) &&
+        const bool fused_i420 = fused_ok && !wave_path && e->allow_fused && in == UG_PF_I420 && e->sub == 420 && w % 16 == 0 && (!src_pitch || src_pitch == w) && !(7 & (uintptr_t) src_dev) &&
                                 (frames == 1 || !(src_stride & 7)) && 32 % e->ri == 0;
         const bool fused = fused_yuv || fused_rgb || fused_i420;
         if (fused) {
@@ -1601,6 +1611,16 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.width = w; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
                 a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
+                // divisions by S, blocks per MCU and MCUs per row as multiplications, where the ranges allow (CodeArgs)
+                {
+                        const int per_mcu = e->hs * e->vs + 2;
+                        auto m16 = [](int d) { return (uint32_t) (65536 / d + 1); };
+                        auto m32 = [](long d) { return d > 1 ? (uint32_t) ((1ull << 32) / (unsigned long long) d + 1ull) : 0u; };
+                        a.S_m16 = m16(S);             // x < 256 lanes, S <= 256: x * S < 2^16
+                        a.per_mcu_m16 = m16(per_mcu); // x < S <= 256, per_mcu <= 6
+                        a.S_m32 = m32(S);             // x <= S * 16 window words + S
+                        a.mcu_w_m32 = m32(e->mcu_w);  // x < n_mcu + 64 (the lanes of a last, short workgroup): see fused_ok
+                }
                 int waves, kwin = 16;
                 if (fused) {
                         const int mcus = fused_rgb ? 64 : 32; // MCUs per workgroup
@@ -1641,7 +1661,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                         a.slots = e->slots;
                         a.wg_bytes = e->wg_bytes;
                 }
-                const dim3 grid((unsigned) a.n_wg * frames);
+                const dim3 grid((unsigned) a.n_wg, (unsigned) frames);
                 if (fused) {
                         if (fused_i420) hipLaunchKernelGGL((jpeg_code_kernel<3, 1420>), grid, dim3(192), 0, st, a, (const float *) e->div);
                         else if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), grid, dim3(192), 0, st, a, (const float *) e->div);
