@@ -98,6 +98,21 @@ constexpr uint32_t kVr = (uint32_t) (0.5 * kCu * 0.5 * kTwo24 + 0.5), kVg = (uin
                    kVb = (uint32_t) (0.5 * kCu * (double) 0.0458f * kTwo24 + 0.5);
 constexpr uint32_t kC0 = (uint32_t) (127.5 * kTwo24) + (1u << 23) + kGuardUyvy;
 
+// k * x (+ acc) on 24-bit operands as ONE instruction each, the constant from a scalar register.  Written out: left to itself the compiler turns
+// "c - k * x" into a full 32-bit multiply by -k behind an AND that re-establishes the 24 bits (v_and + v_mul_lo_u32 + v_add for what
+// v_mad_u32_u24 does) -- 12 instructions for the chroma of a pixel pair instead of 8.
+#define UG_MUL24(dst, k, x) asm("v_mul_u32_u24 %0, %1, %2" : "=v"(dst) : "s"(k), "v"(x))
+#define UG_MAD24(dst, k, x, acc) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(dst) : "s"(k), "v"(x), "v"(acc))
+// Cb / Cr of a pixel pair from the channel sums (0 .. 510): (kA * sa + kC0) - (kB * sb + kC * sc), all modulo 2^32
+__device__ __forceinline__ uint32_t chroma_fixed(uint32_t ka, uint32_t sa, uint32_t kb, uint32_t sb, uint32_t kc, uint32_t sc)
+{
+        uint32_t neg, pos;
+        UG_MUL24(neg, kb, sb);
+        UG_MAD24(neg, kc, sc, neg);
+        UG_MAD24(pos, ka, sa, kC0);
+        return pos - neg;
+}
+
 // returns the UYVY word as the fixed-point values round; `near` = the smallest distance (in 2^-24 units, biased by the guard) of the four
 // values from a rounding boundary: < 2 * kGuardUyvy means the word must not be trusted
 __device__ __forceinline__ uint32_t uyvy_pair_fixed(uint32_t r0, uint32_t g0, uint32_t b0, uint32_t r1, uint32_t g1, uint32_t b1, uint32_t &near)
@@ -105,8 +120,8 @@ __device__ __forceinline__ uint32_t uyvy_pair_fixed(uint32_t r0, uint32_t g0, ui
         const uint32_t y0 = __umul24(kYr, r0) + (__umul24(kYg, g0) + (__umul24(kYb, b0) + kY0));
         const uint32_t y1 = __umul24(kYr, r1) + (__umul24(kYg, g1) + (__umul24(kYb, b1) + kY0));
         const uint32_t sr = r0 + r1, sg = g0 + g1, sb = b0 + b1;
-        const uint32_t u = (__umul24(kUb, sb) + kC0) - (__umul24(kUr, sr) + __umul24(kUg, sg));
-        const uint32_t v = (__umul24(kVr, sr) + kC0) - (__umul24(kVg, sg) + __umul24(kVb, sb));
+        const uint32_t u = chroma_fixed(kUb, sb, kUr, sr, kUg, sg);
+        const uint32_t v = chroma_fixed(kVr, sr, kVg, sg, kVb, sb);
         const uint32_t m = 0xFFFFFFu;
         near = min(min(y0 & m, y1 & m), min(u & m, v & m));
         // the integer parts are the top bytes: U | Y0 << 8 | V << 16 | Y1 << 24
@@ -125,8 +140,8 @@ __device__ __forceinline__ uint32_t uyvy_pair_fixed_packed(uint32_t d0, uint32_t
         UG_MUL24_BYTE(b0, cyr, d0, 3); UG_MUL24_BYTE(b1, cyg, d1, 0); UG_MUL24_BYTE(b2, cyb, d1, 1);
         UG_ADD_BYTES(sr, d0, 0, d0, 3); UG_ADD_BYTES(sg, d0, 1, d1, 0); UG_ADD_BYTES(sb, d0, 2, d1, 1);
         const uint32_t y0 = (a0 + a1) + (a2 + kY0), y1 = (b0 + b1) + (b2 + kY0);
-        const uint32_t u = (__umul24(kUb, sb) + kC0) - (__umul24(kUr, sr) + __umul24(kUg, sg));
-        const uint32_t v = (__umul24(kVr, sr) + kC0) - (__umul24(kVg, sg) + __umul24(kVb, sb));
+        const uint32_t u = chroma_fixed(kUb, sb, kUr, sr, kUg, sg);
+        const uint32_t v = chroma_fixed(kVr, sr, kVg, sg, kVb, sb);
         const uint32_t m = 0xFFFFFFu;
         near = min(min(y0 & m, y1 & m), min(u & m, v & m));
         return __builtin_amdgcn_perm(y0, u, 0x0c0c0703u) | __builtin_amdgcn_perm(y1, v, 0x07030c0cu);
