@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t clamp8(double s)
 template <bool AWAY>
 __device__ __forceinline__ uint8_t unorm8_out(float x)
 {
-        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        x = __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); // the clamp of the write (the values here are finite; -0 and +0 end as the same byte): one operation, not two compares and two selects
         return AWAY ? (uint8_t) (int) (x * 255.0f + 0.5f) : (uint8_t) (int) rintf(x * 255.0f);
 }
 
@@ -465,7 +465,11 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
         if (OUT == UG_PF_UYVY) {
                 // rgba_to_yuv422.glsl on a block with four colours: Y', and the halves of Cb and Cr that the pair average adds up, are functions of
                 // the palette entry alone -- computed once per entry with the shader's own operations (rgb_pair_to_uyvy above), looked up per pixel
-                float hu[4], hv[4];
+                // ... through a column of the lane's own in LDS (entry k of lane t at [k][t]: consecutive lanes in consecutive banks whatever
+                // their indices; nobody else reads it, so no barrier): one address + one ds_read per look-up, where selecting among four
+                // registers by a 2-bit index costs three v_cndmask and their compares -- four look-ups per pixel pair
+                __shared__ float col_u[4][256], col_v[4][256];
+                const int t = threadIdx.y * 64 + threadIdx.x;
                 uint32_t y4 = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -474,8 +478,8 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                         const float uu = 0.5f + ((-r * 0.1145f - g * 0.3854f) + b * 0.5f) * 0.8784f;
                         const float vv = 0.5f + ((r * 0.5f - g * 0.4541f) - b * 0.0458f) * 0.8784f;
                         y4 |= (uint32_t) unorm8_out<AWAY>(yy) << (8 * k);
-                        hu[k] = uu * 0.5f;
-                        hv[k] = vv * 0.5f;
+                        col_u[k][t] = uu * 0.5f;
+                        col_v[k][t] = vv * 0.5f;
                 }
 #pragma unroll
                 for (int y = 0; y < 4; y++) {
@@ -484,10 +488,7 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                         for (int p = 0; p < 2; p++) {
                                 const uint32_t ca = idx & 3, cb = (idx >> 2) & 3;
                                 idx >>= 4;
-                                const float ua = (ca & 2) ? ((ca & 1) ? hu[3] : hu[2]) : ((ca & 1) ? hu[1] : hu[0]);
-                                const float ub = (cb & 2) ? ((cb & 1) ? hu[3] : hu[2]) : ((cb & 1) ? hu[1] : hu[0]);
-                                const float va = (ca & 2) ? ((ca & 1) ? hv[3] : hv[2]) : ((ca & 1) ? hv[1] : hv[0]);
-                                const float vb = (cb & 2) ? ((cb & 1) ? hv[3] : hv[2]) : ((cb & 1) ? hv[1] : hv[0]);
+                                const float ua = col_u[ca][t], ub = col_u[cb][t], va = col_v[ca][t], vb = col_v[cb][t];
                                 word[p] = (uint32_t) unorm8_out<AWAY>(ua + ub) | ((y4 >> (8 * ca)) & 0xff) << 8 | (uint32_t) unorm8_out<AWAY>(va + vb) << 16 |
                                           ((y4 >> (8 * cb)) & 0xff) << 24;
                         }
