@@ -1,6 +1,6 @@
 cd ${GRAFT_REPO_ROOT:-.}
-ROOT=$(pwd)
-timeout 900 python -m pytest tests/test_gpu_dxt_decode.py tests/test_module_harness.py -q -x -k "decode or dxt" 2>&1 | grep -E "passed|failed" | tail -2
-for i in 1 2; do for lib in libug_mi355x_prev.so libug_mi355x.so; do
-  echo "== $lib"; UG_MI355X_LIB=$ROOT/ultragrid_amd/$lib timeout 200 python tools/bench_decode.py 2>&1 | grep "UYVY"
-done; done
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04z; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 2>&1 | grep -v "lavc_vid_conv" | tail -15 > $OUT/pytest.log; grep -E "passed|failed" $OUT/pytest.log | tail -1
+timeout 300 python tools/bench_decode.py --json $OUT/decode.json > $OUT/decode.txt 2>&1; grep -v amdgpu $OUT/decode.txt
+timeout 900 python tools/bench_kernels.py --json $OUT/kernels.json > $OUT/kernels_table.txt 2>&1; grep "dxt_decode\|jpeg encoder" $OUT/kernels_table.txt | cut -c1-150
+timeout 600 python tools/find_dxt_mismatch.py 1500 2>&1 | tail -1 > $OUT/find_dxt.txt; cat $OUT/find_dxt.txt
