@@ -33,6 +33,7 @@
 #include "tv.h"
 #include "types.h"
 #include "utils/vf_split.h"
+#include "utils/video_frame_pool.h"
 #include "video_frame.h"
 
 namespace mi355x {
@@ -274,6 +275,22 @@ private:
         uint32_t m_out_seq = 0;
         size_t m_ended_count = 0;
 };
+
+/// A frame of `pool` that keeps the pool alive.  The reference's video_frame_pool waits in its destructor for every frame it gave out
+/// (video_frame_pool.cpp:150-155), so a module that owns its pool by value blocks in done() -- on the capture thread, inside CHANGE_COMPRESS
+/// (video_compress.cpp:191-195) -- until the sender has let go of the last compressed frame, and deadlocks with a sender that keeps a frame
+/// while it waits for the next one.  Here the encoder state holds the pool through a shared_ptr and every frame holds it too: done() never
+/// waits, and the pool (with its pinned buffers) goes when the last frame does.  The frame returns to the pool BEFORE the reference to the pool
+/// is dropped -- the other order would be the pool's destructor waiting for the very frame whose deleter runs it.
+inline std::shared_ptr<video_frame> get_frame_keeping_pool(const std::shared_ptr<video_frame_pool> &pool)
+{
+        std::shared_ptr<video_frame> pooled = pool->get_frame();
+        video_frame *raw = pooled.get();
+        return std::shared_ptr<video_frame>(raw, [pooled = std::move(pooled), pool = std::shared_ptr<video_frame_pool>(pool)](video_frame *) mutable {
+                pooled.reset();
+                pool.reset();
+        });
+}
 
 /// "dev=<n>[,<n>...]" -> device list (default {0})
 inline std::vector<int> parse_device_list(const char *s)

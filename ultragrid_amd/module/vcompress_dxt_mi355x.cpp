@@ -92,7 +92,7 @@ struct state_video_compress_dxt_mi355x {
         int               batch_slices = 16;
         void             *b_in = nullptr, *b_pre = nullptr, *b_out = nullptr;
         size_t            b_in_stride = 0, b_pre_stride = 0, b_out_stride = 0;
-        video_frame_pool  pool{0, hip_pinned_allocator()};
+        std::shared_ptr<video_frame_pool> pool = std::make_shared<video_frame_pool>(0, hip_pinned_allocator()); ///< shared with the frames it gives out (mi355x::get_frame_keeping_pool)
 };
 
 void cleanup(state_video_compress_dxt_mi355x *s)
@@ -249,7 +249,7 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
         if (s->interlaced_input) {
                 compressed_desc.interlacing = PROGRESSIVE; // dxt_glsl.cpp:196-198
         }
-        s->pool.reconfigure(compressed_desc, s->out_len);
+        s->pool->reconfigure(compressed_desc, s->out_len);
         return true;
 }
 
@@ -298,7 +298,7 @@ std::shared_ptr<video_frame> dxt_mi355x_compress_tile(void *state, std::shared_p
         CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, enc_src, s->dev_out, w, h, 0, 1, 0, 0, s->ties, s->stream),
                   "Encoding failed", return {});
 
-        std::shared_ptr<video_frame> out = s->pool.get_frame();
+        std::shared_ptr<video_frame> out = mi355x::get_frame_keeping_pool(s->pool);
         CHECK_HIP(ug_hip_download_ordered(s->device, out->tiles[0].data, s->dev_out, s->out_len, s->stream), "D2H copy failed", return {});
         CHECK_HIP(ug_hip_stream_sync(s->stream), "stream sync failed", return {});
         out->tiles[0].data_len = (unsigned int) s->out_len;
@@ -361,7 +361,7 @@ std::vector<std::shared_ptr<video_frame>> dxt_mi355x_compress_batch(void *state,
                                              s->ties, s->stream),
                   "Encoding failed", return out);
         for (int f = 0; f < n; f++) {
-                out[f] = s->pool.get_frame();
+                out[f] = mi355x::get_frame_keeping_pool(s->pool);
                 CHECK_HIP(ug_hip_download_ordered(s->device, out[f]->tiles[0].data, (char *) s->b_out + f * s->b_out_stride, s->out_len, s->stream), "D2H copy failed",
                           { for (auto &o : out) o.reset(); return out; });
                 out[f]->tiles[0].data_len = (unsigned int) s->out_len;

@@ -62,7 +62,7 @@ struct state_video_compress_jpeg_mi355x {
         int                  batch_slices = 16; // slices to allocate: the module's batch=<n>, handed down by the sharder as batch_slices=<n>
         size_t               b_in_stride = 0, b_target_stride = 0, b_enc_stride = 0, b_out_stride = 0;
         void                *b_in = nullptr, *b_target = nullptr, *b_enc = nullptr, *b_out = nullptr;
-        video_frame_pool     pool{0, hip_pinned_allocator()};
+        std::shared_ptr<video_frame_pool> pool = std::make_shared<video_frame_pool>(0, hip_pinned_allocator()); ///< shared with the frames it gives out (mi355x::get_frame_keeping_pool)
 };
 
 void cleanup(state_video_compress_jpeg_mi355x *s)
@@ -226,7 +226,7 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         struct video_desc compressed_desc = desc;
         compressed_desc.color_spec = JPEG;
         compressed_desc.tile_count = 1;
-        s->pool.reconfigure(compressed_desc, s->max_out);
+        s->pool->reconfigure(compressed_desc, s->max_out);
         return true;
 }
 
@@ -278,7 +278,7 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
                 MSG(ERROR, "Encoding failed: %s\n", ug_hip_last_error_string());
                 return {};
         }
-        std::shared_ptr<video_frame> out = s->pool.get_frame();
+        std::shared_ptr<video_frame> out = mi355x::get_frame_keeping_pool(s->pool);
         if (ug_hip_download_ordered(s->device, out->tiles[0].data, s->dev_out, len, s->stream) != UG_HIP_SUCCESS ||
             ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "D2H copy failed: %s\n", ug_hip_last_error_string());
@@ -362,7 +362,7 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
                         MSG(ERROR, "Encoding failed: stream of %zu bytes does not fit the output buffer\n", lens[f]);
                         continue;
                 }
-                out[f] = s->pool.get_frame();
+                out[f] = mi355x::get_frame_keeping_pool(s->pool);
                 if (ug_hip_download_ordered(s->device, out[f]->tiles[0].data, (char *) s->b_out + f * s->b_out_stride, lens[f], s->stream) != UG_HIP_SUCCESS) {
                         out[f].reset();
                         continue;
