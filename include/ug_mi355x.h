@@ -23,6 +23,11 @@
  * read bottom-up (vertical mirror), exactly as cuda_dxt.h:38-39.  `src_pitch` is the
  * source line stride in bytes; 0 selects the tightly packed UltraGrid line size
  * (vc_get_linesize, src/video_codec.c:507-521).
+ *
+ * Argument ranges: width and |height| from 1 to 65536 (UltraGrid's largest mode is 8K) and at most INT_MAX bytes per frame or plane
+ * (pitch x lines).  Anything outside -- sizes that are not a picture, or whose byte counts would leave int / size_t range somewhere -- is
+ * refused with UG_HIP_EINVAL before any device call (cuda_dxt.cu:745-746 returns -1 for a bad size); no entry point returns success, a
+ * wrapped value or a runtime error for such input (tests/test_abi.py::test_absurd_geometry_is_refused, every entry point of this header).
  */
 #ifndef UG_MI355X_H
 #define UG_MI355X_H
@@ -34,7 +39,9 @@
 extern "C" {
 #endif
 
-#define UG_HIP_ABI_VERSION 3 /* 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions only) */
+#define UG_HIP_ABI_VERSION 3 /* 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions), and ONE
+                              * change of behaviour: ug_hip_jpeg_encoder_encode_batch with frames > 1 reports a stream that does not fit its slice through
+                              * out_len[f] > out_capacity and returns success for the call (it used to fail the whole call with UG_HIP_EINVAL) */
 
 /* error codes (cuda_dxt.cu:745-746,759 uses -1 bad size/alignment, -3 runtime failure) */
 #define UG_HIP_SUCCESS      0
@@ -230,7 +237,8 @@ int ug_hip_pixfmt_convert_batch(ug_pixfmt_t in, ug_pixfmt_t out, const void *src
  *   "vc_copylineToRGBA_inplace" (:907-921; rshift/gshift/bshift are the SOURCE shifts, alpha byte 0; dst may equal src). */
 int ug_hip_pixfmt_line_func(const char *func, const void *src_dev, void *dst_dev, int width, int height, int src_pitch, int dst_pitch, int dst_len,
                             int rshift, int gshift, int bshift, ug_hip_stream_t stream);
-/* vc_get_linesize (video_codec.c:507-521) for the formats above */
+/* vc_get_linesize (video_codec.c:507-521) for the formats above; UG_HIP_EINVAL for an unknown format or a width outside 1..65536
+ * (the reference's int arithmetic wraps there; this never returns a wrapped value) */
 int ug_hip_linesize(ug_pixfmt_t fmt, int width);
 /* vc_deinterlace (src/video_codec.c:597-664) IN PLACE on a device frame of `lines` lines of `linesize` bytes (pitch == linesize, as there):
  * the linear-blend de-interlace RTDXT applies to INTERLACED_MERGED input before encoding (dxt_glsl.cpp:195-201,291-293), computed as the

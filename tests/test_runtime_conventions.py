@@ -16,6 +16,7 @@ discarded (the reference discards them) but only as a suffix; nothing hangs (the
 CPU half: the test-only "fake" module (ultragrid_amd/module/ug_fake_compress.cpp: the product modules' structure on the product's sharder, the GPU
 replaced by a hash) -- plain, under ThreadSanitizer and under AddressSanitizer.  GPU half: the product's `dxt` and `jpeg` modules."""
 import os
+import shutil
 import struct
 import subprocess
 import sys
@@ -56,8 +57,15 @@ def _run(binary, tmp_path, script, env=None, timeout=300):
     sp.write_text(script)
     e = dict(os.environ, UG_RT_WATCHDOG_S="45")
     e.update(env or {})
-    r = subprocess.run([_binary(binary), str(sp), str(out)], capture_output=True, text=True, timeout=timeout, env=e)
+    cmd = [_binary(binary), str(sp), str(out)]
+    if binary.endswith("_tsan") and shutil.which("setarch"):
+        # libtsan of gcc 11 cannot place its shadow under the 32 bits of mmap randomisation newer kernels use ("unexpected memory mapping"):
+        # run without address-space randomisation, the documented way out
+        cmd = ["setarch", "x86_64", "-R"] + cmd
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
     text = r.stdout + r.stderr
+    if "ThreadSanitizer: unexpected memory mapping" in text:
+        pytest.skip("this kernel's address-space layout cannot host libtsan, even without randomisation")
     assert "WATCHDOG" not in text and r.returncode != 4, "hang:\n" + text[-3000:]
     assert "Sanitizer" not in text and "runtime error" not in text, text[-6000:]
     assert r.returncode == 0, text[-3000:]
@@ -262,6 +270,9 @@ def _oracle_bytes(po, cfg, codec, il, src, w, h):
     if cfg.startswith("dxt"):
         if il:
             decoded = po.deinterlace_blend(decoded, {"UYVY": 2 * w, "RGB": 3 * w}[target], h)  # RTDXT's vc_deinterlace (dxt_glsl.cpp:291-293)
+        if "DXT1_YUV" in cfg:                                # DXT1 over the Y,Cb,Cr samples of the UYVY form (dxt_glsl.cpp:104-110)
+            assert target == "UYVY"
+            return po.dxt_encode(po.IN_UYVY_RAW, po.OUT_DXT1, decoded, w, h).tobytes()
         oid = po.OUT_DXT5YCOCG if "DXT5" in cfg else po.OUT_DXT1
         return po.dxt_encode(po.IN_UYVY if target == "UYVY" else po.IN_RGB, oid, decoded, w, h).tobytes()
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -290,7 +301,7 @@ def _check_real(po, records, pushes, sets):
         assert (r["w"], r["h"], r["tiles"]) == (s.w, s.h, 1), (r["index"], r["w"], r["h"])
         hit = None
         for ci, cfg in cfgs:
-            name_out = "JPEG" if cfg.startswith("jpeg") else ("DXT5" if "DXT5" in cfg else "DXT1")
+            name_out = "JPEG" if cfg.startswith("jpeg") else ("DXT5" if "DXT5" in cfg else "DXT1_YUV" if "DXT1_YUV" in cfg else "DXT1")
             if r["codec"] != name_out:
                 continue
             want = s.want(po, cfg, r["index"] % s.n)
@@ -389,7 +400,7 @@ def test_change_compress_between_the_product_modules(tmp_path, po, binary, holds
 @pytest.mark.parametrize("binary", _real_binaries())
 def test_change_compress_from_a_control_thread_on_the_gpu(tmp_path, po, binary):
     sets = {"S": RealSet(tmp_path, "S", "UYVY", 320, 192, False, 4, 43), "A": RealSet(tmp_path, "A", "UYVY", 1920, 1080, False, 2, 13)}
-    cfgs = ["dxt:DXT5:workers=4:batch=4", "dxt:DXT1:workers=2:batch=2", "jpeg:q=50:restart=4:batch=4", "dxt:DXT5:workers=3"]
+    cfgs = ["dxt:DXT5:workers=4:batch=4", "dxt:DXT1:workers=2:batch=2", "jpeg:q=50:restart=4:batch=4", "dxt:DXT1_YUV:workers=3"]   # (told apart by their bytes)
     body = (f"init {cfgs[0]}\npace_us 500\nmsg_ctl 30 {cfgs[1]}\nmsg_ctl 90 {cfgs[2]}\nmsg_ctl 160 {cfgs[3]}\n"
             "push S 100\npush A 100\npush S 150\nsleep_ms 200\npush A 20\ndone\n")
     pushes = [(n, list(enumerate(cfgs))) for n, c in (("S", 100), ("A", 100), ("S", 150), ("A", 20)) for _ in range(c)]

@@ -93,7 +93,10 @@ def yuv422_to_yuv444(src: torch.Tensor, pix_count: int) -> torch.Tensor:
 
 
 def linesize(fmt: int, w: int) -> int:
-    return L.load().ug_hip_linesize(fmt, w)
+    n = L.load().ug_hip_linesize(fmt, w)
+    if n <= 0:
+        raise L.UgHipError(n, f"ug_hip_linesize({fmt}, {w})")
+    return n
 
 
 def pixfmt_convert(in_fmt: int, out_fmt: int, src: torch.Tensor, w: int, h: int, shifts=(0, 8, 16)) -> torch.Tensor:

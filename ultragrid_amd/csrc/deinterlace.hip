@@ -130,6 +130,9 @@ __global__ __launch_bounds__(kWaves * 64) void deinterlace_kernel(uint8_t *__res
 
 extern "C" int ug_hip_deinterlace_blend_batch(void *frame_dev, size_t linesize, int lines, int frames, size_t frame_stride, ug_hip_stream_t stream)
 {
+        if (lines < 0 || lines > ug::kMaxDim || linesize > 8ull * ug::kMaxDim || !ug::span_ok((long long) linesize, lines)) {
+                return ug::refuse_size("ug_hip_deinterlace_blend"); // (8 bytes per pixel: the widest line of the library)
+        }
         if (!frame_dev || linesize == 0 || lines < 0 || frames < 0 || frames > 65535 || (frames > 1 && frame_stride < linesize * (size_t) lines)) {
                 ug::set_last_error_msg("ug_hip_deinterlace_blend: bad arguments");
                 return UG_HIP_EINVAL;

@@ -594,6 +594,7 @@ extern "C" int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *sr
                 ug::set_last_error_msg("ug_hip_dxt_decode: unknown tie rule");
                 return UG_HIP_EINVAL;
         }
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_dxt_decode");
         if (!src_dev || !dst_dev || width <= 0 || height <= 0 || (width & 3) || (height & 3) || (15 & (uintptr_t) dst_dev) ||
             ((in == UG_DXT5_YCOCG ? 15 : 7) & (uintptr_t) src_dev) || (height / 4 + 3) / 4 > 65535) {
                 ug::set_last_error_msg("ug_hip_dxt_decode: bad size or alignment");
@@ -610,6 +611,7 @@ extern "C" int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *sr
         if (dst_pitch == 0) {
                 dst_pitch = ug::linesize(out, width);
         }
+        if (dst_pitch < 0 || !ug::span_ok(dst_pitch, height)) return ug::refuse_size("ug_hip_dxt_decode");
         OutArgs o = { (uint8_t *) dst_dev, dst_pitch, rshift, gshift, bshift };
         hipStream_t st = (hipStream_t) stream;
         switch (out) {

@@ -1172,6 +1172,7 @@ extern "C" {
 
 size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height)
 {
+        if (!ug::dims_ok_signed(width, height)) return 0; // not a picture: no size (never a wrapped one)
         if (height < 0) height = -height;
         const size_t px = (size_t) width * (size_t) height; // dxt_util.h:59-67
         return out == UG_DXT1 || out == UG_DXT1_YUV ? px / 2 : px;
@@ -1181,6 +1182,7 @@ int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src, vo
                                int src_pitch, int frames, size_t src_frame_stride, size_t dst_frame_stride, int ties,
                                ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok_signed(width, height)) return ug::refuse_size("ug_hip_dxt_encode");
         const int ah = height < 0 ? -height : height;
         if (out == UG_DXT1_YUV) { // DXT1 over the Y,Cb,Cr samples: UYVY is its only input (dxt_glsl.cpp:104-110)
                 if (in != UG_PF_UYVY && in != UG_PF_UYVY_RAW) {
@@ -1206,6 +1208,7 @@ int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src, vo
                 ug::set_last_error_msg("ug_hip_dxt_encode: bad pitch / unsupported input format");
                 return src_pitch <= 0 ? UG_HIP_EUNSUPP : UG_HIP_EINVAL;
         }
+        if (!ug::span_ok(src_pitch, ah)) return ug::refuse_size("ug_hip_dxt_encode");
         if (frames > 1 && ((src_frame_stride & 15) || (dst_frame_stride & 15))) {
                 ug::set_last_error_msg("ug_hip_dxt_encode: frame strides must be multiples of 16");
                 return UG_HIP_EINVAL;
@@ -1262,11 +1265,12 @@ int ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *
 {
         if (!ms_per_launch || iters <= 0) return UG_HIP_EINVAL;
         hipStream_t st = (hipStream_t) stream;
+        int rc = ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, frames, sfs, dfs, stream); // warm; refuses bad arguments before any device call
+        if (rc != UG_HIP_SUCCESS) return rc;
         hipEvent_t e0, e1;
         UG_HIP_TRY(hipEventCreate(&e0));
         UG_HIP_TRY(hipEventCreate(&e1));
-        int rc = ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, frames, sfs, dfs, stream); // warm
-        if (rc == UG_HIP_SUCCESS) {
+        {
                 (void) hipEventRecord(e0, st);
                 for (int i = 0; i < iters && rc == UG_HIP_SUCCESS; i++) {
                         rc = ug_hip_dxt_encode_batch(in, out, src, dst, width, height, src_pitch, frames, sfs, dfs, stream);

@@ -417,6 +417,10 @@ template <int SUB>
 int launch_uyvy_jpeg(const void *src, int src_pitch, int width, int height, const float *div, int16_t *out_y, int16_t *out_cb,
                      int16_t *out_cr, int frames, const FrameStrides &fs, ug_hip_stream_t stream, const char *who)
 {
+        if (!ug::dims_ok(width, height) || src_pitch < 0 || !ug::span_ok(src_pitch ? src_pitch : ug::linesize(UG_PF_UYVY, width), height) ||
+            !ug::span_ok(2LL * ((width + 15) / 16 * 16), (height + 15) / 16 * 16)) { // (the luma coefficients: an int16 per padded sample)
+                return ug::refuse_size(who);
+        }
         if (!src || !div || !out_y || !out_cb || !out_cr || width <= 0 || height <= 0 || frames < 0 || frames > 65535 ||
             ((uintptr_t) out_y | (uintptr_t) out_cb | (uintptr_t) out_cr) & 15 || (frames > 1 && ((fs.luma | fs.chroma) & 15))) {
                 ug::set_last_error_msg(who);
@@ -444,6 +448,10 @@ int launch_uyvy_jpeg(const void *src, int src_pitch, int width, int height, cons
 int ug::jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width, int height, int blocks_w, int blocks_h,
                                 const float *div, int16_t *out, float *coef, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height) || blocks_w <= 0 || blocks_h <= 0 || blocks_w > ug::kMaxDim / 8 || blocks_h > ug::kMaxDim / 8 || !ug::span_ok(pitch, height) ||
+            !ug::span_ok(128LL * blocks_w, blocks_h)) { // (a block is 64 int16 coefficients)
+                return ug::refuse_size("ug_hip_jpeg_fdct_quant_plane");
+        }
         if (!plane || !div || !out || width <= 0 || height <= 0 || xstride < 1 || blocks_w * 8 < width || blocks_h * 8 < height ||
             (15 & (uintptr_t) out) || pitch < width * xstride) {
                 ug::set_last_error_msg("ug_hip_jpeg_fdct_quant_plane: bad arguments");

@@ -1375,7 +1375,11 @@ bool fill_frame(Args &a, const ug_av_frame *f, int planes, int align)
         }
         a.w = f->width;
         a.h = f->height;
-        return a.w > 0 && a.h > 0;
+        if (!ug::dims_ok(a.w, a.h)) return false; // (the C ABI's size bound, ug_common.h)
+        for (int i = 0; i < planes; i++) {
+                if (!ug::span_ok(f->linesize[i], a.h)) return false;
+        }
+        return true;
 }
 
 } // namespace
@@ -1429,6 +1433,7 @@ int ug_hip_uv_to_av(const char *uv_codec, const char *av_pixfmt, const void *in_
                 return UG_HIP_EINVAL;
         }
         const int w = a.w, h = a.h;
+        if (!ug::span_ok(uv_linesize(c->uv, w), h)) return ug::refuse_size("ug_hip_uv_to_av");
         switch (c->fwd) {
         case F_I420:
                 return ug_hip_uyvy_to_i420(in_data, 0, out->data[0], out->linesize[0], out->data[1], out->linesize[1], out->data[2], out->linesize[2], w, h, stream);
@@ -1466,7 +1471,7 @@ int ug_hip_av_to_uv(const char *av_pixfmt, const char *uv_codec, void *dst, int 
                 return UG_HIP_EUNSUPP;
         }
         Args a = {};
-        if (!dst || !in || pitch <= 0 || !fill_frame(a, in, c->min_planes, frame_align(c->av)) || (((uintptr_t) dst | (uintptr_t) pitch) & (uintptr_t) (uv_align(c->uv) - 1))) {
+        if (!dst || !in || pitch <= 0 || !fill_frame(a, in, c->min_planes, frame_align(c->av)) || !ug::span_ok(pitch, a.h) || (((uintptr_t) dst | (uintptr_t) pitch) & (uintptr_t) (uv_align(c->uv) - 1))) {
                 ug::set_last_error_msg("ug_hip_av_to_uv: null pointer, bad geometry or misaligned buffer");
                 return UG_HIP_EINVAL;
         }

@@ -744,8 +744,10 @@ int ug_hip_pixfmt_supported(ug_pixfmt_t in, ug_pixfmt_t out)
         return 0;
 }
 
-int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height,
-                          int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
+// the converter behind ug_hip_pixfmt_convert: every argument check but the bound on the number of lines -- a batch of frames laid end to end
+// is handed over as ONE picture that may be taller than any frame (the kernels index lines with 64-bit offsets)
+static int pixfmt_convert_lines(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height,
+                                int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
 
 // `frames` images at constant strides.  Frames that follow each other exactly one picture apart (stride == pitch * height on both
 // sides -- tiles and frame rings are laid out like that) are ONE picture of frames * height lines to every line converter, so the
@@ -754,7 +756,8 @@ int ug_hip_pixfmt_convert_batch(ug_pixfmt_t in, ug_pixfmt_t out, const void *src
                                 int dst_pitch, int rshift, int gshift, int bshift, int frames, size_t src_frame_stride,
                                 size_t dst_frame_stride, ug_hip_stream_t stream)
 {
-        if (frames < 0 || width <= 0 || height <= 0) {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_pixfmt_convert_batch");
+        if (frames < 0 || src_pitch < 0 || dst_pitch < 0) {
                 ug::set_last_error_msg("ug_hip_pixfmt_convert_batch: bad arguments");
                 return UG_HIP_EINVAL;
         }
@@ -764,9 +767,11 @@ int ug_hip_pixfmt_convert_batch(ug_pixfmt_t in, ug_pixfmt_t out, const void *src
                 ug::set_last_error_msg("ug_hip_pixfmt_convert_batch: unsupported format");
                 return UG_HIP_EUNSUPP;
         }
+        if (!ug::span_ok(sp, height) || !ug::span_ok(dp, height)) return ug::refuse_size("ug_hip_pixfmt_convert_batch");
+        // (one picture of at most 4 * 65535 lines: the line kernels put four lines into a workgroup and the grid's y extent ends at 65535)
         if (frames == 1 || (src_frame_stride == (size_t) sp * height && dst_frame_stride == (size_t) dp * height &&
-                            (long long) height * frames <= 0x7fffffffLL)) {
-                return ug_hip_pixfmt_convert(in, out, src, dst, width, height * frames, sp, dp, rshift, gshift, bshift, stream);
+                            (long long) height * frames <= 4LL * 65535)) {
+                return pixfmt_convert_lines(in, out, src, dst, width, height * frames, sp, dp, rshift, gshift, bshift, stream);
         }
         for (int f = 0; f < frames; f++) {
                 const int rc = ug_hip_pixfmt_convert(in, out, (const uint8_t *) src + (size_t) f * src_frame_stride,
@@ -779,6 +784,17 @@ int ug_hip_pixfmt_convert_batch(ug_pixfmt_t in, ug_pixfmt_t out, const void *src
 
 int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height,
                           int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
+{
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_pixfmt_convert");
+        if (src_pitch < 0 || dst_pitch < 0 || !ug::span_ok(src_pitch ? src_pitch : ug::linesize(in, width), height) ||
+            !ug::span_ok(dst_pitch ? dst_pitch : ug::linesize(out, width), height)) {
+                return ug::refuse_size("ug_hip_pixfmt_convert");
+        }
+        return pixfmt_convert_lines(in, out, src, dst, width, height, src_pitch, dst_pitch, rshift, gshift, bshift, stream);
+}
+
+static int pixfmt_convert_lines(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void *dst, int width, int height,
+                                int src_pitch, int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream)
 {
         if (!src || !dst || width <= 0 || height <= 0) {
                 ug::set_last_error_msg("ug_hip_pixfmt_convert: bad arguments");
@@ -865,8 +881,10 @@ int ug_hip_pixfmt_convert(ug_pixfmt_t in, ug_pixfmt_t out, const void *src, void
 int ug_hip_uyvy_to_i420(const void *src, int src_pitch, void *y, int y_pitch, void *u, int u_pitch, void *v,
                         int v_pitch, int width, int height, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_uyvy_to_i420");
         if (!src || !y || !u || !v || width <= 0 || height <= 0) return UG_HIP_EINVAL;
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
+        if (!ug::planes_ok(height, { src_pitch, y_pitch, u_pitch, v_pitch })) return ug::refuse_size("ug_hip_uyvy_to_i420");
         hipStream_t st = (hipStream_t) stream;
         const bool fast = width % 8 == 0 && height % 2 == 0 && !(src_pitch & 15) && !(y_pitch & 7) && !(u_pitch & 3) &&
                           !(v_pitch & 3) && !(15 & (uintptr_t) src) && !(7 & (uintptr_t) y) && !(3 & (uintptr_t) u) &&
@@ -890,8 +908,10 @@ int ug_hip_uyvy_to_i420(const void *src, int src_pitch, void *y, int y_pitch, vo
 int ug_hip_v210_to_p010le(const void *src, int src_pitch, void *y, int y_pitch, void *uv, int uv_pitch, int width,
                           int height, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_v210_to_p010le");
         if (!src || !y || !uv || width <= 0 || height <= 0) return UG_HIP_EINVAL;
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_V210, width);
+        if (!ug::planes_ok(height, { src_pitch, y_pitch, uv_pitch })) return ug::refuse_size("ug_hip_v210_to_p010le");
         const int gpl = (width + 5) / 6;
         // to_planar.c:68-70 asserts a 4-byte aligned source and even output line sizes; a line must hold its own samples
         if ((src_pitch & 3) || src_pitch < 16 * gpl || (y_pitch & 1) || (uv_pitch & 1) || y_pitch < 2 * width || uv_pitch < 2 * width ||
@@ -926,7 +946,8 @@ int ug_hip_v210_to_p010le(const void *src, int src_pitch, void *y, int y_pitch, 
 
 int ug_hip_yuv422_to_yuv444(const void *src, void *out, int pix_count, ug_hip_stream_t stream)
 {
-        if (!src || !out || pix_count < 0 || (pix_count & 3) || (7 & (uintptr_t) src) || (3 & (uintptr_t) out)) {
+        if (pix_count < 0 || pix_count > ug::kMaxFrameBytes / 3) return ug::refuse_size("ug_hip_yuv422_to_yuv444"); // (3 output bytes per pixel)
+        if (!src || !out || (pix_count & 3) || (7 & (uintptr_t) src) || (3 & (uintptr_t) out)) {
                 return UG_HIP_EINVAL;
         }
         const int quads = pix_count / 4; // cuda_dxt.cu:766

@@ -1087,6 +1087,9 @@ extern "C" int ug_hip_pixfmt_best(ug_pixfmt_t in, const ug_pixfmt_t *candidates,
 extern "C" int ug_hip_pixfmt_line_func(const char *func, const void *src, void *dst, int width, int height, int src_pitch, int dst_pitch, int dst_len,
                                        int rshift, int gshift, int bshift, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height) || src_pitch < 0 || dst_pitch < 0 || dst_len > 8 * ug::kMaxDim || !ug::planes_ok(height, { src_pitch, dst_pitch, dst_len })) {
+                return ug::refuse_size("ug_hip_pixfmt_line_func");
+        }
         if (!func || !src || !dst || width <= 0 || height <= 0 || dst_len < 0 || (((uintptr_t) src | (uintptr_t) src_pitch) & 3)) {
                 ug::set_last_error_msg("ug_hip_pixfmt_line_func: bad arguments (the sources are read as 32-bit words)");
                 return UG_HIP_EINVAL;

@@ -221,6 +221,7 @@ extern "C" {
 int ug_hip_yuv420p_to_uyvy(const void *y, int y_pitch, const void *cb, int cb_pitch, const void *cr, int cr_pitch, void *dst, int dst_pitch,
                            int width, int height, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_yuv420p_to_uyvy");
         if (bad_planes(y, cb, cr, dst, width, height) || (3 & (uintptr_t) dst)) {
                 ug::set_last_error_msg("ug_hip_yuv420p_to_uyvy: bad arguments");
                 return UG_HIP_EINVAL;
@@ -230,6 +231,7 @@ int ug_hip_yuv420p_to_uyvy(const void *y, int y_pitch, const void *cb, int cb_pi
         if (!cb_pitch) cb_pitch = cw;
         if (!cr_pitch) cr_pitch = cw;
         if (!dst_pitch) dst_pitch = ug::linesize(UG_PF_UYVY, width);
+        if (!ug::planes_ok(height, { y_pitch, cb_pitch, cr_pitch, dst_pitch })) return ug::refuse_size("ug_hip_yuv420p_to_uyvy");
         if (dst_pitch & 3) {
                 ug::set_last_error_msg("ug_hip_yuv420p_to_uyvy: destination pitch must be a multiple of 4");
                 return UG_HIP_EINVAL;
@@ -241,6 +243,7 @@ int ug_hip_yuv420p_to_uyvy(const void *y, int y_pitch, const void *cb, int cb_pi
 int ug_hip_yuv422p_to_uyvy(const void *y, int y_pitch, const void *cb, int cb_pitch, const void *cr, int cr_pitch, void *dst, int dst_pitch,
                            int width, int height, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_yuv422p_to_uyvy");
         if (bad_planes(y, cb, cr, dst, width, height) || (3 & (uintptr_t) dst)) {
                 ug::set_last_error_msg("ug_hip_yuv422p_to_uyvy: bad arguments");
                 return UG_HIP_EINVAL;
@@ -250,6 +253,7 @@ int ug_hip_yuv422p_to_uyvy(const void *y, int y_pitch, const void *cb, int cb_pi
         if (!cb_pitch) cb_pitch = cw;
         if (!cr_pitch) cr_pitch = cw;
         if (!dst_pitch) dst_pitch = ug::linesize(UG_PF_UYVY, width);
+        if (!ug::planes_ok(height, { y_pitch, cb_pitch, cr_pitch, dst_pitch })) return ug::refuse_size("ug_hip_yuv422p_to_uyvy");
         if (dst_pitch & 3) {
                 ug::set_last_error_msg("ug_hip_yuv422p_to_uyvy: destination pitch must be a multiple of 4");
                 return UG_HIP_EINVAL;
@@ -261,6 +265,7 @@ int ug_hip_yuv422p_to_uyvy(const void *y, int y_pitch, const void *cb, int cb_pi
 int ug_hip_yuv422p10le_to_v210(const void *y, int y_pitch, const void *cb, int cb_pitch, const void *cr, int cr_pitch, void *dst, int dst_pitch,
                                int width, int height, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_yuv422p10le_to_v210");
         if (bad_planes(y, cb, cr, dst, width, height) || (3 & (uintptr_t) dst) || (1 & ((uintptr_t) y | (uintptr_t) cb | (uintptr_t) cr))) {
                 ug::set_last_error_msg("ug_hip_yuv422p10le_to_v210: bad arguments");
                 return UG_HIP_EINVAL;
@@ -270,6 +275,7 @@ int ug_hip_yuv422p10le_to_v210(const void *y, int y_pitch, const void *cb, int c
         if (!cb_pitch) cb_pitch = 2 * cw;
         if (!cr_pitch) cr_pitch = 2 * cw;
         if (!dst_pitch) dst_pitch = ug::linesize(UG_PF_V210, width);
+        if (!ug::planes_ok(height, { y_pitch, cb_pitch, cr_pitch, dst_pitch })) return ug::refuse_size("ug_hip_yuv422p10le_to_v210");
         if ((dst_pitch & 3) || ((y_pitch | cb_pitch | cr_pitch) & 1)) {
                 ug::set_last_error_msg("ug_hip_yuv422p10le_to_v210: pitches must keep 16-bit samples / 32-bit words aligned");
                 return UG_HIP_EINVAL;
@@ -286,6 +292,7 @@ int ug_hip_yuv422p10le_to_v210(const void *y, int y_pitch, const void *cb, int c
 int ug_hip_uyvy_to_i422(const void *src, int src_pitch, void *y, int y_pitch, void *cb, int cb_pitch, void *cr, int cr_pitch, int width,
                         int height, ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_uyvy_to_i422");
         if (bad_planes(y, cb, cr, src, width, height) || (3 & (uintptr_t) src)) {
                 ug::set_last_error_msg("ug_hip_uyvy_to_i422: bad arguments");
                 return UG_HIP_EINVAL;
@@ -295,6 +302,7 @@ int ug_hip_uyvy_to_i422(const void *src, int src_pitch, void *y, int y_pitch, vo
         if (!y_pitch) y_pitch = width;
         if (!cb_pitch) cb_pitch = cw;
         if (!cr_pitch) cr_pitch = cw;
+        if (!ug::planes_ok(height, { src_pitch, y_pitch, cb_pitch, cr_pitch })) return ug::refuse_size("ug_hip_uyvy_to_i422");
         if (src_pitch & 3) {
                 ug::set_last_error_msg("ug_hip_uyvy_to_i422: source pitch must be a multiple of 4");
                 return UG_HIP_EINVAL;
@@ -318,6 +326,7 @@ int ug_hip_uyvy_to_i422(const void *src, int src_pitch, void *y, int y_pitch, vo
 int ug_hip_uyvy_to_nv12(const void *src, int src_pitch, void *y, int y_pitch, void *cbcr, int cbcr_pitch, int width, int height,
                         ug_hip_stream_t stream)
 {
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_uyvy_to_nv12");
         if (!src || !y || !cbcr || width <= 0 || height <= 0 || (height + 7) / 8 > 65535 || (3 & (uintptr_t) src) || (1 & (uintptr_t) cbcr)) {
                 ug::set_last_error_msg("ug_hip_uyvy_to_nv12: bad arguments");
                 return UG_HIP_EINVAL;
@@ -326,6 +335,7 @@ int ug_hip_uyvy_to_nv12(const void *src, int src_pitch, void *y, int y_pitch, vo
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
         if (!y_pitch) y_pitch = width;
         if (!cbcr_pitch) cbcr_pitch = 2 * cw;
+        if (!ug::planes_ok(height, { src_pitch, y_pitch, cbcr_pitch })) return ug::refuse_size("ug_hip_uyvy_to_nv12");
         if ((src_pitch & 3) || (cbcr_pitch & 1)) {
                 ug::set_last_error_msg("ug_hip_uyvy_to_nv12: source pitch must be a multiple of 4, CbCr pitch of 2");
                 return UG_HIP_EINVAL;

@@ -653,6 +653,10 @@ int ug_hip_from_planar(const char *func, const struct ug_from_planar_data *d, ug
                 ug::set_last_error_msg("ug_hip_from_planar: unknown conversion name");
                 return UG_HIP_EINVAL;
         }
+        if (!ug::dims_ok(d->width, d->height) ||
+            !ug::planes_ok(d->height, { d->out_pitch, d->in_linesize[0], d->in_linesize[1], d->in_linesize[2], d->in_linesize[3] })) {
+                return ug::refuse_size("ug_hip_from_planar");
+        }
         if (d->width <= 0 || d->height <= 0 || !d->out_data) {
                 ug::set_last_error_msg("ug_hip_from_planar: bad geometry or null output");
                 return UG_HIP_EINVAL;
@@ -682,6 +686,10 @@ int ug_hip_to_planar(const char *func, const struct ug_to_planar_data *d, ug_hip
         if (!c || !d) {
                 ug::set_last_error_msg("ug_hip_to_planar: unknown conversion name");
                 return UG_HIP_EINVAL;
+        }
+        if (!ug::dims_ok(d->width, d->height) ||
+            !ug::planes_ok(d->height, { d->out_linesize[0], d->out_linesize[1], d->out_linesize[2], d->out_linesize[3], 8LL * d->width })) {
+                return ug::refuse_size("ug_hip_to_planar"); // (8 bytes per pixel: the widest packed source, Y416)
         }
         if (d->width <= 0 || d->height <= 0 || !d->in_data || !d->out_data[0]) {
                 ug::set_last_error_msg("ug_hip_to_planar: bad geometry or null pointer");

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <initializer_list>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -32,8 +33,35 @@ void set_last_error_msg(const char *msg);
                 }                                                            \
         } while (0)
 
+// ---- argument ranges of the C ABI ----
+// The header promises "0 or a negative UG_HIP_E* code" from every entry point, so a size that is not a picture, or whose byte counts leave the
+// range the kernels index with, is refused before anything is launched (the reference: cuda_dxt.cu:745-746 returns -1 for a bad size; its
+// vc_get_linesize is plain int arithmetic and wraps).  Bound: width and |height| up to 65 536 -- UltraGrid's largest mode is 8K -- and every
+// frame or plane up to INT_MAX bytes, which is what the kernels' 32-bit byte offsets inside one frame cover.  (Batches multiply by size_t strides.)
+constexpr int kMaxDim = 65536;
+constexpr long long kMaxFrameBytes = 0x7fffffffLL;
+static inline bool dims_ok(int width, int height) { return width > 0 && width <= kMaxDim && height > 0 && height <= kMaxDim; }
+/// height < 0 = bottom-up where an entry point allows it (cuda_dxt.h:36-39); INT_MIN has no absolute value
+static inline bool dims_ok_signed(int width, int height) { return height != INT32_MIN && dims_ok(width, height < 0 ? -height : height); }
+/// rows lines of pitch bytes: one frame / plane the kernels may index with 32 bits
+static inline bool span_ok(long long pitch, long long rows) { return pitch >= 0 && rows >= 0 && (rows == 0 || pitch <= kMaxFrameBytes / rows); }
+/// every plane of a picture: no negative pitch, rows * pitch within the bound
+static inline bool planes_ok(int rows, std::initializer_list<long long> pitches)
+{
+        for (long long p : pitches) if (!span_ok(p, rows)) return false;
+        return true;
+}
+static inline int refuse_size(const char *who)
+{
+        char msg[160];
+        snprintf(msg, sizeof msg, "%s: size out of range (width, |height| 1..%d, at most %lld bytes per frame or plane)", who, kMaxDim, kMaxFrameBytes);
+        set_last_error_msg(msg);
+        return UG_HIP_EINVAL;
+}
+
 static inline int linesize(ug_pixfmt_t f, int width)
 {
+        if (width <= 0 || width > kMaxDim) return 0; // (callers refuse 0; ug_hip_linesize turns it into UG_HIP_EINVAL)
         // video_codec.c:120-206 (block bytes / pixels, h_align) and :507-521
         int bb, bp, ha;
         switch (f) {

@@ -225,7 +225,15 @@ int ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, siz
         return UG_HIP_SUCCESS;
 }
 
-int ug_hip_linesize(ug_pixfmt_t fmt, int width) { return ug::linesize(fmt, width); }
+int ug_hip_linesize(ug_pixfmt_t fmt, int width)
+{
+        const int ls = ug::linesize(fmt, width); // 0: unknown format, or a width outside 1..65536 (never a wrapped int)
+        if (ls <= 0) {
+                ug::set_last_error_msg("ug_hip_linesize: unknown pixel format, or width outside 1..65536");
+                return UG_HIP_EINVAL;
+        }
+        return ls;
+}
 
 // ---- NUMA placement of the threads that feed a GPU ("expect host-side limits before 8x scaling") ----
 // A worker of the frame sharder copies frames into pinned memory, queues the transfers and waits for them; on a two-socket box with
