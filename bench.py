@@ -307,6 +307,7 @@ def main() -> None:
             rc = l_.ug_hip_jpeg_encoder_encode_batch(enc, pf, F, src[b].data_ptr(), 0, frame_bytes, jout[b].data_ptr(), stride, stride, lens,
                                                      torch.cuda.current_stream().cuda_stream)
             assert rc == 0, lib.last_error()
+            assert all(lens[f] <= stride for f in range(F)), "a stream did not fit its slice: the call would be timed on a truncated stream"
             stream_bytes[0] = sum(lens[f] for f in range(F))
 
     # calibrate the launches of a step: >= 50 ms of GPU work per step, so that box noise averages out and gpu_busy registers

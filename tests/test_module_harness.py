@@ -808,7 +808,7 @@ def test_workers_run_on_the_gpu_s_numa_node(tmp_path, po, cfg):
         r = _run([cfg + extra, "UYVY", w, h, raw, out, 1, "host", n], env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         outs[tag] = out.read_bytes()
-        lines = [l for l in r.stdout.splitlines() if l.startswith("NUMA worker")]
+        lines = [l for l in (r.stdout + r.stderr).splitlines() if l.startswith("NUMA worker")]
         if tag == "off":
             assert not lines
             continue

@@ -48,6 +48,7 @@ def single():
 def batch():
     k = batch.k = getattr(batch, "k", 0) + 1
     assert l.ug_hip_jpeg_encoder_encode_batch(enc, pf_in, a.n, src[k % sets].data_ptr(), 0, src.shape[2], out.data_ptr(), stride, stride, lens, st) == 0, L.last_error()
+    assert all(lens[f] <= stride for f in range(a.n)), "a stream did not fit its slice"
 
 
 legs = (("one frame per call", single), (f"{a.n} frames per call", batch), ("one frame per call", single), (f"{a.n} frames per call", batch))

@@ -323,6 +323,10 @@ class JpegEncoder:
         lens = (C.c_size_t * n)()
         rc = L.load().ug_hip_jpeg_encoder_encode_batch(self._h, in_fmt, n, srcs.data_ptr(), 0, srcs.shape[1], out.data_ptr(), stride, self.max_size, lens, _stream())
         L.check(rc, "ug_hip_jpeg_encoder_encode_batch")
+        # ABI 3: with frames > 1 a stream that did not fit its slice is reported per frame (out_len[f] > capacity), not through the return code
+        for f in range(n):
+            if lens[f] > self.max_size:
+                raise L.UgHipError(L.EINVAL, f"ug_hip_jpeg_encoder_encode_batch: the stream of frame {f} needs {lens[f]} bytes, its slice holds {self.max_size}")
         return [bytes(out[f, : lens[f]].cpu().numpy()) for f in range(n)]
 
     def close(self):

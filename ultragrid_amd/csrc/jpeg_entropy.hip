@@ -1648,7 +1648,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                                 e->slots = nullptr;
                                 e->slots_cap = 0;
                                 const size_t want = a.slot_bytes * (size_t) a.n_wg * (size_t) e->batch_cap;
-                                const hipError_t err = hipMalloc((void **) &e->slots, want);
+                                // + 8: the gather reads the stream in 8-byte words and may touch up to 7 bytes past byte n of a slot; a general-path workgroup
+                                // may fill its slot to the last byte, and the last slot of the last frame ends where the allocation would
+                                const hipError_t err = hipMalloc((void **) &e->slots, want + 8);
                                 if (err != hipSuccess) {
                                         (void) hipGetLastError();
                                         two_launch = false; // no room for the slots: the one-launch placement needs none
@@ -1717,6 +1719,11 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 (void) hipMemset(e->ticket, 0, 4);
                 if (!e->use_ticket) { // the start order was not the index order after all: from now on the index IS the start order; once more
                         e->use_ticket = true;
+                        // said once, loudly: the call that met it cost a spin-out (the waiting waves gave up after kSpinLimit polls) and is encoded again, and
+                        // every later call of this encoder takes the ticket form (measured ~8 % of the coder kernel); UG_JPEG_TICKET=1 starts that way
+                        fprintf(stderr, "[ug_mi355x] JPEG encoder %dx%d: a workgroup of the one-launch stream placement waited for a predecessor that had not been "
+                                        "dispatched (workgroups did not start in index order); this call is encoded again and the encoder uses start-order tickets "
+                                        "from now on (UG_JPEG_TICKET=1 selects that from the start)\n", e->width, e->height);
                         return ug_hip_jpeg_encoder_encode_batch(enc, in, frames, src_dev, src_pitch, src_stride, out_dev, out_stride, out_capacity, out_len, stream);
                 }
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: the stream placement gave up waiting for an earlier workgroup");

@@ -425,11 +425,14 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
         }, (unsigned) batch, make_batch, numa && bind_thread != nullptr ? std::function<void(int)>([bind_thread, numa_node](int dev) {
                 int cpus = 0, node = -1;
                 const int rc = bind_thread(dev, &cpus);
-                if (numa_node) (void) numa_node(dev, &node);
+                const int nrc = numa_node ? numa_node(dev, &node) : 0;
                 if (rc == 0 && cpus > 0) {
                         log_msg(LOG_LEVEL_VERBOSE, "[MI355X] worker of device %d runs on the %d CPUs of NUMA node %d (the GPU's)\n", dev, cpus, node);
+                } else if (rc != 0 || nrc != 0) { // the worker runs where the scheduler puts it: correct, possibly slower copies -- say so
+                        log_msg(LOG_LEVEL_WARNING, "[MI355X] worker of device %d could not be bound to the GPU's NUMA node (bind rc=%d, node query rc=%d); numa=0 silences this\n",
+                                dev, rc, nrc);
                 }
-                if (getenv("UG_MI355X_NUMA_REPORT")) { // test hook: where this worker thread may run now
+                if (getenv("UG_MI355X_NUMA_REPORT")) { // test hook: where this worker thread may run now; on stderr -- a host application's stdout may be a pipe it owns
                         std::string cpus_now;
                         cpu_set_t set;
                         if (sched_getaffinity(0, sizeof set, &set) == 0) {
@@ -437,8 +440,7 @@ inline void *sharded_init(struct module *parent, const char *cfg, tile_init_t ti
                                         if (CPU_ISSET(c, &set)) cpus_now += (cpus_now.empty() ? "" : ",") + std::to_string(c);
                                 }
                         }
-                        printf("NUMA worker dev=%d node=%d bound=%d rc=%d affinity=%s\n", dev, node, cpus, rc, cpus_now.c_str());
-                        fflush(stdout);
+                        fprintf(stderr, "NUMA worker dev=%d node=%d bound=%d rc=%d affinity=%s\n", dev, node, cpus, rc, cpus_now.c_str());
                 }
         }) : nullptr));
         return m;
