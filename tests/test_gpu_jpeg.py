@@ -572,3 +572,47 @@ def test_streams_equal_libjpeg_turbo_with_its_float_dct(hip, po):
                 e.close()
                 want = ljf.compress_planes(lj, y, u, v, w, h, sub, q, restart=ri)
                 assert ljf.scan_bytes(got) == ljf.scan_bytes(want), (sub, w, h, q, ri)
+
+
+@pytest.mark.gpu
+def test_streams_equal_the_frozen_libjpeg_turbo_fixture(hip, po):
+    """the libjpeg-turbo pin as a COMMITTED fixture (tests/golden/libjpeg_float.npz: what libjpeg-turbo 2.1.2 with JDCT_FLOAT
+    produced, generator beside it) -- compared ALWAYS, whether or not the library is in the image:
+      * ug_hip_jpeg_fdct_quant_plane's unquantised coefficients == jpeg_fdct_float's output BITS for all 512 committed blocks;
+      * its quantised coefficients of the grey planes, entropy-coded by the test writer == libjpeg-turbo's scan bytes;
+      * the encoder's streams for packed RGB (4:4:4) and UYVY (4:2:2, 4:2:0) carry libjpeg-turbo's scan bytes -- one-frame call and batch call.
+    Towards libgpujpeg (what UltraGrid links; unobtainable here) the stage stays "parity unpinned"."""
+    import torch
+
+    import jpeg_bitstream as jb
+    import libjpeg_float as ljf
+    from test_oracle_jpeg import libjpeg_fixture
+    g, meta = libjpeg_fixture()
+    blocks = g["fdct_blocks"]
+    plane = torch.from_numpy(np.ascontiguousarray(blocks.transpose(1, 0, 2).reshape(8, 512 * 8))).cuda()
+    div = torch.from_numpy(po.jpeg_divisors(po.jpeg_qtable(75, 0))).cuda()
+    _, coef = hip.jpeg_fdct_quant_plane(plane, div, want_coef=True)
+    assert np.array_equal(coef.cpu().numpy().reshape(512, 64).view(np.uint32), g["fdct_out"])
+    dcl, acl = jb._codes(*jb.DC_L), jb._codes(*jb.AC_L)
+    seen = {}
+    for j, c in enumerate(meta["cases"]):
+        src, w, h, q, ri = g["in_" + c["input"]], c["w"], c["h"], c["q"], c["ri"]
+        want = g[f"scan_{j}"].tobytes()
+        if c["kind"] == "grey":
+            d = torch.from_numpy(po.jpeg_divisors(po.jpeg_qtable(q, 0))).cuda()
+            out = hip.jpeg_fdct_quant_plane(torch.from_numpy(np.ascontiguousarray(src)).cuda(), d).cpu().numpy()
+            bw, pred = jb._Bits(), 0
+            for u in range(out.shape[0]):
+                pred = jb._block(bw, out[u], pred, dcl, acl)
+            bw.flush()
+            assert bytes(bw.buf) == want, c
+        else:
+            sub, pf = (444, hip.L.PF_RGB) if c["kind"] == "rgb" else (int(c["kind"]), hip.L.PF_UYVY)
+            dev = torch.from_numpy(np.ascontiguousarray(src).ravel()).cuda()
+            e = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+            assert ljf.scan_bytes(e.encode(dev, pf)) == want, c
+            two = e.encode_batch(torch.stack([dev, dev]), pf)
+            assert ljf.scan_bytes(two[0]) == want and two[1] == two[0], c
+            e.close()
+        seen[c["kind"]] = seen.get(c["kind"], 0) + 1
+    assert set(seen) == {"grey", "rgb", "422", "420"} and sum(seen.values()) >= 80, seen

@@ -201,3 +201,71 @@ def test_plane_to_scan_equals_libjpeg_turbo_float_pipeline(po):
             assert bytes(bw.buf) == ljf.scan_bytes(ljf.compress(lj, plane, q)), (seed, h, w, q)
             cases += 1
     assert cases == 240
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The same pin as a COMMITTED fixture: tests/golden/libjpeg_float.npz holds what libjpeg-turbo 2.1.2 produced
+# (tests/golden/make_libjpeg_golden.py), so the pin does not disappear with the library.  No skip on this path.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def libjpeg_fixture():
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "libjpeg_float.npz"))
+    meta = json.loads(str(g["meta"]))
+    return g, meta
+
+
+def oracle_scan(po, kind, src, w, h, q, ri):
+    """the entropy-coded bytes the test writer makes of the ORACLE's coefficients for one fixture case"""
+    import jpeg_bitstream as jb
+    import libjpeg_float as ljf
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    if kind == "grey":
+        coef = po.jpeg_fdct_quant_plane(np.ascontiguousarray(src), po.jpeg_divisors(ql))
+        dcl, acl = jb._codes(*jb.DC_L), jb._codes(*jb.AC_L)
+        bw, pred = jb._Bits(), 0
+        for u in range(coef.shape[0]):
+            pred = jb._block(bw, coef[u], pred, dcl, acl)
+        bw.flush()
+        return bytes(bw.buf)
+    if kind == "rgb":
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(src[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        return ljf.scan_bytes(jb.write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=444))
+    sub = int(kind)
+    mw = (w + 15) // 16
+    if sub == 420:
+        y, u, v = po.uyvy_to_i420(src.ravel(), w, h)
+        mh, vy = (h + 15) // 16, 2
+    else:
+        y, u, v = po.uyvy_to_i422(src.ravel(), w, h)
+        mh, vy = (h + 7) // 8, 1
+    return ljf.scan_bytes(jb.write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, vy * mh),
+                                        po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh), po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh),
+                                        restart=ri, sub=sub))
+
+
+def test_fdct_equals_the_frozen_ijg_float_dct(po):
+    """oracle FDCT == jpeg_fdct_float of libjpeg-turbo 2.1.2 as committed: the same BITS for all 512 blocks; the quality rule == jpeg_quality_scaling"""
+    g, meta = libjpeg_fixture()
+    assert "libjpeg-turbo" in meta["library"]
+    blocks, want = g["fdct_blocks"], g["fdct_out"]
+    plane = np.ascontiguousarray(blocks.transpose(1, 0, 2).reshape(8, 512 * 8))          # the blocks side by side: block b = columns 8b .. 8b+7
+    _, coef = po.jpeg_fdct_quant_plane(plane, po.jpeg_divisors(po.jpeg_qtable(75, 0)), want_coef=True)
+    assert coef.shape[0] == 512
+    assert np.array_equal(coef.reshape(512, 64).view(np.uint32), want)
+    k1, k2 = po.jpeg_qtable(50, 0).astype(np.int64), po.jpeg_qtable(50, 1).astype(np.int64)
+    for q in range(1, 101):
+        s = int(g["quality_scaling"][q - 1])
+        for comp, base in ((0, k1), (1, k2)):
+            assert np.array_equal(po.jpeg_qtable(q, comp), np.clip((base * s + 50) // 100, 1, 255)), (q, comp)
+
+
+def test_scans_equal_the_frozen_libjpeg_turbo_streams(po):
+    """every committed case -- grey planes, packed RGB 4:4:4, UYVY as 4:2:2 and 4:2:0; edge blocks, q = 100 on noise, restart intervals -- : the
+    oracle's coefficients, entropy-coded by the test writer, are libjpeg-turbo's bytes"""
+    g, meta = libjpeg_fixture()
+    kinds = set()
+    for j, c in enumerate(meta["cases"]):
+        got = oracle_scan(po, c["kind"], g["in_" + c["input"]], c["w"], c["h"], c["q"], c["ri"])
+        assert got == g[f"scan_{j}"].tobytes(), c
+        kinds.add(c["kind"])
+    assert kinds == {"grey", "rgb", "422", "420"} and len(meta["cases"]) >= 80
