@@ -19,6 +19,13 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
                   beside `value`, never as `value`;
   cpu_baseline -- the CPU oracle (oracle/dxt_oracle.c, "port": the reference has no CPU DXT encoder)
                   timed on this box's host cores on a bounded sample (rank 0, at every N).
+Additive keys of the default N = 1 line (`value` / `roofline` are computed exactly as before, and first):
+  parity_check -- frame 0 of the timed batch, as the timed kernel left it, compared byte for byte with oracle/dxt_oracle.c AFTER the timed region;
+  configs      -- the other BASELINE configurations under the same clock: ~1 s of timed launches each (HIP events on the launch stream) ->
+                  ms_per_launch, frac of 8 TB/s, launches_timed (the code paths of --workload);
+  e2e.latency_ms_depth1 -- one frame in flight: H2D + kernel + D2H of one frame, stage by stage, beside the depth-3 rates;
+  roofline.valu.frac_of_measured_peak -- the VALU rate against what a pure v_add_f32 stream issues on this chip (profiles/valu_microbench_mi355x.txt),
+                  next to the nominal 2 wave-instructions per clock and CU.
 """
 from __future__ import annotations
 
@@ -50,6 +57,9 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK = 256 * 2 * 2.4e9  # wave64 VALU instructions per second: 256 CUs x 4 SIMD-32 x one wave64 op per 2 cycles x 2.4 GHz
+# what the SIMDs deliver on a dependent-free stream of full-rate fp32 operations, measured (tools/valu_microbench.hip, profiles/valu_microbench_mi355x.txt:
+# v_add_f32 1.492, v_mul_f32 1.448, v_mov_b32 1.775 wave-instr/clk/CU; half-rate classes -- v_min3, v_cvt, v_perm, v_bfe, DPP -- 0.95-0.97)
+VALU_MEASURED_PEAK = 256 * 1.492 * 2.4e9
 
 
 def make_frames(n: int, rank: int, fmt: str = "UYVY", w: int = W, h: int = H) -> np.ndarray:
@@ -190,12 +200,156 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
         dist.barrier()
     if lp is not None:
         res["link_gbs_h2d"], res["link_gbs_d2h"], res["link_gbs_bidir_each"] = lp["h2d_gbs"], lp["d2h_gbs"], lp["bidir_each_gbs"]
+    # one frame in flight (VERDICT r4 next #2c): what a display-rate source waits for between handing a frame over and holding its compressed form
+    lat = {}
+    for wl in workloads:
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            try:
+                lat[wl] = pipeline.latency_depth1(wl, frames=24, salt=5)
+            except Exception as e:
+                print(f"bench.py: latency leg {wl} failed: {e}", file=sys.stderr, flush=True)
+    if dist is not None:
+        dist.barrier()
+    if lat:
+        res["latency_ms_depth1"] = lat
     res["path"] = ("pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU, all ranks concurrently; "
                    "one upload, one compute and one download stream with events between the stages of a frame (tools/e2e_bench.py --sweep: better than a stream per frame); copy_only_fps = the same copies without the kernel (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
     res["numa_node_rank0"] = node
     res["cpus_bound_rank0"] = bound
     if affinity is not None and bound:
         os.sched_setaffinity(0, affinity)   # the CPU baseline that follows is not meant to run on one NUMA node only
+    return res
+
+
+def setup_workload(name: str, frames: int, batches: int, rank: int) -> dict:
+    """B resident batches of F distinct frames of the workload in HBM and launch(b): one pass of its hot path over batch b on torch's current stream"""
+    from ultragrid_amd import codec, lib
+    stream_bytes, enc = [0], None
+    wl = WORKLOADS[name]
+    W, H = wl["w"], wl["h"]
+    ALG_BYTES_PER_PX = wl["bpp"]
+    F = frames or wl["frames"]
+    B = max(1, batches)
+    out_name = wl.get("out", "DXT5")
+    # B resident batches of F distinct frames: a few generated bases, the rest row-rotations made on the device
+    host = make_frames(min(F, 4 if W <= 3840 else 2), rank, wl["fmt"], W, H)
+    frame_bytes = host.shape[1]
+    ls = frame_bytes // H
+    bases = torch.from_numpy(host).cuda().view(host.shape[0], H, ls)
+    src = torch.empty((B, F, H, ls), dtype=torch.uint8, device="cuda")
+    for b in range(B):
+        for i in range(F):
+            k = b * F + i
+            src[b, i] = torch.roll(bases[k % bases.shape[0]], 4 * 37 * (k // bases.shape[0]), dims=0)
+    del bases
+    src = src.view(B, F * frame_bytes)
+    out_bytes = {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3, "JPEGENC": 16}[out_name]
+    dst = torch.empty((B, F * out_bytes), dtype=torch.uint8, device="cuda")
+    pf = lib.PF_NAMES[wl["fmt"]]
+    oid = lib.DXT5_YCOCG if out_name == "DXT5" else lib.DXT1
+
+    def launch(b: int):
+        codec.dxt_encode_batch(pf, oid, src[b], W, H, F, frame_bytes, dst=dst[b])
+
+    if out_name == "JPEG420":   # the JPEG front end: UYVY -> 4:2:0 (uyvy_to_i420 rounding) -> FDCT -> quantise, int16 coefficients out
+        div = codec.jpeg_divisors_device(75, "cuda")
+        mw, mh = (W + 15) // 16, (H + 15) // 16
+        nblk = mw * mh
+        oy = torch.empty((F, 4 * nblk, 64), dtype=torch.int16, device="cuda")
+        ocb, ocr = torch.empty((F, nblk, 64), dtype=torch.int16, device="cuda"), torch.empty((F, nblk, 64), dtype=torch.int16, device="cuda")
+        fn = lib.load().ug_hip_uyvy_to_jpeg42x_coeffs_batch
+
+        def launch(b: int):  # noqa: F811  (one launch over the F frames of the batch, grid.z = frame)
+            rc = fn(420, src[b].data_ptr(), 0, W, H, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), F, frame_bytes,
+                    4 * nblk * 128, nblk * 128, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.last_error()
+
+    if out_name == "JPEGENC":   # the whole JPEG encoder: F frames per (synchronous) call, streams into a per-batch buffer
+        import ctypes as C
+        l_ = lib.load()
+        enc = C.c_void_p()
+        assert l_.ug_hip_jpeg_encoder_create_sub(W, H, 75, 4, 420, C.byref(enc)) == 0, lib.last_error()
+        stride = (W * H + 4096 + 15) // 16 * 16          # a 4K q75 stream is ~1.5 MB; the capacity a caller would give a 4:2:0 frame of video
+        jout = torch.empty((B, F, stride), dtype=torch.uint8, device="cuda")
+        lens = (C.c_size_t * F)()
+
+        def launch(b: int):  # noqa: F811
+            rc = l_.ug_hip_jpeg_encoder_encode_batch(enc, pf, F, src[b].data_ptr(), 0, frame_bytes, jout[b].data_ptr(), stride, stride, lens,
+                                                     torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.last_error()
+            assert all(lens[f] <= stride for f in range(F)), "a stream did not fit its slice: the call would be timed on a truncated stream"
+            stream_bytes[0] = sum(lens[f] for f in range(F))
+
+    # (the device buffers a workload needs live as long as its launch closure does)
+    return dict(wl=wl, W=W, H=H, F=F, B=B, bpp=ALG_BYTES_PER_PX, out_name=out_name, frame_bytes=frame_bytes, out_bytes=out_bytes, launch=launch,
+                stream_bytes=stream_bytes, host=host, src=src, dst=dst, enc=enc)
+
+
+def time_launches(launch, B: int, seconds: float) -> tuple:
+    """~0.2 s of launches to reach steady clocks, then `seconds` of back-to-back launches between two HIP events on the launch stream
+    (torch's current stream): (average ms per launch, launches timed)"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:
+        for i in range(4 * B):
+            launch(i % B)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(8 * B):
+        launch(i % B)
+    e1.record()
+    torch.cuda.synchronize()
+    n = max(B, int(seconds * 1e3 / max(e0.elapsed_time(e1) / (8 * B), 1e-3)) // B * B)
+    e0.record()
+    for i in range(n):
+        launch(i % B)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, n
+
+
+def parity_check(ws: dict) -> dict:
+    """frame 0 of batch 0 as the timed kernel left it in its output buffer, against oracle/dxt_oracle.c on the same input bytes (the checker, after the
+    timed region; DXT workloads)"""
+    from oracle import pyoracle as po
+    W, H, fmt = ws["W"], ws["H"], ws["wl"]["fmt"]
+    torch.cuda.synchronize()
+    src0 = ws["src"][0][: ws["frame_bytes"]].cpu().numpy()
+    got = ws["dst"][0][: ws["out_bytes"]].cpu().numpy()
+    pin = {"UYVY": po.IN_UYVY, "v210": po.IN_V210, "RGB": po.IN_RGB}[fmt]
+    pout = po.OUT_DXT5YCOCG if ws["out_name"] == "DXT5" else po.OUT_DXT1
+    t0 = time.perf_counter()
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    want = po.dxt_encode(pin, pout, src0, W, H, threads=min(ncpu, 16))
+    return {"frames": 1, "bytes_compared": int(want.size), "bytes_differing": int(np.count_nonzero(got != want)) if got.size == want.size else int(max(got.size, want.size)),
+            "checker": "oracle/dxt_oracle.c (dxt_encode) on frame 0 of resident batch 0, output of the last timed launch over that batch", "cpu_s": round(time.perf_counter() - t0, 3)}
+
+
+def other_configs(rank: int, seconds: float) -> dict:
+    """the BASELINE configurations that are not this line's `value`, each through its --workload code path for ~`seconds` of timed launches"""
+    res = {}
+    for name in ("1080p-rgb-dxt1", "4k-uyvy-jpeg420", "4k-uyvy-jpeg-encode", "8k-v210"):
+        ws = setup_workload(name, 0, 4, rank)
+        for b in range(ws["B"]):
+            ws["launch"](b)
+        torch.cuda.synchronize()
+        ms, n = time_launches(ws["launch"], ws["B"], seconds)
+        px = ws["F"] * ws["W"] * ws["H"]
+        alg = ws["bpp"] * px if ws["out_name"] != "JPEGENC" else 2 * px + ws["stream_bytes"][0]
+        res[name] = {"workload": ws["wl"]["name"], "frames_per_launch": ws["F"], "ms_per_launch": round(ms, 5), "launches_timed": n,
+                     "algorithmic_bytes_per_launch": int(alg), "achieved_gbs": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "mpixels_per_s": round(px / (ms * 1e-3) / 1e6, 1), "fps": round(ws["F"] / (ms * 1e-3), 1)}
+        if ws["out_name"] in ("DXT5", "DXT1"):
+            res[name]["parity_check"] = parity_check(ws)
+        if ws["out_name"] == "JPEGENC":
+            res[name]["note"] = "the whole encoder per (synchronous) call of 8 frames; the FDCT / quantiser stage is unpinned towards libgpujpeg (pinned to libjpeg-turbo's float DCT)"
+            from ultragrid_amd import lib
+            lib.load().ug_hip_jpeg_encoder_destroy(ws["enc"])
+        del ws
+        torch.cuda.empty_cache()
     return res
 
 
@@ -211,6 +365,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--e2e-seconds", type=float, default=2.0)
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` leg (the other BASELINE configurations, ~1 s of timed launches each; default N = 1 line only)")
+    ap.add_argument("--configs-seconds", type=float, default=1.0)
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of frame 0 after the timed region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU smoke test of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="smoke test only: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (RCCL) at world size 1 too, so that the barrier, "
@@ -254,61 +411,9 @@ def main() -> None:
     from ultragrid_amd import codec, lib
     lib.load()
 
-    wl = WORKLOADS[args.workload]
-    W, H = wl["w"], wl["h"]
-    ALG_BYTES_PER_PX = wl["bpp"]
-    F = args.frames or wl["frames"]
-    B = max(1, args.batches)
-    out_name = wl.get("out", "DXT5")
-    # B resident batches of F distinct frames: a few generated bases, the rest row-rotations made on the device
-    host = make_frames(min(F, 4 if W <= 3840 else 2), rank, wl["fmt"], W, H)
-    frame_bytes = host.shape[1]
-    ls = frame_bytes // H
-    bases = torch.from_numpy(host).cuda().view(host.shape[0], H, ls)
-    src = torch.empty((B, F, H, ls), dtype=torch.uint8, device="cuda")
-    for b in range(B):
-        for i in range(F):
-            k = b * F + i
-            src[b, i] = torch.roll(bases[k % bases.shape[0]], 4 * 37 * (k // bases.shape[0]), dims=0)
-    del bases
-    src = src.view(B, F * frame_bytes)
-    out_bytes = {"DXT5": W * H, "DXT1": W * H // 2, "JPEG420": W * H * 3, "JPEGENC": 16}[out_name]
-    dst = torch.empty((B, F * out_bytes), dtype=torch.uint8, device="cuda")
-    pf = lib.PF_NAMES[wl["fmt"]]
-    oid = lib.DXT5_YCOCG if out_name == "DXT5" else lib.DXT1
-
-    def launch(b: int):
-        codec.dxt_encode_batch(pf, oid, src[b], W, H, F, frame_bytes, dst=dst[b])
-
-    if out_name == "JPEG420":   # the JPEG front end: UYVY -> 4:2:0 (uyvy_to_i420 rounding) -> FDCT -> quantise, int16 coefficients out
-        div = codec.jpeg_divisors_device(75, "cuda")
-        mw, mh = (W + 15) // 16, (H + 15) // 16
-        nblk = mw * mh
-        oy = torch.empty((F, 4 * nblk, 64), dtype=torch.int16, device="cuda")
-        ocb, ocr = torch.empty((F, nblk, 64), dtype=torch.int16, device="cuda"), torch.empty((F, nblk, 64), dtype=torch.int16, device="cuda")
-        fn = lib.load().ug_hip_uyvy_to_jpeg42x_coeffs_batch
-
-        def launch(b: int):  # noqa: F811  (one launch over the F frames of the batch, grid.z = frame)
-            rc = fn(420, src[b].data_ptr(), 0, W, H, div.data_ptr(), oy.data_ptr(), ocb.data_ptr(), ocr.data_ptr(), F, frame_bytes,
-                    4 * nblk * 128, nblk * 128, torch.cuda.current_stream().cuda_stream)
-            assert rc == 0, lib.last_error()
-
-    if out_name == "JPEGENC":   # the whole JPEG encoder: F frames per (synchronous) call, streams into a per-batch buffer
-        import ctypes as C
-        l_ = lib.load()
-        enc = C.c_void_p()
-        assert l_.ug_hip_jpeg_encoder_create_sub(W, H, 75, 4, 420, C.byref(enc)) == 0, lib.last_error()
-        stride = (W * H + 4096 + 15) // 16 * 16          # a 4K q75 stream is ~1.5 MB; the capacity a caller would give a 4:2:0 frame of video
-        jout = torch.empty((B, F, stride), dtype=torch.uint8, device="cuda")
-        lens = (C.c_size_t * F)()
-        stream_bytes = [0]
-
-        def launch(b: int):  # noqa: F811
-            rc = l_.ug_hip_jpeg_encoder_encode_batch(enc, pf, F, src[b].data_ptr(), 0, frame_bytes, jout[b].data_ptr(), stride, stride, lens,
-                                                     torch.cuda.current_stream().cuda_stream)
-            assert rc == 0, lib.last_error()
-            assert all(lens[f] <= stride for f in range(F)), "a stream did not fit its slice: the call would be timed on a truncated stream"
-            stream_bytes[0] = sum(lens[f] for f in range(F))
+    ws = setup_workload(args.workload, args.frames, args.batches, rank)
+    wl, W, H, F, B, ALG_BYTES_PER_PX = ws["wl"], ws["W"], ws["H"], ws["F"], ws["B"], ws["bpp"]
+    out_name, frame_bytes, out_bytes, launch, stream_bytes, host = ws["out_name"], ws["frame_bytes"], ws["out_bytes"], ws["launch"], ws["stream_bytes"], ws["host"]
 
     # calibrate the launches of a step: >= 50 ms of GPU work per step, so that box noise averages out and gpu_busy registers
     for b in range(B):
@@ -356,9 +461,19 @@ def main() -> None:
     wall = shard.timed_steps(timed_step, args.steps, torch.cuda.synchronize, dist, device=coll_dev)
     kern_ms = ev0.elapsed_time(ev1) / (args.steps * L)   # average launch duration (back-to-back launches on one stream)
 
+    # ---- additive legs, all after the timed region ----
+    parity = None
+    if rank == 0 and not args.no_parity_check and out_name in ("DXT5", "DXT1"):
+        parity = parity_check(ws)
+    ws.clear()
+    launch = None   # (with it go the resident batches: the closure held them)
+    torch.cuda.empty_cache()
+    configs = None
+    if world == 1 and not args.no_configs and args.workload == "4k-uyvy":   # the default N = 1 line only: at N > 1 nothing is added to what the ranks wait for
+        configs = other_configs(rank, args.configs_seconds)
+
     e2e = None
     if not args.no_e2e and out_name in ("DXT5", "DXT1"):
-        del src, dst
         torch.cuda.empty_cache()
         # 8k-uyvy = the north star's literal target configuration (>= 60 fps 8K UYVY -> DXT5-YCoCg on one MI355X)
         e2e = e2e_leg(["8k-uyvy", "8k-v210", "4k-uyvy"], rank, dist, coll_dev, args.e2e_seconds)
@@ -412,6 +527,10 @@ def main() -> None:
                 rate = ipw * waves / (kern_ms * 1e-3)
                 roof["valu"]["wave_instr_per_s"] = round(rate, 0)
                 roof["valu_frac"] = round(rate / VALU_PEAK, 4)
+                roof["valu"]["measured_peak_wave_instr_per_s"] = VALU_MEASURED_PEAK
+                roof["valu"]["measured_peak_def"] = ("256 CU x 1.492 wave64 v_add_f32 / clk / CU x 2.4 GHz: what a dependent-free full-rate fp32 stream issues on this chip "
+                                                     "(profiles/valu_microbench_mi355x.txt; half-rate classes issue 0.95-0.97)")
+                roof["valu"]["frac_of_measured_peak"] = round(rate / VALU_MEASURED_PEAK, 4)
             ratio = f"{pmc['traffic'] / (ALG_BYTES_PER_PX * px_per_launch):.3f}x" if pmc.get("traffic") else "not measured for this workload"
             roof["note"] = ("VALU-issue-bound kernel: the bit-exactness contract (every shader operation one separately rounded fp32 operation, no FMA) "
                             f"fixes ~65 VALU instructions per pixel against 3 B/px; HBM traffic / algorithmic bytes = {ratio} (DESIGN.md 4.1)")
@@ -435,6 +554,10 @@ def main() -> None:
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": roof,
         }
+        if parity is not None:
+            out["parity_check"] = parity
+        if configs is not None:
+            out["configs"] = configs
         if e2e is not None:
             out["e2e"] = e2e
         if dist is not None:

@@ -22,9 +22,23 @@ def _line(out):
 
 def test_single_gpu_line(hip):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--launches-per-step", "8", "--e2e-seconds", "0.3",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--configs-seconds", "0.25", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     d = _line(r.stdout)
+    # the additive keys of round 5: an in-run oracle check of the timed kernel's output, every other BASELINE configuration
+    # under the same clock, one-frame-in-flight latency, the VALU rate against the measured issue peak
+    assert d["parity_check"] == dict(d["parity_check"], frames=1, bytes_compared=3840 * 2160, bytes_differing=0)
+    assert set(d["configs"]) == {"1080p-rgb-dxt1", "4k-uyvy-jpeg420", "4k-uyvy-jpeg-encode", "8k-v210"}
+    for name, c in d["configs"].items():
+        assert c["ms_per_launch"] > 0 and c["launches_timed"] >= 4 and 0.05 < c["frac"] < 1, (name, c)
+        assert abs(c["algorithmic_bytes_per_launch"] / (c["ms_per_launch"] * 1e-3) / 1e9 / 8000.0 - c["frac"]) < 2e-3
+    assert d["configs"]["1080p-rgb-dxt1"]["parity_check"]["bytes_differing"] == 0 and d["configs"]["8k-v210"]["parity_check"]["bytes_differing"] == 0
+    assert d["configs"]["8k-v210"]["parity_check"]["bytes_compared"] == 7680 * 4320
+    lat = d["e2e"]["latency_ms_depth1"]
+    assert set(lat) == {"8k-uyvy", "8k-v210", "4k-uyvy"}
+    for name, v in lat.items():
+        assert v["ms"] >= max(v["h2d_ms"], v["d2h_ms"]) and v["ms"] < 16.7 and v["kernel_ms"] < v["h2d_ms"], (name, v)   # one frame period at 60 fps is 16.7 ms
+    assert 0 < d["roofline"]["valu_frac"] < d["roofline"]["valu"]["frac_of_measured_peak"] < 1.05
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert "configs[2]" in d["config"]["workload"] and d["config"]["launches_per_step"] == 8
     roof = d["roofline"]

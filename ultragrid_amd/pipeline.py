@@ -132,6 +132,41 @@ def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_fra
             "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len}
 
 
+def latency_depth1(workload: str = "8k-v210", frames: int = 24, salt: int = 0) -> dict:
+    """ONE frame in flight, as a display-rate source drives the module: pinned host frame -> H2D -> fused kernel -> D2H -> synchronise, then the
+    next frame.  Returns the median wall-clock per frame (submit to synchronised, what the caller waits) and the three stages as HIP events on the
+    frame's stream see them, plus what serial and perfectly overlapped copies would take at the rates the stages themselves ran at."""
+    fmt, pf, oid, w, h = WORKLOADS[workload]
+    lib.load()
+    srcs = [torch.from_numpy(host_frame(workload, salt + i)).pin_memory() for i in range(2)]
+    in_len, out_len = srcs[0].numel(), codec.dxt_size(oid, w, h)
+    dev_in, dev_out = torch.empty(in_len, dtype=torch.uint8, device="cuda"), torch.empty(out_len, dtype=torch.uint8, device="cuda")
+    host_out = torch.empty(out_len, dtype=torch.uint8).pin_memory()
+    st = torch.cuda.Stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    wall, stages = [], []
+    for i in range(frames + 3):
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st):
+            ev[0].record()
+            dev_in.copy_(srcs[i % 2], non_blocking=True)
+            ev[1].record()
+            codec.dxt_encode(pf, oid, dev_in, w, h, dst=dev_out)
+            ev[2].record()
+            host_out.copy_(dev_out, non_blocking=True)
+            ev[3].record()
+        st.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        if i >= 3:   # the first frames page things in
+            wall.append(dt)
+            stages.append([ev[k].elapsed_time(ev[k + 1]) for k in range(3)])
+    med = lambda v: float(np.median(v))  # noqa: E731
+    h2d, kern, d2h = (med([s[k] for s in stages]) for k in range(3))
+    return {"ms": round(med(wall), 3), "h2d_ms": round(h2d, 3), "kernel_ms": round(kern, 3), "d2h_ms": round(d2h, 3), "frames": frames,
+            "bytes_in": in_len, "bytes_out": out_len, "h2d_gbs": round(in_len / h2d / 1e6, 1), "d2h_gbs": round(out_len / d2h / 1e6, 1),
+            "over_longer_copy": round(med(wall) / max(h2d, d2h), 3)}
+
+
 def link_probe(nbytes: int = 64 << 20, seconds: float = 1.0, streams: int = 2) -> dict:
     """What the host link of THIS box gives, pure copies between pinned (first-touched after NUMA binding) and device memory:
     H2D only, D2H only, and both directions at once, `streams` copies in flight per direction."""
