@@ -400,8 +400,9 @@ def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypat
                 continue                # (beyond the 32 MCUs of a 4:2:x workgroup: the two-kernel path, covered by the other tests)
             out = {}
             for tag, env in (("fused", {}), ("two", {"UG_JPEG_FUSED": "0"}), ("wave", {"UG_JPEG_WAVE_KERNEL": "1"}),
-                             ("look", {"UG_JPEG_LOOKBACK": "1"}), ("twolook", {"UG_JPEG_FUSED": "0", "UG_JPEG_LOOKBACK": "1"}), ("ticket", {"UG_JPEG_LOOKBACK": "1", "UG_JPEG_TICKET": "1"}), ("force", {"UG_JPEG_LOOKBACK": "0"})):
-                for k in ("UG_JPEG_FUSED", "UG_JPEG_WAVE_KERNEL", "UG_JPEG_LOOKBACK", "UG_JPEG_TICKET"):
+                             ("look", {"UG_JPEG_LOOKBACK": "1"}), ("twolook", {"UG_JPEG_FUSED": "0", "UG_JPEG_LOOKBACK": "1"}), ("ticket", {"UG_JPEG_LOOKBACK": "1", "UG_JPEG_TICKET": "1"}), ("force", {"UG_JPEG_LOOKBACK": "0"}),
+                             ("flat", {"UG_JPEG_FLAT": "1"}), ("flat0", {"UG_JPEG_FLAT": "0"}), ("flatticket", {"UG_JPEG_FLAT": "1", "UG_JPEG_TICKET": "1"}), ("flattwo", {"UG_JPEG_FLAT": "1", "UG_JPEG_FUSED": "0"})):
+                for k in ("UG_JPEG_FUSED", "UG_JPEG_WAVE_KERNEL", "UG_JPEG_LOOKBACK", "UG_JPEG_TICKET", "UG_JPEG_FLAT"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -414,9 +415,10 @@ def test_fused_encoder_equals_the_two_kernel_paths(hip, po, sub, dims, monkeypat
             # the placement in one launch (decoupled look-back; the default for one-frame calls, UG_JPEG_LOOKBACK=1 for all) -- what the two-launch
             # placement (slots + gather; the default from two frames up, UG_JPEG_LOOKBACK=0 for all) falls back to when a workgroup's bytes exceed
             # its slot --, with the workgroup index from blockIdx and from a start-order ticket
-            for tag in ("look", "look2", "twolook", "twolook2", "ticket", "ticket2", "force", "force2"):
+            # round 5: the flat form of the one-launch placement for one-frame calls (every workgroup sums all its predecessors' byte counts itself)
+            for tag in ("look", "look2", "twolook", "twolook2", "ticket", "ticket2", "force", "force2", "flat", "flat2", "flat0", "flatticket", "flattwo"):
                 assert out[tag] == out["wave"], (tag, sub, dims, q, ri)
-    for k in ("UG_JPEG_FUSED", "UG_JPEG_WAVE_KERNEL", "UG_JPEG_LOOKBACK", "UG_JPEG_TICKET"):
+    for k in ("UG_JPEG_FUSED", "UG_JPEG_WAVE_KERNEL", "UG_JPEG_LOOKBACK", "UG_JPEG_TICKET", "UG_JPEG_FLAT"):
         monkeypatch.delenv(k, raising=False)
 
 
@@ -441,6 +443,26 @@ def test_block_parallel_coder_full_4k_frame(hip, po):
         del os.environ["UG_JPEG_WAVE_KERNEL"]
     assert da == db
     assert Image.open(io.BytesIO(da)).size == (w, h)
+    for flat in ("1", "0"):                       # round 5: both forms of the one-launch placement at the size they were built for (1 013 workgroups), 8K too
+        os.environ["UG_JPEG_FLAT"] = flat
+        try:
+            c = hip.JpegEncoder(w, h, 75, 4)
+            assert [c.encode(dev) for _ in range(3)] == [da] * 3, flat
+            c.close()
+        finally:
+            del os.environ["UG_JPEG_FLAT"]
+    w8, h8 = 7680, 4320
+    dev8 = torch.from_numpy(synth.s2_video("UYVY", w8, h8)).cuda()
+    outs = []
+    for flat in ("1", "0"):
+        os.environ["UG_JPEG_FLAT"] = flat
+        try:
+            c = hip.JpegEncoder(w8, h8, 75, 4, subsampling=422)
+            outs.append(c.encode(dev8))
+            c.close()
+        finally:
+            del os.environ["UG_JPEG_FLAT"]
+    assert outs[0] == outs[1] and Image.open(io.BytesIO(outs[0])).size == (w8, h8)
 
 
 @pytest.mark.parametrize("sub,fmt,ri", [(420, "UYVY", 4), (422, "UYVY", 4), (422, "UYVY", 40), (444, "RGB", 8), (420, "I420", 2)])

@@ -29,6 +29,7 @@ from ultragrid_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 SUPP = os.path.join(ROOT, "ultragrid_amd", "module", "tsan_reference.supp")
+SUPP_GPU = os.path.join(ROOT, "ultragrid_amd", "module", "tsan_gpu.supp")
 HDR = struct.Struct("<4s7I16s")
 
 
@@ -327,7 +328,7 @@ def _real_binaries():
 REAL_SAN_ENV = {
     REAL: {},
     "ug_runtime_harness_asan": {"ASAN_OPTIONS": "detect_leaks=0 exitcode=66 protect_shadow_gap=0", "UBSAN_OPTIONS": "print_stacktrace=1 halt_on_error=1"},
-    "ug_runtime_harness_tsan": {"TSAN_OPTIONS": f"halt_on_error=1 exitcode=66 suppressions={SUPP}"},
+    "ug_runtime_harness_tsan": {"TSAN_OPTIONS": f"halt_on_error=1 exitcode=66 suppressions={SUPP_GPU}"},
 }
 
 

@@ -503,6 +503,50 @@ __device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *statu
         return excl;
 }
 
+// The flat form, for one-frame calls (round 5).  All workgroups of one frame are resident at once (a 4K 4:2:0 frame: 1 013 workgroups, the chip
+// holds 1 536) and finish coding within a few microseconds of each other, so with the windowed walk above the LAST workgroups resolve their prefix
+// window after window -- up to n_wg / 64 = 16 dependent memory round trips (measured with UG_JPEG_PROF: 11.4 k clocks of waiting per workgroup on
+// average at one frame per call against 0.4 k at eight).  Here nobody publishes an inclusive prefix: every workgroup leaves its own byte count and sums
+// ALL its predecessors' counts itself, 64 * U words per round with the U loads of a lane in flight together -- two rounds for the last workgroup of
+// a 4K frame instead of sixteen; n_wg^2 / 2 eight-byte loads per frame (4 MB at 4K), all of them L2 hits.
+template <int U>
+__device__ __forceinline__ uint32_t lookback_exclusive_flat(unsigned long long *status, int wg, uint32_t aggregate, uint32_t gen, int lane, uint32_t *stuck) // one wave
+{
+        if (lane == 0) __hip_atomic_store(&status[wg], status_word(gen, 1, aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t sum = 0;
+        for (int base = 0; base < wg; base += 64 * U) {
+                unsigned long long s[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                        const int idx = base + 64 * u + lane;
+                        s[u] = idx < wg ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : status_word(gen, 1, 0);
+                }
+                for (int polls = 0;; polls++) {
+                        bool missing = false;
+#pragma unroll
+                        for (int u = 0; u < U; u++) missing = missing || (uint32_t) (s[u] >> 34) != gen || ((uint32_t) (s[u] >> 32) & 3u) == 0u;
+                        if (__ballot(missing) == 0) break;
+                        if (polls == kSpinLimit) {
+                                if (lane == 0) *stuck = 1u;
+                                break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                                const int idx = base + 64 * u + lane;
+                                if ((uint32_t) (s[u] >> 34) != gen || ((uint32_t) (s[u] >> 32) & 3u) == 0u) {
+                                        s[u] = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                        if ((uint32_t) (s[u] >> 34) == gen && ((uint32_t) (s[u] >> 32) & 3u) != 0u) sum += (uint32_t) s[u];
+                }
+        }
+        return (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan((int) sum, lane), 63);
+}
+
 struct CodeArgs {
         // scan geometry
         int mcu_w, n_mcu, hs, vs, ctab, ri, n_seg, S /* blocks per full segment */, G /* segments per workgroup (SRC = 0) */, n_wg /* workgroups per frame */;
@@ -523,6 +567,7 @@ struct CodeArgs {
         long n_status;
         uint32_t gen;
         uint32_t *ticket;               // workgroups take their index from here, in the order they start (0 before and after every launch)
+        int flat;                       // one-launch placement: 1 = every workgroup sums all its predecessors' byte counts itself (lookback_exclusive_flat; one-frame calls)
         // two-launch placement (the default): the workgroup leaves its finished bytes in a slot of its own and its byte count in wg_bytes; the gather
         // launch behind it moves the stretches to their places.  slots == NULL: one launch, the position comes from the look-back (status, gen)
         uint8_t *slots;
@@ -995,7 +1040,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                         if ((size_t) carry > a.slot_bytes) a.total_pinned[kMaxBatch + 1] = 1u; // does not fit its slot: the host runs the call again, with the look-back
                                 }
                         } else {
-                                const uint32_t before = lookback_exclusive(a.status + (long) frame * a.n_status, wg, carry, a.gen, lane, a.total_pinned + kMaxBatch);
+                                const uint32_t before = a.flat ? lookback_exclusive_flat<8>(a.status + (long) frame * a.n_status, wg, carry, a.gen, lane, a.total_pinned + kMaxBatch)
+                                                               : lookback_exclusive(a.status + (long) frame * a.n_status, wg, carry, a.gen, lane, a.total_pinned + kMaxBatch);
                                 if (lane == 0) lds_base = (uint32_t) a.header_len + before;
                         }
                 }
@@ -1112,7 +1158,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                         }
                 } else {
                         if (wv == 0) {
-                                const uint32_t before = lookback_exclusive(a.status + (long) frame * a.n_status, wg, stretch, a.gen, lane, a.total_pinned + kMaxBatch);
+                                const uint32_t before = a.flat ? lookback_exclusive_flat<8>(a.status + (long) frame * a.n_status, wg, stretch, a.gen, lane, a.total_pinned + kMaxBatch)
+                                                               : lookback_exclusive(a.status + (long) frame * a.n_status, wg, stretch, a.gen, lane, a.total_pinned + kMaxBatch);
                                 if (lane == 0) lds_base = (uint32_t) a.header_len + before;
                         }
                         __syncthreads();
@@ -1305,6 +1352,7 @@ struct Encoder {
         bool force_two_launch;  // UG_JPEG_LOOKBACK=0: the two-launch placement for one-frame calls too (tests: every path with every input)
         unsigned long long *prof; // UG_JPEG_PROF=1: phase clock sums of the placing coder (device memory, kProfPhases + 1 words)
         bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
+        bool flat_lookback;     // one-frame calls: the flat form of the look-back (the default; UG_JPEG_FLAT=0 switches back to the windowed walk for A/B)
         uint8_t *header_dev;
         uint32_t *total_host; // pinned, mapped
         uint32_t *total_host_dev; // the same word as the device sees it
@@ -1465,6 +1513,7 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         e->force_wave_kernel = getenv("UG_JPEG_WAVE_KERNEL") != nullptr && getenv("UG_JPEG_WAVE_KERNEL")[0] == '1';
         e->allow_fused = !(getenv("UG_JPEG_FUSED") != nullptr && getenv("UG_JPEG_FUSED")[0] == '0');
         e->use_ticket = getenv("UG_JPEG_TICKET") != nullptr && getenv("UG_JPEG_TICKET")[0] == '1';
+        e->flat_lookback = !(getenv("UG_JPEG_FLAT") != nullptr && getenv("UG_JPEG_FLAT")[0] == '0'); // the default since round 5 (profiles/r05_jpeg_one_frame.txt)
         e->two_launch = !(getenv("UG_JPEG_LOOKBACK") != nullptr && getenv("UG_JPEG_LOOKBACK")[0] == '1');
         e->force_two_launch = getenv("UG_JPEG_LOOKBACK") != nullptr && getenv("UG_JPEG_LOOKBACK")[0] == '0';
         e->sub = subsampling;
@@ -1611,6 +1660,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.width = w; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
                 a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
+                a.flat = frames == 1 && e->flat_lookback ? 1 : 0;
                 // divisions by S, blocks per MCU and MCUs per row as multiplications, where the ranges allow (CodeArgs)
                 {
                         const int per_mcu = e->hs * e->vs + 2;
