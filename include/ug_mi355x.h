@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define UG_HIP_ABI_VERSION 3 /* 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions), and ONE
+#define UG_HIP_ABI_VERSION 4 /* 4: ug_hip_{upload,download}_ordered_ex (additions only); 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions), and ONE
                               * change of behaviour: ug_hip_jpeg_encoder_encode_batch with frames > 1 reports a stream that does not fit its slice through
                               * out_len[f] > out_capacity and returns success for the call (it used to fail the whole call with UG_HIP_EINVAL) */
 
@@ -109,6 +109,17 @@ int         ug_hip_memset_async(void *dst_dev, int value, size_t count, ug_hip_s
  * ug_hip_stream_sync(after_stream) also waits for it.  The calling thread's current device must be `device`. */
 int         ug_hip_upload_ordered(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream);
 int         ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream);
+/* The same with one half of the ordering left to the caller -- what a frame cut into row bands needs (module option bands=<k>: upload of band k+1,
+ * kernels of band k and download of band k-1 at the same time, inside ONE frame; the tile fan-out of video_compress.cpp:441-490 is the reference's
+ * only intra-frame parallelism):
+ *   UG_HIP_COPY_NO_WAIT  upload: the lane does NOT wait for what `then_stream` holds (the caller knows the destination is not in use any more, e.g. the
+ *                        next band of a frame whose first band's upload did wait); `then_stream` still continues after the copy
+ *   UG_HIP_COPY_NO_JOIN  download: `after_stream` does NOT wait for the copy (its later kernels run beside it); the lane is in order, so a later
+ *                        download on the same device WITHOUT this flag makes ug_hip_stream_sync(after_stream) wait for this one too */
+#define UG_HIP_COPY_NO_WAIT 1
+#define UG_HIP_COPY_NO_JOIN 2
+int         ug_hip_upload_ordered_ex(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream, int flags);
+int         ug_hip_download_ordered_ex(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream, int flags);
 int         ug_hip_stream_create(ug_hip_stream_t *stream);
 int         ug_hip_stream_destroy(ug_hip_stream_t stream);
 int         ug_hip_stream_sync(ug_hip_stream_t stream);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     l = lib.load()  # raises if the .so or a symbol is missing
     for name in _declared():
         assert getattr(l, name) is not None
-    assert l.ug_hip_abi_version() == 3
+    assert l.ug_hip_abi_version() == 4
 
 
 def test_no_torch_or_cxx_types_in_the_abi():

@@ -21,7 +21,7 @@ for step in "$@"; do
     tests:*)  timeout 1800 python -m pytest tests -m gpu -q --maxfail=20 -k "${step#tests:}" 2>&1 | tail -40 > $OUT/pytest_k.log; tail -15 $OUT/pytest_k.log ;;
     runtime)
       timeout 1500 python -m pytest tests/test_runtime_conventions.py -q --maxfail=20 2>&1 | tail -40 > $OUT/runtime_plain.log; tail -5 $OUT/runtime_plain.log
-      UG_RT_SANITIZED_GPU=1 timeout 1500 python -m pytest tests/test_runtime_conventions.py -m gpu -q -k "asan or tsan" --maxfail=40 2>&1 | tail -120 > $OUT/runtime_sanitized.log; tail -8 $OUT/runtime_sanitized.log ;;
+      timeout 1500 python -m pytest tests/test_runtime_conventions.py -m gpu -q -k "asan or tsan" --maxfail=40 2>&1 | tail -120 > $OUT/runtime_sanitized.log; tail -8 $OUT/runtime_sanitized.log ;;
     bench)    python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench_line.json; tail -3 $OUT/bench.err ;;
     bench:*)  wl=${step#bench:}; python bench.py --workload $wl --no-e2e > $OUT/bench_$wl.json 2>> $OUT/bench.err; cut -c1-300 $OUT/bench_$wl.json ;;
     trace)

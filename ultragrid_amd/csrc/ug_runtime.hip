@@ -203,26 +203,48 @@ hipError_t chain(int device, int which, hipStream_t from, hipStream_t to)
 }
 } // namespace
 
-int ug_hip_upload_ordered(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream)
+int ug_hip_upload_ordered_ex(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream, int flags)
 {
+        if (flags & ~UG_HIP_COPY_NO_WAIT) {
+                ug::set_last_error_msg("ug_hip_upload_ordered_ex: unknown flag");
+                return UG_HIP_EINVAL;
+        }
         if (!lanes_enabled()) return ug_hip_memcpy_async(dst_dev, src, count, kind, then_stream);
         Lanes l;
         UG_HIP_TRY(lanes_of(device, l));
-        UG_HIP_TRY(chain(device, 0, (hipStream_t) then_stream, l.up)); // the destination may still be read by what the caller queued before (its previous frame)
+        if (!(flags & UG_HIP_COPY_NO_WAIT)) {
+                UG_HIP_TRY(chain(device, 0, (hipStream_t) then_stream, l.up)); // the destination may still be read by what the caller queued before (its previous frame)
+        }
         UG_HIP_TRY(hipMemcpyAsync(dst_dev, src, count, kind_of(kind), l.up));
         UG_HIP_TRY(chain(device, 1, l.up, (hipStream_t) then_stream));
         return UG_HIP_SUCCESS;
 }
 
-int ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream)
+int ug_hip_upload_ordered(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream)
 {
+        return ug_hip_upload_ordered_ex(device, dst_dev, src, count, kind, then_stream, 0);
+}
+
+int ug_hip_download_ordered_ex(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream, int flags)
+{
+        if (flags & ~UG_HIP_COPY_NO_JOIN) {
+                ug::set_last_error_msg("ug_hip_download_ordered_ex: unknown flag");
+                return UG_HIP_EINVAL;
+        }
         if (!lanes_enabled()) return ug_hip_memcpy_async(dst_host, src_dev, count, UG_HIP_MEMCPY_DEVICE_TO_HOST, after_stream);
         Lanes l;
         UG_HIP_TRY(lanes_of(device, l));
         UG_HIP_TRY(chain(device, 0, (hipStream_t) after_stream, l.down));
         UG_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, count, hipMemcpyDeviceToHost, l.down));
-        UG_HIP_TRY(chain(device, 1, l.down, (hipStream_t) after_stream)); // ug_hip_stream_sync(after_stream) now also waits for the download
+        if (!(flags & UG_HIP_COPY_NO_JOIN)) {
+                UG_HIP_TRY(chain(device, 1, l.down, (hipStream_t) after_stream)); // ug_hip_stream_sync(after_stream) now also waits for the download (and every earlier one of the lane)
+        }
         return UG_HIP_SUCCESS;
+}
+
+int ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream)
+{
+        return ug_hip_download_ordered_ex(device, dst_host, src_dev, count, after_stream, 0);
 }
 
 int ug_hip_linesize(ug_pixfmt_t fmt, int width)

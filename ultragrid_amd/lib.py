@@ -23,7 +23,8 @@ PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "B
 DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 # UG_DXT_TIES_*
 TIES_EVEN, TIES_AWAY = 0, 1
-ABI_VERSION = 3
+COPY_NO_WAIT, COPY_NO_JOIN = 1, 2
+ABI_VERSION = 4
 
 SUCCESS, EINVAL, EUNSUPP, ERUNTIME = 0, -1, -2, -3
 
@@ -45,6 +46,8 @@ SYMBOLS = {
     "ug_hip_memset_async": (_i, [_vp, _i, _sz, _vp]),
     "ug_hip_upload_ordered": (_i, [_i, _vp, _vp, _sz, _i, _vp]),
     "ug_hip_download_ordered": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "ug_hip_upload_ordered_ex": (_i, [_i, _vp, _vp, _sz, _i, _vp, _i]),
+    "ug_hip_download_ordered_ex": (_i, [_i, _vp, _vp, _sz, _vp, _i]),
     "ug_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "ug_hip_stream_destroy": (_i, [_vp]),
     "ug_hip_stream_sync": (_i, [_vp]),

@@ -10,11 +10,15 @@
  * usage: ug_harness <cfg> <codec> <width> <height> <in.raw> <out.bin> [tiles] [dev|host] [frames]
  *        frames: number of frames in in.raw (default 1); all are pushed, the compressed frames are written in pop order
  *        [repeat]: push the frame set that many times (throughput measurement; only the last pass is kept)
+ *        UG_HARNESS_PACE_US=<n>: sleep that long between pushes (a source at display rate: one frame in flight); the run then also prints
+ *        "LATENCY frames=.. median_ms=.. p95_ms=.. min_ms=.." over compress_end - compress_start of every frame that came back
  *        dev: hand the frame over device-resident (tile data = device pointers, mem_location = CUDA_MEM)
  *        ug_harness list
  * The compressed tile(s) are written to <out.bin> (tile after tile); a test compares them with the
  * CPU oracle.  Exit code 0 = OK, 2 = module refused (no GPU / bad cfg), 3 = frame dropped.
  */
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +65,7 @@ int main(int argc, char **argv)
         const bool devmem = argc > 8 && strcmp(argv[8], "dev") == 0;
         FILE *in = fopen(argv[5], "rb");
         if (!in) { perror("in"); return 1; }
-        std::vector<void *> dev_bufs;
+        std::vector<void *> dev_bufs, pinned_bufs;
         std::vector<std::shared_ptr<video_frame>> inputs;
         for (unsigned n = 0; n < nframes; n++) {
                 struct video_frame *f = vf_alloc_desc_data(desc);
@@ -88,6 +92,19 @@ int main(int argc, char **argv)
                         vf_free(f); // the host copy is gone: only the device copy can be what gets encoded
                         f = fd;
                 }
+                if (!devmem && getenv("UG_HARNESS_PINNED")) { // the source's frames in pinned host memory (a capture module that allocates through the module's allocator hook)
+                        struct video_frame *fp = vf_alloc_desc(desc);
+                        for (unsigned t = 0; t < tiles; t++) {
+                                void *p = nullptr;
+                                if (ug_hip_malloc_host(&p, f->tiles[t].data_len + 64) != UG_HIP_SUCCESS) { fprintf(stderr, "pinned allocation failed\n"); return 1; }
+                                memcpy(p, f->tiles[t].data, f->tiles[t].data_len);
+                                pinned_bufs.push_back(p);
+                                fp->tiles[t].data = (char *) p;
+                                fp->tiles[t].data_len = f->tiles[t].data_len;
+                        }
+                        vf_free(f);
+                        f = fp;
+                }
                 inputs.emplace_back(f, vf_free);
         }
         fclose(in);
@@ -100,8 +117,11 @@ int main(int argc, char **argv)
         }
         // sender-thread stand-in (rxtx.cpp:260-288): pops until the poison pill arrives
         std::vector<std::shared_ptr<video_frame>> popped;
+        std::vector<double> latency_ms;
+        const unsigned pace_us = getenv("UG_HARNESS_PACE_US") ? (unsigned) atoi(getenv("UG_HARNESS_PACE_US")) : 0;
         std::thread sender([&] {
                 while (std::shared_ptr<video_frame> f2 = compress_pop(c)) {
+                        latency_ms.push_back((double) (f2->compress_end - f2->compress_start) / 1e6);
                         popped.push_back(f2);
                         if (repeat > 1 && popped.size() > nframes) { // like the real sender: frames go back to the module's pool
                                 popped.erase(popped.begin());
@@ -112,6 +132,7 @@ int main(int argc, char **argv)
         for (unsigned r = 0; r < repeat; r++) {
                 for (auto &frame : inputs) {
                         compress_frame(c, frame);
+                        if (pace_us) std::this_thread::sleep_for(std::chrono::microseconds(pace_us));
                 }
         }
         inputs.clear();
@@ -119,6 +140,11 @@ int main(int argc, char **argv)
         sender.join();
         const double wall_s = (double) (get_time_in_ns() - t_start) / 1e9;
         printf("THROUGHPUT frames=%u wall_s=%.4f fps=%.1f\n", nframes * repeat, wall_s, nframes * repeat / wall_s);
+        if (pace_us && latency_ms.size() > 4) {
+                std::vector<double> v(latency_ms.begin() + 2, latency_ms.end()); // (the first frames configure the state and page the buffers in)
+                std::sort(v.begin(), v.end());
+                printf("LATENCY frames=%zu median_ms=%.3f p95_ms=%.3f min_ms=%.3f\n", v.size(), v[v.size() / 2], v[v.size() * 95 / 100], v[0]);
+        }
         if (popped.empty()) { // only the pill came back: the module dropped the frame (video_compress.cpp:394-398)
                 fprintf(stderr, "frame dropped\n");
                 compress_done(c);
@@ -144,5 +170,6 @@ int main(int argc, char **argv)
         popped.clear();
         compress_done(c);
         for (void *p : dev_bufs) ug_hip_free(p);
+        for (void *p : pinned_bufs) ug_hip_free_host(p);
         return 0;
 }
