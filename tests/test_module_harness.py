@@ -887,7 +887,7 @@ def test_row_bands_give_the_bytes_of_the_whole_frame(tmp_path, po, cfg, codec, w
             assert r.returncode == 0, r.stdout + r.stderr
             outs[(k, pinned)] = out.read_bytes()
     assert len(set(outs.values())) == 1
-    if codec in ("UYVY", "v210", "RGB", "RGBA"):
+    if codec in ("UYVY", "v210", "RGB", "RGBA") and not cfg.endswith("DXT1_YUV"):
         oid = po.OUT_DXT5YCOCG if cfg.endswith("DXT5") else po.OUT_DXT1
         want = po.dxt_encode({"UYVY": po.IN_UYVY, "v210": po.IN_V210, "RGB": po.IN_RGB, "RGBA": po.IN_RGBA}[codec], oid, src, w, h).tobytes()
         assert outs[(4, True)] == want + want

@@ -132,7 +132,7 @@ def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_fra
             "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len}
 
 
-def latency_depth1(workload: str = "8k-v210", frames: int = 24, salt: int = 0) -> dict:
+def latency_depth1(workload: str = "8k-v210", frames: int = 24, salt: int = 0, bands=(4, 8)) -> dict:
     """ONE frame in flight, as a display-rate source drives the module: pinned host frame -> H2D -> fused kernel -> D2H -> synchronise, then the
     next frame.  Returns the median wall-clock per frame (submit to synchronised, what the caller waits) and the three stages as HIP events on the
     frame's stream see them, plus what serial and perfectly overlapped copies would take at the rates the stages themselves ran at."""
@@ -162,7 +162,31 @@ def latency_depth1(workload: str = "8k-v210", frames: int = 24, salt: int = 0) -
             stages.append([ev[k].elapsed_time(ev[k + 1]) for k in range(3)])
     med = lambda v: float(np.median(v))  # noqa: E731
     h2d, kern, d2h = (med([s[k] for s in stages]) for k in range(3))
-    return {"ms": round(med(wall), 3), "h2d_ms": round(h2d, 3), "kernel_ms": round(kern, 3), "d2h_ms": round(d2h, 3), "frames": frames,
+    # the same frame as row bands (the module's bands=<k>): upload of band i + 1 | kernel of band i | download of band i - 1, through the C ABI's copy lanes
+    banded = {}
+    l, dev = lib.load(), torch.cuda.current_device()
+    ls, orow = in_len // h, out_len // (h // 4)
+    for K in bands:
+        edges = [0] + [min(h, (h * (k + 1) // K + 15) // 16 * 16) for k in range(K - 1)] + [h]
+        t = []
+        for i in range(frames + 3):
+            src = srcs[i % 2]
+            t0 = time.perf_counter()
+            with torch.cuda.stream(st):
+                for k in range(K):
+                    r0, r1 = edges[k], edges[k + 1]
+                    if r1 <= r0:
+                        continue
+                    lib.check(l.ug_hip_upload_ordered_ex(dev, dev_in.data_ptr() + r0 * ls, src.data_ptr() + r0 * ls, (r1 - r0) * ls, 0, st.cuda_stream, lib.COPY_NO_WAIT if k else 0),
+                              "ug_hip_upload_ordered_ex")
+                    codec.dxt_encode(pf, oid, dev_in[r0 * ls: r1 * ls], w, r1 - r0, dst=dev_out[r0 // 4 * orow: r1 // 4 * orow])
+                    lib.check(l.ug_hip_download_ordered_ex(dev, host_out.data_ptr() + r0 // 4 * orow, dev_out.data_ptr() + r0 // 4 * orow, (r1 - r0) // 4 * orow, st.cuda_stream,
+                                                           0 if r1 == h else lib.COPY_NO_JOIN), "ug_hip_download_ordered_ex")
+            st.synchronize()
+            if i >= 3:
+                t.append((time.perf_counter() - t0) * 1e3)
+        banded[f"bands{K}_ms"] = round(med(t), 3)
+    return {"ms": round(med(wall), 3), **banded, "h2d_ms": round(h2d, 3), "kernel_ms": round(kern, 3), "d2h_ms": round(d2h, 3), "frames": frames,
             "bytes_in": in_len, "bytes_out": out_len, "h2d_gbs": round(in_len / h2d / 1e6, 1), "d2h_gbs": round(out_len / d2h / 1e6, 1),
             "over_longer_copy": round(med(wall) / max(h2d, d2h), 3)}
 
