@@ -897,3 +897,34 @@ def test_row_bands_give_the_bytes_of_the_whole_frame(tmp_path, po, cfg, codec, w
         a, b = tmp_path / "ia.bin", tmp_path / "ib.bin"
         assert _run([cfg + ":bands=4", codec, w, h, raw, a, 1, "host", 1], env=env).returncode == 0 and _run([cfg, codec, w, h, raw, b, 1, "host", 1], env=env).returncode == 0
         assert a.read_bytes() == b.read_bytes() != outs[(1, False)][: len(b.read_bytes())]
+
+
+@needs_dec_harness
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary", ["ug_dec_harness", "ug_dec_harness_asan", "ug_dec_harness_tsan"])
+def test_receiver_tile_fanout_decodes_all_tiles_at_once(tmp_path, po, binary):
+    """The receive side's concurrency convention (rtp/video_decoders.cpp:590-612,676-690): one decompress state per tile from ONE decompress_init_multi(..., n),
+    decompress_frame of all tiles at the same time on worker threads -- four states of each module on one GPU, sharing the process-wide copy lanes, 20 frames
+    each: every output equals the single-state result (which the other tests pin to the oracle).  Plain, under ASan + UBSan and under ThreadSanitizer."""
+    import shutil
+    exe = os.path.join(ROOT, "oracle", "_ref", binary)
+    if not os.path.exists(exe):
+        pytest.skip(f"oracle/_ref/{binary} not built")
+    w, h = 640, 368
+    uyvy = synth.s2_video("UYVY", w, h)
+    raw, jpg, dxt5, dxt1 = (tmp_path / n for n in ("in.raw", "f.jpg", "f.dxt5", "f.dxt1"))
+    uyvy.tofile(raw)
+    assert _run(["jpeg:q=85:restart=4", "UYVY", w, h, raw, jpg]).returncode == 0
+    po.dxt_encode(po.IN_UYVY, po.OUT_DXT5YCOCG, uyvy, w, h).tofile(dxt5)
+    po.dxt_encode(po.IN_UYVY, po.OUT_DXT1, uyvy, w, h).tofile(dxt1)
+    env = dict(os.environ, UG_DEC_TILES="4", ASAN_OPTIONS="detect_leaks=0 exitcode=66 protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1 halt_on_error=1",
+               TSAN_OPTIONS="halt_on_error=1 exitcode=66 suppressions=" + os.path.join(ROOT, "ultragrid_amd", "module", "tsan_gpu.supp"))
+    pre = ["setarch", "x86_64", "-R"] if binary.endswith("_tsan") and shutil.which("setarch") else []
+    for comp, out, f in (("DXT5", "RGBA", dxt5), ("DXT5", "UYVY", dxt5), ("DXT1", "RGB", dxt1), ("JPEG", "UYVY", jpg), ("JPEG", "RGBA", jpg), ("JPEG", "DXT1", jpg), ("JPEG", "DXT5", jpg)):
+        r = subprocess.run(pre + [exe, comp, out, str(w), str(h), str(f), str(tmp_path / "o.raw")], capture_output=True, text=True, timeout=300, env=env)
+        text = r.stdout + r.stderr
+        if "unexpected memory mapping" in text or "ReserveShadowMemoryRange failed" in text or "Shadow memory range interleaves" in text:
+            pytest.skip("this box's address-space layout cannot host the sanitizer runtime")
+        assert "Sanitizer" not in text and "runtime error" not in text, text[-5000:]
+        assert r.returncode == 0 and "TILES n=4 rounds=20 OK" in r.stdout, (comp, out, text[-2000:])

@@ -7,7 +7,11 @@
  * usage: ug_dec_harness <DXT1|DXT1_YUV|DXT5|JPEG> <out codec> <w> <h> <in.bin> <out.raw> [pitch] [src_len]
  *        ug_dec_harness list
  * UG_DEC_REPEAT=<n>: the frame is decompressed n more times and the rate printed (THROUGHPUT ...), host frame in, host frame out.
+ * UG_DEC_TILES=<n>: the receiver's tile fan-out (rtp/video_decoders.cpp:590-612,676-690: one decompress state per tile, decompress_frame of all tiles
+ *                   at the same time on worker threads): n states from ONE decompress_init_multi(..., n), n threads, UG_DEC_TILE_ROUNDS (default 20) frames each
+ *                   into buffers of their own; every output must equal the single-state result ("TILES n=.. rounds=.. OK").
  */
+#include <pthread.h>
 #include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +21,24 @@
 #include "types.h"
 #include "video_codec.h"
 #include "video_decompress.h"
+
+struct tile_job {
+        struct state_decompress *s;
+        unsigned char *dst;
+        const unsigned char *src, *want;
+        unsigned src_len;
+        size_t out_bytes;
+        int rounds, bad;
+};
+static void *tile_worker(void *arg)
+{
+        struct tile_job *j = arg;
+        for (int r = 0; r < j->rounds; r++) {
+                memset(j->dst, 0, j->out_bytes);
+                if (decompress_frame(j->s, j->dst, (unsigned char *) j->src, j->src_len, r, NULL, NULL) != DECODER_GOT_FRAME || memcmp(j->dst, j->want, j->out_bytes) != 0) j->bad++;
+        }
+        return NULL;
+}
 
 int main(int argc, char **argv)
 {
@@ -74,6 +96,23 @@ int main(int argc, char **argv)
         fwrite(dst, 1, out_bytes, f);
         fclose(f);
         printf("OK %s -> %s %ux%u pitch=%d\n", argv[1], argv[2], w, h, pitch);
+        const int tiles = getenv("UG_DEC_TILES") ? atoi(getenv("UG_DEC_TILES")) : 0;
+        if (tiles > 1 && tiles <= 16) {
+                struct state_decompress *ts[16] = { 0 };
+                struct tile_job jobs[16];
+                pthread_t th[16];
+                if (!decompress_init_multi(in, internal, out, ts, tiles)) { fprintf(stderr, "tiles: no decompressor\n"); return 2; }
+                int bad = 0;
+                for (int t = 0; t < tiles; t++) {
+                        if (!decompress_reconfigure(ts[t], desc, 0, 8, 16, pitch, out)) { fprintf(stderr, "tiles: reconfigure failed\n"); return 2; }
+                        jobs[t] = (struct tile_job){ ts[t], calloc(out_bytes + 64, 1), src, dst, src_len, out_bytes, getenv("UG_DEC_TILE_ROUNDS") ? atoi(getenv("UG_DEC_TILE_ROUNDS")) : 20, 0 };
+                }
+                for (int t = 0; t < tiles; t++) pthread_create(&th[t], NULL, tile_worker, &jobs[t]);
+                for (int t = 0; t < tiles; t++) { pthread_join(th[t], NULL); bad += jobs[t].bad; }
+                for (int t = 0; t < tiles; t++) { decompress_done(ts[t]); free(jobs[t].dst); }
+                printf("TILES n=%d rounds=%d %s bad=%d\n", tiles, jobs[0].rounds, bad ? "MISMATCH" : "OK", bad);
+                if (bad) return 5;
+        }
         const int repeat = getenv("UG_DEC_REPEAT") ? atoi(getenv("UG_DEC_REPEAT")) : 0;
         if (repeat > 0) {
                 struct timespec t0, t1;
