@@ -435,3 +435,11 @@ def test_teardown_with_frames_in_the_workers(tmp_path, po, binary, cfg):
     records, out = _run(binary, tmp_path, _script(sets, body), REAL_SAN_ENV[binary], timeout=600)
     _check_real(po, records, [(n, [(0, cfg)]) for _ in range(4) for n in ("A", "C")], sets)
     assert len(records) == 8 and "pill=0" in out
+
+
+def test_random_scripts_on_the_fake_module():
+    """tools/fuzz_runtime_conventions.py: random sequences of format changes, CHANGE_COMPRESS from the capture side and from control threads, paces, slow and
+    holding senders, encoder failures, teardown with and without a pill -- 45 of them here (plain / TSan / ASan in turn); 292 more were run for
+    profiles/r05_runtime_conventions.txt"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_runtime_conventions.py"), "45", "20260925"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "every check held" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
