@@ -276,6 +276,13 @@ std::shared_ptr<video_frame> compress_tile_in_bands(state_video_compress_dxt_mi3
         const bool pre = s->pre_in != UG_PF_NONE;
         const size_t pre_ls = pre ? (size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->pre_out)) : 0;
         const size_t out_row = s->out_len / (size_t) (h / 4); // bytes of one row of blocks
+        // a failure half way: downloads of earlier bands may still be writing into `out` (they were not joined) -- wait for the lane before the frame goes
+        // back to its pool (a joined 16-byte download behind them, then the stream)
+        auto fail = [&]() -> std::shared_ptr<video_frame> {
+                (void) ug_hip_download_ordered_ex(s->device, out->tiles[0].data, s->dev_out, 16, s->stream, 0);
+                (void) ug_hip_stream_sync(s->stream);
+                return {};
+        };
         int r0 = 0;
         for (int k = 0; k < s->bands && r0 < h; k++) {
                 const int r1 = k == s->bands - 1 ? h : std::min(h, (int) ((long) h * (k + 1) / s->bands + 15) / 16 * 16);
@@ -286,19 +293,19 @@ std::shared_ptr<video_frame> compress_tile_in_bands(state_video_compress_dxt_mi3
                 // the first band's upload waits for whatever this state's stream still holds; the others follow it on the upload lane
                 CHECK_HIP(ug_hip_upload_ordered_ex(s->device, src_band, tx->tiles[0].data + (size_t) r0 * wire_ls, (size_t) rows * wire_ls, UG_HIP_MEMCPY_HOST_TO_DEVICE,
                                                    s->stream, k == 0 ? 0 : UG_HIP_COPY_NO_WAIT),
-                          "upload failed", return {});
+                          "upload failed", return fail());
                 const void *enc_src = src_band;
                 if (pre) {
                         char *const pre_band = (char *) s->dev_pre + (size_t) r0 * pre_ls;
-                        CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, src_band, pre_band, w, rows, 0, 0, 0, 8, 16, s->stream), "device swizzle failed", return {});
+                        CHECK_HIP(ug_hip_pixfmt_convert(s->pre_in, s->pre_out, src_band, pre_band, w, rows, 0, 0, 0, 8, 16, s->stream), "device swizzle failed", return fail());
                         enc_src = pre_band;
                 }
                 char *const blocks = (char *) s->dev_out + (size_t) (r0 / 4) * out_row;
-                CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, enc_src, blocks, w, rows, 0, 1, 0, 0, s->ties, s->stream), "Encoding failed", return {});
+                CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, enc_src, blocks, w, rows, 0, 1, 0, 0, s->ties, s->stream), "Encoding failed", return fail());
                 // every download but the last leaves the stream free to go on with the next band; the last one joins, and the lane is in order
                 CHECK_HIP(ug_hip_download_ordered_ex(s->device, out->tiles[0].data + (size_t) (r0 / 4) * out_row, blocks, (size_t) (rows / 4) * out_row, s->stream,
                                                      last ? 0 : UG_HIP_COPY_NO_JOIN),
-                          "D2H copy failed", return {});
+                          "D2H copy failed", return fail());
                 r0 = r1;
         }
         CHECK_HIP(ug_hip_stream_sync(s->stream), "stream sync failed", return {});
