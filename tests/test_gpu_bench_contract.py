@@ -38,6 +38,8 @@ def test_single_gpu_line(hip):
     assert set(lat) == {"8k-uyvy", "8k-v210", "4k-uyvy"}
     for name, v in lat.items():
         assert v["ms"] >= max(v["h2d_ms"], v["d2h_ms"]) and v["ms"] < 16.7 and v["kernel_ms"] < v["h2d_ms"], (name, v)   # one frame period at 60 fps is 16.7 ms
+        assert 0 < v["bands4_ms"] < 16.7 and 0 < v["bands8_ms"] < 16.7
+    assert lat["8k-uyvy"]["bands4_ms"] < lat["8k-uyvy"]["ms"] and lat["8k-v210"]["bands4_ms"] < lat["8k-v210"]["ms"]    # row bands overlap the copies of ONE frame
     assert 0 < d["roofline"]["valu_frac"] < d["roofline"]["valu"]["frac_of_measured_peak"] < 1.05
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert "configs[2]" in d["config"]["workload"] and d["config"]["launches_per_step"] == 8
