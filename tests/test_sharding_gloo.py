@@ -103,4 +103,8 @@ def test_bench_self_launch_runs_the_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                        timeout=600, cwd=str(tmp_path), env=env)
     assert r.returncode != 0
-    assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 2, (r.stdout + r.stderr)[-3000:]
+    out = r.stdout + r.stderr
+    # both ranks say so -- unless the launcher's agent saw the first one fail and sent SIGTERM to the second while that was still
+    # importing torch (a loaded box: pytest -n 4); the agent's log line then names the second process it had started
+    n = out.count("bench.py needs a GPU")
+    assert n >= 2 or (n == 1 and "closing signal SIGTERM" in out), out[-3000:]
