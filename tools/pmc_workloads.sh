@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/pmc_workloads
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in 8k-v210 1080p-rgb-dxt1 4k-uyvy-jpeg420; do
-  CMD="python $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --launches-per-step 16 --no-cpu-baseline --no-e2e"
+  CMD="python $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --launches-per-step 16 --no-cpu-baseline --no-e2e --no-configs --no-parity-check"
   rm -rf /tmp/pw; mkdir -p /tmp/pw
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES -d /tmp/pw -o sq -- $CMD > /tmp/pw/sq.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o write -- $CMD > /tmp/pw/write.log 2>&1
