@@ -353,6 +353,36 @@ def other_configs(rank: int, seconds: float) -> dict:
     return res
 
 
+def load_pmc(pmc_key, root: str = ROOT) -> dict:
+    """The counter entry of one bench workload from profiles/pmc_traffic.json (rocprofv3 --pmc passes, tools/gpu_session.sh <tag> pmc) --
+    quoted only while the kernel sources it names are the ones of this tree."""
+    pmc = {}
+    pmc_path = os.path.join(root, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes (tools/pmc_collect.sh)
+    if pmc_key and os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path)).get(pmc_key) or {}
+            if not isinstance(pmc, dict):
+                pmc = {"traffic": pmc}
+        except Exception:
+            pmc = {}
+    if pmc.get("kernel_sources_sha16"):
+        # the counters name the sources they were taken on (tools/pmc_to_json.py): counters of another build are not quoted
+        import hashlib
+        h = hashlib.sha256()
+        try:
+            for f in pmc["kernel_sources"]:
+                h.update(open(os.path.join(root, f), "rb").read())
+            now = h.hexdigest()[:16]
+        except OSError:
+            now = None
+        if now != pmc["kernel_sources_sha16"]:
+            pmc = {"source": f"STALE, not quoted: profiles/pmc_traffic.json[{pmc_key}] was taken on another build of {', '.join(pmc['kernel_sources'])} "
+                             f"(sha16 {pmc['kernel_sources_sha16']} then, {now} now); re-run tools/gpu_session.sh <tag> pmc"}
+        else:
+            pmc = dict(pmc, source=pmc.get("source", "") + f"; kernel sources sha16 {now} = the build timed here")
+    return pmc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,15 +516,7 @@ def main() -> None:
         read_bpp = {"UYVY": 2.0, "v210": 16 / 6, "RGB": 3.0}[wl["fmt"]]
         pmc_key = {"4k-uyvy": f"uyvy_dxt5_4k_x{F}", "8k-v210": f"v210_dxt5_8k_x{F}", "1080p-rgb-dxt1": f"rgb_dxt1_1080p_x{F}",
                    "4k-uyvy-jpeg420": f"uyvy_jpeg420_4k_x{F}", "4k-uyvy-jpeg-encode": f"uyvy_jpeg_encode_4k_x{F}"}.get(args.workload)
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes (tools/pmc_collect.sh)
-        if pmc_key and os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path)).get(pmc_key) or {}
-                if not isinstance(pmc, dict):
-                    pmc = {"traffic": pmc}
-            except Exception:
-                pmc = {}
+        pmc = load_pmc(pmc_key)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
                 "kernel": ("uyvy_jpeg_kernel<420> (batched)" if out_name == "JPEG420" else "jpeg_code_kernel<3,420> + jpeg_gather_kernel (one call)" if out_name == "JPEGENC"

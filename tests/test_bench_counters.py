@@ -1,0 +1,45 @@
+"""bench.py quotes the HBM traffic / VALU counters of its kernel from profiles/pmc_traffic.json (rocprofv3 --pmc passes cannot run inside the
+timed process).  The entry names the kernel sources it was taken on; counters of another build are not quoted (CPU test of that rule)."""
+import importlib.util
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_committed_counters_belong_to_the_committed_kernels():
+    bench = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for key in ("uyvy_dxt5_4k_x16", "v210_dxt5_8k_x4", "rgb_dxt1_1080p_x64", "uyvy_jpeg420_4k_x8"):
+        assert d[key].get("kernel_sources_sha16"), key
+        pmc = bench.load_pmc(key)
+        assert pmc.get("traffic") == d[key]["traffic"] and "= the build timed here" in pmc["source"], (key, pmc.get("source"))
+    # headline: traffic within 0.5 % of the algorithmic 3.0 B/px x 16 x 3840 x 2160
+    assert abs(d["uyvy_dxt5_4k_x16"]["traffic"] / (3.0 * 16 * 3840 * 2160) - 1) < 0.005
+
+
+def test_counters_of_another_build_are_not_quoted(tmp_path):
+    bench = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    (tmp_path / "profiles").mkdir()
+    shutil.copy(os.path.join(ROOT, "profiles", "pmc_traffic.json"), tmp_path / "profiles" / "pmc_traffic.json")
+    for f in d["uyvy_dxt5_4k_x16"]["kernel_sources"]:
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        shutil.copy(os.path.join(ROOT, f), tmp_path / f)
+    assert bench.load_pmc("uyvy_dxt5_4k_x16", root=str(tmp_path)).get("traffic") == d["uyvy_dxt5_4k_x16"]["traffic"]
+    with open(tmp_path / "ultragrid_amd/csrc/dxt_encode.hip", "a") as f:
+        f.write("\n// a kernel change\n")
+    pmc = bench.load_pmc("uyvy_dxt5_4k_x16", root=str(tmp_path))
+    assert pmc.get("traffic") is None and pmc.get("valu_instr_per_wave") is None and pmc["source"].startswith("STALE")
+    # an entry without a hash (counters of an earlier round) is quoted as it is, with its own source note
+    assert bench.load_pmc("uyvy_jpeg_encode_4k_x8", root=str(tmp_path)).get("traffic") == d["uyvy_jpeg_encode_4k_x8"]["traffic"]
+    assert bench.load_pmc("no_such_workload", root=str(tmp_path)) == {}
