@@ -5,7 +5,7 @@ ROUNDS=${ROUNDS:-3}
 STEPS=${STEPS:-300}
 for r in $(seq $ROUNDS); do
   for lib in "$@"; do
-    UG_MI355X_LIB=$(realpath $lib) python bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-e2e ${WORKLOAD:+--workload $WORKLOAD} 2>/dev/null | tail -1 | \
+    UG_MI355X_LIB=$(realpath $lib) python bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-e2e --no-configs --no-parity-check ${WORKLOAD:+--workload $WORKLOAD} 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', d['roofline']['ms_per_launch'], d['roofline']['frac'])"
   done
 done
