@@ -594,8 +594,14 @@ constexpr int kProfPhases = 10;
                 prof_t = now_;                                                                                           \
         }
 
-template <int WAVES, int SRC>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC == 420 ? 5 : 4))) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
+// The register allocator's occupancy target (amdgpu_waves_per_eu = the MINIMUM it has to keep; the workgroup's LDS caps the resident waves at
+// 4.5 per SIMD anyway).  Round 5, interleaved A/B over every call form (profiles/r05_jpeg_code_occupancy.txt): with a target of 3 instead of 5 the
+// 4:2:0 kernel keeps its 95 VGPRs but is scheduled for latency instead of occupancy -- 12.1 -> 11.4 us per 4K frame at 8 per call, one frame
+// per call unchanged (31.9); 4:2:2 gains as much in batches (15.4 -> 14.3) and LOSES as much one frame per call (35.0 -> 37.6), so the batch
+// launches (BATCH = true, two frames or more per call) take the target-3 instantiation and the one-frame call keeps 4; RGB 4:4:4, I420 and
+// the unfused variants are indifferent and stay at 4.
+template <int WAVES, int SRC, bool BATCH = false>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC == 420 || (SRC == 422 && BATCH) ? 3 : 4))) void jpeg_code_kernel(const CodeArgs a, const float *__restrict__ div /* the quantiser (fused variants): a parameter of its own, restrict, so that its 128 words are scalar loads */)
 {
         constexpr int W = 64 * WAVES;
         // The look-back below waits for workgroups with smaller indices.  Index = blockIdx.x within the frame blockIdx.y: the dispatcher starts the workgroups of a grid in
@@ -1717,6 +1723,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 if (fused) {
                         if (fused_i420) hipLaunchKernelGGL((jpeg_code_kernel<3, 1420>), grid, dim3(192), 0, st, a, (const float *) e->div);
                         else if (e->sub == 420) hipLaunchKernelGGL((jpeg_code_kernel<3, 420>), grid, dim3(192), 0, st, a, (const float *) e->div);
+                        else if (e->sub == 422 && frames >= 2) hipLaunchKernelGGL((jpeg_code_kernel<2, 422, true>), grid, dim3(128), 0, st, a, (const float *) e->div);
                         else if (e->sub == 422) hipLaunchKernelGGL((jpeg_code_kernel<2, 422>), grid, dim3(128), 0, st, a, (const float *) e->div);
                         else hipLaunchKernelGGL((jpeg_code_kernel<3, 444>), grid, dim3(192), 0, st, a, (const float *) e->div);
                 } else {

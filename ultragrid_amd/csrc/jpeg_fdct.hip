@@ -311,8 +311,11 @@ __global__ __launch_bounds__(256) void uyvy_jpeg_kernel(const uint8_t *__restric
 // waves take one luma block row of the strip each (64 blocks), the last wave = 32 Cb blocks (lanes 0-31) + 32 Cr blocks
 // (lanes 32-63).  Every wave does 64 block DCTs, reads its rows with 128-bit loads that are contiguous across lanes (the
 // chroma wave re-reads the strip from L1/L2, so HBM sees each input byte once) and writes through wave_store_blocks().
+// Occupancy: capped at 3 waves per SIMD.  Unlike the light pixel-format kernels (which want all 8), this one is slower with more waves
+// resident: 7 / 6 / 5 (the allocator's own choice: 81 VGPRs) / 4 / 3 / 2 waves per SIMD measure 73.0 / 64.3 / 62.9 / 62.0 / 57.1 (58.8 for 5 on
+// that box) / 62.7 us per 8 4K frames, interleaved A/B (profiles/r05_jpeg_front_end_occupancy.txt): 0.705 -> 0.727 of 8 TB/s.
 template <int SUB>
-__global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height,
+__global__ __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height,
                                                                                 int mcu_w, const float *__restrict__ div,
                                                                                 int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
                                                                                 int16_t *__restrict__ out_cr, FrameStrides fs)
