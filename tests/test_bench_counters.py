@@ -46,5 +46,7 @@ def test_counters_of_another_build_are_not_quoted(tmp_path):
     pmc = bench.load_pmc("uyvy_dxt5_4k_x16", root=str(tmp_path))
     assert pmc.get("traffic") is None and pmc.get("valu_instr_per_wave") is None and pmc["source"].startswith("STALE")
     # an entry without a hash (counters of an earlier round) is quoted as it is, with its own source note
-    assert bench.load_pmc("uyvy_jpeg_encode_4k_x8", root=str(tmp_path)).get("traffic") == d["uyvy_jpeg_encode_4k_x8"]["traffic"]
+    legacy = dict(d, legacy_entry={"traffic": 123, "valu_instr_per_wave": 4.5, "source": "counters of an earlier round"})
+    json.dump(legacy, open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
+    assert bench.load_pmc("legacy_entry", root=str(tmp_path)) == legacy["legacy_entry"]
     assert bench.load_pmc("no_such_workload", root=str(tmp_path)) == {}
