@@ -519,7 +519,7 @@ def main() -> None:
         pmc = load_pmc(pmc_key)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
-                "kernel": ("uyvy_jpeg_kernel<420> (batched)" if out_name == "JPEG420" else "jpeg_code_kernel<3,420> + jpeg_gather_kernel (one call)" if out_name == "JPEGENC"
+                "kernel": ("uyvy_jpeg_fast_batch_kernel<420>" if out_name == "JPEG420" else "jpeg_code_kernel<3,420> + jpeg_gather_kernel (one call)" if out_name == "JPEGENC"
                            else f"dxt_encode_kernel<{wl['fmt']},{'DXT5_YCOCG' if out_name == 'DXT5' else 'DXT1'}>"),
                 "ms_per_launch": round(kern_ms, 5), "launches_timed": args.steps * L,
                 "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_PX * px_per_launch),

@@ -34,7 +34,7 @@ for step in "$@"; do
       tail -1 $OUT/trace.log > $OUT/trace_bench_line.json; rm -rf $OUT/trace ;;
     pmc-jpeg)  # the two JPEG workloads only
       R=${TAG}; WORKLOADS="4k-uyvy-jpeg420 4k-uyvy-jpeg-encode" bash tools/pmc_workloads.sh > $OUT/pmc_workloads.log 2>&1; cp gpurun_out/pmc_workloads/*.txt $OUT/
-      python tools/pmc_to_json.py uyvy_jpeg420_4k_x8 "uyvy_jpeg_fast_kernel" "rocprof passes of session $R, uyvy_jpeg_fast_kernel<420> batched" $OUT/4k-uyvy-jpeg420.txt
+      python tools/pmc_to_json.py uyvy_jpeg420_4k_x8 "uyvy_jpeg_fast_batch_kernel" "rocprof passes of session $R, uyvy_jpeg_fast_batch_kernel<420>" $OUT/4k-uyvy-jpeg420.txt
       python tools/pmc_to_json.py uyvy_jpeg_encode_4k_x8 "jpeg_code_kernel<3, 420" "rocprof passes of session $R, jpeg_code_kernel<3,420>: the fused encoder kernel of ug_hip_jpeg_encoder_encode_batch, 8 frames per launch (jpeg_gather_kernel beside it moves the stream bytes once more)" $OUT/4k-uyvy-jpeg-encode.txt
       cp profiles/pmc_traffic.json $OUT/pmc_traffic.json ;;
     pmc)
@@ -43,7 +43,7 @@ for step in "$@"; do
       bash tools/pmc_workloads.sh > $OUT/pmc_workloads.log 2>&1; cp gpurun_out/pmc_workloads/*.txt $OUT/
       python tools/pmc_to_json.py v210_dxt5_8k_x4 "dxt_encode_kernel<6, 6" "rocprof passes of session $R, dxt_encode_kernel<v210,DXT5,ties even>" $OUT/8k-v210.txt
       python tools/pmc_to_json.py rgb_dxt1_1080p_x64 "dxt_encode_kernel<4, 1" "rocprof passes of session $R, dxt_encode_kernel<RGB,DXT1,ties even>" $OUT/1080p-rgb-dxt1.txt
-      python tools/pmc_to_json.py uyvy_jpeg420_4k_x8 "uyvy_jpeg_fast_kernel" "rocprof passes of session $R, uyvy_jpeg_fast_kernel<420> batched" $OUT/4k-uyvy-jpeg420.txt
+      python tools/pmc_to_json.py uyvy_jpeg420_4k_x8 "uyvy_jpeg_fast_batch_kernel" "rocprof passes of session $R, uyvy_jpeg_fast_batch_kernel<420>" $OUT/4k-uyvy-jpeg420.txt
       python tools/pmc_to_json.py uyvy_jpeg_encode_4k_x8 "jpeg_code_kernel<3, 420" "rocprof passes of session $R, jpeg_code_kernel<3,420>: the fused encoder kernel of ug_hip_jpeg_encoder_encode_batch, 8 frames per launch (jpeg_gather_kernel beside it moves the stream bytes once more)" $OUT/4k-uyvy-jpeg-encode.txt
       cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; grep -c . $OUT/pmc_traffic.json ;;
     jpeg)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # counters of another build from counters of the build it times ("the line cannot notice a kernel change")
 KERNEL_SOURCES = {
     "dxt_encode_kernel": ["ultragrid_amd/csrc/dxt_encode.hip", "ultragrid_amd/csrc/ug_common.h"],
-    "uyvy_jpeg_fast_kernel": ["ultragrid_amd/csrc/jpeg_fdct.hip", "ultragrid_amd/csrc/jpeg_fdct_device.h", "ultragrid_amd/csrc/ug_common.h"],
+    "uyvy_jpeg_fast": ["ultragrid_amd/csrc/jpeg_fdct.hip", "ultragrid_amd/csrc/jpeg_fdct_device.h", "ultragrid_amd/csrc/ug_common.h"],
     "jpeg_code_kernel": ["ultragrid_amd/csrc/jpeg_entropy.hip", "ultragrid_amd/csrc/jpeg_fdct_device.h", "ultragrid_amd/csrc/jpeg_huffman_tables.h", "ultragrid_amd/csrc/ug_common.h"],
 }
 

@@ -314,11 +314,11 @@ __global__ __launch_bounds__(256) void uyvy_jpeg_kernel(const uint8_t *__restric
 // Occupancy: capped at 3 waves per SIMD.  Unlike the light pixel-format kernels (which want all 8), this one is slower with more waves
 // resident: 7 / 6 / 5 (the allocator's own choice: 81 VGPRs) / 4 / 3 / 2 waves per SIMD measure 73.0 / 64.3 / 62.9 / 62.0 / 57.1 (58.8 for 5 on
 // that box) / 62.7 us per 8 4K frames, interleaved A/B (profiles/r05_jpeg_front_end_occupancy.txt): 0.705 -> 0.727 of 8 TB/s.
+// The cap applies to launches of two frames or more (uyvy_jpeg_fast_batch_kernel).  One frame per launch keeps the allocator's choice: the 4 050 waves of a 4K 4:2:2 frame are
+// 15.8 per CU -- one round of residency at 5 per SIMD, two at 3 (14.0 -> 14.8 us); a 4:2:0 frame (11.9 per CU) does not care.
 template <int SUB>
-__global__ __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height,
-                                                                                int mcu_w, const float *__restrict__ div,
-                                                                                int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb,
-                                                                                int16_t *__restrict__ out_cr, FrameStrides fs)
+__device__ __forceinline__ void uyvy_jpeg_fast_body(const uint8_t *__restrict__ src, int pitch, int height, int mcu_w, const float *__restrict__ div,
+                                                    int16_t *__restrict__ out_y, int16_t *__restrict__ out_cb, int16_t *__restrict__ out_cr, FrameStrides fs)
 {
         fs.apply(blockIdx.z, src, out_y, out_cb, out_cr); // blockIdx.z = frame of the batch
         constexpr int kLumaWaves = SUB == 420 ? 2 : 1;
@@ -401,6 +401,23 @@ __global__ __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(SUB == 4
         }
 }
 
+// one frame per launch: the allocator's own choice (81 VGPRs, 5 waves per SIMD)
+template <int SUB>
+__global__ __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_kernel(const uint8_t *__restrict__ src, int pitch, int height, int mcu_w,
+                                                                                const float *__restrict__ div, int16_t *__restrict__ out_y,
+                                                                                int16_t *__restrict__ out_cb, int16_t *__restrict__ out_cr, FrameStrides fs)
+{
+        uyvy_jpeg_fast_body<SUB>(src, pitch, height, mcu_w, div, out_y, out_cb, out_cr, fs);
+}
+// two frames or more per launch: capped at 3 waves per SIMD
+template <int SUB>
+__global__ __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(SUB == 420 ? 192 : 128) void uyvy_jpeg_fast_batch_kernel(
+        const uint8_t *__restrict__ src, int pitch, int height, int mcu_w, const float *__restrict__ div, int16_t *__restrict__ out_y,
+        int16_t *__restrict__ out_cb, int16_t *__restrict__ out_cr, FrameStrides fs)
+{
+        uyvy_jpeg_fast_body<SUB>(src, pitch, height, mcu_w, div, out_y, out_cb, out_cr, fs);
+}
+
 // T.81 Annex K tables (natural order) -- same data as oracle/jpeg_oracle.c by construction of the
 // standard; kept separately so the product never links the oracle.
 const uint8_t kLuma[64] = {
@@ -433,9 +450,12 @@ int launch_uyvy_jpeg(const void *src, int src_pitch, int width, int height, cons
         if (!src_pitch) src_pitch = ug::linesize(UG_PF_UYVY, width);
         const int mcu_w = (width + 15) / 16, mcu_h = SUB == 420 ? (height + 15) / 16 : (height + 7) / 8;
         if (width % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src) && (frames == 1 || !(fs.src & 15))) {
-                hipLaunchKernelGGL((uyvy_jpeg_fast_kernel<SUB>), dim3((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h, (unsigned) frames),
-                                   dim3(SUB == 420 ? 192 : 128), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w,
-                                   div, out_y, out_cb, out_cr, fs);
+                const dim3 grid((unsigned) ((mcu_w + 31) / 32), (unsigned) mcu_h, (unsigned) frames), wg(SUB == 420 ? 192 : 128);
+                if (frames >= 2) {
+                        hipLaunchKernelGGL((uyvy_jpeg_fast_batch_kernel<SUB>), grid, wg, 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w, div, out_y, out_cb, out_cr, fs);
+                } else {
+                        hipLaunchKernelGGL((uyvy_jpeg_fast_kernel<SUB>), grid, wg, 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, height, mcu_w, div, out_y, out_cb, out_cr, fs);
+                }
                 UG_HIP_LAUNCH_CHECK();
                 return UG_HIP_SUCCESS;
         }
