@@ -66,3 +66,19 @@ def test_installed_sources_compile_where_they_were_put(tmp_path, src, std):
     cc = ["g++", "-std=" + std] if src.endswith(".cpp") else ["gcc", "-std=" + std]
     r = subprocess.run(cc + ["-fsyntax-only", "-D_GNU_SOURCE", "-msse4.1", "-I", os.path.join(REF, "src"), str(ug / src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_library_installs_into_the_prefix_the_patch_looks_in(tmp_path):
+    """`make -C ultragrid_amd/csrc install PREFIX=<dir>` lays out <dir>/lib/libug_mi355x.so + <dir>/include/ug_mi355x.h -- what the patched
+    configure.ac's --with-ug-mi355x=<dir> puts on the link line (-L<dir>/lib -lug_mi355x); the installed library exports the symbol AC_CHECK_LIB asks for."""
+    so = os.path.join(ROOT, "ultragrid_amd", "libug_mi355x.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built yet (build() runs first in the driver's order)")
+    prefix = tmp_path / "prefix"
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "ultragrid_amd", "csrc"), "install", f"PREFIX={prefix}", "VARIANT=0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (prefix / "include" / "ug_mi355x.h").is_file()
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(prefix / "lib" / "libug_mi355x.so")], capture_output=True, text=True, check=True).stdout
+    assert " T ug_hip_abi_version" in nm
+    patch = open(os.path.join(ROOT, "integration", "ultragrid_mi355x.patch")).read()
+    assert "AC_CHECK_LIB(ug_mi355x, ug_hip_abi_version" in patch and "-L$UG_MI355X_PREFIX/lib" in patch
