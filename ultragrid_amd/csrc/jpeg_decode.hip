@@ -396,7 +396,11 @@ constexpr int kTileWords = 36; // 32 words of coefficients, padded: 16-byte alig
 // tiles out together, 128 contiguous bytes per block, zeros included -- so the coefficient planes need no clearing and no lane issues
 // scattered 2-byte stores -- and leaves the tiles zeroed for the next block.  The coefficient planes are in zigzag order; the IDCT kernel
 // undoes it with compile-time indices.
-__global__ __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
+// amdgpu_waves_per_eu(1, 1): the launch puts at most one wave on a SIMD (above), and told so the compiler schedules the symbol loop for latency
+// instead of occupancy -- same 44 VGPRs, whole 4K decode calls 142.4-143.2 -> 139.0-139.8 us (4:2:2) and 162.0-162.5 -> 156.9 (4:2:0), interleaved A/B,
+// (1, 2) and (2, 2) equal the default (profiles/r05_jpeg_decode_occupancy.txt).  The attribute only bounds the register budget: waves of OTHER kernels
+// (four decoders on four streams) share the SIMD as before.
+__global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
                                                          int n_seg, const int *__restrict__ found, int lanes, int stage_bytes, ScanDev sp,
                                                          const HuffDev *__restrict__ tabs /* [0..3] DC, [4..7] AC */)
 {
