@@ -396,10 +396,12 @@ constexpr int kTileWords = 36; // 32 words of coefficients, padded: 16-byte alig
 // tiles out together, 128 contiguous bytes per block, zeros included -- so the coefficient planes need no clearing and no lane issues
 // scattered 2-byte stores -- and leaves the tiles zeroed for the next block.  The coefficient planes are in zigzag order; the IDCT kernel
 // undoes it with compile-time indices.
-// amdgpu_waves_per_eu(1, 1): the launch puts at most one wave on a SIMD (above), and told so the compiler schedules the symbol loop for latency
-// instead of occupancy -- same 44 VGPRs, whole 4K decode calls 142.4-143.2 -> 139.0-139.8 us (4:2:2) and 162.0-162.5 -> 156.9 (4:2:0), interleaved A/B,
-// (1, 2) and (2, 2) equal the default (profiles/r05_jpeg_decode_occupancy.txt).  The attribute only bounds the register budget: waves of OTHER kernels
-// (four decoders on four streams) share the SIMD as before.
+// amdgpu_waves_per_eu(1, 1): the launch is shaped for one wave per SIMD (above), but nothing makes the dispatcher spread 1 013 waves over 1 024 SIMDs
+// that way -- two on one SIMD take turns at every instruction of a latency-bound loop.  The attribute enforces it: the compiler requests 264 registers
+// for the 44 the kernel uses (.amdhsa_next_free_vgpr 257), so a second wave of THIS kernel does not fit a SIMD.  Whole 4K decode calls
+// 142.4-143.2 -> 139.0-139.8 us (4:2:2), 162.0-162.5 -> 156.9 (4:2:0), interleaved A/B; (1, 2) and (2, 2) equal the default
+// (profiles/r05_jpeg_decode_occupancy.txt).  Waves of other kernels (up to 248 registers) still share the SIMD; the Huffman kernels of two decoders
+// running on two streams no longer do -- four decoders on four streams: 87.5 -> 89.0 us per frame, inside that figure's spread.
 __global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
                                                          int n_seg, const int *__restrict__ found, int lanes, int stage_bytes, ScanDev sp,
                                                          const HuffDev *__restrict__ tabs /* [0..3] DC, [4..7] AC */)
