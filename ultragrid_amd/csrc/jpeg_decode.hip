@@ -401,7 +401,8 @@ constexpr int kTileWords = 36; // 32 words of coefficients, padded: 16-byte alig
 // for the 44 the kernel uses (.amdhsa_next_free_vgpr 257), so a second wave of THIS kernel does not fit a SIMD.  Whole 4K decode calls
 // 142.4-143.2 -> 139.0-139.8 us (4:2:2), 162.0-162.5 -> 156.9 (4:2:0), interleaved A/B; (1, 2) and (2, 2) equal the default
 // (profiles/r05_jpeg_decode_occupancy.txt).  Waves of other kernels (up to 248 registers) still share the SIMD; the Huffman kernels of two decoders
-// running on two streams no longer do -- four decoders on four streams: 87.5 -> 89.0 us per frame, inside that figure's spread.
+// running on two streams no longer do -- which costs nothing measurable: four decoders on four streams 90.2-91.7 us per frame without the attribute,
+// 89.1-90.4 with it (three interleaved rounds).
 __global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void huff_decode_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
                                                          int n_seg, const int *__restrict__ found, int lanes, int stage_bytes, ScanDev sp,
                                                          const HuffDev *__restrict__ tabs /* [0..3] DC, [4..7] AC */)
