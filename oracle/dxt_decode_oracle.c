@@ -45,8 +45,8 @@ static double alpha_decode(double a0, double a1, int idx)
 
 void oracle_dxt5ycocg_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
 {
-        for (int by = 0; by < h / 4; by++) {
-                for (int bx = 0; bx < w / 4; bx++) {
+        for (int by = 0; by < (h + 3) / 4; by++) {
+                for (int bx = 0; bx < (w + 3) / 4; bx++) {
                         uint64_t ac, cc;
                         memcpy(&ac, src, 8);
                         memcpy(&cc, src + 8, 8);
@@ -72,6 +72,7 @@ void oracle_dxt5ycocg_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
                                         const double scale = 1.0 / (31.875 * b[ci] + 1.0);
                                         const double Co = (r[ci] - 5.01960814E-01) * scale;
                                         const double Cg = (g[ci] - 5.01960814E-01) * scale;
+                                        if (4 * by + y >= h || 4 * bx + x >= w) continue; /* texels past the picture are not shown */
                                         uint8_t *o = dst + 3 * ((long) (4 * by + y) * w + 4 * bx + x);
                                         o[0] = clamp8(((a + Co) - Cg) * 255.0);
                                         o[1] = clamp8((a + Cg) * 255.0);
@@ -84,8 +85,8 @@ void oracle_dxt5ycocg_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
 
 void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
 {
-        for (int by = 0; by < h / 4; by++) {
-                for (int bx = 0; bx < w / 4; bx++) {
+        for (int by = 0; by < (h + 3) / 4; by++) {
+                for (int bx = 0; bx < (w + 3) / 4; bx++) {
                         uint16_t c0, c1;
                         uint32_t idx;
                         memcpy(&c0, src, 2);
@@ -106,6 +107,7 @@ void oracle_dxt1_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
                         }
                         for (int i = 0; i < 16; i++) {
                                 const int ci = (idx >> (2 * i)) & 3;
+                                if (4 * by + i / 4 >= h || 4 * bx + i % 4 >= w) continue;
                                 uint8_t *o = dst + 3 * ((long) (4 * by + i / 4) * w + 4 * bx + i % 4);
                                 for (int k = 0; k < 3; k++) o[k] = clamp8(p[ci][k] * 255.0);
                         }
@@ -122,8 +124,8 @@ static inline uint8_t unorm8_out(float x);
  * unorm conversion to the implementation: parity unpinned, like the rest of the receiver side. */
 void oracle_dxt1yuv_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
 {
-        for (int by = 0; by < h / 4; by++) {
-                for (int bx = 0; bx < w / 4; bx++) {
+        for (int by = 0; by < (h + 3) / 4; by++) {
+                for (int bx = 0; bx < (w + 3) / 4; bx++) {
                         uint16_t c0, c1;
                         uint32_t idx;
                         memcpy(&c0, src, 2);
@@ -156,6 +158,7 @@ void oracle_dxt1yuv_decode_rgb(const uint8_t *src, uint8_t *dst, int w, int h)
                         }
                         for (int i = 0; i < 16; i++) {
                                 const int ci = (idx >> (2 * i)) & 3;
+                                if (4 * by + i / 4 >= h || 4 * bx + i % 4 >= w) continue;
                                 memcpy(dst + 3 * ((long) (4 * by + i / 4) * w + 4 * bx + i % 4), pal[ci], 3);
                         }
                 }
@@ -216,7 +219,9 @@ static void rgb_pair_to_uyvy(const uint8_t *p1, const uint8_t *p2, uint8_t *out)
 int oracle_dxt_decode(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long dst_pitch,
                       int rs, int gs, int bs)
 {
-        if (w <= 0 || h <= 0 || (w & 3) || (h & 3)) {
+        /* any size: the stream holds (w+3)/4 x (h+3)/4 blocks (dxt_util.h:59-67), of which the w x h picture is shown
+         * (dxt_decoder.c:146-149,368-389: the S3TC texture is created w x h, the upload covers the rounded-up block grid) */
+        if (w <= 0 || h <= 0 || (out_fmt == OPF_UYVY && (w & 1))) {
                 return -1;
         }
         uint8_t *rgb = (uint8_t *) malloc((size_t) w * h * 3);

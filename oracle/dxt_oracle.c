@@ -529,27 +529,44 @@ int oracle_dxt_encode_mt(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *d
         return encode_rows(in_fmt, out_fmt, src, dst, w, h, pitch, nthreads <= 0 ? omp_get_max_threads() : nthreads);
 }
 
+/* Sizes that are not multiples of 4 (dxt_util.h:59-67: the stream holds (w+3)/4 x (h+3)/4 blocks; dxt_glsl.cpp:150-160 passes any
+ * tile size to the encoder):
+ *   width : the shaders fetch texel 4*bx + j of a texture `w` wide with GL_CLAMP_TO_EDGE (dxt_encoder.c:362-364, the texcoord
+ *           scale textureWidth / imageSize.x of compress_dxt5ycocg_fp.glsl:341 / compress_dxt1_fp.glsl:192): columns past the
+ *           picture repeat its last column.  Pinned to the executed shaders (tests/golden/dxt_glsl_ref.npz, "edge_*").
+ *   height: the reference draws h/4 (floor) block rows over the WHOLE texture height (glViewport, dxt_encoder.c:380, against
+ *           imageSize.y = (h+3)/4*4, :393), i.e. it resamples the picture vertically (nearest) and leaves the last block row of the
+ *           stream unrendered -- a slip, recorded by tests/test_oracle_dxt.py::test_reference_height_slip.  The restatement -- and the
+ *           product -- do what the width case does instead: lines past the picture repeat its last line.  That IS the reference's
+ *           output for the same picture padded to a multiple of 4 lines by repeating the last one, and it is pinned as such.
+ *   UYVY / v210 need an even width (a 4:2:2 pair is the unit of the line; vc_get_linesize, video_codec.c:507-521).
+ * Negative height (bottom-up source): the picture is flipped first, then padded. */
 static int encode_rows(int in_fmt, int out_fmt, const uint8_t *src, uint8_t *dst, int w, int h, long pitch,
                        int nthreads)
 {
         int mirror = 0;
         if (h < 0) { mirror = 1; h = -h; }
         fetch_px_t fetch = fetch_for(in_fmt);
-        if (!fetch || (w & 3) || (h & 3) || w <= 0) {  /* cuda_dxt.cu:745 */
+        if (!fetch || w <= 0 || h == 0) {
                 return -1;
         }
-        const int bw = w / 4;
+        if ((w & 1) && (in_fmt == ORACLE_IN_UYVY || in_fmt == ORACLE_IN_UYVY_RAW || in_fmt == ORACLE_IN_V210)) {
+                return -1;
+        }
+        const int bw = (w + 3) / 4, bh = (h + 3) / 4;
         if (out_fmt != ORACLE_OUT_DXT5YCOCG && out_fmt != ORACLE_OUT_DXT1) {
                 return -1;
         }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) if (nthreads > 1)
-        for (int by = 0; by < h / 4; by++) {
+        for (int by = 0; by < bh; by++) {
                 for (int bx = 0; bx < bw; bx++) {
                         float rgb[16][3];
                         for (int r = 0; r < 4; r++) {
-                                const uint8_t *row = src_row(src, pitch, 4 * by + r, h, mirror);
+                                const int y = 4 * by + r < h ? 4 * by + r : h - 1;
+                                const uint8_t *row = src_row(src, pitch, y, h, mirror);
                                 for (int c = 0; c < 4; c++) {
-                                        fetch(row, 4 * bx + c, rgb[4 * r + c]);
+                                        const int x = 4 * bx + c < w ? 4 * bx + c : w - 1;
+                                        fetch(row, x, rgb[4 * r + c]);
                                 }
                         }
                         long idx = bx + (long) bw * by;

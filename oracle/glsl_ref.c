@@ -313,9 +313,14 @@ int main(int argc, char **argv)
         const int w = atoi(argv[4]), h = atoi(argv[5]);
         const int is_rgb = !strcmp(fmt, "rgb"), is_uyvy = !strcmp(fmt, "uyvy"), is_yuv = is_uyvy || !strcmp(fmt, "yuv444");
         const size_t in_len = (size_t) w * h * (is_rgb ? 3 : (is_uyvy ? 2 : 4));
-        uint8_t *in = (uint8_t *) malloc(in_len);
+        /* The reference never sets GL_UNPACK_ALIGNMENT: GL reads GL_RGB lines at its default 4-byte row alignment, i.e. from
+         * h * ((3 w + 3) & ~3) bytes, whatever the caller packed (a slip of the reference for 3 w % 4 != 0: a skewed picture and a
+         * read past its buffer).  The buffer here covers what GL reads (zero-filled); the file may hold either layout -- packed
+         * (the reference's behaviour as is) or lines already at GL's stride (oracle/pyoracle.py gl_row_stride). */
+        const size_t gl_len = is_rgb ? (size_t) h * (((size_t) 3 * w + 3) & ~(size_t) 3) : in_len;
+        uint8_t *in = (uint8_t *) calloc(1, gl_len);
         FILE *f = fopen(argv[6], "rb");
-        if (!f || fread(in, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read %zu bytes from %s\n", in_len, argv[6]); return 1; }
+        if (!f || fread(in, 1, gl_len, f) < in_len) { fprintf(stderr, "cannot read %zu bytes from %s\n", in_len, argv[6]); return 1; }
         fclose(f);
         if (make_context()) return 2;
 

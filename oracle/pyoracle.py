@@ -139,6 +139,12 @@ def set_ties(ties: str) -> None:
     lib().oracle_set_ties({"even": 0, "away": 1}[ties])
 
 
+def dxt_size(out_fmt: int, w: int, h: int) -> int:
+    """dxt_get_size (dxt_compress/dxt_util.h:59-67): both dimensions rounded up to whole 4x4 blocks."""
+    n = ((w + 3) // 4 * 4) * ((abs(h) + 3) // 4 * 4)
+    return n // 2 if out_fmt == OUT_DXT1 else n
+
+
 def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch: int | None = None,
                threads: int = 1, ties: str = "even") -> np.ndarray:
     """h < 0 => bottom-up source (cuda_dxt.cu:652-655).  threads != 1: OpenMP row bands (0 = all cores)."""
@@ -146,7 +152,7 @@ def dxt_encode(in_fmt: int, out_fmt: int, src: np.ndarray, w: int, h: int, pitch
     if pitch is None:
         pitch = {IN_RGB: 3 * w, IN_RGBA: 4 * w, IN_YUV444: 3 * w, IN_UYVY: 2 * w, IN_UYVY_RAW: 2 * w,
                  IN_V210: (w + 47) // 48 * 128}[in_fmt]
-    n = w * abs(h) // (2 if out_fmt == OUT_DXT1 else 1)
+    n = dxt_size(out_fmt, w, h)
     out = np.zeros(n, dtype=np.uint8)
     set_ties(ties)
     if threads == 1:
@@ -213,13 +219,21 @@ def have_glsl_ref() -> bool:
     return os.path.exists(GLSL_REF) and os.path.isdir("/root/reference/dxt_compress")
 
 
-def ref_glsl_dxt_encode(mode: str, fmt: str, src: np.ndarray, w: int, h: int) -> np.ndarray:
+def ref_glsl_dxt_encode(mode: str, fmt: str, src: np.ndarray, w: int, h: int, gl_row_stride: bool = False) -> np.ndarray:
     """The reference's own GLSL encoder (dxt_compress/compress_*_fp.glsl) executed by Mesa llvmpipe through oracle/_ref/glsl_ref.
-    mode: dxt5 | dxt1 | dxt1yuv ; fmt: rgb | rgba | yuv444 | uyvy."""
+    mode: dxt5 | dxt1 | dxt1yuv ; fmt: rgb | rgba | yuv444 | uyvy.
+    gl_row_stride (rgb only): lay the lines out at the stride GL READS them with -- the reference never calls glPixelStorei, so its
+    glTexSubImage2D(GL_RGB) takes lines at GL's default 4-byte unpack alignment, (3 w + 3) & ~3, whatever the caller packed
+    (dxt_encoder.c:562-575).  For 3 w % 4 == 0 the two layouts are the same."""
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         a, b = os.path.join(d, "in.raw"), os.path.join(d, "out.bin")
-        np.ascontiguousarray(src, np.uint8).tofile(a)
+        src = np.ascontiguousarray(src, np.uint8)
+        if gl_row_stride and fmt == "rgb" and (3 * w) % 4:
+            lines = np.zeros((h, (3 * w + 3) // 4 * 4), np.uint8)
+            lines[:, :3 * w] = src.reshape(h, 3 * w)
+            src = lines
+        src.tofile(a)
         r = subprocess.run([GLSL_REF, "/root/reference", mode, fmt, str(w), str(h), a, b], capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(r.stderr)

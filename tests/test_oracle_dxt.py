@@ -71,8 +71,7 @@ def test_structural_invariants(po):
         d1 = po.dxt_encode(po.IN_RGB, po.OUT_DXT1, src, w, h).view(np.uint16).reshape(-1, 4)
         assert (d1[:, 0] >= d1[:, 1]).all()  # 4-colour mode (compress_dxt1_fp.glsl:116-123)
     assert po.dxt_encode(po.IN_RGB, po.OUT_DXT1, synth.s1_random("RGB", 16, 8), 16, 8).size == 16 * 8 // 2  # dxt_util.h:59-67
-    with pytest.raises(ValueError):
-        po.dxt_encode(po.IN_RGB, po.OUT_DXT1, np.zeros(18 * 4 * 3, np.uint8), 18, 4)  # cuda_dxt.cu:745
+    assert po.dxt_encode(po.IN_RGB, po.OUT_DXT1, np.zeros(18 * 5 * 3, np.uint8), 18, 5).size == 20 * 8 // 2  # both dimensions rounded up to 4
 
 
 def test_format_equivalences(po):
@@ -254,6 +253,109 @@ def test_restatement_vs_reference_glsl_big_frames_and_the_tie_rule(po, fmt):
             assert changed.size == 1 and (abs(a[changed[0]] - b[changed[0]]) == 1 or bin(a[changed[0]] ^ b[changed[0]]).count("1") <= 2), (mode, i, a, b)
 
 
+# ---- sizes that are not multiples of 4 (dxt_util.h:59-67; VERDICT r5 "What's missing" #3) ----
+def _golden_generator():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_glsl_golden", os.path.join(os.path.dirname(__file__), "golden", "make_glsl_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _edge_cases():
+    for key in GLSL_GOLD.files:
+        if key.startswith("edge_out_"):
+            _, _, size, fmt, mode = key.split("_")
+            w, h = (int(x) for x in size.split("x"))
+            yield w, h, fmt, mode
+
+
+@pytest.mark.parametrize("w,h,fmt,mode", sorted(set(_edge_cases())))
+def test_restatement_reproduces_the_reference_glsl_shaders_at_unaligned_sizes(po, w, h, fmt, mode):
+    """Widths = 1, 2, 3 (mod 4): the shaders' own GL_CLAMP_TO_EDGE fetches, the reference as it is.  Heights != 0 (mod 4): the reference's
+    output for the picture padded with copies of its last line (generator: tests/golden/make_glsl_golden.py).  Bit for bit, every block."""
+    src = GLSL_GOLD[f"edge_in_{w}x{h}_{fmt}"]
+    gold = GLSL_GOLD[f"edge_out_{w}x{h}_{fmt}_{mode}"]
+    got = _oracle_for(po, fmt, mode, src, w, h)
+    assert got.size == ((w + 3) // 4 * 4) * ((h + 3) // 4 * 4) // (1 if mode == "dxt5" else 2)  # dxt_get_size
+    assert np.array_equal(got, gold)
+
+
+def test_unaligned_size_is_the_padded_picture(po):
+    """What the rule amounts to: the blocks of a w x h picture == the blocks of the picture padded to whole blocks by repeating its last
+    column and last line -- and a bottom-up source (negative height) is flipped first, then padded."""
+    rng = np.random.default_rng(5)
+    for w, h in ((10, 6), (7, 9), (1, 1), (33, 2), (1366, 5)):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        W4, H4 = (w + 3) // 4 * 4, (h + 3) // 4 * 4
+        padded = np.pad(rgb, ((0, H4 - h), (0, W4 - w), (0, 0)), mode="edge")
+        for out in (po.OUT_DXT5YCOCG, po.OUT_DXT1):
+            assert np.array_equal(po.dxt_encode(po.IN_RGB, out, rgb, w, h), po.dxt_encode(po.IN_RGB, out, padded, W4, H4)), (w, h)
+            flipped = np.pad(rgb[::-1], ((0, H4 - h), (0, W4 - w), (0, 0)), mode="edge")
+            assert np.array_equal(po.dxt_encode(po.IN_RGB, out, rgb, w, -h), po.dxt_encode(po.IN_RGB, out, flipped, W4, H4)), (w, h)
+    for w, h in ((10, 6), (2, 3), (1366, 5)):  # 4:2:2: the last pixel repeats with its own chroma pair
+        uyvy = rng.integers(0, 256, (h, w // 2, 4), dtype=np.uint8)
+        W4, H4 = (w + 3) // 4 * 4, (h + 3) // 4 * 4
+        last = uyvy[:, -1:, :].copy()
+        last[:, :, 1] = last[:, :, 3]
+        padded = np.pad(np.concatenate([uyvy] + [last] * ((W4 - w) // 2), axis=1), ((0, H4 - h), (0, 0), (0, 0)), mode="edge")
+        for pin in (po.IN_UYVY, po.IN_UYVY_RAW):
+            assert np.array_equal(po.dxt_encode(pin, po.OUT_DXT1, uyvy, w, h), po.dxt_encode(pin, po.OUT_DXT1, padded, W4, H4)), (w, h)
+    with pytest.raises(ValueError):
+        po.dxt_encode(po.IN_UYVY, po.OUT_DXT1, np.zeros(12, np.uint8), 3, 2)  # 4:2:2 needs an even width
+
+
+@pytest.mark.parametrize("w,h", [(16, 10), (8, 6), (8, 486)])
+def test_reference_height_slip(po, w, h):
+    """Record of the ONE deliberate deviation: with a height that is not a multiple of 4 the reference draws h/4 block rows
+    over the whole texture height (glViewport(.., height / 4), dxt_encoder.c:380, against imageSize.y = (height + 3) / 4 * 4, :393): block
+    row `by` is cut from lines floor(h * ((by + 0.5) / (h / 4) + (i - 1.5) / H4)), i = 0..3 -- a vertical resampling -- and the last block
+    row of the stream is never rendered.  The committed vectors are the reference's shaders executed on exactly such sizes."""
+    edge_input = _golden_generator().edge_input
+    src = edge_input(w, h, "RGBA").reshape(h, w, 4)
+    ref = GLSL_GOLD[f"slip_h_{w}x{h}_RGBA_dxt5"].reshape((h + 3) // 4, -1)
+    H4 = (h + 3) // 4 * 4
+    lines = [min(h - 1, max(0, int(np.floor(h * ((by + 0.5) / (h // 4) + (i - 1.5) / H4))))) for by in range(h // 4) for i in range(4)]
+    resampled = np.ascontiguousarray(src[lines])
+    assert np.array_equal(po.dxt_encode(po.IN_RGBA, po.OUT_DXT5YCOCG, resampled, w, 4 * (h // 4)).reshape(h // 4, -1), ref[:h // 4])
+    assert not ref[h // 4:].any()          # unrendered (glsl_ref starts from a zeroed buffer; the reference from whatever the FBO held)
+    ours = po.dxt_encode(po.IN_RGBA, po.OUT_DXT5YCOCG, src, w, h).reshape((h + 3) // 4, -1)
+    assert lines[:4] != [0, 1, 2, 3] or lines[-4:] != list(range(4 * (h // 4) - 4, 4 * (h // 4)))   # it IS a resampling
+    assert ours[h // 4:].any()             # ... where this implementation encodes the remaining lines
+
+
+@pytest.mark.parametrize("w,h", [(10, 8), (6, 8)])
+def test_reference_rgb_unpack_alignment_slip(po, w, h):
+    """Second record: the reference uploads GL_RGB lines without ever setting GL_UNPACK_ALIGNMENT, so for 3 w % 4 != 0 GL takes line y at
+    byte y * ((3 w + 3) & ~3) of a buffer packed at 3 w (dxt_encoder.c:562-575; dxt_glsl.cpp:169 packs at 3 w): a skewed picture, and a read
+    past the end.  The committed vectors are the shaders run on a packed buffer (zero-filled behind its end)."""
+    edge_input = _golden_generator().edge_input
+    packed = edge_input(w, h, "RGB").ravel()
+    stride = (3 * w + 3) // 4 * 4
+    flat = np.concatenate([packed, np.zeros(stride * h - packed.size, np.uint8)])
+    skewed = np.stack([flat[y * stride: y * stride + 3 * w] for y in range(h)])
+    ref = GLSL_GOLD[f"slip_rgb_{w}x{h}_dxt1"]
+    assert np.array_equal(po.dxt_encode(po.IN_RGB, po.OUT_DXT1, skewed, w, h), ref)
+    assert not np.array_equal(po.dxt_encode(po.IN_RGB, po.OUT_DXT1, packed, w, h), ref)
+
+
+def test_decode_oracle_at_unaligned_sizes(po):
+    """Receiver side: the stream holds (w+3)/4 x (h+3)/4 blocks, the picture shown is w x h (dxt_decoder.c:146-149,368-389): decoding the
+    blocks at the padded size and cropping is the same thing."""
+    rng = np.random.default_rng(11)
+    for w, h in ((10, 6), (7, 9), (1, 1), (1366, 5), (6, 4)):
+        W4, H4 = (w + 3) // 4 * 4, (h + 3) // 4 * 4
+        for fmt, bs in ((po.OUT_DXT5YCOCG, 16), (po.OUT_DXT1, 8), (po.OUT_DXT1_YUV, 8)):
+            blocks = rng.integers(0, 256, W4 * H4 // 16 * bs, dtype=np.uint8)
+            for out, bpp in (("RGB", 3), ("RGBA", 4), ("BGR", 3), ("UYVY", 2)):
+                if out == "UYVY" and w % 2:
+                    with pytest.raises(ValueError):
+                        po.dxt_decode(fmt, out, blocks, w, h)
+                    continue
+                full = po.dxt_decode(fmt, out, blocks, W4, H4).reshape(H4, W4 * bpp)
+                assert np.array_equal(po.dxt_decode(fmt, out, blocks, w, h).reshape(h, -1)[:, :w * bpp], full[:h, :w * bpp]), (w, h, fmt, out)
+
+
 def test_live_reference_glsl_when_available(po):
     """In the build container the shaders are run live on other geometries than the committed vectors."""
     if not po.have_glsl_ref():
@@ -262,6 +364,10 @@ def test_live_reference_glsl_when_available(po):
                                     (1920, 64, "UYVY", "dxt5", "S2"), (256, 256, "RGB", "dxt1", "S1")]:
         src = synth.frame(kind, fmt, w, h, 9)
         assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), po.ref_glsl_dxt_encode(mode, fmt.lower(), src, w, h)), (w, h, fmt, mode)
+    rng = np.random.default_rng(21)
+    for (w, h, fmt, mode) in [(1366, 768, "UYVY", "dxt5"), (1998, 40, "RGBA", "dxt1"), (50, 20, "RGB", "dxt5"), (2, 8, "UYVY", "dxt1yuv"), (721, 12, "RGBA", "dxt5")]:
+        src = rng.integers(0, 256, (h, w * {"RGB": 3, "RGBA": 4, "UYVY": 2}[fmt]), dtype=np.uint8)
+        assert np.array_equal(_oracle_for(po, fmt, mode, src, w, h), po.ref_glsl_dxt_encode(mode, fmt.lower(), src, w, h, gl_row_stride=True)), (w, h, fmt, mode)
 
 
 def test_decode_oracle_vs_the_reference_gl_decoder_when_available(po):
