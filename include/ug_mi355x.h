@@ -162,10 +162,15 @@ int         ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src
 
 /* Fused pixel-format unpack + colour conversion + 4x4 block encode, one pass, no
  * intermediate buffer.  `in` in {RGB, RGBA, UYVY, UYVY_RAW, V210, YUV444}.
- * Requirements (cuda_dxt.cu:745): width % 4 == 0, |height| % 4 == 0, src 16-B aligned, dst 16-B aligned, pitch % 4 == 0
- * (V210: pitch % 16 == 0 and >= 32 * ceil(width / 12), which vc_get_linesize's 128-byte padding always satisfies; any
- * width % 4 == 0 is taken, e.g. 1280 or 2048 -- the partial last 12-pixel unit of a line is read whole and encoded in part).
- * These use UG_DXT_TIES_DEFAULT. */
+ * Requirements: src 16-B aligned, dst 16-B aligned, pitch % 4 == 0 (V210: pitch % 16 == 0 and >= 32 * ceil(width / 12), which
+ * vc_get_linesize's 128-byte padding always satisfies; the partial last 12-pixel unit of a line is read whole and encoded in part).
+ * ANY width and |height| >= 1 is taken, as dxt_encoder_create does (dxt_compress/dxt_encoder.c:235, called with any tile size by
+ * src/video_compress/dxt_glsl.cpp:150-160): the stream holds (width+3)/4 x (height+3)/4 blocks (dxt_get_size, dxt_util.h:59-67);
+ * columns past the picture repeat its last column -- the shaders' GL_CLAMP_TO_EDGE fetches (dxt_encoder.c:362-364,
+ * compress_dxt5ycocg_fp.glsl:45-55,341), bit for bit -- and lines past the picture repeat its last line (the one deliberate deviation:
+ * the reference resamples such a picture vertically and leaves the last block row unrendered, dxt_encoder.c:380 vs :393,653-671;
+ * INTEGRATION.md).  With a width that is not a multiple of 4, RGB / YUV444 lines may have any pitch (3 * width bytes), RGBA and
+ * UYVY pitch % 4 == 0.  UYVY / V210 need an even width.  These use UG_DXT_TIES_DEFAULT. */
 int ug_hip_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev, void *dst_dev,
                       int width, int height, int src_pitch, ug_hip_stream_t stream);
 /* Same, `frames` images per launch (tiles of one frame or consecutive frames):
@@ -179,11 +184,12 @@ int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src_dev
                                int width, int height, int src_pitch, int frames,
                                size_t src_frame_stride, size_t dst_frame_stride, int ties,
                                ug_hip_stream_t stream);
-/* bytes produced for one image */
+/* bytes produced for one image: ((width+3)/4*4) * ((|height|+3)/4*4), half of it for DXT1 (dxt_get_size, dxt_util.h:59-67) */
 size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height);
 
 /* Signature-compatible counterparts of cuda_dxt.h (src = tightly packed 3 B/px device
- * buffer; cuda_yuv_* take packed Y,U,V triplets).  These are asynchronous too. */
+ * buffer; cuda_yuv_* take packed Y,U,V triplets).  These are asynchronous too.  They keep that interface's limits: size_x and
+ * |size_y| must be multiples of 4 (cuda_dxt.cu:745 returns -1 otherwise; here UG_HIP_EINVAL). */
 int ug_hip_rgb_to_dxt1(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_rgb_to_dxt1, cuda_dxt.h:41 */
 int ug_hip_yuv_to_dxt1(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_yuv_to_dxt1, cuda_dxt.h:62 */
 int ug_hip_rgb_to_dxt6(const void *src, void *out, int size_x, int size_y, ug_hip_stream_t stream); /* cuda_rgb_to_dxt6, cuda_dxt.h:83 */
@@ -196,7 +202,8 @@ int ug_hip_yuv422_to_yuv444(const void *src, void *out, int pix_count, ug_hip_st
  * ---------------------------------------------------------------------------------- */
 /* `in` in {UG_DXT1, UG_DXT5_YCOCG}; `out` in {UG_PF_RGB, UG_PF_BGR, UG_PF_RGBA, UG_PF_UYVY}.  RGBA output honours
  * rshift/gshift/bshift exactly like the decompress modules' reconfigure() arguments (video_decompress.h:85-100);
- * UYVY follows dxt_compress/rgba_to_yuv422.glsl.  width % 4 == 0, height % 4 == 0, dst_pitch 0 = packed. */
+ * UYVY follows dxt_compress/rgba_to_yuv422.glsl.  dst_pitch 0 = packed.  Any width, height >= 1 (UYVY: even width): the stream
+ * holds (width+3)/4 x (height+3)/4 blocks, width x height pixels are written (dxt_compress/dxt_decoder.c:146-149,368-389). */
 int ug_hip_dxt_decode(ug_dxt_t in, ug_pixfmt_t out, const void *src_dev, void *dst_dev, int width, int height,
                       int dst_pitch, int rshift, int gshift, int bshift, ug_hip_stream_t stream);
 /* Same with the tie rule given explicitly (UG_DXT_TIES_*): it decides the float -> unorm8 writes of the UYVY output pass and of the

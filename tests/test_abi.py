@@ -34,8 +34,11 @@ def test_no_torch_or_cxx_types_in_the_abi():
 def test_error_paths_without_a_gpu():
     l = lib.load()
     # argument validation happens before any device call (cuda_dxt.cu:745 semantics: -1)
-    assert l.ug_hip_dxt_encode(lib.PF_RGB, lib.DXT1, 16, 16, 18, 4, 0, None) == lib.EINVAL       # width % 4
-    assert l.ug_hip_dxt_encode(lib.PF_RGB, lib.DXT1, 16, 16, 16, 6, 0, None) == lib.EINVAL       # height % 4
+    assert l.ug_hip_rgb_to_dxt1(16, 16, 18, 4, None) == lib.EINVAL                              # width % 4: the cuda_dxt.h-shaped entry points keep
+    assert l.ug_hip_yuv_to_dxt6(16, 16, 16, 6, None) == lib.EINVAL                              # height % 4: that interface's limit (cuda_dxt.cu:745)
+    assert l.ug_hip_dxt_encode(lib.PF_UYVY, lib.DXT1, 16, 16, 17, 4, 0, None) == lib.EINVAL      # 4:2:2: even width (any other size is taken, dxt_util.h:59-67)
+    assert l.ug_hip_dxt_encode(lib.PF_RGBA, lib.DXT1, 16, 16, 18, 4, 74, None) == lib.EINVAL     # RGBA pitch % 4
+    assert l.ug_hip_dxt_decode(lib.DXT1, lib.PF_UYVY, 16, 16, 17, 4, 0, 0, 8, 16, None) == lib.EINVAL  # UYVY output: even width
     assert l.ug_hip_dxt_encode(lib.PF_RGB, lib.DXT1, 8, 16, 16, 4, 0, None) == lib.EINVAL        # src alignment
     assert l.ug_hip_dxt_encode(lib.PF_RGB, lib.DXT1, None, 16, 16, 4, 0, None) == lib.EINVAL     # NULL
     assert l.ug_hip_dxt_encode(lib.PF_RG48, lib.DXT1, 16, 16, 16, 4, 0, None) == lib.EUNSUPP
@@ -44,6 +47,7 @@ def test_error_paths_without_a_gpu():
     assert b"unsupported" in l.ug_hip_last_error_string()
     assert l.ug_hip_pixfmt_supported(lib.PF_V210, lib.PF_UYVY) == 1 and l.ug_hip_pixfmt_supported(lib.PF_RGB, lib.PF_V210) == 0
     assert l.ug_hip_dxt_size(lib.DXT1, 1920, 1080) == 1036800 and l.ug_hip_dxt_size(lib.DXT5_YCOCG, 3840, -2160) == 8294400
+    assert l.ug_hip_dxt_size(lib.DXT5_YCOCG, 1366, 766) == 1368 * 768 and l.ug_hip_dxt_size(lib.DXT1, 5, -5) == 32   # dxt_get_size: whole blocks
     # linesizes == vc_get_linesize (video_codec.c:507-521; SURVEY.md 8 geometry table)
     assert l.ug_hip_linesize(lib.PF_V210, 1920) == 5120 and l.ug_hip_linesize(lib.PF_V210, 7680) == 20480
     assert l.ug_hip_linesize(lib.PF_UYVY, 3841) == 7684 and l.ug_hip_linesize(lib.PF_RGB, 1920) == 5760

@@ -178,7 +178,7 @@ def test_error_codes_on_device(hip):
     from ultragrid_amd import lib as L
     buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     with pytest.raises(L.UgHipError) as e:
-        hip.dxt_encode(L.PF_RGB, L.DXT1, buf, 18, 4)
+        hip.dxt_encode(L.PF_UYVY, L.DXT1, buf, 17, 4)       # (18 x 4 RGB is a picture like any other: tests/test_gpu_dxt_edge.py)
     assert e.value.rc == L.EINVAL
     with pytest.raises(L.UgHipError) as e:
         hip.dxt_encode(L.PF_RG48, L.DXT1, buf, 16, 4)

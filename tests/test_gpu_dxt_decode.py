@@ -87,7 +87,7 @@ def test_decode_error_codes(hip):
     from ultragrid_amd import lib as L
     b = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     with pytest.raises(L.UgHipError) as e:
-        hip.dxt_decode(L.DXT1, L.PF_RGB, b, 18, 4)
+        hip.dxt_decode(L.DXT1, L.PF_UYVY, b, 17, 4)         # (18 x 4 is a picture like any other: tests/test_gpu_dxt_edge.py)
     assert e.value.rc == L.EINVAL
     with pytest.raises(L.UgHipError) as e:
         hip.dxt_decode(L.DXT1, L.PF_V210, b, 48, 4)

@@ -162,10 +162,41 @@ __device__ __forceinline__ double div_const(double x)
 }
 
 struct OutArgs {
+        static constexpr bool kEdge = false;
         uint8_t *dst;
         long pitch;
         int rs, gs, bs;
 };
+// Pictures whose width or height is not a multiple of 4: the stream holds (w+3)/4 x (h+3)/4 blocks, the picture shown is w x h
+// (dxt_decoder.c:146-149,368-389; dxt_util.h:59-67).  They run the EDGE instantiations of the kernels below, whose row stores drop the
+// lines and pixels past the picture and take whatever alignment a line of such a width has; multiples of 4 run the code they always ran.
+struct OutArgsE : OutArgs {
+        static constexpr bool kEdge = true;
+        int w, h;
+};
+template <bool EDGE> struct ArgsOf { typedef OutArgs type; };
+template <> struct ArgsOf<true> { typedef OutArgsE type; };
+typedef uint32_t u32_any __attribute__((aligned(1)));
+
+// EDGE only: one row of block column bx as the bytes it occupies in memory -- 4 words RGBA, 3 words RGB / BGR, 2 words UYVY
+__device__ __forceinline__ void put_row_edge(int words, const OutArgsE &o, int y, int bx, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+        if (y >= o.h) return; // (scalar) block rows end below the picture
+        const int valid = o.w - 4 * bx; // pixel columns of this block inside the picture; `words` = bytes per pixel
+        uint8_t *at = o.dst + (long) y * o.pitch + bx * (4 * words);
+        const uint32_t w[4] = { w0, w1, w2, w3 };
+        if (valid >= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                        if (k < words) *((u32_any *) at + k) = w[k]; // (3 * width bytes per line: a line starts wherever it starts)
+                }
+        } else { // the block the right edge cuts: one lane per block row
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                        if (i < valid * words) at[i] = (uint8_t) (w[i / 4] >> (8 * (i % 4)));
+                }
+        }
+}
 
 // one pixel in the form the row store wants it: RGBA = the final 32-bit pixel; RGB = R | G << 8 | B << 16; BGR = B | G << 8 | R << 16;
 // UYVY = R | G << 8 | B << 16 (the shader input)
@@ -180,9 +211,19 @@ __device__ __forceinline__ uint32_t pack_px(const OutArgs &o, uint32_t R, uint32
 }
 
 // store one decoded row (4 pixels as pack_px made them) of block column bx
-template <int OUT, bool AWAY>
-__device__ __forceinline__ void store_words(const OutArgs &o, int y, int bx, const uint32_t (&p)[4], const float *unorm)
+template <int OUT, bool AWAY, class A>
+__device__ __forceinline__ void store_words(const A &o, int y, int bx, const uint32_t (&p)[4], const float *unorm)
 {
+        if constexpr (A::kEdge) {
+                if (OUT == UG_PF_RGBA) {
+                        put_row_edge(4, o, y, bx, p[0], p[1], p[2], p[3]);
+                } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
+                        put_row_edge(3, o, y, bx, p[0] | p[1] << 24, (p[1] >> 8) | p[2] << 16, (p[2] >> 16) | p[3] << 8, 0);
+                } else {
+                        put_row_edge(2, o, y, bx, rgb_pair_to_uyvy<AWAY>(p[0], p[1], unorm), rgb_pair_to_uyvy<AWAY>(p[2], p[3], unorm), 0, 0);
+                }
+                return;
+        }
         uint8_t *row = o.dst + (long) y * o.pitch;
         if (OUT == UG_PF_RGBA) {
                 ug::st_stream((uint4 *) row + bx, make_uint4(p[0], p[1], p[2], p[3]));
@@ -197,8 +238,8 @@ __device__ __forceinline__ void store_words(const OutArgs &o, int y, int bx, con
 }
 
 // the same from 4 pixels packed R | G<<8 | B<<16 (the DXT1 palettes)
-template <int OUT, bool AWAY>
-__device__ __forceinline__ void store_row(const OutArgs &o, int y, int bx, const uint32_t (&px)[4], const float *unorm)
+template <int OUT, bool AWAY, class A>
+__device__ __forceinline__ void store_row(const A &o, int y, int bx, const uint32_t (&px)[4], const float *unorm)
 {
         uint32_t p[4];
 #pragma unroll
@@ -217,8 +258,8 @@ __device__ __forceinline__ double sel8(const double (&t)[8], int i)
 }
 
 // `pal` = this lane's column of a [4][64] table of (Co, Cg) pairs in LDS
-template <int OUT, bool AWAY>
-__device__ __noinline__ void decode_block_exact(uint4 q, OutArgs o, int bx, int by, double2 *pal, const float *unorm) // (o by value: a reference would put the kernel's copy into scratch memory)
+template <int OUT, bool AWAY, class A>
+__device__ __noinline__ void decode_block_exact(uint4 q, A o, int bx, int by, double2 *pal, const float *unorm) // (o by value: a reference would put the kernel's copy into scratch memory)
 {
         unsigned long long ac = (unsigned long long) q.x | (unsigned long long) q.y << 32;
         unsigned long long cc = (unsigned long long) q.z | (unsigned long long) q.w << 32;
@@ -305,8 +346,8 @@ __device__ __forceinline__ uint32_t clamp_shift(int t) // min(max(t >> 20, 0), 2
 }
 
 // one block: fixed-point tables -> 16 pixels -> rows stored; guarded blocks decoded again exactly
-template <int OUT, bool AWAY, int MODE>
-__device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o, int bx, int by, int (*lds_a)[64], const double *lds_rs, const float *unorm, int lane,
+template <int OUT, bool AWAY, int MODE, class ARGS>
+__device__ __forceinline__ void dxt5_decode_one(const uint4 q, const ARGS &o, int bx, int by, int (*lds_a)[64], const double *lds_rs, const float *unorm, int lane,
                                                 unsigned *flagged)
 {
         bool redo = MODE == 1;
@@ -369,12 +410,18 @@ __device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o,
                         if (OUT == UG_PF_RGBA) {
                                 const uint4 v4 = make_uint4(pk2_u8(t0[0], t1[0], t2[0], opaque), pk2_u8(t0[1], t1[1], t2[1], opaque),
                                                             pk2_u8(t0[2], t1[2], t2[2], opaque), pk2_u8(t0[3], t1[3], t2[3], opaque));
-                                ug::st_stream((uint4 *) row + bx, v4);
+                                if constexpr (ARGS::kEdge) put_row_edge(4, o, 4 * by + y, bx, v4.x, v4.y, v4.z, v4.w);
+                                else ug::st_stream((uint4 *) row + bx, v4);
                         } else if (OUT == UG_PF_RGB || OUT == UG_PF_BGR) {
-                                uint32_t *d = (uint32_t *) row + 3 * bx;
-                                ug::st_stream(d, pk2_u8(t0[0], t1[0], t2[0], t0[1]));
-                                ug::st_stream(d + 1, pk2_u8(t1[1], t2[1], t0[2], t1[2]));
-                                ug::st_stream(d + 2, pk2_u8(t2[2], t0[3], t1[3], t2[3]));
+                                if constexpr (ARGS::kEdge) {
+                                        put_row_edge(3, o, 4 * by + y, bx, pk2_u8(t0[0], t1[0], t2[0], t0[1]), pk2_u8(t1[1], t2[1], t0[2], t1[2]),
+                                                     pk2_u8(t2[2], t0[3], t1[3], t2[3]), 0);
+                                } else {
+                                        uint32_t *d = (uint32_t *) row + 3 * bx;
+                                        ug::st_stream(d, pk2_u8(t0[0], t1[0], t2[0], t0[1]));
+                                        ug::st_stream(d + 1, pk2_u8(t1[1], t2[1], t0[2], t1[2]));
+                                        ug::st_stream(d + 2, pk2_u8(t2[2], t0[3], t1[3], t2[3]));
+                                }
                         } else { // UYVY: rgba_to_yuv422.glsl in fixed point; a pair with a value near a rounding boundary goes through the shader's own fp32 operations
                                 uint32_t w2[2];
 #pragma unroll
@@ -393,7 +440,8 @@ __device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o,
                                         if (un < 2u * kGuardUyvy) w2[k] = rgb_pair_to_uyvy_call<AWAY>(ra | ga << 8 | ba << 16, rb | gb << 8 | bb << 16, unorm);
 #endif
                                 }
-                                ug::st_stream((uint2 *) row + bx, make_uint2(w2[0], w2[1]));
+                                if constexpr (ARGS::kEdge) put_row_edge(2, o, 4 * by + y, bx, w2[0], w2[1], 0, 0);
+                                else ug::st_stream((uint2 *) row + bx, make_uint2(w2[0], w2[1]));
                         }
                 }
                 redo = MODE == 0 && near < 2u * kGuard;
@@ -404,8 +452,8 @@ __device__ __forceinline__ void dxt5_decode_one(const uint4 q, const OutArgs &o,
         if (redo) decode_block_exact<OUT, AWAY>(q, o, bx, by, (double2 *) &lds_a[0][0] + lane, unorm);
 }
 
-template <int OUT, bool AWAY, int MODE> // MODE 0: fixed point + guard + exact fallback (the product); 1: exact only; 2: fixed point only (tests)
-__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, OutArgs o, int bw, int bh, unsigned *__restrict__ flagged)
+template <int OUT, bool AWAY, int MODE, bool EDGE> // MODE 0: fixed point + guard + exact fallback (the product); 1: exact only; 2: fixed point only (tests)
+__global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__restrict__ src, typename ArgsOf<EDGE>::type o, int bw, int bh, unsigned *__restrict__ flagged)
 {
         // per-lane tables, one region per wave, entry-major inside it so that a wave's accesses to one entry are contiguous (conflict-free
         // whatever the indices): rows 0-7 the luma entries, rows 8 + 4 j + k = palette entry k of output byte j.  The exact path overlays
@@ -427,8 +475,8 @@ __global__ __launch_bounds__(256) void dxt5ycocg_decode_kernel(const uint4 *__re
 
 // YUV = true: DXT1_YUV -- the palette holds Y, Cb, Cr and goes through the display matrix of
 // dxt_compress/display_dxt1_yuv_fp.glsl:21-32 (fp32, one operation per shader operation) before the 8-bit write.
-template <int OUT, bool YUV, bool AWAY>
-__global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restrict__ src, OutArgs o, int bw, int bh)
+template <int OUT, bool YUV, bool AWAY, bool EDGE>
+__global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restrict__ src, typename ArgsOf<EDGE>::type o, int bw, int bh)
 {
         __shared__ float unorm[OUT == UG_PF_UYVY ? 256 : 1];
         fill_unorm<OUT>(unorm);
@@ -492,7 +540,8 @@ __global__ __launch_bounds__(256) void dxt1_decode_kernel(const uint2 *__restric
                                 word[p] = (uint32_t) unorm8_out<AWAY>(ua + ub) | ((y4 >> (8 * ca)) & 0xff) << 8 | (uint32_t) unorm8_out<AWAY>(va + vb) << 16 |
                                           ((y4 >> (8 * cb)) & 0xff) << 24;
                         }
-                        ug::st_stream((uint2 *) (o.dst + (long) (4 * by + y) * o.pitch) + bx, make_uint2(word[0], word[1]));
+                        if constexpr (EDGE) put_row_edge(2, o, 4 * by + y, bx, word[0], word[1], 0, 0);
+                        else ug::st_stream((uint2 *) (o.dst + (long) (4 * by + y) * o.pitch) + bx, make_uint2(word[0], word[1]));
                 }
                 return;
         }
@@ -549,10 +598,10 @@ __global__ void selftest_div_kernel(unsigned *mismatches)
 int g_dxt5_mode = 0;
 unsigned *g_dxt5_flagged = nullptr;
 
-template <int OUT, bool AWAY>
-int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
+template <int OUT, bool AWAY, bool EDGE>
+int launch_decode_e(ug_dxt_t in, const void *src, const typename ArgsOf<EDGE>::type &o, int w, int h, hipStream_t st)
 {
-        const int bw = w / 4, bh = h / 4;
+        const int bw = (w + 3) / 4, bh = (h + 3) / 4; // dxt_util.h:59-67
         const dim3 block(64, 4), grid((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
         if (in == UG_DXT5_YCOCG) {
                 // The fixed-point RGBA path keeps one palette column per output byte 0..2 and writes alpha to byte 3: right for the shifts
@@ -560,19 +609,32 @@ int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h
                 // may ask, dxt_glsl.c:178) goes through the exact kernel, whose pack_px places the channels by shifting.
                 const bool rgb_low = OUT != UG_PF_RGBA || ((1 << (o.rs >> 3)) | (1 << (o.gs >> 3)) | (1 << (o.bs >> 3))) == 7;
                 if (g_dxt5_mode == 1 || !rgb_low) {
-                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 1>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 1, EDGE>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 } else if (g_dxt5_mode == 2) {
-                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 2>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 2, EDGE>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 } else {
-                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 0>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
+                        hipLaunchKernelGGL((dxt5ycocg_decode_kernel<OUT, AWAY, 0, EDGE>), grid, block, 0, st, (const uint4 *) src, o, bw, bh, g_dxt5_flagged);
                 }
         } else if (in == UG_DXT1_YUV) {
-                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true, AWAY>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, true, AWAY, EDGE>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         } else {
-                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, false, AWAY>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
+                hipLaunchKernelGGL((dxt1_decode_kernel<OUT, false, AWAY, EDGE>), grid, block, 0, st, (const uint2 *) src, o, bw, bh);
         }
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
+}
+
+template <int OUT, bool AWAY>
+int launch_decode_t(ug_dxt_t in, const void *src, const OutArgs &o, int w, int h, hipStream_t st)
+{
+        if ((w & 3) || (h & 3)) {
+                OutArgsE e;
+                (OutArgs &) e = o;
+                e.w = w;
+                e.h = h;
+                return launch_decode_e<OUT, AWAY, true>(in, src, e, w, h, st);
+        }
+        return launch_decode_e<OUT, AWAY, false>(in, src, o, w, h, st);
 }
 
 template <int OUT>
@@ -595,9 +657,16 @@ extern "C" int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *sr
                 return UG_HIP_EINVAL;
         }
         if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_dxt_decode");
-        if (!src_dev || !dst_dev || width <= 0 || height <= 0 || (width & 3) || (height & 3) || (15 & (uintptr_t) dst_dev) ||
-            ((in == UG_DXT5_YCOCG ? 15 : 7) & (uintptr_t) src_dev) || (height / 4 + 3) / 4 > 65535) {
+        if (!src_dev || !dst_dev || width <= 0 || height <= 0 || (15 & (uintptr_t) dst_dev) ||
+            ((in == UG_DXT5_YCOCG ? 15 : 7) & (uintptr_t) src_dev) || ((height + 3) / 4 + 3) / 4 > 65535) {
                 ug::set_last_error_msg("ug_hip_dxt_decode: bad size or alignment");
+                return UG_HIP_EINVAL;
+        }
+        // any width and height >= 1 (dxt_decoder.c:146-149: the texture is created width x height over a stream of whole blocks);
+        // the 4:2:2 output is made of pixel pairs (rgba_to_yuv422.glsl renders width / 2 texels)
+        const bool edge = (width & 3) || (height & 3);
+        if (out == UG_PF_UYVY && (width & 1)) {
+                ug::set_last_error_msg("ug_hip_dxt_decode: UYVY output needs an even width");
                 return UG_HIP_EINVAL;
         }
         if (in != UG_DXT1 && in != UG_DXT1_YUV && in != UG_DXT5_YCOCG) {
@@ -616,16 +685,16 @@ extern "C" int ug_hip_dxt_decode_ex(ug_dxt_t in, ug_pixfmt_t out, const void *sr
         hipStream_t st = (hipStream_t) stream;
         switch (out) {
         case UG_PF_RGBA:
-                if (dst_pitch & 15) break;
+                if (dst_pitch & (edge ? 3 : 15)) break;
                 return launch_decode<UG_PF_RGBA>(in, ties, src_dev, o, width, height, st);
         case UG_PF_RGB:
-                if (dst_pitch & 3) break;
+                if ((dst_pitch & 3) && !edge) break;
                 return launch_decode<UG_PF_RGB>(in, ties, src_dev, o, width, height, st);
         case UG_PF_BGR:
-                if (dst_pitch & 3) break;
+                if ((dst_pitch & 3) && !edge) break;
                 return launch_decode<UG_PF_BGR>(in, ties, src_dev, o, width, height, st);
         case UG_PF_UYVY:
-                if (dst_pitch & 7) break;
+                if (dst_pitch & (edge ? 3 : 7)) break;
                 return launch_decode<UG_PF_UYVY>(in, ties, src_dev, o, width, height, st);
         default:
                 ug::set_last_error_msg("ug_hip_dxt_decode: unsupported output format");

@@ -21,6 +21,13 @@
 // The work is VALU-bound: no LDS staging is needed because each input
 // byte is read by exactly one lane.  LDS only holds each lane's own lookup columns of the fast
 // index stages (IndexTables below): the threshold / palette pair a pixel's one open comparison needs.
+//
+// Frame sizes that are not multiples of 4 (dxt_util.h:59-67, dxt_encoder.c:362-364,380-394; what -c RTDXT accepts): the stream holds
+// (w+3)/4 x (h+3)/4 blocks and pixels past the picture repeat its last column / last line (oracle/dxt_oracle.c, encode_rows, says how
+// that is pinned to the executed shaders and where the reference itself slips).  Such frames run the EDGE instantiation of the same
+// kernel: line numbers are clamped on the scalar unit, the one lane per block row that holds the cut block fills its registers
+// through Loader::load_edge (nothing past the last byte of a line is read), and lines may start at any alignment the packed width
+// gives them.  Frames whose sizes ARE multiples of 4 never see any of it: their instantiation is the code it was before.
 #include "ug_common.h"
 
 #ifndef UG_DXT_TBUF
@@ -85,6 +92,7 @@ __device__ __forceinline__ uint32_t palette_index(float d0, float d1, float d2, 
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_any __attribute__((aligned(1))); // a dword wherever it lies (lines of 3 * width bytes, EDGE instantiations only)
 
 // acc = 2*acc + bit in ONE VALU instruction: the boolean lives in an SGPR lane mask (it is the
 // result of v_cmp / SALU mask logic) and is consumed as the carry-in of v_addc_co_u32.
@@ -195,12 +203,35 @@ template <bool YUV>
 struct Loader3 {
         static constexpr int kBlocks = 1;
         uint32_t w[4][3];
+        template <bool EDGE = false>
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        const uint32_t *p = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 12u));
-                        w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+                        if (EDGE) { // 3 * width bytes per line: a line starts wherever it starts
+                                const u32_any *p = (const u32_any *) (src + ((uint32_t) rows[r] * pitch + unit_x * 12u));
+                                w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+                        } else {
+                                const uint32_t *p = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 12u));
+                                w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+                        }
+                }
+        }
+        // The block at the right edge of a picture whose width is not a multiple of 4: `valid` (1..3) of its pixel columns exist, the
+        // others repeat the last one (GL_CLAMP_TO_EDGE, dxt_encoder.c:362-364).  Nothing past the last byte of a line is read.
+        __device__ __forceinline__ void load_edge(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4], int valid)
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint8_t *p = src + ((uint32_t) rows[r] * pitch + unit_x * 12u);
+                        uint32_t b[12];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                                const int jj = 3 * min(j, valid - 1);
+                                b[3 * j] = p[jj]; b[3 * j + 1] = p[jj + 1]; b[3 * j + 2] = p[jj + 2];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; k++) w[r][k] = b[4 * k] | b[4 * k + 1] << 8 | b[4 * k + 2] << 16 | b[4 * k + 3] << 24;
                 }
         }
         __device__ __forceinline__ void block(int, Px16 &p) const
@@ -226,11 +257,25 @@ struct Loader3 {
 struct LoaderRGBAWords {
         static constexpr int kBlocks = 1;
         uint4 w[4];
+        template <bool EDGE = false>
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        w[r] = *(const uint4 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 16u));
+                        if (EDGE) { // 4 * width bytes per line: 4-byte alignment is all a line has
+                                const uint32_t *q = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 16u));
+                                w[r] = make_uint4(q[0], q[1], q[2], q[3]);
+                        } else {
+                                w[r] = *(const uint4 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 16u));
+                        }
+                }
+        }
+        __device__ __forceinline__ void load_edge(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4], int valid)
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t *q = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 16u));
+                        w[r] = make_uint4(q[0], q[min(1, valid - 1)], q[min(2, valid - 1)], q[min(3, valid - 1)]);
                 }
         }
         __device__ __forceinline__ void block(int, Px16 &p) const
@@ -253,11 +298,26 @@ template <bool CONVERT>
 struct LoaderUYVY {
         static constexpr int kBlocks = 1;
         uint2 w[4];
+        template <bool EDGE = false>
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        w[r] = *(const uint2 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        if (EDGE) { // 2 * width bytes per line, width even: 4-byte alignment
+                                const uint32_t *q = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                                w[r] = make_uint2(q[0], q[1]);
+                        } else {
+                                w[r] = *(const uint2 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        }
+                }
+        }
+        // width = 2 (mod 4): one U Y0 V Y1 group exists; the second one repeats its last pixel: U Y1 V Y1
+        __device__ __forceinline__ void load_edge(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4], int)
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t q = *(const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        w[r] = make_uint2(q, (q & 0xffff00ffu) | (q >> 24) << 8);
                 }
         }
         __device__ __forceinline__ void block(int, Px16 &p) const
@@ -299,11 +359,26 @@ struct LoaderUYVYLds {
         static constexpr bool kLdsConv = CONVERT;
         uint2 w[4];
         const ConvTables *lut;
+        template <bool EDGE = false>
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        w[r] = *(const uint2 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        if (EDGE) { // 2 * width bytes per line, width even: 4-byte alignment
+                                const uint32_t *q = (const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                                w[r] = make_uint2(q[0], q[1]);
+                        } else {
+                                w[r] = *(const uint2 *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        }
+                }
+        }
+        // width = 2 (mod 4): one U Y0 V Y1 group exists; the second one repeats its last pixel: U Y1 V Y1
+        __device__ __forceinline__ void load_edge(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4], int)
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t q = *(const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        w[r] = make_uint2(q, (q & 0xffff00ffu) | (q >> 24) << 8);
                 }
         }
         __device__ __forceinline__ void block(int, Px16 &p) const
@@ -347,6 +422,19 @@ template <bool CONVERT>
 struct LoaderUYVYTyped {
         static constexpr int kBlocks = 1;
         f32x4 f[4][2];
+        // width = 2 (mod 4): one U Y0 V Y1 group exists; the second one repeats its last pixel: U Y1 V Y1.  (float) byte is what the
+        // USCALED typed load returns.
+        __device__ __forceinline__ void load_edge(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4], int)
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const uint32_t q = *(const uint32_t *) (src + ((uint32_t) rows[r] * pitch + unit_x * 8u));
+                        const float u = (float) (q & 0xffu), y0 = (float) ((q >> 8) & 0xffu), v = (float) ((q >> 16) & 0xffu), y1 = (float) (q >> 24);
+                        f[r][0] = f32x4{ u, y0, v, y1 };
+                        f[r][1] = f32x4{ u, y1, v, y1 };
+                }
+        }
+        template <bool EDGE = false> // (the typed loads take 4-byte elements: a line that is only 4-byte aligned is no different)
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
                 const uint64_t base = (uint64_t) src;
@@ -407,6 +495,7 @@ template <>
 struct Loader<UG_PF_V210> {
         static constexpr int kBlocks = 3;
         uint32_t w[4][8];
+        template <bool EDGE = false> // (a v210 line is padded to 128 bytes whatever the width, video_codec.c:507-521: whole units are always there)
         __device__ __forceinline__ void load(const uint8_t *src, uint32_t pitch, uint32_t unit_x, const int (&rows)[4])
         {
 #pragma unroll
@@ -431,6 +520,19 @@ struct Loader<UG_PF_V210> {
                                 const int s = 8 * k + 4 * pr; // U Y0 V Y1
                                 yuv_pair_to_rgb(samp(r, s + 1), samp(r, s + 3), samp(r, s), samp(r, s + 2), p, 4 * r + 2 * pr);
                         }
+                }
+        }
+        // the same for a block that may be the cut one of a width = 2 (mod 4): `half` = only its first pixel pair exists, the
+        // second repeats the pair's last pixel (Y1 with the pair's chroma)
+        __device__ __forceinline__ void block_edge(int k, Px16 &p, bool half) const
+        {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                        const int s = 8 * k;
+                        const float u0 = samp(r, s), y00 = samp(r, s + 1), v0 = samp(r, s + 2), y01 = samp(r, s + 3);
+                        yuv_pair_to_rgb(y00, y01, u0, v0, p, 4 * r);
+                        const float u1 = half ? u0 : samp(r, s + 4), y10 = half ? y01 : samp(r, s + 5), v1 = half ? v0 : samp(r, s + 6), y11 = half ? y01 : samp(r, s + 7);
+                        yuv_pair_to_rgb(y10, y11, u1, v1, p, 4 * r + 2);
                 }
         }
 };
@@ -993,10 +1095,10 @@ __device__ __forceinline__ uint2 encode_dxt1(const Px16 &p, const IndexTables &t
 // wave and latency hiding is left to the 4 resident waves per SIMD.
 constexpr int kRowsPerWave = UG_DXT_ROWS_PER_WAVE;
 
-template <int IN, int OUT, bool MIRROR, bool AWAY>
+template <int IN, int OUT, bool MIRROR, bool AWAY, bool EDGE>
 __global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVES)) void dxt_encode_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                          int units_per_row, int blocks_per_row, int block_rows, int height, uint32_t pitch,
-                                                         size_t src_frame_stride, size_t dst_frame_stride)
+                                                         size_t src_frame_stride, size_t dst_frame_stride, int width)
 {
         using L = Loader<IN>;
         constexpr bool kTables = UG_DXT_FAST_INDEX, kAlpha = kTables && OUT == UG_DXT5_YCOCG;
@@ -1038,10 +1140,17 @@ __global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVE
                 int rows[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                        const int y = 4 * by + r;
+                        const int y = EDGE ? min(4 * by + r, height - 1) : 4 * by + r; // (scalar) lines past the picture repeat its last line
                         rows[r] = MIRROR ? height - 1 - y : y; // cuda_dxt.cu:652-655
                 }
-                ld.load(src, pitch, ux, rows);
+                if constexpr (EDGE && L::kBlocks == 1) {
+                        const int valid = width - 4 * ux; // pixel columns of this lane's block that lie inside the picture
+                        if (valid < 4) { // one lane per block row, when width % 4 != 0
+                                ld.load_edge(src, pitch, ux, rows, valid);
+                                return;
+                        }
+                }
+                ld.template load<EDGE>(src, pitch, ux, rows);
         };
         L cur, nxt;
 #if UG_DXT_LDS_CONV
@@ -1074,7 +1183,11 @@ __global__ __launch_bounds__(256, (Loader<IN>::kBlocks > 1 ? 1 : UG_DXT_MIN_WAVE
                                 break;
                         }
                         Px16 p;
-                        cur.block(k, p);
+                        if constexpr (EDGE && L::kBlocks > 1) {
+                                cur.block_edge(k, p, width - 4 * (ux * L::kBlocks + k) < 4);
+                        } else {
+                                cur.block(k, p);
+                        }
                         if (OUT == UG_DXT5_YCOCG) {
                                 res[k] = encode_dxt5ycocg<AWAY>(p, tab);
                         } else {
@@ -1130,7 +1243,8 @@ int launch(const EncodeJob &j)
         using L = Loader<IN>;
         const bool mirror = j.h < 0;
         const int h = mirror ? -j.h : j.h;
-        const int bpr = j.w / 4, upr = (bpr + L::kBlocks - 1) / L::kBlocks, brows = h / 4;
+        const int bpr = (j.w + 3) / 4, upr = (bpr + L::kBlocks - 1) / L::kBlocks, brows = (h + 3) / 4; // dxt_util.h:59-67
+        const bool edge = (j.w & 3) || (h & 3);
         if (upr == 0 || brows == 0 || j.frames == 0) return UG_HIP_SUCCESS;
         constexpr int wg_rows = 4; // waves per workgroup; 1, 2 and 4 measure the same (0.1878-0.1889 ms)
         const int rows_per_group = wg_rows * kRowsPerWave;
@@ -1143,13 +1257,14 @@ int launch(const EncodeJob &j)
                 return UG_HIP_EINVAL;
         }
         const dim3 block(64, wg_rows), grid((unsigned) ((upr + 63) / 64), (unsigned) ((brows + rows_per_group - 1) / rows_per_group), (unsigned) j.frames);
-        if (mirror) {
-                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, true, AWAY>), grid, block, 0, j.st, (const uint8_t *) j.src,
-                                   (uint8_t *) j.dst, upr, bpr, brows, h, (uint32_t) j.pitch, j.sfs, j.dfs);
+#define UG_DXT_LAUNCH(MIRROR, EDGE) hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, MIRROR, AWAY, EDGE>), grid, block, 0, j.st, (const uint8_t *) j.src, \
+                                                      (uint8_t *) j.dst, upr, bpr, brows, h, (uint32_t) j.pitch, j.sfs, j.dfs, j.w)
+        if (edge) {
+                if (mirror) UG_DXT_LAUNCH(true, true); else UG_DXT_LAUNCH(false, true);
         } else {
-                hipLaunchKernelGGL((dxt_encode_kernel<IN, OUT, false, AWAY>), grid, block, 0, j.st, (const uint8_t *) j.src,
-                                   (uint8_t *) j.dst, upr, bpr, brows, h, (uint32_t) j.pitch, j.sfs, j.dfs);
+                if (mirror) UG_DXT_LAUNCH(true, false); else UG_DXT_LAUNCH(false, false);
         }
+#undef UG_DXT_LAUNCH
         UG_HIP_LAUNCH_CHECK();
         return UG_HIP_SUCCESS;
 }
@@ -1174,7 +1289,7 @@ size_t ug_hip_dxt_size(ug_dxt_t out, int width, int height)
 {
         if (!ug::dims_ok_signed(width, height)) return 0; // not a picture: no size (never a wrapped one)
         if (height < 0) height = -height;
-        const size_t px = (size_t) width * (size_t) height; // dxt_util.h:59-67
+        const size_t px = ((size_t) width + 3) / 4 * 4 * (((size_t) height + 3) / 4 * 4); // dxt_util.h:59-67: whole 4x4 blocks
         return out == UG_DXT1 || out == UG_DXT1_YUV ? px / 2 : px;
 }
 
@@ -1196,15 +1311,22 @@ int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src, vo
                 ug::set_last_error_msg("ug_hip_dxt_encode: unknown tie rule");
                 return UG_HIP_EINVAL;
         }
-        if (!src || !dst || width <= 0 || ah == 0 || (width & 3) || (ah & 3) || frames < 0 ||
-            (15 & (uintptr_t) src) || (15 & (uintptr_t) dst)) { // cuda_dxt.cu:745
+        if (!src || !dst || width <= 0 || ah == 0 || frames < 0 || (15 & (uintptr_t) src) || (15 & (uintptr_t) dst)) {
                 ug::set_last_error_msg("ug_hip_dxt_encode: bad size or alignment");
+                return UG_HIP_EINVAL;
+        }
+        // Any width and height >= 1, as dxt_encoder_create takes them (dxt_glsl.cpp:150-160); the cuda_dxt.h-shaped entry points below keep
+        // cuda_dxt.cu:745's multiples of 4.  A 4:2:2 line is made of pixel pairs.
+        const bool edge = (width & 3) || (ah & 3);
+        if ((width & 1) && (in == UG_PF_UYVY || in == UG_PF_UYVY_RAW || in == UG_PF_V210)) {
+                ug::set_last_error_msg("ug_hip_dxt_encode: 4:2:2 input needs an even width");
                 return UG_HIP_EINVAL;
         }
         if (src_pitch == 0) {
                 src_pitch = ug::linesize(in, width);
         }
-        if (src_pitch <= 0 || (src_pitch & 3)) {
+        const bool any_pitch = edge && (in == UG_PF_RGB || in == UG_PF_YUV444); // lines of 3 * width bytes start wherever they start
+        if (src_pitch <= 0 || ((src_pitch & 3) && !any_pitch)) {
                 ug::set_last_error_msg("ug_hip_dxt_encode: bad pitch / unsupported input format");
                 return src_pitch <= 0 ? UG_HIP_EUNSUPP : UG_HIP_EINVAL;
         }
@@ -1217,14 +1339,14 @@ int ug_hip_dxt_encode_batch_ex(ug_pixfmt_t in, ug_dxt_t out, const void *src, vo
         switch (in) {
         case UG_PF_RGB: return launch_out<UG_PF_RGB>(out, ties, j);
         case UG_PF_RGBA:
-                if (src_pitch & 15) break;
+                if (src_pitch & (edge ? 3 : 15)) break;
                 return launch_out<UG_PF_RGBA>(out, ties, j);
         case UG_PF_YUV444: return launch_out<UG_PF_YUV444>(out, ties, j);
         case UG_PF_UYVY:
-                if (src_pitch & 7) break;
+                if (src_pitch & (edge ? 3 : 7)) break;
                 return launch_out<UG_PF_UYVY>(out, ties, j);
         case UG_PF_UYVY_RAW:
-                if (src_pitch & 7) break;
+                if (src_pitch & (edge ? 3 : 7)) break;
                 return launch_out<UG_PF_UYVY_RAW>(out, ties, j);
         case UG_PF_V210:
                 // 12 px = 32 B units; a last unit with fewer pixels is read whole, which the 128-byte line padding of v210
@@ -1253,11 +1375,19 @@ int ug_hip_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, 
         return ug_hip_dxt_encode_batch_ex(in, out, src, dst, width, height, src_pitch, 1, 0, 0, UG_DXT_TIES_DEFAULT, stream);
 }
 
-// cuda_dxt.h-shaped entry points
-int ug_hip_rgb_to_dxt1(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_RGB, UG_DXT1, src, out, sx, sy, 0, s); }
-int ug_hip_yuv_to_dxt1(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_YUV444, UG_DXT1, src, out, sx, sy, 0, s); }
-int ug_hip_rgb_to_dxt6(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_RGB, UG_DXT5_YCOCG, src, out, sx, sy, 0, s); }
-int ug_hip_yuv_to_dxt6(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return ug_hip_dxt_encode(UG_PF_YUV444, UG_DXT5_YCOCG, src, out, sx, sy, 0, s); }
+// cuda_dxt.h-shaped entry points: the interface of cuda_dxt.h:30-89 with its own limits -- sizes that are multiples of 4 (cuda_dxt.cu:745)
+static int cuda_dxt_shaped(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int sx, int sy, ug_hip_stream_t s)
+{
+        if ((sx & 3) || (sy & 3)) {
+                ug::set_last_error_msg("ug_hip_*_to_dxt*: width and height must be multiples of 4 (cuda_dxt.cu:745); ug_hip_dxt_encode takes any size");
+                return UG_HIP_EINVAL;
+        }
+        return ug_hip_dxt_encode(in, out, src, dst, sx, sy, 0, s);
+}
+int ug_hip_rgb_to_dxt1(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return cuda_dxt_shaped(UG_PF_RGB, UG_DXT1, src, out, sx, sy, s); }
+int ug_hip_yuv_to_dxt1(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return cuda_dxt_shaped(UG_PF_YUV444, UG_DXT1, src, out, sx, sy, s); }
+int ug_hip_rgb_to_dxt6(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return cuda_dxt_shaped(UG_PF_RGB, UG_DXT5_YCOCG, src, out, sx, sy, s); }
+int ug_hip_yuv_to_dxt6(const void *src, void *out, int sx, int sy, ug_hip_stream_t s) { return cuda_dxt_shaped(UG_PF_YUV444, UG_DXT5_YCOCG, src, out, sx, sy, s); }
 
 int ug_hip_time_dxt_encode(ug_pixfmt_t in, ug_dxt_t out, const void *src, void *dst, int width, int height,
                            int src_pitch, int frames, size_t sfs, size_t dfs, int iters, ug_hip_stream_t stream,

@@ -238,8 +238,10 @@ bool configure_with(state_video_compress_dxt_mi355x *s, struct video_desc desc)
                 s->pre_out = UG_PF_UYVY;
                 s->in_fmt = UG_PF_UYVY_RAW;
         }
-        if (desc.width % 4 != 0 || desc.height % 4 != 0) { // cuda_dxt.cu:745
-                MSG(ERROR, "Frame size %ux%u is not a multiple of the 4x4 block\n", desc.width, desc.height);
+        // Any frame size, as RTDXT takes it (dxt_glsl.cpp:150-160 -> dxt_encoder_create; the stream holds whole blocks, dxt_util.h:59-67) --
+        // not cuda_dxt.cu:745's multiples of 4.  What the encoder does past the picture's edge: include/ug_mi355x.h, ug_hip_dxt_encode.
+        if (desc.width % 2 != 0 && (s->in_fmt == UG_PF_UYVY || s->in_fmt == UG_PF_UYVY_RAW || s->in_fmt == UG_PF_V210)) {
+                MSG(ERROR, "A 4:2:2 frame %u pixels wide is not made of pixel pairs\n", desc.width);
                 return false;
         }
         if (get_bits_per_component(desc.color_spec) > 8) {
@@ -275,7 +277,7 @@ std::shared_ptr<video_frame> compress_tile_in_bands(state_video_compress_dxt_mi3
         const size_t wire_ls = (size_t) vc_get_linesize(w, tx->color_spec);
         const bool pre = s->pre_in != UG_PF_NONE;
         const size_t pre_ls = pre ? (size_t) vc_get_linesize(w, ug_codec_from_pixfmt(s->pre_out)) : 0;
-        const size_t out_row = s->out_len / (size_t) (h / 4); // bytes of one row of blocks
+        const size_t out_row = s->out_len / (size_t) ((h + 3) / 4); // bytes of one row of blocks
         // a failure half way: downloads of earlier bands may still be writing into `out` (they were not joined) -- wait for the lane before the frame goes
         // back to its pool (a joined 16-byte download behind them, then the stream)
         auto fail = [&]() -> std::shared_ptr<video_frame> {
@@ -303,7 +305,7 @@ std::shared_ptr<video_frame> compress_tile_in_bands(state_video_compress_dxt_mi3
                 char *const blocks = (char *) s->dev_out + (size_t) (r0 / 4) * out_row;
                 CHECK_HIP(ug_hip_dxt_encode_batch_ex(s->in_fmt, s->out_fmt, enc_src, blocks, w, rows, 0, 1, 0, 0, s->ties, s->stream), "Encoding failed", return fail());
                 // every download but the last leaves the stream free to go on with the next band; the last one joins, and the lane is in order
-                CHECK_HIP(ug_hip_download_ordered_ex(s->device, out->tiles[0].data + (size_t) (r0 / 4) * out_row, blocks, (size_t) (rows / 4) * out_row, s->stream,
+                CHECK_HIP(ug_hip_download_ordered_ex(s->device, out->tiles[0].data + (size_t) (r0 / 4) * out_row, blocks, (size_t) ((rows + 3) / 4) * out_row, s->stream,
                                                      last ? 0 : UG_HIP_COPY_NO_JOIN),
                           "D2H copy failed", return fail());
                 r0 = r1;
