@@ -168,13 +168,14 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
         if dist is not None:
             dist.barrier()
         try:
-            r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank, mode="split")
-            # the same traffic without the kernel: what the link alone gives for this in/out byte mix (all ranks at once, like the leg itself)
-            ceil = pipeline.run(wl, depth=3, seconds=min(seconds, 1.0), salt=17 * rank, mode="split", encode=False)["fps"]
+            # the leg and, BESIDE it, the same traffic without the kernel (what the link alone gives for this in/out byte mix, all ranks at once like the
+            # leg itself): copy 0.7 s, half the leg, copy, the other half, copy -- the ceiling is the best of the three
+            r = pipeline.run(wl, depth=3, seconds=seconds, salt=17 * rank, mode="split", copy_only_runs=3, copy_only_seconds=0.7)
+            ceil = r["copy_only_fps"]
         except Exception as e:   # a rank that cannot run its leg reports 0 fps; the collectives below still see every rank
             print(f"bench.py: e2e leg {wl} failed on rank {rank}: {e}", file=sys.stderr, flush=True)
             _, _, oid, w_, h_ = pipeline.WORKLOADS[wl]
-            r = {"fps": 0.0, "pcie_gbs": 0.0, "in_flight": 3, "bytes_in_per_frame": 0, "bytes_out_per_frame": 0, "seconds": 0.0}
+            r = {"fps": 0.0, "pcie_gbs": 0.0, "in_flight": 3, "bytes_in_per_frame": 0, "bytes_out_per_frame": 0, "seconds": 0.0, "copy_only_fps_runs": []}
             ceil = 0.0
         from ultragrid_amd import shard
         rates = shard.gather_rates([r["fps"], r["pcie_gbs"], ceil], dist, device_for_gather)
@@ -184,7 +185,7 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
         w, h = pipeline.WORKLOADS[wl][3], pipeline.WORKLOADS[wl][4]
         res[wl] = {"fps_total": round(sum(per), 1), "fps_per_gpu": per, "mpixels_per_s_total": round(sum(per) * w * h / 1e6, 1),
                    "pcie_gbs_total": round(sum(pcie), 2), "pcie_gbs_per_gpu": pcie, "in_flight": r["in_flight"],
-                   "copy_only_fps_per_gpu": ceils, "frac_of_copy_only": round(sum(per) / sum(ceils), 3) if sum(ceils) else None,
+                   "copy_only_fps_per_gpu": ceils, "copy_only_runs": r.get("copy_only_fps_runs", []), "frac_of_copy_only": round(sum(per) / sum(ceils), 3) if sum(ceils) else None,
                    "bytes_in_per_frame": r["bytes_in_per_frame"], "bytes_out_per_frame": r["bytes_out_per_frame"], "seconds": r["seconds"]}
     # the box's link by itself (rank 0's GPU; pure copies, 2 in flight per direction); the other ranks wait: both barriers are reached whatever the probe does
     torch.cuda.synchronize()
@@ -216,7 +217,8 @@ def e2e_leg(workloads, rank: int, dist, device_for_gather: str, seconds: float) 
     if lat:
         res["latency_ms_depth1"] = lat
     res["path"] = ("pinned host frame -> H2D -> fused unpack+encode kernel -> D2H, 3 frames in flight per GPU, all ranks concurrently; "
-                   "one upload, one compute and one download stream with events between the stages of a frame (tools/e2e_bench.py --sweep: better than a stream per frame); copy_only_fps = the same copies without the kernel (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
+                   "one upload, one compute and one download stream with events between the stages of a frame (tools/e2e_bench.py --sweep: better than a stream per frame); copy_only_fps = the same copies without the kernel, best of the three 0.7 s runs "
+                   "(copy_only_runs, rank 0's) taken before, between and after the two halves of the leg they bound (the link's ceiling for that byte mix); link_gbs_* = pure copies on rank 0's GPU")
     res["numa_node_rank0"] = node
     res["cpus_bound_rank0"] = bound
     if affinity is not None and bound:
@@ -284,8 +286,13 @@ def setup_workload(name: str, frames: int, batches: int, rank: int) -> dict:
             stream_bytes[0] = sum(lens[f] for f in range(F))
 
     # (the device buffers a workload needs live as long as its launch closure does)
-    return dict(wl=wl, W=W, H=H, F=F, B=B, bpp=ALG_BYTES_PER_PX, out_name=out_name, frame_bytes=frame_bytes, out_bytes=out_bytes, launch=launch,
-                stream_bytes=stream_bytes, host=host, src=src, dst=dst, enc=enc)
+    ws = dict(wl=wl, W=W, H=H, F=F, B=B, bpp=ALG_BYTES_PER_PX, out_name=out_name, frame_bytes=frame_bytes, out_bytes=out_bytes, launch=launch,
+              stream_bytes=stream_bytes, host=host, src=src, dst=dst, enc=enc)
+    if out_name == "JPEG420":
+        ws["coef"] = (oy, ocb, ocr)
+    if out_name == "JPEGENC":
+        ws["jout"], ws["lens"], ws["stride"] = jout, lens, stride
+    return ws
 
 
 def time_launches(launch, B: int, seconds: float) -> tuple:
@@ -328,6 +335,54 @@ def parity_check(ws: dict) -> dict:
             "checker": "oracle/dxt_oracle.c (dxt_encode) on frame 0 of resident batch 0, output of the last timed launch over that batch", "cpu_s": round(time.perf_counter() - t0, 3)}
 
 
+def _jpeg_oracle_coeffs(src0: np.ndarray, W: int, H: int, quality: int = 75):
+    """what the JPEG oracle computes for one UYVY frame, 4:2:0: uyvy_to_i420 (the reference's rounding) + AAN FDCT + quantiser, per component,
+    (blocks in raster order of the MCU-padded grid, 64) int16 in zig-zag order"""
+    from oracle import pyoracle as po
+    y, u, v = po.uyvy_to_i420(src0, W, H)
+    mw, mh = (W + 15) // 16, (H + 15) // 16
+    dl, dc = po.jpeg_divisors(po.jpeg_qtable(quality, 0)), po.jpeg_divisors(po.jpeg_qtable(quality, 1))
+    return po.jpeg_fdct_quant_plane(y, dl, 2 * mw, 2 * mh), po.jpeg_fdct_quant_plane(u, dc, mw, mh), po.jpeg_fdct_quant_plane(v, dc, mw, mh)
+
+
+def parity_check_jpeg420(ws: dict) -> dict:
+    """BASELINE configs[3]: the Y / Cb / Cr coefficients of frame 0 as the LAST timed launch left them (it ran over the last resident batch) against
+    po.uyvy_to_i420 + po.jpeg_fdct_quant_plane on the same input bytes; after the timed region"""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = ws["B"] - 1
+    src0 = ws["src"][b][: ws["frame_bytes"]].cpu().numpy()
+    want = _jpeg_oracle_coeffs(src0, ws["W"], ws["H"])
+    got = [c[0].cpu().numpy() for c in ws["coef"]]
+    differing = sum(int(np.count_nonzero(g != w_)) if g.shape == w_.shape else int(max(g.size, w_.size)) for g, w_ in zip(got, want))
+    return {"frames": 1, "coefficients_compared": int(sum(w_.size for w_ in want)), "coefficients_differing": differing,
+            "checker": "oracle/pixfmt_oracle.c (uyvy_to_i420) + oracle/jpeg_oracle.c (jpeg_fdct_quant_plane) on frame 0 of the last resident batch, output of the last timed launch; "
+                       "the FDCT / quantiser oracle is pinned to libjpeg-turbo's float DCT, unpinned towards libgpujpeg", "cpu_s": round(time.perf_counter() - t0, 3)}
+
+
+def parity_check_jpegenc(ws: dict) -> dict:
+    """the whole encoder: frame 0's STREAM as the last timed call wrote it, entropy-decoded by oracle/jpeg_decode_oracle.c back to the quantised
+    coefficients it codes, against the coefficients the FDCT oracle computes for the same input bytes; plus the stream lengths of that call"""
+    from oracle import pyoracle as po
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = ws["B"] - 1
+    lens = [int(ws["lens"][f]) for f in range(ws["F"])]
+    stream = bytes(ws["jout"][b, 0, : lens[0]].cpu().numpy())
+    src0 = ws["src"][b][: ws["frame_bytes"]].cpu().numpy()
+    want = _jpeg_oracle_coeffs(src0, ws["W"], ws["H"])
+    try:
+        info, got = po.jpeg_decode_coeffs(stream)
+        ok_hdr = info["width"] == ws["W"] and info["height"] == ws["H"] and info["h"] == [2, 1, 1] and info["v"] == [2, 1, 1]
+        differing = sum(int(np.count_nonzero(g != w_)) if g.shape == w_.shape else int(max(g.size, w_.size)) for g, w_ in zip(got, want)) if ok_hdr else int(sum(w_.size for w_ in want))
+    except ValueError:
+        differing = int(sum(w_.size for w_ in want))
+    return {"frames": 1, "coefficients_compared": int(sum(w_.size for w_ in want)), "coefficients_differing": differing, "stream_bytes": lens[0], "lens": lens,
+            "ends_with_eoi": stream[-2:] == b"\xff\xd9",
+            "checker": "oracle/jpeg_decode_oracle.c (entropy decoder: the stream of frame 0 of the last timed call -> the quantised coefficients it codes) == "
+                       "oracle/pixfmt_oracle.c + oracle/jpeg_oracle.c on the same input bytes; unpinned towards libgpujpeg like the FDCT itself", "cpu_s": round(time.perf_counter() - t0, 3)}
+
+
 def other_configs(rank: int, seconds: float) -> dict:
     """the BASELINE configurations that are not this line's `value`, each through its --workload code path for ~`seconds` of timed launches"""
     res = {}
@@ -344,6 +399,10 @@ def other_configs(rank: int, seconds: float) -> dict:
                      "mpixels_per_s": round(px / (ms * 1e-3) / 1e6, 1), "fps": round(ws["F"] / (ms * 1e-3), 1)}
         if ws["out_name"] in ("DXT5", "DXT1"):
             res[name]["parity_check"] = parity_check(ws)
+        if ws["out_name"] == "JPEG420":
+            res[name]["parity_check"] = parity_check_jpeg420(ws)
+        if ws["out_name"] == "JPEGENC":
+            res[name]["parity_check"] = parity_check_jpegenc(ws)
         if ws["out_name"] == "JPEGENC":
             res[name]["note"] = "the whole encoder per (synchronous) call of 8 frames; the FDCT / quantiser stage is unpinned towards libgpujpeg (pinned to libjpeg-turbo's float DCT)"
             from ultragrid_amd import lib
@@ -369,14 +428,15 @@ def load_pmc(pmc_key, root: str = ROOT) -> dict:
         # the counters name the sources they were taken on (tools/pmc_to_json.py): counters of another build are not quoted
         import hashlib
         h = hashlib.sha256()
+        files = pmc.get("kernel_sources") if isinstance(pmc.get("kernel_sources"), list) else []   # (a hash without its file list -- a hand-edited entry -- is stale, not fatal)
         try:
-            for f in pmc["kernel_sources"]:
-                h.update(open(os.path.join(root, f), "rb").read())
-            now = h.hexdigest()[:16]
+            for f in files:
+                h.update(open(os.path.join(root, str(f)), "rb").read())
+            now = h.hexdigest()[:16] if files else None
         except OSError:
             now = None
         if now != pmc["kernel_sources_sha16"]:
-            pmc = {"source": f"STALE, not quoted: profiles/pmc_traffic.json[{pmc_key}] was taken on another build of {', '.join(pmc['kernel_sources'])} "
+            pmc = {"source": f"STALE, not quoted: profiles/pmc_traffic.json[{pmc_key}] was taken on another build of {', '.join(map(str, files)) or '(no file list)'} "
                              f"(sha16 {pmc['kernel_sources_sha16']} then, {now} now); re-run tools/gpu_session.sh <tag> pmc"}
         else:
             pmc = dict(pmc, source=pmc.get("source", "") + f"; kernel sources sha16 {now} = the build timed here")

@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define UG_HIP_ABI_VERSION 4 /* 4: ug_hip_{upload,download}_ordered_ex (additions only); 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions), and ONE
+#define UG_HIP_ABI_VERSION 5 /* 5: ug_hip_memcpy_2d_async, ug_hip_download_2d_ordered_ex, ug_hip_event_* / ug_hip_stream_wait_event (additions), and the DXT encoder / decoders take ANY frame size (they refused sizes
+                              * that are not multiples of 4; ug_hip_dxt_size rounds up to whole blocks as dxt_get_size does); 4: ug_hip_{upload,download}_ordered_ex (additions only); 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions), and ONE
                               * change of behaviour: ug_hip_jpeg_encoder_encode_batch with frames > 1 reports a stream that does not fit its slice through
                               * out_len[f] > out_capacity and returns success for the call (it used to fail the whole call with UG_HIP_EINVAL) */
 
@@ -102,6 +103,10 @@ int         ug_hip_free_host(void *buffer);                            /* cuda_w
 #define UG_HIP_MEMCPY_DEVICE_TO_DEVICE 2
 int         ug_hip_memcpy(void *dst, const void *src, size_t count, int kind);       /* cuda_wrapper_memcpy */
 int         ug_hip_memcpy_async(void *dst, const void *src, size_t count, int kind, ug_hip_stream_t stream);
+/* `rows` lines of `width_bytes` bytes, `spitch` / `dpitch` bytes from one line to the next: ONE copy for a picture whose pitch differs from its
+ * line size (the receivers' display pitch: src/video_decompress/dxt_glsl.c:163-186, gpujpeg.c:305-315 loop over the lines on the CPU there).
+ * 0 < width_bytes <= both pitches, 0 < rows <= 65536, else UG_HIP_EINVAL before any device call. */
+int         ug_hip_memcpy_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows, int kind, ug_hip_stream_t stream);
 int         ug_hip_memset_async(void *dst_dev, int value, size_t count, ug_hip_stream_t stream); /* device memory only */
 /* Copy lanes: the copy goes onto the ONE upload (download) stream of `device` -- shared by every caller in the process, so that concurrent
  * frames do not split the link between two copies of the same direction -- and is ordered against `stream`: an upload starts after what
@@ -120,6 +125,17 @@ int         ug_hip_download_ordered(int device, void *dst_host, const void *src_
 #define UG_HIP_COPY_NO_JOIN 2
 int         ug_hip_upload_ordered_ex(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream, int flags);
 int         ug_hip_download_ordered_ex(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream, int flags);
+/* the download lane with a 2-D copy (a row band of a picture with a display pitch): geometry as ug_hip_memcpy_2d_async, ordering and flags as above */
+int         ug_hip_download_2d_ordered_ex(int device, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width_bytes, size_t rows,
+                                          ug_hip_stream_t after_stream, int flags);
+/* Events (hipEvent_t, timing disabled): record a point of one stream, make another stream wait for it.  What lets a second host thread
+ * download the first bands of a picture while the first thread still uploads its last ones (copies from / to pageable host memory block the
+ * calling thread: only two threads ever have an upload and a download in flight together). */
+typedef void *ug_hip_event_t;
+int         ug_hip_event_create(ug_hip_event_t *event);
+int         ug_hip_event_destroy(ug_hip_event_t event);                /* NULL: nothing to do */
+int         ug_hip_event_record(ug_hip_event_t event, ug_hip_stream_t stream);
+int         ug_hip_stream_wait_event(ug_hip_stream_t stream, ug_hip_event_t event);
 int         ug_hip_stream_create(ug_hip_stream_t *stream);
 int         ug_hip_stream_destroy(ug_hip_stream_t stream);
 int         ug_hip_stream_sync(ug_hip_stream_t stream);

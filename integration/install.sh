@@ -17,6 +17,7 @@ cp "$M/ug_codec_map.h" "$M/mi355x_frame_sharder.h" "$UG/src/video_compress/"
 cp "$M/vdecompress_dxt_mi355x.c"             "$UG/src/video_decompress/dxt_mi355x.c"
 cp "$M/vdecompress_jpeg_mi355x.c"            "$UG/src/video_decompress/jpeg_mi355x.c"
 cp "$M/vdecompress_jpeg_to_dxt_mi355x.c"     "$UG/src/video_decompress/jpeg_to_dxt_mi355x.c"
+cp "$M/mi355x_receiver.h"                    "$UG/src/video_decompress/"
 cp "$M/lavc_conv_mi355x.cpp"                 "$UG/src/libavcodec/lavc_conv_mi355x.cpp"
 if grep -q "found_ug_mi355x" "$UG/configure.ac"; then
         echo "configure.ac is patched already"

@@ -143,7 +143,7 @@ static void idct_islow(const int *in, uint8_t *out, int out_pitch)
  * Adobe marker), scans }.  planes[c] receives component c, pitch[c] bytes per line, (MCU-padded) -- the caller allocates
  * ceil-to-MCU sizes: plane c is (mcu_w * 8 * h_c) x (mcu_h * 8 * v_c).  planes may be NULL to query `info` only.
  * Returns 0, or a negative code: -1 not a baseline JPEG this decoder takes, -2 truncated. */
-int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *planes[3], const int pitch[3])
+static int decode_impl(const uint8_t *data, long len, int info[12], uint8_t *planes[3], const int pitch[3], int16_t *qcoef[3])
 {
         uint16_t qt[4][64];
         huff_t dc[4], ac[4];
@@ -242,8 +242,10 @@ int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *pla
                                         for (int by = 0; by < nb_v; by++) {
                                                 for (int bx = 0; bx < nb_h; bx++) {
                                                         int blk[64] = { 0 };
+                                                        int16_t coded[64] = { 0 }; /* the quantised values as the stream holds them, zig-zag order */
                                                         const int t = decode_symbol(&br, &dc[td[k]]);
                                                         pred[k] += extend(receive(&br, t), t);
+                                                        coded[0] = (int16_t) pred[k];
                                                         /* a coefficient is 16 bits wide (libjpeg's JCOEF; jdhuff.c stores `(JCOEF) s`): only damaged
                                                          * streams ever run the DC prediction out of that range */
                                                         blk[0] = (int16_t) pred[k] * qt[tq[c]][0];
@@ -261,14 +263,16 @@ int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *pla
                                                                 const int value = extend(receive(&br, sz), sz);
                                                                 if (z > 63) break;
                                                                 blk[kZigzag[z]] = value * qt[tq[c]][kZigzag[z]];
+                                                                coded[z] = (int16_t) value;
                                                                 z++;
                                                         }
-                                                        if (coef) {
+                                                        if (coef || qcoef) {
                                                                 const long gw = (long) mcu_w * hs[c];
                                                                 long bxg, byg;
                                                                 if (single) { bxg = u % bw1; byg = u / bw1; }
                                                                 else { bxg = (u % mcu_w) * hs[c] + bx; byg = (u / mcu_w) * vs[c] + by; }
-                                                                memcpy(coef + coef_off[c] + (byg * gw + bxg) * 64, blk, sizeof blk);
+                                                                if (coef) memcpy(coef + coef_off[c] + (byg * gw + bxg) * 64, blk, sizeof blk);
+                                                                if (qcoef && qcoef[c]) memcpy(qcoef[c] + (byg * gw + bxg) * 64, coded, sizeof coded);
                                                         }
                                                 }
                                         }
@@ -298,4 +302,18 @@ int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *pla
         }
         free(coef);
         return rc;
+}
+
+int oracle_jpeg_decode(const uint8_t *data, long len, int info[12], uint8_t *planes[3], const int pitch[3])
+{
+        return decode_impl(data, len, info, planes, pitch, NULL);
+}
+
+/* The entropy decoder alone: qcoef[c] receives the QUANTISED coefficients of component c exactly as the stream codes them -- blocks in
+ * raster order of the component's MCU-padded block grid ((mcu_w * h_c) x (mcu_h * v_c) blocks), 64 int16 each in zig-zag order: the layout
+ * of oracle_jpeg_fdct_quant_plane's output, so that "what the encoder wrote" can be compared with "what the FDCT oracle computes"
+ * coefficient by coefficient (bench.py's parity_check of the JPEG encoder leg). */
+int oracle_jpeg_decode_coeffs(const uint8_t *data, long len, int info[12], int16_t *qcoef[3])
+{
+        return decode_impl(data, len, info, NULL, NULL, qcoef);
 }

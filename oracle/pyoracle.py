@@ -527,6 +527,28 @@ def jpeg_decode_planes(data: bytes):
     return d, crop, planes
 
 
+def jpeg_decode_coeffs(data: bytes):
+    """The entropy decoder of oracle/jpeg_decode_oracle.c alone: (info dict, [quantised coefficients of each component as the stream codes them:
+    (blocks of the MCU-padded grid in raster order, 64) int16, zig-zag order -- jpeg_fdct_quant_plane's layout])."""
+    l = lib()
+    l.oracle_jpeg_decode_coeffs.restype = C.c_int
+    l.oracle_jpeg_decode_coeffs.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    info = (C.c_int * 12)()
+    rc = l.oracle_jpeg_decode_coeffs(data, len(data), info, None)
+    if rc:
+        raise ValueError(f"oracle_jpeg_decode_coeffs rc={rc}")
+    w, h, nc = info[0], info[1], info[2]
+    hs, vs = [info[3], info[5], info[7]][:nc], [info[4], info[6], info[8]][:nc]
+    hmax, vmax = max(hs), max(vs)
+    mw, mh = -(-w // (8 * hmax)), -(-h // (8 * vmax))
+    coefs = [np.zeros((mh * vs[c] * mw * hs[c], 64), np.int16) for c in range(nc)]
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in coefs] + [None] * (3 - nc))
+    rc = l.oracle_jpeg_decode_coeffs(data, len(data), info, ptrs)
+    if rc:
+        raise ValueError(f"oracle_jpeg_decode_coeffs rc={rc}")
+    return dict(width=w, height=h, components=nc, h=hs, v=vs, restart=info[9], adobe=info[10], scans=info[11]), coefs
+
+
 ZIGZAG = np.array([
     0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34,
     27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,

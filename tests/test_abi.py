@@ -22,7 +22,35 @@ def test_library_exports_every_declared_symbol():
     l = lib.load()  # raises if the .so or a symbol is missing
     for name in _declared():
         assert getattr(l, name) is not None
-    assert l.ug_hip_abi_version() == 4
+    assert l.ug_hip_abi_version() == 5
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+
+
+def test_exports_equal_the_header():
+    """The converse of the test above (VERDICT r5 "What's weak" #4): the library exports the header's functions and NOTHING else -- no C++
+    helper, no anonymous-namespace function that an extern "C" block turned into a plain C name, no data.  UltraGrid dlopens its plugins
+    RTLD_GLOBAL into a host linked -rdynamic (src/lib_common.cpp:186-223): any other global name could interpose or be interposed."""
+    for so in ("libug_mi355x.so", "libug_mi355x_alphalinear.so"):
+        path = os.path.join(ROOT, "ultragrid_amd", so)
+        assert os.path.exists(path), f"{path} not built"
+        exp = _exported(path)
+        assert exp - _declared() == set(), (so, sorted(exp - _declared()))
+        assert _declared() - exp == set(), (so, sorted(_declared() - exp))
+
+
+def test_export_map_is_in_step_with_the_header():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_export_map", os.path.join(ROOT, "ultragrid_amd", "csrc", "gen_export_map.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert set(gen.header_functions()) == _declared()
+    committed = open(os.path.join(ROOT, "ultragrid_amd", "csrc", "libug_mi355x.map")).read()
+    assert committed == gen.render(), "include/ug_mi355x.h changed: run python3 ultragrid_amd/csrc/gen_export_map.py"
 
 
 def test_no_torch_or_cxx_types_in_the_abi():
@@ -190,6 +218,11 @@ def test_absurd_geometry_is_refused():
     assert not bad, bad
     for n in (-4, 2 ** 31 - 4, 2 ** 30):
         assert l.ug_hip_yuv422_to_yuv444(_P, _P, n, None) == lib.EINVAL, n
+    # the 2-D copies: 0 < width_bytes <= both pitches, 0 < rows <= 65536
+    for dp, sp, wb, rows in ((64, 64, 65, 4), (64, 32, 64, 4), (64, 64, 0, 4), (64, 64, 64, 0), (64, 64, 64, 65537), (2 ** 31, 64, 64, 4)):
+        assert l.ug_hip_memcpy_2d_async(_P, dp, _P, sp, wb, rows, lib.MEMCPY_D2H if hasattr(lib, "MEMCPY_D2H") else 1, None) == lib.EINVAL, (dp, sp, wb, rows)
+        assert l.ug_hip_download_2d_ordered_ex(0, _P, dp, _P, sp, wb, rows, None, 0) == lib.EINVAL, (dp, sp, wb, rows)
+    assert l.ug_hip_download_2d_ordered_ex(0, _P, 64, _P, 64, 64, 4, None, 4) == lib.EINVAL   # unknown flag
     # the two size helpers: a wrapped int is not an answer
     for fmt in (lib.PF_V210, lib.PF_RGBA, lib.PF_Y416, lib.PF_R12L, lib.PF_UYVY):
         for w in (_BIG, 2 ** 31 - 1, 65537, 0, -1, -2 ** 31):

@@ -36,10 +36,15 @@ def test_counters_of_another_build_are_not_quoted(tmp_path):
     bench = _bench()
     d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     (tmp_path / "profiles").mkdir()
-    shutil.copy(os.path.join(ROOT, "profiles", "pmc_traffic.json"), tmp_path / "profiles" / "pmc_traffic.json")
+    import hashlib
+    h = hashlib.sha256()
     for f in d["uyvy_dxt5_4k_x16"]["kernel_sources"]:
         os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
         shutil.copy(os.path.join(ROOT, f), tmp_path / f)
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    # (the entry as a counter pass over THIS tree would write it -- whether the committed one is of this tree or of an earlier kernel is the test above's subject)
+    d["uyvy_dxt5_4k_x16"] = dict(d["uyvy_dxt5_4k_x16"], kernel_sources_sha16=h.hexdigest()[:16])
+    json.dump(d, open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
     assert bench.load_pmc("uyvy_dxt5_4k_x16", root=str(tmp_path)).get("traffic") == d["uyvy_dxt5_4k_x16"]["traffic"]
     with open(tmp_path / "ultragrid_amd/csrc/dxt_encode.hip", "a") as f:
         f.write("\n// a kernel change\n")
@@ -50,3 +55,7 @@ def test_counters_of_another_build_are_not_quoted(tmp_path):
     json.dump(legacy, open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
     assert bench.load_pmc("legacy_entry", root=str(tmp_path)) == legacy["legacy_entry"]
     assert bench.load_pmc("no_such_workload", root=str(tmp_path)) == {}
+    # a hash without its file list (a hand-edited entry): stale, not a KeyError that takes the whole bench line down
+    json.dump({"broken": {"traffic": 1, "kernel_sources_sha16": "0123456789abcdef"}}, open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
+    broken = bench.load_pmc("broken", root=str(tmp_path))
+    assert broken.get("traffic") is None and broken["source"].startswith("STALE")

@@ -34,6 +34,16 @@ def test_single_gpu_line(hip):
         assert abs(c["algorithmic_bytes_per_launch"] / (c["ms_per_launch"] * 1e-3) / 1e9 / 8000.0 - c["frac"]) < 2e-3
     assert d["configs"]["1080p-rgb-dxt1"]["parity_check"]["bytes_differing"] == 0 and d["configs"]["8k-v210"]["parity_check"]["bytes_differing"] == 0
     assert d["configs"]["8k-v210"]["parity_check"]["bytes_compared"] == 7680 * 4320
+    # round 6: the two JPEG configurations carry an oracle check of what the TIMED launches produced too -- the front end's
+    # coefficients, and the encoder's stream entropy-decoded back to the coefficients it codes -- and the e2e ceiling is taken beside the leg it bounds
+    pj, pe = d["configs"]["4k-uyvy-jpeg420"]["parity_check"], d["configs"]["4k-uyvy-jpeg-encode"]["parity_check"]
+    assert pj["coefficients_differing"] == 0 and pj["coefficients_compared"] == 240 * 135 * 6 * 64
+    assert pe["coefficients_differing"] == 0 and pe["coefficients_compared"] == 240 * 135 * 6 * 64 and pe["ends_with_eoi"]
+    assert len(pe["lens"]) == 8 and pe["stream_bytes"] == pe["lens"][0] and all(100_000 < n < 3840 * 2160 for n in pe["lens"])
+    for wl in ("8k-uyvy", "8k-v210", "4k-uyvy"):
+        runs = d["e2e"][wl]["copy_only_runs"]
+        assert len(runs) == 3 and max(runs) == d["e2e"][wl]["copy_only_fps_per_gpu"][0]
+        assert 0.5 < d["e2e"][wl]["frac_of_copy_only"] <= 1.10, (wl, d["e2e"][wl])    # (0.3 s legs here: the driver's default 2 s legs are held to 1.02, profiles/)
     lat = d["e2e"]["latency_ms_depth1"]
     assert set(lat) == {"8k-uyvy", "8k-v210", "4k-uyvy"}
     for name, v in lat.items():

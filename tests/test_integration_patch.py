@@ -47,7 +47,7 @@ def test_install_places_the_sources_and_patches_configure(tmp_path):
     assert after.index("add_module() {") < after.index("add_module vcompress_dxt ")
     for f in ("include/ug_mi355x.h", "src/video_compress/dxt_mi355x.cpp", "src/video_compress/jpeg_mi355x.cpp", "src/video_compress/ug_codec_map.h",
               "src/video_compress/mi355x_frame_sharder.h", "src/video_decompress/dxt_mi355x.c", "src/video_decompress/jpeg_mi355x.c",
-              "src/video_decompress/jpeg_to_dxt_mi355x.c", "src/libavcodec/lavc_conv_mi355x.cpp"):
+              "src/video_decompress/jpeg_to_dxt_mi355x.c", "src/video_decompress/mi355x_receiver.h", "src/libavcodec/lavc_conv_mi355x.cpp"):
         assert (ug / f).is_file(), f
     # a second run leaves the tree as it is
     r = subprocess.run(["sh", os.path.join(ROOT, "integration", "install.sh"), str(ug)], capture_output=True, text=True)

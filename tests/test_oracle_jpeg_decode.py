@@ -77,6 +77,9 @@ def test_streams_of_the_repository_writer(po, sub):
     data = write_jpeg(w, h, ql, qc, *coefs, restart=3, sub=sub)
     info, crop, _ = po.jpeg_decode_planes(data)
     assert info["restart"] == 3 and (info["adobe"] == 0) == (sub == 444)
+    # the entropy decoder alone hands back the very coefficients the stream was written from (bench.py's parity_check of the encoder leg rests on this)
+    _, coded = po.jpeg_decode_coeffs(data)
+    assert all(np.array_equal(a, b) for a, b in zip(coded, coefs))
     ref = Image.open(io.BytesIO(data))
     if sub == 444:
         assert ref.mode == "RGB"
@@ -98,6 +101,7 @@ def test_one_scan_per_component_equals_libjpeg(po, ri):
     data = write_jpeg_noninterleaved(w, h, ql, coefs, restart=ri)
     info, crop, _ = po.jpeg_decode_planes(data)
     assert info["scans"] == 3 and info["restart"] == ri
+    assert all(np.array_equal(a, b) for a, b in zip(po.jpeg_decode_coeffs(data)[1], coefs))
     ref = np.asarray(Image.open(io.BytesIO(data)))
     assert all(np.array_equal(crop[c], ref[..., c]) for c in range(3))
 

@@ -1666,7 +1666,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.width = w; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
                 a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
-                a.flat = frames == 1 && e->flat_lookback ? 1 : 0;
+                a.flat = 0; // decided below, once the number of workgroups of a frame is known
                 // divisions by S, blocks per MCU and MCUs per row as multiplications, where the ranges allow (CodeArgs)
                 {
                         const int per_mcu = e->hs * e->vs + 2;
@@ -1719,6 +1719,11 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                         a.slots = e->slots;
                         a.wg_bytes = e->wg_bytes;
                 }
+                // The flat look-back reads n_wg^2 / 2 eight-byte words per frame: 4 MB at 4K (n_wg ~ 1000) -- all L2 hits, 10 % off the one-frame call --,
+                // 64 MB at 8K (-6 %), and it grows with the square: past kFlatMaxWg workgroups a frame the windowed walk (16 round trips per 1024
+                // workgroups) is the cheaper form again (nothing bounded it for the sizes create() accepts, up to 65535 x 65535)
+                constexpr int kFlatMaxWg = 4096;
+                a.flat = frames == 1 && e->flat_lookback && a.n_wg <= kFlatMaxWg ? 1 : 0;
                 const dim3 grid((unsigned) a.n_wg, (unsigned) frames);
                 if (fused) {
                         if (fused_i420) hipLaunchKernelGGL((jpeg_code_kernel<3, 1420>), grid, dim3(192), 0, st, a, (const float *) e->div);

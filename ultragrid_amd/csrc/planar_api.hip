@@ -687,9 +687,19 @@ int ug_hip_to_planar(const char *func, const struct ug_to_planar_data *d, ug_hip
                 ug::set_last_error_msg("ug_hip_to_planar: unknown conversion name");
                 return UG_HIP_EINVAL;
         }
+        // the packed source's own line size (vc_get_linesize of the codec the conversion reads), not the widest one there is: a 16384 x 16384 UYVY
+        // picture is 512 MiB, inside the documented limits
+        long long src_ls = 0;
+        switch (c->family) {
+        case ToConv::P010: src_ls = ((long long) d->width + 47) / 48 * 128; break;          // v210
+        case ToConv::NV12: case ToConv::I420: src_ls = ((long long) d->width + 1) / 2 * 4; break; // UYVY
+        case ToConv::Y216: src_ls = ((long long) d->width + 1) / 2 * 8; break;
+        case ToConv::BGRA: case ToConv::I444: src_ls = 4LL * d->width; break;                // RGBA, VUYA
+        case ToConv::R12L: src_ls = ((long long) d->width + 7) / 8 * 36; break;
+        }
         if (!ug::dims_ok(d->width, d->height) ||
-            !ug::planes_ok(d->height, { d->out_linesize[0], d->out_linesize[1], d->out_linesize[2], d->out_linesize[3], 8LL * d->width })) {
-                return ug::refuse_size("ug_hip_to_planar"); // (8 bytes per pixel: the widest packed source, Y416)
+            !ug::planes_ok(d->height, { d->out_linesize[0], d->out_linesize[1], d->out_linesize[2], d->out_linesize[3], src_ls })) {
+                return ug::refuse_size("ug_hip_to_planar");
         }
         if (d->width <= 0 || d->height <= 0 || !d->in_data || !d->out_data[0]) {
                 ug::set_last_error_msg("ug_hip_to_planar: bad geometry or null pointer");

@@ -87,6 +87,7 @@ int ug_hip_free_host(void *buffer)
         return UG_HIP_SUCCESS;
 }
 
+} // extern "C"
 static hipMemcpyKind kind_of(int kind)
 {
         switch (kind) {
@@ -96,6 +97,7 @@ static hipMemcpyKind kind_of(int kind)
         }
         return hipMemcpyDefault;
 }
+extern "C" {
 
 int ug_hip_memcpy(void *dst, const void *src, size_t count, int kind)
 {
@@ -106,6 +108,26 @@ int ug_hip_memcpy(void *dst, const void *src, size_t count, int kind)
 int ug_hip_memcpy_async(void *dst, const void *src, size_t count, int kind, ug_hip_stream_t stream)
 {
         UG_HIP_TRY(hipMemcpyAsync(dst, src, count, kind_of(kind), (hipStream_t) stream));
+        return UG_HIP_SUCCESS;
+}
+
+// `rows` lines of `width_bytes` each, `spitch` / `dpitch` bytes apart: what a display pitch that differs from the packed line size needs
+// (video_decompress/dxt_glsl.c:163-186 and gpujpeg.c:305-315 do a CPU line loop there; one copy per LINE through the runtime measures
+// 1-3 GB/s, one 2-D copy the full rate of the link: profiles/r06_copy_probe.txt)
+static bool copy_2d_ok(const void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows, const char *who)
+{
+        // (hipMemcpy2D's own limits are the pitches of its 2-D descriptor; the sizes here are those of one picture: ug::dims_ok's range)
+        if (!dst || !src || width_bytes == 0 || rows == 0 || width_bytes > dpitch || width_bytes > spitch || rows > 65536 ||
+            dpitch > (size_t) 0x7fffffff || spitch > (size_t) 0x7fffffff) {
+                ug::set_last_error_msg(who);
+                return false;
+        }
+        return true;
+}
+int ug_hip_memcpy_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows, int kind, ug_hip_stream_t stream)
+{
+        if (!copy_2d_ok(dst, dpitch, src, spitch, width_bytes, rows, "ug_hip_memcpy_2d_async: bad geometry (0 < width_bytes <= both pitches, 0 < rows <= 65536)")) return UG_HIP_EINVAL;
+        UG_HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind_of(kind), (hipStream_t) stream));
         return UG_HIP_SUCCESS;
 }
 
@@ -130,6 +152,39 @@ int ug_hip_stream_destroy(ug_hip_stream_t stream)
         return UG_HIP_SUCCESS;
 }
 
+// Events: what lets one host thread queue work on a stream while ANOTHER host thread waits for a point of it on a stream of its own -- the
+// receivers' band pipeline (vdecompress_dxt_mi355x.c): copies from / to pageable memory block the thread that issues them
+// (profiles/r06_copy_probe.txt), so an upload and a download are only ever in flight together when two threads issue them.
+int ug_hip_event_create(ug_hip_event_t *event)
+{
+        if (!event) return UG_HIP_EINVAL;
+        hipEvent_t e = nullptr;
+        UG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        *event = (ug_hip_event_t) e;
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_event_destroy(ug_hip_event_t event)
+{
+        if (!event) return UG_HIP_SUCCESS;
+        UG_HIP_TRY(hipEventDestroy((hipEvent_t) event));
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_event_record(ug_hip_event_t event, ug_hip_stream_t stream)
+{
+        if (!event) return UG_HIP_EINVAL;
+        UG_HIP_TRY(hipEventRecord((hipEvent_t) event, (hipStream_t) stream));
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_stream_wait_event(ug_hip_stream_t stream, ug_hip_event_t event)
+{
+        if (!event) return UG_HIP_EINVAL;
+        UG_HIP_TRY(hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0));
+        return UG_HIP_SUCCESS;
+}
+
 int ug_hip_stream_sync(ug_hip_stream_t stream)
 {
         UG_HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
@@ -143,6 +198,7 @@ int ug_hip_stream_sync(ug_hip_stream_t stream)
 // the kernels of frame k overlap the upload of k + 1 and the download of k - 1.  Measured PCIe-inclusive, 8K UYVY -> DXT5, two frames
 // in flight: 651 -> 780 fps; 8K v210: 447 -> 593 (profiles/r03_e2e_sweep.txt).  UG_MI355X_COPY_LANES=0 puts the copies back on the
 // caller's stream (A/B).
+} // extern "C"  (the helpers below are C++ with internal linkage: inside the block their names would be exported as plain C symbols)
 namespace {
 constexpr int kMaxDevices = 64;
 struct Lanes {
@@ -202,6 +258,7 @@ hipError_t chain(int device, int which, hipStream_t from, hipStream_t to)
         return e;
 }
 } // namespace
+extern "C" {
 
 int ug_hip_upload_ordered_ex(int device, void *dst_dev, const void *src, size_t count, int kind, ug_hip_stream_t then_stream, int flags)
 {
@@ -242,6 +299,25 @@ int ug_hip_download_ordered_ex(int device, void *dst_host, const void *src_dev, 
         return UG_HIP_SUCCESS;
 }
 
+int ug_hip_download_2d_ordered_ex(int device, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width_bytes, size_t rows,
+                                  ug_hip_stream_t after_stream, int flags)
+{
+        if (flags & ~UG_HIP_COPY_NO_JOIN) {
+                ug::set_last_error_msg("ug_hip_download_2d_ordered_ex: unknown flag");
+                return UG_HIP_EINVAL;
+        }
+        if (!copy_2d_ok(dst_host, dpitch, src_dev, spitch, width_bytes, rows, "ug_hip_download_2d_ordered_ex: bad geometry (0 < width_bytes <= both pitches, 0 < rows <= 65536)")) return UG_HIP_EINVAL;
+        if (!lanes_enabled()) return ug_hip_memcpy_2d_async(dst_host, dpitch, src_dev, spitch, width_bytes, rows, UG_HIP_MEMCPY_DEVICE_TO_HOST, after_stream);
+        Lanes l;
+        UG_HIP_TRY(lanes_of(device, l));
+        UG_HIP_TRY(chain(device, 0, (hipStream_t) after_stream, l.down));
+        UG_HIP_TRY(hipMemcpy2DAsync(dst_host, dpitch, src_dev, spitch, width_bytes, rows, hipMemcpyDeviceToHost, l.down));
+        if (!(flags & UG_HIP_COPY_NO_JOIN)) {
+                UG_HIP_TRY(chain(device, 1, l.down, (hipStream_t) after_stream));
+        }
+        return UG_HIP_SUCCESS;
+}
+
 int ug_hip_download_ordered(int device, void *dst_host, const void *src_dev, size_t count, ug_hip_stream_t after_stream)
 {
         return ug_hip_download_ordered_ex(device, dst_host, src_dev, count, after_stream, 0);
@@ -262,10 +338,12 @@ int ug_hip_linesize(ug_pixfmt_t fmt, int width)
 // eight GPUs it should do that on the socket the GPU's PCIe root complex hangs off, and its pinned pool should be first touched there.
 // The node comes from sysfs (numa_node of the PCI function), the CPUs from the node's cpulist; `sysfs_root` (NULL = "/sys") lets the
 // CPU tests point both at a fake tree.
+} // extern "C"
 namespace {
 constexpr int kMaxCpus = 4096;
 const char *sysroot(const char *r) { return r && *r ? r : "/sys"; }
 } // namespace
+extern "C" {
 
 int ug_hip_numa_node_of_pci(const char *bdf, const char *sysfs_root, int *node)
 {

@@ -24,7 +24,7 @@ DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 # UG_DXT_TIES_*
 TIES_EVEN, TIES_AWAY = 0, 1
 COPY_NO_WAIT, COPY_NO_JOIN = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SUCCESS, EINVAL, EUNSUPP, ERUNTIME = 0, -1, -2, -3
 
@@ -44,10 +44,16 @@ SYMBOLS = {
     "ug_hip_memcpy": (_i, [_vp, _vp, _sz, _i]),
     "ug_hip_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ug_hip_memset_async": (_i, [_vp, _i, _sz, _vp]),
+    "ug_hip_event_create": (_i, [C.POINTER(C.c_void_p)]),
+    "ug_hip_event_destroy": (_i, [_vp]),
+    "ug_hip_event_record": (_i, [_vp, _vp]),
+    "ug_hip_stream_wait_event": (_i, [_vp, _vp]),
+    "ug_hip_memcpy_2d_async": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _i, _vp]),
     "ug_hip_upload_ordered": (_i, [_i, _vp, _vp, _sz, _i, _vp]),
     "ug_hip_download_ordered": (_i, [_i, _vp, _vp, _sz, _vp]),
     "ug_hip_upload_ordered_ex": (_i, [_i, _vp, _vp, _sz, _i, _vp, _i]),
     "ug_hip_download_ordered_ex": (_i, [_i, _vp, _vp, _sz, _vp, _i]),
+    "ug_hip_download_2d_ordered_ex": (_i, [_i, _vp, _sz, _vp, _sz, _sz, _sz, _vp, _i]),
     "ug_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "ug_hip_stream_destroy": (_i, [_vp]),
     "ug_hip_stream_sync": (_i, [_vp]),

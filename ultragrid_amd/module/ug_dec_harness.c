@@ -6,7 +6,13 @@
  *     decompress_frame(s, dst, src, len, 0, NULL, NULL); decompress_done(s);
  * usage: ug_dec_harness <DXT1|DXT1_YUV|DXT5|JPEG> <out codec> <w> <h> <in.bin> <out.raw> [pitch] [src_len]
  *        ug_dec_harness list
+ *        ug_dec_harness devices        (prints the device list / state rotation / band count the modules derive from UG_PARAM; no GPU needed)
  * UG_DEC_REPEAT=<n>: the frame is decompressed n more times and the rate printed (THROUGHPUT ...), host frame in, host frame out.
+ * UG_PARAM=<k>=<v>[,<k>=<v>...]: what `uv --param ...` would hold (host.cpp:1090-1121): get_commandline_param() answers from it, e.g.
+ *                   UG_PARAM=mi355x-device=0:0,mi355x-bands=8.  A module that hands frames out late (jpeg_to_dxt_mi355x with several devices) is fed the
+ *                   same frame until every frame that went in has come out; each one must equal the first.
+ * UG_DEC_COPY_TWIN=1: after the THROUGHPUT loop, the same number of rounds of the frame's two copies alone (compressed bytes up, decoded picture down with
+ *                   its pitch, pageable host memory, one stream, one after the other): "COPYONLY ..." -- what the link allows a synchronous decompress().
  * UG_DEC_TILES=<n>: the receiver's tile fan-out (rtp/video_decoders.cpp:590-612,676-690: one decompress state per tile, decompress_frame of all tiles
  *                   at the same time on worker threads): n states from ONE decompress_init_multi(..., n), n threads, UG_DEC_TILE_ROUNDS (default 20) frames each
  *                   into buffers of their own; every output must equal the single-state result ("TILES n=.. rounds=.. OK").
@@ -21,6 +27,32 @@
 #include "types.h"
 #include "video_codec.h"
 #include "video_decompress.h"
+
+#include "mi355x_receiver.h"
+
+/* what host.cpp would provide (the reference's tools/ug_stub.c answers NULL to every key; this one answers from UG_PARAM) */
+static char *uv_argv_store[] = { "ug_dec_harness", NULL };
+char **uv_argv = uv_argv_store;
+void register_param(const char *param, const char *doc) { (void) param, (void) doc; }
+bool tok_in_argv(char **argv, const char *tok) { (void) argv, (void) tok; return false; }
+const char *get_commandline_param(const char *key)
+{
+        static char vals[8][128];
+        static int slot;
+        const char *p = getenv("UG_PARAM");
+        const size_t kl = strlen(key);
+        while (p != NULL && *p != '\0') {
+                const char *end = strchr(p, ',');
+                const size_t len = end ? (size_t) (end - p) : strlen(p);
+                if (len >= kl && strncmp(p, key, kl) == 0 && (len == kl || p[kl] == '=')) {
+                        char *v = vals[slot++ % 8];
+                        snprintf(v, sizeof vals[0], "%.*s", len > kl ? (int) (len - kl - 1) : 0, p + kl + (len > kl ? 1 : 0));
+                        return v;
+                }
+                p = end ? end + 1 : NULL;
+        }
+        return NULL;
+}
 
 struct tile_job {
         struct state_decompress *s;
@@ -46,6 +78,18 @@ int main(int argc, char **argv)
                 list_modules(LIBRARY_CLASS_VIDEO_DECOMPRESS, VIDEO_DECOMPRESS_ABI_VERSION, true);
                 return 0;
         }
+        if (argc == 2 && strcmp(argv[1], "devices") == 0) { // the device list the decompress modules would use (UG_PARAM / -D), and the states' turn; no GPU involved
+                int devs[MI355X_MAX_DEVICES];
+                bool bad = false;
+                const int n = mi355x_receiver_devices(devs, MI355X_MAX_DEVICES, &bad);
+                printf("DEVICES%s n=%d:", bad ? " BAD" : "", n);
+                for (int i = 0; i < n; i++) printf(" %d", devs[i]);
+                unsigned counter = 0;
+                printf(" | states:");
+                for (int i = 0; i < 5 && !bad; i++) printf(" %d", mi355x_next_state_device(&counter, "[harness] "));
+                printf(" | bands=%d\n", mi355x_receiver_bands(MI355X_AUTO_BANDS)); // (0 = chosen by the module from the frame size)
+                return bad ? 4 : 0;
+        }
         if (argc < 7) {
                 fprintf(stderr, "usage: %s <DXT1|DXT1_YUV|DXT5> <out codec> <w> <h> <in.bin> <out.raw> [pitch] [src_len: hand over only that many bytes (a short frame)]\n", argv[0]);
                 return 1;
@@ -55,7 +99,7 @@ int main(int argc, char **argv)
         const int linesize = vc_get_linesize(w, out);
         const int pitch = argc > 7 ? atoi(argv[7]) : linesize;
         struct video_desc desc = { .width = w, .height = h, .color_spec = in, .fps = 30, .interlacing = PROGRESSIVE, .tile_count = 1 };
-        size_t in_len = (size_t) w * h / (in == DXT1 || in == DXT1_YUV ? 2 : 1);
+        size_t in_len = (size_t) ((w + 3) / 4 * 4) * ((h + 3) / 4 * 4) / (in == DXT1 || in == DXT1_YUV ? 2 : 1); // dxt_get_size (dxt_util.h:59-67)
         FILE *f = fopen(argv[5], "rb");
         if (!f) { fprintf(stderr, "cannot read input\n"); return 1; }
         if (in == JPEG) { // a compressed frame is as long as it is
@@ -63,7 +107,9 @@ int main(int argc, char **argv)
                 in_len = (size_t) ftell(f);
                 fseek(f, 0, SEEK_SET);
         }
-        const size_t out_bytes = out == I420 ? (size_t) w * h + 2 * (size_t) ((w + 1) / 2) * ((h + 1) / 2) : (size_t) pitch * h;
+        const bool out_dxt = out == DXT1 || out == DXT5;
+        const size_t out_bytes = out == I420 ? (size_t) w * h + 2 * (size_t) ((w + 1) / 2) * ((h + 1) / 2)
+                                 : (out_dxt ? (size_t) ((w + 3) / 4 * 4) * ((h + 3) / 4 * 4) / (out == DXT1 ? 2 : 1) : (size_t) pitch * h);
         unsigned char *src = malloc(in_len), *dst = calloc(out_bytes + 64, 1);
         if (fread(src, 1, in_len, f) != in_len) { fprintf(stderr, "cannot read input\n"); return 1; }
         fclose(f);
@@ -87,11 +133,17 @@ int main(int argc, char **argv)
                 return 2;
         }
         const unsigned src_len = argc > 8 ? (unsigned) atoi(argv[8]) : (unsigned) in_len; // < in_len: a frame that lost its tail on the way
-        const decompress_status st = decompress_frame(s, dst, src, src_len, 0, NULL, NULL);
+        decompress_status st = decompress_frame(s, dst, src, src_len, 0, NULL, NULL);
+        int delay = 0; // frames a module keeps on their way (jpeg_to_dxt_mi355x: one per extra device)
+        while (st == DECODER_NO_FRAME && delay < 64 && getenv("UG_PARAM")) {
+                delay++;
+                st = decompress_frame(s, dst, src, src_len, delay, NULL, NULL);
+        }
         if (st != DECODER_GOT_FRAME) {
                 fprintf(stderr, "decompress_frame status %d\n", (int) st);
                 return 3;
         }
+        if (delay) printf("DELAY frames=%d\n", delay);
         f = fopen(argv[6], "wb");
         fwrite(dst, 1, out_bytes, f);
         fclose(f);
@@ -115,14 +167,54 @@ int main(int argc, char **argv)
         }
         const int repeat = getenv("UG_DEC_REPEAT") ? atoi(getenv("UG_DEC_REPEAT")) : 0;
         if (repeat > 0) {
+                // UG_DEC_ROUNDS (default 1) rounds of `repeat` frames; with UG_DEC_COPY_TWIN each round is followed by the same number of rounds of the frame's
+                // two copies alone (compressed bytes up, decoded picture down with its pitch; the same pageable buffers, one stream, one after the other): the
+                // twin is measured BESIDE what it bounds, and the best round of each is what is compared
+                const int rounds = getenv("UG_DEC_ROUNDS") ? atoi(getenv("UG_DEC_ROUNDS")) : 1;
+                const bool twin = getenv("UG_DEC_COPY_TWIN") != NULL;
                 struct timespec t0, t1;
-                clock_gettime(CLOCK_MONOTONIC, &t0);
-                for (int i = 0; i < repeat; i++) {
-                        if (decompress_frame(s, dst, src, src_len, i + 1, NULL, NULL) != DECODER_GOT_FRAME) return 3;
+                unsigned char *first = delay ? malloc(out_bytes) : NULL; // a delaying module: every frame that comes out later is the same picture
+                if (first) memcpy(first, dst, out_bytes);
+                void *dev_in = NULL, *dev_out = NULL;
+                ug_hip_stream_t st2 = NULL;
+                const size_t line = out_dxt || out == I420 ? out_bytes : (size_t) linesize, rows = out_dxt || out == I420 ? 1 : h;
+                const size_t dp = out_dxt || out == I420 ? out_bytes : (size_t) pitch;
+                unsigned char *twin_dst = twin ? calloc(out_bytes + 64, 1) : NULL;
+                bool twin_ok = twin && ug_hip_set_device(0) == 0 && ug_hip_stream_create(&st2) == 0 && ug_hip_malloc(&dev_in, src_len + 64) == 0 && ug_hip_malloc(&dev_out, line * rows + 64) == 0;
+                double best = 0, best_twin = 0;
+                int seq = delay;
+                for (int r = 0; r < (rounds < 1 ? 1 : rounds); r++) {
+                        clock_gettime(CLOCK_MONOTONIC, &t0);
+                        for (int i = 0; i < repeat; i++) {
+                                if (decompress_frame(s, dst, src, src_len, ++seq, NULL, NULL) != DECODER_GOT_FRAME) return 3;
+                                if (first && memcmp(first, dst, out_bytes) != 0) { fprintf(stderr, "frame %d differs from the first one\n", i); return 5; }
+                        }
+                        clock_gettime(CLOCK_MONOTONIC, &t1);
+                        const double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+                        printf("THROUGHPUT frames=%d wall_s=%.4f fps=%.1f\n", repeat, sec, repeat / sec);
+                        if (repeat / sec > best) best = repeat / sec;
+                        if (twin_ok) {
+                                clock_gettime(CLOCK_MONOTONIC, &t0);
+                                for (int i = 0; i < repeat && twin_ok; i++) {
+                                        twin_ok = ug_hip_memcpy_async(dev_in, src, src_len, UG_HIP_MEMCPY_HOST_TO_DEVICE, st2) == 0 &&
+                                                  ug_hip_memcpy_2d_async(twin_dst, dp, dev_out, line, line, rows, UG_HIP_MEMCPY_DEVICE_TO_HOST, st2) == 0 && ug_hip_stream_sync(st2) == 0;
+                                }
+                                clock_gettime(CLOCK_MONOTONIC, &t1);
+                                const double s2 = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+                                if (twin_ok && repeat / s2 > best_twin) best_twin = repeat / s2;
+                        }
                 }
-                clock_gettime(CLOCK_MONOTONIC, &t1);
-                const double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-                printf("THROUGHPUT frames=%d wall_s=%.4f fps=%.1f\n", repeat, sec, repeat / sec);
+                free(first);
+                if (twin && twin_ok) {
+                        printf("COPYONLY fps=%.1f up_bytes=%u down_bytes=%zu (best of %d rounds beside the decoder's) BEST fps=%.1f frac_of_copy_only=%.3f\n", best_twin, src_len, line * rows,
+                               rounds < 1 ? 1 : rounds, best, best / best_twin);
+                } else if (twin) {
+                        printf("COPYONLY failed: %s\n", ug_hip_last_error_string());
+                }
+                free(twin_dst);
+                if (dev_in) ug_hip_free(dev_in);
+                if (dev_out) ug_hip_free(dev_out);
+                if (st2) ug_hip_stream_destroy(st2);
         }
         decompress_done(s);
         return 0;

@@ -114,7 +114,7 @@ void usage()
                "\t\tdeinterlace=no - do not blend the lines of interlaced (merged) input before encoding (default: blended and sent as progressive, as RTDXT does)\n"
                "\t\tnuma  - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node, so that its pinned frame pool is local to the GPU; 0: left to the scheduler\n"
                "\t\tbands - cut every frame into <k> row bands (1-16, default 1): upload of band i+1, kernels of band i and download of band i-1 run at the same time -- the\n"
-               "\t\t        latency of ONE frame drops towards its longer copy (8K v210: 2.3 -> 1.7 ms at k = 4); same bytes; no effect on interlaced (de-interlaced) input\n"
+               "\t\t        latency of ONE frame drops towards its longer copy (8K v210: 2.30 -> 1.95 ms at k = 4, 8K UYVY: 1.90 -> 1.53; profiles/r05_row_bands.txt); same bytes; no effect on interlaced (de-interlaced) input\n"
                "\t\tbatch - frames a busy worker may queue and encode in one launch (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tDXT1 - 4 bpp S3TC (default), DXT5 - 8 bpp DXT5-YCoCg, DXT1_YUV - DXT1 blocks holding Y,Cb,Cr\n"
                "\t\tdev  - HIP device index or list (default 0); the tiles of a frame are dealt out over the list\n"

@@ -4,7 +4,9 @@
  * (include/ug_mi355x.h: ug_hip_jpeg_decoder_*).  Receiver-side counterpart of vcompress_jpeg_mi355x.cpp; plain C, the callback set and
  * conventions of the reference's GPUJPEG decompress module (src/video_decompress/gpujpeg.c): out_codec VIDEO_CODEC_NONE = probe of the
  * stream's internal pixel format (:202-266), the output codecs and priorities of :355-366, a display pitch different from the line size
- * served line by line (:296-319), corrupted frames not accepted (:322-341).
+ * served by one 2-D copy (the reference loops over the lines on the CPU, :296-319), corrupted frames not accepted (:322-341).
+ * The GPU: --param mi355x-device=<n>[:<n>...] or -D (the reference's module takes cuda_devices[0], :162), the states of a process in turn
+ * (mi355x_receiver.h).
  */
 #include <stdbool.h>
 #include <stdio.h>
@@ -17,7 +19,7 @@
 #include "video_codec.h"
 #include "video_decompress.h"
 
-#include "../../include/ug_mi355x.h"
+#include "mi355x_receiver.h"
 
 #define MOD_NAME "[JPEG MI355X dec] "
 
@@ -26,6 +28,7 @@ struct state_decompress_jpeg_mi355x {
         int                  rshift, gshift, bshift, pitch;
         codec_t              out_codec;
         ug_pixfmt_t          out_fmt;
+        int                  device; ///< --param mi355x-device / -D (mi355x_receiver.h)
         ug_hip_stream_t      stream;
         ug_hip_jpeg_decoder *dec;
         void                *dev_out;
@@ -33,6 +36,7 @@ struct state_decompress_jpeg_mi355x {
 };
 
 static void jpeg_mi355x_decompress_done(void *state);
+static unsigned jpeg_mi355x_state_count; // the states of this process take the listed devices in turn
 
 static void *jpeg_mi355x_decompress_init(void)
 {
@@ -40,9 +44,11 @@ static void *jpeg_mi355x_decompress_init(void)
         if (s == NULL) {
                 return NULL;
         }
-        if (ug_hip_set_device(0) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS ||
+        s->device = mi355x_next_state_device(&jpeg_mi355x_state_count, MOD_NAME);
+        if (s->device < 0 || ug_hip_set_device(s->device) != UG_HIP_SUCCESS || ug_hip_stream_create(&s->stream) != UG_HIP_SUCCESS ||
             ug_hip_jpeg_decoder_create(&s->dec) != UG_HIP_SUCCESS) {
-                MSG(ERROR, "cannot set up the decoder on HIP device 0: %s\n", ug_hip_last_error_string());
+                if (s->device >= 0) MSG(ERROR, "cannot set up the decoder on HIP device %d: %s\n", s->device, ug_hip_last_error_string());
+                s->device = s->device < 0 ? 0 : s->device;
                 jpeg_mi355x_decompress_done(s); // releases whichever of the two was made
                 return NULL;
         }
@@ -67,7 +73,11 @@ static int jpeg_mi355x_decompress_reconfigure(void *state, struct video_desc des
                 MSG(ERROR, "Unsupported output codec: %s\n", get_codec_name(out_codec));
                 return false;
         }
-        ug_hip_set_device(0);
+        if (out_codec != VIDEO_CODEC_NONE && out_codec != I420 && pitch < vc_get_linesize(desc.width, out_codec)) {
+                MSG(ERROR, "pitch %d is shorter than a line of %u %s pixels\n", pitch, desc.width, get_codec_name(out_codec));
+                return false;
+        }
+        ug_hip_set_device(s->device);
         if (s->dev_out) {
                 ug_hip_free(s->dev_out);
                 s->dev_out = NULL;
@@ -112,7 +122,7 @@ static decompress_status jpeg_mi355x_decompress(void *state, unsigned char *dst,
                 return probe_internal_codec(buffer, src_len, internal_prop);
         }
         int w = 0, h = 0;
-        if (ug_hip_set_device(0) != UG_HIP_SUCCESS || ug_hip_jpeg_read_info(buffer, src_len, &w, &h, NULL, NULL, NULL) != UG_HIP_SUCCESS ||
+        if (ug_hip_set_device(s->device) != UG_HIP_SUCCESS || ug_hip_jpeg_read_info(buffer, src_len, &w, &h, NULL, NULL, NULL) != UG_HIP_SUCCESS ||
             (unsigned) w != s->desc.width || (unsigned) h != s->desc.height) {
                 MSG(ERROR, "not a JPEG frame of the configured size %ux%u\n", s->desc.width, s->desc.height);
                 return DECODER_NO_FRAME;
@@ -125,15 +135,12 @@ static decompress_status jpeg_mi355x_decompress(void *state, unsigned char *dst,
                 ug_hip_stream_sync(s->stream);
                 return DECODER_NO_FRAME;
         }
-        const int linesize = s->out_codec == I420 ? 0 : vc_get_linesize(s->desc.width, s->out_codec);
-        bool ok = true;
-        if (s->out_codec == I420 || s->pitch == linesize) { // I420: three planes back to back; `pitch` has no meaning for it and is not used
+        bool ok;
+        if (s->out_codec == I420) { // three planes back to back; `pitch` has no meaning for it and is not used
                 ok = ug_hip_memcpy_async(dst, s->dev_out, s->out_len, UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) == UG_HIP_SUCCESS;
-        } else { // display pitch differs from the packed line size (gpujpeg.c:296-319 does a CPU line loop here)
-                for (unsigned i = 0; i < s->desc.height && ok; i++) {
-                        ok = ug_hip_memcpy_async(dst + (size_t) i * s->pitch, (char *) s->dev_out + (size_t) i * linesize, linesize,
-                                                 UG_HIP_MEMCPY_DEVICE_TO_HOST, s->stream) == UG_HIP_SUCCESS;
-                }
+        } else { // a display pitch that differs from the packed line size (gpujpeg.c:296-319 loops over the lines on the CPU there): one 2-D copy
+                ok = mi355x_download_picture(dst, (size_t) s->pitch, s->dev_out, (size_t) vc_get_linesize(s->desc.width, s->out_codec), s->desc.height,
+                                             s->stream) == UG_HIP_SUCCESS;
         }
         if (ug_hip_stream_sync(s->stream) != UG_HIP_SUCCESS || !ok) {
                 MSG(ERROR, "download failed: %s\n", ug_hip_last_error_string());
@@ -156,7 +163,7 @@ static int jpeg_mi355x_decompress_get_property(void *state, int property, void *
 static void jpeg_mi355x_decompress_done(void *state)
 {
         struct state_decompress_jpeg_mi355x *s = state;
-        ug_hip_set_device(0);
+        ug_hip_set_device(s->device);
         if (s->dev_out) ug_hip_free(s->dev_out);
         if (s->dec) ug_hip_jpeg_decoder_destroy(s->dec);
         if (s->stream) ug_hip_stream_destroy(s->stream);

@@ -82,13 +82,17 @@ def _rate_loop(submit, slots, seconds: float, min_frames: int):
 
 
 def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_frames: int = 30, distinct: int = 3, salt: int = 0,
-        mode: str = "per-frame-stream", encode: bool = True) -> dict:
+        mode: str = "per-frame-stream", encode: bool = True, copy_only_runs: int = 0, copy_only_seconds: float = 0.7) -> dict:
     """`depth` frames in flight, `distinct` different pinned input frames cycled.  Runs for about `seconds`; returns fps, Mpixel/s and the
     PCIe traffic both ways.
       mode "per-frame-stream": every frame in flight has its own stream carrying H2D, encode, D2H in order (what the modules do);
       mode "split": ONE upload stream, ONE compute stream, ONE download stream, events between the stages of a frame (copy engines never
                     share a stream with the kernel);
-      encode=False: the same traffic without the kernel -- what the link alone gives for this in/out byte mix (the ceiling of the leg)."""
+      encode=False: the same traffic without the kernel -- what the link alone gives for this in/out byte mix (the ceiling of the leg).
+      copy_only_runs = k > 0: the ceiling measured BESIDE the leg it bounds -- k copy-only runs of copy_only_seconds each (same slots, same pinned frames,
+                    same streams), the leg cut into k - 1 parts between them: copy, leg, copy, leg, ... copy.  The result carries "copy_only_fps" (the best
+                    run: a ceiling is what the link CAN do) and "copy_only_fps_runs"; fps is frames / time over the leg's parts.  A ceiling taken once,
+                    seconds after the leg, was beaten by the leg it was meant to bound by 5 % (VERDICT r5 "What's weak" #8)."""
     fmt, pf, oid, w, h = WORKLOADS[workload]
     lib.load()
     srcs = [torch.from_numpy(host_frame(workload, salt + i)).pin_memory() for i in range(distinct)]
@@ -103,7 +107,10 @@ def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_fra
     for s in slots:
         s["done"].record()
 
+    kernel = [encode]
+
     def submit(s, i):
+        encode = kernel[0]
         if mode == "split":
             with torch.cuda.stream(up):
                 s["dev_in"].copy_(srcs[i % distinct], non_blocking=True)
@@ -125,11 +132,25 @@ def run(workload: str = "8k-v210", depth: int = 3, seconds: float = 2.0, min_fra
                 s["host_out"].copy_(s["dev_out"], non_blocking=True)
                 s["done"].record()
 
-    n, dt = _rate_loop(submit, slots, seconds, min_frames)
+    extra = {}
+    if copy_only_runs > 0 and encode:
+        parts = max(1, copy_only_runs - 1)
+        n, dt, ceil = 0, 0.0, []
+        for k in range(copy_only_runs):
+            kernel[0] = False
+            cn, cdt = _rate_loop(submit, slots, copy_only_seconds, min(min_frames, 10))
+            ceil.append(round(cn / cdt, 1))
+            kernel[0] = True
+            if k < parts:
+                pn, pdt = _rate_loop(submit, slots, seconds / parts, -(-min_frames // parts))
+                n, dt = n + pn, dt + pdt
+        extra = {"copy_only_fps": max(ceil), "copy_only_fps_runs": ceil}
+    else:
+        n, dt = _rate_loop(submit, slots, seconds, min_frames)
     fps = n / dt
     return {"workload": workload, "fps": round(fps, 1), "mpixels_per_s": round(w * h * fps / 1e6, 1), "frames": n, "seconds": round(dt, 3),
             "in_flight": depth, "mode": mode, "kernel": encode, "pcie_gbs": round((in_len + out_len) * fps / 1e9, 2), "h2d_gbs": round(in_len * fps / 1e9, 2),
-            "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len}
+            "d2h_gbs": round(out_len * fps / 1e9, 2), "bytes_in_per_frame": in_len, "bytes_out_per_frame": out_len, **extra}
 
 
 def latency_depth1(workload: str = "8k-v210", frames: int = 24, salt: int = 0, bands=(4, 8)) -> dict:
