@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define UG_HIP_ABI_VERSION 5 /* 5: ug_hip_memcpy_2d_async, ug_hip_download_2d_ordered_ex, ug_hip_event_* / ug_hip_stream_wait_event (additions), and the DXT encoder / decoders take ANY frame size (they refused sizes
+#define UG_HIP_ABI_VERSION 5 /* 5: ug_hip_memcpy_2d_async, ug_hip_download_2d_ordered_ex, ug_hip_event_* / ug_hip_stream_wait_event, ug_hip_jpeg_encoder_create_ex, ug_hip_jpeg_colour_* (additions), and the DXT encoder / decoders take ANY frame size (they refused sizes
                               * that are not multiples of 4; ug_hip_dxt_size rounds up to whole blocks as dxt_get_size does); 4: ug_hip_{upload,download}_ordered_ex (additions only); 2: tie-rule option (UG_DXT_TIES_*), default = ties to even; *_ex / batched entry points; 3: NUMA placement, de-interlace (additions), and ONE
                               * change of behaviour: ug_hip_jpeg_encoder_encode_batch with frames > 1 reports a stream that does not fit its slice through
                               * out_len[f] > out_capacity and returns success for the call (it used to fail the whole call with UG_HIP_EINVAL) */
@@ -439,6 +439,34 @@ int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restar
 /* subsampling = 420, 422 or 444 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */
 int    ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int restart_interval, int subsampling,
                                       ug_hip_jpeg_encoder **out);
+/* The rest of the reference module's encoder options (src/video_compress/gpujpeg.cpp:303-305,396-405):
+ *   internal_cs  color_space_internal -- the colour space the samples are CODED in.  UG_JPEG_CS_ASIS (what the two calls above do): the samples as
+ *                they come -- R, G, B for RGB input, the BT.709 limited-range Y'CbCr of UltraGrid's UYVY / I420 for the rest.  Otherwise the encoder
+ *                converts in front of its forward DCT (ug_hip_jpeg_colour_convert below), taking RGB input as full-range R'G'B' and UYVY as BT.709
+ *                limited range: RGB input + a Y'CbCr space -> a JFIF-shaped stream, components 1, 2, 3, chroma tables for Cb and Cr (Y601full IS
+ *                JFIF); UYVY input + BT.601 (either range) -> the usual 4:2:x stream of the converted samples; UG_JPEG_CS_RGB with RGB input and
+ *                UG_JPEG_CS_YCBCR_BT709 with UYVY / I420 input = UG_JPEG_CS_ASIS.  Not offered (UG_HIP_EUNSUPP at encode): UYVY / I420 coded as RGB,
+ *                I420 with a conversion.  The colour stage is UNPINNED towards libgpujpeg like the FDCT: published BT.601 / BT.709 definitions, fp32.
+ *   flags        UG_JPEG_NONINTERLEAVED (subsampling 444 only): one scan per component (T.81 A.2.2; restart intervals count blocks of the scan's
+ *                component) -- the reference's DEFAULT for RGB input (interleaved = 0 unless `:interleaved`, gpujpeg.cpp:303); the header then
+ *                carries what those scans use (RGB: quantiser and Huffman table 0 only).  The scans are coded one after the other and assembled
+ *                behind a synchronisation: slower than the single interleaved scan (one fused kernel). */
+#define UG_JPEG_CS_ASIS                0
+#define UG_JPEG_CS_RGB                 1 /* GPUJPEG_RGB: full-range R'G'B' */
+#define UG_JPEG_CS_YCBCR_BT601         2 /* GPUJPEG_YCBCR_BT601: limited range (16-235 / 16-240) */
+#define UG_JPEG_CS_YCBCR_BT601_256LVLS 3 /* GPUJPEG_YCBCR_BT601_256LVLS: full range -- the JFIF colour space */
+#define UG_JPEG_CS_YCBCR_BT709         4 /* GPUJPEG_YCBCR_BT709: limited range */
+#define UG_JPEG_NONINTERLEAVED         1
+int    ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restart_interval, int subsampling, int internal_cs, int flags,
+                                     ug_hip_jpeg_encoder **out);
+/* The colour stage by itself.  m[12]: out_i = m[4 i] * in_0 + m[4 i + 1] * in_1 + m[4 i + 2] * in_2 + m[4 i + 3] on 8-bit code values, cs_in -> cs_out
+ * (UG_JPEG_CS_RGB .. UG_JPEG_CS_YCBCR_BT709), derived in double from Kr / Kb of BT.601 (0.299, 0.114) and BT.709 (0.2126, 0.0722) and the 219 / 224
+ * (limited) or 255 / 255 (256 levels) code ranges.  convert: fmt = UG_PF_RGB (3 bytes per pixel, whatever the three components mean) or UG_PF_UYVY
+ * (every pixel with its pair's chroma, the two chroma results of a pair averaged); fp32, one multiply-add at a time, clamp, round to nearest even;
+ * pitch 0 = packed. */
+int    ug_hip_jpeg_colour_matrix(int cs_in, int cs_out, float m[12]);
+int    ug_hip_jpeg_colour_convert(ug_pixfmt_t fmt, int cs_in, int cs_out, const void *src_dev, int src_pitch, void *dst_dev, int dst_pitch, int width, int height,
+                                  ug_hip_stream_t stream);
 void   ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc);
 size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc);
 int    ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch,

@@ -181,3 +181,86 @@ void oracle_jpeg_fdct_quant_plane(const uint8_t *plane, int ls, int width, int h
                 }
         }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * The encoder's colour stage (color_space_internal of src/video_compress/gpujpeg.cpp:303-305,398-405; GPUJPEG's preprocessor, whose source is
+ * not in the reference tree: UNPINNED, like the FDCT).  Restated from the published definitions: luma weights Kr, Kb of BT.601 (0.299,
+ * 0.114) and BT.709 (0.2126, 0.0722); E'Cb = (B' - Y') / (2 (1 - Kb)), E'Cr = (R' - Y') / (2 (1 - Kr)); 8-bit limited range
+ * 16 + 219 E'Y, 128 + 224 E'C; "256 levels" (JFIF) 255 E'Y, 128 + 255 E'C.  cs: 1 = full-range R'G'B', 2 = BT.601 limited,
+ * 3 = BT.601 256 levels, 4 = BT.709 limited (UG_JPEG_CS_* of include/ug_mi355x.h).
+ * ------------------------------------------------------------------------------------------------------------------------------- */
+static void cs_from_rgb(int cs, double t[3][4])
+{
+        const int bt709 = cs == 4, full = cs == 3;
+        const double kr = bt709 ? 0.2126 : 0.299, kb = bt709 ? 0.0722 : 0.114, kg = 1.0 - kr - kb;
+        const double ys = (full ? 255.0 : 219.0) / 255.0, cs_ = (full ? 255.0 : 224.0) / 255.0;
+        const double y[3] = { kr, kg, kb }, cb[3] = { -kr / (2 * (1 - kb)), -kg / (2 * (1 - kb)), 0.5 }, cr[3] = { 0.5, -kg / (2 * (1 - kr)), -kb / (2 * (1 - kr)) };
+        for (int i = 0; i < 3; i++) {
+                t[0][i] = ys * y[i];
+                t[1][i] = cs_ * cb[i];
+                t[2][i] = cs_ * cr[i];
+        }
+        t[0][3] = full ? 0.0 : 16.0;
+        t[1][3] = t[2][3] = 128.0;
+}
+
+int oracle_jpeg_colour_matrix(int cs_in, int cs_out, float m[12])
+{
+        if (cs_in < 1 || cs_in > 4 || cs_out < 1 || cs_out > 4) return -1;
+        double to_rgb[3][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 } }, from_rgb[3][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 } };
+        if (cs_in != 1) { /* invert the affine map RGB -> cs_in */
+                double a[3][4];
+                cs_from_rgb(cs_in, a);
+                const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                                   a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+                for (int i = 0; i < 3; i++) {
+                        for (int j = 0; j < 3; j++) {
+                                const int r0 = (j + 1) % 3, r1 = (j + 2) % 3, c0 = (i + 1) % 3, c1 = (i + 2) % 3;
+                                to_rgb[i][j] = (a[r0][c0] * a[r1][c1] - a[r0][c1] * a[r1][c0]) / det;
+                        }
+                }
+                for (int i = 0; i < 3; i++) to_rgb[i][3] = -(to_rgb[i][0] * a[0][3] + to_rgb[i][1] * a[1][3] + to_rgb[i][2] * a[2][3]);
+        }
+        if (cs_out != 1) cs_from_rgb(cs_out, from_rgb);
+        for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 4; j++) {
+                        double v = j == 3 ? from_rgb[i][3] : 0.0;
+                        for (int k = 0; k < 3; k++) v += from_rgb[i][k] * to_rgb[k][j];
+                        m[4 * i + j] = (float) v;
+                }
+        }
+        return 0;
+}
+
+static float cs_row(const float *m, float a, float b, float c)
+{
+        float t = m[0] * a;
+        t = t + m[1] * b;
+        t = t + m[2] * c;
+        return t + m[3];
+}
+static uint8_t cs_code(float v) { return (uint8_t) rintf(fminf(255.0f, fmaxf(0.0f, v))); }
+
+/* fmt 0: packed 3 bytes per pixel; 1: UYVY (every pixel with its pair's chroma; the pair's two chroma results averaged a * 0.5 + b * 0.5) */
+int oracle_jpeg_colour_convert(int fmt, int cs_in, int cs_out, const uint8_t *src, uint8_t *dst, int width, int height)
+{
+        float m[12];
+        if (oracle_jpeg_colour_matrix(cs_in, cs_out, m) || (fmt == 1 && (width & 1))) return -1;
+        for (long i = 0; i < (long) width * height / (fmt ? 2 : 1); i++) {
+                if (fmt == 0) {
+                        const float a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];
+                        dst[3 * i] = cs_code(cs_row(m, a, b, c));
+                        dst[3 * i + 1] = cs_code(cs_row(m + 4, a, b, c));
+                        dst[3 * i + 2] = cs_code(cs_row(m + 8, a, b, c));
+                } else {
+                        const float u = src[4 * i], y0 = src[4 * i + 1], v = src[4 * i + 2], y1 = src[4 * i + 3];
+                        const float cb0 = cs_row(m + 4, y0, u, v), cb1 = cs_row(m + 4, y1, u, v), cr0 = cs_row(m + 8, y0, u, v), cr1 = cs_row(m + 8, y1, u, v);
+                        const float cb = cb0 * 0.5f + cb1 * 0.5f, cr = cr0 * 0.5f + cr1 * 0.5f;
+                        dst[4 * i] = cs_code(cb);
+                        dst[4 * i + 1] = cs_code(cs_row(m, y0, u, v));
+                        dst[4 * i + 2] = cs_code(cr);
+                        dst[4 * i + 3] = cs_code(cs_row(m, y1, u, v));
+                }
+        }
+        return 0;
+}

@@ -527,6 +527,23 @@ def jpeg_decode_planes(data: bytes):
     return d, crop, planes
 
 
+def jpeg_colour_matrix(cs_in: int, cs_out: int) -> np.ndarray:
+    """oracle/jpeg_oracle.c: the 3 x 4 affine map of the encoder's colour stage on 8-bit code values (1 = RGB, 2 = BT.601, 3 = BT.601 256 levels, 4 = BT.709)"""
+    m = np.zeros(12, np.float32)
+    if lib().oracle_jpeg_colour_matrix(cs_in, cs_out, _ptr(m)):
+        raise ValueError("oracle_jpeg_colour_matrix")
+    return m.reshape(3, 4)
+
+
+def jpeg_colour_convert(fmt: str, cs_in: int, cs_out: int, src: np.ndarray, w: int, h: int) -> np.ndarray:
+    """fmt "RGB" (3 bytes per pixel, whatever they mean) or "UYVY"; packed lines"""
+    src = np.ascontiguousarray(src, np.uint8).ravel()
+    out = np.zeros_like(src)
+    if lib().oracle_jpeg_colour_convert(0 if fmt == "RGB" else 1, cs_in, cs_out, _ptr(src), _ptr(out), w, h):
+        raise ValueError("oracle_jpeg_colour_convert")
+    return out
+
+
 def jpeg_decode_coeffs(data: bytes):
     """The entropy decoder of oracle/jpeg_decode_oracle.c alone: (info dict, [quantised coefficients of each component as the stream codes them:
     (blocks of the MCU-padded grid in raster order, 64) int16, zig-zag order -- jpeg_fdct_quant_plane's layout])."""

@@ -103,14 +103,15 @@ def write_jpeg420(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, r
     return write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart, header_only, sub=420)
 
 
-def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart=0, header_only=False, sub=420):
+def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, restart=0, header_only=False, sub=420, ycc=False):
     """coef_*: (n_blocks, 64) int16 zig-zag; component-0 blocks in raster order over a (hs*mcu_w) x (vs*mcu_h) block grid,
     the others over mcu_w x mcu_h.  sub=420: MCU 16x16 (hs=vs=2); 422: MCU 16x8 (hs=2, vs=1), both JFIF YCbCr;
     444: MCU 8x8 (hs=vs=1), components R, G, B without colour transform, libjpeg conventions for JCS_RGB (Adobe APP14
     transform 0, ids 'R','G','B', table 0 for every component; pass the table-0 quantiser as qt_chroma too).
+    sub=444, ycc=True: 4:4:4 Y'CbCr instead (JFIF, components 1, 2, 3, the chroma tables for Cb and Cr).
     qt_*: 64 quantiser steps in natural order.  restart = MCUs per restart interval (0 = none).  Returns the stream."""
     hs, vs = (1, 1) if sub == 444 else ((2, 2) if sub == 420 else (2, 1))
-    rgb = sub == 444
+    rgb = sub == 444 and not ycc
     mw, mh = (width + 8 * hs - 1) // (8 * hs), (height + 8 * vs - 1) // (8 * vs)
     out = io.BytesIO()
     out.write(b"\xff\xd8")
@@ -155,24 +156,33 @@ def write_jpeg(width, height, qt_luma, qt_chroma, coef_y, coef_cb, coef_cr, rest
     return out.getvalue()
 
 
-def write_jpeg_noninterleaved(width, height, qt, coefs, restart=0):
+def write_jpeg_noninterleaved(width, height, qt, coefs, restart=0, qt_chroma=None):
     """Baseline R,G,B 4:4:4 stream with ONE SCAN PER COMPONENT (T.81 A.2.2: a non-interleaved scan walks the component's own
     ceil(size / 8) block grid; the restart interval counts its data units) -- the layout GPUJPEG writes for RGB input by default
-    (gpujpeg.cpp:302: interleaved = 0).  coefs: three (n_blocks, 64) zig-zag arrays over the 8x8-block grid; table 0 for everything."""
+    (gpujpeg.cpp:302: interleaved = 0).  coefs: three (n_blocks, 64) zig-zag arrays over the 8x8-block grid; table 0 for everything.
+    qt_chroma given: the same layout for Y'CbCr components (RGB input with color_space_internal = a Y'CbCr space): JFIF, components 1, 2, 3,
+    both quantiser tables and all four Huffman tables, the chroma ones for the Cb and Cr scans."""
     bw_, bh_ = (width + 7) // 8, (height + 7) // 8
+    ycc = qt_chroma is not None
     out = io.BytesIO()
     out.write(b"\xff\xd8")
-    out.write(b"\xff\xee" + struct.pack(">H5sHHHB", 14, b"Adobe", 100, 0, 0, 0))
+    if ycc:
+        out.write(b"\xff\xe0" + struct.pack(">H5sBBBHHBB", 16, b"JFIF\0", 1, 1, 0, 1, 1, 0, 0))
+    else:
+        out.write(b"\xff\xee" + struct.pack(">H5sHHHB", 14, b"Adobe", 100, 0, 0, 0))
     out.write(b"\xff\xdb" + struct.pack(">HB", 67, 0) + bytes(int(qt[i]) for i in ZIGZAG))
-    ids = (0x52, 0x47, 0x42)
-    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([ids[0], 0x11, 0, ids[1], 0x11, 0, ids[2], 0x11, 0]))
-    for (tc, th, (bits, vals)) in ((0, 0, DC_L), (1, 0, AC_L)):
+    if ycc:
+        out.write(b"\xff\xdb" + struct.pack(">HB", 67, 1) + bytes(int(qt_chroma[i]) for i in ZIGZAG))
+    ids = (1, 2, 3) if ycc else (0x52, 0x47, 0x42)
+    t12 = 1 if ycc else 0
+    out.write(b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, height, width, 3) + bytes([ids[0], 0x11, 0, ids[1], 0x11, t12, ids[2], 0x11, t12]))
+    for (tc, th, (bits, vals)) in ((0, 0, DC_L), (1, 0, AC_L)) + (((0, 1, DC_C), (1, 1, AC_C)) if ycc else ()):
         out.write(b"\xff\xc4" + struct.pack(">HB", 19 + len(vals), (tc << 4) | th) + bytes(bits) + bytes(vals))
     if restart:
         out.write(b"\xff\xdd" + struct.pack(">HH", 4, restart))
-    dcl, acl = _codes(*DC_L), _codes(*AC_L)
     for c in range(3):
-        out.write(b"\xff\xda" + struct.pack(">HB", 8, 1) + bytes([ids[c], 0x00, 0, 63, 0]))
+        dcl, acl = (_codes(*DC_C), _codes(*AC_C)) if ycc and c else (_codes(*DC_L), _codes(*AC_L))
+        out.write(b"\xff\xda" + struct.pack(">HB", 8, 1) + bytes([ids[c], 0x11 if ycc and c else 0x00, 0, 63, 0]))
         bw = _Bits()
         pred = 0
         for u in range(bw_ * bh_):

@@ -191,6 +191,8 @@ def _entry_points(l):
         "ug_hip_uyvy_to_jpeg42x_coeffs_batch": lambda w, h: l.ug_hip_uyvy_to_jpeg42x_coeffs_batch(420, _P, 0, w, h, _P, _P, _P, _P, 2, 0, 0, 0, None),
         "ug_hip_jpeg_encoder_create": lambda w, h: l.ug_hip_jpeg_encoder_create(w, h, 75, 4, C.byref(enc)),
         "ug_hip_jpeg_encoder_create_sub": lambda w, h: l.ug_hip_jpeg_encoder_create_sub(w, h, 75, 4, 422, C.byref(enc)),
+        "ug_hip_jpeg_encoder_create_ex": lambda w, h: l.ug_hip_jpeg_encoder_create_ex(w, h, 75, 4, 444, lib.JPEG_CS_YCBCR_BT601_256LVLS, lib.JPEG_NONINTERLEAVED, C.byref(enc)),
+        "ug_hip_jpeg_colour_convert": lambda w, h: l.ug_hip_jpeg_colour_convert(lib.PF_RGB, lib.JPEG_CS_RGB, lib.JPEG_CS_YCBCR_BT709, _P, 0, _P, 0, w, h, None),
     }
 
 

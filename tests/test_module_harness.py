@@ -370,7 +370,11 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
     if eff == 444:
         comp = rgb if codec == "RGB" else po.convert_frame("RGBA", "RGB", rgba, w, h).reshape(h, w, 3)
         coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comp[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
-        assert data == write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444)
+        from jpeg_bitstream import write_jpeg_noninterleaved
+        assert data == write_jpeg_noninterleaved(w, h, ql, coefs, restart=4)        # RGB input: one scan per component unless `:interleaved` (gpujpeg.cpp:303)
+        out_i = tmp_path / "out_i.jpg"
+        assert _run(["jpeg:q=80:restart=4:interleaved" + (f":subsampling={sub}" if sub else ""), codec, w, h, raw, out_i]).returncode == 0
+        assert out_i.read_bytes() == write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444)
         img = Image.open(io.BytesIO(data))
         assert img.mode == "RGB"
         assert 10 * np.log10(255.0 ** 2 / np.mean((np.asarray(img).astype(float) - rgb.astype(float)) ** 2)) > 36
@@ -498,7 +502,8 @@ def test_jpeg_every_codec_the_reference_module_takes(tmp_path, po, codec):
     else:
         comp = conv.reshape(h, w, 4 if target == "RGBA" else 3)
         coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comp[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
-        want = write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444)
+        from jpeg_bitstream import write_jpeg_noninterleaved
+        want = write_jpeg_noninterleaved(w, h, ql, coefs, restart=4)
     assert out.read_bytes() == want
 
 
@@ -546,10 +551,60 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
         assert r.returncode == 0, cfg + r.stdout + r.stderr
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] == outs[2]
-    assert _run(["jpeg:Y601", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 2
-    assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails: frame dropped
+    assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails (4:2:x input is not coded as R, G, B): frame dropped
     r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
-    assert r.returncode == 0 and "alpha" in (r.stdout + r.stderr)
+    assert r.returncode == 0 and "Requested alpha encode but input codec is unsupported pixel format" in (r.stdout + r.stderr)      # gpujpeg.cpp:327-328
+    rgba = tmp_path / "rgba.raw"
+    synth.s1_random("RGBA", w, h).tofile(rgba)
+    r = _run(["jpeg:alpha", "RGBA", w, h, rgba, tmp_path / "x"])
+    assert r.returncode == 3 and "fourth component" in (r.stdout + r.stderr)            # refused, not silently dropped
+    assert _run(["jpeg", "RGBA", w, h, rgba, tmp_path / "x"]).returncode == 0
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt,cs", [("Y601", 2), ("Y601full", 3), ("Y709", 4)])
+@pytest.mark.parametrize("codec", ["RGB", "RGBA", "UYVY", "v210"])
+def test_jpeg_internal_colour_space_options(tmp_path, po, codec, opt, cs):
+    """`-c jpeg:Y601 | Y601full | Y709` (gpujpeg.cpp:398-403): RGB-family input is coded as Y'CbCr 4:4:4 of that space (one scan per component, or one
+    with `:interleaved`), 4:2:x input as BT.601 where asked; bytes == the test writer's over the oracle's colour stage + FDCT; Pillow reads them all."""
+    import io
+    from PIL import Image
+    from jpeg_bitstream import write_jpeg, write_jpeg_noninterleaved
+    w, h = 200, 72
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1).clip(0, 255).astype(np.uint8)
+    ql, qc = po.jpeg_qtable(85, 0), po.jpeg_qtable(85, 1)
+    raw = tmp_path / "in.raw"
+    if codec in ("RGB", "RGBA"):
+        src = rgb.ravel() if codec == "RGB" else po.convert_frame("RGB", "RGBA", rgb, w, h)
+        np.ascontiguousarray(src).tofile(raw)
+        picture = rgb if codec == "RGB" else po.convert_frame("RGBA", "RGB", src, w, h).reshape(h, w, 3)
+        ycc = po.jpeg_colour_convert("RGB", 1, cs, picture, w, h).reshape(h, w, 3)
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(ycc[..., c]), po.jpeg_divisors(ql if c == 0 else qc), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        for cfg, want in ((f"jpeg:q=85:restart=4:{opt}", write_jpeg_noninterleaved(w, h, ql, coefs, restart=4, qt_chroma=qc)),
+                          (f"jpeg:q=85:restart=4:{opt}:interleaved", write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444, ycc=True))):
+            out = tmp_path / "o.jpg"
+            r = _run([cfg, codec, w, h, raw, out])
+            assert r.returncode == 0, cfg + r.stdout + r.stderr
+            assert out.read_bytes() == want, cfg
+            img = np.asarray(Image.open(io.BytesIO(want)).convert("RGB")).astype(float)
+            assert 10 * np.log10(255.0 ** 2 / np.mean((img - rgb) ** 2)) > (34 if opt == "Y601full" else 14)
+    else:
+        uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+        src = uyvy if codec == "UYVY" else po.convert_frame("UYVY", "v210", uyvy, w, h)
+        np.ascontiguousarray(src).tofile(raw)
+        as_uyvy = uyvy if codec == "UYVY" else po.convert_frame("v210", "UYVY", src, w, h)
+        conv = as_uyvy if opt == "Y709" else po.jpeg_colour_convert("UYVY", 4, cs, as_uyvy, w, h)
+        y, u, v = po.uyvy_to_i422(conv, w, h)
+        mw, mh = (w + 15) // 16, (h + 7) // 8
+        want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, mh), po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh),
+                          po.jpeg_fdct_quant_plane(v, po.jpeg_divisors(qc), mw, mh), restart=4, sub=422)
+        out = tmp_path / "o.jpg"
+        r = _run([f"jpeg:q=85:restart=4:{opt}", codec, w, h, raw, out])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert out.read_bytes() == want
+        Image.open(io.BytesIO(want)).load()
 
 
 @needs_dec_harness

@@ -290,14 +290,36 @@ def uyvy_to_jpeg420_coeffs(src: torch.Tensor, w: int, h: int, div: torch.Tensor)
     return uyvy_to_jpeg_coeffs(src, w, h, div, 420)
 
 
+def jpeg_colour_matrix(cs_in: int, cs_out: int):
+    """the 3 x 4 affine map of the JPEG encoder's colour stage on 8-bit code values (ug_hip_jpeg_colour_matrix); no GPU involved"""
+    import ctypes as C
+    import numpy as np
+    m = (C.c_float * 12)()
+    L.check(L.load().ug_hip_jpeg_colour_matrix(cs_in, cs_out, m), "ug_hip_jpeg_colour_matrix")
+    return np.frombuffer(m, np.float32).reshape(3, 4).copy()
+
+
+def jpeg_colour_convert(fmt: int, cs_in: int, cs_out: int, src: torch.Tensor, w: int, h: int) -> torch.Tensor:
+    """RGB (3 B/px) or UYVY frame from colour space cs_in to cs_out (L.JPEG_CS_RGB .. L.JPEG_CS_YCBCR_BT709), packed lines"""
+    src = _u8(src)
+    dst = torch.empty_like(src)
+    L.check(L.load().ug_hip_jpeg_colour_convert(fmt, cs_in, cs_out, src.data_ptr(), 0, dst.data_ptr(), 0, w, h, _stream()), "ug_hip_jpeg_colour_convert")
+    return dst
+
+
 class JpegEncoder:
     """ug_hip_jpeg_encoder_* (gpujpeg_encoder_create / _encode / _destroy shape, gpujpeg.cpp:353,624,639)."""
 
-    def __init__(self, w: int, h: int, quality: int = 75, restart_interval: int = 4, subsampling: int = 420):
+    def __init__(self, w: int, h: int, quality: int = 75, restart_interval: int = 4, subsampling: int = 420, internal_cs: int = 0, flags: int = 0):
+        """internal_cs: L.JPEG_CS_* (color_space_internal of gpujpeg.cpp:303-305), flags: L.JPEG_NONINTERLEAVED (ug_hip_jpeg_encoder_create_ex)"""
         import ctypes as C
         self._h = C.c_void_p()
-        L.check(L.load().ug_hip_jpeg_encoder_create_sub(w, h, quality, restart_interval, subsampling, C.byref(self._h)),
-                "ug_hip_jpeg_encoder_create_sub")
+        if internal_cs or flags:
+            L.check(L.load().ug_hip_jpeg_encoder_create_ex(w, h, quality, restart_interval, subsampling, internal_cs, flags, C.byref(self._h)),
+                    "ug_hip_jpeg_encoder_create_ex")
+        else:
+            L.check(L.load().ug_hip_jpeg_encoder_create_sub(w, h, quality, restart_interval, subsampling, C.byref(self._h)),
+                    "ug_hip_jpeg_encoder_create_sub")
         self.max_size = L.load().ug_hip_jpeg_encoder_max_size(self._h)
         self._out = None
 

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "ug_common.h"
@@ -550,6 +551,9 @@ __device__ __forceinline__ uint32_t lookback_exclusive_flat(unsigned long long *
 struct CodeArgs {
         // scan geometry
         int mcu_w, n_mcu, hs, vs, ctab, ri, n_seg, S /* blocks per full segment */, G /* segments per workgroup (SRC = 0) */, n_wg /* workgroups per frame */;
+        // SRC = 0 only: nc = chroma blocks of an MCU -- 2, or 0 for the scan of ONE component (a non-interleaved scan, T.81 A.2.2: its MCU is one block, cy = that
+        // component's blocks); tab0 = the Huffman table pair of the blocks b < hs * vs (0; 1 for the Cb / Cr scans of a non-interleaved YCbCr stream)
+        int nc, tab0;
         // SRC = 0: quantised blocks in HBM, per-frame strides in int16 elements
         const int16_t *cy, *cb, *cr;
         long coef_y, coef_c;
@@ -660,7 +664,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 if (tid < 24) dc_tab[tid / 12][tid % 12] = kDcTab[tid / 12][tid % 12];
                 if (tid < 2) lds_flag[tid] = 0;
         };
-        const int ybl = a.hs * a.vs, per_mcu = ybl + 2, S = a.S, ri = a.ri;
+        const int nc = SRC == 0 ? a.nc : 2; // (the fused variants code three components: a constant there)
+        const int ybl = a.hs * a.vs, per_mcu = ybl + nc, S = a.S, ri = a.ri;
         // ---- which segments, which block ----
         int seg0, nseg_wg, m0 = 0; // m0 (fused): the workgroup's first MCU, raster order
         if (SRC == 0) {
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 n_blk = sl < nseg_wg ? per_mcu * (min(a.n_mcu, m_first + ri) - m_first) : 0;
                 active = j < n_blk;
                 ml = div16(j, a.per_mcu_m16); b = j - ml * per_mcu; // MCU of the segment, block of the MCU
-                comp = b < ybl ? 0 : a.ctab;
+                comp = b < ybl ? (SRC == 0 ? a.tab0 : 0) : a.ctab;
         };
         uint32_t w[32];
         if (SRC == 0) {
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
         lds_dc[sid] = dc;
         __syncthreads(); // tables, DC values; (SRC = 0) the staging rows have been read
         UG_PHASE(1) // tables + DC values (SRC = 0: the block loads)
-        const int back = b < ybl ? (b > 0 ? 1 : 3) : per_mcu;
+        const int back = b < ybl ? (b > 0 ? 1 : 1 + nc) : per_mcu;
         const bool has_pred = b < ybl ? j > 0 : ml > 0;
         const int diff = dc - (has_pred ? lds_dc[max(sid - back, 0)] : 0);
         const uint32_t dneg = (uint32_t) (diff >> 31), da = ((uint32_t) diff ^ dneg) - dneg;
@@ -1133,7 +1138,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 const int wbits = wsl < nseg_wg ? lds_seg_bits[wsl] : 0; // (written before the merge's barrier)
                 const uint32_t *const wwin = win + min(wsl * S, W - 1) * kWin;
                 const int nbytes = (wbits + 7) >> 3, nwords = (nbytes + 3) >> 2; // (0 for lanes behind the workgroup's last segment)
-                const int K = div32(nwords + S - 1, a.S_m32), i_first = wj * K;
+                const int K = SRC == 0 && S == 1 ? nwords : div32(nwords + S - 1, a.S_m32), i_first = wj * K; // (S = 1 -- a one-component scan with restart interval 1 -- has no 32-bit reciprocal)
                 const int padw = wbits >> 5, padn = 8 - (wbits & 7);
                 const uint32_t padmask = (wbits & 7) ? ((1u << padn) - 1u) << (32 - (wbits & 31) - padn) : 0u;
                 const bool seg_last = wsl < nseg_wg && wj == S - 1; // the lane that writes the marker behind the segment
@@ -1360,38 +1365,61 @@ struct Encoder {
         bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
         bool flat_lookback;     // one-frame calls: the flat form of the look-back (the default; UG_JPEG_FLAT=0 switches back to the windowed walk for A/B)
         uint8_t *header_dev;
-        uint32_t *total_host; // pinned, mapped
+        uint32_t *total_host; // pinned, mapped: kTotalWords words for the stream(s) of a call, then as many per scan of a non-interleaved stream
         uint32_t *total_host_dev; // the same word as the device sees it
+        // ug_hip_jpeg_encoder_create_ex (gpujpeg.cpp:303-305,396-405)
+        bool ycc;      // 4:4:4 coded as Y'CbCr (components 1, 2, 3, chroma tables for Cb / Cr) instead of R, G, B
+        bool nonint;   // one scan per component (4:4:4 only)
+        int ctab;      // Huffman table pair of the chroma blocks: 0 = the luma pair (R, G, B streams), 1
+        int cs_rgb;    // RGB input is converted to this colour space in front of the FDCT (0: coded as it comes)
+        int cs_uyvy;   // UYVY input (BT.709 limited range) is converted to this one (0: coded as it comes)
+        uint8_t *cs_tmp;       // the converted frame(s)
+        size_t cs_tmp_bytes;
+        std::vector<uint8_t> scan_header[3]; // non-interleaved: what precedes the entropy-coded bytes of scan c (scan 0: the whole header)
+        uint8_t *scan_header_dev[3];
+        uint8_t *scan_tmp;     // non-interleaved: the three scans of every frame of a call before they are put behind one another
+        size_t scan_tmp_bytes;
 };
+constexpr int kTotalWords = 32; // per block of total_host: kMaxBatch lengths, [kMaxBatch] "a wait was given up", [kMaxBatch + 1] "a slot overflowed"
 
 void put16(std::vector<uint8_t> &v, int x) { v.push_back((uint8_t) (x >> 8)); v.push_back((uint8_t) x); }
 
-std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t *qc, int ri, int sub)
+// 4:2:0 / 4:2:2: JFIF (YCbCr, BT.709 limited range samples as they come from the UYVY frame, or what internal_cs asked for).  4:4:4, !ycc: the
+// components are R, G, B without colour transform (what the reference's module asks of GPUJPEG for RGB input: color_space_internal =
+// GPUJPEG_RGB, gpujpeg.cpp:303-305), signalled the libjpeg way: Adobe APP14 with transform 0 and ids 'R','G','B'; every component uses
+// quantiser / Huffman table 0.  4:4:4, ycc: JFIF again, components 1, 2, 3 at 1x1.  scan >= 0: the header of a NON-INTERLEAVED stream up to and
+// including the SOS of its first scan (scan = 0; an R, G, B stream then carries table 0 only, the layout of tests/jpeg_bitstream.py
+// write_jpeg_noninterleaved), or just the SOS segment of scan 1 / 2.
+std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t *qc, int ri, int sub, bool ycc = false, int scan = -1)
 {
-        // 4:2:0 / 4:2:2: JFIF (YCbCr, BT.709 limited range samples as they come from the UYVY frame).  4:4:4: the components are
-        // R, G, B without colour transform (what the reference's module asks of GPUJPEG for RGB input: color_space_internal =
-        // GPUJPEG_RGB, gpujpeg.cpp:303-305), signalled the libjpeg way: Adobe APP14 with transform 0 and ids 'R','G','B';
-        // every component uses quantiser / Huffman table 0.
-        const bool rgb = sub == 444;
-        std::vector<uint8_t> v = { 0xFF, 0xD8 };
+        const bool rgb = sub == 444 && !ycc;
+        const uint8_t id[3] = { (uint8_t) (rgb ? 'R' : 1), (uint8_t) (rgb ? 'G' : 2), (uint8_t) (rgb ? 'B' : 3) };
+        const uint8_t t12 = rgb ? 0 : 1;
+        std::vector<uint8_t> v;
+        if (scan > 0) {
+                v.insert(v.end(), { 0xFF, 0xDA, 0, 8, 1, id[scan], (uint8_t) (t12 * 0x11), 0, 63, 0 });
+                return v;
+        }
+        v = { 0xFF, 0xD8 };
         if (rgb) {
                 v.insert(v.end(), { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 });
         } else {
                 v.insert(v.end(), { 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 });
         }
-        for (int t = 0; t < 2; t++) {
+        const bool table0_only = scan == 0 && rgb;
+        for (int t = 0; t < (table0_only ? 1 : 2); t++) {
                 v.insert(v.end(), { 0xFF, 0xDB, 0, 67, (uint8_t) t });
                 for (int i = 0; i < 64; i++) v.push_back((t ? qc : ql)[kZigHost[i]]);
         }
         v.insert(v.end(), { 0xFF, 0xC0, 0, 17, 8 });
         put16(v, h); put16(v, w);
-        const uint8_t id[3] = { (uint8_t) (rgb ? 'R' : 1), (uint8_t) (rgb ? 'G' : 2), (uint8_t) (rgb ? 'B' : 3) };
-        const uint8_t s0 = sub == 420 ? 0x22 : (sub == 422 ? 0x21 : 0x11), t12 = rgb ? 0 : 1; // H x V sampling of component 0
+        const uint8_t s0 = sub == 420 ? 0x22 : (sub == 422 ? 0x21 : 0x11); // H x V sampling of component 0
         v.insert(v.end(), { 3, id[0], s0, 0, id[1], 0x11, t12, id[2], 0x11, t12 });
         const struct { int tc, th; const uint8_t *bits, *vals; int n; } dht[4] = {
                 { 0, 0, kDcL_bits, kDcL_vals, (int) sizeof kDcL_vals }, { 1, 0, kAcL_bits, kAcL_vals, (int) sizeof kAcL_vals },
                 { 0, 1, kDcC_bits, kDcC_vals, (int) sizeof kDcC_vals }, { 1, 1, kAcC_bits, kAcC_vals, (int) sizeof kAcC_vals } };
-        for (const auto &d : dht) {
+        for (int k = 0; k < (table0_only ? 2 : 4); k++) {
+                const auto &d = dht[k];
                 v.insert(v.end(), { 0xFF, 0xC4 });
                 put16(v, 19 + d.n);
                 v.push_back((uint8_t) (d.tc << 4 | d.th));
@@ -1402,8 +1430,12 @@ std::vector<uint8_t> build_header(int w, int h, const uint8_t *ql, const uint8_t
                 v.insert(v.end(), { 0xFF, 0xDD, 0, 4 });
                 put16(v, ri);
         }
-        const uint8_t h12 = rgb ? 0x00 : 0x11;
-        v.insert(v.end(), { 0xFF, 0xDA, 0, 12, 3, id[0], 0x00, id[1], h12, id[2], h12, 0, 63, 0 });
+        if (scan == 0) {
+                v.insert(v.end(), { 0xFF, 0xDA, 0, 8, 1, id[0], 0x00, 0, 63, 0 });
+        } else {
+                const uint8_t h12 = (uint8_t) (t12 * 0x11);
+                v.insert(v.end(), { 0xFF, 0xDA, 0, 12, 3, id[0], 0x00, id[1], h12, id[2], h12, 0, 63, 0 });
+        }
         return v;
 }
 
@@ -1491,7 +1523,8 @@ void destroy(Encoder *e)
                         fprintf(stderr, "\n");
                 }
         }
-        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket, (void *) e->prof }) {
+        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket, (void *) e->prof, (void *) e->cs_tmp, (void *) e->scan_tmp,
+                         (void *) e->scan_header_dev[0], (void *) e->scan_header_dev[1], (void *) e->scan_header_dev[2] }) {
                 if (p) (void) hipFree(p);
         }
         if (e->total_host) (void) hipHostFree(e->total_host);
@@ -1504,7 +1537,7 @@ extern "C" {
 
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 
-int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int restart_interval, int subsampling, ug_hip_jpeg_encoder **out)
+int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restart_interval, int subsampling, int internal_cs, int flags, ug_hip_jpeg_encoder **out)
 {
         if (!out || width <= 0 || height <= 0 || width > 65535 || height > 65535 || restart_interval < 1 || restart_interval > 65535) {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: bad arguments");
@@ -1514,7 +1547,24 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: subsampling must be 420, 422 or 444");
                 return UG_HIP_EUNSUPP;
         }
+        if (internal_cs < UG_JPEG_CS_ASIS || internal_cs > UG_JPEG_CS_YCBCR_BT709 || (flags & ~UG_JPEG_NONINTERLEAVED)) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: unknown colour space or flag");
+                return UG_HIP_EINVAL;
+        }
+        if (subsampling != 444 && ((flags & UG_JPEG_NONINTERLEAVED) || internal_cs == UG_JPEG_CS_RGB)) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: a 4:2:x stream is Y'CbCr in one interleaved scan (R, G, B components and one scan per component: 4:4:4)");
+                return UG_HIP_EUNSUPP;
+        }
+        if ((flags & UG_JPEG_NONINTERLEAVED) && restart_interval > 256) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: restart intervals of a non-interleaved stream: 1..256 blocks");
+                return UG_HIP_EUNSUPP;
+        }
         Encoder *e = new Encoder();
+        e->nonint = (flags & UG_JPEG_NONINTERLEAVED) != 0;
+        e->ycc = subsampling == 444 && internal_cs >= UG_JPEG_CS_YCBCR_BT601;
+        e->cs_rgb = e->ycc ? internal_cs : 0;
+        e->cs_uyvy = subsampling != 444 && (internal_cs == UG_JPEG_CS_YCBCR_BT601 || internal_cs == UG_JPEG_CS_YCBCR_BT601_256LVLS) ? internal_cs : 0;
+        e->ctab = subsampling == 444 && !e->ycc ? 0 : 1;
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
         e->force_wave_kernel = getenv("UG_JPEG_WAVE_KERNEL") != nullptr && getenv("UG_JPEG_WAVE_KERNEL")[0] == '1';
         e->allow_fused = !(getenv("UG_JPEG_FUSED") != nullptr && getenv("UG_JPEG_FUSED")[0] == '0');
@@ -1532,8 +1582,12 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         ug_hip_jpeg_qtable(quality, 0, ql);
         ug_hip_jpeg_qtable(quality, 1, qc);
         ug_hip_jpeg_divisors(ql, div);
-        ug_hip_jpeg_divisors(subsampling == 444 ? ql : qc, div + 64); // RGB: every component is quantised with table 0
-        e->header = build_header(width, height, ql, qc, e->ri, e->sub);
+        ug_hip_jpeg_divisors(e->ctab == 0 ? ql : qc, div + 64); // R, G, B: every component is quantised with table 0
+        e->header = build_header(width, height, ql, qc, e->ri, e->sub, e->ycc);
+        if (e->nonint) {
+                for (int c = 0; c < 3; c++) e->scan_header[c] = build_header(width, height, ql, qc, e->ri, e->sub, e->ycc, c);
+                e->header = e->scan_header[0]; // (what max_size and the capacity check count)
+        }
         hipError_t err = hipSuccess;
         auto alloc = [&](void **p, size_t n) { if (err == hipSuccess) err = hipMalloc(p, n); };
         alloc((void **) &e->div, sizeof div);
@@ -1547,8 +1601,13 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
                 if (err == hipSuccess) err = hipMemset(e->prof, 0, bytes);
         }
         static_assert(kMaxBatch * sizeof(uint32_t) <= 64, "one length word per frame of a batch");
-        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 128, hipHostMallocMapped); // [kMaxBatch] lengths, then the coder's error word
-        if (err == hipSuccess) memset(e->total_host, 0, 128);
+        static_assert(kMaxBatch + 2 <= kTotalWords, "lengths + the two flag words");
+        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 4 * kTotalWords * 4, hipHostMallocMapped); // the call's block, then one per scan
+        if (err == hipSuccess) memset(e->total_host, 0, 4 * kTotalWords * 4);
+        for (int c = 0; c < 3 && e->nonint; c++) {
+                alloc((void **) &e->scan_header_dev[c], e->scan_header[c].size());
+                if (err == hipSuccess) err = hipMemcpy(e->scan_header_dev[c], e->scan_header[c].data(), e->scan_header[c].size(), hipMemcpyHostToDevice);
+        }
         if (err == hipSuccess) err = hipHostGetDevicePointer((void **) &e->total_host_dev, e->total_host, 0);
         if (err == hipSuccess) err = hipMemcpy(e->div, div, sizeof div, hipMemcpyHostToDevice);
         if (err == hipSuccess) err = hipMemcpy(e->header_dev, e->header.data(), e->header.size(), hipMemcpyHostToDevice);
@@ -1561,6 +1620,11 @@ int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int resta
         return UG_HIP_SUCCESS;
 }
 
+int ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int restart_interval, int subsampling, ug_hip_jpeg_encoder **out)
+{
+        return ug_hip_jpeg_encoder_create_ex(width, height, quality, restart_interval, subsampling, UG_JPEG_CS_ASIS, 0, out);
+}
+
 int ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out)
 {
         return ug_hip_jpeg_encoder_create_sub(width, height, quality, restart_interval, 420, out);
@@ -1571,7 +1635,7 @@ void ug_hip_jpeg_encoder_destroy(ug_hip_jpeg_encoder *enc) { destroy((Encoder *)
 size_t ug_hip_jpeg_encoder_max_size(const ug_hip_jpeg_encoder *enc)
 {
         const Encoder *e = (const Encoder *) enc;
-        return e ? e->header.size() + (size_t) e->n_seg * (2 * (size_t) e->cap + 2) : 0; // every byte stuffed = worst case
+        return e ? e->header.size() + 20 + (size_t) e->n_seg * (2 * (size_t) e->cap + 2) : 0; // every byte stuffed = worst case (+ the SOS of two more scans)
 }
 
 int ug_hip_jpeg_encoder_encode(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, const void *src_dev, int src_pitch, void *out_dev,
@@ -1606,9 +1670,33 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         bs.out_bytes = (long) out_stride;
         int rc = UG_HIP_SUCCESS;
         const int w = e->width, h = e->height;
-        const int S = e->ri * (e->ybl + 2); // blocks per (full) restart segment
-        const bool wave_path = S > 256 || e->force_wave_kernel;
+        const int S_frame = e->ri * (e->ybl + 2); // blocks per (full) restart segment
+        const bool wave_path = !e->nonint && (S_frame > 256 || e->force_wave_kernel);
         if (!src_pitch && in == UG_PF_UYVY) src_pitch = ug::linesize(UG_PF_UYVY, w);
+        // ---- the colour stage (create_ex's internal_cs): the frame(s) converted into a buffer of the encoder's, which then takes the input's place ----
+        const int cs_to = in == UG_PF_RGB ? e->cs_rgb : (in == UG_PF_UYVY ? e->cs_uyvy : 0);
+        if (in == UG_PF_I420 && e->cs_uyvy) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: planar input is coded as it comes (no colour conversion)");
+                return UG_HIP_EUNSUPP;
+        }
+        if (cs_to) {
+                if (!src_pitch) src_pitch = 3 * w;
+                const int ls = in == UG_PF_RGB ? 3 * w : ug::linesize(UG_PF_UYVY, w);
+                const size_t fb = ((size_t) ls * h + 15) / 16 * 16;
+                if (e->cs_tmp_bytes < fb * frames) {
+                        if (e->cs_tmp) (void) hipFree(e->cs_tmp);
+                        e->cs_tmp = nullptr;
+                        e->cs_tmp_bytes = 0;
+                        UG_HIP_TRY(hipMalloc((void **) &e->cs_tmp, fb * kMaxBatch));
+                        e->cs_tmp_bytes = fb * kMaxBatch;
+                }
+                const int crc = ug::jpeg_colour_convert(in, in == UG_PF_RGB ? UG_JPEG_CS_RGB : UG_JPEG_CS_YCBCR_BT709, cs_to, src_dev, src_pitch, e->cs_tmp, ls, w, h, frames,
+                                                        src_stride, fb, stream);
+                if (crc != UG_HIP_SUCCESS) return crc;
+                src_dev = e->cs_tmp;
+                src_pitch = ls;
+                src_stride = fb;
+        }
         // Fused: forward DCT, quantiser, Huffman coding and byte stuffing in ONE kernel, a workgroup per 32 consecutive MCUs -- the quantised
         // coefficients never reach HBM.  Needs whole segments per workgroup (32 % ri == 0) and the aligned geometry of the fast front end.
         if (!src_pitch && in == UG_PF_RGB) src_pitch = 3 * w;
@@ -1619,7 +1707,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         const bool fused_yuv = fused_ok && !wave_path && e->allow_fused && in == UG_PF_UYVY && e->sub != 444 && w % 16 == 0 && !(src_pitch & 15) && !(15 & (uintptr_t) src_dev) &&
                                (frames == 1 || !(src_stride & 15)) && 32 % e->ri == 0;
         // packed RGB (4:4:4, R, G, B components): any width and alignment (the edge blocks of the picture are loaded byte by byte)
-        const bool fused_rgb = fused_ok && !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0;
+        const bool fused_rgb = fused_ok && !wave_path && e->allow_fused && in == UG_PF_RGB && e->sub == 444 && 64 % e->ri == 0 && !e->ycc && !e->nonint;
         // planar I420: 8-byte row pieces of the three planes (width % 16 == 0 keeps the chroma rows 8-byte aligned too)
         const bool fused_i420 = fused_ok && !wave_path && e->allow_fused && in == UG_PF_I420 && e->sub == 420 && w % 16 == 0 && (!src_pitch || src_pitch == w) && !(7 & (uintptr_t) src_dev) &&
                                 (frames == 1 || !(src_stride & 7)) && 32 % e->ri == 0;
@@ -1632,8 +1720,14 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         } else if (in == UG_PF_RGB && e->sub == 444) { // GPUJPEG_444_U8_P012, components kept as R, G, B (gpujpeg.cpp:303-305,336)
                 if (!src_pitch) src_pitch = 3 * w;
                 for (int f = 0; f < frames && rc == UG_HIP_SUCCESS; f++) {
-                        rc = ug::jpeg_fdct_quant_rgb444((const uint8_t *) src_dev + f * src_stride, src_pitch, w, h, e->mcu_w, e->mcu_h, e->div, e->cy + f * bs.coef_y,
-                                                        e->cb + f * bs.coef_c, e->cr + f * bs.coef_c, stream);
+                        const uint8_t *const fr = (const uint8_t *) src_dev + f * src_stride;
+                        if (e->ycc) { // Y', Cb, Cr (the colour stage's output): the luma quantiser for component 0, the chroma one for the others
+                                rc = ug::jpeg_fdct_quant_strided(fr, src_pitch, 3, w, h, e->mcu_w, e->mcu_h, e->div, e->cy + f * bs.coef_y, nullptr, stream);
+                                if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(fr + 1, src_pitch, 3, w, h, e->mcu_w, e->mcu_h, e->div + 64, e->cb + f * bs.coef_c, nullptr, stream);
+                                if (rc == UG_HIP_SUCCESS) rc = ug::jpeg_fdct_quant_strided(fr + 2, src_pitch, 3, w, h, e->mcu_w, e->mcu_h, e->div + 64, e->cr + f * bs.coef_c, nullptr, stream);
+                        } else {
+                                rc = ug::jpeg_fdct_quant_rgb444(fr, src_pitch, w, h, e->mcu_w, e->mcu_h, e->div, e->cy + f * bs.coef_y, e->cb + f * bs.coef_c, e->cr + f * bs.coef_c, stream);
+                        }
                 }
         } else if (in == UG_PF_I420 && e->sub == 420) { // planar passthrough (GPUJPEG_420_U8_P0P1P2, gpujpeg.cpp:335): Y, U, V planes back to back
                 if (src_pitch && src_pitch != w) {
@@ -1655,21 +1749,32 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         if (rc != UG_HIP_SUCCESS) return rc;
         e->total_host[kMaxBatch] = 0;
         // the block-parallel coder, fused or behind the front end; two_launch: slots + gather launch, else the one-launch placement (look-back)
-        auto launch_coder = [&](bool two_launch) -> int {
+        // `scan` = nullptr: the frame's one interleaved scan.  Else one scan of a non-interleaved stream: a single component's blocks (its MCU is one block),
+        // its own header bytes, destination and length words; always the one-launch placement
+        struct ScanPlan { const int16_t *coef; int tab0; const uint8_t *header; int header_len; uint8_t *out; size_t out_stride, capacity; uint32_t *total; };
+        auto launch_coder = [&](bool two_launch, const ScanPlan *scan = nullptr) -> int {
+                const int S = scan ? e->ri : S_frame;
+                const bool fused = !scan && (fused_yuv || fused_rgb || fused_i420); // (shadows the call's: a scan of one component reads coefficients)
                 if (++e->gen >= (1u << 30)) { // the status words carry the call's generation in 30 bits: start over on clean words
                         UG_HIP_TRY(hipMemsetAsync(e->status, 0, (size_t) e->n_mcu * 8 * e->batch_cap, st));
                         e->gen = 1;
                 }
                 CodeArgs a = {};
-                a.mcu_w = e->mcu_w; a.n_mcu = e->n_mcu; a.hs = e->hs; a.vs = e->vs; a.ctab = e->sub == 444 ? 0 : 1; a.ri = e->ri; a.n_seg = e->n_seg; a.S = S;
-                a.cy = e->cy; a.cb = e->cb; a.cr = e->cr; a.coef_y = bs.coef_y; a.coef_c = bs.coef_c;
+                a.mcu_w = e->mcu_w; a.n_mcu = e->n_mcu; a.hs = e->hs; a.vs = e->vs; a.ctab = e->ctab; a.ri = e->ri; a.n_seg = e->n_seg; a.S = S;
+                a.nc = scan ? 0 : 2; a.tab0 = scan ? scan->tab0 : 0;
+                a.cy = scan ? scan->coef : e->cy; a.cb = e->cb; a.cr = e->cr; a.coef_y = bs.coef_y; a.coef_c = bs.coef_c;
                 a.src = (const uint8_t *) src_dev; a.pitch = src_pitch; a.width = w; a.height = h; a.src_stride = src_stride;
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
-                a.total_pinned = e->total_host_dev; a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
+                a.total_pinned = e->total_host_dev;
+                if (scan) {
+                        a.out = scan->out; a.out_stride = scan->out_stride; a.capacity = scan->capacity; a.header = scan->header; a.header_len = scan->header_len;
+                        a.total_pinned = scan->total;
+                }
+                a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
                 a.flat = 0; // decided below, once the number of workgroups of a frame is known
                 // divisions by S, blocks per MCU and MCUs per row as multiplications, where the ranges allow (CodeArgs)
                 {
-                        const int per_mcu = e->hs * e->vs + 2;
+                        const int per_mcu = e->hs * e->vs + a.nc;
                         auto m16 = [](int d) { return (uint32_t) (65536 / d + 1); };
                         auto m32 = [](long d) { return d > 1 ? (uint32_t) ((1ull << 32) / (unsigned long long) d + 1ull) : 0u; };
                         a.S_m16 = m16(S);             // x < 256 lanes, S <= 256: x * S < 2^16
@@ -1691,7 +1796,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                                 if (64 * k >= S && (64 * k / S) * S * (64 * waves) > (64 * waves / S) * S * (64 * k)) waves = k;
                                 if (64 * waves < S) waves = k;
                         }
-                        a.G = 64 * waves / S;
+                        // (the kernel's per-segment LDS words are sized for segments of at least 3 blocks, kMaxSeg = lanes / 3 + 1: the shortest ones an
+                        // interleaved scan has; a one-component scan with restart interval 1 or 2 has shorter ones and leaves lanes idle instead)
+                        a.G = std::min(64 * waves / S, 64 * waves / 3);
                         a.n_wg = (e->n_seg + a.G - 1) / a.G;
                 }
                 if (two_launch) {
@@ -1746,6 +1853,64 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 }
                 return UG_HIP_SUCCESS;
         };
+        if (e->nonint) {
+                // One scan per component (T.81 A.2.2; the reference's default for RGB input, gpujpeg.cpp:303).  Each scan is the block coder over ONE
+                // component's coefficients -- DC prediction and restart intervals (in blocks) of its own, its markers numbered from RST0 -- written
+                // with its header bytes into a region of its own; where a scan ends is only known once it is coded, so the three are put behind
+                // one another after the synchronisation (device-to-device copies; the EOI the coder ends every stream with is dropped from scans
+                // 0 and 1).  Three launches + a synchronisation + three copies per frame: the price of the layout (`:interleaved` avoids it).
+                const size_t cap1 = (out_capacity + 15) / 16 * 16;
+                if (e->scan_tmp_bytes < 3 * cap1 * (size_t) frames) {
+                        if (e->scan_tmp) (void) hipFree(e->scan_tmp);
+                        e->scan_tmp = nullptr;
+                        e->scan_tmp_bytes = 0;
+                        UG_HIP_TRY(hipMalloc((void **) &e->scan_tmp, 3 * cap1 * (size_t) frames));
+                        e->scan_tmp_bytes = 3 * cap1 * (size_t) frames;
+                }
+                memset(e->total_host, 0, 4 * kTotalWords * 4);
+                for (int c = 0; c < 3; c++) {
+                        const ScanPlan pl = { c == 0 ? e->cy : (c == 1 ? e->cb : e->cr), e->ycc && c > 0 ? 1 : 0, e->scan_header_dev[c], (int) e->scan_header[c].size(),
+                                              e->scan_tmp + (size_t) c * cap1 * frames, cap1, cap1, e->total_host_dev + (c + 1) * kTotalWords };
+                        const int lrc = launch_coder(false, &pl);
+                        if (lrc != UG_HIP_SUCCESS) return lrc;
+                }
+                UG_HIP_LAUNCH_CHECK();
+                UG_HIP_TRY(hipStreamSynchronize(st));
+                const uint32_t *const t1 = e->total_host + kTotalWords, *const t2 = t1 + kTotalWords, *const t3 = t2 + kTotalWords;
+                if (t1[kMaxBatch] | t2[kMaxBatch] | t3[kMaxBatch]) { // a workgroup gave up waiting for an earlier one (see below): start-order tickets, once more
+                        (void) hipMemset(e->ticket, 0, 4);
+                        if (!e->use_ticket) {
+                                e->use_ticket = true;
+                                fprintf(stderr, "[ug_mi355x] JPEG encoder %dx%d: workgroups did not start in index order; this call is encoded again and the encoder uses "
+                                                "start-order tickets from now on (UG_JPEG_TICKET=1 selects that from the start)\n", e->width, e->height);
+                                return ug_hip_jpeg_encoder_encode_batch(enc, in, frames, src_dev, src_pitch, src_stride, out_dev, out_stride, out_capacity, out_len, stream);
+                        }
+                        ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: the stream placement gave up waiting for an earlier workgroup");
+                        return UG_HIP_ERUNTIME;
+                }
+                bool fits = true;
+                for (int f = 0; f < frames; f++) {
+                        const size_t l0 = t1[f], l1 = t2[f], l2 = t3[f];
+                        const size_t total = l0 - 2 + l1 - 2 + l2;
+                        out_len[f] = total;
+                        if (l0 > cap1 || l1 > cap1 || l2 > cap1 || total > out_capacity) { // (a scan that did not fit its region reports the size it needs, like a stream)
+                                fits = false;
+                                if (out_len[f] <= out_capacity) out_len[f] = out_capacity + 1;
+                                continue;
+                        }
+                        uint8_t *const dst = (uint8_t *) out_dev + (size_t) f * out_stride;
+                        const uint8_t *const s0 = e->scan_tmp + (size_t) f * cap1, *const s1 = s0 + cap1 * frames, *const s2 = s1 + cap1 * frames;
+                        UG_HIP_TRY(hipMemcpyAsync(dst, s0, l0 - 2, hipMemcpyDeviceToDevice, st));
+                        UG_HIP_TRY(hipMemcpyAsync(dst + l0 - 2, s1, l1 - 2, hipMemcpyDeviceToDevice, st));
+                        UG_HIP_TRY(hipMemcpyAsync(dst + l0 - 2 + l1 - 2, s2, l2, hipMemcpyDeviceToDevice, st));
+                }
+                UG_HIP_TRY(hipStreamSynchronize(st));
+                if (!fits && frames == 1) {
+                        ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: stream does not fit the output buffer (out_len = needed size)");
+                        return UG_HIP_EINVAL;
+                }
+                return UG_HIP_SUCCESS;
+        }
         e->total_host[kMaxBatch + 1] = 0;
         if (!wave_path) {
                 // one frame per call: the look-back's waits are short (every workgroup of the frame is resident at once) and the second launch
@@ -1764,7 +1929,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 // the totals this call's coder adds into start from zero (a smaller batch in between must not leave stale slices behind)
                 UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
-                                   e->sub == 444 ? 0 : 1, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                                   e->ctab, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
                 hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, e->chunk_tot,
                                    e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, bs);
         }

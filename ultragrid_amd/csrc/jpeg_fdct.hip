@@ -14,6 +14,8 @@
 #include "ug_common.h"
 #include "jpeg_fdct_device.h"
 
+#include <cstring>
+
 namespace {
 
 using namespace ug_jpeg;
@@ -503,7 +505,159 @@ int ug::jpeg_fdct_quant_rgb444(const void *src, int pitch, int width, int height
         return UG_HIP_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Colour stage of the JPEG encoder (gpujpeg.cpp:303-305,398-405: color_space_internal = Y601 / Y601full / Y709 / RGB; GPUJPEG converts the
+// input to that space in its preprocessor, at full resolution, before it subsamples).  One affine map per pixel, out = M * in + offset, the
+// twelve numbers derived on the host in double from the PUBLISHED definitions -- luma weights Kr, Kb of BT.601 (0.299, 0.114) and BT.709
+// (0.2126, 0.0722), E'Cb = (B' - Y') / (2 (1 - Kb)), E'Cr = (R' - Y') / (2 (1 - Kr)); 8-bit limited range 16 + 219 E'Y, 128 + 224 E'C;
+// "256 levels" (JFIF) 255 E'Y, 128 + 255 E'C -- and rounded to float.  Per sample: three multiply-adds in fp32, in the order written, clamp to
+// [0, 255], round to nearest even.  Unpinned towards libgpujpeg like the FDCT (whose preprocessor source is not in the reference tree):
+// the oracle restates it operation for operation, and an fp64 evaluation of the same definitions bounds both (tests/test_gpu_jpeg_colour.py).
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ColourMap { float m[12]; };
+
+// 3 x 4 affine map: full-range R'G'B' (0..255) -> the 8-bit Y'CbCr code values of `cs`
+void rgb_to_ycbcr(int cs, double t[3][4])
+{
+        const bool bt709 = cs == UG_JPEG_CS_YCBCR_BT709, full = cs == UG_JPEG_CS_YCBCR_BT601_256LVLS;
+        const double kr = bt709 ? 0.2126 : 0.299, kb = bt709 ? 0.0722 : 0.114, kg = 1.0 - kr - kb;
+        const double ys = (full ? 255.0 : 219.0) / 255.0, cs_ = (full ? 255.0 : 224.0) / 255.0, y0 = full ? 0.0 : 16.0;
+        const double row_y[3] = { kr, kg, kb };
+        const double row_cb[3] = { -kr / (2 * (1 - kb)), -kg / (2 * (1 - kb)), 0.5 }, row_cr[3] = { 0.5, -kg / (2 * (1 - kr)), -kb / (2 * (1 - kr)) };
+        for (int i = 0; i < 3; i++) {
+                t[0][i] = ys * row_y[i];
+                t[1][i] = cs_ * row_cb[i];
+                t[2][i] = cs_ * row_cr[i];
+        }
+        t[0][3] = y0; t[1][3] = 128.0; t[2][3] = 128.0;
+}
+
+// inverse of an affine 3 x 4 map (Cramer; the maps above are far from singular)
+void invert_affine(const double a[3][4], double inv[3][4])
+{
+        const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+        for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) {
+                        const int r0 = (j + 1) % 3, r1 = (j + 2) % 3, c0 = (i + 1) % 3, c1 = (i + 2) % 3;
+                        inv[i][j] = (a[r0][c0] * a[r1][c1] - a[r0][c1] * a[r1][c0]) / det;
+                }
+        }
+        for (int i = 0; i < 3; i++) inv[i][3] = -(inv[i][0] * a[0][3] + inv[i][1] * a[1][3] + inv[i][2] * a[2][3]);
+}
+
+bool colour_map(int cs_in, int cs_out, ColourMap &out)
+{
+        auto known = [](int cs) { return cs >= UG_JPEG_CS_RGB && cs <= UG_JPEG_CS_YCBCR_BT709; };
+        if (!known(cs_in) || !known(cs_out)) return false;
+        double to_rgb[3][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 } }, from_rgb[3][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 } };
+        if (cs_in != UG_JPEG_CS_RGB) {
+                double f[3][4];
+                rgb_to_ycbcr(cs_in, f);
+                invert_affine(f, to_rgb);
+        }
+        if (cs_out != UG_JPEG_CS_RGB) rgb_to_ycbcr(cs_out, from_rgb);
+        for (int i = 0; i < 3; i++) { // from_rgb o to_rgb
+                for (int j = 0; j < 4; j++) {
+                        double v = j == 3 ? from_rgb[i][3] : 0.0;
+                        for (int k = 0; k < 3; k++) v += from_rgb[i][k] * to_rgb[k][j];
+                        out.m[4 * i + j] = (float) v;
+                }
+        }
+        return true;
+}
+
+__device__ __forceinline__ float affine_row(const float *m, float a, float b, float c)
+{
+        float t = m[0] * a;
+        t = t + m[1] * b;
+        t = t + m[2] * c;
+        return t + m[3];
+}
+__device__ __forceinline__ uint32_t to_code(float v) { return (uint32_t) rintf(fminf(255.0f, fmaxf(0.0f, v))); }
+
+// packed 3 B / px (R,G,B or Y,Cb,Cr) -> packed 3 B / px; one lane per pixel (lines of 3 * width bytes: no alignment to speak of)
+__global__ __launch_bounds__(256) void colour_packed3_kernel(const uint8_t *__restrict__ src, int src_pitch, uint8_t *__restrict__ dst, int dst_pitch, int width, int height,
+                                                             size_t src_stride, size_t dst_stride, ColourMap cm)
+{
+        const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+        if (x >= width || y >= height) return;
+        const uint8_t *p = src + blockIdx.z * src_stride + (size_t) y * src_pitch + 3 * (size_t) x;
+        uint8_t *o = dst + blockIdx.z * dst_stride + (size_t) y * dst_pitch + 3 * (size_t) x;
+        const float a = (float) p[0], b = (float) p[1], c = (float) p[2];
+        o[0] = (uint8_t) to_code(affine_row(cm.m, a, b, c));
+        o[1] = (uint8_t) to_code(affine_row(cm.m + 4, a, b, c));
+        o[2] = (uint8_t) to_code(affine_row(cm.m + 8, a, b, c));
+}
+
+// UYVY -> UYVY: each pixel of a pair with the pair's chroma (4:2:2 -> 4:4:4 by replication), mapped, the two chroma results averaged
+// (mix(a, b, 0.5) as a * 0.5 + b * 0.5) back into one pair; one lane per pair
+__global__ __launch_bounds__(256) void colour_uyvy_kernel(const uint8_t *__restrict__ src, int src_pitch, uint8_t *__restrict__ dst, int dst_pitch, int pairs, int height,
+                                                          size_t src_stride, size_t dst_stride, ColourMap cm)
+{
+        const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+        if (x >= pairs || y >= height) return;
+        const uint32_t q = *(const uint32_t *) (src + blockIdx.z * src_stride + (size_t) y * src_pitch + 4 * (size_t) x);
+        const float u = (float) (q & 0xff), y0 = (float) ((q >> 8) & 0xff), v = (float) ((q >> 16) & 0xff), y1 = (float) (q >> 24);
+        const float cb0 = affine_row(cm.m + 4, y0, u, v), cb1 = affine_row(cm.m + 4, y1, u, v);
+        const float cr0 = affine_row(cm.m + 8, y0, u, v), cr1 = affine_row(cm.m + 8, y1, u, v);
+        const float cb = cb0 * 0.5f + cb1 * 0.5f, cr = cr0 * 0.5f + cr1 * 0.5f;
+        *(uint32_t *) (dst + blockIdx.z * dst_stride + (size_t) y * dst_pitch + 4 * (size_t) x) =
+                to_code(cb) | to_code(affine_row(cm.m, y0, u, v)) << 8 | to_code(cr) << 16 | to_code(affine_row(cm.m, y1, u, v)) << 24;
+}
+
+} // namespace
+
+int ug::jpeg_colour_convert(ug_pixfmt_t fmt, int cs_in, int cs_out, const void *src, int src_pitch, void *dst, int dst_pitch, int width, int height, int frames,
+                            size_t src_stride, size_t dst_stride, ug_hip_stream_t stream)
+{
+        ColourMap cm;
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_jpeg_colour_convert");
+        if (!src || !dst || frames < 1 || frames > 65535 || (fmt != UG_PF_RGB && fmt != UG_PF_UYVY) || !colour_map(cs_in, cs_out, cm)) {
+                ug::set_last_error_msg("ug_hip_jpeg_colour_convert: RGB (3 B/px) or UYVY, colour spaces UG_JPEG_CS_RGB .. UG_JPEG_CS_YCBCR_BT709");
+                return UG_HIP_EINVAL;
+        }
+        const int ls = fmt == UG_PF_RGB ? 3 * width : (width + 1) / 2 * 4;
+        if (!src_pitch) src_pitch = ls;
+        if (!dst_pitch) dst_pitch = ls;
+        if (src_pitch < ls || dst_pitch < ls || !ug::span_ok(src_pitch, height) || !ug::span_ok(dst_pitch, height) ||
+            (fmt == UG_PF_UYVY && ((width & 1) || ((src_pitch | dst_pitch) & 3) || (3 & ((uintptr_t) src | (uintptr_t) dst)) || (frames > 1 && ((src_stride | dst_stride) & 3))))) {
+                ug::set_last_error_msg("ug_hip_jpeg_colour_convert: bad pitch / alignment (UYVY: even width, 4-byte aligned lines)");
+                return UG_HIP_EINVAL;
+        }
+        const int units = fmt == UG_PF_RGB ? width : width / 2;
+        const dim3 grid((unsigned) ((units + 255) / 256), (unsigned) height, (unsigned) frames);
+        if (fmt == UG_PF_RGB) {
+                hipLaunchKernelGGL(colour_packed3_kernel, grid, dim3(256), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, (uint8_t *) dst, dst_pitch, width, height,
+                                   src_stride, dst_stride, cm);
+        } else {
+                hipLaunchKernelGGL(colour_uyvy_kernel, grid, dim3(256), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, (uint8_t *) dst, dst_pitch, units, height,
+                                   src_stride, dst_stride, cm);
+        }
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
+
 extern "C" {
+
+int ug_hip_jpeg_colour_matrix(int cs_in, int cs_out, float m[12])
+{
+        ColourMap cm;
+        if (!m || !colour_map(cs_in, cs_out, cm)) {
+                ug::set_last_error_msg("ug_hip_jpeg_colour_matrix: colour spaces UG_JPEG_CS_RGB .. UG_JPEG_CS_YCBCR_BT709");
+                return UG_HIP_EINVAL;
+        }
+        memcpy(m, cm.m, sizeof cm.m);
+        return UG_HIP_SUCCESS;
+}
+
+int ug_hip_jpeg_colour_convert(ug_pixfmt_t fmt, int cs_in, int cs_out, const void *src_dev, int src_pitch, void *dst_dev, int dst_pitch, int width, int height,
+                               ug_hip_stream_t stream)
+{
+        return ug::jpeg_colour_convert(fmt, cs_in, cs_out, src_dev, src_pitch, dst_dev, dst_pitch, width, height, 1, 0, 0, stream);
+}
 
 void ug_hip_jpeg_qtable(int quality, int comp, uint8_t table[64])
 {

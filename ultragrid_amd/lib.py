@@ -23,6 +23,8 @@ PF_NAMES = {"RGBA": PF_RGBA, "UYVY": PF_UYVY, "YUYV": PF_YUYV, "RGB": PF_RGB, "B
 DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 # UG_DXT_TIES_*
 TIES_EVEN, TIES_AWAY = 0, 1
+JPEG_CS_ASIS, JPEG_CS_RGB, JPEG_CS_YCBCR_BT601, JPEG_CS_YCBCR_BT601_256LVLS, JPEG_CS_YCBCR_BT709 = 0, 1, 2, 3, 4
+JPEG_NONINTERLEAVED = 1
 COPY_NO_WAIT, COPY_NO_JOIN = 1, 2
 ABI_VERSION = 5
 
@@ -111,6 +113,9 @@ SYMBOLS = {
     "ug_hip_uyvy_to_jpeg42x_coeffs_batch": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _sz, _sz, _sz, _vp]),
     "ug_hip_jpeg_encoder_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
     "ug_hip_jpeg_encoder_create_sub": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ug_hip_jpeg_encoder_create_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ug_hip_jpeg_colour_matrix": (_i, [_i, _i, C.POINTER(C.c_float)]),
+    "ug_hip_jpeg_colour_convert": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "ug_hip_jpeg_encoder_destroy": (None, [_vp]),
     "ug_hip_jpeg_encoder_max_size": (_sz, [_vp]),
     "ug_hip_jpeg_decoder_create": (_i, [C.POINTER(_vp)]),

@@ -49,7 +49,9 @@ struct state_video_compress_jpeg_mi355x {
         struct video_desc    saved_desc{};
         int                  device = 0, quality = 75, restart = 2;
         int                  subsampling = 0;  ///< 0 = autoselect: that of the input codec (gpujpeg.cpp:168,295-302)
-        int                  internal_cs = 0;  ///< 0 = as the input dictates, 1 = "RGB", 2 = "Y709" asked for (gpujpeg.cpp:398-405)
+        int                  internal_cs = 0;  ///< color_space_internal asked for (gpujpeg.cpp:398-405): 0 = as the input dictates, else UG_JPEG_CS_RGB / _YCBCR_BT601 / _YCBCR_BT601_256LVLS / _YCBCR_BT709
+        bool                 force_interleaved = false; ///< `:interleaved` (gpujpeg.cpp:396-397): RGB input as ONE scan instead of one scan per component
+        bool                 alpha = false;    ///< `:alpha` (gpujpeg.cpp:409-414)
         ug_pixfmt_t          wire = UG_PF_NONE;     ///< format of the uploaded frame
         ug_pixfmt_t          target = UG_PF_NONE;   ///< what the reference's CPU line decoder would convert it to (UYVY, RGB or RGBA)
         ug_pixfmt_t          enc_in = UG_PF_NONE;   ///< what the encoder is fed: UYVY, RGB or I420
@@ -77,9 +79,11 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y709][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
+               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y601|:Y601full|:Y709][:alpha][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
                "\t\tnuma        - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node (pinned frame pool local to the GPU); 0: left to the scheduler\n"
                "\t\tbatch       - frames a busy worker may queue and encode together (1-16, default 1); only matters for sources faster than the encoder\n"
+               "\t\tinterleaved - RGB input as one interleaved scan; default (as the reference's): one scan per component -- three coder launches, slower\n"
+               "\t\tRGB | Y601 | Y601full | Y709 - colour space the samples are coded in (default: R,G,B for RGB input, BT.709 limited range for the rest)\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
                "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
                "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
@@ -106,17 +110,17 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                 } else if (strncasecmp(tok.c_str(), "subsampling=", 12) == 0 || strncasecmp(tok.c_str(), "sub=", 4) == 0) {
                         s->subsampling = atoi(strchr(tok.c_str(), '=') + 1); // gpujpeg.cpp:406-408
                 } else if (strncasecmp(tok.c_str(), "interleaved", 11) == 0) {
-                        // gpujpeg.cpp:396-397 forces one interleaved scan for RGB input: this encoder always writes one interleaved scan
-                } else if (strcasecmp(tok.c_str(), "RGB") == 0 || strcasecmp(tok.c_str(), "Y709") == 0) {
-                        // gpujpeg.cpp:398-405 (internal colour space): the two the module uses anyway -- R,G,B for RGB-family input, BT.709
-                        // limited-range YCbCr samples as they come for 4:2:x input (gpujpeg.cpp:303-305); checked against the input at configure
-                        s->internal_cs = strcasecmp(tok.c_str(), "RGB") == 0 ? 1 : 2;
-                } else if (strcasecmp(tok.c_str(), "Y601") == 0 || strcasecmp(tok.c_str(), "Y601full") == 0) {
-                        MSG(ERROR, "internal colour space %s needs a colour conversion this encoder does not do (samples are coded as they come)\n", tok.c_str());
-                        delete s;
-                        return nullptr;
+                        s->force_interleaved = true; // gpujpeg.cpp:396-397: one interleaved scan for RGB input too (the default there: one scan per component, :303)
+                } else if (strcasecmp(tok.c_str(), "RGB") == 0) { // gpujpeg.cpp:398-405: color_space_internal; what it means for the input at hand: configure_with
+                        s->internal_cs = UG_JPEG_CS_RGB;
+                } else if (strcasecmp(tok.c_str(), "Y709") == 0) {
+                        s->internal_cs = UG_JPEG_CS_YCBCR_BT709;
+                } else if (strcasecmp(tok.c_str(), "Y601") == 0) {
+                        s->internal_cs = UG_JPEG_CS_YCBCR_BT601;
+                } else if (strcasecmp(tok.c_str(), "Y601full") == 0) {
+                        s->internal_cs = UG_JPEG_CS_YCBCR_BT601_256LVLS;
                 } else if (tok == "alpha") {
-                        MSG(WARNING, "alpha is not coded by this encoder; the option is ignored\n"); // gpujpeg.cpp:409-414 warns likewise when unsupported
+                        s->alpha = true; // gpujpeg.cpp:409-414; decided against the input at configure (:318-330)
                 } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
                         s->device = atoi(tok.c_str() + 4);
                 } else if (strncasecmp(tok.c_str(), "batch_slices=", 13) == 0) { // internal: from mi355x::sharded_init
@@ -183,10 +187,32 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 rgb_family = s->target != UG_PF_UYVY;
         }
         const int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (s->wire == UG_PF_I420 ? 420 : 422));
-        if (s->internal_cs != 0 && (s->internal_cs == 1) != (sub == 444)) {
-                MSG(ERROR, "internal colour space %s does not match what this input is coded as (%s): no colour conversion is done\n",
-                    s->internal_cs == 1 ? "RGB" : "Y709", sub == 444 ? "R,G,B 4:4:4" : "YCbCr 4:2:x");
+        // color_space_internal (gpujpeg.cpp:303-305: the option, else RGB for RGB input and BT.709 for the rest).  4:4:4 from an RGB-family input: R, G, B
+        // as they are, or converted to the Y'CbCr space asked for; 4:2:x (UYVY, or RGB-family input brought to UYVY with pixfmt_conv.c's BT.709
+        // arithmetic): BT.709 limited range as the samples are, or converted to BT.601.  Not done: 4:2:x input coded as R, G, B; planar input converted.
+        int enc_cs = UG_JPEG_CS_ASIS;
+        if (sub == 444) {
+                enc_cs = s->internal_cs == UG_JPEG_CS_RGB ? UG_JPEG_CS_ASIS : s->internal_cs;
+        } else if (s->internal_cs == UG_JPEG_CS_RGB) {
+                MSG(ERROR, "internal colour space RGB: this input is coded as Y'CbCr 4:2:x (no conversion to R, G, B components is done)\n");
                 return false;
+        } else if (s->internal_cs == UG_JPEG_CS_YCBCR_BT601 || s->internal_cs == UG_JPEG_CS_YCBCR_BT601_256LVLS) {
+                if (s->wire == UG_PF_I420) {
+                        MSG(ERROR, "internal colour space Y601 / Y601full: planar I420 input is coded as it comes (no colour conversion)\n");
+                        return false;
+                }
+                enc_cs = s->internal_cs;
+        }
+        // one scan per component for RGB input unless `:interleaved` (gpujpeg.cpp:303) -- where the components are not subsampled (the reference
+        // writes subsampled RGB-input streams that way too; here those are 4:2:x Y'CbCr streams of one scan)
+        const int enc_flags = rgb_family && sub == 444 && !s->force_interleaved ? UG_JPEG_NONINTERLEAVED : 0;
+        if (s->alpha) { // gpujpeg.cpp:318-330
+                if (desc.color_spec == RGBA) {
+                        MSG(ERROR, "alpha: a fourth component is not coded by this encoder (the reference needs GPUJPEG >= 0.20.2 for it, gpujpeg.cpp:410-413); "
+                                   "without the option the colour planes are coded and the pad byte dropped\n");
+                        return false;
+                }
+                MSG(WARNING, "Requested alpha encode but input codec is unsupported pixel format: %s\n", get_codec_name(desc.color_spec)); // :327-328, and on it goes
         }
         if (s->wire == UG_PF_I420) {
                 if (sub != 420) {
@@ -204,7 +230,11 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         }
         s->in_len = s->wire == UG_PF_I420 ? (size_t) desc.width * desc.height + 2 * (size_t) ((desc.width + 1) / 2) * ((desc.height + 1) / 2)
                                           : (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
-        if (ug_hip_jpeg_encoder_create_sub((int) desc.width, (int) desc.height, s->quality, s->restart, sub, &s->enc) != UG_HIP_SUCCESS) {
+        if (enc_flags && s->restart > 256) {
+                MSG(ERROR, "restart intervals above 256 need `:interleaved` for RGB input\n");
+                return false;
+        }
+        if (ug_hip_jpeg_encoder_create_ex((int) desc.width, (int) desc.height, s->quality, s->restart, sub, enc_cs, enc_flags, &s->enc) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "encoder creation failed: %s\n", ug_hip_last_error_string());
                 return false;
         }
