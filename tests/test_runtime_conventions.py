@@ -288,7 +288,10 @@ def _oracle_bytes(po, cfg, codec, il, src, w, h):
     if target == "RGB":
         comp = decoded.reshape(h, w, 3)
         coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comp[..., c]), po.jpeg_divisors(ql), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
-        return write_jpeg(w, h, ql, qc, *coefs, restart=restart, sub=444)
+        if "interleaved" in cfg:
+            return write_jpeg(w, h, ql, qc, *coefs, restart=restart, sub=444)
+        from jpeg_bitstream import write_jpeg_noninterleaved
+        return write_jpeg_noninterleaved(w, h, ql, coefs, restart=restart)       # RGB input: one scan per component (gpujpeg.cpp:303)
     y, u, v = po.uyvy_to_i422(decoded, w, h)
     mw, mh = (w + 15) // 16, (h + 7) // 8
     return write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, po.jpeg_divisors(ql), 2 * mw, mh), po.jpeg_fdct_quant_plane(u, po.jpeg_divisors(qc), mw, mh),

@@ -31,7 +31,7 @@ for step in "$@"; do
     trace)
       ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-e2e > $OUT/trace.log 2>&1 )
       python tools/pmc_summary.py $(find $OUT/trace -name "*.db") 2>&1 | sed "s#$ROOT/##" > $OUT/kernel_trace.txt; head -6 $OUT/kernel_trace.txt | cut -c1-170
-      tail -1 $OUT/trace.log > $OUT/trace_bench_line.json; rm -rf $OUT/trace ;;
+      grep "^{" $OUT/trace.log | tail -1 > $OUT/trace_bench_line.json; rm -rf $OUT/trace ;;
     pmc-jpeg)  # the two JPEG workloads only
       R=${TAG}; WORKLOADS="4k-uyvy-jpeg420 4k-uyvy-jpeg-encode" bash tools/pmc_workloads.sh > $OUT/pmc_workloads.log 2>&1; cp gpurun_out/pmc_workloads/*.txt $OUT/
       python tools/pmc_to_json.py uyvy_jpeg420_4k_x8 "uyvy_jpeg_fast_batch_kernel" "rocprof passes of session $R, uyvy_jpeg_fast_batch_kernel<420>" $OUT/4k-uyvy-jpeg420.txt
