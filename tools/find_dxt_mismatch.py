@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Random search for a DXT encode / decode call on which the GPU differs from the oracle: input formats x outputs, widths and heights that
-are any multiple of 4 (v210 widths that are not a multiple of 12 included), padded pitches, bottom-up sources, both tie rules, content from
+"""Random search for a DXT encode / decode call on which the GPU differs from the oracle: input formats x outputs, ANY width and height (round 6:
+half the draws are not multiples of 4 -- 4:2:2 formats keep an even width; v210 widths that are not a multiple of 12 included), padded pitches, bottom-up sources, both tie rules, content from
 flat over gradients to noise and extreme values; every encoded frame is also decoded on both sides.  GPU box.
 usage: python tools/find_dxt_mismatch.py [n]"""
 import os
@@ -26,9 +26,14 @@ def main():
         name, pin, pf, bpp = COMBOS[int(rng.integers(len(COMBOS)))]
         pout, oid = OUTS[int(rng.integers(2))]
         w, h = 4 * int(rng.integers(1, 90)), 4 * int(rng.integers(1, 12))
+        if rng.random() < 0.5:                                                # any size (dxt_util.h:59-67): the EDGE instantiations
+            w, h = max(1, w - int(rng.integers(0, 4))), max(1, h - int(rng.integers(0, 4)))
+            if name in ("UYVY", "v210"):
+                w += w & 1
         ties = ["even", "away"][int(rng.integers(2))]
         line = (w + 47) // 48 * 128 if name == "v210" else bpp * w
-        pitch = line + 16 * int(rng.integers(0, 3))
+        line = line if name != "UYVY" else 2 * w
+        pitch = line + 16 * int(rng.integers(0, 3)) + (0 if name != "RGB" or not ((w & 3) or (h & 3)) else int(rng.integers(0, 4)))   # (3 w bytes per line: any pitch, when the EDGE form runs)
         kind = int(rng.integers(5))
         buf = np.zeros(pitch * h + 64, np.uint8)
         if kind == 0:
@@ -50,7 +55,7 @@ def main():
         if not np.array_equal(got, want):
             print("ENCODE MISMATCH", seed, name, "DXT1" if oid == L.DXT1 else "DXT5", w, hh, pitch, ties, kind, "bytes differing", int((got != want).sum()), flush=True)
             bad += 1
-        if seed % 3 == 0 and (w * h // (2 if oid == L.DXT1 else 1)) % 16 == 0:   # the batched entry point (frames start on 16-byte boundaries on both sides): 2-3 frames a stride apart, each must equal its own single-frame result
+        if seed % 3 == 0 and po.dxt_size(pout, w, h) % 16 == 0:   # the batched entry point (frames start on 16-byte boundaries on both sides): 2-3 frames a stride apart, each must equal its own single-frame result
             frames = int(rng.integers(2, 4))
             stride = (pitch * h + 15) // 16 * 16 + 16 * int(rng.integers(0, 5))   # frames start on 16-byte boundaries (the API asks for it)
             big = np.zeros(stride * frames + 64, np.uint8)

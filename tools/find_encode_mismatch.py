@@ -30,15 +30,27 @@ for seed in range(n):
     rgb = (base + rng.normal(0, [0.0, 2.0, 10.0, 60.0, 200.0][int(rng.integers(5))], base.shape)).clip(0, 255).astype(np.uint8)
     ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
     dl, dc = po.jpeg_divisors(ql), po.jpeg_divisors(qc)
-    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+    # round 6: the encoder's other options on a third of the draws -- color_space_internal (1 = RGB as it comes .. 4 = BT.709; 4:2:x: BT.601 / 256 levels) and, 4:4:4 only, one scan per component
+    cs = int(rng.integers(2, 5)) if seed % 3 == 0 else 0
+    nonint = sub == 444 and seed % 6 < 3
+    if sub != 444 and cs == 4:
+        cs = 0
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub, internal_cs=cs, flags=L.JPEG_NONINTERLEAVED if nonint else 0)
     if sub == 444:
         dev = torch.from_numpy(np.ascontiguousarray(rgb).ravel()).cuda()
         data = enc.encode_batch(torch.stack([dev, dev]), L.PF_RGB)[1] if two else enc.encode(dev, L.PF_RGB)
-        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(rgb[..., c]), dl, (w + 7) // 8, (h + 7) // 8) for c in range(3)]
-        want = write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=444)
+        comps = po.jpeg_colour_convert("RGB", 1, cs, rgb, w, h).reshape(h, w, 3) if cs else rgb
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comps[..., c]), dc if cs and c else dl, (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        if nonint:
+            from jpeg_bitstream import write_jpeg_noninterleaved
+            want = write_jpeg_noninterleaved(w, h, ql, coefs, restart=ri, qt_chroma=qc if cs else None)
+        else:
+            want = write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=444, ycc=bool(cs))
     else:
         uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
-        dev = torch.from_numpy(uyvy).cuda()
+        if cs:
+            src709, uyvy = uyvy, po.jpeg_colour_convert("UYVY", 4, cs, uyvy, w, h)       # the samples the stream must hold; the encoder is fed the BT.709 ones
+        dev = torch.from_numpy(src709 if cs else uyvy).cuda()
         data = enc.encode_batch(torch.stack([dev, dev]))[1] if two else enc.encode(dev)
         if sub == 422:
             y, u, v = po.uyvy_to_i422(uyvy, w, h)
@@ -50,7 +62,7 @@ for seed in range(n):
             want = write_jpeg420(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, dl, 2 * mw, 2 * mh), po.jpeg_fdct_quant_plane(u, dc, mw, mh), po.jpeg_fdct_quant_plane(v, dc, mw, mh), restart=ri)
     enc.close()
     if data != want:
-        print("ENCODE MISMATCH seed", seed, sub, w, h, q, ri, len(data), len(want), flush=True)
+        print("ENCODE MISMATCH seed", seed, sub, w, h, q, ri, "cs", cs, "nonint", nonint, len(data), len(want), flush=True)
         bad += 1
     _, crop, _ = po.jpeg_decode_planes(data)
     for c, pl in enumerate(dec.planes(data)):
