@@ -189,11 +189,12 @@ static bool start_downloader(struct state_decompress_dxt_mi355x *s)
         if (s->has_downloader) {
                 return true;
         }
-        if (ug_hip_stream_create(&s->down) != UG_HIP_SUCCESS) {
+        // (what a failed earlier attempt left behind is kept and used: done() releases it)
+        if (s->down == NULL && ug_hip_stream_create(&s->down) != UG_HIP_SUCCESS) {
                 return false;
         }
         for (int k = 0; k < MI355X_MAX_BANDS; k++) {
-                if (ug_hip_event_create(&s->band_done[k]) != UG_HIP_SUCCESS) return false;
+                if (s->band_done[k] == NULL && ug_hip_event_create(&s->band_done[k]) != UG_HIP_SUCCESS) return false;
         }
         s->issued = -1;
         if (pthread_create(&s->downloader, NULL, downloader_thread, s) != 0) {
