@@ -225,7 +225,7 @@ static int jpeg_to_dxt_mi355x_decompress_reconfigure(void *state, struct video_d
                 return false;
         }
         const int ppb = out_codec == DXT1 ? 2 : 1; // pixels per byte (gpujpeg_to_dxt.cpp:239-243)
-        if (pitch != (int) desc.width / ppb) {
+        if (pitch != (int) desc.width / ppb && pitch != vc_get_linesize(desc.width, out_codec)) { // (an odd width: the reference's assert knows width / ppb only, :244)
                 MSG(ERROR, "a DXT frame has no other pitch than width / %d\n", ppb);
                 return false;
         }
