@@ -186,9 +186,17 @@ __device__ __forceinline__ void put_row_edge(int words, const OutArgsE &o, int y
         uint8_t *at = o.dst + (long) y * o.pitch + bx * (4 * words);
         const uint32_t w[4] = { w0, w1, w2, w3 };
         if (valid >= 4) {
+                // (scalar choice) lines that keep the alignment of the wide streaming stores -- a width that IS a multiple of 4 with a height that is not,
+                // 2048 x 858 -- take them as the other instantiation does; else dwords wherever they lie (3 * width bytes per line: no alignment at all)
+                if (words == 4 && (o.pitch & 15) == 0) {
+                        ug::st_stream((uint4 *) at, make_uint4(w0, w1, w2, w3));
+                } else if (words == 2 && (o.pitch & 7) == 0) {
+                        ug::st_stream((uint2 *) at, make_uint2(w0, w1));
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                        if (k < words) *((u32_any *) at + k) = w[k]; // (3 * width bytes per line: a line starts wherever it starts)
+                        for (int k = 0; k < 4; k++) {
+                                if (k < words) *((u32_any *) at + k) = w[k];
+                        }
                 }
         } else { // the block the right edge cuts: one lane per block row
 #pragma unroll
