@@ -545,12 +545,12 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
     raw = tmp_path / "in.raw"
     synth.s2_video("UYVY", w, h).tofile(raw)
     outs = []
-    for cfg in ("jpeg:q=60:restart=3", "jpeg:60:3", "jpeg:quality=60:restart=3:interleaved:Y709"):
+    for cfg in ("jpeg:q=60:restart=3", "jpeg:60:3", "jpeg:quality=60:restart=3:interleaved:Y709", "jpeg:qual=60:r=3:inter:sub=422"):   # (<k>=<v> with any prefix of the key: IS_KEY_PREFIX, utils/macros.h:162-164)
         out = tmp_path / f"o{len(outs)}.jpg"
         r = _run([cfg, "UYVY", w, h, raw, out])
         assert r.returncode == 0, cfg + r.stdout + r.stderr
         outs.append(out.read_bytes())
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
     assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails (4:2:x input is not coded as R, G, B): frame dropped
     r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
     assert r.returncode == 0 and "Requested alpha encode but input codec is unsupported pixel format" in (r.stdout + r.stderr)      # gpujpeg.cpp:327-328

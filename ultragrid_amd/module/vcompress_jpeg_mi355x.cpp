@@ -89,6 +89,13 @@ void usage()
                "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
 }
 
+/// IS_KEY_PREFIX (utils/macros.h:162-164): tok is <k>=<v> and <k> is a (non-empty) prefix of key
+bool key_prefix(const std::string &tok, const char *key)
+{
+        const size_t eq = tok.find('=');
+        return eq != std::string::npos && eq > 0 && eq <= strlen(key) && strncmp(key, tok.c_str(), eq) == 0;
+}
+
 void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
 {
         (void) parent;
@@ -101,15 +108,18 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                 std::string tok = cfg.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
                 if (!tok.empty() && isdigit((unsigned char) tok[0])) { // gpujpeg.cpp:379-391: "-c gpujpeg:<quality>[:<restart interval>]"
                         (numeric++ == 0 ? s->quality : s->restart) = atoi(tok.c_str());
-                } else if (strncasecmp(tok.c_str(), "q=", 2) == 0) {
-                        s->quality = atoi(tok.c_str() + 2);
-                } else if (strncasecmp(tok.c_str(), "quality=", 8) == 0) {
-                        s->quality = atoi(tok.c_str() + 8);
-                } else if (strncasecmp(tok.c_str(), "restart=", 8) == 0) {
-                        s->restart = atoi(tok.c_str() + 8);
-                } else if (strncasecmp(tok.c_str(), "subsampling=", 12) == 0 || strncasecmp(tok.c_str(), "sub=", 4) == 0) {
+                } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
+                        s->device = atoi(tok.c_str() + 4);
+                } else if (strncasecmp(tok.c_str(), "batch_slices=", 13) == 0) { // internal: from mi355x::sharded_init
+                        s->batch_slices = atoi(tok.c_str() + 13);
+                        if (s->batch_slices < 1 || s->batch_slices > 16) s->batch_slices = 16;
+                } else if (key_prefix(tok, "quality")) { // <k>=<v> with <k> any prefix of the key, as IS_KEY_PREFIX reads it (utils/macros.h:162-164; gpujpeg.cpp:392-395,406): q=, qual=, r=, sub= ...
+                        s->quality = atoi(strchr(tok.c_str(), '=') + 1);
+                } else if (key_prefix(tok, "restart")) {
+                        s->restart = atoi(strchr(tok.c_str(), '=') + 1);
+                } else if (key_prefix(tok, "subsampling")) {
                         s->subsampling = atoi(strchr(tok.c_str(), '=') + 1); // gpujpeg.cpp:406-408
-                } else if (strncasecmp(tok.c_str(), "interleaved", 11) == 0) {
+                } else if (key_prefix(tok, "interleaved") || (tok.find('=') == std::string::npos && strncmp("interleaved", tok.c_str(), tok.size()) == 0)) { // IS_PREFIX: "i", "inter", "interleaved[=…]"
                         s->force_interleaved = true; // gpujpeg.cpp:396-397: one interleaved scan for RGB input too (the default there: one scan per component, :303)
                 } else if (strcasecmp(tok.c_str(), "RGB") == 0) { // gpujpeg.cpp:398-405: color_space_internal; what it means for the input at hand: configure_with
                         s->internal_cs = UG_JPEG_CS_RGB;
@@ -121,11 +131,6 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                         s->internal_cs = UG_JPEG_CS_YCBCR_BT601_256LVLS;
                 } else if (tok == "alpha") {
                         s->alpha = true; // gpujpeg.cpp:409-414; decided against the input at configure (:318-330)
-                } else if (strncasecmp(tok.c_str(), "dev=", 4) == 0) {
-                        s->device = atoi(tok.c_str() + 4);
-                } else if (strncasecmp(tok.c_str(), "batch_slices=", 13) == 0) { // internal: from mi355x::sharded_init
-                        s->batch_slices = atoi(tok.c_str() + 13);
-                        if (s->batch_slices < 1 || s->batch_slices > 16) s->batch_slices = 16;
                 } else if (tok == "help") {
                         usage();
                         delete s;
