@@ -449,8 +449,8 @@ int    ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int re
  *                I420 with a conversion.  The colour stage is UNPINNED towards libgpujpeg like the FDCT: published BT.601 / BT.709 definitions, fp32.
  *   flags        UG_JPEG_NONINTERLEAVED (subsampling 444 only): one scan per component (T.81 A.2.2; restart intervals count blocks of the scan's
  *                component) -- the reference's DEFAULT for RGB input (interleaved = 0 unless `:interleaved`, gpujpeg.cpp:303); the header then
- *                carries what those scans use (RGB: quantiser and Huffman table 0 only).  The scans are coded one after the other and assembled
- *                behind a synchronisation: slower than the single interleaved scan (one fused kernel). */
+ *                carries what those scans use (RGB: quantiser and Huffman table 0 only).  Three coder launches, each going on where the one before
+ *                ended (one synchronisation, no intermediate buffer); the single interleaved scan is ONE fused kernel and faster. */
 #define UG_JPEG_CS_ASIS                0
 #define UG_JPEG_CS_RGB                 1 /* GPUJPEG_RGB: full-range R'G'B' */
 #define UG_JPEG_CS_YCBCR_BT601         2 /* GPUJPEG_YCBCR_BT601: limited range (16-235 / 16-240) */

@@ -554,6 +554,10 @@ struct CodeArgs {
         // SRC = 0 only: nc = chroma blocks of an MCU -- 2, or 0 for the scan of ONE component (a non-interleaved scan, T.81 A.2.2: its MCU is one block, cy = that
         // component's blocks); tab0 = the Huffman table pair of the blocks b < hs * vs (0; 1 for the Cb / Cr scans of a non-interleaved YCbCr stream)
         int nc, tab0;
+        // SRC = 0, one-launch placement only: the stream of frame f goes on at byte base[f] - 2 of its buffer -- behind the previous scan of a non-interleaved stream,
+        // over the EOI that scan ended with (NULL: at byte 0).  The word is the length the previous scan's launch left in (mapped, pinned) host memory: kernels of one
+        // stream run in order, so it is final when this launch reads it.
+        const uint32_t *base;
         // SRC = 0: quantised blocks in HBM, per-frame strides in int16 elements
         const int16_t *cy, *cb, *cr;
         long coef_y, coef_c;
@@ -1058,8 +1062,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                 }
                 __syncthreads();
         };
-        uint8_t *const out = a.slots != nullptr ? a.slots + ((size_t) frame * a.n_wg + wg) * a.slot_bytes : a.out + (size_t) frame * a.out_stride;
-        const size_t capacity = a.slots != nullptr ? a.slot_bytes : a.capacity;
+        const uint32_t base0 = SRC == 0 && a.base != nullptr ? a.base[frame] - 2u : 0u; // (wave-uniform: a scalar load)
+        uint8_t *const out = a.slots != nullptr ? a.slots + ((size_t) frame * a.n_wg + wg) * a.slot_bytes : a.out + (size_t) frame * a.out_stride + base0;
+        const size_t capacity = a.slots != nullptr ? a.slot_bytes : (a.capacity > base0 ? a.capacity - base0 : 0);
         // the window words of this pass to their place in the stream, 0x00 after every 0xFF; after the last pass RSTm / EOI
         auto write_pass = [&](int lo_idx, bool last_pass, bool pad) {
 #pragma unroll 1
@@ -1101,7 +1106,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                                 out[end - 2] = 0xFF;
                                                 out[end - 1] = sg == a.n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (sg & 7));
                                         }
-                                        if (sg == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = end;
+                                        if (sg == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = base0 + end;
                                 }
                         }
                 }
@@ -1201,7 +1206,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(SRC 
                                 p[1] = sg == a.n_seg - 1 ? 0xD9 : (uint8_t) (0xD0 + (sg & 7));
                         }
                 }
-                if (seg_last && seg0 + wsl == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = at + mine; // the stream's length
+                if (seg_last && seg0 + wsl == a.n_seg - 1 && a.slots == nullptr) a.total_pinned[frame] = base0 + at + mine; // the stream's length
                 UG_PHASE(7) // write-out
                 if (a.prof != nullptr && threadIdx.x == 0) a.prof[((size_t) blockIdx.y * gridDim.x + blockIdx.x) * (kProfPhases + 1) + kProfPhases] = 1ull;
         } else {
@@ -1377,8 +1382,6 @@ struct Encoder {
         size_t cs_tmp_bytes;
         std::vector<uint8_t> scan_header[3]; // non-interleaved: what precedes the entropy-coded bytes of scan c (scan 0: the whole header)
         uint8_t *scan_header_dev[3];
-        uint8_t *scan_tmp;     // non-interleaved: the three scans of every frame of a call before they are put behind one another
-        size_t scan_tmp_bytes;
 };
 constexpr int kTotalWords = 32; // per block of total_host: kMaxBatch lengths, [kMaxBatch] "a wait was given up", [kMaxBatch + 1] "a slot overflowed"
 
@@ -1523,7 +1526,7 @@ void destroy(Encoder *e)
                         fprintf(stderr, "\n");
                 }
         }
-        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket, (void *) e->prof, (void *) e->cs_tmp, (void *) e->scan_tmp,
+        for (void *p : { (void *) e->div, (void *) e->header_dev, (void *) e->ticket, (void *) e->prof, (void *) e->cs_tmp,
                          (void *) e->scan_header_dev[0], (void *) e->scan_header_dev[1], (void *) e->scan_header_dev[2] }) {
                 if (p) (void) hipFree(p);
         }
@@ -1751,7 +1754,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         // the block-parallel coder, fused or behind the front end; two_launch: slots + gather launch, else the one-launch placement (look-back)
         // `scan` = nullptr: the frame's one interleaved scan.  Else one scan of a non-interleaved stream: a single component's blocks (its MCU is one block),
         // its own header bytes, destination and length words; always the one-launch placement
-        struct ScanPlan { const int16_t *coef; int tab0; const uint8_t *header; int header_len; uint8_t *out; size_t out_stride, capacity; uint32_t *total; };
+        struct ScanPlan { const int16_t *coef; int tab0; const uint8_t *header; int header_len; const uint32_t *base; uint32_t *total; };
         auto launch_coder = [&](bool two_launch, const ScanPlan *scan = nullptr) -> int {
                 const int S = scan ? e->ri : S_frame;
                 const bool fused = !scan && (fused_yuv || fused_rgb || fused_i420); // (shadows the call's: a scan of one component reads coefficients)
@@ -1767,7 +1770,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 a.out = (uint8_t *) out_dev; a.out_stride = out_stride; a.capacity = out_capacity; a.header = e->header_dev; a.header_len = (int) e->header.size();
                 a.total_pinned = e->total_host_dev;
                 if (scan) {
-                        a.out = scan->out; a.out_stride = scan->out_stride; a.capacity = scan->capacity; a.header = scan->header; a.header_len = scan->header_len;
+                        a.header = scan->header; a.header_len = scan->header_len; a.base = scan->base;
                         a.total_pinned = scan->total;
                 }
                 a.status = e->status; a.n_status = e->n_mcu; a.gen = e->gen; a.ticket = e->use_ticket ? e->ticket : nullptr; a.prof = e->prof;
@@ -1855,22 +1858,14 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         };
         if (e->nonint) {
                 // One scan per component (T.81 A.2.2; the reference's default for RGB input, gpujpeg.cpp:303).  Each scan is the block coder over ONE
-                // component's coefficients -- DC prediction and restart intervals (in blocks) of its own, its markers numbered from RST0 -- written
-                // with its header bytes into a region of its own; where a scan ends is only known once it is coded, so the three are put behind
-                // one another after the synchronisation (device-to-device copies; the EOI the coder ends every stream with is dropped from scans
-                // 0 and 1).  Three launches + a synchronisation + three copies per frame: the price of the layout (`:interleaved` avoids it).
-                const size_t cap1 = (out_capacity + 15) / 16 * 16;
-                if (e->scan_tmp_bytes < 3 * cap1 * (size_t) frames) {
-                        if (e->scan_tmp) (void) hipFree(e->scan_tmp);
-                        e->scan_tmp = nullptr;
-                        e->scan_tmp_bytes = 0;
-                        UG_HIP_TRY(hipMalloc((void **) &e->scan_tmp, 3 * cap1 * (size_t) frames));
-                        e->scan_tmp_bytes = 3 * cap1 * (size_t) frames;
-                }
+                // component's coefficients -- DC prediction and restart intervals (in blocks) of its own, its markers numbered from RST0 -- preceded by
+                // its header bytes (scan 0: SOI .. SOS; scans 1, 2: their SOS).  Where a scan ends is only known once it is coded: the launch of scan c
+                // reads the length scan c - 1 left behind (CodeArgs::base) and goes on from there, over the EOI every coded stream ends with.  Three
+                // launches on the stream, one synchronisation, no intermediate buffer.
                 memset(e->total_host, 0, 4 * kTotalWords * 4);
                 for (int c = 0; c < 3; c++) {
                         const ScanPlan pl = { c == 0 ? e->cy : (c == 1 ? e->cb : e->cr), e->ycc && c > 0 ? 1 : 0, e->scan_header_dev[c], (int) e->scan_header[c].size(),
-                                              e->scan_tmp + (size_t) c * cap1 * frames, cap1, cap1, e->total_host_dev + (c + 1) * kTotalWords };
+                                              c > 0 ? e->total_host_dev + c * kTotalWords : nullptr, e->total_host_dev + (c + 1) * kTotalWords };
                         const int lrc = launch_coder(false, &pl);
                         if (lrc != UG_HIP_SUCCESS) return lrc;
                 }
@@ -1890,21 +1885,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 }
                 bool fits = true;
                 for (int f = 0; f < frames; f++) {
-                        const size_t l0 = t1[f], l1 = t2[f], l2 = t3[f];
-                        const size_t total = l0 - 2 + l1 - 2 + l2;
-                        out_len[f] = total;
-                        if (l0 > cap1 || l1 > cap1 || l2 > cap1 || total > out_capacity) { // (a scan that did not fit its region reports the size it needs, like a stream)
-                                fits = false;
-                                if (out_len[f] <= out_capacity) out_len[f] = out_capacity + 1;
-                                continue;
-                        }
-                        uint8_t *const dst = (uint8_t *) out_dev + (size_t) f * out_stride;
-                        const uint8_t *const s0 = e->scan_tmp + (size_t) f * cap1, *const s1 = s0 + cap1 * frames, *const s2 = s1 + cap1 * frames;
-                        UG_HIP_TRY(hipMemcpyAsync(dst, s0, l0 - 2, hipMemcpyDeviceToDevice, st));
-                        UG_HIP_TRY(hipMemcpyAsync(dst + l0 - 2, s1, l1 - 2, hipMemcpyDeviceToDevice, st));
-                        UG_HIP_TRY(hipMemcpyAsync(dst + l0 - 2 + l1 - 2, s2, l2, hipMemcpyDeviceToDevice, st));
+                        out_len[f] = t3[f]; // the last scan's end = the stream's length (what it needs, when it does not fit: nothing past the capacity was written)
+                        fits = fits && out_len[f] <= out_capacity;
                 }
-                UG_HIP_TRY(hipStreamSynchronize(st));
                 if (!fits && frames == 1) {
                         ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: stream does not fit the output buffer (out_len = needed size)");
                         return UG_HIP_EINVAL;

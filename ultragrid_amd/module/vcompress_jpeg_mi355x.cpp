@@ -82,7 +82,7 @@ void usage()
                "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y601|:Y601full|:Y709][:alpha][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
                "\t\tnuma        - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node (pinned frame pool local to the GPU); 0: left to the scheduler\n"
                "\t\tbatch       - frames a busy worker may queue and encode together (1-16, default 1); only matters for sources faster than the encoder\n"
-               "\t\tinterleaved - RGB input as one interleaved scan; default (as the reference's): one scan per component -- three coder launches, slower\n"
+               "\t\tinterleaved - RGB input as one interleaved scan; default (as the reference's): one scan per component -- three coder launches, a little slower\n"
                "\t\tRGB | Y601 | Y601full | Y709 - colour space the samples are coded in (default: R,G,B for RGB input, BT.709 limited range for the rest)\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
                "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
