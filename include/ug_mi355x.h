@@ -445,18 +445,24 @@ int    ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int re
  *                converts in front of its forward DCT (ug_hip_jpeg_colour_convert below), taking RGB input as full-range R'G'B' and UYVY as BT.709
  *                limited range: RGB input + a Y'CbCr space -> a JFIF-shaped stream, components 1, 2, 3, chroma tables for Cb and Cr (Y601full IS
  *                JFIF); UYVY input + BT.601 (either range) -> the usual 4:2:x stream of the converted samples; UG_JPEG_CS_RGB with RGB input and
- *                UG_JPEG_CS_YCBCR_BT709 with UYVY / I420 input = UG_JPEG_CS_ASIS.  Not offered (UG_HIP_EUNSUPP at encode): UYVY / I420 coded as RGB,
- *                I420 with a conversion.  The colour stage is UNPINNED towards libgpujpeg like the FDCT: published BT.601 / BT.709 definitions, fp32.
+ *                UG_JPEG_CS_YCBCR_BT709 with UYVY / I420 input = UG_JPEG_CS_ASIS.  Not offered (UG_HIP_EUNSUPP): R, G, B components with
+ *                subsampling 420 / 422, I420 with a conversion.  The colour stage is UNPINNED towards libgpujpeg like the FDCT: published BT.601 /
+ *                BT.709 definitions, fp32.
  *   flags        UG_JPEG_NONINTERLEAVED (subsampling 444 only): one scan per component (T.81 A.2.2; restart intervals count blocks of the scan's
  *                component) -- the reference's DEFAULT for RGB input (interleaved = 0 unless `:interleaved`, gpujpeg.cpp:303); the header then
  *                carries what those scans use (RGB: quantiser and Huffman table 0 only).  Three coder launches, each going on where the one before
- *                ended (one synchronisation, no intermediate buffer); the single interleaved scan is ONE fused kernel and faster. */
+ *                ended (one synchronisation, no intermediate buffer); the single interleaved scan is ONE fused kernel and faster.
+ *                UG_JPEG_INPUT_UYVY (subsampling 444 only): the 4:4:4 encoder is fed UYVY instead of RGB (`-c jpeg:subsampling=444` on a 4:2:2
+ *                source, gpujpeg.cpp:297-302 with GPUJPEG_422_U8_P1020 input): every pixel takes its pair's chroma, and the samples are coded as
+ *                they are (UG_JPEG_CS_ASIS / _BT709: a Y'CbCr stream like the one RGB input + _BT709 gives), converted to BT.601 (either range),
+ *                or converted to R, G, B (UG_JPEG_CS_RGB: the R,G,B stream of RGB input, from a 4:2:2 source). */
 #define UG_JPEG_CS_ASIS                0
 #define UG_JPEG_CS_RGB                 1 /* GPUJPEG_RGB: full-range R'G'B' */
 #define UG_JPEG_CS_YCBCR_BT601         2 /* GPUJPEG_YCBCR_BT601: limited range (16-235 / 16-240) */
 #define UG_JPEG_CS_YCBCR_BT601_256LVLS 3 /* GPUJPEG_YCBCR_BT601_256LVLS: full range -- the JFIF colour space */
 #define UG_JPEG_CS_YCBCR_BT709         4 /* GPUJPEG_YCBCR_BT709: limited range */
 #define UG_JPEG_NONINTERLEAVED         1
+#define UG_JPEG_INPUT_UYVY             2
 int    ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restart_interval, int subsampling, int internal_cs, int flags,
                                      ug_hip_jpeg_encoder **out);
 /* The colour stage by itself.  m[12]: out_i = m[4 i] * in_0 + m[4 i + 1] * in_1 + m[4 i + 2] * in_2 + m[4 i + 3] on 8-bit code values, cs_in -> cs_out

@@ -241,11 +241,31 @@ static float cs_row(const float *m, float a, float b, float c)
 }
 static uint8_t cs_code(float v) { return (uint8_t) rintf(fminf(255.0f, fmaxf(0.0f, v))); }
 
-/* fmt 0: packed 3 bytes per pixel; 1: UYVY (every pixel with its pair's chroma; the pair's two chroma results averaged a * 0.5 + b * 0.5) */
+/* fmt 0: packed 3 bytes per pixel; 1: UYVY (every pixel with its pair's chroma; the pair's two chroma results averaged a * 0.5 + b * 0.5);
+ * 2: UYVY -> packed 3 bytes per pixel (4:2:2 -> 4:4:4, every pixel with its pair's chroma; cs_in == cs_out: the samples as they are; lines of (width + 1) / 2
+ *    pairs) -- what a 4:4:4 stream from a 4:2:2 source codes (gpujpeg.cpp:297-302 with subsampling=444 on UYVY input) */
 int oracle_jpeg_colour_convert(int fmt, int cs_in, int cs_out, const uint8_t *src, uint8_t *dst, int width, int height)
 {
         float m[12];
         if (oracle_jpeg_colour_matrix(cs_in, cs_out, m) || (fmt == 1 && (width & 1))) return -1;
+        if (fmt == 2) {
+                const long pairs = (width + 1) / 2;
+                for (long y = 0; y < height; y++) {
+                        for (long x = 0; x < width; x++) {
+                                const uint8_t *p = src + 4 * (y * pairs + x / 2);
+                                uint8_t *o = dst + 3 * (y * width + x);
+                                const float a = p[1 + 2 * (x & 1)], b = p[0], c = p[2];
+                                if (cs_in == cs_out) {
+                                        o[0] = p[1 + 2 * (x & 1)]; o[1] = p[0]; o[2] = p[2];
+                                } else {
+                                        o[0] = cs_code(cs_row(m, a, b, c));
+                                        o[1] = cs_code(cs_row(m + 4, a, b, c));
+                                        o[2] = cs_code(cs_row(m + 8, a, b, c));
+                                }
+                        }
+                }
+                return 0;
+        }
         for (long i = 0; i < (long) width * height / (fmt ? 2 : 1); i++) {
                 if (fmt == 0) {
                         const float a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];

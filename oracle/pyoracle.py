@@ -536,10 +536,10 @@ def jpeg_colour_matrix(cs_in: int, cs_out: int) -> np.ndarray:
 
 
 def jpeg_colour_convert(fmt: str, cs_in: int, cs_out: int, src: np.ndarray, w: int, h: int) -> np.ndarray:
-    """fmt "RGB" (3 bytes per pixel, whatever they mean) or "UYVY"; packed lines"""
+    """fmt "RGB" (3 bytes per pixel, whatever they mean), "UYVY", or "UYVY444" (UYVY -> 3 bytes per pixel, every pixel with its pair's chroma); packed lines"""
     src = np.ascontiguousarray(src, np.uint8).ravel()
-    out = np.zeros_like(src)
-    if lib().oracle_jpeg_colour_convert(0 if fmt == "RGB" else 1, cs_in, cs_out, _ptr(src), _ptr(out), w, h):
+    out = np.zeros(3 * w * h, np.uint8) if fmt == "UYVY444" else np.zeros_like(src)
+    if lib().oracle_jpeg_colour_convert({"RGB": 0, "UYVY": 1, "UYVY444": 2}[fmt], cs_in, cs_out, _ptr(src), _ptr(out), w, h):
         raise ValueError("oracle_jpeg_colour_convert")
     return out
 

@@ -209,6 +209,54 @@ def test_gpu_uyvy_coded_as_bt601(hip, po, cs, sub):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cs", [0, RGB, Y601, Y601FULL, Y709])
+@pytest.mark.parametrize("dims", [(640, 368), (322, 166), (75, 33)], ids=str)
+def test_gpu_uyvy_coded_444(hip, po, cs, dims):
+    """subsampling=444 on a 4:2:2 source (UG_JPEG_INPUT_UYVY; gpujpeg.cpp:297-302 with UYVY input): every pixel with its pair's chroma, coded as the
+    samples are (BT.709 Y'CbCr), as BT.601, or as R, G, B -- the stream == the 4:4:4 encoder for RGB input fed the oracle's 3 B/px picture"""
+    import torch
+    from jpeg_bitstream import write_jpeg
+    from ultragrid_amd import lib as L
+    w, h = dims
+    q, ri = 80, 4
+    uyvy = synth.s2_video("UYVY", w + (w & 1), h, salt=11).reshape(h, -1)[:, :(w + 1) // 2 * 4].copy().ravel()
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=444, internal_cs=cs, flags=L.JPEG_INPUT_UYVY)
+    dev = torch.from_numpy(uyvy).cuda()
+    data = enc.encode(dev, L.PF_UYVY)
+    if w % 2 == 0:
+        two = enc.encode_batch(torch.stack([dev, dev.flip(0)]), L.PF_UYVY)
+        assert two[0] == data and two[1] != data
+    with pytest.raises(RuntimeError):
+        enc.encode(torch.zeros(3 * w * h, dtype=torch.uint8).cuda(), L.PF_RGB)          # it was created for UYVY
+    enc.close()
+    pic = po.jpeg_colour_convert("UYVY444", Y709, cs or Y709, uyvy, w, h).reshape(h, w, 3)
+    if cs in (0, Y709):
+        pairs = uyvy.reshape(h, -1, 4)
+        assert np.array_equal(pic[:, 0::2, 0], pairs[:, :, 1]) and np.array_equal(pic[:, 1::2, 0], pairs[:, :w // 2, 3])
+        assert np.array_equal(pic[:, 0::2, 1], pairs[:, :, 0]) and np.array_equal(pic[:, 1::2, 2], pairs[:, :w // 2, 2])
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    if cs == RGB:
+        want = write_jpeg(w, h, ql, qc, *_coefs444(po, pic, ql, None, w, h), restart=ri, sub=444)     # (the header carries table 1 too; R, G, B all use table 0)
+        if w % 2 == 0:    # the picture a viewer gets == the reference's own UYVY -> RGB conversion of the source, within the codec's loss
+            img = np.asarray(Image.open(io.BytesIO(data))).astype(float)
+            ref = po.convert_frame("UYVY", "RGB", uyvy, w, h).reshape(h, w, 3).astype(float)
+            assert 10 * np.log10(255.0 ** 2 / np.mean((img - ref) ** 2)) > 28
+    else:
+        want = write_jpeg(w, h, ql, qc, *_coefs444(po, pic, ql, qc, w, h), restart=ri, sub=444, ycc=True)
+    assert data == want
+    plain = hip.JpegEncoder(w, h, q, ri, subsampling=444, internal_cs=0 if cs == RGB else cs or Y709)
+    same = plain.encode(torch.from_numpy(pic.ravel()).cuda(), L.PF_RGB)
+    plain.close()
+    if cs == RGB:
+        assert same == data          # (for the Y'CbCr spaces the plain encoder would convert the picture once more: nothing to compare)
+    dec = hip.JpegDecoder()
+    got = dec.decode(data, L.PF_RGB).cpu().numpy().reshape(h, w, 3)
+    dec.close()
+    _, crop, _ = po.jpeg_decode_planes(data)
+    assert np.abs(np.stack(crop, -1).astype(int) - pic).mean() < 2.5 and got.shape == (h, w, 3)
+
+
+@pytest.mark.gpu
 def test_gpu_create_ex_refusals(hip):
     import ctypes as C
     from ultragrid_amd import lib as L
@@ -217,4 +265,5 @@ def test_gpu_create_ex_refusals(hip):
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 422, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP     # one scan per component: 4:4:4
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 420, L.JPEG_CS_RGB, 0, C.byref(enc)) == L.EUNSUPP             # a 4:2:x stream is Y'CbCr
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 300, 444, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP
-    assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 7, 0, C.byref(enc)) == L.EINVAL and l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 0, 2, C.byref(enc)) == L.EINVAL
+    assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 7, 0, C.byref(enc)) == L.EINVAL and l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 0, 4, C.byref(enc)) == L.EINVAL
+    assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 422, 0, L.JPEG_INPUT_UYVY, C.byref(enc)) == L.EUNSUPP          # a 4:2:x encoder takes UYVY anyway

@@ -402,8 +402,9 @@ def test_jpeg_through_reference_framework(tmp_path, po, codec, sub):
 def test_jpeg_module_rejects_impossible_subsampling(tmp_path):
     raw = tmp_path / "in.raw"
     np.zeros(64 * 64 * 2, np.uint8).tofile(raw)
-    assert _run(["jpeg:subsampling=444", "UYVY", 64, 64, raw, tmp_path / "o"]).returncode != 0   # 4:4:4 needs RGB-family input
     assert _run(["jpeg:subsampling=411", "UYVY", 64, 64, raw, tmp_path / "o"]).returncode != 0
+    np.zeros(64 * 64 * 3 // 2, np.uint8).tofile(raw)
+    assert _run(["jpeg:subsampling=444", "I420", 64, 64, raw, tmp_path / "o"]).returncode != 0   # planar input is coded as it comes, 4:2:0
 
 
 @needs_harness
@@ -551,7 +552,7 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
         assert r.returncode == 0, cfg + r.stdout + r.stderr
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] == outs[2] == outs[3]
-    assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails (4:2:x input is not coded as R, G, B): frame dropped
+    assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails (R, G, B components are coded 4:4:4 only; `:subsampling=444:RGB` is taken): frame dropped
     r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
     assert r.returncode == 0 and "Requested alpha encode but input codec is unsupported pixel format" in (r.stdout + r.stderr)      # gpujpeg.cpp:327-328
     rgba = tmp_path / "rgba.raw"
@@ -559,6 +560,35 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
     r = _run(["jpeg:alpha", "RGBA", w, h, rgba, tmp_path / "x"])
     assert r.returncode == 3 and "fourth component" in (r.stdout + r.stderr)            # refused, not silently dropped
     assert _run(["jpeg", "RGBA", w, h, rgba, tmp_path / "x"]).returncode == 0
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt,cs", [("", 4), (":Y709", 4), (":Y601", 2), (":Y601full", 3), (":RGB", 1)])
+@pytest.mark.parametrize("codec", ["UYVY", "v210"])
+def test_jpeg_444_from_a_422_source(tmp_path, po, codec, opt, cs):
+    """`-c jpeg:subsampling=444` on 4:2:2 input (gpujpeg.cpp:297-302: the option overrides the codec's own subsampling): every pixel with its pair's chroma,
+    one interleaved scan (the input is not RGB, :303), coded in BT.709 as it comes, in BT.601, or as R, G, B with `:RGB`; bytes == the test writer's over the
+    oracle's 3 B/px picture; the product's decompress module gives the source back within the codec's loss"""
+    from jpeg_bitstream import write_jpeg
+    w, h = 208, 72
+    uyvy = synth.s2_video("UYVY", w, h, salt=3)
+    src = uyvy if codec == "UYVY" else po.convert_frame("UYVY", "v210", uyvy, w, h)
+    as_uyvy = uyvy if codec == "UYVY" else po.convert_frame("v210", "UYVY", src, w, h)
+    raw, out = tmp_path / "in.raw", tmp_path / "o.jpg"
+    np.ascontiguousarray(src).tofile(raw)
+    r = _run([f"jpeg:q=85:restart=4:subsampling=444{opt}", codec, w, h, raw, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    pic = po.jpeg_colour_convert("UYVY444", 4, cs, as_uyvy, w, h).reshape(h, w, 3)
+    ql, qc = po.jpeg_qtable(85, 0), po.jpeg_qtable(85, 1)
+    coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(pic[..., c]), po.jpeg_divisors(ql if c == 0 or cs == 1 else qc), (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+    assert out.read_bytes() == write_jpeg(w, h, ql, qc, *coefs, restart=4, sub=444, ycc=cs != 1)     # (R, G, B: table 0 for every component)
+    if os.path.exists(DEC_HARNESS) and cs in (4, 1):
+        back = tmp_path / "back.raw"
+        r = subprocess.run([DEC_HARNESS, "JPEG", "UYVY", str(w), str(h), str(out), str(back)], capture_output=True, text=True, timeout=30)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = np.fromfile(back, np.uint8)[:2 * w * h].reshape(h, w, 2)[..., 1].astype(float)
+        assert 10 * np.log10(255.0 ** 2 / np.mean((got - as_uyvy.reshape(h, w, 2)[..., 1]) ** 2)) > 32
 
 
 @needs_harness

@@ -35,8 +35,23 @@ for seed in range(n):
     nonint = sub == 444 and seed % 6 < 3
     if sub != 444 and cs == 4:
         cs = 0
-    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub, internal_cs=cs, flags=L.JPEG_NONINTERLEAVED if nonint else 0)
-    if sub == 444:
+    from422 = sub == 444 and seed % 5 == 4      # a 4:4:4 encoder fed UYVY (UG_JPEG_INPUT_UYVY), any internal colour space, either scan layout
+    if from422:
+        cs = int(rng.integers(0, 5))
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub, internal_cs=cs, flags=(L.JPEG_NONINTERLEAVED if nonint else 0) | (L.JPEG_INPUT_UYVY if from422 else 0))
+    if from422:
+        uyvy = po.convert_frame("RGB", "UYVY", rgb, w, h)
+        dev = torch.from_numpy(uyvy).cuda()
+        data = enc.encode_batch(torch.stack([dev, dev]), L.PF_UYVY)[1] if two else enc.encode(dev, L.PF_UYVY)
+        comps = po.jpeg_colour_convert("UYVY444", 4, cs or 4, uyvy, w, h).reshape(h, w, 3)
+        ycc = cs != 1
+        coefs = [po.jpeg_fdct_quant_plane(np.ascontiguousarray(comps[..., c]), dc if ycc and c else dl, (w + 7) // 8, (h + 7) // 8) for c in range(3)]
+        if nonint:
+            from jpeg_bitstream import write_jpeg_noninterleaved
+            want = write_jpeg_noninterleaved(w, h, ql, coefs, restart=ri, qt_chroma=qc if ycc else None)
+        else:
+            want = write_jpeg(w, h, ql, qc, *coefs, restart=ri, sub=444, ycc=ycc)
+    elif sub == 444:
         dev = torch.from_numpy(np.ascontiguousarray(rgb).ravel()).cuda()
         data = enc.encode_batch(torch.stack([dev, dev]), L.PF_RGB)[1] if two else enc.encode(dev, L.PF_RGB)
         comps = po.jpeg_colour_convert("RGB", 1, cs, rgb, w, h).reshape(h, w, 3) if cs else rgb

@@ -311,7 +311,7 @@ class JpegEncoder:
     """ug_hip_jpeg_encoder_* (gpujpeg_encoder_create / _encode / _destroy shape, gpujpeg.cpp:353,624,639)."""
 
     def __init__(self, w: int, h: int, quality: int = 75, restart_interval: int = 4, subsampling: int = 420, internal_cs: int = 0, flags: int = 0):
-        """internal_cs: L.JPEG_CS_* (color_space_internal of gpujpeg.cpp:303-305), flags: L.JPEG_NONINTERLEAVED (ug_hip_jpeg_encoder_create_ex)"""
+        """internal_cs: L.JPEG_CS_* (color_space_internal of gpujpeg.cpp:303-305), flags: L.JPEG_NONINTERLEAVED, L.JPEG_INPUT_UYVY (ug_hip_jpeg_encoder_create_ex)"""
         import ctypes as C
         self._h = C.c_void_p()
         if internal_cs or flags:

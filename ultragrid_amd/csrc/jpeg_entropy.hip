@@ -1378,6 +1378,8 @@ struct Encoder {
         int ctab;      // Huffman table pair of the chroma blocks: 0 = the luma pair (R, G, B streams), 1
         int cs_rgb;    // RGB input is converted to this colour space in front of the FDCT (0: coded as it comes)
         int cs_uyvy;   // UYVY input (BT.709 limited range) is converted to this one (0: coded as it comes)
+        bool in_uyvy;  // UG_JPEG_INPUT_UYVY: a 4:4:4 encoder fed UYVY (brought to 3 B/px, in colour space cs_444, in front of everything else)
+        int cs_444;
         uint8_t *cs_tmp;       // the converted frame(s)
         size_t cs_tmp_bytes;
         std::vector<uint8_t> scan_header[3]; // non-interleaved: what precedes the entropy-coded bytes of scan c (scan 0: the whole header)
@@ -1550,12 +1552,13 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: subsampling must be 420, 422 or 444");
                 return UG_HIP_EUNSUPP;
         }
-        if (internal_cs < UG_JPEG_CS_ASIS || internal_cs > UG_JPEG_CS_YCBCR_BT709 || (flags & ~UG_JPEG_NONINTERLEAVED)) {
+        if (internal_cs < UG_JPEG_CS_ASIS || internal_cs > UG_JPEG_CS_YCBCR_BT709 || (flags & ~(UG_JPEG_NONINTERLEAVED | UG_JPEG_INPUT_UYVY))) {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: unknown colour space or flag");
                 return UG_HIP_EINVAL;
         }
-        if (subsampling != 444 && ((flags & UG_JPEG_NONINTERLEAVED) || internal_cs == UG_JPEG_CS_RGB)) {
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: a 4:2:x stream is Y'CbCr in one interleaved scan (R, G, B components and one scan per component: 4:4:4)");
+        if (subsampling != 444 && ((flags & (UG_JPEG_NONINTERLEAVED | UG_JPEG_INPUT_UYVY)) || internal_cs == UG_JPEG_CS_RGB)) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: a 4:2:x stream is Y'CbCr in one interleaved scan (R, G, B components, one scan per component, "
+                                       "UG_JPEG_INPUT_UYVY: 4:4:4)");
                 return UG_HIP_EUNSUPP;
         }
         if ((flags & UG_JPEG_NONINTERLEAVED) && restart_interval > 256) {
@@ -1564,8 +1567,10 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
         }
         Encoder *e = new Encoder();
         e->nonint = (flags & UG_JPEG_NONINTERLEAVED) != 0;
-        e->ycc = subsampling == 444 && internal_cs >= UG_JPEG_CS_YCBCR_BT601;
-        e->cs_rgb = e->ycc ? internal_cs : 0;
+        e->in_uyvy = (flags & UG_JPEG_INPUT_UYVY) != 0;
+        e->cs_444 = internal_cs;
+        e->ycc = subsampling == 444 && (internal_cs >= UG_JPEG_CS_YCBCR_BT601 || (e->in_uyvy && internal_cs == UG_JPEG_CS_ASIS));
+        e->cs_rgb = e->ycc && !e->in_uyvy ? internal_cs : 0;
         e->cs_uyvy = subsampling != 444 && (internal_cs == UG_JPEG_CS_YCBCR_BT601 || internal_cs == UG_JPEG_CS_YCBCR_BT601_256LVLS) ? internal_cs : 0;
         e->ctab = subsampling == 444 && !e->ycc ? 0 : 1;
         e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
@@ -1698,6 +1703,27 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 if (crc != UG_HIP_SUCCESS) return crc;
                 src_dev = e->cs_tmp;
                 src_pitch = ls;
+                src_stride = fb;
+        }
+        // ---- a 4:4:4 encoder fed UYVY (UG_JPEG_INPUT_UYVY): the frame(s) as 3 B/px in the coded colour space, which then take the place of RGB input ----
+        if (e->sub == 444 && e->in_uyvy != (in == UG_PF_UYVY)) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: a 4:4:4 encoder takes RGB, or UYVY when created with UG_JPEG_INPUT_UYVY");
+                return UG_HIP_EUNSUPP;
+        }
+        if (e->sub == 444 && e->in_uyvy) {
+                const size_t fb = ((size_t) 3 * w * h + 15) / 16 * 16;
+                if (e->cs_tmp_bytes < fb * frames) {
+                        if (e->cs_tmp) (void) hipFree(e->cs_tmp);
+                        e->cs_tmp = nullptr;
+                        e->cs_tmp_bytes = 0;
+                        UG_HIP_TRY(hipMalloc((void **) &e->cs_tmp, fb * kMaxBatch));
+                        e->cs_tmp_bytes = fb * kMaxBatch;
+                }
+                const int crc = ug::jpeg_uyvy_to_444(e->cs_444, src_dev, src_pitch, e->cs_tmp, 3 * w, w, h, frames, src_stride, fb, stream);
+                if (crc != UG_HIP_SUCCESS) return crc;
+                in = UG_PF_RGB;
+                src_dev = e->cs_tmp;
+                src_pitch = 3 * w;
                 src_stride = fb;
         }
         // Fused: forward DCT, quantiser, Huffman coding and byte stuffing in ONE kernel, a workgroup per 32 consecutive MCUs -- the quantised

@@ -608,7 +608,57 @@ __global__ __launch_bounds__(256) void colour_uyvy_kernel(const uint8_t *__restr
                 to_code(cb) | to_code(affine_row(cm.m, y0, u, v)) << 8 | to_code(cr) << 16 | to_code(affine_row(cm.m, y1, u, v)) << 24;
 }
 
+// UYVY -> packed 3 B / px (4:2:2 -> 4:4:4: both pixels of a pair take the pair's chroma), MAP: through the colour map, else the samples as they are;
+// one lane per pair; the last pair of an odd width has one pixel
+template <bool MAP>
+__global__ __launch_bounds__(256) void uyvy_to_444_kernel(const uint8_t *__restrict__ src, int src_pitch, uint8_t *__restrict__ dst, int dst_pitch, int width, int height,
+                                                          size_t src_stride, size_t dst_stride, ColourMap cm)
+{
+        const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+        if (2 * x >= width || y >= height) return;
+        const uint32_t q = *(const uint32_t *) (src + blockIdx.z * src_stride + (size_t) y * src_pitch + 4 * (size_t) x);
+        uint8_t *o = dst + blockIdx.z * dst_stride + (size_t) y * dst_pitch + 6 * (size_t) x;
+        const uint32_t u = q & 0xff, v = (q >> 16) & 0xff;
+        for (int i = 0; i < 2 && 2 * x + i < width; i++) {
+                const uint32_t l = i ? q >> 24 : (q >> 8) & 0xff;
+                if (MAP) {
+                        const float a = (float) l, b = (float) u, c = (float) v;
+                        o[3 * i] = (uint8_t) to_code(affine_row(cm.m, a, b, c));
+                        o[3 * i + 1] = (uint8_t) to_code(affine_row(cm.m + 4, a, b, c));
+                        o[3 * i + 2] = (uint8_t) to_code(affine_row(cm.m + 8, a, b, c));
+                } else {
+                        o[3 * i] = (uint8_t) l; o[3 * i + 1] = (uint8_t) u; o[3 * i + 2] = (uint8_t) v;
+                }
+        }
+}
+
 } // namespace
+
+int ug::jpeg_uyvy_to_444(int cs_out, const void *src, int src_pitch, void *dst, int dst_pitch, int width, int height, int frames, size_t src_stride, size_t dst_stride,
+                         ug_hip_stream_t stream)
+{
+        ColourMap cm = {};
+        const bool map = cs_out != UG_JPEG_CS_ASIS && cs_out != UG_JPEG_CS_YCBCR_BT709;
+        if (!ug::dims_ok(width, height)) return ug::refuse_size("ug_hip_jpeg_encoder_encode");
+        const int ls = (width + 1) / 2 * 4;
+        if (!src_pitch) src_pitch = ls;
+        if (!dst_pitch) dst_pitch = 3 * width;
+        if (!src || !dst || frames < 1 || frames > 65535 || (map && !colour_map(UG_JPEG_CS_YCBCR_BT709, cs_out, cm)) || src_pitch < ls || dst_pitch < 3 * width ||
+            !ug::span_ok(src_pitch, height) || !ug::span_ok(dst_pitch, height) || (src_pitch & 3) || (3 & (uintptr_t) src) || (frames > 1 && (src_stride & 3))) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_encode: UYVY input of a 4:4:4 encoder: 4-byte aligned lines");
+                return UG_HIP_EINVAL;
+        }
+        const dim3 grid((unsigned) (((width + 1) / 2 + 255) / 256), (unsigned) height, (unsigned) frames);
+        if (map) {
+                hipLaunchKernelGGL(uyvy_to_444_kernel<true>, grid, dim3(256), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, (uint8_t *) dst, dst_pitch, width, height,
+                                   src_stride, dst_stride, cm);
+        } else {
+                hipLaunchKernelGGL(uyvy_to_444_kernel<false>, grid, dim3(256), 0, (hipStream_t) stream, (const uint8_t *) src, src_pitch, (uint8_t *) dst, dst_pitch, width, height,
+                                   src_stride, dst_stride, cm);
+        }
+        UG_HIP_LAUNCH_CHECK();
+        return UG_HIP_SUCCESS;
+}
 
 int ug::jpeg_colour_convert(ug_pixfmt_t fmt, int cs_in, int cs_out, const void *src, int src_pitch, void *dst, int dst_pitch, int width, int height, int frames,
                             size_t src_stride, size_t dst_stride, ug_hip_stream_t stream)

@@ -93,6 +93,9 @@ int jpeg_fdct_quant_strided(const void *plane, int pitch, int xstride, int width
 // the JPEG encoder's colour stage (jpeg_fdct.hip): RGB (3 B/px) or UYVY frames from colour space cs_in to cs_out (UG_JPEG_CS_*), grid.z = frame
 int jpeg_colour_convert(ug_pixfmt_t fmt, int cs_in, int cs_out, const void *src, int src_pitch, void *dst, int dst_pitch, int width, int height, int frames,
                         size_t src_stride, size_t dst_stride, ug_hip_stream_t stream);
+// UYVY frames -> packed 3 B/px for a 4:4:4 encoder (pair's chroma for both pixels), as they are (cs_out UG_JPEG_CS_ASIS / _BT709) or mapped BT.709 -> cs_out
+int jpeg_uyvy_to_444(int cs_out, const void *src, int src_pitch, void *dst, int dst_pitch, int width, int height, int frames, size_t src_stride, size_t dst_stride,
+                     ug_hip_stream_t stream);
 int jpeg_fdct_quant_rgb444(const void *src, int pitch, int width, int height, int blocks_w, int blocks_h, const float *div,
                            int16_t *out_r, int16_t *out_g, int16_t *out_b, ug_hip_stream_t stream);
 

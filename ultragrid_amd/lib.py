@@ -25,6 +25,7 @@ DXT1, DXT1_YUV, DXT5_YCOCG = 1, 2, 6
 TIES_EVEN, TIES_AWAY = 0, 1
 JPEG_CS_ASIS, JPEG_CS_RGB, JPEG_CS_YCBCR_BT601, JPEG_CS_YCBCR_BT601_256LVLS, JPEG_CS_YCBCR_BT709 = 0, 1, 2, 3, 4
 JPEG_NONINTERLEAVED = 1
+JPEG_INPUT_UYVY = 2
 COPY_NO_WAIT, COPY_NO_JOIN = 1, 2
 ABI_VERSION = 5
 

@@ -86,7 +86,8 @@ void usage()
                "\t\tRGB | Y601 | Y601full | Y709 - colour space the samples are coded in (default: R,G,B for RGB input, BT.709 limited range for the rest)\n"
                "\t\tsubsampling - JPEG subsampling; default = that of the codec the input is decoded to (get_best_decoder_from over\n"
                "\t\t              UYVY, RGB, RGBA): 422 for UYVY/YUYV/v210/Y216/DVS10, 444 (R,G,B components) for\n"
-               "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs\n");
+               "\t\t              RGB/RGBA/BGR/R10k/R12L/RG48/Y416/VUYA, 420 for I420; 420 from 4:2:2 input averages line pairs,\n"
+               "\t\t              444 from 4:2:2 input gives every pixel its pair's chroma (Y'CbCr, or R,G,B with :RGB)\n");
 }
 
 /// IS_KEY_PREFIX (utils/macros.h:162-164): tok is <k>=<v> and <k> is a (non-empty) prefix of key
@@ -194,12 +195,16 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         const int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (s->wire == UG_PF_I420 ? 420 : 422));
         // color_space_internal (gpujpeg.cpp:303-305: the option, else RGB for RGB input and BT.709 for the rest).  4:4:4 from an RGB-family input: R, G, B
         // as they are, or converted to the Y'CbCr space asked for; 4:2:x (UYVY, or RGB-family input brought to UYVY with pixfmt_conv.c's BT.709
-        // arithmetic): BT.709 limited range as the samples are, or converted to BT.601.  Not done: 4:2:x input coded as R, G, B; planar input converted.
+        // arithmetic): BT.709 limited range as the samples are, or converted to BT.601.  subsampling=444 on a 4:2:2 source: every pixel with its pair's
+        // chroma, coded as BT.709 / BT.601 Y'CbCr or as R, G, B.  Not done: R, G, B components subsampled (4:2:x + RGB); planar input converted.
         int enc_cs = UG_JPEG_CS_ASIS;
-        if (sub == 444) {
+        const bool uyvy_as_444 = sub == 444 && !rgb_family && s->wire != UG_PF_I420;
+        if (uyvy_as_444) {
+                enc_cs = s->internal_cs;
+        } else if (sub == 444) {
                 enc_cs = s->internal_cs == UG_JPEG_CS_RGB ? UG_JPEG_CS_ASIS : s->internal_cs;
         } else if (s->internal_cs == UG_JPEG_CS_RGB) {
-                MSG(ERROR, "internal colour space RGB: this input is coded as Y'CbCr 4:2:x (no conversion to R, G, B components is done)\n");
+                MSG(ERROR, "internal colour space RGB: R, G, B components are coded 4:4:4 only (add subsampling=444)\n");
                 return false;
         } else if (s->internal_cs == UG_JPEG_CS_YCBCR_BT601 || s->internal_cs == UG_JPEG_CS_YCBCR_BT601_256LVLS) {
                 if (s->wire == UG_PF_I420) {
@@ -210,7 +215,7 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         }
         // one scan per component for RGB input unless `:interleaved` (gpujpeg.cpp:303) -- where the components are not subsampled (the reference
         // writes subsampled RGB-input streams that way too; here those are 4:2:x Y'CbCr streams of one scan)
-        const int enc_flags = rgb_family && sub == 444 && !s->force_interleaved ? UG_JPEG_NONINTERLEAVED : 0;
+        const int enc_flags = (rgb_family && sub == 444 && !s->force_interleaved ? UG_JPEG_NONINTERLEAVED : 0) | (uyvy_as_444 ? UG_JPEG_INPUT_UYVY : 0);
         if (s->alpha) { // gpujpeg.cpp:318-330
                 if (desc.color_spec == RGBA) {
                         MSG(ERROR, "alpha: a fourth component is not coded by this encoder (the reference needs GPUJPEG >= 0.20.2 for it, gpujpeg.cpp:410-413); "
@@ -224,12 +229,8 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                         MSG(ERROR, "I420 input can only be coded as 4:2:0\n");
                         return false;
                 }
-        } else if (sub == 444) {
+        } else if (sub == 444 && rgb_family) {
                 s->enc_in = UG_PF_RGB;
-                if (!rgb_family) {
-                        MSG(ERROR, "subsampling=444 needs an RGB-family input, not %s\n", get_codec_name(desc.color_spec));
-                        return false;
-                }
         } else {
                 s->enc_in = UG_PF_UYVY;
         }
