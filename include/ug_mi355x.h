@@ -446,7 +446,7 @@ int    ug_hip_jpeg_encoder_create_sub(int width, int height, int quality, int re
  *                limited range: RGB input + a Y'CbCr space -> a JFIF-shaped stream, components 1, 2, 3, chroma tables for Cb and Cr (Y601full IS
  *                JFIF); UYVY input + BT.601 (either range) -> the usual 4:2:x stream of the converted samples; UG_JPEG_CS_RGB with RGB input and
  *                UG_JPEG_CS_YCBCR_BT709 with UYVY / I420 input = UG_JPEG_CS_ASIS.  Not offered (UG_HIP_EUNSUPP): R, G, B components with
- *                subsampling 420 / 422, I420 with a conversion.  The colour stage is UNPINNED towards libgpujpeg like the FDCT: published BT.601 /
+ *                subsampling 420 / 422, I420 with a conversion (ug_hip_yuv420p_to_uyvy first, as the module does).  The colour stage is UNPINNED towards libgpujpeg like the FDCT: published BT.601 /
  *                BT.709 definitions, fp32.
  *   flags        UG_JPEG_NONINTERLEAVED (subsampling 444 only): one scan per component (T.81 A.2.2; restart intervals count blocks of the scan's
  *                component) -- the reference's DEFAULT for RGB input (interleaved = 0 unless `:interleaved`, gpujpeg.cpp:303); the header then

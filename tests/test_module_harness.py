@@ -403,8 +403,8 @@ def test_jpeg_module_rejects_impossible_subsampling(tmp_path):
     raw = tmp_path / "in.raw"
     np.zeros(64 * 64 * 2, np.uint8).tofile(raw)
     assert _run(["jpeg:subsampling=411", "UYVY", 64, 64, raw, tmp_path / "o"]).returncode != 0
-    np.zeros(64 * 64 * 3 // 2, np.uint8).tofile(raw)
-    assert _run(["jpeg:subsampling=444", "I420", 64, 64, raw, tmp_path / "o"]).returncode != 0   # planar input is coded as it comes, 4:2:0
+    np.zeros(63 * 64 + 2 * 32 * 32, np.uint8).tofile(raw)
+    assert _run(["jpeg:subsampling=422", "I420", 63, 64, raw, tmp_path / "o"]).returncode != 0   # planar input with an option goes through UYVY: pixel pairs
 
 
 @needs_harness
@@ -589,6 +589,35 @@ def test_jpeg_444_from_a_422_source(tmp_path, po, codec, opt, cs):
         assert r.returncode == 0, r.stdout + r.stderr
         got = np.fromfile(back, np.uint8)[:2 * w * h].reshape(h, w, 2)[..., 1].astype(float)
         assert 10 * np.log10(255.0 ** 2 / np.mean((got - as_uyvy.reshape(h, w, 2)[..., 1]) ** 2)) > 32
+
+
+@needs_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["subsampling=422", "subsampling=444", "Y601", "Y601full:subsampling=420", "subsampling=444:RGB", "subsampling=420:Y709"])
+def test_jpeg_planar_input_with_options(tmp_path, po, cfg):
+    """I420 input is handed over as it is (gpujpeg.cpp:335) unless an option asks for another subsampling or colour space -- GPUJPEG then resamples / converts in its
+    preprocessor; here the picture goes through the reference's i420_8_to_uyvy shuffle (both lines of a pair take the chroma line) and on as UYVY input: the
+    stream == the one UYVY input of those samples gives; with nothing to change (`subsampling=420:Y709`) == the planar path's"""
+    w, h = 208, 80
+    uyvy0 = synth.s2_video("UYVY", w, h, salt=5)
+    planes = po.uyvy_to_i420(uyvy0, w, h)
+    i420 = np.concatenate([p.ravel() for p in planes])
+    as_uyvy = np.empty((h, w // 2, 4), np.uint8)
+    as_uyvy[..., 1], as_uyvy[..., 3] = planes[0][:, 0::2], planes[0][:, 1::2]
+    as_uyvy[..., 0], as_uyvy[..., 2] = np.repeat(planes[1], 2, axis=0)[:h], np.repeat(planes[2], 2, axis=0)[:h]
+    a, b, oa, ob = tmp_path / "a.raw", tmp_path / "b.raw", tmp_path / "a.jpg", tmp_path / "b.jpg"
+    i420.tofile(a)
+    as_uyvy.tofile(b)
+    r = _run([f"jpeg:q=85:restart=4:{cfg}", "I420", w, h, a, oa])
+    assert r.returncode == 0, r.stdout + r.stderr
+    if cfg == "subsampling=420:Y709":
+        assert _run(["jpeg:q=85:restart=4", "I420", w, h, a, ob]).returncode == 0
+    else:
+        assert _run([f"jpeg:q=85:restart=4:{cfg}" + ("" if "subsampling" in cfg else ":subsampling=420"), "UYVY", w, h, b, ob]).returncode == 0     # (I420's own subsampling where none is asked for)
+    assert oa.read_bytes() == ob.read_bytes() and len(oa.read_bytes()) > 1000
+    import io
+    from PIL import Image
+    Image.open(io.BytesIO(oa.read_bytes())).load()
 
 
 @needs_harness

@@ -90,6 +90,17 @@ void usage()
                "\t\t              444 from 4:2:2 input gives every pixel its pair's chroma (Y'CbCr, or R,G,B with :RGB)\n");
 }
 
+/// the device-side decoder_t pass wire -> target; planar I420 (which has no decoder_t) with the reference's i420_8_to_uyvy shuffle
+int wire_to_target(state_video_compress_jpeg_mi355x *s, const void *src, void *dst, int w, int h)
+{
+        if (s->wire == UG_PF_I420) {
+                const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+                const char *y = (const char *) src, *u = y + (size_t) w * h, *v = u + (size_t) cw * ch;
+                return ug_hip_yuv420p_to_uyvy(y, w, u, cw, v, cw, dst, 2 * w, w, h, s->stream);
+        }
+        return ug_hip_pixfmt_convert(s->wire, s->target, src, dst, w, h, 0, 0, 0, 8, 16, s->stream);
+}
+
 /// IS_KEY_PREFIX (utils/macros.h:162-164): tok is <k>=<v> and <k> is a (non-empty) prefix of key
 bool key_prefix(const std::string &tok, const char *key)
 {
@@ -182,8 +193,19 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         // RGB (the pad byte is ignored by GPUJPEG's 444_U8_P012Z too).  RGB-family targets with subsampling=422/420 go through
         // the pixfmt_conv.c RGB->UYVY arithmetic.
         bool rgb_family = false;
-        if (s->wire == UG_PF_I420) {
+        // Planar I420 goes to the encoder as it is (GPUJPEG_420_U8_P0P1P2, :335) -- unless an option asks for something a 4:2:0 planar picture is not
+        // (another subsampling, BT.601, R,G,B): GPUJPEG resamples / converts such input in its preprocessor; here the picture is first brought to UYVY
+        // with the reference's own i420_8_to_uyvy shuffle (video_codec.c:1073-1094: both lines of a pair take the chroma line) and then treated as UYVY input.
+        const bool planar_as_it_is = s->wire == UG_PF_I420 && (s->subsampling == 0 || s->subsampling == 420) &&
+                                     (s->internal_cs == UG_JPEG_CS_ASIS || s->internal_cs == UG_JPEG_CS_YCBCR_BT709);
+        if (planar_as_it_is) {
                 s->enc_in = UG_PF_I420;
+        } else if (s->wire == UG_PF_I420) {
+                if (desc.width % 2) {
+                        MSG(ERROR, "I420 %u pixels wide with subsampling= / a colour space option: the conversion goes through UYVY, which needs pixel pairs\n", desc.width);
+                        return false;
+                }
+                s->target = UG_PF_UYVY;
         } else {
                 const ug_pixfmt_t cand[] = { UG_PF_UYVY, UG_PF_RGB, UG_PF_RGBA, UG_PF_NONE };
                 if (s->wire == UG_PF_NONE || ug_hip_pixfmt_best(s->wire, cand, &s->target) != UG_HIP_SUCCESS) {
@@ -192,13 +214,13 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 }
                 rgb_family = s->target != UG_PF_UYVY;
         }
-        const int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (s->wire == UG_PF_I420 ? 420 : 422));
+        const int sub = s->subsampling ? s->subsampling : (rgb_family ? 444 : (s->wire == UG_PF_I420 ? 420 : 422));     // (get_subsampling(m_enc_input_codec), gpujpeg.cpp:297-302)
         // color_space_internal (gpujpeg.cpp:303-305: the option, else RGB for RGB input and BT.709 for the rest).  4:4:4 from an RGB-family input: R, G, B
         // as they are, or converted to the Y'CbCr space asked for; 4:2:x (UYVY, or RGB-family input brought to UYVY with pixfmt_conv.c's BT.709
         // arithmetic): BT.709 limited range as the samples are, or converted to BT.601.  subsampling=444 on a 4:2:2 source: every pixel with its pair's
         // chroma, coded as BT.709 / BT.601 Y'CbCr or as R, G, B.  Not done: R, G, B components subsampled (4:2:x + RGB); planar input converted.
         int enc_cs = UG_JPEG_CS_ASIS;
-        const bool uyvy_as_444 = sub == 444 && !rgb_family && s->wire != UG_PF_I420;
+        const bool uyvy_as_444 = sub == 444 && !rgb_family;
         if (uyvy_as_444) {
                 enc_cs = s->internal_cs;
         } else if (sub == 444) {
@@ -207,10 +229,6 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 MSG(ERROR, "internal colour space RGB: R, G, B components are coded 4:4:4 only (add subsampling=444)\n");
                 return false;
         } else if (s->internal_cs == UG_JPEG_CS_YCBCR_BT601 || s->internal_cs == UG_JPEG_CS_YCBCR_BT601_256LVLS) {
-                if (s->wire == UG_PF_I420) {
-                        MSG(ERROR, "internal colour space Y601 / Y601full: planar I420 input is coded as it comes (no colour conversion)\n");
-                        return false;
-                }
                 enc_cs = s->internal_cs;
         }
         // one scan per component for RGB input unless `:interleaved` (gpujpeg.cpp:303) -- where the components are not subsampled (the reference
@@ -224,11 +242,8 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
                 }
                 MSG(WARNING, "Requested alpha encode but input codec is unsupported pixel format: %s\n", get_codec_name(desc.color_spec)); // :327-328, and on it goes
         }
-        if (s->wire == UG_PF_I420) {
-                if (sub != 420) {
-                        MSG(ERROR, "I420 input can only be coded as 4:2:0\n");
-                        return false;
-                }
+        if (planar_as_it_is) {
+                // (s->enc_in = I420, above)
         } else if (sub == 444 && rgb_family) {
                 s->enc_in = UG_PF_RGB;
         } else {
@@ -250,7 +265,7 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         bool ok = ug_hip_malloc(&s->dev_in, s->in_len + MAX_PADDING) == UG_HIP_SUCCESS &&
                   ug_hip_malloc(&s->dev_out, s->max_out) == UG_HIP_SUCCESS;
         if (ok && s->wire != s->target) { // staging buffer for the device-side decoder_t pass (wire -> target)
-                ok = ug_hip_malloc(&s->dev_target, (size_t) vc_get_linesize(desc.width, ug_codec_from_pixfmt(s->target)) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
+                ok = ug_hip_malloc(&s->dev_target, (size_t) vc_get_linesize(desc.width, ug_codec_from_pixfmt(s->target)) * (desc.height + 1) + MAX_PADDING) == UG_HIP_SUCCESS;
         }
         if (ok && s->target != s->enc_in) { // and for target -> encoder input (RGBA -> RGB; RGB-family -> UYVY on subsampling=422/420)
                 ok = ug_hip_malloc(&s->dev_uyvy, (size_t) vc_get_linesize(desc.width, s->enc_in == UG_PF_RGB ? RGB : UYVY) * desc.height + MAX_PADDING) == UG_HIP_SUCCESS;
@@ -296,7 +311,7 @@ std::shared_ptr<video_frame> jpeg_mi355x_compress_tile(void *state, std::shared_
                 return {};
         }
         if (s->wire != s->target) {
-                if (ug_hip_pixfmt_convert(s->wire, s->target, enc_src, s->dev_target, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) {
+                if (wire_to_target(s, enc_src, s->dev_target, w, h) != UG_HIP_SUCCESS) {
                         MSG(ERROR, "device conversion %s -> %s failed: %s\n", get_codec_name(tx->color_spec), get_codec_name(ug_codec_from_pixfmt(s->target)), ug_hip_last_error_string());
                         return {};
                 }
@@ -378,7 +393,7 @@ std::vector<std::shared_ptr<video_frame>> jpeg_mi355x_compress_batch(void *state
                 const void *cur = (char *) s->b_in + f * s->b_in_stride;
                 if (s->wire != s->target) {
                         void *t = (char *) s->b_target + f * s->b_target_stride;
-                        if (ug_hip_pixfmt_convert(s->wire, s->target, cur, t, w, h, 0, 0, 0, 8, 16, s->stream) != UG_HIP_SUCCESS) return out;
+                        if (wire_to_target(s, cur, t, w, h) != UG_HIP_SUCCESS) return out;
                         cur = t;
                 }
                 if (s->target != s->enc_in) {
