@@ -433,7 +433,9 @@ int ug_hip_uyvy_to_jpeg42x_coeffs_batch(int subsampling, const void *src_dev, in
  *        Adobe APP14 transform 0, component ids 'R','G','B', quantiser / Huffman table 0 for every component.
  * `encode` is synchronous on `stream` (it returns the stream length).  ug_hip_jpeg_encoder_max_size() is the capacity that can
  * never overflow (every coefficient at its longest code, every byte stuffed: ~10 B per pixel); a smaller out_capacity is allowed:
- * if the stream does not fit, UG_HIP_EINVAL is returned with *out_len = the size it needs and the buffer contents undefined. */
+ * if the stream does not fit, UG_HIP_EINVAL is returned with *out_len = the size it needs and the buffer contents undefined.
+ * restart_interval: MCUs per restart interval, 1..65535; 0 = none (one entropy-coded segment, no DRI: the scan is coded by ONE wave, milliseconds per
+ * frame -- for readers that cannot take restart markers; what makes this encoder parallel is the restart interval). */
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out);
 /* subsampling = 420, 422 or 444 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */

@@ -257,6 +257,49 @@ def test_gpu_uyvy_coded_444(hip, po, cs, dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sub,dims", [(422, (64, 32)), (420, (640, 368)), (422, (1920, 1080)), (444, (322, 166)), (420, (150, 71))], ids=str)
+def test_gpu_no_restart_intervals(hip, po, sub, dims):
+    """restart_interval 0 (`-c jpeg:restart=0`, gpujpeg.cpp:345): ONE entropy-coded segment, no DRI, no RSTn -- == the test writer's stream without
+    restart intervals; libjpeg, the decode oracle and the product's decoder (one lane for the whole scan) read it; a batch gives the same bytes"""
+    import torch
+    from jpeg_bitstream import write_jpeg
+    from ultragrid_amd import lib as L
+    w, h = dims
+    q = 80
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    dl, dc = po.jpeg_divisors(ql), po.jpeg_divisors(qc)
+    enc = hip.JpegEncoder(w, h, q, 0, subsampling=sub)
+    if sub == 444:
+        rgb = _rgb_picture(w, h)
+        dev, fmt = torch.from_numpy(rgb.ravel()).cuda(), L.PF_RGB
+        want = write_jpeg(w, h, ql, qc, *_coefs444(po, rgb, ql, None, w, h), restart=0, sub=444)
+    else:
+        uyvy = synth.s2_video("UYVY", w, h, salt=2)
+        dev, fmt = torch.from_numpy(uyvy).cuda(), L.PF_UYVY
+        y, u, v = po.uyvy_to_i422(uyvy, w, h) if sub == 422 else po.uyvy_to_i420(uyvy, w, h)
+        mw, mh = (w + 15) // 16, (h + 7) // 8 if sub == 422 else (h + 15) // 16
+        want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, dl, 2 * mw, mh * (1 if sub == 422 else 2)), po.jpeg_fdct_quant_plane(u, dc, mw, mh),
+                          po.jpeg_fdct_quant_plane(v, dc, mw, mh), restart=0, sub=sub)
+    data = enc.encode(dev, fmt)
+    assert data == want and b"\xff\xdd" not in data[:700]
+    if w <= 640:
+        two = enc.encode_batch(torch.stack([dev, dev.flip(0)]), fmt)
+        assert two[0] == data and two[1] != data
+    enc.close()
+    Image.open(io.BytesIO(data)).load()
+    info = hip.jpeg_read_info(data) if hasattr(hip, "jpeg_read_info") else None
+    assert info is None or info["restart"] == 0
+    dec = hip.JpegDecoder()
+    got = dec.decode(data, L.PF_RGB if sub == 444 else L.PF_UYVY).cpu().numpy()
+    dec.close()
+    _, crop, _ = po.jpeg_decode_planes(data)
+    if sub == 444:
+        assert np.array_equal(got.reshape(h, w, 3), np.stack(crop, -1))
+    else:
+        assert np.array_equal(got.reshape(h, w, 2)[..., 1], crop[0])
+
+
+@pytest.mark.gpu
 def test_gpu_create_ex_refusals(hip):
     import ctypes as C
     from ultragrid_amd import lib as L
@@ -265,5 +308,7 @@ def test_gpu_create_ex_refusals(hip):
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 422, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP     # one scan per component: 4:4:4
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 420, L.JPEG_CS_RGB, 0, C.byref(enc)) == L.EUNSUPP             # a 4:2:x stream is Y'CbCr
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 300, 444, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP
+    assert l.ug_hip_jpeg_encoder_create_ex(640, 64, 75, 0, 444, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP     # 640 blocks in one segment of a one-component scan
+    assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, -1, 444, 0, 0, C.byref(enc)) == L.EINVAL
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 7, 0, C.byref(enc)) == L.EINVAL and l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 0, 4, C.byref(enc)) == L.EINVAL
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 422, 0, L.JPEG_INPUT_UYVY, C.byref(enc)) == L.EUNSUPP          # a 4:2:x encoder takes UYVY anyway

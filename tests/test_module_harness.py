@@ -552,6 +552,15 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
         assert r.returncode == 0, cfg + r.stdout + r.stderr
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] == outs[2] == outs[3]
+    out = tmp_path / "nori.jpg"                                                         # restart interval 0 = none (the value goes to GPUJPEG as it is, gpujpeg.cpp:345)
+    r = _run(["jpeg:60:0", "UYVY", w, h, raw, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = out.read_bytes()
+    assert b"\xff\xdd" not in data[:700] and not any(bytes([0xff, 0xd0 + k]) in data[600:] for k in range(8))
+    import io
+    from PIL import Image
+    a, b = (np.asarray(Image.open(io.BytesIO(d)).convert("L")).astype(float) for d in (data, outs[0]))
+    assert np.array_equal(a, b)                                                          # the same coefficients, with and without restart markers
     assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails (R, G, B components are coded 4:4:4 only; `:subsampling=444:RGB` is taken): frame dropped
     r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
     assert r.returncode == 0 and "Requested alpha encode but input codec is unsupported pixel format" in (r.stdout + r.stderr)      # gpujpeg.cpp:327-328

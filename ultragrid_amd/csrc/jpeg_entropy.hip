@@ -1544,7 +1544,7 @@ typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 
 int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restart_interval, int subsampling, int internal_cs, int flags, ug_hip_jpeg_encoder **out)
 {
-        if (!out || width <= 0 || height <= 0 || width > 65535 || height > 65535 || restart_interval < 1 || restart_interval > 65535) {
+        if (!out || width <= 0 || height <= 0 || width > 65535 || height > 65535 || restart_interval < 0 || restart_interval > 65535) {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: bad arguments");
                 return UG_HIP_EINVAL;
         }
@@ -1573,7 +1573,7 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
         e->cs_rgb = e->ycc && !e->in_uyvy ? internal_cs : 0;
         e->cs_uyvy = subsampling != 444 && (internal_cs == UG_JPEG_CS_YCBCR_BT601 || internal_cs == UG_JPEG_CS_YCBCR_BT601_256LVLS) ? internal_cs : 0;
         e->ctab = subsampling == 444 && !e->ycc ? 0 : 1;
-        e->width = width; e->height = height; e->quality = quality; e->ri = restart_interval;
+        e->width = width; e->height = height; e->quality = quality;
         e->force_wave_kernel = getenv("UG_JPEG_WAVE_KERNEL") != nullptr && getenv("UG_JPEG_WAVE_KERNEL")[0] == '1';
         e->allow_fused = !(getenv("UG_JPEG_FUSED") != nullptr && getenv("UG_JPEG_FUSED")[0] == '0');
         e->use_ticket = getenv("UG_JPEG_TICKET") != nullptr && getenv("UG_JPEG_TICKET")[0] == '1';
@@ -1583,6 +1583,20 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
         e->sub = subsampling;
         e->hs = subsampling == 444 ? 1 : 2; e->vs = subsampling == 420 ? 2 : 1; e->ybl = e->hs * e->vs;
         e->mcu_w = (width + 8 * e->hs - 1) / (8 * e->hs); e->mcu_h = (height + 8 * e->vs - 1) / (8 * e->vs); e->n_mcu = e->mcu_w * e->mcu_h;
+        // restart_interval 0 (gpujpeg.cpp:345: the option's value goes to GPUJPEG as it is, and 0 = no restart markers): the scan is ONE segment, no DRI in the
+        // header -- coded by a single wave, block after block (entropy_wave_kernel): milliseconds per frame instead of microseconds; for streams a reader without
+        // restart marker support must take
+        e->ri = restart_interval ? restart_interval : e->n_mcu;
+        if ((long) e->ri * (e->ybl + 2) * kRawBytesPerBlock + 8 > (1L << 30)) {
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create: picture too large for a scan without restart intervals");
+                delete e;
+                return UG_HIP_EUNSUPP;
+        }
+        if (e->nonint && e->ri > 256) { // (restart_interval 0 on a picture of more than 256 blocks)
+                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: restart intervals of a non-interleaved stream: 1..256 blocks");
+                delete e;
+                return UG_HIP_EUNSUPP;
+        }
         e->n_seg = (e->n_mcu + e->ri - 1) / e->ri;
         e->cap = e->ri * (e->ybl + 2) * kRawBytesPerBlock + 8; // unstuffed scan bytes of one segment (worst case 27 bits per coefficient)
         uint8_t ql[64], qc[64];
@@ -1591,9 +1605,9 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
         ug_hip_jpeg_qtable(quality, 1, qc);
         ug_hip_jpeg_divisors(ql, div);
         ug_hip_jpeg_divisors(e->ctab == 0 ? ql : qc, div + 64); // R, G, B: every component is quantised with table 0
-        e->header = build_header(width, height, ql, qc, e->ri, e->sub, e->ycc);
+        e->header = build_header(width, height, ql, qc, restart_interval, e->sub, e->ycc);
         if (e->nonint) {
-                for (int c = 0; c < 3; c++) e->scan_header[c] = build_header(width, height, ql, qc, e->ri, e->sub, e->ycc, c);
+                for (int c = 0; c < 3; c++) e->scan_header[c] = build_header(width, height, ql, qc, restart_interval, e->sub, e->ycc, c);
                 e->header = e->scan_header[0]; // (what max_size and the capacity check count)
         }
         hipError_t err = hipSuccess;

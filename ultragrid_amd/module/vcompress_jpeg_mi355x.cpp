@@ -79,7 +79,7 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y601|:Y601full|:Y709][:alpha][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
+               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval; 0 = none: one wave codes the frame, ms instead of us>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y601|:Y601full|:Y709][:alpha][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
                "\t\tnuma        - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node (pinned frame pool local to the GPU); 0: left to the scheduler\n"
                "\t\tbatch       - frames a busy worker may queue and encode together (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tinterleaved - RGB input as one interleaved scan; default (as the reference's): one scan per component -- three coder launches, a little slower\n"
@@ -167,8 +167,8 @@ void *jpeg_mi355x_compress_init(struct module *parent, const char *fmt)
                 delete s;
                 return nullptr;
         }
-        if (s->quality < 1 || s->quality > 100 || s->restart < 1) {
-                MSG(ERROR, "quality must be 1-100 and restart >= 1\n");
+        if (s->quality < 1 || s->quality > 100 || s->restart < 0 || s->restart > 65535) {
+                MSG(ERROR, "quality must be 1-100 and restart 0-65535\n");
                 delete s;
                 return nullptr;
         }
@@ -251,7 +251,7 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         }
         s->in_len = s->wire == UG_PF_I420 ? (size_t) desc.width * desc.height + 2 * (size_t) ((desc.width + 1) / 2) * ((desc.height + 1) / 2)
                                           : (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
-        if (enc_flags && s->restart > 256) {
+        if ((enc_flags & UG_JPEG_NONINTERLEAVED) && s->restart > 256) {
                 MSG(ERROR, "restart intervals above 256 need `:interleaved` for RGB input\n");
                 return false;
         }
