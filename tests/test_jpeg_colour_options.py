@@ -161,6 +161,41 @@ def test_gpu_rgb_one_scan_per_component(hip, po, dims, ri):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ri", [4, 0, 257, 300, 5000])
+@pytest.mark.parametrize("cs", [0, Y601FULL])
+def test_gpu_one_scan_per_component_long_restart_intervals(hip, po, ri, cs):
+    """restart intervals of more than 256 blocks, and none at all, in a stream of one scan per component: the wave-per-segment coder, scan after scan
+    (the block coder takes segments of up to 256 blocks); bytes == the test writer's; a batch gives the same"""
+    import torch
+    from jpeg_bitstream import write_jpeg_noninterleaved
+    from ultragrid_amd import lib as L
+    w, h, q = 640, 360, 85
+    rgb = _rgb_picture(w, h)
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=444, internal_cs=cs, flags=L.JPEG_NONINTERLEAVED)
+    dev = torch.from_numpy(rgb.ravel()).cuda()
+    data = enc.encode(dev, L.PF_RGB)
+    two = enc.encode_batch(torch.stack([dev.flip(0), dev]), L.PF_RGB)
+    enc.close()
+    comps = po.jpeg_colour_convert("RGB", RGB, cs, rgb, w, h).reshape(h, w, 3) if cs else rgb
+    want = write_jpeg_noninterleaved(w, h, ql, _coefs444(po, comps, ql, qc if cs else None, w, h), restart=ri, qt_chroma=qc if cs else None)
+    assert data == want and two[1] == data and two[0] != data
+    img = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(float)
+    assert 10 * np.log10(255.0 ** 2 / np.mean((img - rgb) ** 2)) > 33
+    # a buffer the stream does not fit is reported with the size it takes, and nothing behind the buffer is written (the guard bytes stay)
+    import ctypes as C
+    l = L.load()
+    h_enc = C.c_void_p()
+    assert l.ug_hip_jpeg_encoder_create_ex(w, h, q, ri, 444, cs, L.JPEG_NONINTERLEAVED, C.byref(h_enc)) == 0
+    for short in (len(data) // 5, len(data) - 3000):
+        buf = torch.full((short + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        n = C.c_size_t(0)
+        assert l.ug_hip_jpeg_encoder_encode(h_enc, L.PF_RGB, dev.data_ptr(), 0, buf.data_ptr(), short, C.byref(n), torch.cuda.current_stream().cuda_stream) == L.EINVAL
+        assert n.value >= short and bool((buf[short:] == 0xA5).all())
+    l.ug_hip_jpeg_encoder_destroy(h_enc)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cs", [Y601, Y601FULL, Y709])
 @pytest.mark.parametrize("nonint", [False, True])
 def test_gpu_rgb_coded_as_ycbcr(hip, po, cs, nonint):
@@ -307,8 +342,6 @@ def test_gpu_create_ex_refusals(hip):
     enc = C.c_void_p()
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 422, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP     # one scan per component: 4:4:4
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 420, L.JPEG_CS_RGB, 0, C.byref(enc)) == L.EUNSUPP             # a 4:2:x stream is Y'CbCr
-    assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 300, 444, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP
-    assert l.ug_hip_jpeg_encoder_create_ex(640, 64, 75, 0, 444, 0, L.JPEG_NONINTERLEAVED, C.byref(enc)) == L.EUNSUPP     # 640 blocks in one segment of a one-component scan
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, -1, 444, 0, 0, C.byref(enc)) == L.EINVAL
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 7, 0, C.byref(enc)) == L.EINVAL and l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 444, 0, 4, C.byref(enc)) == L.EINVAL
     assert l.ug_hip_jpeg_encoder_create_ex(64, 64, 75, 4, 422, 0, L.JPEG_INPUT_UYVY, C.byref(enc)) == L.EUNSUPP          # a 4:2:x encoder takes UYVY anyway

@@ -79,7 +79,9 @@ constexpr int kMaxBatch = 16; // frames per encode_batch call (the pinned length
 
 __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__restrict__ cy, const int16_t *__restrict__ cb,
                                                            const int16_t *__restrict__ cr, int mcu_w, int n_mcu, int hs, int vs /* sampling factors of component 0: 2x2 (4:2:0), 2x1 (4:2:2), 1x1 (4:4:4) */,
-                                                           int ctab /* Huffman table set of components 1,2: 1 = chroma (YCbCr), 0 = same as component 0 (RGB) */, int ri, int n_seg,
+                                                           int ctab /* Huffman table set of components 1,2: 1 = chroma (YCbCr), 0 = same as component 0 (RGB) */,
+                                                           int nc /* components behind component 0 in the MCU: 2, or 0 for one scan of a non-interleaved stream (cy = that component) */,
+                                                           int tab0 /* Huffman table set of component 0 */, int ri, int n_seg,
                                                            uint32_t *__restrict__ raw, int cap_words, uint32_t *__restrict__ seg_len,
                                                            uint32_t *__restrict__ seg_ff /* final size of the segment */,
                                                            uint32_t *__restrict__ chunk_tot /* sums of seg_ff over chunks of kChunk segments */, BatchStride bs)
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         uint32_t carry_word = 0; // partial word, bits left-aligned
         int carry_bits = 0, wbase = 0, ff = 0;
         int pred[3] = { 0, 0, 0 };
-        const int ybl = hs * vs, per_mcu = ybl + 2;
+        const int ybl = hs * vs, per_mcu = ybl + nc;
         const int m0 = seg * ri, n_blk = per_mcu * (min(n_mcu, (seg + 1) * ri) - m0);
         // Walk the blocks of the segment in scan order (per MCU: Y00 Y01 [Y10 Y11] Cb Cr) with incrementally updated
         // wave-uniform indices (one division per segment), always one block ahead: the load of block t+1 is issued before
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void entropy_wave_kernel(const int16_t *__rest
         for (int t = 0; t < n_blk; t++) {
                 {
                         b = b == per_mcu - 1 ? 0 : b + 1;
-                        const int comp = b < ybl ? 0 : ctab, pi = b < ybl ? 0 : b - ybl + 1;
+                        const int comp = b < ybl ? tab0 : ctab, pi = b < ybl ? 0 : b - ybl + 1;
                         int v = v_next;
                         if (t + 1 < n_blk) v_next = next_ptr()[lane];
                         const int dc = __builtin_amdgcn_readfirstlane(v);
@@ -1306,11 +1308,14 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
                                                       const uint32_t *__restrict__ seg_ff, const uint32_t *__restrict__ chunk_tot,
                                                       int n_seg, uint8_t *__restrict__ out,
                                                       const uint8_t *__restrict__ header, int header_len, size_t capacity,
-                                                      uint32_t *__restrict__ total_pinned, BatchStride bs)
+                                                      uint32_t *__restrict__ total_pinned, const uint32_t *__restrict__ base /* see CodeArgs::base */, BatchStride bs)
 {
         raw += blockIdx.y * bs.raw_words * 4; seg_len += blockIdx.y * bs.seg; seg_ff += blockIdx.y * bs.seg;
         chunk_tot += blockIdx.y * bs.tot_words; out += blockIdx.y * bs.out_bytes; total_pinned += blockIdx.y;
-        if (blockIdx.x == 0) { // the first workgroup also lays down SOI .. SOS
+        const uint32_t base0 = base != nullptr ? base[blockIdx.y] - 2u : 0u; // a later scan of a non-interleaved stream goes on over the EOI of the one before
+        out += base0;
+        capacity = capacity > base0 ? capacity - base0 : 0;
+        if (blockIdx.x == 0 && (size_t) header_len <= capacity) { // the first workgroup also lays down SOI .. SOS (a later scan: its SOS)
                 for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
         }
         const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
         for (int i = chunk * kChunk + lane; i < seg; i += 64) before += seg_ff[i];
         const uint32_t off = (uint32_t) header_len + (uint32_t) __builtin_amdgcn_readlane(wave_inclusive_scan((int) before, lane), 63);
         const uint32_t end = off + seg_ff[seg];
-        if (seg == n_seg - 1 && lane == 0) *total_pinned = end; // pinned host memory mapped into the device: the length needs no copy back
+        if (seg == n_seg - 1 && lane == 0) *total_pinned = base0 + end; // pinned host memory mapped into the device: the length needs no copy back
         if ((size_t) end > capacity) return; // would not fit: the host reports the needed size from the total
         const uint8_t *s = raw + (size_t) seg * cap_bytes;
         uint8_t *d = out + off;
@@ -1561,10 +1566,6 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
                                        "UG_JPEG_INPUT_UYVY: 4:4:4)");
                 return UG_HIP_EUNSUPP;
         }
-        if ((flags & UG_JPEG_NONINTERLEAVED) && restart_interval > 256) {
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: restart intervals of a non-interleaved stream: 1..256 blocks");
-                return UG_HIP_EUNSUPP;
-        }
         Encoder *e = new Encoder();
         e->nonint = (flags & UG_JPEG_NONINTERLEAVED) != 0;
         e->in_uyvy = (flags & UG_JPEG_INPUT_UYVY) != 0;
@@ -1589,11 +1590,6 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
         e->ri = restart_interval ? restart_interval : e->n_mcu;
         if ((long) e->ri * (e->ybl + 2) * kRawBytesPerBlock + 8 > (1L << 30)) {
                 ug::set_last_error_msg("ug_hip_jpeg_encoder_create: picture too large for a scan without restart intervals");
-                delete e;
-                return UG_HIP_EUNSUPP;
-        }
-        if (e->nonint && e->ri > 256) { // (restart_interval 0 on a picture of more than 256 blocks)
-                ug::set_last_error_msg("ug_hip_jpeg_encoder_create_ex: restart intervals of a non-interleaved stream: 1..256 blocks");
                 delete e;
                 return UG_HIP_EUNSUPP;
         }
@@ -1693,7 +1689,7 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         int rc = UG_HIP_SUCCESS;
         const int w = e->width, h = e->height;
         const int S_frame = e->ri * (e->ybl + 2); // blocks per (full) restart segment
-        const bool wave_path = !e->nonint && (S_frame > 256 || e->force_wave_kernel);
+        const bool wave_path = (e->nonint ? e->ri : S_frame) > 256 || e->force_wave_kernel; // (a scan of one component: a segment is ri blocks)
         if (!src_pitch && in == UG_PF_UYVY) src_pitch = ug::linesize(UG_PF_UYVY, w);
         // ---- the colour stage (create_ex's internal_cs): the frame(s) converted into a buffer of the encoder's, which then takes the input's place ----
         const int cs_to = in == UG_PF_RGB ? e->cs_rgb : (in == UG_PF_UYVY ? e->cs_uyvy : 0);
@@ -1903,9 +1899,25 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 // reads the length scan c - 1 left behind (CodeArgs::base) and goes on from there, over the EOI every coded stream ends with.  Three
                 // launches on the stream, one synchronisation, no intermediate buffer.
                 memset(e->total_host, 0, 4 * kTotalWords * 4);
+                if (wave_path && frames > e->raw_cap) {
+                        const hipError_t err = alloc_raw(e, e->batch_cap);
+                        if (err != hipSuccess) {
+                                ug::set_last_error(err, "ug_hip_jpeg_encoder_encode: work buffers of the wave-per-segment coder");
+                                free_raw(e);
+                                return UG_HIP_ERUNTIME;
+                        }
+                }
                 for (int c = 0; c < 3; c++) {
                         const ScanPlan pl = { c == 0 ? e->cy : (c == 1 ? e->cb : e->cr), e->ycc && c > 0 ? 1 : 0, e->scan_header_dev[c], (int) e->scan_header[c].size(),
                                               c > 0 ? e->total_host_dev + c * kTotalWords : nullptr, e->total_host_dev + (c + 1) * kTotalWords };
+                        if (wave_path) { // restart intervals of more than 256 blocks (and none at all): a wave per segment, then the compaction -- scan after scan on the stream
+                                UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
+                                hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, pl.coef, pl.coef, pl.coef, e->mcu_w, e->n_mcu, 1, 1,
+                                                   0, 0, pl.tab0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                                hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff,
+                                                   e->chunk_tot, e->n_seg, (uint8_t *) out_dev, pl.header, pl.header_len, out_capacity, pl.total, pl.base, bs);
+                                continue;
+                        }
                         const int lrc = launch_coder(false, &pl);
                         if (lrc != UG_HIP_SUCCESS) return lrc;
                 }
@@ -1952,9 +1964,9 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 // the totals this call's coder adds into start from zero (a smaller batch in between must not leave stale slices behind)
                 UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
-                                   e->ctab, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                                   e->ctab, 2, 0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
                 hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, e->chunk_tot,
-                                   e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, bs);
+                                   e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, nullptr, bs);
         }
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipStreamSynchronize(st)); // ONE synchronisation for the batch

@@ -251,10 +251,6 @@ bool configure_with(state_video_compress_jpeg_mi355x *s, struct video_desc desc)
         }
         s->in_len = s->wire == UG_PF_I420 ? (size_t) desc.width * desc.height + 2 * (size_t) ((desc.width + 1) / 2) * ((desc.height + 1) / 2)
                                           : (size_t) vc_get_linesize(desc.width, desc.color_spec) * desc.height;
-        if ((enc_flags & UG_JPEG_NONINTERLEAVED) && s->restart > 256) {
-                MSG(ERROR, "restart intervals above 256 need `:interleaved` for RGB input\n");
-                return false;
-        }
         if (ug_hip_jpeg_encoder_create_ex((int) desc.width, (int) desc.height, s->quality, s->restart, sub, enc_cs, enc_flags, &s->enc) != UG_HIP_SUCCESS) {
                 MSG(ERROR, "encoder creation failed: %s\n", ug_hip_last_error_string());
                 return false;
