@@ -502,6 +502,7 @@ int    ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in
  *                    UG_PF_I420 (4:2:0 streams: planes back to back);
  *   R,G,B streams (Adobe APP14 transform 0 or component ids 'R','G','B': what `-c jpeg` writes for RGB input) -> UG_PF_RGB / UG_PF_RGBA
  *                    directly, UG_PF_UYVY through vc_copylineRGBtoUYVY's arithmetic.
+ *   one-component (greyscale) streams: a Y'CbCr picture with both chroma planes at 128, every output above (what another sender's grey MJPEG needs).
  * The component planes equal libjpeg's bit for bit (integer IDCT jidctint).  `jpeg_host` is host memory (compressed frames arrive from the
  * network); everything after the header parse is asynchronous on `stream` (a stream in pinned memory is read by the copy engine when the stream
  * gets there: keep it until then; pageable memory is staged before the call returns).  UG_PF_NONE: decode to the internal planes only

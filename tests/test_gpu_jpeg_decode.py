@@ -165,6 +165,29 @@ def test_greyscale_planes_ignore_the_sampling_factors(hip, po):
     assert one.shape == (37, 50) and np.array_equal(one, two) and np.array_equal(one, want)
 
 
+@pytest.mark.parametrize("dims,rst", [((50, 37), 0), ((640, 360), 3), ((1281, 721), 0)], ids=str)
+def test_greyscale_streams_decode_to_every_output(hip, po, dims, rst):
+    """A one-component stream (GPUJPEG_U8, video_decompress/gpujpeg.c:239-241) is a Y'CbCr picture whose chroma sits at its zero: UYVY = the plane with
+    U = V = 128, I420 = the plane + two planes of 128, RGB / RGBA = that UYVY through the reference's conversion."""
+    from ultragrid_amd import lib as L
+    w, h = dims
+    yy, xx = np.mgrid[0:h, 0:w]
+    grey = (128 + 90 * np.sin(xx / 17.0) * np.cos(yy / 11.0) + np.random.default_rng(w).normal(0, 4, (h, w))).clip(0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(grey, "L").save(b, "JPEG", quality=88, **({"restart_marker_blocks": rst} if rst else {}))
+    data = b.getvalue()
+    want = np.asarray(Image.open(io.BytesIO(data)))
+    dec = hip.JpegDecoder()
+    if w % 2 == 0:
+        uyvy = dec.decode(data, L.PF_UYVY).cpu().numpy().reshape(h, w, 2)
+        assert np.array_equal(uyvy[..., 1], want) and (uyvy[..., 0] == 128).all()
+        assert np.array_equal(dec.decode(data, L.PF_RGB).cpu().numpy(), po.convert_frame("UYVY", "RGB", uyvy.ravel(), w, h))
+        assert np.array_equal(dec.decode(data, L.PF_RGBA).cpu().numpy(), po.convert_frame("UYVY", "RGBA", uyvy.ravel(), w, h))
+    i420 = dec.decode(data, L.PF_I420).cpu().numpy()
+    dec.close()
+    assert np.array_equal(i420[:w * h].reshape(h, w), want) and (i420[w * h:] == 128).all() and i420.size == w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)
+
+
 def test_full_4k_frame_and_rejections(hip, po):
     import torch
     from ultragrid_amd import lib as L, synth

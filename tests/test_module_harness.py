@@ -676,6 +676,30 @@ def test_jpeg_internal_colour_space_options(tmp_path, po, codec, opt, cs):
 
 
 @needs_dec_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("out", ["UYVY", "RGB", "RGBA"])
+def test_greyscale_jpeg_through_the_decompress_framework(tmp_path, po, out):
+    """a one-component JPEG (another sender's; GPUJPEG_U8 in gpujpeg.c:239-241) through decompress_init_multi / reconfigure / decompress_frame: the probe
+    answers, the picture is the luma plane with neutral chroma"""
+    import io
+    from PIL import Image
+    w, h = 320, 176
+    yy, xx = np.mgrid[0:h, 0:w]
+    grey = (128 + 100 * np.sin(xx / 23.0) * np.cos(yy / 13.0)).clip(0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(grey, "L").save(b, "JPEG", quality=90, restart_marker_blocks=4)
+    src, dst = tmp_path / "g.jpg", tmp_path / "o.raw"
+    src.write_bytes(b.getvalue())
+    r = subprocess.run([DEC_HARNESS, "JPEG", out, str(w), str(h), str(src), str(dst)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    luma = np.asarray(Image.open(io.BytesIO(b.getvalue())))
+    uyvy = np.empty((h, w, 2), np.uint8)
+    uyvy[..., 0], uyvy[..., 1] = 128, luma
+    want = uyvy.ravel() if out == "UYVY" else po.convert_frame("UYVY", out, uyvy.ravel(), w, h)
+    assert np.array_equal(np.fromfile(dst, np.uint8)[:want.size], want)
+
+
+@needs_dec_harness
 def test_jpeg_decompress_module_registers():
     r = subprocess.run([DEC_HARNESS, "list"], capture_output=True, text=True, timeout=30)
     assert r.returncode == 0 and "jpeg_mi355x" in r.stdout.split()

@@ -963,9 +963,25 @@ int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_
         const int w = h.width, hh = h.height;
         const bool rgb = h.is_rgb();
         if (!dst_pitch) dst_pitch = ug::linesize(out, w);
-        if (h.ncomp != 3) {
-                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: greyscale streams have no output mapping here");
-                return UG_HIP_EUNSUPP;
+        if (h.ncomp == 1) {
+                // greyscale (GPUJPEG_U8, video_decompress/gpujpeg.c:239-241): a Y'CbCr picture whose chroma is nowhere off its zero -- two planes of 128 beside
+                // the decoded one, then the 4:4:4 path (I420: the luma plane and 128s)
+                if (out == UG_PF_I420) {
+                        const int cw = (w + 1) / 2, ch = (hh + 1) / 2;
+                        uint8_t *o = (uint8_t *) dst_dev;
+                        UG_HIP_TRY(hipMemcpy2DAsync(o, w, d->plane[0], d->plane_pitch[0], w, hh, hipMemcpyDeviceToDevice, st));
+                        UG_HIP_TRY(hipMemsetAsync(o + (size_t) w * hh, 128, 2 * (size_t) cw * ch, st));
+                        return UG_HIP_SUCCESS;
+                }
+                const size_t bytes = (size_t) (gw[0] * gh[0]) * 64;
+                for (int c = 1; c < 3; c++) {
+                        if (!grow((void **) &d->plane[c], &d->plane_cap[c], bytes)) {
+                                ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: out of device memory");
+                                return UG_HIP_ERUNTIME;
+                        }
+                        d->plane_pitch[c] = d->plane_pitch[0];
+                        UG_HIP_TRY(hipMemsetAsync(d->plane[c], 128, bytes, st));
+                }
         }
         auto need_tmp = [&](ug_pixfmt_t f) {
                 return grow((void **) &d->tmp, &d->tmp_cap, (size_t) ug::linesize(f, w) * hh + 64);
