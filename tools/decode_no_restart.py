@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""How the JPEG decoder fares on streams WITHOUT restart intervals (another sender's; UltraGrid's own always carry them, gpujpeg.cpp:345-352): the whole scan is one
+segment = one lane.  Pillow-encoded 4:2:0 pictures, decode to UYVY, ms per frame; beside it the same picture with restart intervals.  GPU box."""
+import io
+import sys
+import time
+
+import numpy as np
+import torch
+from PIL import Image
+
+sys.path.insert(0, ".")
+from ultragrid_amd import codec as hip, lib as L
+
+for (w, h) in [(640, 360), (1280, 720), (1920, 1080), (3840, 2160)]:
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    rgb = (rgb + np.random.default_rng(1).normal(0, 6, rgb.shape)).clip(0, 255).astype(np.uint8)
+    for rst in (0, 1):
+        b = io.BytesIO()
+        Image.fromarray(rgb).save(b, "JPEG", quality=75, subsampling=2, **({"restart_marker_rows": 1} if rst else {}))
+        data = b.getvalue()
+        dec = hip.JpegDecoder()
+        dec.decode(data, L.PF_UYVY)
+        torch.cuda.synchronize()
+        n = 5 if not rst else 50
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dec.decode(data, L.PF_UYVY)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        dec.close()
+        print(f"{w}x{h} 4:2:0 q75 {len(data):8d} B  {'one restart interval per MCU row' if rst else 'no restart intervals            '}: {dt * 1e3:9.3f} ms per frame")
