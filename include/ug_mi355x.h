@@ -505,7 +505,8 @@ int    ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in
  *   one-component (greyscale) streams: a Y'CbCr picture with both chroma planes at 128, every output above (what another sender's grey MJPEG needs).
  * The component planes equal libjpeg's bit for bit (integer IDCT jidctint).  `jpeg_host` is host memory (compressed frames arrive from the
  * network); everything after the header parse is asynchronous on `stream` (a stream in pinned memory is read by the copy engine when the stream
- * gets there: keep it until then; pageable memory is staged before the call returns).  UG_PF_NONE: decode to the internal planes only
+ * gets there: keep it until then; pageable memory is staged before the call returns; a scan WITHOUT restart intervals -- one segment, decoded by a lane per 1024
+ * bits of it with the decoder's states handed from piece to piece until they settle -- synchronises with the host between its launches).  UG_PF_NONE: decode to the internal planes only
  * (ug_hip_jpeg_decoder_plane).  Not a baseline stream / unsupported layout (incl. a second frame header, or a table redefined between
  * the scans of a one-scan-per-component stream): UG_HIP_EUNSUPP.  Damage inside the entropy-coded data is not
  * an error: a segment ends at its first marker, a missing one decodes as an empty one (what a sequential decoder does).  A decoder object

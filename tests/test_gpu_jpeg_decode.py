@@ -266,6 +266,72 @@ def test_damaged_streams_decode_like_the_oracle(hip, po, kind):
     dec.close()
 
 
+# ---- scans without restart intervals: the self-synchronising parallel decode (jpeg_decode.hip, pass 2b; taken from 4 KiB of scan data up) ----
+@pytest.mark.parametrize("mode,sub,dims,q,opt", [("RGB", 2, (1920, 1080), 75, False), ("RGB", 1, (1281, 723), 90, True), ("RGB", 0, (640, 360), 95, False), ("L", 0, (1000, 700), 85, True),
+                                                  ("RGB", 2, (3840, 2160), 60, False), ("RGB", 0, (333, 129), 100, False)], ids=str)
+def test_streams_without_restart_intervals(hip, po, mode, sub, dims, q, opt):
+    """another sender's stream (libjpeg: no restart markers, optimised tables or not): one segment, decoded by a lane per 1024 bits -- the planes are the oracle's = libjpeg's"""
+    w, h = dims
+    rgb = picture(w, h, seed=w, noise=6.0)
+    b = io.BytesIO()
+    Image.fromarray(rgb if mode == "RGB" else rgb[..., 1], mode).save(b, "JPEG", quality=q, optimize=opt, **({"subsampling": sub} if mode == "RGB" else {}))
+    data = b.getvalue()
+    assert b"\xff\xdd" not in data[:1200] and len(data) > 8192
+    _, crop, _ = po.jpeg_decode_planes(data)
+    dec = hip.JpegDecoder()
+    for rep in range(2):        # (twice: the second call reuses the work buffers of the first)
+        got = dec.planes(data)
+        assert len(got) == len(crop) and all(np.array_equal(g.cpu().numpy(), c) for g, c in zip(got, crop)), rep
+    dec.close()
+    if mode == "L":
+        assert np.array_equal(crop[0], np.asarray(Image.open(io.BytesIO(data))))
+
+
+@pytest.mark.parametrize("nonint", [False, True])
+def test_own_streams_without_restart_intervals(hip, po, nonint):
+    """`-c jpeg:restart=0` streams, one interleaved scan and one scan per component (three one-segment scans): decoded in parallel, equal to the oracle and to the picture"""
+    import torch
+    from ultragrid_amd import lib as L
+    w, h = 1280, 720
+    rgb = picture(w, h, seed=3, noise=4.0)
+    enc = hip.JpegEncoder(w, h, 85, 0, subsampling=444, flags=L.JPEG_NONINTERLEAVED if nonint else 0)
+    data = enc.encode(torch.from_numpy(rgb.ravel()).cuda(), L.PF_RGB)
+    enc.close()
+    _, crop, _ = po.jpeg_decode_planes(data)
+    dec = hip.JpegDecoder()
+    got = dec.decode(data, L.PF_RGB).cpu().numpy().reshape(h, w, 3)
+    dec.close()
+    assert np.array_equal(got, np.stack(crop, -1))
+    assert 10 * np.log10(255.0 ** 2 / np.mean((got.astype(float) - rgb) ** 2)) > 34
+
+
+@pytest.mark.parametrize("kind", ["cut", "cut_raw", "extra_rst", "marker", "bytes", "tail"])
+def test_damaged_streams_without_restart_intervals(hip, po, kind):
+    """Damage to a one-segment stream: whatever the bits say, the parallel decode is the sequential decoder's chain of states (bit flips resynchronise or not --
+    the fixed point is the same); a stream that ends early goes the sequential way (zero bits to the end of the picture); bytes behind the last block are ignored"""
+    w, h = 640, 360
+    b = io.BytesIO()
+    Image.fromarray(picture(w, h, seed=9, noise=5.0)).save(b, "JPEG", quality=88, subsampling=1)
+    data = b.getvalue()
+    rng = np.random.default_rng(sum(kind.encode()))
+    dec = hip.JpegDecoder()
+    compared = 0
+    for trial in range(40):
+        bad = data[:-2] + bytes(rng.integers(0, 255, int(rng.integers(1, 3000)), dtype=np.uint8).tolist()).replace(b"\xff", b"\xfe") + b"\xff\xd9" if kind == "tail" else _damage(data, rng, kind)
+        try:
+            _, crop, _ = po.jpeg_decode_planes(bad)
+        except Exception:
+            continue
+        got = dec.planes(bad)
+        for c in range(3):
+            assert np.array_equal(got[c].cpu().numpy(), crop[c]), (kind, trial, c)
+        compared += 1
+    assert compared >= (0 if kind == "marker" else 20)      # (a table marker in the data: the oracle refuses most such streams)
+    _, crop, _ = po.jpeg_decode_planes(data)
+    assert all(np.array_equal(pl.cpu().numpy(), crop[c]) for c, pl in enumerate(dec.planes(data)))
+    dec.close()
+
+
 def test_mutated_headers_never_fault(hip, po):
     """Headers damaged at random (tables, frame and scan parameters, restart interval, lengths): every stream is either refused or decoded to
     something, the process survives, and the decoder still decodes a good stream correctly afterwards."""

@@ -5,7 +5,8 @@ usage: python tools/find_decode_mismatch_valid.py [n]"""
 import io, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from PIL import Image
+from PIL import Image, ImageFile
+ImageFile.MAXBLOCK = 1 << 24     # (Pillow's encoder buffer: optimised tables on the larger pictures need more than the default)
 from oracle import pyoracle as po
 from ultragrid_amd import codec as hip, lib as L
 
@@ -15,6 +16,8 @@ found = refused = 0
 for seed in range(n):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+    if seed % 4 == 3:      # round 6: pictures large enough for the parallel decode of scans without restart intervals (from 4 KiB of scan data)
+        w, h = int(rng.integers(100, 900)), int(rng.integers(80, 600))
     yy, xx = np.mgrid[0:h, 0:w]
     base = np.stack([128 + 100 * np.sin(xx / (3 + 40 * rng.random())) * np.cos(yy / (3 + 30 * rng.random())), 128 + 90 * np.cos(xx / 33.0 + yy / (5 + 20 * rng.random())),
                      128 + 80 * np.sin(yy / (2 + 9 * rng.random()))], -1)

@@ -7,6 +7,8 @@
 //   GPU 2  Huffman decoding (F.2.2), one lane per restart segment on an LDS copy of its bytes: 10-bit look-up for the short codes, a
 //          branch-free form of the MAXCODE walk for the long ones; quantised coefficients are collected per block in LDS and written
 //          out 128 bytes at a time;
+//   GPU 2b a scan WITHOUT restart intervals (one segment; other senders' streams): self-synchronising parallel decoding, a lane per 1024 bits of the segment --
+//          1080p 126 ms -> 0.85 ms; see the comment in front of sync_settle_kernel;
 //   GPU 3  dequantisation + inverse DCT, one lane per 8x8 block: libjpeg's jidctint ("slow but accurate integer": Loeffler-Ligtenberg-
 //          Moschytz, 13-bit constants, PASS1_BITS 2) -- integer arithmetic, so the component planes equal libjpeg's bit for bit;
 //   GPU 4  planes -> the output codec with the pixel-format kernels the library already has (planar 4:2:2 / 4:2:0 -> UYVY as
@@ -567,6 +569,285 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void
         else walk(std::true_type());
 }
 
+// ---- pass 2b: a scan WITHOUT restart intervals -- self-synchronising parallel Huffman decoding ---------------------------------------------------------
+// One segment = one lane in the kernel above: 126 ms for a 1080p frame of a third-party sender that writes no restart markers (profiles/r06_decode_no_restart.txt).
+// Huffman-coded data synchronises itself: a decoder started at an arbitrary bit falls into step with the real code boundaries after a few symbols.  So
+// (Klein & Wiseman 2003; Weissenberger & Schmidt 2018 / 2021 for JPEG): cut the segment into chunks of kSyncChunkBits, let one lane per chunk decode from a guessed
+// state, hand every chunk's EXIT state (bit position, block of the unit, zigzag index -- where the sequential decoder would stand) to its right neighbour as that one's
+// start, and decode again whoever's start changed, until nothing changes: a fixed point, and since chunk 0 starts from the true state it is the sequential decoder's own
+// chain of states -- for any data, damaged or not.  Then a prefix sum over the blocks completed per chunk tells every chunk which block it starts in, one more pass
+// writes the coefficients (DC as differences), and a prefix sum per component in scan order turns the differences into DC values.  Bit-identical to the one-lane walk;
+// taken when a scan is ONE segment of at least kSyncMinBytes, and only when the chunks hold the whole picture (a stream that ends early goes the sequential way, whose
+// zero-bit tail it would otherwise have to imitate).
+constexpr int kSyncChunkBits = 1024;
+constexpr int kSyncWG = 256;
+constexpr size_t kSyncMinBytes = 4096;
+constexpr int kSyncMaxUnitBlocks = 12; // blocks of one unit: 3 components of up to 2 x 2 (the layouts the output stage takes have at most 6)
+
+__device__ __forceinline__ unsigned long long sync_pack(uint32_t p, int blk, int z) { return (unsigned long long) p << 16 | (unsigned) blk << 8 | (unsigned) z; }
+
+// what the lanes index by the block they are in: kept in LDS (a lane-varying index into the kernel's arguments would send them through scratch memory)
+struct SyncLds {
+        uint16_t *lut_dc, *lut_ac;
+        LongCodes *longs;
+        int blk_k[kSyncMaxUnitBlocks], blk_by[kSyncMaxUnitBlocks], blk_bx[kSyncMaxUnitBlocks]; // the blocks of a unit in scan order: component of the scan, row, column
+        int blk_dc[kSyncMaxUnitBlocks], blk_ac[kSyncMaxUnitBlocks];                             // their table slots
+        int nbh[3], nbv[3], gw[3];
+        int16_t *coef[3];
+        int per_unit, row_units, n_dc;
+};
+
+// the scan's tables -> LDS (the layout of huff_decode_kernel); s is in LDS too, filled by lane 0
+__device__ void sync_setup(uint8_t *lds, SyncLds *s, const ScanDev &sp, const HuffDev *__restrict__ tabs)
+{
+        const int tid = threadIdx.x;
+        uint16_t *const lut_dc = (uint16_t *) lds, *const lut_ac = lut_dc + sp.n_dc * (1 << kDcLutBits);
+        LongCodes *const longs = (LongCodes *) (lut_ac + sp.n_ac * (1 << kLutBits));
+        for (int j = 0; j < sp.n_dc + sp.n_ac; j++) {
+                const bool dc = j < sp.n_dc;
+                const HuffDev &t = tabs[dc ? sp.dc_tab[j] : 4 + sp.ac_tab[j - sp.n_dc]];
+                uint16_t *dst = dc ? lut_dc + j * (1 << kDcLutBits) : lut_ac + (j - sp.n_dc) * (1 << kLutBits);
+                for (int i = tid; i < (dc ? (1 << kDcLutBits) : (1 << kLutBits)); i += blockDim.x) dst[i] = t.lut[i];
+                LongCodes &lc = longs[j];
+                for (int i = tid; i < 256; i += blockDim.x) lc.vals[i] = t.vals[i];
+                if (tid < 17) {
+                        lc.limit[tid] = t.limit[tid];
+                        lc.offset[tid] = t.offset[tid];
+                }
+        }
+        if (tid == 0) {
+                s->lut_dc = lut_dc; s->lut_ac = lut_ac; s->longs = longs;
+                int n = 0;
+                for (int k = 0; k < sp.ns; k++) {
+                        s->nbh[k] = sp.nbh[k]; s->nbv[k] = sp.nbv[k]; s->gw[k] = sp.gw[k]; s->coef[k] = sp.coef[k];
+                        for (int by = 0; by < sp.nbv[k]; by++) {
+                                for (int bx = 0; bx < sp.nbh[k]; bx++, n++) {
+                                        if (n < kSyncMaxUnitBlocks) {
+                                                s->blk_k[n] = k; s->blk_by[n] = by; s->blk_bx[n] = bx;
+                                                s->blk_dc[n] = sp.dc_slot[k]; s->blk_ac[n] = sp.ac_slot[k];
+                                        }
+                                }
+                        }
+                }
+                s->per_unit = n;
+                s->row_units = sp.single ? sp.bw1 : sp.mcu_w;
+                s->n_dc = sp.n_dc;
+        }
+        __syncthreads();
+}
+
+// The sequential decoder's steps from state (p, blk, z) until p >= stop_bits: p = bit position in the segment, blk = block of the unit, z = 0 in front of a DC
+// symbol, else the zigzag index the next AC symbol starts from.  nb counts the blocks completed.  WRITE: coefficients go to their planes (zigzag order, DC as the
+// difference), blocks from number `first_block` on, those below `total_blocks` only.  The symbol arithmetic is huff_decode_kernel's.
+template <bool WRITE>
+__device__ __forceinline__ void sync_decode(const uint8_t *__restrict__ seg, uint32_t end_bits, uint32_t stop_bits, uint32_t &p, int &blk, int &z, uint32_t &nb, const SyncLds &s,
+                                            uint32_t first_block, uint32_t total_blocks)
+{
+        const uint32_t *const words = (const uint32_t *) seg;
+        uint32_t n = first_block;    // number of the block in work (WRITE)
+        int16_t *dst = nullptr;      // its 64 coefficients, nullptr: not kept
+        auto place = [&]() {
+                if (!WRITE) return;
+                dst = nullptr;
+                if (n >= total_blocks) return;
+                const uint32_t u = n / (uint32_t) s.per_unit;
+                const int k = s.blk_k[blk];
+                const uint32_t uy = u / (uint32_t) s.row_units, ux = u - uy * (uint32_t) s.row_units;
+                dst = s.coef[k] + ((size_t) (uy * s.nbv[k] + s.blk_by[blk]) * s.gw[k] + ux * s.nbh[k] + s.blk_bx[blk]) * 64;
+        };
+        place();
+        while (p < stop_bits) {
+                // 32 bits from bit p on, zero bits behind the end of the segment
+                const uint32_t w0 = __builtin_bswap32(words[p >> 5]), w1 = __builtin_bswap32(words[(p >> 5) + 1]);
+                uint32_t hi = (uint32_t) ((((unsigned long long) w0 << 32 | w1) << (p & 31)) >> 32);
+                const uint32_t left = end_bits - p;
+                if (left < 32) hi &= ~0u << (32 - left);
+                const bool dc = z == 0;
+                const uint16_t *lut = dc ? s.lut_dc + s.blk_dc[blk] * (1 << kDcLutBits) : s.lut_ac + s.blk_ac[blk] * (1 << kLutBits);
+                const LongCodes &lc = s.longs[dc ? s.blk_dc[blk] : s.n_dc + s.blk_ac[blk]];
+                const int bits = dc ? kDcLutBits : kLutBits;
+                const unsigned e = lut[hi >> (32 - bits)];
+                int l = (int) (e >> 8), sym = (int) (e & 0xff);
+                if (e == 0) {
+                        const unsigned pk = hi >> 16;
+                        l = bits + 1;
+                        for (int i = bits + 1; i <= 16; i++) l += pk >= lc.limit[i];
+                        if (l > 16) {
+                                l = 17;
+                                sym = 0;
+                        } else {
+                                sym = lc.vals[(int) (pk >> (16 - l)) + lc.offset[l] & 0xff];
+                        }
+                }
+                const int sz = sym & 15;
+                const int v = (int) (((hi << l) >> 1) >> (31 - sz));
+                const int value = v < ((1 << sz) >> 1) ? v + 1 - (1 << sz) : v;
+                p += (uint32_t) (l + sz);
+                if (dc) {
+                        if (WRITE && dst) dst[0] = (int16_t) value;
+                        z = 1;
+                } else if (sz == 0 && sym != 0xF0) {
+                        z = 64; // EOB
+                } else {
+                        z += sym >> 4;
+                        if (WRITE && dst && sz && z < 64) dst[z] = (int16_t) value;
+                        z++;
+                }
+                if (z >= 64) {
+                        z = 0;
+                        nb++;
+                        blk = blk + 1 == s.per_unit ? 0 : blk + 1;
+                        n++;
+                        place();
+                }
+        }
+}
+
+struct SyncBuffers {
+        unsigned long long *start, *exit; // per chunk: the state it was last decoded from, the state it left in
+        uint32_t *nblk, *base;            // blocks completed in the chunk; blocks completed in front of it
+        unsigned long long *wg_last;      // per workgroup: the exit state of its last chunk
+        uint32_t *host;                   // mapped host memory: [0] a workgroup's last exit state changed, [1] blocks in all chunks, [2] chunks the segment has
+};
+
+// first = true: every chunk decodes from the guess "a block starts at my first bit" and the workgroup settles its 256 chunks among themselves (the workgroup's first
+// chunk keeps its guess, except chunk 0, whose state is the true one).  first = false: the workgroup's first chunk takes the exit state of the workgroup in front;
+// if that is news, the workgroup settles again.  Run until no workgroup's last exit state changes (the host reads host[0]).
+__global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
+                                                             const int *__restrict__ found, ScanDev sp, const HuffDev *__restrict__ tabs, SyncBuffers b, int first)
+{
+        extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+        __shared__ SyncLds s;
+        __shared__ unsigned long long s_exit[kSyncWG];
+        sync_setup(lds, &s, sp, tabs);
+        const int tid = threadIdx.x;
+        const uint32_t t = blockIdx.x * kSyncWG + tid;
+        const uint32_t end_bits = found[0] >= 1 ? 8u * (seg_end[0] - seg_start[0]) : 0u;
+        const uint8_t *const seg = clean + seg_start[0];
+        const uint32_t stop = min((t + 1) * (uint32_t) kSyncChunkBits, end_bits);
+        const bool live = (unsigned long long) t * kSyncChunkBits < end_bits; // (the launch covers an upper bound of the segment's length: chunks behind its end hold nothing and take no part)
+        unsigned long long st, ex = 0;
+        uint32_t nb = 0;
+        bool redo;
+        if (first) {
+                st = ex = sync_pack(t * (uint32_t) kSyncChunkBits, 0, 0);
+                redo = live;
+        } else {
+                st = b.start[t]; ex = b.exit[t]; nb = b.nblk[t];
+                redo = false;
+                if (tid == 0 && blockIdx.x > 0 && live) {
+                        const unsigned long long in = __atomic_load_n(b.wg_last + blockIdx.x - 1, __ATOMIC_RELAXED);
+                        redo = in != st;
+                        st = in;
+                }
+                if (!__syncthreads_or(redo)) return; // (uniform) the workgroup in front left where this one started from: nothing changes here
+        }
+        const unsigned long long last_before = first ? ~0ull : b.wg_last[blockIdx.x];
+        for (int it = 0; it <= kSyncWG; it++) {
+                if (redo) {
+                        uint32_t p = (uint32_t) (st >> 16);
+                        int blk = (int) (st >> 8 & 0xff), z = (int) (st & 0xff);
+                        nb = 0;
+                        sync_decode<false>(seg, end_bits, stop, p, blk, z, nb, s, 0, 0);
+                        ex = sync_pack(p, blk, z);
+                }
+                s_exit[tid] = ex;
+                __syncthreads();
+                const unsigned long long in = tid == 0 || !live ? st : s_exit[tid - 1];
+                redo = in != st;
+                st = in;
+                if (!__syncthreads_or(redo)) break;
+        }
+        b.start[t] = st; b.exit[t] = ex; b.nblk[t] = nb;
+        if (tid == kSyncWG - 1 && ex != last_before) {
+                __atomic_store_n(b.wg_last + blockIdx.x, ex, __ATOMIC_RELAXED);
+                if (!first) b.host[0] = 1;
+        }
+}
+
+// blocks completed in front of every chunk (one workgroup, the chunks in strides of 1024)
+__global__ __launch_bounds__(1024) void sync_prefix_kernel(SyncBuffers b, int n_chunks, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, const int *__restrict__ found)
+{
+        __shared__ uint32_t wave_tot[16];
+        __shared__ uint32_t carry_s;
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n_chunks; i0 += 1024) {
+                const int i = i0 + tid;
+                const uint32_t v = i < n_chunks ? b.nblk[i] : 0;
+                uint32_t incl = v;
+                for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += o;
+                }
+                if (lane == 63) wave_tot[wv] = incl;
+                __syncthreads();
+                uint32_t before = carry_s;
+                for (int j = 0; j < wv; j++) before += wave_tot[j];
+                if (i < n_chunks) b.base[i] = before + incl - v;
+                __syncthreads();
+                if (tid == 1023) carry_s = before + incl;
+                __syncthreads();
+        }
+        if (tid == 0) {
+                b.host[1] = carry_s;
+                b.host[2] = found[0] >= 1 ? (8u * (seg_end[0] - seg_start[0]) + kSyncChunkBits - 1) / kSyncChunkBits : 0u;
+        }
+}
+
+// every chunk once more, from its settled state, coefficients written
+__global__ __launch_bounds__(kSyncWG) void sync_write_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
+                                                            const int *__restrict__ found, ScanDev sp, const HuffDev *__restrict__ tabs, SyncBuffers b, uint32_t total_blocks)
+{
+        extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+        __shared__ SyncLds s;
+        sync_setup(lds, &s, sp, tabs);
+        const uint32_t t = blockIdx.x * kSyncWG + threadIdx.x;
+        const uint32_t end_bits = found[0] >= 1 ? 8u * (seg_end[0] - seg_start[0]) : 0u;
+        const uint32_t stop = min((t + 1) * (uint32_t) kSyncChunkBits, end_bits);
+        const unsigned long long st = b.start[t];
+        uint32_t p = (uint32_t) (st >> 16), nb = 0;
+        int blk = (int) (st >> 8 & 0xff), z = (int) (st & 0xff);
+        sync_decode<true>(clean + seg_start[0], end_bits, stop, p, blk, z, nb, s, b.base[t], total_blocks);
+}
+
+// DC differences -> DC values: a running sum per component over its blocks in scan order (unit after unit, the blocks of a unit row by row); blockIdx.x = component of the scan
+__global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp)
+{
+        __shared__ int wave_tot[16];
+        __shared__ int carry_s;
+        const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int per = sp.nbh[k] * sp.nbv[k], row_units = sp.single ? sp.bw1 : sp.mcu_w;
+        const long total = (long) sp.units * per;
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        for (long i0 = 0; i0 < total; i0 += 1024) {
+                const long i = i0 + tid;
+                int16_t *at = nullptr;
+                if (i < total) {
+                        const int u = (int) (i / per), j = (int) (i - (long) u * per);
+                        const int by = j / sp.nbh[k], bx = j - by * sp.nbh[k];
+                        const int uy = u / row_units, ux = u - uy * row_units;
+                        at = sp.coef[k] + ((size_t) (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64;
+                }
+                const int v = at ? (int) *at : 0;
+                int incl = v;
+                for (int d = 1; d < 64; d <<= 1) {
+                        const int o = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += o;
+                }
+                if (lane == 63) wave_tot[wv] = incl;
+                __syncthreads();
+                int before = carry_s;
+                for (int j = 0; j < wv; j++) before += wave_tot[j];
+                if (at) *at = (int16_t) (before + incl);
+                __syncthreads();
+                if (tid == 1023) carry_s = before + incl;
+                __syncthreads();
+        }
+}
+
 // jidctint.c; see oracle/jpeg_decode_oracle.c
 #define CONST_BITS 13
 #define PASS1_BITS 2
@@ -696,6 +977,11 @@ struct Decoder {
         size_t coef_cap[3] = { 0, 0, 0 }, plane_cap[3] = { 0, 0, 0 };
         uint8_t *tmp = nullptr;      // intermediate packed frame (UYVY or RGB) when the output needs a second conversion
         size_t tmp_cap = 0;
+        // scans without restart intervals (pass 2b): per-chunk states and counts, the mapped words the host reads between the launches
+        unsigned long long *sync_start = nullptr, *sync_exit = nullptr, *sync_wg_last = nullptr;
+        uint32_t *sync_nblk = nullptr, *sync_base = nullptr;
+        size_t sync_start_cap = 0, sync_exit_cap = 0, sync_wg_cap = 0, sync_nblk_cap = 0, sync_base_cap = 0;
+        uint32_t *sync_host = nullptr, *sync_host_dev = nullptr;
         // pinned staging for the tables; they are uploaded when they differ from the last frame's
         void *pinned = nullptr;
         HuffHost dc_now[4], ac_now[4];
@@ -748,9 +1034,11 @@ void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec)
         Decoder *d = (Decoder *) dec;
         if (!d) return;
         for (void *p : { (void *) d->stream, (void *) d->clean, (void *) d->seg_start, (void *) d->seg_end, (void *) d->scan_counts, (void *) d->tabs, (void *) d->qt, (void *) d->coef[0], (void *) d->coef[1], (void *) d->coef[2],
-                         (void *) d->plane[0], (void *) d->plane[1], (void *) d->plane[2], (void *) d->tmp }) {
+                         (void *) d->plane[0], (void *) d->plane[1], (void *) d->plane[2], (void *) d->tmp, (void *) d->sync_start, (void *) d->sync_exit, (void *) d->sync_wg_last,
+                         (void *) d->sync_nblk, (void *) d->sync_base }) {
                 if (p) (void) hipFree(p);
         }
+        if (d->sync_host) (void) hipHostFree(d->sync_host);
         if (d->pinned) (void) hipHostFree(d->pinned);
         if (d->uploaded) (void) hipEventDestroy(d->uploaded);
         delete d;
@@ -939,8 +1227,55 @@ int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_
                 static const int forced_lanes = getenv("UG_JPEG_DEC_LANES") ? atoi(getenv("UG_JPEG_DEC_LANES")) : 0;
                 if (forced_lanes >= 1 && forced_lanes <= 64) lanes = forced_lanes;
                 const size_t stage = stage_for(lanes);
-                hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + lanes - 1) / lanes)), dim3(64), lds_for(lanes), st, d->clean, d->seg_start, d->seg_end, n_seg,
-                                   d->scan_counts, lanes, (int) stage, sp, d->tabs);
+                auto one_lane_per_segment = [&]() {
+                        hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + lanes - 1) / lanes)), dim3(64), lds_for(lanes), st, d->clean, d->seg_start, d->seg_end, n_seg,
+                                           d->scan_counts, lanes, (int) stage, sp, d->tabs);
+                };
+                // ---- a scan that is ONE long segment (no restart intervals): self-synchronising parallel decoding (pass 2b) -- synchronises with the host between its launches ----
+                static const bool sync_off = getenv("UG_JPEG_DEC_SYNC") != nullptr && getenv("UG_JPEG_DEC_SYNC")[0] == '0';
+                int per_unit = 0;
+                for (int k = 0; k < sp.ns; k++) per_unit += sp.nbh[k] * sp.nbv[k];
+                const size_t scan_bytes = sc.data_end - sc.data_begin;
+                if (n_seg != 1 || scan_bytes < kSyncMinBytes || scan_bytes >= ((size_t) 1 << 28) || per_unit > kSyncMaxUnitBlocks || (long) sp.units * per_unit >= (1L << 31) || sync_off) {
+                        one_lane_per_segment();
+                        continue;
+                }
+                const int n_chunks = (int) ((scan_bytes * 8 + kSyncChunkBits - 1) / kSyncChunkBits); // (an upper bound: the clean stream is no longer than the scan)
+                const int n_wg = (n_chunks + kSyncWG - 1) / kSyncWG;
+                const size_t padded = (size_t) n_wg * kSyncWG;
+                if (!d->sync_host) {
+                        UG_HIP_TRY(hipHostMalloc((void **) &d->sync_host, 64, hipHostMallocMapped));
+                        UG_HIP_TRY(hipHostGetDevicePointer((void **) &d->sync_host_dev, d->sync_host, 0));
+                }
+                if (!grow((void **) &d->sync_start, &d->sync_start_cap, padded * 8) || !grow((void **) &d->sync_exit, &d->sync_exit_cap, padded * 8) ||
+                    !grow((void **) &d->sync_nblk, &d->sync_nblk_cap, padded * 4) || !grow((void **) &d->sync_base, &d->sync_base_cap, padded * 4) ||
+                    !grow((void **) &d->sync_wg_last, &d->sync_wg_cap, (size_t) n_wg * 8)) {
+                        ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: out of device memory");
+                        return UG_HIP_ERUNTIME;
+                }
+                const SyncBuffers sb = { d->sync_start, d->sync_exit, d->sync_nblk, d->sync_base, d->sync_wg_last, d->sync_host_dev };
+                const size_t sync_lds = (size_t) lds_tile_offset(sp.n_dc, sp.n_ac);
+                hipLaunchKernelGGL(sync_settle_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, d->scan_counts, sp, d->tabs, sb, 1);
+                bool settled = n_wg == 1;
+                for (int round = 0; round < n_wg + 1 && !settled; round++) { // (a change travels at least one workgroup per round: n_wg rounds at the very worst; usually one or two)
+                        UG_HIP_TRY(hipStreamSynchronize(st)); // the earlier launch is through: the flag may be cleared
+                        d->sync_host[0] = 0;
+                        hipLaunchKernelGGL(sync_settle_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, d->scan_counts, sp, d->tabs, sb, 0);
+                        UG_HIP_TRY(hipStreamSynchronize(st));
+                        settled = d->sync_host[0] == 0;
+                }
+                hipLaunchKernelGGL(sync_prefix_kernel, dim3(1), dim3(1024), 0, st, sb, n_chunks, d->seg_start, d->seg_end, d->scan_counts);
+                UG_HIP_TRY(hipStreamSynchronize(st));
+                const uint32_t total_blocks = (uint32_t) ((long) sp.units * per_unit);
+                if (!settled || d->sync_host[1] < total_blocks) { // the data ends before the picture does (or the states never settled): the sequential walk, zero-bit tail and all
+                        one_lane_per_segment();
+                        continue;
+                }
+                if (gpu_scan) { // (the other scans' planes were cleared above) the write pass stores the coefficients that are there, not the zeros between them
+                        for (int k = 0; k < sc.ns; k++) UG_HIP_TRY(hipMemsetAsync(sp.coef[k], 0, (size_t) (gw[sc.comp[k]] * gh[sc.comp[k]]) * 128, st));
+                }
+                hipLaunchKernelGGL(sync_write_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, d->scan_counts, sp, d->tabs, sb, total_blocks);
+                hipLaunchKernelGGL(sync_dc_kernel, dim3((unsigned) sc.ns), dim3(1024), 0, st, sp);
         }
         // ---- dequantisation + IDCT ----
         {
