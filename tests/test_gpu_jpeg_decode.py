@@ -267,16 +267,19 @@ def test_damaged_streams_decode_like_the_oracle(hip, po, kind):
 
 
 # ---- scans without restart intervals: the self-synchronising parallel decode (jpeg_decode.hip, pass 2b; taken from 4 KiB of scan data up) ----
+@pytest.mark.parametrize("rows", [0, 1, 9])
 @pytest.mark.parametrize("mode,sub,dims,q,opt", [("RGB", 2, (1920, 1080), 75, False), ("RGB", 1, (1281, 723), 90, True), ("RGB", 0, (640, 360), 95, False), ("L", 0, (1000, 700), 85, True),
                                                   ("RGB", 2, (3840, 2160), 60, False), ("RGB", 0, (333, 129), 100, False)], ids=str)
-def test_streams_without_restart_intervals(hip, po, mode, sub, dims, q, opt):
-    """another sender's stream (libjpeg: no restart markers, optimised tables or not): one segment, decoded by a lane per 1024 bits -- the planes are the oracle's = libjpeg's"""
+def test_streams_without_restart_intervals(hip, po, mode, sub, dims, q, opt, rows):
+    """another sender's stream (libjpeg: no restart markers -- or one per MCU row, or per 9 rows, as FFmpeg's slice threads write them; optimised tables or not): long
+    segments, decoded by a lane per 1024 bits -- the planes are the oracle's = libjpeg's"""
     w, h = dims
     rgb = picture(w, h, seed=w, noise=6.0)
     b = io.BytesIO()
-    Image.fromarray(rgb if mode == "RGB" else rgb[..., 1], mode).save(b, "JPEG", quality=q, optimize=opt, **({"subsampling": sub} if mode == "RGB" else {}))
+    Image.fromarray(rgb if mode == "RGB" else rgb[..., 1], mode).save(b, "JPEG", quality=q, optimize=opt, **({"subsampling": sub} if mode == "RGB" else {}),
+                                                                      **({"restart_marker_rows": rows} if rows else {}))
     data = b.getvalue()
-    assert b"\xff\xdd" not in data[:1200] and len(data) > 8192
+    assert (b"\xff\xdd" in data[:1200]) == bool(rows) and len(data) > 8192
     _, crop, _ = po.jpeg_decode_planes(data)
     dec = hip.JpegDecoder()
     for rep in range(2):        # (twice: the second call reuses the work buffers of the first)
@@ -305,13 +308,14 @@ def test_own_streams_without_restart_intervals(hip, po, nonint):
     assert 10 * np.log10(255.0 ** 2 / np.mean((got.astype(float) - rgb) ** 2)) > 34
 
 
-@pytest.mark.parametrize("kind", ["cut", "cut_raw", "extra_rst", "marker", "bytes", "tail"])
-def test_damaged_streams_without_restart_intervals(hip, po, kind):
-    """Damage to a one-segment stream: whatever the bits say, the parallel decode is the sequential decoder's chain of states (bit flips resynchronise or not --
-    the fixed point is the same); a stream that ends early goes the sequential way (zero bits to the end of the picture); bytes behind the last block are ignored"""
+@pytest.mark.parametrize("kind,rows", [(k, r) for r in (0, 6) for k in ("cut", "cut_raw", "drop_rst", "extra_rst", "marker", "bytes", "tail") if r or k != "drop_rst"])
+def test_damaged_streams_without_restart_intervals(hip, po, kind, rows):
+    """Damage to a stream of one segment (rows = 0) or of a few long ones (a restart interval per 6 MCU rows: FFmpeg's slices): whatever the bits say, the parallel
+    decode is the sequential decoder's chain of states (bit flips resynchronise or not -- the fixed point is the same); data that ends early, a missing or an extra
+    marker send the scan the sequential way (zero bits to the end of the segment); bytes behind the last block are ignored"""
     w, h = 640, 360
     b = io.BytesIO()
-    Image.fromarray(picture(w, h, seed=9, noise=5.0)).save(b, "JPEG", quality=88, subsampling=1)
+    Image.fromarray(picture(w, h, seed=9, noise=5.0)).save(b, "JPEG", quality=88, subsampling=1, **({"restart_marker_rows": rows} if rows else {}))
     data = b.getvalue()
     rng = np.random.default_rng(sum(kind.encode()))
     dec = hip.JpegDecoder()

@@ -31,3 +31,22 @@ for (w, h) in [(640, 360), (1280, 720), (1920, 1080), (3840, 2160)]:
         dt = (time.perf_counter() - t0) / n
         dec.close()
         print(f"{w}x{h} 4:2:0 q75 {len(data):8d} B  {'one restart interval per MCU row' if rst else 'no restart intervals            '}: {dt * 1e3:9.3f} ms per frame")
+
+# few, long segments: FFmpeg's slice-threaded MJPEG writes one restart interval per slice (8 here), libjpeg users often one per MCU row
+for (w, h) in [(1920, 1080), (3840, 2160)]:
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    rgb = (rgb + np.random.default_rng(1).normal(0, 6, rgb.shape)).clip(0, 255).astype(np.uint8)
+    rows = (h + 15) // 16
+    b = io.BytesIO()
+    Image.fromarray(rgb).save(b, "JPEG", quality=75, subsampling=2, restart_marker_rows=(rows + 7) // 8)
+    data = b.getvalue()
+    dec = hip.JpegDecoder()
+    dec.decode(data, L.PF_UYVY)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dec.decode(data, L.PF_UYVY)
+    torch.cuda.synchronize()
+    dec.close()
+    print(f"{w}x{h} 4:2:0 q75 {len(data):8d} B  eight restart intervals per frame  : {(time.perf_counter() - t0) / 20 * 1e3:9.3f} ms per frame")

@@ -16,12 +16,13 @@ data = _own_stream(hip, po.convert_frame("RGB", "UYVY", rgb, w, h), L.PF_UYVY, w
 # round 6: every third draw damages a stream WITHOUT restart intervals (one segment: the self-synchronising parallel decode, or the sequential walk where the data ends early)
 w2, h2 = 400, 240
 data_nori = _own_stream(hip, po.convert_frame("RGB", "UYVY", picture(w2, h2, seed=12, noise=5.0), w2, h2), L.PF_UYVY, w2, h2, 90, 0, 420)
+data_few = _own_stream(hip, po.convert_frame("RGB", "UYVY", picture(w2, h2, seed=13, noise=5.0), w2, h2), L.PF_UYVY, w2, h2, 90, 100, 420)   # ... and one of four long segments (FFmpeg's slices)
 dec = hip.JpegDecoder()
 found = 0
 KINDS = ["bytes", "cut", "cut_raw", "drop_rst", "extra_rst", "marker"]
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12000):
     rng = np.random.default_rng(seed)
-    bad = _damage(data_nori if (seed // 6) % 3 == 2 else data, rng, KINDS[seed % len(KINDS)])
+    bad = _damage((data_nori if (seed // 6) % 3 == 2 else (data_few if (seed // 6) % 3 == 1 else data)), rng, KINDS[seed % len(KINDS)])
     if seed % 7 == 0:                      # and two kinds of damage at once
         bad = _damage(bad, rng, "bytes")
     try:

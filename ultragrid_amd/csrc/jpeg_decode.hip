@@ -7,8 +7,8 @@
 //   GPU 2  Huffman decoding (F.2.2), one lane per restart segment on an LDS copy of its bytes: 10-bit look-up for the short codes, a
 //          branch-free form of the MAXCODE walk for the long ones; quantised coefficients are collected per block in LDS and written
 //          out 128 bytes at a time;
-//   GPU 2b a scan WITHOUT restart intervals (one segment; other senders' streams): self-synchronising parallel decoding, a lane per 1024 bits of the segment --
-//          1080p 126 ms -> 0.85 ms; see the comment in front of sync_settle_kernel;
+//   GPU 2b scans of LONG segments (other senders' streams: no restart intervals, or a few per frame): self-synchronising parallel decoding, a lane per 1024 bits
+//          of a segment -- 1080p without restart intervals 126 ms -> 0.85 ms; see the comment in front of sync_setup;
 //   GPU 3  dequantisation + inverse DCT, one lane per 8x8 block: libjpeg's jidctint ("slow but accurate integer": Loeffler-Ligtenberg-
 //          Moschytz, 13-bit constants, PASS1_BITS 2) -- integer arithmetic, so the component planes equal libjpeg's bit for bit;
 //   GPU 4  planes -> the output codec with the pixel-format kernels the library already has (planar 4:2:2 / 4:2:0 -> UYVY as
@@ -569,19 +569,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void
         else walk(std::true_type());
 }
 
-// ---- pass 2b: a scan WITHOUT restart intervals -- self-synchronising parallel Huffman decoding ---------------------------------------------------------
-// One segment = one lane in the kernel above: 126 ms for a 1080p frame of a third-party sender that writes no restart markers (profiles/r06_decode_no_restart.txt).
-// Huffman-coded data synchronises itself: a decoder started at an arbitrary bit falls into step with the real code boundaries after a few symbols.  So
-// (Klein & Wiseman 2003; Weissenberger & Schmidt 2018 / 2021 for JPEG): cut the segment into chunks of kSyncChunkBits, let one lane per chunk decode from a guessed
-// state, hand every chunk's EXIT state (bit position, block of the unit, zigzag index -- where the sequential decoder would stand) to its right neighbour as that one's
-// start, and decode again whoever's start changed, until nothing changes: a fixed point, and since chunk 0 starts from the true state it is the sequential decoder's own
-// chain of states -- for any data, damaged or not.  Then a prefix sum over the blocks completed per chunk tells every chunk which block it starts in, one more pass
-// writes the coefficients (DC as differences), and a prefix sum per component in scan order turns the differences into DC values.  Bit-identical to the one-lane walk;
-// taken when a scan is ONE segment of at least kSyncMinBytes, and only when the chunks hold the whole picture (a stream that ends early goes the sequential way, whose
-// zero-bit tail it would otherwise have to imitate).
+// ---- pass 2b: scans with LONG segments (no restart intervals, or few of them) -- self-synchronising parallel Huffman decoding ------------------------------------
+// One segment = one lane in the kernel above: 126 ms for a 1080p frame of a sender that writes no restart markers (libjpeg's default), 16 ms with FFmpeg's eight
+// slices (profiles/r06_decode_no_restart.txt).  Huffman-coded data synchronises itself: a decoder started at an arbitrary bit falls into step with the real code
+// boundaries after a few symbols.  So (Klein & Wiseman 2003; Weissenberger & Schmidt 2018 / 2021 for JPEG): cut every segment into chunks of kSyncChunkBits, let one
+// lane per chunk decode from a guessed state, hand every chunk's EXIT state (bit position, block of the unit, zigzag index -- where the sequential decoder would stand)
+// to its right neighbour as that one's start, and decode again whoever's start changed, until nothing changes: a fixed point, and since the first chunk of every
+// segment starts from the true state it is the sequential decoder's own chain of states -- for any data, damaged or not.  Then a prefix sum over the blocks completed per
+// chunk tells every chunk which block it starts in, one more pass writes the coefficients (DC as differences), and a running sum per component in scan order, started
+// anew at every restart interval, turns the differences into DC values.  Bit-identical to the one-lane walk; taken when the segments of a scan average at least
+// kSyncMinSegBytes, and only when every segment holds all its blocks (data that ends early goes the sequential way, whose zero-bit tail it would otherwise have to imitate).
 constexpr int kSyncChunkBits = 1024;
 constexpr int kSyncWG = 256;
-constexpr size_t kSyncMinBytes = 4096;
+constexpr size_t kSyncMinBytes = 4096, kSyncMinSegBytes = 2048;
 constexpr int kSyncMaxUnitBlocks = 12; // blocks of one unit: 3 components of up to 2 x 2 (the layouts the output stage takes have at most 6)
 
 __device__ __forceinline__ unsigned long long sync_pack(uint32_t p, int blk, int z) { return (unsigned long long) p << 16 | (unsigned) blk << 8 | (unsigned) z; }
@@ -636,20 +636,21 @@ __device__ void sync_setup(uint8_t *lds, SyncLds *s, const ScanDev &sp, const Hu
         __syncthreads();
 }
 
-// The sequential decoder's steps from state (p, blk, z) until p >= stop_bits: p = bit position in the segment, blk = block of the unit, z = 0 in front of a DC
-// symbol, else the zigzag index the next AC symbol starts from.  nb counts the blocks completed.  WRITE: coefficients go to their planes (zigzag order, DC as the
-// difference), blocks from number `first_block` on, those below `total_blocks` only.  The symbol arithmetic is huff_decode_kernel's.
+// The sequential decoder's steps from state (p, blk, z) until p >= stop_bits: p = bit position in the clean stream, blk = block of the unit, z = 0 in front of a DC
+// symbol, else the zigzag index the next AC symbol starts from; bits from end_bits on (the end of the segment) read as zero.  nb counts the blocks completed.  WRITE:
+// coefficients go to their planes (zigzag order, DC as the difference), blocks from number `first_block` on, those below `limit` only.  The symbol arithmetic is
+// huff_decode_kernel's.
 template <bool WRITE>
-__device__ __forceinline__ void sync_decode(const uint8_t *__restrict__ seg, uint32_t end_bits, uint32_t stop_bits, uint32_t &p, int &blk, int &z, uint32_t &nb, const SyncLds &s,
-                                            uint32_t first_block, uint32_t total_blocks)
+__device__ __forceinline__ void sync_decode(const uint8_t *__restrict__ clean, uint32_t end_bits, uint32_t stop_bits, uint32_t &p, int &blk, int &z, uint32_t &nb, const SyncLds &s,
+                                            uint32_t first_block, uint32_t limit)
 {
-        const uint32_t *const words = (const uint32_t *) seg;
+        const uint32_t *const words = (const uint32_t *) clean;
         uint32_t n = first_block;    // number of the block in work (WRITE)
         int16_t *dst = nullptr;      // its 64 coefficients, nullptr: not kept
         auto place = [&]() {
                 if (!WRITE) return;
                 dst = nullptr;
-                if (n >= total_blocks) return;
+                if (n >= limit) return;
                 const uint32_t u = n / (uint32_t) s.per_unit;
                 const int k = s.blk_k[blk];
                 const uint32_t uy = u / (uint32_t) s.row_units, ux = u - uy * (uint32_t) s.row_units;
@@ -705,16 +706,72 @@ __device__ __forceinline__ void sync_decode(const uint8_t *__restrict__ seg, uin
 
 struct SyncBuffers {
         unsigned long long *start, *exit; // per chunk: the state it was last decoded from, the state it left in
-        uint32_t *nblk, *base;            // blocks completed in the chunk; blocks completed in front of it
+        uint32_t *nblk, *excl;            // blocks completed in the chunk; blocks completed in all the chunks in front of it (one more entry: the total)
+        uint32_t *chunk_off;              // per segment: its first chunk (one more entry: the chunks in use)
         unsigned long long *wg_last;      // per workgroup: the exit state of its last chunk
-        uint32_t *host;                   // mapped host memory: [0] a workgroup's last exit state changed, [1] blocks in all chunks, [2] chunks the segment has
+        uint32_t *host;                   // mapped host memory: [0] a workgroup's last exit state changed, [1] every segment holds its blocks, [2] chunks in use
+};
+struct SyncGeom {
+        int n_seg, seg_units, n_chunks; // segments the scan should have, units per segment, chunks the launches cover (an upper bound of those in use)
 };
 
-// first = true: every chunk decodes from the guess "a block starts at my first bit" and the workgroup settles its 256 chunks among themselves (the workgroup's first
-// chunk keeps its guess, except chunk 0, whose state is the true one).  first = false: the workgroup's first chunk takes the exit state of the workgroup in front;
-// if that is news, the workgroup settles again.  Run until no workgroup's last exit state changes (the host reads host[0]).
+// chunks per segment -> first chunk of every segment (one workgroup, the segments in strides of 1024)
+__global__ __launch_bounds__(1024) void sync_layout_kernel(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, const int *__restrict__ found, SyncGeom g,
+                                                           SyncBuffers b)
+{
+        __shared__ uint32_t wave_tot[16];
+        __shared__ uint32_t carry_s;
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int n_found = min(g.n_seg, found[0]);
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < g.n_seg; i0 += 1024) {
+                const int i = i0 + tid;
+                uint32_t v = 0;
+                if (i < n_found) {
+                        const uint32_t a = seg_start[i], e = seg_end[i];
+                        v = e > a ? (8u * (e - a) + kSyncChunkBits - 1) / kSyncChunkBits : 0u;
+                }
+                uint32_t incl = v;
+                for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += o;
+                }
+                if (lane == 63) wave_tot[wv] = incl;
+                __syncthreads();
+                uint32_t before = carry_s;
+                for (int j = 0; j < wv; j++) before += wave_tot[j];
+                if (i < g.n_seg) b.chunk_off[i] = before + incl - v;
+                __syncthreads();
+                if (tid == 1023) carry_s = before + incl;
+                __syncthreads();
+        }
+        if (tid == 0) {
+                b.chunk_off[g.n_seg] = carry_s;
+                b.host[2] = carry_s;
+        }
+}
+
+// chunk t -> its segment and its number inside it; false: not in use
+__device__ __forceinline__ bool sync_locate(uint32_t t, const uint32_t *__restrict__ chunk_off, int n_seg, int &seg, uint32_t &j)
+{
+        if (t >= chunk_off[n_seg]) return false;
+        int lo = 0, hi = n_seg; // the last segment whose first chunk is <= t (segments without chunks share their successor's first chunk: the last of them is the one with chunks)
+        while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (chunk_off[mid] <= t) lo = mid;
+                else hi = mid;
+        }
+        seg = lo;
+        j = t - chunk_off[lo];
+        return true;
+}
+
+// first = true: every chunk decodes from the guess "a block starts at my first bit" (for the first chunk of a segment that is the truth) and the workgroup settles its
+// 256 chunks among themselves.  first = false: the workgroup's first chunk takes the exit state of the workgroup in front (unless it starts a segment); if that is
+// news, the workgroup settles again.  Run until no workgroup's last exit state changes (the host reads host[0]).
 __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
-                                                             const int *__restrict__ found, ScanDev sp, const HuffDev *__restrict__ tabs, SyncBuffers b, int first)
+                                                             ScanDev sp, const HuffDev *__restrict__ tabs, SyncGeom g, SyncBuffers b, int first)
 {
         extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
         __shared__ SyncLds s;
@@ -722,20 +779,22 @@ __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__r
         sync_setup(lds, &s, sp, tabs);
         const int tid = threadIdx.x;
         const uint32_t t = blockIdx.x * kSyncWG + tid;
-        const uint32_t end_bits = found[0] >= 1 ? 8u * (seg_end[0] - seg_start[0]) : 0u;
-        const uint8_t *const seg = clean + seg_start[0];
-        const uint32_t stop = min((t + 1) * (uint32_t) kSyncChunkBits, end_bits);
-        const bool live = (unsigned long long) t * kSyncChunkBits < end_bits; // (the launch covers an upper bound of the segment's length: chunks behind its end hold nothing and take no part)
+        int seg = 0;
+        uint32_t j = 0;
+        const bool live = sync_locate(t, b.chunk_off, g.n_seg, seg, j); // (the launch covers an upper bound: chunks behind the last one in use hold nothing and take no part)
+        const bool head = j == 0;                                       // the first chunk of its segment: its start state is known
+        const uint32_t end_bits = live ? 8u * seg_end[seg] : 0u, c0 = live ? 8u * seg_start[seg] + j * (uint32_t) kSyncChunkBits : 0u;
+        const uint32_t stop = min(c0 + (uint32_t) kSyncChunkBits, end_bits);
         unsigned long long st, ex = 0;
         uint32_t nb = 0;
         bool redo;
         if (first) {
-                st = ex = sync_pack(t * (uint32_t) kSyncChunkBits, 0, 0);
+                st = ex = sync_pack(c0, 0, 0);
                 redo = live;
         } else {
                 st = b.start[t]; ex = b.exit[t]; nb = b.nblk[t];
                 redo = false;
-                if (tid == 0 && blockIdx.x > 0 && live) {
+                if (tid == 0 && blockIdx.x > 0 && live && !head) {
                         const unsigned long long in = __atomic_load_n(b.wg_last + blockIdx.x - 1, __ATOMIC_RELAXED);
                         redo = in != st;
                         st = in;
@@ -748,12 +807,12 @@ __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__r
                         uint32_t p = (uint32_t) (st >> 16);
                         int blk = (int) (st >> 8 & 0xff), z = (int) (st & 0xff);
                         nb = 0;
-                        sync_decode<false>(seg, end_bits, stop, p, blk, z, nb, s, 0, 0);
+                        sync_decode<false>(clean, end_bits, stop, p, blk, z, nb, s, 0, 0);
                         ex = sync_pack(p, blk, z);
                 }
                 s_exit[tid] = ex;
                 __syncthreads();
-                const unsigned long long in = tid == 0 || !live ? st : s_exit[tid - 1];
+                const unsigned long long in = tid == 0 || !live || head ? st : s_exit[tid - 1];
                 redo = in != st;
                 st = in;
                 if (!__syncthreads_or(redo)) break;
@@ -765,17 +824,18 @@ __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__r
         }
 }
 
-// blocks completed in front of every chunk (one workgroup, the chunks in strides of 1024)
-__global__ __launch_bounds__(1024) void sync_prefix_kernel(SyncBuffers b, int n_chunks, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, const int *__restrict__ found)
+// blocks completed in front of every chunk; then: does every segment hold the blocks its units need?  (one workgroup, strides of 1024)
+__global__ __launch_bounds__(1024) void sync_prefix_kernel(SyncBuffers b, SyncGeom g, int units, int per_unit, const int *__restrict__ found)
 {
         __shared__ uint32_t wave_tot[16];
         __shared__ uint32_t carry_s;
+        __shared__ int bad;
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        if (tid == 0) carry_s = 0;
+        if (tid == 0) { carry_s = 0; bad = found[0] < g.n_seg; } // (a segment the stream does not have is an empty one to the sequential walk: zero bits)
         __syncthreads();
-        for (int i0 = 0; i0 < n_chunks; i0 += 1024) {
+        for (int i0 = 0; i0 < g.n_chunks; i0 += 1024) {
                 const int i = i0 + tid;
-                const uint32_t v = i < n_chunks ? b.nblk[i] : 0;
+                const uint32_t v = i < g.n_chunks ? b.nblk[i] : 0;
                 uint32_t incl = v;
                 for (int d = 1; d < 64; d <<= 1) {
                         const uint32_t o = __shfl_up(incl, d, 64);
@@ -785,37 +845,49 @@ __global__ __launch_bounds__(1024) void sync_prefix_kernel(SyncBuffers b, int n_
                 __syncthreads();
                 uint32_t before = carry_s;
                 for (int j = 0; j < wv; j++) before += wave_tot[j];
-                if (i < n_chunks) b.base[i] = before + incl - v;
+                if (i < g.n_chunks) b.excl[i] = before + incl - v;
                 __syncthreads();
                 if (tid == 1023) carry_s = before + incl;
                 __syncthreads();
         }
-        if (tid == 0) {
-                b.host[1] = carry_s;
-                b.host[2] = found[0] >= 1 ? (8u * (seg_end[0] - seg_start[0]) + kSyncChunkBits - 1) / kSyncChunkBits : 0u;
+        if (tid == 0) b.excl[g.n_chunks] = carry_s;
+        __threadfence();
+        __syncthreads();
+        for (int sg = tid; sg < g.n_seg; sg += 1024) {
+                const int need = min(g.seg_units, units - sg * g.seg_units) * per_unit;
+                const uint32_t have = b.excl[b.chunk_off[sg + 1]] - b.excl[b.chunk_off[sg]];
+                if (have < (uint32_t) need) bad = 1;
         }
+        __syncthreads();
+        if (tid == 0) b.host[1] = !bad;
 }
 
 // every chunk once more, from its settled state, coefficients written
 __global__ __launch_bounds__(kSyncWG) void sync_write_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
-                                                            const int *__restrict__ found, ScanDev sp, const HuffDev *__restrict__ tabs, SyncBuffers b, uint32_t total_blocks)
+                                                            ScanDev sp, const HuffDev *__restrict__ tabs, SyncGeom g, SyncBuffers b)
 {
         extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
         __shared__ SyncLds s;
         sync_setup(lds, &s, sp, tabs);
         const uint32_t t = blockIdx.x * kSyncWG + threadIdx.x;
-        const uint32_t end_bits = found[0] >= 1 ? 8u * (seg_end[0] - seg_start[0]) : 0u;
-        const uint32_t stop = min((t + 1) * (uint32_t) kSyncChunkBits, end_bits);
+        int seg = 0;
+        uint32_t j = 0;
+        if (!sync_locate(t, b.chunk_off, g.n_seg, seg, j)) return;
+        const uint32_t end_bits = 8u * seg_end[seg];
+        const uint32_t stop = min(8u * seg_start[seg] + (j + 1) * (uint32_t) kSyncChunkBits, end_bits);
         const unsigned long long st = b.start[t];
         uint32_t p = (uint32_t) (st >> 16), nb = 0;
         int blk = (int) (st >> 8 & 0xff), z = (int) (st & 0xff);
-        sync_decode<true>(clean + seg_start[0], end_bits, stop, p, blk, z, nb, s, b.base[t], total_blocks);
+        const uint32_t seg_first = (uint32_t) seg * (uint32_t) g.seg_units * (uint32_t) s.per_unit;
+        const uint32_t limit = (uint32_t) min((long) (seg + 1) * g.seg_units, (long) sp.units) * (uint32_t) s.per_unit; // blocks behind the segment's last unit are nobody's
+        sync_decode<true>(clean, end_bits, stop, p, blk, z, nb, s, seg_first + b.excl[t] - b.excl[b.chunk_off[seg]], limit);
 }
 
-// DC differences -> DC values: a running sum per component over its blocks in scan order (unit after unit, the blocks of a unit row by row); blockIdx.x = component of the scan
-__global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp)
+// DC differences -> DC values: a running sum per component over its blocks in scan order (unit after unit, the blocks of a unit row by row), started anew with every
+// segment; blockIdx.x = component of the scan
+__global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp, int seg_units)
 {
-        __shared__ int wave_tot[16];
+        __shared__ int wave_v[16], wave_f[16];
         __shared__ int carry_s;
         const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         const int per = sp.nbh[k] * sp.nbv[k], row_units = sp.single ? sp.bw1 : sp.mcu_w;
@@ -825,25 +897,30 @@ __global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp)
         for (long i0 = 0; i0 < total; i0 += 1024) {
                 const long i = i0 + tid;
                 int16_t *at = nullptr;
+                int f = 0; // 1: the sum starts anew here (the first block of the component in a segment)
                 if (i < total) {
                         const int u = (int) (i / per), j = (int) (i - (long) u * per);
                         const int by = j / sp.nbh[k], bx = j - by * sp.nbh[k];
                         const int uy = u / row_units, ux = u - uy * row_units;
                         at = sp.coef[k] + ((size_t) (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64;
+                        f = j == 0 && u % seg_units == 0;
                 }
-                const int v = at ? (int) *at : 0;
-                int incl = v;
-                for (int d = 1; d < 64; d <<= 1) {
-                        const int o = __shfl_up(incl, d, 64);
-                        if (lane >= d) incl += o;
+                int v = at ? (int) *at : 0;
+                for (int d = 1; d < 64; d <<= 1) { // segmented inclusive scan: (f, v) o (f', v') = (f | f', f' ? v' : v + v')
+                        const int of = __shfl_up(f, d, 64), ov = __shfl_up(v, d, 64);
+                        if (lane >= d) {
+                                if (!f) v += ov;
+                                f |= of;
+                        }
                 }
-                if (lane == 63) wave_tot[wv] = incl;
+                if (lane == 63) { wave_v[wv] = v; wave_f[wv] = f; }
                 __syncthreads();
-                int before = carry_s;
-                for (int j = 0; j < wv; j++) before += wave_tot[j];
-                if (at) *at = (int16_t) (before + incl);
+                int cv = carry_s;
+                for (int w = 0; w < wv; w++) cv = wave_f[w] ? wave_v[w] : cv + wave_v[w];
+                const int out = f ? v : cv + v;
+                if (at) *at = (int16_t) out;
                 __syncthreads();
-                if (tid == 1023) carry_s = before + incl;
+                if (tid == 1023) carry_s = out;
                 __syncthreads();
         }
 }
@@ -979,8 +1056,8 @@ struct Decoder {
         size_t tmp_cap = 0;
         // scans without restart intervals (pass 2b): per-chunk states and counts, the mapped words the host reads between the launches
         unsigned long long *sync_start = nullptr, *sync_exit = nullptr, *sync_wg_last = nullptr;
-        uint32_t *sync_nblk = nullptr, *sync_base = nullptr;
-        size_t sync_start_cap = 0, sync_exit_cap = 0, sync_wg_cap = 0, sync_nblk_cap = 0, sync_base_cap = 0;
+        uint32_t *sync_nblk = nullptr, *sync_base = nullptr, *sync_chunk_off = nullptr;
+        size_t sync_start_cap = 0, sync_exit_cap = 0, sync_wg_cap = 0, sync_nblk_cap = 0, sync_base_cap = 0, sync_chunk_off_cap = 0;
         uint32_t *sync_host = nullptr, *sync_host_dev = nullptr;
         // pinned staging for the tables; they are uploaded when they differ from the last frame's
         void *pinned = nullptr;
@@ -1035,7 +1112,7 @@ void ug_hip_jpeg_decoder_destroy(ug_hip_jpeg_decoder *dec)
         if (!d) return;
         for (void *p : { (void *) d->stream, (void *) d->clean, (void *) d->seg_start, (void *) d->seg_end, (void *) d->scan_counts, (void *) d->tabs, (void *) d->qt, (void *) d->coef[0], (void *) d->coef[1], (void *) d->coef[2],
                          (void *) d->plane[0], (void *) d->plane[1], (void *) d->plane[2], (void *) d->tmp, (void *) d->sync_start, (void *) d->sync_exit, (void *) d->sync_wg_last,
-                         (void *) d->sync_nblk, (void *) d->sync_base }) {
+                         (void *) d->sync_nblk, (void *) d->sync_base, (void *) d->sync_chunk_off }) {
                 if (p) (void) hipFree(p);
         }
         if (d->sync_host) (void) hipHostFree(d->sync_host);
@@ -1231,51 +1308,54 @@ int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_
                         hipLaunchKernelGGL(huff_decode_kernel, dim3((unsigned) ((n_seg + lanes - 1) / lanes)), dim3(64), lds_for(lanes), st, d->clean, d->seg_start, d->seg_end, n_seg,
                                            d->scan_counts, lanes, (int) stage, sp, d->tabs);
                 };
-                // ---- a scan that is ONE long segment (no restart intervals): self-synchronising parallel decoding (pass 2b) -- synchronises with the host between its launches ----
+                // ---- a scan of LONG segments (no restart intervals, or few): self-synchronising parallel decoding (pass 2b) -- synchronises with the host between its launches ----
                 static const bool sync_off = getenv("UG_JPEG_DEC_SYNC") != nullptr && getenv("UG_JPEG_DEC_SYNC")[0] == '0';
                 int per_unit = 0;
                 for (int k = 0; k < sp.ns; k++) per_unit += sp.nbh[k] * sp.nbv[k];
                 const size_t scan_bytes = sc.data_end - sc.data_begin;
-                if (n_seg != 1 || scan_bytes < kSyncMinBytes || scan_bytes >= ((size_t) 1 << 28) || per_unit > kSyncMaxUnitBlocks || (long) sp.units * per_unit >= (1L << 31) || sync_off) {
+                if (scan_bytes < kSyncMinBytes || scan_bytes / (size_t) n_seg < kSyncMinSegBytes || scan_bytes >= ((size_t) 1 << 28) || per_unit > kSyncMaxUnitBlocks ||
+                    (long) sp.units * per_unit >= (1L << 31) || sync_off) {
                         one_lane_per_segment();
                         continue;
                 }
-                const int n_chunks = (int) ((scan_bytes * 8 + kSyncChunkBits - 1) / kSyncChunkBits); // (an upper bound: the clean stream is no longer than the scan)
-                const int n_wg = (n_chunks + kSyncWG - 1) / kSyncWG;
+                // (an upper bound of the chunks: the clean stream is no longer than the scan, and every segment's last chunk may be a partial one)
+                const int n_wg = (int) (((scan_bytes * 8 + kSyncChunkBits - 1) / kSyncChunkBits + (size_t) n_seg + kSyncWG - 1) / kSyncWG);
                 const size_t padded = (size_t) n_wg * kSyncWG;
+                const int per_seg = sp.ri && sp.ri < sp.units ? sp.ri : sp.units; // units per segment (huff_decode_kernel's rule)
+                const SyncGeom geom = { n_seg, per_seg, (int) padded };
                 if (!d->sync_host) {
                         UG_HIP_TRY(hipHostMalloc((void **) &d->sync_host, 64, hipHostMallocMapped));
                         UG_HIP_TRY(hipHostGetDevicePointer((void **) &d->sync_host_dev, d->sync_host, 0));
                 }
                 if (!grow((void **) &d->sync_start, &d->sync_start_cap, padded * 8) || !grow((void **) &d->sync_exit, &d->sync_exit_cap, padded * 8) ||
-                    !grow((void **) &d->sync_nblk, &d->sync_nblk_cap, padded * 4) || !grow((void **) &d->sync_base, &d->sync_base_cap, padded * 4) ||
-                    !grow((void **) &d->sync_wg_last, &d->sync_wg_cap, (size_t) n_wg * 8)) {
+                    !grow((void **) &d->sync_nblk, &d->sync_nblk_cap, padded * 4) || !grow((void **) &d->sync_base, &d->sync_base_cap, (padded + 1) * 4) ||
+                    !grow((void **) &d->sync_chunk_off, &d->sync_chunk_off_cap, ((size_t) n_seg + 1) * 4) || !grow((void **) &d->sync_wg_last, &d->sync_wg_cap, (size_t) n_wg * 8)) {
                         ug::set_last_error_msg("ug_hip_jpeg_decoder_decode: out of device memory");
                         return UG_HIP_ERUNTIME;
                 }
-                const SyncBuffers sb = { d->sync_start, d->sync_exit, d->sync_nblk, d->sync_base, d->sync_wg_last, d->sync_host_dev };
+                const SyncBuffers sb = { d->sync_start, d->sync_exit, d->sync_nblk, d->sync_base, d->sync_chunk_off, d->sync_wg_last, d->sync_host_dev };
                 const size_t sync_lds = (size_t) lds_tile_offset(sp.n_dc, sp.n_ac);
-                hipLaunchKernelGGL(sync_settle_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, d->scan_counts, sp, d->tabs, sb, 1);
+                hipLaunchKernelGGL(sync_layout_kernel, dim3(1), dim3(1024), 0, st, d->seg_start, d->seg_end, d->scan_counts, geom, sb);
+                hipLaunchKernelGGL(sync_settle_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, sp, d->tabs, geom, sb, 1);
                 bool settled = n_wg == 1;
                 for (int round = 0; round < n_wg + 1 && !settled; round++) { // (a change travels at least one workgroup per round: n_wg rounds at the very worst; usually one or two)
                         UG_HIP_TRY(hipStreamSynchronize(st)); // the earlier launch is through: the flag may be cleared
                         d->sync_host[0] = 0;
-                        hipLaunchKernelGGL(sync_settle_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, d->scan_counts, sp, d->tabs, sb, 0);
+                        hipLaunchKernelGGL(sync_settle_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, sp, d->tabs, geom, sb, 0);
                         UG_HIP_TRY(hipStreamSynchronize(st));
                         settled = d->sync_host[0] == 0;
                 }
-                hipLaunchKernelGGL(sync_prefix_kernel, dim3(1), dim3(1024), 0, st, sb, n_chunks, d->seg_start, d->seg_end, d->scan_counts);
+                hipLaunchKernelGGL(sync_prefix_kernel, dim3(1), dim3(1024), 0, st, sb, geom, sp.units, per_unit, d->scan_counts);
                 UG_HIP_TRY(hipStreamSynchronize(st));
-                const uint32_t total_blocks = (uint32_t) ((long) sp.units * per_unit);
-                if (!settled || d->sync_host[1] < total_blocks) { // the data ends before the picture does (or the states never settled): the sequential walk, zero-bit tail and all
+                if (!settled || !d->sync_host[1]) { // a segment's data ends before its units do (or the states never settled): the sequential walk, zero-bit tail and all
                         one_lane_per_segment();
                         continue;
                 }
                 if (gpu_scan) { // (the other scans' planes were cleared above) the write pass stores the coefficients that are there, not the zeros between them
                         for (int k = 0; k < sc.ns; k++) UG_HIP_TRY(hipMemsetAsync(sp.coef[k], 0, (size_t) (gw[sc.comp[k]] * gh[sc.comp[k]]) * 128, st));
                 }
-                hipLaunchKernelGGL(sync_write_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, d->scan_counts, sp, d->tabs, sb, total_blocks);
-                hipLaunchKernelGGL(sync_dc_kernel, dim3((unsigned) sc.ns), dim3(1024), 0, st, sp);
+                hipLaunchKernelGGL(sync_write_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, sp, d->tabs, geom, sb);
+                hipLaunchKernelGGL(sync_dc_kernel, dim3((unsigned) sc.ns), dim3(1024), 0, st, sp, per_seg);
         }
         // ---- dequantisation + IDCT ----
         {
