@@ -700,6 +700,27 @@ def test_greyscale_jpeg_through_the_decompress_framework(tmp_path, po, out):
 
 
 @needs_dec_harness
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [0, 8])
+def test_third_party_jpeg_with_long_segments_through_the_decompress_framework(tmp_path, po, rows):
+    """a libjpeg / FFmpeg-style stream (no restart intervals, or one per 8 MCU rows) through decompress_frame: the parallel decode of long segments inside the module"""
+    import io
+    from PIL import Image
+    w, h = 1280, 720
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 20.0) * np.cos(yy / 15.0), 128 + 90 * np.cos(xx / 33.0 + yy / 21.0), 128 + 80 * np.sin(yy / 9.0)], -1)
+    rgb = (rgb + np.random.default_rng(2).normal(0, 5, rgb.shape)).clip(0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(rgb).save(b, "JPEG", quality=80, subsampling=1, **({"restart_marker_rows": rows} if rows else {}))
+    src, dst = tmp_path / "t.jpg", tmp_path / "o.raw"
+    src.write_bytes(b.getvalue())
+    r = subprocess.run([DEC_HARNESS, "JPEG", "UYVY", str(w), str(h), str(src), str(dst)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, crop, _ = po.jpeg_decode_planes(b.getvalue())
+    assert np.array_equal(np.fromfile(dst, np.uint8)[:2 * w * h], po.planar_to_uyvy(*crop, w, h, chroma=422))
+
+
+@needs_dec_harness
 def test_jpeg_decompress_module_registers():
     r = subprocess.run([DEC_HARNESS, "list"], capture_output=True, text=True, timeout=30)
     assert r.returncode == 0 and "jpeg_mi355x" in r.stdout.split()
