@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from ultragrid_amd import codec as hip, lib as L
 
 for (w, h) in [(640, 360), (1280, 720), (1920, 1080), (3840, 2160)]:
