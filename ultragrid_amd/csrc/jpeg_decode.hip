@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include <vector>
@@ -581,6 +582,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void
 // kSyncMinSegBytes, and only when every segment holds all its blocks (data that ends early goes the sequential way, whose zero-bit tail it would otherwise have to imitate).
 constexpr int kSyncChunkBits = 1024;
 constexpr int kSyncWG = 256;
+constexpr int kSyncWarm = 16, kSyncOwn = kSyncWG - kSyncWarm; // chunks a workgroup of the settling kernel runs ahead of its own (see there); chunks it owns
 constexpr size_t kSyncMinBytes = 4096, kSyncMinSegBytes = 2048;
 constexpr int kSyncMaxUnitBlocks = 12; // blocks of one unit: 3 components of up to 2 x 2 (the layouts the output stage takes have at most 6)
 
@@ -768,8 +770,12 @@ __device__ __forceinline__ bool sync_locate(uint32_t t, const uint32_t *__restri
 }
 
 // first = true: every chunk decodes from the guess "a block starts at my first bit" (for the first chunk of a segment that is the truth) and the workgroup settles its
-// 256 chunks among themselves.  first = false: the workgroup's first chunk takes the exit state of the workgroup in front (unless it starts a segment); if that is
-// news, the workgroup settles again.  Run until no workgroup's last exit state changes (the host reads host[0]).
+// chunks among themselves.  first = false: the workgroup's first chunk takes the exit state of the workgroup in front (unless it starts a segment); if that is news, the
+// workgroup settles again.  Run until no workgroup's last exit state changes (the host reads host[0]).
+// A workgroup owns kSyncOwn chunks and, in the first pass, runs kSyncWarm lanes AHEAD of them over the last chunks of the workgroup in front: their only purpose is to
+// hand the first owned chunk a start state that is in step already -- getting the bit position right takes a few symbols, getting the block of the unit right (the
+// tables depend on it) several chunks.  With that the round across the workgroups finds nothing to change in most streams and costs microseconds; without, it cost as
+// much as the first pass (every workgroup settled twice).
 __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__restrict__ clean, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end,
                                                              ScanDev sp, const HuffDev *__restrict__ tabs, SyncGeom g, SyncBuffers b, int first)
 {
@@ -778,10 +784,13 @@ __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__r
         __shared__ unsigned long long s_exit[kSyncWG];
         sync_setup(lds, &s, sp, tabs);
         const int tid = threadIdx.x;
-        const uint32_t t = blockIdx.x * kSyncWG + tid;
+        const long tl = (long) blockIdx.x * kSyncOwn + tid - kSyncWarm; // lanes 0 .. kSyncWarm - 1: the chunks in front of the workgroup's own
+        const uint32_t t = (uint32_t) (tl < 0 ? 0 : tl);
+        const bool own = tid >= kSyncWarm;
         int seg = 0;
         uint32_t j = 0;
-        const bool live = sync_locate(t, b.chunk_off, g.n_seg, seg, j); // (the launch covers an upper bound: chunks behind the last one in use hold nothing and take no part)
+        // (the launch covers an upper bound: chunks behind the last one in use hold nothing and take no part; nor do the lanes ahead once the first pass is through)
+        const bool live = tl >= 0 && (own || first) && sync_locate(t, b.chunk_off, g.n_seg, seg, j);
         const bool head = j == 0;                                       // the first chunk of its segment: its start state is known
         const uint32_t end_bits = live ? 8u * seg_end[seg] : 0u, c0 = live ? 8u * seg_start[seg] + j * (uint32_t) kSyncChunkBits : 0u;
         const uint32_t stop = min(c0 + (uint32_t) kSyncChunkBits, end_bits);
@@ -792,9 +801,10 @@ __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__r
                 st = ex = sync_pack(c0, 0, 0);
                 redo = live;
         } else {
-                st = b.start[t]; ex = b.exit[t]; nb = b.nblk[t];
+                st = ex = 0;
+                if (own) { st = b.start[t]; ex = b.exit[t]; nb = b.nblk[t]; }
                 redo = false;
-                if (tid == 0 && blockIdx.x > 0 && live && !head) {
+                if (tid == kSyncWarm && blockIdx.x > 0 && live && !head) {
                         const unsigned long long in = __atomic_load_n(b.wg_last + blockIdx.x - 1, __ATOMIC_RELAXED);
                         redo = in != st;
                         st = in;
@@ -812,12 +822,13 @@ __global__ __launch_bounds__(kSyncWG) void sync_settle_kernel(const uint8_t *__r
                 }
                 s_exit[tid] = ex;
                 __syncthreads();
-                const unsigned long long in = tid == 0 || !live || head ? st : s_exit[tid - 1];
+                // (the first lane has nobody to its left; nor has the first owned one once the lanes ahead are out of the game: it got its state from the workgroup in front)
+                const unsigned long long in = tid == 0 || !live || head || (!first && tid == kSyncWarm) ? st : s_exit[tid - 1];
                 redo = in != st;
                 st = in;
                 if (!__syncthreads_or(redo)) break;
         }
-        b.start[t] = st; b.exit[t] = ex; b.nblk[t] = nb;
+        if (own) { b.start[t] = st; b.exit[t] = ex; b.nblk[t] = nb; }
         if (tid == kSyncWG - 1 && ex != last_before) {
                 __atomic_store_n(b.wg_last + blockIdx.x, ex, __ATOMIC_RELAXED);
                 if (!first) b.host[0] = 1;
@@ -887,6 +898,7 @@ __global__ __launch_bounds__(kSyncWG) void sync_write_kernel(const uint8_t *__re
 // segment; blockIdx.x = component of the scan
 __global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp, int seg_units)
 {
+        constexpr int kPer = 8; // consecutive blocks per lane: summed in registers, so that the workgroup-wide scan (barriers, shuffles) runs once per 8 192 blocks
         __shared__ int wave_v[16], wave_f[16];
         __shared__ int carry_s;
         const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -894,19 +906,35 @@ __global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp, int seg_units
         const long total = (long) sp.units * per;
         if (tid == 0) carry_s = 0;
         __syncthreads();
-        for (long i0 = 0; i0 < total; i0 += 1024) {
-                const long i = i0 + tid;
-                int16_t *at = nullptr;
-                int f = 0; // 1: the sum starts anew here (the first block of the component in a segment)
-                if (i < total) {
-                        const int u = (int) (i / per), j = (int) (i - (long) u * per);
-                        const int by = j / sp.nbh[k], bx = j - by * sp.nbh[k];
-                        const int uy = u / row_units, ux = u - uy * row_units;
-                        at = sp.coef[k] + ((size_t) (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64;
-                        f = j == 0 && u % seg_units == 0;
+        for (long i0 = 0; i0 < total; i0 += 1024 * kPer) {
+                int16_t *at[kPer];
+                int fl[kPer], val[kPer];
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        const long i = i0 + (long) tid * kPer + e;
+                        at[e] = nullptr;
+                        fl[e] = 0; // 1: the sum starts anew here (the first block of the component in a segment)
+                        if (i < total) {
+                                const int u = (int) (i / per), j = (int) (i - (long) u * per);
+                                const int by = j / sp.nbh[k], bx = j - by * sp.nbh[k];
+                                const int uy = u / row_units, ux = u - uy * row_units;
+                                at[e] = sp.coef[k] + ((size_t) (uy * sp.nbv[k] + by) * sp.gw[k] + ux * sp.nbh[k] + bx) * 64;
+                                fl[e] = j == 0 && u % seg_units == 0;
+                        }
                 }
-                int v = at ? (int) *at : 0;
-                for (int d = 1; d < 64; d <<= 1) { // segmented inclusive scan: (f, v) o (f', v') = (f | f', f' ? v' : v + v')
+#pragma unroll
+                for (int e = 0; e < kPer; e++) val[e] = at[e] ? (int) *at[e] : 0;
+                // the lane's own blocks: running sums since the lane's first block or the last restart inside it
+                int f = 0, v = 0;
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        v = fl[e] ? val[e] : v + val[e];
+                        f |= fl[e];
+                        val[e] = v;
+                        fl[e] = f; // from here on: a restart lies at or in front of block e inside the lane
+                }
+                // segmented inclusive scan of the lanes' totals: (f, v) o (f', v') = (f | f', f' ? v' : v + v')
+                for (int d = 1; d < 64; d <<= 1) {
                         const int of = __shfl_up(f, d, 64), ov = __shfl_up(v, d, 64);
                         if (lane >= d) {
                                 if (!f) v += ov;
@@ -914,13 +942,18 @@ __global__ __launch_bounds__(1024) void sync_dc_kernel(ScanDev sp, int seg_units
                         }
                 }
                 if (lane == 63) { wave_v[wv] = v; wave_f[wv] = f; }
+                int pf = __shfl_up(f, 1, 64), pv = __shfl_up(v, 1, 64); // what the lanes in front of this one (in its wave) add up to
+                if (lane == 0) { pf = 0; pv = 0; }
                 __syncthreads();
                 int cv = carry_s;
                 for (int w = 0; w < wv; w++) cv = wave_f[w] ? wave_v[w] : cv + wave_v[w];
-                const int out = f ? v : cv + v;
-                if (at) *at = (int16_t) out;
+                const int before = pf ? pv : cv + pv; // the running sum in front of the lane's first block
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        if (at[e]) *at[e] = (int16_t) (fl[e] ? val[e] : before + val[e]);
+                }
                 __syncthreads();
-                if (tid == 1023) carry_s = out;
+                if (tid == 1023) carry_s = fl[kPer - 1] ? val[kPer - 1] : before + val[kPer - 1];
                 __syncthreads();
         }
 }
@@ -1319,10 +1352,11 @@ int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_
                         continue;
                 }
                 // (an upper bound of the chunks: the clean stream is no longer than the scan, and every segment's last chunk may be a partial one)
-                const int n_wg = (int) (((scan_bytes * 8 + kSyncChunkBits - 1) / kSyncChunkBits + (size_t) n_seg + kSyncWG - 1) / kSyncWG);
-                const size_t padded = (size_t) n_wg * kSyncWG;
+                const size_t chunks_ub = (scan_bytes * 8 + kSyncChunkBits - 1) / kSyncChunkBits + (size_t) n_seg;
+                const int n_wg = (int) ((chunks_ub + kSyncOwn - 1) / kSyncOwn), n_wg_write = (int) ((chunks_ub + kSyncWG - 1) / kSyncWG); // (the settling kernel's workgroups own kSyncOwn chunks each)
+                const size_t padded = std::max((size_t) n_wg * kSyncOwn, (size_t) n_wg_write * kSyncWG);
                 const int per_seg = sp.ri && sp.ri < sp.units ? sp.ri : sp.units; // units per segment (huff_decode_kernel's rule)
-                const SyncGeom geom = { n_seg, per_seg, (int) padded };
+                const SyncGeom geom = { n_seg, per_seg, n_wg * kSyncOwn }; // (the chunks the settling kernel gives a block count)
                 if (!d->sync_host) {
                         UG_HIP_TRY(hipHostMalloc((void **) &d->sync_host, 64, hipHostMallocMapped));
                         UG_HIP_TRY(hipHostGetDevicePointer((void **) &d->sync_host_dev, d->sync_host, 0));
@@ -1354,7 +1388,7 @@ int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_
                 if (gpu_scan) { // (the other scans' planes were cleared above) the write pass stores the coefficients that are there, not the zeros between them
                         for (int k = 0; k < sc.ns; k++) UG_HIP_TRY(hipMemsetAsync(sp.coef[k], 0, (size_t) (gw[sc.comp[k]] * gh[sc.comp[k]]) * 128, st));
                 }
-                hipLaunchKernelGGL(sync_write_kernel, dim3((unsigned) n_wg), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, sp, d->tabs, geom, sb);
+                hipLaunchKernelGGL(sync_write_kernel, dim3((unsigned) n_wg_write), dim3(kSyncWG), sync_lds, st, d->clean, d->seg_start, d->seg_end, sp, d->tabs, geom, sb);
                 hipLaunchKernelGGL(sync_dc_kernel, dim3((unsigned) sc.ns), dim3(1024), 0, st, sp, per_seg);
         }
         // ---- dequantisation + IDCT ----
