@@ -50,3 +50,22 @@ for (w, h) in [(1920, 1080), (3840, 2160)]:
     torch.cuda.synchronize()
     dec.close()
     print(f"{w}x{h} 4:2:0 q75 {len(data):8d} B  eight restart intervals per frame  : {(time.perf_counter() - t0) / 20 * 1e3:9.3f} ms per frame")
+
+# the repository's own 4K 4:2:2 streams with longer restart intervals than the default: where the choice between the two ways falls (run with UG_JPEG_DEC_SYNC=0 for the other side)
+from ultragrid_amd import synth
+w, h = 3840, 2160
+src = torch.from_numpy(synth.s2_video("UYVY", w, h, salt=1)).cuda()
+for q, ri in [(75, 4), (75, 32), (95, 16), (95, 32), (95, 128), (75, 256), (75, 2000)]:
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=422)
+    data = enc.encode(src, L.PF_UYVY)
+    enc.close()
+    n_seg = -(-(w // 16 * (h // 8)) // ri)
+    dec = hip.JpegDecoder()
+    dec.decode(data, L.PF_UYVY)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dec.decode(data, L.PF_UYVY)
+    torch.cuda.synchronize()
+    dec.close()
+    print(f"own 4K 4:2:2 q{q} restart {ri:4d}: {len(data):8d} B, {len(data) // n_seg:7d} B per segment: {(time.perf_counter() - t0) / 20 * 1e3:9.3f} ms per frame")

@@ -578,12 +578,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(64) void
 // to its right neighbour as that one's start, and decode again whoever's start changed, until nothing changes: a fixed point, and since the first chunk of every
 // segment starts from the true state it is the sequential decoder's own chain of states -- for any data, damaged or not.  Then a prefix sum over the blocks completed per
 // chunk tells every chunk which block it starts in, one more pass writes the coefficients (DC as differences), and a running sum per component in scan order, started
-// anew at every restart interval, turns the differences into DC values.  Bit-identical to the one-lane walk; taken when the segments of a scan average at least
-// kSyncMinSegBytes, and only when every segment holds all its blocks (data that ends early goes the sequential way, whose zero-bit tail it would otherwise have to imitate).
+// anew at every restart interval, turns the differences into DC values.  Bit-identical to the one-lane walk; taken when the segments of a scan are long enough for it
+// to be the faster way (the rule is where the choice is made), and only when every segment holds all its blocks (data that ends early goes the sequential way, whose zero-bit tail it would otherwise have to imitate).
 constexpr int kSyncChunkBits = 1024;
 constexpr int kSyncWG = 256;
 constexpr int kSyncWarm = 16, kSyncOwn = kSyncWG - kSyncWarm; // chunks a workgroup of the settling kernel runs ahead of its own (see there); chunks it owns
-constexpr size_t kSyncMinBytes = 4096, kSyncMinSegBytes = 2048;
+constexpr size_t kSyncMinBytes = 4096;
 constexpr int kSyncMaxUnitBlocks = 12; // blocks of one unit: 3 components of up to 2 x 2 (the layouts the output stage takes have at most 6)
 
 __device__ __forceinline__ unsigned long long sync_pack(uint32_t p, int blk, int z) { return (unsigned long long) p << 16 | (unsigned) blk << 8 | (unsigned) z; }
@@ -1346,7 +1346,11 @@ int ug_hip_jpeg_decoder_decode_sized(ug_hip_jpeg_decoder *dec, const void *jpeg_
                 int per_unit = 0;
                 for (int k = 0; k < sp.ns; k++) per_unit += sp.nbh[k] * sp.nbv[k];
                 const size_t scan_bytes = sc.data_end - sc.data_begin;
-                if (scan_bytes < kSyncMinBytes || scan_bytes / (size_t) n_seg < kSyncMinSegBytes || scan_bytes >= ((size_t) 1 << 28) || per_unit > kSyncMaxUnitBlocks ||
+                // Which way is faster (profiles/r06_decode_no_restart.txt): a lane walks its segment at ~0.5 us per byte, and the segments run side by side; the parallel
+                // decode costs ~0.55 ms of launches, host synchronisations and settling however small the picture, plus what grows with the picture (clearing the
+                // planes, the DC sums: ~0.06 us per 1000 pixels), and hardly depends on the length of the stream.  4K: segments from ~2 KiB; 1080p: from ~1.3 KiB.
+                const bool long_segments = 0.5 * (double) (scan_bytes / (size_t) n_seg) > 550.0 + 6e-5 * (double) h.width * (double) h.height;
+                if (scan_bytes < kSyncMinBytes || !long_segments || scan_bytes >= ((size_t) 1 << 28) || per_unit > kSyncMaxUnitBlocks ||
                     (long) sp.units * per_unit >= (1L << 31) || sync_off) {
                         one_lane_per_segment();
                         continue;
