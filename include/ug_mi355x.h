@@ -434,8 +434,9 @@ int ug_hip_uyvy_to_jpeg42x_coeffs_batch(int subsampling, const void *src_dev, in
  * `encode` is synchronous on `stream` (it returns the stream length).  ug_hip_jpeg_encoder_max_size() is the capacity that can
  * never overflow (every coefficient at its longest code, every byte stuffed: ~10 B per pixel); a smaller out_capacity is allowed:
  * if the stream does not fit, UG_HIP_EINVAL is returned with *out_len = the size it needs and the buffer contents undefined.
- * restart_interval: MCUs per restart interval, 1..65535; 0 = none (one entropy-coded segment, no DRI: the scan is coded by ONE wave, milliseconds per
- * frame -- for readers that cannot take restart markers; what makes this encoder parallel is the restart interval). */
+ * restart_interval: MCUs per restart interval, 1..65535; 0 = none (one entropy-coded segment, no DRI -- for readers that cannot take restart markers): a lane per
+ * block, bit positions by prefix sum, byte stuffing as a second prefix sum; one more host synchronisation per frame; 0.24 ms per 1080p frame, 0.63 ms at 4K against
+ * 0.08 / 0.16 ms with restart intervals (profiles/r06_encode_no_restart.txt). */
 typedef struct ug_hip_jpeg_encoder ug_hip_jpeg_encoder;
 int    ug_hip_jpeg_encoder_create(int width, int height, int quality, int restart_interval, ug_hip_jpeg_encoder **out);
 /* subsampling = 420, 422 or 444 (gpujpeg.cpp:406-408 `subsampling=` option); ug_hip_jpeg_encoder_create() is the 420 form. */

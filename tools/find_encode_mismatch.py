@@ -23,6 +23,8 @@ for seed in range(n):
     if seed % 2:  # round 4: half of the cases where the fused kernels run (width % 16 == 0 for UYVY, restart interval a power of two up to 32 / 64) ...
         w = 16 * int(rng.integers(1, 70))
         ri = int(rng.choice([r for r in (1, 2, 4, 8, 16, 32, 64) if sub == 444 or r <= 32]))
+    if seed % 11 == 0:     # round 6: no restart intervals at all (restart_interval 0: one segment, coded in parallel by the nori_* kernels)
+        ri = 0
     two = seed % 4 >= 2   # ... and half of all cases as a batch of two frames (the two-launch placement; one-frame calls place in one launch)
     yy, xx = np.mgrid[0:h, 0:w]
     base = np.stack([128 + 100 * np.sin(xx / (3 + 40 * rng.random())) * np.cos(yy / (3 + 30 * rng.random())), 128 + 90 * np.cos(xx / 33.0 + yy / (5 + 20 * rng.random())),

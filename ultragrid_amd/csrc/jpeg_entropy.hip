@@ -1350,6 +1350,199 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
         }
 }
 
+// ---- a scan WITHOUT restart intervals (restart_interval 0), in parallel ----------------------------------------------------------------------------------------
+// One segment was one wave walking the frame block after block (entropy_wave_kernel with a grid of one wave): 40 ms for a 1080p frame, 159 ms at 4K.  Nothing in
+// Huffman CODING is sequential but where the bits go: a lane per block works out its block's bit count (the DC prediction of a block is the DC value of the block before
+// it in the component, which is in the coefficient planes already), a prefix sum turns the counts into bit positions, a lane per block codes its bits to that position
+// of a zeroed buffer (atomic OR: blocks share words at their ends), and byte stuffing is one more count / prefix sum / move over 64-byte pieces of the buffer.  The
+// stream is the sequential coder's, bit for bit (tests/test_jpeg_colour_options.py::test_gpu_no_restart_intervals).
+struct NoriScan {
+        const int16_t *c0, *c1, *c2; // component 0 (hs x vs blocks per MCU), the components behind it (nc = 2) -- or one component alone (nc = 0: a scan of a non-interleaved stream)
+        int mcu_w, n_mcu, hs, vs, nc, tab0, ctab;
+};
+
+// block b of the scan -> its coefficients, Huffman table set, and the DC value its prediction starts from
+__device__ __forceinline__ const int16_t *nori_block(const NoriScan &s, uint32_t b, int &tab, int &pred)
+{
+        const int ybl = s.hs * s.vs, per_mcu = ybl + s.nc;
+        const int m = (int) (b / (uint32_t) per_mcu), j = (int) (b - (uint32_t) m * per_mcu);
+        auto luma = [&](int mm, int jj) {
+                const int my = mm / s.mcu_w, mx = mm - my * s.mcu_w;
+                const int yrow = s.vs * my + (s.hs == 2 ? jj >> 1 : 0), ycol = s.hs * mx + (s.hs == 2 ? jj & 1 : 0);
+                return s.c0 + 64 * ((long) yrow * (s.hs * s.mcu_w) + ycol);
+        };
+        if (j < ybl) {
+                tab = s.tab0;
+                pred = j > 0 ? luma(m, j - 1)[0] : (m > 0 ? luma(m - 1, ybl - 1)[0] : 0);
+                return luma(m, j);
+        }
+        const int16_t *const plane = j == ybl ? s.c1 : s.c2;
+        tab = s.ctab;
+        pred = m > 0 ? plane[64L * (m - 1)] : 0;
+        return plane + 64L * m;
+}
+
+// the symbols of one block, in order: put(bits, n) for every code and every run of value bits
+template <class Put>
+__device__ __forceinline__ void nori_walk(const int16_t *__restrict__ c, int tab, int pred, Put put)
+{
+        auto value = [&](int v, int &size) -> uint32_t {
+                const int a = v < 0 ? -v : v;
+                size = a ? 32 - __builtin_clz((unsigned) a) : 0;
+                return (uint32_t) (v < 0 ? v + (1 << size) - 1 : v) & ((1u << size) - 1);
+        };
+        int size;
+        const uint32_t dbits = value((int) c[0] - pred, size);
+        const uint32_t de = kDcTab[tab][size];
+        put(de & 0xffff, (int) (de >> 16));
+        if (size) put(dbits, size);
+        int run = 0;
+        for (int k = 1; k < 64; k++) {
+                const int v = c[k];
+                if (v == 0) {
+                        run++;
+                        continue;
+                }
+                for (; run > 15; run -= 16) {
+                        const uint32_t z = kAcTab[tab][0xF0];
+                        put(z & 0xffff, (int) (z >> 16));
+                }
+                const uint32_t vb = value(v, size);
+                const uint32_t e = kAcTab[tab][(run << 4) | size];
+                put(e & 0xffff, (int) (e >> 16));
+                put(vb, size);
+                run = 0;
+        }
+        if (run) {
+                const uint32_t e = kAcTab[tab][0x00];
+                put(e & 0xffff, (int) (e >> 16));
+        }
+}
+
+__global__ __launch_bounds__(256) void nori_len_kernel(NoriScan s, uint32_t n_blocks, uint32_t *__restrict__ bits)
+{
+        const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+        if (b >= n_blocks) return;
+        int tab, pred;
+        const int16_t *c = nori_block(s, b, tab, pred);
+        uint32_t n = 0;
+        nori_walk(c, tab, pred, [&](uint32_t, int len) { n += (uint32_t) len; });
+        bits[b] = n;
+}
+
+// v[0 .. n) -> the sums in front of every entry, v[n] = the total (one workgroup, 8 entries per lane)
+__global__ __launch_bounds__(1024) void nori_scan_kernel(uint32_t *__restrict__ v, uint32_t n)
+{
+        constexpr int kPer = 8;
+        __shared__ uint32_t wave_tot[16];
+        __shared__ uint32_t carry_s;
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024 * kPer) {
+                uint32_t x[kPer], sum = 0;
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        const uint32_t i = i0 + (uint32_t) tid * kPer + e;
+                        x[e] = i < n ? v[i] : 0;
+                        sum += x[e];
+                }
+                uint32_t incl = sum;
+                for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += o;
+                }
+                if (lane == 63) wave_tot[wv] = incl;
+                __syncthreads();
+                uint32_t before = carry_s + incl - sum;
+                for (int w = 0; w < wv; w++) before += wave_tot[w];
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        const uint32_t i = i0 + (uint32_t) tid * kPer + e;
+                        if (i < n) v[i] = before;
+                        before += x[e];
+                }
+                __syncthreads();
+                if (tid == 1023) carry_s = before;
+                __syncthreads();
+        }
+        if (tid == 0) v[n] = carry_s;
+}
+
+// raw: zeroed; the bits of block b go to bit position pos[b] (stream order: the first bit is the top bit of byte 0); the last block also pads the last byte with 1-bits (F.1.2.3)
+__global__ __launch_bounds__(256) void nori_emit_kernel(NoriScan s, uint32_t n_blocks, const uint32_t *__restrict__ pos, uint32_t *__restrict__ raw)
+{
+        const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+        if (b >= n_blocks) return;
+        int tab, pred;
+        const int16_t *c = nori_block(s, b, tab, pred);
+        uint32_t at = pos[b];              // the next bit
+        unsigned long long acc = 0;        // bits waiting, left-aligned behind the `at & 31` bits of the word that belong to whoever came before
+        int fill = (int) (at & 31);
+        uint32_t word = at >> 5;
+        auto flush = [&]() { // the top 32 bits are a word's worth
+                atomicOr(raw + word, __builtin_bswap32((uint32_t) (acc >> 32)));
+                acc <<= 32;
+                fill -= 32;
+                word++;
+        };
+        nori_walk(c, tab, pred, [&](uint32_t v, int len) {
+                acc |= (unsigned long long) v << (64 - fill - len); // fill < 32, len <= 16 + 11
+                fill += len;
+                if (fill >= 32) flush();
+        });
+        if (b == n_blocks - 1) {
+                const int pad = (8 - (fill & 7)) & 7;
+                if (pad) {
+                        acc |= (unsigned long long) ((1u << pad) - 1u) << (64 - fill - pad);
+                        fill += pad;
+                        if (fill >= 32) flush();
+                }
+        }
+        if (fill) atomicOr(raw + word, __builtin_bswap32((uint32_t) (acc >> 32)));
+}
+
+// bytes 0xFF per 64-byte piece of the scan's bytes (total_bits = pos[n_blocks])
+__global__ __launch_bounds__(256) void nori_ff_kernel(const uint32_t *__restrict__ raw, const uint32_t *__restrict__ total_bits, uint32_t n_pieces, uint32_t *__restrict__ ff)
+{
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_pieces) return;
+        const uint32_t bytes = (*total_bits + 7) / 8;
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < 64 && 64 * i + k < bytes; k++) n += ((const uint8_t *) raw)[64 * i + k] == 0xFF;
+        ff[i] = n;
+}
+
+// header, the scan's bytes with a 0x00 behind every 0xFF (B.1.1.5), EOI; the length to mapped host memory.  `base`: see CodeArgs::base (compact_kernel does the same)
+__global__ __launch_bounds__(256) void nori_place_kernel(const uint32_t *__restrict__ raw, const uint32_t *__restrict__ total_bits, uint32_t n_pieces, const uint32_t *__restrict__ ff_before,
+                                                         uint8_t *__restrict__ out, const uint8_t *__restrict__ header, int header_len, size_t capacity, uint32_t *__restrict__ total_pinned,
+                                                         const uint32_t *__restrict__ base, int frame)
+{
+        const uint32_t base0 = base != nullptr ? base[frame] - 2u : 0u;
+        out += base0;
+        capacity = capacity > base0 ? capacity - base0 : 0;
+        const uint32_t bytes = (*total_bits + 7) / 8;
+        const uint32_t total = (uint32_t) header_len + bytes + ff_before[n_pieces] + 2u;
+        if (blockIdx.x == 0 && (size_t) header_len <= capacity) {
+                for (int i = threadIdx.x; i < header_len; i += 256) out[i] = header[i];
+        }
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i == 0) total_pinned[frame] = base0 + total;
+        if (i >= n_pieces || (size_t) total > capacity) return; // would not fit: nothing of the scan is written, the host reports the needed size from the total
+        uint8_t *d = out + header_len + 64 * (size_t) i + ff_before[i];
+        const uint8_t *src = (const uint8_t *) raw + 64 * (size_t) i;
+        for (uint32_t k = 0; k < 64 && 64 * i + k < bytes; k++) {
+                const uint8_t v = src[k];
+                *d++ = v;
+                if (v == 0xFF) *d++ = 0;
+        }
+        if (i == 0) { // (any lane knows where the scan ends)
+                uint8_t *const e = out + header_len + bytes + ff_before[n_pieces];
+                e[0] = 0xFF;
+                e[1] = 0xD9;
+        }
+}
+
 struct Encoder {
         int width, height, quality, ri, sub, hs, vs, ybl, mcu_w, mcu_h, n_mcu, n_seg, cap, device;
         int batch_cap; // frames the workspace below is sized for (1 after create; encode_batch grows it)
@@ -1375,6 +1568,8 @@ struct Encoder {
         bool use_ticket;        // workgroup index = start-order ticket instead of blockIdx (UG_JPEG_TICKET=1, or for good after a wait was given up)
         bool flat_lookback;     // one-frame calls: the flat form of the look-back (the default; UG_JPEG_FLAT=0 switches back to the windowed walk for A/B)
         uint8_t *header_dev;
+        uint32_t *nori_bits, *nori_ff; // restart_interval 0, the parallel way: bit counts -> positions per block (+ the total); 0xFF bytes per 64-byte piece (+ the total)
+        size_t nori_ff_cap;
         uint32_t *total_host; // pinned, mapped: kTotalWords words for the stream(s) of a call, then as many per scan of a non-interleaved stream
         uint32_t *total_host_dev; // the same word as the device sees it
         // ug_hip_jpeg_encoder_create_ex (gpujpeg.cpp:303-305,396-405)
@@ -1462,11 +1657,12 @@ BatchStride strides_of(const Encoder *e)
 
 void free_raw(Encoder *e)
 {
-        for (void **p : { (void **) &e->scratch, (void **) &e->seg_len, (void **) &e->seg_ff, (void **) &e->chunk_tot }) {
+        for (void **p : { (void **) &e->scratch, (void **) &e->seg_len, (void **) &e->seg_ff, (void **) &e->chunk_tot, (void **) &e->nori_bits, (void **) &e->nori_ff }) {
                 if (*p) (void) hipFree(*p);
                 *p = nullptr;
         }
         e->raw_cap = 0;
+        e->nori_ff_cap = 0;
 }
 
 void free_workspace(Encoder *e)
@@ -1620,8 +1816,8 @@ int ug_hip_jpeg_encoder_create_ex(int width, int height, int quality, int restar
         }
         static_assert(kMaxBatch * sizeof(uint32_t) <= 64, "one length word per frame of a batch");
         static_assert(kMaxBatch + 2 <= kTotalWords, "lengths + the two flag words");
-        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 4 * kTotalWords * 4, hipHostMallocMapped); // the call's block, then one per scan
-        if (err == hipSuccess) memset(e->total_host, 0, 4 * kTotalWords * 4);
+        if (err == hipSuccess) err = hipHostMalloc((void **) &e->total_host, 5 * kTotalWords * 4, hipHostMallocMapped); // the call's block, one per scan, one for odd words
+        if (err == hipSuccess) memset(e->total_host, 0, 5 * kTotalWords * 4);
         for (int c = 0; c < 3 && e->nonint; c++) {
                 alloc((void **) &e->scan_header_dev[c], e->scan_header[c].size());
                 if (err == hipSuccess) err = hipMemcpy(e->scan_header_dev[c], e->scan_header[c].data(), e->scan_header[c].size(), hipMemcpyHostToDevice);
@@ -1892,6 +2088,41 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 }
                 return UG_HIP_SUCCESS;
         };
+        // A scan that is ONE segment (restart_interval 0), coded in parallel (nori_*_kernel above); frame after frame on the stream, one more host synchronisation per frame
+        // (the scan's length in bits, to size the byte-stuffing launches).  scan = nullptr: the interleaved scan.
+        static const bool nori_off = getenv("UG_JPEG_NORI") != nullptr && getenv("UG_JPEG_NORI")[0] == '0';
+        const bool nori = wave_path && e->n_seg == 1 && !nori_off && (unsigned long long) e->cap * 8ull < (1ull << 32);
+        auto code_without_restart = [&](const ScanPlan *scan) -> int {
+                const uint32_t n_blocks = (uint32_t) e->n_mcu * (uint32_t) (scan ? 1 : e->ybl + 2);
+                if (!e->nori_bits) UG_HIP_TRY(hipMalloc((void **) &e->nori_bits, ((size_t) e->n_mcu * (e->ybl + 2) + 1) * 4));
+                for (int f = 0; f < frames; f++) {
+                        NoriScan s = {};
+                        s.c0 = (scan ? scan->coef : e->cy) + f * bs.coef_y; s.c1 = e->cb + f * bs.coef_c; s.c2 = e->cr + f * bs.coef_c;
+                        s.mcu_w = e->mcu_w; s.n_mcu = e->n_mcu; s.hs = scan ? 1 : e->hs; s.vs = scan ? 1 : e->vs; s.nc = scan ? 0 : 2; s.tab0 = scan ? scan->tab0 : 0; s.ctab = e->ctab;
+                        hipLaunchKernelGGL(nori_len_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, e->nori_bits);
+                        hipLaunchKernelGGL(nori_scan_kernel, dim3(1), dim3(1024), 0, st, e->nori_bits, n_blocks);
+                        uint32_t *const bits_host = e->total_host + 4 * kTotalWords; // (a word of the pinned block of its own)
+                        UG_HIP_TRY(hipMemcpyAsync(bits_host, e->nori_bits + n_blocks, 4, hipMemcpyDeviceToHost, st));
+                        UG_HIP_TRY(hipStreamSynchronize(st));
+                        const size_t bytes = ((size_t) *bits_host + 7) / 8;
+                        const uint32_t n_pieces = (uint32_t) ((bytes + 63) / 64);
+                        if (e->nori_ff_cap < (size_t) n_pieces + 1) {
+                                if (e->nori_ff) (void) hipFree(e->nori_ff);
+                                e->nori_ff = nullptr;
+                                e->nori_ff_cap = 0;
+                                UG_HIP_TRY(hipMalloc((void **) &e->nori_ff, ((size_t) n_pieces + 1) * 4 * 2));
+                                e->nori_ff_cap = ((size_t) n_pieces + 1) * 2;
+                        }
+                        UG_HIP_TRY(hipMemsetAsync(e->scratch, 0, (bytes + 8 + 3) & ~(size_t) 3, st));
+                        hipLaunchKernelGGL(nori_emit_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, (const uint32_t *) e->nori_bits, e->scratch);
+                        if (n_pieces) hipLaunchKernelGGL(nori_ff_kernel, dim3((n_pieces + 255) / 256), dim3(256), 0, st, (const uint32_t *) e->scratch, (const uint32_t *) e->nori_bits + n_blocks, n_pieces, e->nori_ff);
+                        hipLaunchKernelGGL(nori_scan_kernel, dim3(1), dim3(1024), 0, st, e->nori_ff, n_pieces);
+                        hipLaunchKernelGGL(nori_place_kernel, dim3(n_pieces ? (n_pieces + 255) / 256 : 1), dim3(256), 0, st, (const uint32_t *) e->scratch, (const uint32_t *) e->nori_bits + n_blocks,
+                                           n_pieces, (const uint32_t *) e->nori_ff, (uint8_t *) out_dev + (size_t) f * out_stride, scan ? scan->header : (const uint8_t *) e->header_dev,
+                                           scan ? scan->header_len : (int) e->header.size(), out_capacity, scan ? scan->total : e->total_host_dev, scan ? scan->base : nullptr, f);
+                }
+                return UG_HIP_SUCCESS;
+        };
         if (e->nonint) {
                 // One scan per component (T.81 A.2.2; the reference's default for RGB input, gpujpeg.cpp:303).  Each scan is the block coder over ONE
                 // component's coefficients -- DC prediction and restart intervals (in blocks) of its own, its markers numbered from RST0 -- preceded by
@@ -1910,7 +2141,12 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 for (int c = 0; c < 3; c++) {
                         const ScanPlan pl = { c == 0 ? e->cy : (c == 1 ? e->cb : e->cr), e->ycc && c > 0 ? 1 : 0, e->scan_header_dev[c], (int) e->scan_header[c].size(),
                                               c > 0 ? e->total_host_dev + c * kTotalWords : nullptr, e->total_host_dev + (c + 1) * kTotalWords };
-                        if (wave_path) { // restart intervals of more than 256 blocks (and none at all): a wave per segment, then the compaction -- scan after scan on the stream
+                        if (nori) {
+                                const int nrc = code_without_restart(&pl);
+                                if (nrc != UG_HIP_SUCCESS) return nrc;
+                                continue;
+                        }
+                        if (wave_path) { // restart intervals of more than 256 blocks: a wave per segment, then the compaction -- scan after scan on the stream
                                 UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
                                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, pl.coef, pl.coef, pl.coef, e->mcu_w, e->n_mcu, 1, 1,
                                                    0, 0, pl.tab0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
@@ -1961,12 +2197,17 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                                 return UG_HIP_ERUNTIME;
                         }
                 }
+                if (nori) {
+                        const int nrc = code_without_restart(nullptr);
+                        if (nrc != UG_HIP_SUCCESS) return nrc;
+                } else {
                 // the totals this call's coder adds into start from zero (a smaller batch in between must not leave stale slices behind)
                 UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
                                    e->ctab, 2, 0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
                 hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, e->chunk_tot,
                                    e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, nullptr, bs);
+                }
         }
         UG_HIP_LAUNCH_CHECK();
         UG_HIP_TRY(hipStreamSynchronize(st)); // ONE synchronisation for the batch

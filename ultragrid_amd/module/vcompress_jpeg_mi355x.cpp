@@ -79,7 +79,7 @@ void cleanup(state_video_compress_jpeg_mi355x *s)
 void usage()
 {
         printf("MI355X JPEG compression usage:\n"
-               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval; 0 = none: one wave codes the frame, ms instead of us>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y601|:Y601full|:Y709][:alpha][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
+               "\t-c jpeg[:<quality>[:<restart>]][:q=<quality 1-100>][:restart=<MCUs per restart interval; 0 = none>][:subsampling=<444|422|420>][:interleaved][:RGB|:Y601|:Y601full|:Y709][:alpha][:dev=<index>[,<index>...]][:workers=<per device>][:batch=<frames>][:numa=<0|1>]\n"
                "\t\tnuma        - 1 (default): every worker thread runs on the CPUs of its GPU's NUMA node (pinned frame pool local to the GPU); 0: left to the scheduler\n"
                "\t\tbatch       - frames a busy worker may queue and encode together (1-16, default 1); only matters for sources faster than the encoder\n"
                "\t\tinterleaved - RGB input as one interleaved scan; default (as the reference's): one scan per component -- three coder launches, a little slower\n"
