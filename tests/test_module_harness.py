@@ -561,6 +561,14 @@ def test_jpeg_option_forms_of_the_reference_module(tmp_path):
     from PIL import Image
     a, b = (np.asarray(Image.open(io.BytesIO(d)).convert("L")).astype(float) for d in (data, outs[0]))
     assert np.array_equal(a, b)                                                          # the same coefficients, with and without restart markers
+    if os.path.exists(DEC_HARNESS):                                                      # and the receiving module reads both to the same picture
+        back = []
+        for name, d in (("nori", data), ("ri3", outs[0])):
+            (tmp_path / f"{name}.jpg").write_bytes(d)
+            r = subprocess.run([DEC_HARNESS, "JPEG", "UYVY", str(w), str(h), str(tmp_path / f"{name}.jpg"), str(tmp_path / f"{name}.raw")], capture_output=True, text=True, timeout=60)
+            assert r.returncode == 0, r.stdout + r.stderr
+            back.append(np.fromfile(tmp_path / f"{name}.raw", np.uint8)[:2 * w * h])
+        assert np.array_equal(back[0], back[1])
     assert _run(["jpeg:RGB", "UYVY", w, h, raw, tmp_path / "x"]).returncode == 3       # configure fails (R, G, B components are coded 4:4:4 only; `:subsampling=444:RGB` is taken): frame dropped
     r = _run(["jpeg:alpha", "UYVY", w, h, raw, tmp_path / "x"])
     assert r.returncode == 0 and "Requested alpha encode but input codec is unsupported pixel format" in (r.stdout + r.stderr)      # gpujpeg.cpp:327-328
