@@ -335,6 +335,47 @@ def test_gpu_no_restart_intervals(hip, po, sub, dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sub,dims,ri", [(422, (1920, 1080), 65), (422, (640, 368), 100), (420, (1280, 720), 1000), (444, (642, 366), 300), (420, (150, 71), 44), (422, (3840, 2160), 2000)], ids=str)
+def test_gpu_long_restart_intervals(hip, po, sub, dims, ri):
+    """restart intervals of more than 256 blocks per segment (the block coder's limit): a lane per block codes into the per-segment buffers of the wave-per-segment coder
+    (bit positions by a segmented prefix sum), that coder's compaction kernel assembles the stream -- == the test writer's, == the old kernel's (UG_JPEG_WAVE_KERNEL=1 in a
+    process of its own), one frame and a batch"""
+    import subprocess
+    import sys
+    import torch
+    from jpeg_bitstream import write_jpeg
+    from ultragrid_amd import lib as L
+    w, h = dims
+    q = 80
+    ql, qc = po.jpeg_qtable(q, 0), po.jpeg_qtable(q, 1)
+    dl, dc = po.jpeg_divisors(ql), po.jpeg_divisors(qc)
+    enc = hip.JpegEncoder(w, h, q, ri, subsampling=sub)
+    if sub == 444:
+        rgb = _rgb_picture(w, h)
+        dev, fmt = torch.from_numpy(rgb.ravel()).cuda(), L.PF_RGB
+        want = write_jpeg(w, h, ql, qc, *_coefs444(po, rgb, ql, None, w, h), restart=ri, sub=444)
+    else:
+        uyvy = synth.s2_video("UYVY", w, h, salt=4)
+        dev, fmt = torch.from_numpy(uyvy).cuda(), L.PF_UYVY
+        y, u, v = po.uyvy_to_i422(uyvy, w, h) if sub == 422 else po.uyvy_to_i420(uyvy, w, h)
+        mw, mh = (w + 15) // 16, (h + 7) // 8 if sub == 422 else (h + 15) // 16
+        want = write_jpeg(w, h, ql, qc, po.jpeg_fdct_quant_plane(y, dl, 2 * mw, mh * (1 if sub == 422 else 2)), po.jpeg_fdct_quant_plane(u, dc, mw, mh),
+                          po.jpeg_fdct_quant_plane(v, dc, mw, mh), restart=ri, sub=sub)
+    data = enc.encode(dev, fmt)
+    assert data == want
+    if w <= 1920:
+        two = enc.encode_batch(torch.stack([dev.flip(0), dev, dev]), fmt)
+        assert two[1] == data and two[2] == data and two[0] != data
+    enc.close()
+    if dims == (640, 368):      # the old kernel gives the same bytes (its own process: the switch is read when an encoder is made)
+        code = ("import sys, torch, numpy as np; sys.path.insert(0, %r); from ultragrid_amd import codec as hip, lib as L, synth; "
+                "e = hip.JpegEncoder(640, 368, 80, 100, subsampling=422); d = e.encode(torch.from_numpy(synth.s2_video('UYVY', 640, 368, salt=4)).cuda(), L.PF_UYVY); "
+                "sys.stdout.buffer.write(d)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env={**os.environ, "UG_JPEG_WAVE_KERNEL": "1"})
+        assert r.returncode == 0 and r.stdout == data, r.stderr[-500:]
+
+
+@pytest.mark.gpu
 def test_gpu_create_ex_refusals(hip):
     import ctypes as C
     from ultragrid_amd import lib as L

@@ -1359,6 +1359,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
 struct NoriScan {
         const int16_t *c0, *c1, *c2; // component 0 (hs x vs blocks per MCU), the components behind it (nc = 2) -- or one component alone (nc = 0: a scan of a non-interleaved stream)
         int mcu_w, n_mcu, hs, vs, nc, tab0, ctab;
+        int ri; // MCUs per restart interval (the predictions start from 0 there); n_mcu: none
 };
 
 // block b of the scan -> its coefficients, Huffman table set, and the DC value its prediction starts from
@@ -1373,12 +1374,12 @@ __device__ __forceinline__ const int16_t *nori_block(const NoriScan &s, uint32_t
         };
         if (j < ybl) {
                 tab = s.tab0;
-                pred = j > 0 ? luma(m, j - 1)[0] : (m > 0 ? luma(m - 1, ybl - 1)[0] : 0);
+                pred = j > 0 ? luma(m, j - 1)[0] : (m % s.ri ? luma(m - 1, ybl - 1)[0] : 0);
                 return luma(m, j);
         }
         const int16_t *const plane = j == ybl ? s.c1 : s.c2;
         tab = s.ctab;
-        pred = m > 0 ? plane[64L * (m - 1)] : 0;
+        pred = m % s.ri ? plane[64L * (m - 1)] : 0;
         return plane + 64L * m;
 }
 
@@ -1469,13 +1470,16 @@ __global__ __launch_bounds__(1024) void nori_scan_kernel(uint32_t *__restrict__ 
         if (tid == 0) v[n] = carry_s;
 }
 
-// raw: zeroed; the bits of block b go to bit position pos[b] (stream order: the first bit is the top bit of byte 0); the last block also pads the last byte with 1-bits (F.1.2.3)
-__global__ __launch_bounds__(256) void nori_emit_kernel(NoriScan s, uint32_t n_blocks, const uint32_t *__restrict__ pos, uint32_t *__restrict__ raw)
+// raw: zeroed; the bits of block b go to bit position pos[b] (stream order: the first bit is the top bit of byte 0) of its segment's region (seg_blocks blocks per
+// segment, regions seg_words apart; one segment: seg_blocks = n_blocks); the last block of a segment also pads its last byte with 1-bits (F.1.2.3)
+__global__ __launch_bounds__(256) void nori_emit_kernel(NoriScan s, uint32_t n_blocks, const uint32_t *__restrict__ pos, uint32_t *__restrict__ raw, uint32_t seg_blocks, uint32_t seg_words)
 {
         const uint32_t b = blockIdx.x * 256 + threadIdx.x;
         if (b >= n_blocks) return;
         int tab, pred;
         const int16_t *c = nori_block(s, b, tab, pred);
+        const uint32_t sg = b / seg_blocks;
+        raw += (size_t) sg * seg_words;
         uint32_t at = pos[b];              // the next bit
         unsigned long long acc = 0;        // bits waiting, left-aligned behind the `at & 31` bits of the word that belong to whoever came before
         int fill = (int) (at & 31);
@@ -1491,7 +1495,7 @@ __global__ __launch_bounds__(256) void nori_emit_kernel(NoriScan s, uint32_t n_b
                 fill += len;
                 if (fill >= 32) flush();
         });
-        if (b == n_blocks - 1) {
+        if (b == n_blocks - 1 || b + 1 == (sg + 1) * seg_blocks) {
                 const int pad = (8 - (fill & 7)) & 7;
                 if (pad) {
                         acc |= (unsigned long long) ((1u << pad) - 1u) << (64 - fill - pad);
@@ -1500,6 +1504,76 @@ __global__ __launch_bounds__(256) void nori_emit_kernel(NoriScan s, uint32_t n_b
                 }
         }
         if (fill) atomicOr(raw + word, __builtin_bswap32((uint32_t) (acc >> 32)));
+}
+
+// Several segments (restart intervals too long for the block coder): v[0 .. n) -> the sums in front of every entry INSIDE its segment of S entries; seg_bits[k] = the
+// sum of segment k.  (one workgroup, 8 entries per lane; the scan of sync_dc_kernel in jpeg_decode.hip)
+__global__ __launch_bounds__(1024) void nori_segscan_kernel(uint32_t *__restrict__ v, uint32_t n, uint32_t S, uint32_t *__restrict__ seg_bits)
+{
+        constexpr int kPer = 8;
+        __shared__ uint32_t wave_v[16], wave_f[16];
+        __shared__ uint32_t carry_s;
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024 * kPer) {
+                uint32_t x[kPer], incl[kPer], fl[kPer], f = 0, run = 0;
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        const uint32_t i = i0 + (uint32_t) tid * kPer + e;
+                        x[e] = i < n ? v[i] : 0;
+                        const uint32_t start = i < n && i % S == 0;
+                        run = start ? x[e] : run + x[e];
+                        f |= start;
+                        incl[e] = run;
+                        fl[e] = f;
+                }
+                uint32_t sv = run, sf = f;
+                for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t of = __shfl_up(sf, d, 64), ov = __shfl_up(sv, d, 64);
+                        if (lane >= d) {
+                                if (!sf) sv += ov;
+                                sf |= of;
+                        }
+                }
+                if (lane == 63) { wave_v[wv] = sv; wave_f[wv] = sf; }
+                uint32_t pf = __shfl_up(sf, 1, 64), pv = __shfl_up(sv, 1, 64);
+                if (lane == 0) { pf = 0; pv = 0; }
+                __syncthreads();
+                uint32_t cv = carry_s;
+                for (int w = 0; w < wv; w++) cv = wave_f[w] ? wave_v[w] : cv + wave_v[w];
+                const uint32_t before = pf ? pv : cv + pv;
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                        const uint32_t i = i0 + (uint32_t) tid * kPer + e;
+                        if (i < n) {
+                                const uint32_t in = fl[e] ? incl[e] : before + incl[e]; // inclusive, inside the segment
+                                v[i] = in - x[e];
+                                if (i % S == S - 1 || i == n - 1) seg_bits[i / S] = in;
+                        }
+                }
+                __syncthreads();
+                if (tid == 1023) carry_s = fl[kPer - 1] ? incl[kPer - 1] : before + incl[kPer - 1];
+                __syncthreads();
+        }
+}
+
+// what compact_kernel wants to know of every segment: its bytes, its bytes in the final stream (a 0x00 per 0xFF, the marker behind it), the chunk totals; one wave per segment
+__global__ __launch_bounds__(256) void nori_segstat_kernel(const uint32_t *__restrict__ raw, uint32_t seg_words, const uint32_t *__restrict__ seg_bits, int n_seg,
+                                                           uint32_t *__restrict__ seg_len, uint32_t *__restrict__ seg_ff, uint32_t *__restrict__ chunk_tot)
+{
+        const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (seg >= n_seg) return;
+        const uint32_t bytes = (seg_bits[seg] + 7) / 8;
+        const uint8_t *const p = (const uint8_t *) (raw + (size_t) seg * seg_words);
+        int ff = 0;
+        for (uint32_t i = lane; i < bytes; i += 64) ff += p[i] == 0xFF;
+        ff = __builtin_amdgcn_readlane(wave_inclusive_scan(ff, lane), 63);
+        if (lane == 0) {
+                seg_len[seg] = bytes;
+                seg_ff[seg] = bytes + (uint32_t) ff + 2;
+                atomicAdd(&chunk_tot[(seg / kChunk) * kChunkStride], bytes + (uint32_t) ff + 2);
+        }
 }
 
 // bytes 0xFF per 64-byte piece of the scan's bytes (total_bits = pos[n_blocks])
@@ -2091,14 +2165,14 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
         // A scan that is ONE segment (restart_interval 0), coded in parallel (nori_*_kernel above); frame after frame on the stream, one more host synchronisation per frame
         // (the scan's length in bits, to size the byte-stuffing launches).  scan = nullptr: the interleaved scan.
         static const bool nori_off = getenv("UG_JPEG_NORI") != nullptr && getenv("UG_JPEG_NORI")[0] == '0';
-        const bool nori = wave_path && e->n_seg == 1 && !nori_off && (unsigned long long) e->cap * 8ull < (1ull << 32);
+        const bool nori = wave_path && !e->force_wave_kernel && e->n_seg == 1 && !nori_off && (unsigned long long) e->cap * 8ull < (1ull << 32); // (UG_JPEG_WAVE_KERNEL=1: the old kernels throughout)
         auto code_without_restart = [&](const ScanPlan *scan) -> int {
                 const uint32_t n_blocks = (uint32_t) e->n_mcu * (uint32_t) (scan ? 1 : e->ybl + 2);
                 if (!e->nori_bits) UG_HIP_TRY(hipMalloc((void **) &e->nori_bits, ((size_t) e->n_mcu * (e->ybl + 2) + 1) * 4));
                 for (int f = 0; f < frames; f++) {
                         NoriScan s = {};
                         s.c0 = (scan ? scan->coef : e->cy) + f * bs.coef_y; s.c1 = e->cb + f * bs.coef_c; s.c2 = e->cr + f * bs.coef_c;
-                        s.mcu_w = e->mcu_w; s.n_mcu = e->n_mcu; s.hs = scan ? 1 : e->hs; s.vs = scan ? 1 : e->vs; s.nc = scan ? 0 : 2; s.tab0 = scan ? scan->tab0 : 0; s.ctab = e->ctab;
+                        s.mcu_w = e->mcu_w; s.n_mcu = e->n_mcu; s.hs = scan ? 1 : e->hs; s.vs = scan ? 1 : e->vs; s.nc = scan ? 0 : 2; s.tab0 = scan ? scan->tab0 : 0; s.ctab = e->ctab; s.ri = e->n_mcu;
                         hipLaunchKernelGGL(nori_len_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, e->nori_bits);
                         hipLaunchKernelGGL(nori_scan_kernel, dim3(1), dim3(1024), 0, st, e->nori_bits, n_blocks);
                         uint32_t *const bits_host = e->total_host + 4 * kTotalWords; // (a word of the pinned block of its own)
@@ -2114,12 +2188,44 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                                 e->nori_ff_cap = ((size_t) n_pieces + 1) * 2;
                         }
                         UG_HIP_TRY(hipMemsetAsync(e->scratch, 0, (bytes + 8 + 3) & ~(size_t) 3, st));
-                        hipLaunchKernelGGL(nori_emit_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, (const uint32_t *) e->nori_bits, e->scratch);
+                        hipLaunchKernelGGL(nori_emit_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, (const uint32_t *) e->nori_bits, e->scratch, n_blocks, 0u);
                         if (n_pieces) hipLaunchKernelGGL(nori_ff_kernel, dim3((n_pieces + 255) / 256), dim3(256), 0, st, (const uint32_t *) e->scratch, (const uint32_t *) e->nori_bits + n_blocks, n_pieces, e->nori_ff);
                         hipLaunchKernelGGL(nori_scan_kernel, dim3(1), dim3(1024), 0, st, e->nori_ff, n_pieces);
                         hipLaunchKernelGGL(nori_place_kernel, dim3(n_pieces ? (n_pieces + 255) / 256 : 1), dim3(256), 0, st, (const uint32_t *) e->scratch, (const uint32_t *) e->nori_bits + n_blocks,
                                            n_pieces, (const uint32_t *) e->nori_ff, (uint8_t *) out_dev + (size_t) f * out_stride, scan ? scan->header : (const uint8_t *) e->header_dev,
                                            scan ? scan->header_len : (int) e->header.size(), out_capacity, scan ? scan->total : e->total_host_dev, scan ? scan->base : nullptr, f);
+                }
+                return UG_HIP_SUCCESS;
+        };
+        // Restart intervals too long for the block coder (more than 256 blocks per segment), SEVERAL segments: the same lane-per-block coding, into the per-segment buffers
+        // of the wave-per-segment coder (bit positions inside a segment by a segmented prefix sum), in front of that coder's compaction kernel -- which moves a segment
+        // per wave, where entropy_wave_kernel CODED a segment per wave, block after block (restart=2000 at 4K: 4 ms).  UG_JPEG_NORI=0: the old kernel.
+        // (which is faster, profiles/r06_encode_no_restart.txt: the old kernel takes ~0.9 us per block of a segment, the segments side by side; this way costs what the picture
+        // costs -- clearing the buffers, two passes over the blocks: ~0.58 ms at 4K -- whatever the interval.  4K: from ~650 blocks per segment, 1080p: from ~290)
+        const bool seg_parallel = wave_path && !e->force_wave_kernel && e->n_seg > 1 && !nori_off &&
+                                  0.9 * (double) e->ri * (e->nonint ? 1 : e->ybl + 2) > 150.0 + 5.2e-5 * (double) w * (double) h;
+        auto fill_segments = [&](const ScanPlan *scan) -> int {
+                const uint32_t per_mcu = (uint32_t) (scan ? 1 : e->ybl + 2), n_blocks = (uint32_t) e->n_mcu * per_mcu;
+                if (!e->nori_bits) UG_HIP_TRY(hipMalloc((void **) &e->nori_bits, ((size_t) e->n_mcu * (e->ybl + 2) + 1) * 4));
+                if (e->nori_ff_cap < (size_t) e->n_seg + 1) {
+                        if (e->nori_ff) (void) hipFree(e->nori_ff);
+                        e->nori_ff = nullptr;
+                        e->nori_ff_cap = 0;
+                        UG_HIP_TRY(hipMalloc((void **) &e->nori_ff, ((size_t) e->n_seg + 1) * 4));
+                        e->nori_ff_cap = (size_t) e->n_seg + 1;
+                }
+                for (int f = 0; f < frames; f++) {
+                        NoriScan s = {};
+                        s.c0 = (scan ? scan->coef : e->cy) + f * bs.coef_y; s.c1 = e->cb + f * bs.coef_c; s.c2 = e->cr + f * bs.coef_c;
+                        s.mcu_w = e->mcu_w; s.n_mcu = e->n_mcu; s.hs = scan ? 1 : e->hs; s.vs = scan ? 1 : e->vs; s.nc = scan ? 0 : 2; s.tab0 = scan ? scan->tab0 : 0; s.ctab = e->ctab; s.ri = e->ri;
+                        uint32_t *const raw = e->scratch + (size_t) f * bs.raw_words;
+                        hipLaunchKernelGGL(nori_len_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, e->nori_bits);
+                        hipLaunchKernelGGL(nori_segscan_kernel, dim3(1), dim3(1024), 0, st, e->nori_bits, n_blocks, (uint32_t) e->ri * per_mcu, e->nori_ff);
+                        UG_HIP_TRY(hipMemsetAsync(raw, 0, (size_t) e->n_seg * (size_t) e->cap, st));
+                        hipLaunchKernelGGL(nori_emit_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, s, n_blocks, (const uint32_t *) e->nori_bits, raw, (uint32_t) e->ri * per_mcu,
+                                           (uint32_t) (e->cap / 4));
+                        hipLaunchKernelGGL(nori_segstat_kernel, dim3((e->n_seg + 3) / 4), dim3(256), 0, st, (const uint32_t *) raw, (uint32_t) (e->cap / 4), (const uint32_t *) e->nori_ff, e->n_seg,
+                                           e->seg_len + (size_t) f * bs.seg, e->seg_ff + (size_t) f * bs.seg, e->chunk_tot + (size_t) f * bs.tot_words);
                 }
                 return UG_HIP_SUCCESS;
         };
@@ -2148,8 +2254,13 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                         }
                         if (wave_path) { // restart intervals of more than 256 blocks: a wave per segment, then the compaction -- scan after scan on the stream
                                 UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
-                                hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, pl.coef, pl.coef, pl.coef, e->mcu_w, e->n_mcu, 1, 1,
-                                                   0, 0, pl.tab0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                                if (seg_parallel) {
+                                        const int frc = fill_segments(&pl);
+                                        if (frc != UG_HIP_SUCCESS) return frc;
+                                } else {
+                                        hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, pl.coef, pl.coef, pl.coef, e->mcu_w, e->n_mcu, 1, 1,
+                                                           0, 0, pl.tab0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                                }
                                 hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff,
                                                    e->chunk_tot, e->n_seg, (uint8_t *) out_dev, pl.header, pl.header_len, out_capacity, pl.total, pl.base, bs);
                                 continue;
@@ -2203,8 +2314,13 @@ int ug_hip_jpeg_encoder_encode_batch(ug_hip_jpeg_encoder *enc, ug_pixfmt_t in, i
                 } else {
                 // the totals this call's coder adds into start from zero (a smaller batch in between must not leave stale slices behind)
                 UG_HIP_TRY(hipMemsetAsync(e->chunk_tot, 0, (size_t) bs.tot_words * 4 * frames, st));
+                if (seg_parallel) {
+                        const int frc = fill_segments(nullptr);
+                        if (frc != UG_HIP_SUCCESS) return frc;
+                } else {
                 hipLaunchKernelGGL(entropy_wave_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, e->cy, e->cb, e->cr, e->mcu_w, e->n_mcu, e->hs, e->vs,
                                    e->ctab, 2, 0, e->ri, e->n_seg, e->scratch, e->cap / 4, e->seg_len, e->seg_ff, e->chunk_tot, bs);
+                }
                 hipLaunchKernelGGL(compact_kernel, dim3((e->n_seg + 3) / 4, frames), dim3(256), 0, st, (const uint8_t *) e->scratch, e->cap, e->seg_len, e->seg_ff, e->chunk_tot,
                                    e->n_seg, (uint8_t *) out_dev, e->header_dev, (int) e->header.size(), out_capacity, e->total_host_dev, nullptr, bs);
                 }
